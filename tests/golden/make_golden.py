@@ -1,0 +1,153 @@
+"""Generates tests/golden/golden_v1.npz by running the REAL reference (/root/reference, through
+oracle/ref_shim.py -- the 3 documented import-time patches, nothing else) in the authoring container.
+
+    python tests/golden/make_golden.py
+
+The fixtures pin the oracle (oracle/restated.py, oracle/wn_oracle.c) and, through it, the HIP path.
+Weights are NOT stored: they are regenerated from mi355_wavenet.synth.init_weights(cfg, seed) which is
+bit-stable (numpy RandomState).  Everything stored here was produced by the reference's own code:
+
+  queue_*      DilatedQueue known answers -- the bodies of /root/reference/tests/test_tensor_queue.py:13-50
+  dilate_*     dilate() known answers     -- /root/reference/tests/test_modules.py:8-29
+  gen_<case>_* generate_fast(): float64 audio returned by the reference for a seeded run (sampled branch,
+               np.random.seed), the given first_samples, and the per-step logits obtained by driving the
+               reference's own wavenet(input, queue_dilate) with the same index sequence
+  fwd_<case>   forward() output of the reference on a seeded one-hot batch
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, os.path.join(ROOT, "pytorch-wavenet_amd"))
+
+import ref_shim  # noqa: E402
+from mi355_wavenet import synth  # noqa: E402
+
+# case -> (config name, weight seed, n_given, num_samples, temperature, regularize, np seed)
+GEN_CASES = {
+    "tiny": ("tiny", 11, 20, 300, 1.0, 0.0, 101),
+    "tiny_bias": ("tiny_bias", 12, 33, 300, 0.8, 0.002, 102),
+    "cfg1": ("cfg1", 13, 70, 400, 1.0, 0.0, 103),
+    "cfg1_seed128": ("cfg1", 14, 1, 200, 1.0, 0.0, 104),  # default first_samples=None -> [128]
+}
+FWD_CASES = {"tiny": ("tiny", 11, 2, 5), "tiny_bias": ("tiny_bias", 12, 3, 4), "cfg1": ("cfg1", 13, 1, 3)}
+
+
+def build_ref_model(mdl, cfg, seed, output_length=8):
+    m = mdl.WaveNetModel(output_length=output_length, **cfg)
+    W = synth.init_weights(cfg, seed=seed)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in W.items()})
+    return m
+
+
+def indices_from_audio(audio, classes=256):
+    """invert audio_data.py:156-158 (monotone) to recover the integer indices the reference sampled."""
+    cand = np.arange(classes)
+    o = (cand / classes) * 2. - 1
+    table = np.sign(o) * (np.exp(np.abs(o) * np.log(classes + 1)) - 1) / classes
+    idx = np.array([int(np.argmin(np.abs(table - a))) for a in audio])
+    assert np.array_equal(table[idx], audio)
+    return idx
+
+
+def main():
+    mdl, wm, ad = ref_shim.load()
+    out = {}
+
+    # ---- DilatedQueue known answers (reference tests/test_tensor_queue.py:13-50 bodies) ----
+    q = wm.DilatedQueue(max_length=8, num_channels=3)
+    e = torch.zeros(3)
+    for i in range(11):
+        e = e + 1
+        q.enqueue(e)
+    out["queue_enqueue_data"] = q.data.numpy().copy()
+    assert q.data[0, 0] == 9 and q.data[0, 2] == 11 and q.data[0, 7] == 8
+    q = wm.DilatedQueue(max_length=8, num_channels=1)
+    e = torch.zeros(1)
+    for i in range(11):
+        e = e + 1
+        q.enqueue(e)
+    deq = []
+    for i in range(9):
+        d = q.dequeue(num_deq=3, dilation=2)
+        deq.append(d.numpy().copy())
+    assert d[0][0] == 5 and d[0][1] == 7 and d[0][2] == 9
+    out["queue_dequeue_seq"] = np.stack(deq)
+    q = wm.DilatedQueue(max_length=12, num_channels=1)
+    e = torch.zeros(1)
+    comb = []
+    for i in range(30):
+        e = e + 1
+        q.enqueue(e)
+        d = q.dequeue(num_deq=3, dilation=4)
+        assert d[0][0] == max(i - 7, 0)
+        comb.append(d.numpy().copy())
+    out["queue_combined_seq"] = np.stack(comb)
+
+    # ---- dilate known answers (reference tests/test_modules.py:8-29) ----
+    x = torch.linspace(0, 12, steps=13).view(1, 1, 13)
+    d2 = wm.dilate(x, 2)
+    d4 = wm.dilate(d2, 4, init_dilation=2)
+    d1 = wm.dilate(d4, 1, init_dilation=4)
+    assert d2.size() == (2, 1, 7) and d2[1, 0, 2] == 4
+    assert d4.size() == (4, 1, 4) and d4[3, 0, 1] == 4
+    assert d1.size() == (1, 1, 16) and d1[0, 0, 7] == 4
+    out["dilate_in"], out["dilate_d2"], out["dilate_d4"], out["dilate_d1"] = x.numpy(), d2.numpy(), d4.numpy(), d1.numpy()
+    xm = torch.linspace(0, 35, steps=36).view(2, 3, 6)
+    out["dilate_mc_in"], out["dilate_mc_d4"] = xm.numpy(), wm.dilate(xm, 4).numpy()
+
+    # ---- generate_fast on the sampled branch (the only branch the unmodified reference can run) ----
+    for case, (cname, wseed, n_given, n, temp, regz, npseed) in GEN_CASES.items():
+        cfg = synth.CONFIGS[cname]
+        m = build_ref_model(mdl, cfg, wseed)
+        fs = None if n_given == 1 else torch.from_numpy(np.random.RandomState(wseed).randint(0, 256, n_given))
+        np.random.seed(npseed)
+        audio = m.generate_fast(n, first_samples=fs, temperature=temp, regularize=regz)
+        idx = indices_from_audio(audio)
+        # per-step logits from the reference's own wavenet(): replay the same index sequence
+        for qq in m.dilated_queues:
+            qq.reset()
+        given = [128] if fs is None else fs.tolist()
+        seq = given + idx.tolist()
+        logits = []
+        for t in range(len(seq) - 1):
+            inp = torch.zeros(1, 256, 1)
+            inp[0, seq[t], 0] = 1.
+            y = m.wavenet(inp, dilation_func=m.queue_dilate).squeeze()
+            if t >= len(given) - 1:
+                logits.append(y.detach().numpy().copy())
+        logits = np.stack(logits)
+        assert logits.shape == (n, 256)
+        out["gen_%s_audio" % case] = audio
+        out["gen_%s_idx" % case] = idx.astype(np.int16)
+        out["gen_%s_first" % case] = np.asarray(given, dtype=np.int16)
+        out["gen_%s_logits" % case] = logits[:: max(1, n // 16)].astype(np.float32)  # 16-ish rows is enough
+        out["gen_%s_logit_rows" % case] = np.arange(n)[:: max(1, n // 16)].astype(np.int32)
+        out["gen_%s_meta" % case] = np.array([wseed, n_given, n, npseed], dtype=np.int64)
+        out["gen_%s_tr" % case] = np.array([temp, regz], dtype=np.float64)
+
+    # ---- forward() ----
+    for case, (cname, wseed, N, out_len) in FWD_CASES.items():
+        cfg = synth.CONFIGS[cname]
+        m = build_ref_model(mdl, cfg, wseed, output_length=out_len)
+        L = m.receptive_field + out_len - 1
+        ids = np.random.RandomState(wseed + 1).randint(0, 256, (N, L))
+        x = torch.zeros(N, 256, L)
+        x.scatter_(1, torch.from_numpy(ids).view(N, 1, L), 1.)
+        y = m(x).detach().numpy()
+        out["fwd_%s_ids" % case] = ids.astype(np.int16)
+        out["fwd_%s_out" % case] = y.astype(np.float32)
+        out["fwd_%s_meta" % case] = np.array([wseed, N, out_len], dtype=np.int64)
+
+    path = os.path.join(HERE, "golden_v1.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes;", len(out), "arrays")
+
+
+if __name__ == "__main__":
+    main()
