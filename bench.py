@@ -1,0 +1,184 @@
+#!/usr/bin/env python
+"""bench.py -- generate_fast() throughput of the MI355X engine (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg3x64] [--samples 2000]
+
+A "step" is one generate_fast()-shaped job: every stream of the workload generates ``--samples`` audio samples
+(queue reset + ONE persistent kernel launch; temperature 1.0, host-drawn uniforms, inputs resident in HBM).
+``value`` = audio samples/s summed over all streams and all GPUs.  N > 1: one process per GPU (torchrun), streams
+sharded across ranks with no data-path collective; the finished index blocks are gathered to rank 0 over RCCL inside
+the timed region (that is the job's only exchange step).  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "pytorch-wavenet_amd"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+WORKLOADS = {  # name -> (BASELINE.json config, streams per GPU)
+    "cfg3x64": ("cfg3", 64),   # configs[2] / configs[3]: 64 independent streams per GPU
+    "cfg3x1": ("cfg3", 1),     # the 16 kHz real-time target
+    "cfg2x1": ("cfg2", 1),     # configs[1]
+    "cfg1x1": ("cfg1", 1),     # configs[0]
+}
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def time_workload(cfgname, n_streams, samples, steps, warmup, dist, device):
+    from mi355_wavenet import engine, synth
+    cfg = synth.CONFIGS[cfgname]
+    W = synth.init_weights(cfg, seed=0)
+    eng = engine.Engine(cfg, W, n_streams=n_streams, device_index=device)
+    rs = np.random.RandomState(1234 + (dist.get_rank() if dist else 0))
+    first = eng.mem.upload(np.full((n_streams, 1), 128, dtype=np.int32))
+    uni = eng.mem.upload(rs.random_sample((n_streams, samples)))
+    out = eng.mem.empty((n_streams, samples), np.int32)
+    gathered = None
+    if dist and dist.get_rank() == 0:
+        gathered = [torch.empty_like(out) for _ in range(dist.get_world_size())]
+
+    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
+    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
+
+    def one_step(i=None):
+        eng.reset()
+        if i is not None:
+            ev0[i].record()
+        eng.launch(first, 1, samples, 1.0, None, uni, out, None, timeout_ms=20000)
+        if i is not None:
+            ev1[i].record()
+        if dist:
+            dist.gather(out, gathered, dst=0)
+
+    for _ in range(warmup):
+        one_step()
+    eng.wait()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        one_step(i)
+    eng.wait()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    t1 = time.perf_counter()
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
+    info = eng.info()
+    idx = out.cpu().numpy()
+    assert idx.min() >= 0 and idx.max() < 256
+    eng.close()
+    return t1 - t0, kernel_ms, info, cfg
+
+
+def cpu_baseline(cfgname, budget_s=12.0):
+    """The reference's CPU path (torch restatement of generate_fast, oracle/restated.py, proven bit-equal to the real
+    reference in tests/test_oracle_pinning.py) timed on this box's host cores: a bounded single-stream sample."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import restated
+    from mi355_wavenet import synth
+    cfg = synth.CONFIGS[cfgname]
+    W = synth.init_weights(cfg, seed=0)
+    r = restated.RestatedWaveNet(cfg, W)
+    np.random.seed(0)
+    r.generate_fast(20, temperature=1.0, return_details=True)  # warm-up
+    n = 100
+    t0 = time.perf_counter()
+    r.generate_fast(n, temperature=1.0, return_details=True)
+    dt = time.perf_counter() - t0
+    n2 = int(max(100, min(3000, budget_s / (dt / n))))
+    t0 = time.perf_counter()
+    r.generate_fast(n2, temperature=1.0, return_details=True)
+    dt2 = time.perf_counter() - t0
+    return {"value": round(n2 / dt2, 2), "unit": "samples/s", "cores": int(torch.get_num_threads()), "kind": "port",
+            "sample": "%s single stream, %d samples of generate_fast(temperature=1.0) through oracle/restated.py "
+                      "(op-for-op torch restatement of the reference's CPU path)" % (cfgname, n2)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="cfg3x64", choices=sorted(WORKLOADS))
+    ap.add_argument("--samples", type=int, default=2000, help="audio samples per stream per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local)
+        dist_mod.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        dist = dist_mod
+    else:
+        torch.cuda.set_device(local)
+    n_gpus = world if world > 1 else 1
+    if a.gpus != n_gpus and rank == 0 and world > 1:
+        print("warning: --gpus %d but WORLD_SIZE %d" % (a.gpus, world), file=sys.stderr)
+
+    cfgname, per_gpu = WORKLOADS[a.workload]
+    wall, kernel_ms, info, cfg = time_workload(cfgname, per_gpu, a.samples, a.steps, a.warmup, dist, local)
+    if dist:
+        t = torch.tensor([wall], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+    if rank != 0:
+        if dist:
+            dist.destroy_process_group()
+        return
+
+    from mi355_wavenet import synth
+    total_samples = n_gpus * per_gpu * a.samples * a.steps
+    value = total_samples / wall
+    bytes_per_tstep = synth.algorithmic_bytes_per_step(cfg, per_gpu)   # W_touched + streams*(Q+8)
+    bytes_per_launch = bytes_per_tstep * a.samples
+    achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
+    line = {
+        "metric": "generate_fast() audio samples/sec (256-class mu-law), whole job over all GPUs",
+        "value": round(value, 1), "unit": "samples/s", "n_gpus": n_gpus, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": round(wall / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic (seeded random weights, host-drawn uniforms)",
+        "config": {"workload": "%s: WaveNetModel(%s), %d independent streams per GPU x %d samples per step, "
+                               "temperature 1.0" % (a.workload, ", ".join("%s=%s" % kv for kv in cfg.items()), per_gpu, a.samples),
+                   "streams_per_gpu": per_gpu, "samples_per_stream_per_step": a.samples,
+                   "per_stream_samples_per_s": round(value / (n_gpus * per_gpu), 1),
+                   "chain": {k: info[k] for k in ("layer_split", "head_split", "n_workgroups", "lds_bytes")}},
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                     "kernel": "wn_generate_kernel", "kernel_ms_per_launch": round(kernel_ms, 3),
+                     "algorithmic_bytes_per_launch": int(bytes_per_launch),
+                     "algorithmic_bytes_per_timestep": int(bytes_per_tstep), "launches_per_step": 1},
+    }
+    if n_gpus == 1 and not a.no_extra:
+        extra = {}
+        for wl in ("cfg3x1", "cfg2x1"):
+            if wl == a.workload:
+                continue
+            c2, s2 = WORKLOADS[wl]
+            w2, k2, i2, cf2 = time_workload(c2, s2, 8000, 2, 1, None, local)
+            extra[wl] = {"samples_per_s": round(2 * 8000 * s2 / w2, 1), "kernel_ms_per_launch": round(k2, 3),
+                         "hbm_frac": round(synth.algorithmic_bytes_per_step(cf2, s2) * 8000 / (k2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                         "n_workgroups": i2["n_workgroups"]}
+        line["extra"] = extra
+    if n_gpus == 1 and not a.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(cfgname)
+    print(json.dumps(line))
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

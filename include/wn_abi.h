@@ -1,0 +1,153 @@
+/* wn_abi.h -- C ABI of libwn_mi355.so, the MI355X (gfx950) fast-generation engine.
+ *
+ * This is the drop-in boundary for ONE hot path of vincentherrmann/pytorch-wavenet:
+ * WaveNetModel.generate_fast() and everything it calls per timestep.  The reference has no FFI seam
+ * (it is pure Python); each entry point below names the reference interface it replaces
+ * (paths relative to the reference root).  The Python facade (pytorch-wavenet_amd/wavenet_model.py)
+ * binds these with ctypes; INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - plain C, no C++/torch types; every function returns 0 (WN_OK) or a negative WN_E_* code and never
+ *     throws; wn_last_error() returns a thread-local human-readable message for the last failure.
+ *   - "device pointer" = HIP device memory on the handle's device (e.g. torch.Tensor.data_ptr()),
+ *     "host pointer"   = ordinary process memory.
+ *   - a handle is single-threaded (like a reference model object whose DilatedQueues are mutable
+ *     state); distinct handles may be used concurrently from different threads (the reference calls
+ *     generate_fast from a daemon thread during training: model_logging.py:48-58).
+ */
+#ifndef WN_ABI_H
+#define WN_ABI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WN_ABI_VERSION 1
+
+enum {
+    WN_OK = 0,
+    WN_E_BADARG = -1,      /* NULL / out-of-range argument */
+    WN_E_UNSUPPORTED = -2, /* configuration does not fit this device (see wn_last_error) */
+    WN_E_HIP = -3,         /* a HIP runtime call failed (message carries hipGetErrorString) */
+    WN_E_NOMEM = -4,
+    WN_E_TIMEOUT = -5,     /* the persistent kernel gave up waiting on a hand-off (bounded spins) */
+    WN_E_STATE = -6        /* call order violated, e.g. generate before load_weights */
+};
+
+/* Mirrors the constructor of WaveNetModel (wavenet_model.py:28-39) plus engine placement. */
+typedef struct wn_config {
+    int32_t layers;            /* layers per block                    wavenet_model.py:29 */
+    int32_t blocks;            /*                                      :30 */
+    int32_t dilation_channels; /* D                                    :31 */
+    int32_t residual_channels; /* R                                    :32 */
+    int32_t skip_channels;     /* S                                    :33 */
+    int32_t end_channels;      /* E                                    :34 */
+    int32_t classes;           /* C (mu-law classes, 256)              :35 */
+    int32_t kernel_size;       /* k taps of the dilated convs          :37 */
+    int32_t bias;              /* stack convs carry a bias             :39 */
+    int32_t n_streams;         /* independent generation streams; the reference API has exactly 1 */
+    int32_t device_id;         /* HIP device ordinal */
+    int32_t layer_split;       /* workgroups (CUs) that share one layer; 0 = choose automatically */
+    int32_t head_split;        /* workgroups that share end_conv_1/end_conv_2; 0 = automatic */
+    int32_t reserved[3];       /* must be 0 */
+} wn_config;
+
+/* Host pointers to fp32 parameters in the reference's nn.Conv1d layout (out, in, k), the per-layer
+ * tensors concatenated along a leading NL = layers*blocks axis (state_dict names in comments,
+ * wavenet_model.py:59-119).  Bias pointers of the stack may be NULL when cfg.bias == 0. */
+typedef struct wn_weight_ptrs {
+    const float* start_w;  /* start_conv.weight        (R, C, 1)      */
+    const float* start_b;  /* start_conv.bias          (R)      | NULL */
+    const float* filter_w; /* filter_convs.N.weight    (NL, D, R, k)  */
+    const float* filter_b; /* filter_convs.N.bias      (NL, D)  | NULL */
+    const float* gate_w;   /* gate_convs.N.weight      (NL, D, R, k)  */
+    const float* gate_b;   /* gate_convs.N.bias        (NL, D)  | NULL */
+    const float* res_w;    /* residual_convs.N.weight  (NL, R, D, 1)  */
+    const float* res_b;    /* residual_convs.N.bias    (NL, R)  | NULL */
+    const float* skip_w;   /* skip_convs.N.weight      (NL, S, D, 1)  */
+    const float* skip_b;   /* skip_convs.N.bias        (NL, S)  | NULL */
+    const float* end1_w;   /* end_conv_1.weight        (E, S, 1)      */
+    const float* end1_b;   /* end_conv_1.bias          (E)            */
+    const float* end2_w;   /* end_conv_2.weight        (C, E, 1)      */
+    const float* end2_b;   /* end_conv_2.bias          (C)            */
+} wn_weight_ptrs;
+
+/* One generate_fast()-shaped job: n_given-1 priming evaluations followed by num_samples generating
+ * evaluations, for every stream (wavenet_model.py:259-311).  All array pointers are DEVICE pointers. */
+typedef struct wn_generate_args {
+    const int32_t* first_samples; /* [n_streams][n_given] given class indices (first_samples, :245-257)   */
+    int64_t n_given;              /* >= 1; the last given sample is the input of generating step 0        */
+    int64_t num_samples;          /* >= 0                                                                 */
+    float temperature;            /* > 0: sample from softmax(x/T) (:282-289);  <= 0: argmax (:290-294)   */
+    int32_t flags;                /* 0 */
+    const float* regularizer;     /* [classes] fp32 values subtracted from the logits (:273-274,280) | NULL */
+    const double* uniforms;       /* [n_streams][num_samples] U[0,1) draws, one per generated sample, the
+                                     host's np.random.random_sample() stream (np.random.choice, :288);
+                                     NULL => greedy regardless of temperature                              */
+    int32_t* out_idx;             /* [n_streams][num_samples] generated class indices                      */
+    float* dbg_logits;            /* [n_streams][num_samples][classes] pre-regulariser logits | NULL       */
+    void* hip_stream;             /* hipStream_t to enqueue on (NULL = default stream)                     */
+    int32_t timeout_ms;           /* per-hand-off spin bound inside the kernel; 0 = default (10 s)         */
+    int32_t reserved;
+} wn_generate_args;
+
+/* What the planner decided (for logs, benches and tests). */
+typedef struct wn_info {
+    int32_t abi_version;
+    int32_t n_layers;        /* NL */
+    int32_t layer_split;     /* P  */
+    int32_t head_split;      /* PA */
+    int32_t n_workgroups;    /* NL*P + PA persistent workgroups = CUs used */
+    int32_t lds_bytes;       /* dynamic LDS per workgroup */
+    int32_t n_compute_units; /* CUs on the device */
+    int32_t receptive_field; /* wavenet_model.py:53,106-107 */
+    int64_t weight_bytes;    /* packed weight banks resident in HBM (copied to LDS at launch) */
+    int64_t queue_bytes;     /* dilation-queue rings */
+    int64_t handoff_bytes;   /* inter-workgroup granule buffers */
+    int64_t evals_done;      /* timesteps evaluated since the last wn_reset (queue time) */
+} wn_info;
+
+typedef struct wn_handle wn_handle;
+
+int wn_abi_version(void);
+
+/* WaveNetModel.__init__ (wavenet_model.py:28-123): plans the workgroup chain, allocates queues/hand-off
+ * buffers on cfg->device_id.  No weights yet. */
+int wn_create(const wn_config* cfg, wn_handle** out);
+void wn_destroy(wn_handle* h);
+
+/* nn.Module.load_state_dict / the parameters the convs of wavenet() read (wavenet_model.py:59-119,
+ * 125-171): repacks the banks into per-workgroup LDS images and uploads them.  May be called again
+ * after the parameters change. */
+int wn_load_weights(wn_handle* h, const wn_weight_ptrs* w);
+
+/* DilatedQueue.reset() for every layer (wavenet_modules.py:74-77, called at wavenet_model.py:250-251):
+ * zeroes all queue rings of all streams and rewinds queue time to 0.  Asynchronous on hip_stream. */
+int wn_reset(wn_handle* h, void* hip_stream);
+
+/* The priming loop + hot loop of generate_fast (wavenet_model.py:259-311): ONE persistent kernel
+ * launch for the whole job.  Does NOT reset the queues: call wn_reset first for a fresh
+ * generate_fast; call again with n_given = 1 and first_samples = the last generated index to continue
+ * a stream (used for progress callbacks).  Asynchronous: returns after enqueueing on hip_stream. */
+int wn_generate(wn_handle* h, const wn_generate_args* args);
+
+/* Blocks until the last wn_generate on this handle finished; returns its outcome
+ * (WN_OK / WN_E_TIMEOUT / WN_E_HIP).  out_idx is valid afterwards. */
+int wn_wait(wn_handle* h);
+
+int wn_get_info(wn_handle* h, wn_info* out);
+
+/* Copies the live queue of layer `layer`, stream `stream` into host memory laid out like the reference's
+ * DilatedQueue.data after the same number of pushes: (R, (k-1)*d+1) row-major fp32, plus in_pos/out_pos
+ * (wavenet_modules.py:43-57).  For tests and for facade code that inspects model.dilated_queues. */
+int wn_export_queue(wn_handle* h, int32_t layer, int32_t stream, float* host_data, int32_t* in_pos, int32_t* out_pos);
+
+/* Thread-local message for the most recent failing call on this thread ("" if none). */
+const char* wn_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WN_ABI_H */

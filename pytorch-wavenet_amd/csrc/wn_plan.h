@@ -1,0 +1,290 @@
+// wn_plan.h -- host-side planner and weight packer + the POD structs shared with the kernel.
+//
+// The generation engine is a SYSTOLIC CHAIN of persistent workgroups (one per CU):
+//
+//     L0[c] -> L1[c] -> ... -> L(NL-1)[c] -> HEAD[h] -> back to L0 (sampled index feeds start_conv)
+//
+// Every layer of the reference's stack (wavenet_model.py:131-165) is owned by P workgroups ("layer
+// split"), the two end convs (:167-169) by PA workgroups ("head split").  Each workgroup keeps its slice
+// of the fp32 weight banks STATIONARY in its CU's LDS for the whole generate_fast() call, owns the
+// dilation queue (wavenet_modules.py:42-77) of its layer, and exchanges only activations with its
+// neighbours through 8-byte {tag,value} granules in HBM (MI355X guide: "R2, the data IS the flag").
+//
+// Split of one layer across its P workgroups (c = 0..P-1, Dc = ceil(D/P) gated channels each):
+//   filter/gate (wavenet_model.py:147-151): ROW split  -- WG c computes channels [c*Dc, (c+1)*Dc) of
+//       tanh(Wf.[x[t-d];x[t]]) * sigmoid(Wg.[...]); it needs the full layer input x[t] (R floats).
+//   residual 1x1 (:164-165) and skip 1x1 (:154-162): K split -- WG c multiplies ITS Dc channels of z into
+//       partial sums for all R (resp. S) outputs; the consumer adds the P partials in fixed order c=0..P-1
+//       (WG 0's partial also carries the "+ x[t]" residual add and the conv bias).
+//   The running skip sum travels down the chain in P independent lanes; the head adds the lanes.
+// Head WG h: rows [h*Ec,(h+1)*Ec) of end_conv_1 (+bias, ReLU) then the matching K-slice of end_conv_2,
+//   publishing partial logits; every L0 workgroup adds the PA partials, applies regulariser/temperature,
+//   softmax + inverse-CDF sampling (or argmax) redundantly and bit-identically, and gathers the
+//   start_conv column of the sampled class (wavenet_model.py:127 on a one-hot == column gather).
+#ifndef WN_PLAN_H
+#define WN_PLAN_H
+
+#include <stdint.h>
+
+#define WN_THREADS 256
+#define WN_SAMPLER_GROUPS 16
+#define WN_LDS_MAX_BYTES (163840 - 1024) /* 160 KiB per CU on gfx950, minus the static LDS __syncthreads_or() uses */
+
+typedef unsigned long long wn_u64;
+
+// One packed matrix-vector product  out[row] = sum_k W[row][k] * x[k],  rows Nr, reduction K.
+// 256 threads; T threads cooperate on a row (T a power of two), each owning J float4 of that row per
+// pass; a pass covers 256/T rows.  LDS image: float4 W4[(pass*J + j)*256 + tid] -- every ds_read_b128
+// of a wave is lane-linear (conflict-free); thread tid holds row pass*(256/T) + tid/T and the k-range
+// 4*(j*T + tid%T) .. +3.  x must provide xlen = J*T*4 floats (zero padded).
+struct WnMatvec {
+    int32_t Nr, K, T, J, passes;
+    int32_t off4;  // offset of the image inside the workgroup's LDS blob, in float4 units
+    int32_t xlen;  // floats of x consumed (zero padded tail)
+    int32_t n4;    // float4 count of the image = passes*J*256
+};
+
+struct WnPlan {
+    // model (wavenet_model.py:28-39)
+    int32_t layers, blocks, NL, R, D, S, E, C, k, has_bias;
+    int32_t n_streams;
+    // chain geometry
+    int32_t P, PA, Dc, Ec, n_wg;
+    WnMatvec fg, res, skip, end1, end2;
+    // LDS layout of a layer workgroup (float offsets; blob first)
+    int32_t l_bias_fg, l_bias_res, l_bias_skip;  // inside the blob, valid iff has_bias
+    int32_t l_xs, l_fgout, l_z, l_xt, l_skin, l_red, l_smp, l_total;
+    // LDS layout of a head workgroup
+    int32_t h_b1, h_b2, h_sk, h_ev, h_red, h_total;
+    int32_t blob_layer_floats, blob_head_floats;  // multiples of 4
+    int32_t lds_floats;                           // max(l_total, h_total)
+    int32_t red_floats;
+    // device tables / buffers
+    const float* blobs;       // layer WG w: blobs + w*blob_layer_floats ; head h: blobs + NL*P*blob_layer + h*blob_head
+    const float* start_t;     // [C][R] start_conv.weight transposed: column gather = one contiguous row
+    const float* start_b;     // [R] or NULL
+    const int32_t* dil;       // [NL] dilation of each layer (wavenet_model.py:70-110)
+    const int64_t* ring_off;  // [NL] float offset of the layer's queue rings inside `rings`
+    const int32_t* wg_map;    // [n_wg] blockIdx -> chain position
+    float* rings;             // layer l, copy c, stream s: ring_off[l] + (c*n_streams+s)*ML*R ; ML=(k-1)*d+1
+    wn_u64* gx;               // x' partials   [(NL*P)][n_streams][R]
+    wn_u64* gs;               // skip lanes    [(NL*P)][n_streams][S]
+    wn_u64* gl;               // partial logits[PA][n_streams][C]
+    uint32_t* status;         // [8] 0: abort code, 1: chain position, 2: eval, 3: stream, 4: where
+};
+
+struct WnRun {
+    const int32_t* first;  // [n_streams][n_given]
+    int64_t n_given, num_samples, n_eval, t_base;
+    float temperature;
+    int32_t greedy;
+    const float* reg;
+    const double* uniforms;
+    int32_t* out_idx;
+    float* dbg_logits;
+    int64_t timeout_ticks;  // wall_clock64 ticks
+};
+
+// ---- host-side planner / packer (plain C++; also parsed, unused, in the device pass) ----
+#include <functional>
+#include <string>
+#include <vector>
+
+static inline int wn_pow2floor(int v) { int p = 1; while (p * 2 <= v) p *= 2; return p; }
+static inline int wn_pow2ceil(int v) { int p = 1; while (p < v) p *= 2; return p; }
+static inline int wn_cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline int wn_round4(int v) { return (v + 3) & ~3; }
+
+static inline WnMatvec wn_make_matvec(int Nr, int K, int off4) {
+    WnMatvec m;
+    m.Nr = Nr; m.K = K;
+    const int K4 = wn_cdiv(K, 4);
+    int T = Nr >= WN_THREADS ? 1 : wn_pow2floor(WN_THREADS / Nr);
+    const int tmax = wn_pow2ceil(K4);
+    if (T > tmax) T = tmax;
+    if (T > 64) T = 64;
+    m.T = T;
+    m.J = wn_cdiv(K4, T);
+    m.passes = wn_cdiv(Nr, WN_THREADS / T);
+    m.off4 = off4;
+    m.xlen = m.J * T * 4;
+    m.n4 = m.passes * m.J * WN_THREADS;
+    return m;
+}
+
+// dst: float image of m (m.n4*4 floats); W(row,k) -> weight or 0 outside the matrix
+static inline void wn_pack_matvec(float* dst, const WnMatvec& m, const std::function<float(int, int)>& W) {
+    const int rpp = WN_THREADS / m.T;
+    for (int p = 0; p < m.passes; ++p)
+        for (int j = 0; j < m.J; ++j)
+            for (int tid = 0; tid < WN_THREADS; ++tid) {
+                const int row = p * rpp + tid / m.T, q = tid % m.T;
+                for (int i = 0; i < 4; ++i) {
+                    const int kk = (j * m.T + q) * 4 + i;
+                    dst[((size_t)(p * m.J + j) * WN_THREADS + tid) * 4 + i] = (row < m.Nr && kk < m.K) ? W(row, kk) : 0.f;
+                }
+            }
+}
+
+// Fills the geometry part of the plan for a given split; returns LDS bytes needed.
+static inline int64_t wn_plan_geometry(WnPlan& pl, int P, int PA) {
+    pl.P = P; pl.PA = PA;
+    pl.Dc = wn_cdiv(pl.D, P);
+    pl.Ec = wn_cdiv(pl.E, PA);
+    pl.n_wg = pl.NL * P + PA;
+    int off4 = 0;
+    pl.fg = wn_make_matvec(2 * pl.Dc, pl.k * pl.R, off4); off4 += pl.fg.n4;
+    pl.res = wn_make_matvec(pl.R, pl.Dc, off4); off4 += pl.res.n4;
+    pl.skip = wn_make_matvec(pl.S, pl.Dc, off4); off4 += pl.skip.n4;
+    int o = off4 * 4;
+    pl.l_bias_fg = pl.l_bias_res = pl.l_bias_skip = -1;
+    if (pl.has_bias) {
+        pl.l_bias_fg = o; o += wn_round4(2 * pl.Dc);
+        pl.l_bias_res = o; o += wn_round4(pl.R);
+        pl.l_bias_skip = o; o += wn_round4(pl.S);
+    }
+    pl.blob_layer_floats = o;
+    int passes = pl.fg.passes;
+    if (pl.res.passes > passes) passes = pl.res.passes;
+    if (pl.skip.passes > passes) passes = pl.skip.passes;
+    // head
+    int hoff4 = 0;
+    pl.end1 = wn_make_matvec(pl.Ec, pl.S, hoff4); hoff4 += pl.end1.n4;
+    pl.end2 = wn_make_matvec(pl.C, pl.Ec, hoff4); hoff4 += pl.end2.n4;
+    int ho = hoff4 * 4;
+    pl.h_b1 = ho; ho += wn_round4(pl.Ec);
+    pl.h_b2 = ho; ho += wn_round4(pl.C);
+    pl.blob_head_floats = ho;
+    if (pl.end1.passes > passes) passes = pl.end1.passes;
+    if (pl.end2.passes > passes) passes = pl.end2.passes;
+    pl.red_floats = passes * WN_THREADS;
+    // layer scratch
+    pl.l_xs = o; o += wn_round4(pl.fg.xlen > pl.k * pl.R ? pl.fg.xlen : pl.k * pl.R);
+    pl.l_fgout = o; o += wn_round4(2 * pl.Dc);
+    int zlen = pl.res.xlen > pl.skip.xlen ? pl.res.xlen : pl.skip.xlen;
+    if (zlen < pl.Dc) zlen = pl.Dc;
+    pl.l_z = o; o += wn_round4(zlen);
+    pl.l_xt = o; o += wn_round4(pl.R);
+    // skin + red double as the sampler scratch of the L0 workgroups (never live at the same time)
+    // sampler scratch: lgt,xsm,pp floats (3*C4) + pd doubles (2*C4) + per-group partials (see wn_kernel.h WnSmp)
+    const int smp_floats = 5 * wn_round4(pl.C) + 8 * WN_SAMPLER_GROUPS + 16;
+    pl.l_skin = o;
+    pl.l_smp = o;
+    int region = wn_round4(pl.S) + pl.red_floats;
+    if (region < smp_floats) region = smp_floats;
+    pl.l_red = o + wn_round4(pl.S);
+    o += region;
+    pl.l_total = o;
+    // head scratch
+    pl.h_sk = ho; ho += wn_round4(pl.end1.xlen > pl.S ? pl.end1.xlen : pl.S);
+    pl.h_ev = ho; ho += wn_round4(pl.end2.xlen > pl.Ec ? pl.end2.xlen : pl.Ec);
+    pl.h_red = ho; ho += pl.red_floats;
+    pl.h_total = ho;
+    pl.lds_floats = pl.l_total > pl.h_total ? pl.l_total : pl.h_total;
+    return (int64_t)pl.lds_floats * 4;
+}
+
+// Chooses (P, PA): the smallest splits whose LDS image fits one CU, within the CU budget.
+// forced_P / forced_PA > 0 override.  Returns empty string on success, else a reason.
+static inline std::string wn_plan_choose(WnPlan& pl, int n_cu, int forced_P, int forced_PA) {
+    int bestP = -1, bestPA = -1;
+    const int p_lo = forced_P > 0 ? forced_P : 1, p_hi = forced_P > 0 ? forced_P : pl.D;
+    for (int P = p_lo; P <= p_hi; ++P) {
+        if (forced_P <= 0 && P > 1 && wn_cdiv(pl.D, P) == wn_cdiv(pl.D, P - 1)) continue;  // same Dc: no gain
+        WnPlan t = pl;
+        // layer part only depends on P: probe with a head split that certainly fits
+        wn_plan_geometry(t, P, pl.E);
+        if ((int64_t)t.l_total * 4 <= WN_LDS_MAX_BYTES) { bestP = P; break; }
+    }
+    if (bestP < 0) return "no layer split fits the 160 KiB LDS of one CU";
+    const int a_lo = forced_PA > 0 ? forced_PA : 1, a_hi = forced_PA > 0 ? forced_PA : pl.E;
+    for (int PA = a_lo; PA <= a_hi; ++PA) {
+        if (forced_PA <= 0 && PA > 1 && wn_cdiv(pl.E, PA) == wn_cdiv(pl.E, PA - 1)) continue;
+        WnPlan t = pl;
+        wn_plan_geometry(t, bestP, PA);
+        if ((int64_t)t.h_total * 4 <= WN_LDS_MAX_BYTES) { bestPA = PA; break; }
+    }
+    if (bestPA < 0) return "no head split fits the 160 KiB LDS of one CU";
+    const int64_t lds = wn_plan_geometry(pl, bestP, bestPA);
+    if (lds > WN_LDS_MAX_BYTES) return "LDS image does not fit";
+    if (n_cu > 0) {
+        const int per_cu = (int)(WN_LDS_MAX_BYTES / lds) > 0 ? (int)(WN_LDS_MAX_BYTES / lds) : 1;
+        const int cap = n_cu * (per_cu > 4 ? 4 : per_cu);
+        if (pl.n_wg > cap)
+            return "the chain needs " + std::to_string(pl.n_wg) + " co-resident workgroups but the device admits only " +
+                   std::to_string(cap);
+    }
+    return std::string();
+}
+
+struct WnHostWeights {  // host pointers, reference layout (see include/wn_abi.h wn_weight_ptrs)
+    const float *start_w, *start_b, *filter_w, *filter_b, *gate_w, *gate_b, *res_w, *res_b, *skip_w, *skip_b, *end1_w,
+        *end1_b, *end2_w, *end2_b;
+};
+
+// Builds all per-workgroup LDS images: [NL*P layer blobs][PA head blobs].
+static inline void wn_pack_blobs(const WnPlan& pl, const WnHostWeights& w, std::vector<float>& out) {
+    const int R = pl.R, D = pl.D, S = pl.S, E = pl.E, C = pl.C, k = pl.k, Dc = pl.Dc, Ec = pl.Ec;
+    out.assign((size_t)pl.NL * pl.P * pl.blob_layer_floats + (size_t)pl.PA * pl.blob_head_floats, 0.f);
+    for (int l = 0; l < pl.NL; ++l)
+        for (int c = 0; c < pl.P; ++c) {
+            float* b = out.data() + ((size_t)l * pl.P + c) * pl.blob_layer_floats;
+            const float* fw = w.filter_w + (size_t)l * D * R * k;
+            const float* gw = w.gate_w + (size_t)l * D * R * k;
+            const float* rw = w.res_w + (size_t)l * R * D;
+            const float* sw = w.skip_w + (size_t)l * S * D;
+            // rows 0..Dc-1: filter channel c*Dc+row ; rows Dc..2Dc-1: gate.  k index kk = tap*R + ch:
+            // tap 0 multiplies x[t-(k-1)d] ... tap k-1 multiplies x[t]  (Appendix A item 1)
+            wn_pack_matvec(b + (size_t)pl.fg.off4 * 4, pl.fg, [&](int row, int kk) -> float {
+                const bool gate = row >= Dc;
+                const int ch_out = c * Dc + (gate ? row - Dc : row);
+                if (ch_out >= D) return 0.f;
+                const int tap = kk / R, ch = kk % R;
+                return (gate ? gw : fw)[((size_t)ch_out * R + ch) * k + tap];
+            });
+            wn_pack_matvec(b + (size_t)pl.res.off4 * 4, pl.res, [&](int row, int kk) -> float {
+                const int ch = c * Dc + kk;
+                return ch < D ? rw[(size_t)row * D + ch] : 0.f;
+            });
+            wn_pack_matvec(b + (size_t)pl.skip.off4 * 4, pl.skip, [&](int row, int kk) -> float {
+                const int ch = c * Dc + kk;
+                return ch < D ? sw[(size_t)row * D + ch] : 0.f;
+            });
+            if (pl.has_bias) {
+                for (int i = 0; i < Dc; ++i) {
+                    const int ch = c * Dc + i;
+                    b[pl.l_bias_fg + i] = (ch < D && w.filter_b) ? w.filter_b[(size_t)l * D + ch] : 0.f;
+                    b[pl.l_bias_fg + Dc + i] = (ch < D && w.gate_b) ? w.gate_b[(size_t)l * D + ch] : 0.f;
+                }
+                if (c == 0) {  // biases of the K-split convs ride on lane 0 only
+                    for (int i = 0; i < R; ++i) b[pl.l_bias_res + i] = w.res_b ? w.res_b[(size_t)l * R + i] : 0.f;
+                    for (int i = 0; i < S; ++i) b[pl.l_bias_skip + i] = w.skip_b ? w.skip_b[(size_t)l * S + i] : 0.f;
+                }
+            }
+        }
+    for (int h = 0; h < pl.PA; ++h) {
+        float* b = out.data() + (size_t)pl.NL * pl.P * pl.blob_layer_floats + (size_t)h * pl.blob_head_floats;
+        wn_pack_matvec(b + (size_t)pl.end1.off4 * 4, pl.end1, [&](int row, int kk) -> float {
+            const int e = h * Ec + row;
+            return e < E ? w.end1_w[(size_t)e * S + kk] : 0.f;
+        });
+        wn_pack_matvec(b + (size_t)pl.end2.off4 * 4, pl.end2, [&](int row, int kk) -> float {
+            const int e = h * Ec + kk;
+            return e < E ? w.end2_w[(size_t)row * E + e] : 0.f;
+        });
+        for (int i = 0; i < Ec; ++i) b[pl.h_b1 + i] = (h * Ec + i < E) ? w.end1_b[h * Ec + i] : 0.f;
+        if (h == 0)
+            for (int i = 0; i < C; ++i) b[pl.h_b2 + i] = w.end2_b[i];
+    }
+}
+
+// blockIdx -> chain position such that consecutive chain positions share an XCD (block b is observed
+// to land on XCD b % 8; a speed-only assumption -- correctness never depends on it).
+static inline void wn_make_wg_map(int n_wg, int n_xcd, std::vector<int32_t>& map) {
+    map.assign(n_wg, 0);
+    std::vector<int> cnt(n_xcd, 0), pre(n_xcd + 1, 0);
+    for (int b = 0; b < n_wg; ++b) cnt[b % n_xcd]++;
+    for (int x = 0; x < n_xcd; ++x) pre[x + 1] = pre[x] + cnt[x];
+    for (int b = 0; b < n_wg; ++b) map[b] = pre[b % n_xcd] + b / n_xcd;
+}
+#endif  // WN_PLAN_H

@@ -1,0 +1,388 @@
+// wn_runtime.hip -- C ABI of libwn_mi355.so (include/wn_abi.h): handle, planner glue, HIP launch.
+//
+// Built two ways from this one file:
+//   hipcc --offload-arch=gfx950 ... wn_runtime.hip            -> libwn_mi355.so   (the product)
+//   g++ -x c++ -DWN_EMU ... wn_runtime.hip                    -> tests/emu/libwn_emu.so
+// The -DWN_EMU build replaces the device with host memory and runs the workgroups of wn_kernel.h
+// sequentially in dependency order.  It exists so that planner, packer, ABI and the kernel's index
+// arithmetic are testable in the GPU-less authoring container; the Python package never loads it
+// (mi355_wavenet/_abi.py only looks for libwn_mi355.so and raises if it is missing).
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/wn_abi.h"
+#include "wn_kernel.h"
+
+static thread_local char g_err[512] = "";
+
+static int wn_fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+// ------------------------------------------------------------------------------------------------ runtime shim
+#ifdef WN_EMU
+#define RT_CHECK(x) (x)
+static void* rt_malloc(size_t n) { return calloc(1, n ? n : 1); }
+static void rt_free(void* p) { free(p); }
+static int rt_h2d(void* d, const void* h, size_t n) { memcpy(d, h, n); return 0; }
+static int rt_d2h(void* h, const void* d, size_t n) { memcpy(h, d, n); return 0; }
+static int rt_memset_async(void* d, int v, size_t n, void*) { memset(d, v, n); return 0; }
+static int rt_sync(void*) { return 0; }
+#else
+static const char* g_hip_what = "";
+static int rt_hip(hipError_t e, const char* what) {
+    if (e == hipSuccess) return 0;
+    g_hip_what = what;
+    snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+    return WN_E_HIP;
+}
+static void* rt_malloc(size_t n) {
+    void* p = nullptr;
+    if (hipMalloc(&p, n ? n : 1) != hipSuccess) return nullptr;
+    return p;
+}
+static void rt_free(void* p) { if (p) (void)hipFree(p); }
+static int rt_h2d(void* d, const void* h, size_t n) { return rt_hip(hipMemcpy(d, h, n, hipMemcpyHostToDevice), "hipMemcpy H2D"); }
+static int rt_d2h(void* h, const void* d, size_t n) { return rt_hip(hipMemcpy(h, d, n, hipMemcpyDeviceToHost), "hipMemcpy D2H"); }
+static int rt_memset_async(void* d, int v, size_t n, void* stream) {
+    return rt_hip(hipMemsetAsync(d, v, n, (hipStream_t)stream), "hipMemsetAsync");
+}
+static int rt_sync(void* stream) { return rt_hip(hipStreamSynchronize((hipStream_t)stream), "hipStreamSynchronize"); }
+
+// The persistent kernel: one workgroup per chain position, alive for the whole generate_fast() job.
+__global__ __launch_bounds__(WN_THREADS) void wn_generate_kernel(WnPlan p, WnRun r) {
+    extern __shared__ __attribute__((aligned(16))) float wn_lds[];
+    const int w = p.wg_map[blockIdx.x];
+    wn_load_lds(p, w, wn_lds);
+    WnCtx cx;
+    cx.p = &p; cx.r = &r; cx.lds = wn_lds; cx.w = w; cx.fail = 0;
+    cx.t_start = (long long)wall_clock64();
+    const int n_layer_wg = p.NL * p.P;
+    if (w < n_layer_wg) {
+        const int l = w / p.P, c = w % p.P;
+        const long long n_it = r.n_eval + (l == 0 ? 1 : 0);  // L0 runs one sample-only iteration at the end
+        for (long long e = 0; e < n_it; ++e)
+            for (int s = 0; s < p.n_streams; ++s)
+                if (!wn_layer_item(cx, l, c, e, s)) return;
+    } else {
+        const int h = w - n_layer_wg;
+        for (long long e = 0; e < r.n_eval; ++e)
+            for (int s = 0; s < p.n_streams; ++s)
+                if (!wn_head_item(cx, h, e, s)) return;
+    }
+}
+#endif
+
+// ------------------------------------------------------------------------------------------------ handle
+struct wn_handle {
+    wn_config cfg;
+    WnPlan plan;
+    bool have_weights;
+    bool pending;
+    void* last_stream;
+    long long t_base;  // evaluations since the last reset
+    int n_cu, wall_khz;
+    // owned device allocations
+    float *d_blobs, *d_start_t, *d_start_b, *d_rings;
+    int32_t *d_dil, *d_wg_map;
+    int64_t* d_ring_off;
+    wn_u64* d_gran;
+    uint32_t* d_status;
+    size_t blob_floats, ring_floats, gran_count;
+    std::vector<int64_t> ring_off;
+    std::vector<int32_t> dil;
+};
+
+extern "C" int wn_abi_version(void) { return WN_ABI_VERSION; }
+extern "C" const char* wn_last_error(void) { return g_err; }
+
+extern "C" void wn_destroy(wn_handle* h) {
+    if (!h) return;
+#ifndef WN_EMU
+    (void)hipSetDevice(h->cfg.device_id);
+    if (h->pending) (void)hipStreamSynchronize((hipStream_t)h->last_stream);
+#endif
+    rt_free(h->d_blobs); rt_free(h->d_start_t); rt_free(h->d_start_b); rt_free(h->d_rings); rt_free(h->d_dil);
+    rt_free(h->d_wg_map); rt_free(h->d_ring_off); rt_free(h->d_gran); rt_free(h->d_status);
+    delete h;
+}
+
+extern "C" int wn_create(const wn_config* cfg, wn_handle** out) {
+    g_err[0] = 0;
+    if (!cfg || !out) return wn_fail(WN_E_BADARG, "wn_create: NULL argument");
+    *out = nullptr;
+    if (cfg->layers < 1 || cfg->blocks < 1 || cfg->dilation_channels < 1 || cfg->residual_channels < 1 ||
+        cfg->skip_channels < 1 || cfg->end_channels < 1 || cfg->classes < 2 || cfg->n_streams < 1)
+        return wn_fail(WN_E_BADARG, "wn_create: non-positive dimension in wn_config");
+    if (cfg->kernel_size < 1) return wn_fail(WN_E_BADARG, "wn_create: kernel_size must be >= 1");
+    if (cfg->layers > 24) return wn_fail(WN_E_UNSUPPORTED, "wn_create: layers > 24 (dilation 2^layers overflows the queue)");
+    if (cfg->layer_split < 0 || cfg->head_split < 0 || cfg->reserved[0] || cfg->reserved[1] || cfg->reserved[2])
+        return wn_fail(WN_E_BADARG, "wn_create: negative split / non-zero reserved field");
+    int n_cu = 256, wall_khz = 100000;
+#ifndef WN_EMU
+    {
+        int ndev = 0;
+        int rc = rt_hip(hipGetDeviceCount(&ndev), "hipGetDeviceCount");
+        if (rc) return rc;
+        if (cfg->device_id < 0 || cfg->device_id >= ndev) return wn_fail(WN_E_BADARG, "wn_create: device_id %d of %d", cfg->device_id, ndev);
+        if ((rc = rt_hip(hipSetDevice(cfg->device_id), "hipSetDevice"))) return rc;
+        hipDeviceProp_t prop;
+        if ((rc = rt_hip(hipGetDeviceProperties(&prop, cfg->device_id), "hipGetDeviceProperties"))) return rc;
+        n_cu = prop.multiProcessorCount;
+        if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+            return wn_fail(WN_E_UNSUPPORTED, "wn_create: device %d is %s; this library is built for gfx950 (MI355X) only",
+                           cfg->device_id, prop.gcnArchName);
+        int khz = 0;
+        if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, cfg->device_id) == hipSuccess && khz > 0) wall_khz = khz;
+    }
+#endif
+    wn_handle* h = new wn_handle();
+    memset(&h->plan, 0, sizeof(h->plan));
+    h->cfg = *cfg;
+    h->have_weights = false; h->pending = false; h->last_stream = nullptr; h->t_base = 0;
+    h->n_cu = n_cu; h->wall_khz = wall_khz;
+    h->d_blobs = h->d_start_t = h->d_start_b = h->d_rings = nullptr;
+    h->d_dil = h->d_wg_map = nullptr; h->d_ring_off = nullptr; h->d_gran = nullptr; h->d_status = nullptr;
+    WnPlan& pl = h->plan;
+    pl.layers = cfg->layers; pl.blocks = cfg->blocks; pl.NL = cfg->layers * cfg->blocks;
+    pl.R = cfg->residual_channels; pl.D = cfg->dilation_channels; pl.S = cfg->skip_channels; pl.E = cfg->end_channels;
+    pl.C = cfg->classes; pl.k = cfg->kernel_size; pl.has_bias = cfg->bias ? 1 : 0; pl.n_streams = cfg->n_streams;
+    const std::string why = wn_plan_choose(pl, n_cu, cfg->layer_split, cfg->head_split);
+    if (!why.empty()) {
+        delete h;
+        return wn_fail(WN_E_UNSUPPORTED, "wn_create: %s", why.c_str());
+    }
+    // tables
+    h->dil.resize(pl.NL); h->ring_off.resize(pl.NL);
+    int64_t off = 0;
+    for (int l = 0; l < pl.NL; ++l) {
+        const int d = 1 << (l % pl.layers);  // wavenet_model.py:72,108-110
+        h->dil[l] = d;
+        h->ring_off[l] = off;
+        const int64_t ML = (int64_t)(pl.k - 1) * d + 1;  // wavenet_model.py:78
+        off += (int64_t)pl.P * pl.n_streams * ML * pl.R;
+    }
+    h->ring_floats = (size_t)off;
+    std::vector<int32_t> wg_map;
+    wn_make_wg_map(pl.n_wg, 8, wg_map);
+    const size_t n_lw = (size_t)pl.NL * pl.P;
+    const size_t gx_n = n_lw * pl.n_streams * pl.R, gs_n = n_lw * pl.n_streams * pl.S, gl_n = (size_t)pl.PA * pl.n_streams * pl.C;
+    h->gran_count = gx_n + gs_n + gl_n;
+    h->blob_floats = n_lw * pl.blob_layer_floats + (size_t)pl.PA * pl.blob_head_floats;
+    h->d_blobs = (float*)rt_malloc(h->blob_floats * 4);
+    h->d_start_t = (float*)rt_malloc((size_t)pl.C * pl.R * 4);
+    h->d_start_b = (float*)rt_malloc((size_t)pl.R * 4);
+    h->d_rings = (float*)rt_malloc(h->ring_floats * 4);
+    h->d_dil = (int32_t*)rt_malloc((size_t)pl.NL * 4);
+    h->d_ring_off = (int64_t*)rt_malloc((size_t)pl.NL * 8);
+    h->d_wg_map = (int32_t*)rt_malloc((size_t)pl.n_wg * 4);
+    h->d_gran = (wn_u64*)rt_malloc(h->gran_count * 8);
+    h->d_status = (uint32_t*)rt_malloc(8 * 4);
+    if (!h->d_blobs || !h->d_start_t || !h->d_start_b || !h->d_rings || !h->d_dil || !h->d_ring_off || !h->d_wg_map ||
+        !h->d_gran || !h->d_status) {
+        wn_destroy(h);
+        return wn_fail(WN_E_NOMEM, "wn_create: device allocation failed (queues %.1f MB, hand-off %.1f MB, weights %.1f MB)",
+                       h->ring_floats * 4e-6, h->gran_count * 8e-6, h->blob_floats * 4e-6);
+    }
+    int rc = 0;
+    rc = rc ? rc : rt_h2d(h->d_dil, h->dil.data(), (size_t)pl.NL * 4);
+    rc = rc ? rc : rt_h2d(h->d_ring_off, h->ring_off.data(), (size_t)pl.NL * 8);
+    rc = rc ? rc : rt_h2d(h->d_wg_map, wg_map.data(), (size_t)pl.n_wg * 4);
+    rc = rc ? rc : rt_memset_async(h->d_rings, 0, h->ring_floats * 4, nullptr);
+    rc = rc ? rc : rt_memset_async(h->d_status, 0, 32, nullptr);
+    rc = rc ? rc : rt_sync(nullptr);
+    if (rc) { wn_destroy(h); return rc; }
+    pl.blobs = h->d_blobs; pl.start_t = h->d_start_t; pl.start_b = nullptr;
+    pl.dil = h->d_dil; pl.ring_off = h->d_ring_off; pl.wg_map = h->d_wg_map; pl.rings = h->d_rings;
+    pl.gx = h->d_gran; pl.gs = h->d_gran + gx_n; pl.gl = h->d_gran + gx_n + gs_n;
+    pl.status = h->d_status;
+#ifndef WN_EMU
+    rc = rt_hip(hipFuncSetAttribute((const void*)wn_generate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, pl.lds_floats * 4),
+                "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+    if (rc) { wn_destroy(h); return rc; }
+#endif
+    *out = h;
+    return WN_OK;
+}
+
+extern "C" int wn_load_weights(wn_handle* h, const wn_weight_ptrs* w) {
+    g_err[0] = 0;
+    if (!h || !w) return wn_fail(WN_E_BADARG, "wn_load_weights: NULL argument");
+    if (!w->start_w || !w->filter_w || !w->gate_w || !w->res_w || !w->skip_w || !w->end1_w || !w->end1_b || !w->end2_w || !w->end2_b)
+        return wn_fail(WN_E_BADARG, "wn_load_weights: a mandatory weight pointer is NULL");
+    const WnPlan& pl = h->plan;
+    if (pl.has_bias && (!w->start_b || !w->filter_b || !w->gate_b || !w->res_b || !w->skip_b))
+        return wn_fail(WN_E_BADARG, "wn_load_weights: cfg.bias=1 but a stack bias pointer is NULL");
+#ifndef WN_EMU
+    { int rc = rt_hip(hipSetDevice(h->cfg.device_id), "hipSetDevice"); if (rc) return rc; }
+#endif
+    if (h->pending) { int rc = wn_wait(h); if (rc) return rc; }
+    WnHostWeights hw = {w->start_w, w->start_b, w->filter_w, w->filter_b, w->gate_w, w->gate_b, w->res_w,
+                        w->res_b, w->skip_w, w->skip_b, w->end1_w, w->end1_b, w->end2_w, w->end2_b};
+    std::vector<float> blobs;
+    wn_pack_blobs(pl, hw, blobs);
+    if (blobs.size() != h->blob_floats) return wn_fail(WN_E_STATE, "wn_load_weights: internal blob size mismatch");
+    std::vector<float> st((size_t)pl.C * pl.R);
+    for (int r = 0; r < pl.R; ++r)
+        for (int c = 0; c < pl.C; ++c) st[(size_t)c * pl.R + r] = w->start_w[(size_t)r * pl.C + c];
+    int rc = rt_h2d(h->d_blobs, blobs.data(), blobs.size() * 4);
+    rc = rc ? rc : rt_h2d(h->d_start_t, st.data(), st.size() * 4);
+    if (pl.has_bias) {
+        rc = rc ? rc : rt_h2d(h->d_start_b, w->start_b, (size_t)pl.R * 4);
+        h->plan.start_b = h->d_start_b;
+    } else {
+        h->plan.start_b = nullptr;
+    }
+    if (rc) return rc;
+    h->have_weights = true;
+    return WN_OK;
+}
+
+extern "C" int wn_reset(wn_handle* h, void* hip_stream) {
+    g_err[0] = 0;
+    if (!h) return wn_fail(WN_E_BADARG, "wn_reset: NULL handle");
+#ifndef WN_EMU
+    { int rc = rt_hip(hipSetDevice(h->cfg.device_id), "hipSetDevice"); if (rc) return rc; }
+#endif
+    if (h->pending) { int rc = wn_wait(h); if (rc) return rc; }
+    h->t_base = 0;
+    return rt_memset_async(h->d_rings, 0, h->ring_floats * 4, hip_stream);
+}
+
+#ifdef WN_EMU
+// Sequential schedule honouring the chain's dependencies: for every evaluation and stream run L0..L(NL-1)
+// (all slices), then the head slices; finally L0's sample-only iteration.
+static void wn_emu_run(const WnPlan& p, const WnRun& r, std::vector<std::vector<float>>& lds) {
+    const int n_lw = p.NL * p.P;
+    auto ctx = [&](int w) {
+        WnCtx cx;
+        cx.p = &p; cx.r = &r; cx.lds = lds[w].data(); cx.w = w; cx.fail = 0; cx.t_start = 0;
+        return cx;
+    };
+    for (long long e = 0; e <= r.n_eval; ++e)
+        for (int s = 0; s < p.n_streams; ++s) {
+            for (int w = 0; w < n_lw; ++w) {
+                const int l = w / p.P, c = w % p.P;
+                if (e == r.n_eval && l != 0) continue;
+                WnCtx cx = ctx(w);
+                if (!wn_layer_item(cx, l, c, e, s)) return;
+            }
+            if (e == r.n_eval) continue;
+            for (int hh = 0; hh < p.PA; ++hh) {
+                WnCtx cx = ctx(n_lw + hh);
+                if (!wn_head_item(cx, hh, e, s)) return;
+            }
+        }
+}
+#endif
+
+extern "C" int wn_generate(wn_handle* h, const wn_generate_args* a) {
+    g_err[0] = 0;
+    if (!h || !a) return wn_fail(WN_E_BADARG, "wn_generate: NULL argument");
+    if (!h->have_weights) return wn_fail(WN_E_STATE, "wn_generate: wn_load_weights has not been called");
+    if (a->n_given < 1 || a->num_samples < 0) return wn_fail(WN_E_BADARG, "wn_generate: n_given must be >= 1 and num_samples >= 0");
+    if (!a->first_samples) return wn_fail(WN_E_BADARG, "wn_generate: first_samples is NULL");
+    if (a->num_samples > 0 && !a->out_idx) return wn_fail(WN_E_BADARG, "wn_generate: out_idx is NULL");
+    if (a->flags != 0 || a->reserved != 0) return wn_fail(WN_E_BADARG, "wn_generate: flags/reserved must be 0");
+    const bool greedy = !(a->temperature > 0.f) || a->uniforms == nullptr;
+    const long long n_eval = a->n_given - 1 + a->num_samples;
+    if (n_eval + 1 >= 0xFFFFFFFFll) return wn_fail(WN_E_BADARG, "wn_generate: job too long for 32-bit hand-off tags");
+#ifndef WN_EMU
+    { int rc = rt_hip(hipSetDevice(h->cfg.device_id), "hipSetDevice"); if (rc) return rc; }
+#endif
+    if (h->pending) { int rc = wn_wait(h); if (rc) return rc; }
+    if (n_eval == 0) return WN_OK;
+    WnRun r;
+    memset(&r, 0, sizeof(r));
+    r.first = a->first_samples; r.n_given = a->n_given; r.num_samples = a->num_samples; r.n_eval = n_eval;
+    r.t_base = h->t_base; r.temperature = a->temperature; r.greedy = greedy ? 1 : 0; r.reg = a->regularizer;
+    r.uniforms = a->uniforms; r.out_idx = a->out_idx; r.dbg_logits = a->dbg_logits;
+    const long long ms = a->timeout_ms > 0 ? a->timeout_ms : 10000;
+    r.timeout_ticks = ms * (long long)h->wall_khz;
+    // hand-off words restart at tag 1 every call: zero them (and the status word) ahead of the launch
+    int rc = rt_memset_async(h->d_gran, 0, h->gran_count * 8, a->hip_stream);
+    rc = rc ? rc : rt_memset_async(h->d_status, 0, 32, a->hip_stream);
+    if (rc) return rc;
+#ifdef WN_EMU
+    {
+        std::vector<std::vector<float>> lds(h->plan.n_wg, std::vector<float>((size_t)h->plan.lds_floats + 4, 0.f));
+        for (int w = 0; w < h->plan.n_wg; ++w) wn_load_lds(h->plan, w, lds[w].data());
+        wn_emu_run(h->plan, r, lds);
+    }
+#else
+    hipLaunchKernelGGL(wn_generate_kernel, dim3(h->plan.n_wg), dim3(WN_THREADS), (size_t)h->plan.lds_floats * 4,
+                       (hipStream_t)a->hip_stream, h->plan, r);
+    rc = rt_hip(hipGetLastError(), "launch wn_generate_kernel");
+    if (rc) return rc;
+#endif
+    h->pending = true;
+    h->last_stream = a->hip_stream;
+    h->t_base += n_eval;
+    return WN_OK;
+}
+
+extern "C" int wn_wait(wn_handle* h) {
+    if (!h) return wn_fail(WN_E_BADARG, "wn_wait: NULL handle");
+    if (!h->pending) return WN_OK;
+    h->pending = false;
+    int rc = rt_sync(h->last_stream);
+    if (rc) return rc;
+    uint32_t st[8];
+    rc = rt_d2h(st, h->d_status, 32);
+    if (rc) return rc;
+    if (st[0] != 0) {
+        static const char* where[] = {"?", "partial logits (head -> L0)", "x partials (layer -> layer)", "skip lane (layer -> layer)",
+                                      "skip lanes (last layer -> head)"};
+        return wn_fail(WN_E_TIMEOUT,
+                       "wn_generate: hand-off wait gave up at chain position %u (eval %u, stream %u) waiting for %s; "
+                       "queues are in an undefined state -- call wn_reset",
+                       st[1], st[2], st[3], where[st[4] < 5 ? st[4] : 0]);
+    }
+    return WN_OK;
+}
+
+extern "C" int wn_get_info(wn_handle* h, wn_info* out) {
+    if (!h || !out) return wn_fail(WN_E_BADARG, "wn_get_info: NULL argument");
+    const WnPlan& pl = h->plan;
+    memset(out, 0, sizeof(*out));
+    out->abi_version = WN_ABI_VERSION;
+    out->n_layers = pl.NL; out->layer_split = pl.P; out->head_split = pl.PA; out->n_workgroups = pl.n_wg;
+    out->lds_bytes = pl.lds_floats * 4; out->n_compute_units = h->n_cu;
+    out->receptive_field = 1 + pl.blocks * (pl.k - 1) * ((1 << pl.layers) - 1);
+    out->weight_bytes = (int64_t)h->blob_floats * 4 + (int64_t)pl.C * pl.R * 4;
+    out->queue_bytes = (int64_t)h->ring_floats * 4;
+    out->handoff_bytes = (int64_t)h->gran_count * 8;
+    out->evals_done = h->t_base;
+    return WN_OK;
+}
+
+extern "C" int wn_export_queue(wn_handle* h, int32_t layer, int32_t stream, float* host_data, int32_t* in_pos, int32_t* out_pos) {
+    g_err[0] = 0;
+    if (!h || !host_data) return wn_fail(WN_E_BADARG, "wn_export_queue: NULL argument");
+    const WnPlan& pl = h->plan;
+    if (layer < 0 || layer >= pl.NL || stream < 0 || stream >= pl.n_streams) return wn_fail(WN_E_BADARG, "wn_export_queue: index out of range");
+#ifndef WN_EMU
+    { int rc = rt_hip(hipSetDevice(h->cfg.device_id), "hipSetDevice"); if (rc) return rc; }
+#endif
+    if (h->pending) { int rc = wn_wait(h); if (rc) return rc; }
+    const int d = h->dil[layer];
+    const int ML = (pl.k - 1) * d + 1;
+    std::vector<float> tmp((size_t)ML * pl.R);
+    // slice c = 0 holds the layer's queue (all P slices keep identical copies)
+    int rc = rt_d2h(tmp.data(), h->d_rings + h->ring_off[layer] + (size_t)stream * ML * pl.R, tmp.size() * 4);
+    if (rc) return rc;
+    for (int r = 0; r < pl.R; ++r)
+        for (int m = 0; m < ML; ++m) host_data[(size_t)r * ML + m] = tmp[(size_t)m * pl.R + r];  // (slot, R) -> (R, max_length)
+    if (in_pos) *in_pos = (int32_t)(h->t_base % ML);  // one enqueue + one dequeue per evaluation
+    if (out_pos) *out_pos = (int32_t)(h->t_base % ML);
+    return WN_OK;
+}

@@ -1,0 +1,104 @@
+"""ctypes binding of include/wn_abi.h (libwn_mi355.so).
+
+The product loads exactly one library: ``libwn_mi355.so`` next to this file (built in-tree by
+``pytorch-wavenet_amd/build.py`` with hipcc for gfx950).  If it is missing this module raises --
+there is no CPU or torch fallback for the generation path.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+PRODUCT_LIB = os.path.join(_HERE, "libwn_mi355.so")
+
+WN_OK, WN_E_BADARG, WN_E_UNSUPPORTED, WN_E_HIP, WN_E_NOMEM, WN_E_TIMEOUT, WN_E_STATE = 0, -1, -2, -3, -4, -5, -6
+ERROR_NAMES = {0: "WN_OK", -1: "WN_E_BADARG", -2: "WN_E_UNSUPPORTED", -3: "WN_E_HIP", -4: "WN_E_NOMEM",
+               -5: "WN_E_TIMEOUT", -6: "WN_E_STATE"}
+
+
+class WnError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("%s (%d): %s" % (ERROR_NAMES.get(code, "?"), code, msg))
+        self.code = code
+
+
+class wn_config(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in (
+        "layers", "blocks", "dilation_channels", "residual_channels", "skip_channels", "end_channels", "classes",
+        "kernel_size", "bias", "n_streams", "device_id", "layer_split", "head_split")] + [("reserved", ctypes.c_int32 * 3)]
+
+
+WEIGHT_FIELDS = ["start_w", "start_b", "filter_w", "filter_b", "gate_w", "gate_b", "res_w", "res_b", "skip_w", "skip_b",
+                 "end1_w", "end1_b", "end2_w", "end2_b"]
+
+
+class wn_weight_ptrs(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_void_p) for n in WEIGHT_FIELDS]
+
+
+class wn_generate_args(ctypes.Structure):
+    _fields_ = [("first_samples", ctypes.c_void_p), ("n_given", ctypes.c_int64), ("num_samples", ctypes.c_int64),
+                ("temperature", ctypes.c_float), ("flags", ctypes.c_int32), ("regularizer", ctypes.c_void_p),
+                ("uniforms", ctypes.c_void_p), ("out_idx", ctypes.c_void_p), ("dbg_logits", ctypes.c_void_p),
+                ("hip_stream", ctypes.c_void_p), ("timeout_ms", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+
+class wn_info(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in ("abi_version", "n_layers", "layer_split", "head_split", "n_workgroups",
+                                               "lds_bytes", "n_compute_units", "receptive_field")] + \
+               [(n, ctypes.c_int64) for n in ("weight_bytes", "queue_bytes", "handoff_bytes", "evals_done")]
+
+
+EXPORTS = ["wn_abi_version", "wn_create", "wn_destroy", "wn_load_weights", "wn_reset", "wn_generate", "wn_wait",
+           "wn_get_info", "wn_export_queue", "wn_last_error"]
+
+
+class Library:
+    """A loaded wn_abi library.  ``host_memory`` is True only for the test emulator (host pointers)."""
+
+    def __init__(self, path, host_memory=False):
+        self.path = path
+        self.host_memory = host_memory
+        self.dll = ctypes.CDLL(path)
+        d = self.dll
+        for name in EXPORTS:
+            if not hasattr(d, name):
+                raise RuntimeError("%s does not export %s" % (path, name))
+        d.wn_abi_version.restype = ctypes.c_int
+        d.wn_last_error.restype = ctypes.c_char_p
+        d.wn_create.argtypes = [ctypes.POINTER(wn_config), ctypes.POINTER(ctypes.c_void_p)]
+        d.wn_destroy.argtypes = [ctypes.c_void_p]
+        d.wn_destroy.restype = None
+        d.wn_load_weights.argtypes = [ctypes.c_void_p, ctypes.POINTER(wn_weight_ptrs)]
+        d.wn_reset.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        d.wn_generate.argtypes = [ctypes.c_void_p, ctypes.POINTER(wn_generate_args)]
+        d.wn_wait.argtypes = [ctypes.c_void_p]
+        d.wn_get_info.argtypes = [ctypes.c_void_p, ctypes.POINTER(wn_info)]
+        d.wn_export_queue.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p,
+                                      ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]
+        for name in EXPORTS:
+            if name not in ("wn_destroy", "wn_last_error"):
+                getattr(d, name).restype = ctypes.c_int
+        if d.wn_abi_version() != 1:
+            raise RuntimeError("%s: ABI version %d, expected 1" % (path, d.wn_abi_version()))
+
+    def last_error(self):
+        return (self.dll.wn_last_error() or b"").decode("utf-8", "replace")
+
+    def check(self, rc):
+        if rc != 0:
+            raise WnError(rc, self.last_error())
+
+
+_product = None
+
+
+def load_product_library():
+    """The HIP engine.  Fails loudly when it has not been built -- there is no fallback."""
+    global _product
+    if _product is None:
+        if not os.path.exists(PRODUCT_LIB):
+            raise RuntimeError(
+                "mi355_wavenet: %s not found. Build it with `python pytorch-wavenet_amd/build.py` (needs hipcc, "
+                "targets gfx950). The generation path has no CPU/torch fallback." % PRODUCT_LIB)
+        _product = Library(PRODUCT_LIB, host_memory=False)
+    return _product

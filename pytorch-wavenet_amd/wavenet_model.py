@@ -1,0 +1,255 @@
+"""Drop-in for the reference's ``wavenet_model`` module: ``WaveNetModel``, ``load_latest_model_from``,
+``load_to_cpu`` -- same constructor, parameter names, attributes and method signatures
+(/root/reference/wavenet_model.py:8-346), so ``from wavenet_model import *`` callers, reference
+``state_dict``s and pickled snapshots keep working.
+
+What is different underneath:
+  * ``generate_fast()`` does not run the Python per-sample loop.  It hands the whole job to the MI355X
+    engine (mi355_wavenet.engine -> C ABI include/wn_abi.h -> HIP kernels csrc/wn_kernel.h): one persistent
+    kernel launch per call (per progress interval when a callback is given).  There is NO CPU fallback: without
+    a gfx950 GPU and the built library it raises.
+  * the global numpy RNG is consumed exactly as the reference does (one ``random_sample`` per generated
+    sample when ``temperature > 0``: ``np.random.choice``, wavenet_model.py:288) -- the draws are made on the
+    host and shipped to the kernel, which performs the same float64 inverse-CDF lookup.
+  * extension: ``first_samples`` may be 2-D ``(streams, n_given)``; the result is then ``(streams, num_samples)``.
+``forward()`` (training) runs the reference's algorithm with torch ops on whatever device the module lives on.
+"""
+import os
+import os.path
+import time
+
+from wavenet_modules import *  # noqa: F401,F403  (the reference re-exports these names, wavenet_model.py:4)
+from audio_data import *  # noqa: F401,F403       (and these, :5)
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+class WaveNetModel(nn.Module):
+    """
+    A Complete Wavenet Model (constructor arguments as in the reference, wavenet_model.py:28-39)
+
+    Args:
+        layers (Int):               Number of layers in each block
+        blocks (Int):               Number of wavenet blocks of this model
+        dilation_channels (Int):    Number of channels for the dilated convolution
+        residual_channels (Int):    Number of channels for the residual connection
+        skip_channels (Int):        Number of channels for the skip connections
+        end_channels (Int):         Number of channels of the penultimate 1x1 convolution
+        classes (Int):              Number of possible values each sample can have
+        output_length (Int):        Number of samples that are generated for each input
+        kernel_size (Int):          Size of the dilation kernel
+        dtype:                      Parameter type of this model (legacy tensor type object or torch.dtype)
+        bias (Bool):                Whether the stack convolutions carry a bias
+    """
+
+    def __init__(self, layers=10, blocks=4, dilation_channels=32, residual_channels=32, skip_channels=256,
+                 end_channels=256, classes=256, output_length=32, kernel_size=2, dtype=torch.FloatTensor, bias=False):
+        super(WaveNetModel, self).__init__()
+        self.layers = layers
+        self.blocks = blocks
+        self.dilation_channels = dilation_channels
+        self.residual_channels = residual_channels
+        self.skip_channels = skip_channels
+        self.end_channels = end_channels
+        self.classes = classes
+        self.kernel_size = kernel_size
+        self.dtype = dtype
+        self.bias = bias
+
+        self.dilations = []        # (dilation, previous dilation) per layer  (wavenet_model.py:75)
+        self.dilated_queues = []   # plain list on the module, not in state_dict (:56-57, :78-81)
+        self.filter_convs = nn.ModuleList()
+        self.gate_convs = nn.ModuleList()
+        self.residual_convs = nn.ModuleList()
+        self.skip_convs = nn.ModuleList()
+        self.start_conv = nn.Conv1d(classes, residual_channels, kernel_size=1, bias=bias)
+
+        receptive_field = 1
+        previous = 1
+        for _ in range(blocks):
+            span = kernel_size - 1
+            d = 1
+            for _ in range(layers):
+                self.dilations.append((d, previous))
+                self.dilated_queues.append(DilatedQueue(max_length=(kernel_size - 1) * d + 1,
+                                                        num_channels=residual_channels, dilation=d, dtype=dtype))
+                self.filter_convs.append(nn.Conv1d(residual_channels, dilation_channels, kernel_size, bias=bias))
+                self.gate_convs.append(nn.Conv1d(residual_channels, dilation_channels, kernel_size, bias=bias))
+                self.residual_convs.append(nn.Conv1d(dilation_channels, residual_channels, 1, bias=bias))
+                self.skip_convs.append(nn.Conv1d(dilation_channels, skip_channels, 1, bias=bias))
+                receptive_field += span
+                span *= 2
+                previous = d
+                d *= 2
+        self.end_conv_1 = nn.Conv1d(skip_channels, end_channels, 1, bias=True)
+        self.end_conv_2 = nn.Conv1d(end_channels, classes, 1, bias=True)
+        self.output_length = output_length
+        self.receptive_field = receptive_field
+        self._wn_engine = None
+        self._wn_engine_key = None
+
+    # ------------------------------------------------------------------ training path (torch ops)
+    def wavenet(self, input, dilation_func):
+        """The residual stack (wavenet_model.py:125-171) with a pluggable dilation function."""
+        x = self.start_conv(input)
+        skip = None
+        for i in range(self.blocks * self.layers):
+            dilation, init_dilation = self.dilations[i]
+            residual = dilation_func(x, dilation, init_dilation, i)
+            x = torch.tanh(self.filter_convs[i](residual)) * torch.sigmoid(self.gate_convs[i](residual))
+            s = x
+            if x.size(2) != 1:
+                s = dilate(x, 1, init_dilation=dilation)
+            s = self.skip_convs[i](s)
+            # right-aligned crop-add (the reference gets skip=0 on the first layer through a bare except)
+            skip = s if skip is None else s + skip[:, :, -s.size(2):]
+            x = self.residual_convs[i](x)
+            x = x + residual[:, :, (self.kernel_size - 1):]
+        x = F.relu(skip)
+        x = F.relu(self.end_conv_1(x))
+        return self.end_conv_2(x)
+
+    def wavenet_dilate(self, input, dilation, init_dilation, i):
+        return dilate(input, dilation, init_dilation)
+
+    def queue_dilate(self, input, dilation, init_dilation, i):
+        queue = self.dilated_queues[i]
+        queue.enqueue(input.data[0])
+        return queue.dequeue(num_deq=self.kernel_size, dilation=dilation).unsqueeze(0)
+
+    def forward(self, input):
+        """(N, classes, L) one-hot -> (N*output_length, classes) logits (wavenet_model.py:186-196)."""
+        x = self.wavenet(input, dilation_func=self.wavenet_dilate)
+        n, c, _ = x.size()
+        l = self.output_length
+        x = x[:, :, -l:].transpose(1, 2).contiguous()
+        return x.view(n * l, c)
+
+    def generate(self, num_samples, first_samples=None, temperature=1.):
+        raise NotImplementedError("WaveNetModel.generate() is dead code upstream (undefined self.scope, "
+                                  "wavenet_model.py:209); use generate_fast()")
+
+    # ------------------------------------------------------------------ generation path (HIP engine)
+    def _config(self):
+        return dict(layers=self.layers, blocks=self.blocks, dilation_channels=self.dilation_channels,
+                    residual_channels=self.residual_channels, skip_channels=self.skip_channels,
+                    end_channels=self.end_channels, classes=self.classes, kernel_size=self.kernel_size,
+                    bias=self.start_conv.bias is not None)
+
+    def _engine(self, n_streams):
+        """The MI355X engine holding this module's current parameters (rebuilt when they change)."""
+        from mi355_wavenet import engine
+        params = list(self.state_dict().items())
+        dev = next(self.parameters()).device
+        index = dev.index if dev.type == "cuda" and dev.index is not None else int(os.environ.get("WN_DEVICE", "0"))
+        key = (n_streams, index, tuple((k, v.data_ptr(), v._version) for k, v in params))
+        if self._wn_engine is None or self._wn_engine_key != key:
+            if self._wn_engine is not None and self._wn_engine_key[:2] == key[:2]:
+                self._wn_engine.load_weights(dict(params))
+            else:
+                if self._wn_engine is not None:
+                    self._wn_engine.close()
+                self._wn_engine = engine.Engine(self._config(), dict(params), n_streams=n_streams, device_index=index)
+            self._wn_engine_key = key
+        return self._wn_engine
+
+    def generate_fast(self, num_samples, first_samples=None, temperature=1., regularize=0.,
+                      progress_callback=None, progress_interval=100):
+        """Same contract as wavenet_model.py:237-315; returns float64 ndarray (num_samples,)."""
+        self.eval()
+        if first_samples is None:
+            first_samples = torch.LongTensor(1).zero_() + (self.classes // 2)
+        first = torch.as_tensor(first_samples).detach().cpu().numpy().astype(np.int64)
+        batched = first.ndim == 2
+        first = first.reshape(first.shape[0], -1) if batched else first.reshape(1, -1)
+        n_streams, num_given = first.shape
+        total_samples = num_given + num_samples
+        for queue in self.dilated_queues:  # :250-251
+            queue.reset()
+        eng = self._engine(n_streams)
+        eng.reset()
+        sampled = temperature > 0
+
+        # The job is evaluations ev = 0 .. n_eval-1 (num_given-1 priming + num_samples generating).  It is cut
+        # where the reference would have called back / printed, one persistent launch per piece:
+        #   priming step i fires the callback when i % interval == 0            (:266-269)
+        #   generating step i fires it when (i + num_given) % interval == 0      (:308-311)
+        #   the timing line is printed after generating step 99                 (:304-306)
+        n_prime = num_given - 1
+        n_eval = n_prime + num_samples
+        cuts = {n_eval}
+        if num_samples >= 100:
+            cuts.add(n_prime + 100)
+        if progress_callback is not None:
+            cuts.update(i + 1 for i in range(n_prime) if i % progress_interval == 0)
+            cuts.update(n_prime + i + 1 for i in range(num_samples) if (i + num_given) % progress_interval == 0)
+        pieces = []
+        last = None
+        tic = time.time()
+        a = 0
+        for b in sorted(cuts):
+            if b > a:
+                seg_prime = max(0, min(b, n_prime) - a)
+                n_new = (b - a) - seg_prime
+                head = first[:, a:a + seg_prime + 1] if a < num_given else last
+                # one uniform per generated sample from the GLOBAL numpy RNG, drawn right before the piece runs
+                u = np.random.random_sample((n_streams, n_new)) if (sampled and n_new > 0) else None
+                out = eng.generate(n_new, head, temperature=temperature, regularize=regularize, uniforms=u, reset=False)
+                if n_new > 0:
+                    pieces.append(out)
+                    last = out[:, -1:].astype(np.int64)
+                a = b
+            ev = b - 1  # the evaluation that just finished
+            if ev < 0:
+                continue
+            if ev >= n_prime and ev - n_prime + 1 == 100:
+                toc = time.time()
+                print("one generating step does take approximately " + str((toc - tic) * 0.01) + " seconds)")
+            if progress_callback is not None:
+                if ev < n_prime:
+                    if ev % progress_interval == 0:
+                        progress_callback(ev, total_samples)
+                elif (ev - n_prime + num_given) % progress_interval == 0:
+                    progress_callback(ev - n_prime + num_given, total_samples)
+        idx = np.concatenate(pieces, axis=1) if pieces else np.zeros((n_streams, 0), dtype=np.int32)
+        generated = (idx.astype(np.int64) / self.classes) * 2. - 1  # :296
+        self.train()
+        mu_gen = mu_law_expansion(generated, self.classes)  # :314
+        return mu_gen if batched else mu_gen[0]
+
+    # ------------------------------------------------------------------ bookkeeping
+    def parameter_count(self):
+        return sum(int(np.prod(list(p.size()))) for p in self.parameters())
+
+    def cpu(self, type=torch.FloatTensor):
+        self.dtype = type
+        for q in self.dilated_queues:
+            q.dtype = self.dtype
+        return super().cpu()
+
+    def __getstate__(self):  # the engine handle is not picklable and is rebuilt on demand
+        state = self.__dict__.copy()
+        state["_wn_engine"] = None
+        state["_wn_engine_key"] = None
+        return state
+
+
+def load_latest_model_from(location, use_cuda=True):
+    """Newest file (by ctime) in ``location`` -> model (wavenet_model.py:330-340)."""
+    files = [location + "/" + f for f in os.listdir(location)]
+    newest_file = max(files, key=os.path.getctime)
+    print("load model " + newest_file)
+    if use_cuda:
+        model = torch.load(newest_file, weights_only=False)
+    else:
+        model = load_to_cpu(newest_file)
+    return model
+
+
+def load_to_cpu(path):
+    model = torch.load(path, map_location=lambda storage, loc: storage, weights_only=False)
+    model.cpu()
+    return model

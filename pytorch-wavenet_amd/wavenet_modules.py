@@ -1,0 +1,108 @@
+"""Drop-in for the reference's ``wavenet_modules`` (same public names and behaviour):
+``dilate``, ``DilatedQueue``, ``constant_pad_1d`` / ``ConstantPad1d``.
+
+These are the host-side tensor helpers used by ``WaveNetModel.forward()`` (training) and kept for API
+compatibility (``model.dilated_queues``); the generation hot path does not use them -- its queues live on
+the GPU inside the HIP engine (csrc/wn_kernel.h).  Behaviour follows /root/reference/wavenet_modules.py:
+dilate :10-39, DilatedQueue :42-77, ConstantPad1d/constant_pad_1d :80-127.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.nn import Parameter  # noqa: F401  (re-exported like the reference's star-import surface)
+from torch.autograd import Variable, Function  # noqa: F401
+
+
+def constant_pad_1d(input, target_size, dimension=0, value=0, pad_start=False):
+    """Pad ``input`` along ``dimension`` with ``value`` up to ``target_size`` (at the start if ``pad_start``).
+    Same contract as wavenet_modules.py:121-127; differentiable (F.pad), so gradients crop like the
+    reference's hand-written backward (:106-118)."""
+    num_pad = target_size - input.size(dimension)
+    assert num_pad >= 0, 'target size has to be greater than input size'
+    if num_pad == 0:
+        return input
+    spec = [0, 0] * input.dim()
+    spec[2 * (input.dim() - 1 - dimension) + (0 if pad_start else 1)] = num_pad
+    return F.pad(input, spec, mode="constant", value=value)
+
+
+class ConstantPad1d(nn.Module):
+    """Name-compatible wrapper (the reference's is a legacy autograd Function, unusable on torch >= 1.3)."""
+
+    def __init__(self, target_size, dimension=0, value=0, pad_start=False):
+        super().__init__()
+        self.target_size, self.dimension, self.value, self.pad_start = target_size, dimension, value, pad_start
+
+    def forward(self, input):
+        return constant_pad_1d(input, self.target_size, self.dimension, self.value, self.pad_start)
+
+
+def dilate(x, dilation, init_dilation=1, pad_start=True):
+    """(N, C, L) at dilation ``init_dilation`` -> (N*f, C, L/f) at ``dilation``, f = dilation/init_dilation
+    (wavenet_modules.py:10-39).
+
+    An (n, c, l) tensor at dilation n is one sequence of l*n timesteps, time index j*n + i; re-dilating is
+    re-folding that sequence with a different row count.  If l is not a multiple of f each row is zero padded
+    (at the start by default), i.e. the sequence gains pad*n leading zeros -- the reference's quirk that
+    forward() must reproduce."""
+    n, c, l = x.size()
+    factor = dilation / init_dilation
+    if factor == 1:
+        return x
+    padded_l = int(np.ceil(l / factor) * factor)
+    if padded_l != l:
+        x = constant_pad_1d(x, padded_l, dimension=2, pad_start=pad_start)
+        l = padded_l
+    rows = math.ceil(n * dilation / init_dilation)
+    cols = math.ceil(l * init_dilation / dilation)
+    seq = x.permute(1, 2, 0).contiguous().view(c, cols, rows)  # (c, time) refolded as (c, cols, rows)
+    return seq.permute(2, 0, 1).contiguous()
+
+
+def _zeros(dtype, *shape):
+    """``dtype`` may be a legacy tensor type object (torch.FloatTensor, torch.cuda.FloatTensor -- the
+    reference's convention, wavenet_modules.py:53) or a torch.dtype."""
+    if isinstance(dtype, torch.dtype):
+        return torch.zeros(*shape, dtype=dtype)
+    return dtype(*shape).zero_()
+
+
+class DilatedQueue:
+    """Ring buffer (num_channels, max_length): ``enqueue`` writes one column at ``in_pos``; ``dequeue`` returns
+    ``num_deq`` columns spaced ``dilation`` ending at ``out_pos``, oldest first (wavenet_modules.py:42-77)."""
+
+    def __init__(self, max_length, data=None, dilation=1, num_deq=1, num_channels=1, dtype=torch.FloatTensor):
+        self.in_pos = 0
+        self.out_pos = 0
+        self.num_deq = num_deq
+        self.num_channels = num_channels
+        self.dilation = dilation
+        self.max_length = max_length
+        self.data = data
+        self.dtype = dtype
+        if data is None:
+            self.data = _zeros(dtype, num_channels, max_length)
+
+    def enqueue(self, input):
+        self.data[:, self.in_pos] = input.reshape(-1)
+        self.in_pos = (self.in_pos + 1) % self.max_length
+
+    def dequeue(self, num_deq=1, dilation=1):
+        first = self.out_pos - (num_deq - 1) * dilation
+        if first >= 0:
+            cols = list(range(first, self.out_pos + 1, dilation))
+        else:
+            # the reference concatenates data[:, first::dilation] and data[:, out_pos % dilation : out_pos+1 : dilation]
+            cols = list(range(self.max_length + first, self.max_length, dilation))
+            cols += list(range(self.out_pos % dilation, self.out_pos + 1, dilation))
+        t = self.data.index_select(1, torch.as_tensor(cols, dtype=torch.long, device=self.data.device))
+        self.out_pos = (self.out_pos + 1) % self.max_length
+        return t
+
+    def reset(self):
+        self.data = _zeros(self.dtype, self.num_channels, self.max_length)  # rebinds, like the reference (:75)
+        self.in_pos = 0
+        self.out_pos = 0

@@ -1,0 +1,100 @@
+"""C-ABI surface tests that need no GPU: the HIP library builds for gfx950, loads, and exports every symbol
+include/wn_abi.h declares (no compute calls); argument/error handling is exercised on the emulator build of
+the same source."""
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from emu_lib import emu_library
+from mi355_wavenet import _abi, engine, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    src = open(os.path.join(ROOT, "include", "wn_abi.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(wn_[a-z_]+)\s*\(", src)))
+
+
+def test_header_functions_match_binding():
+    assert declared_functions() == sorted(_abi.EXPORTS)
+
+
+def test_hip_library_builds_and_exports_every_symbol():
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "pytorch-wavenet_amd"))
+    import build
+    so = build.build_hip()
+    out = subprocess.check_output(["nm", "-D", "--defined-only", so]).decode()
+    exported = set(l.split()[-1] for l in out.splitlines() if l.strip())
+    for fn in declared_functions():
+        assert fn in exported, "%s not exported by %s" % (fn, so)
+    # it must contain a gfx950 code object and nothing else
+    bundle = subprocess.run(["/opt/rocm/lib/llvm/bin/clang-offload-bundler", "--list", "--type=o", "--input=" + so],
+                            capture_output=True, text=True)
+    if bundle.returncode == 0 and bundle.stdout.strip():
+        targets = [t for t in bundle.stdout.split() if "amdgcn" in t]
+        assert targets and all("gfx950" in t for t in targets), targets
+    lib = _abi.Library(so)  # dlopen + prototype check; no device call
+    assert lib.dll.wn_abi_version() == 1
+
+
+def test_struct_sizes_match_header():
+    assert ctypes.sizeof(_abi.wn_config) == 16 * 4
+    assert ctypes.sizeof(_abi.wn_weight_ptrs) == 14 * 8
+    assert ctypes.sizeof(_abi.wn_generate_args) == 8 + 8 + 8 + 4 + 4 + 8 * 5 + 4 + 4
+    assert ctypes.sizeof(_abi.wn_info) == 8 * 4 + 4 * 8
+
+
+def _cfg(**kw):
+    base = dict(synth.CONFIGS["tiny"])
+    base.update(kw)
+    return base
+
+
+def test_error_codes_never_exceptions():
+    lib = emu_library()
+    d = lib.dll
+    h = ctypes.c_void_p()
+    assert d.wn_create(None, ctypes.byref(h)) == _abi.WN_E_BADARG
+    bad = _abi.wn_config(0, 2, 16, 16, 32, 32, 256, 2, 0, 1, 0, 0, 0)
+    assert d.wn_create(ctypes.byref(bad), ctypes.byref(h)) == _abi.WN_E_BADARG
+    assert b"non-positive" in d.wn_last_error()
+    ok = _abi.wn_config(3, 2, 16, 16, 32, 32, 256, 2, 0, 1, 0, 0, 0)
+    assert d.wn_create(ctypes.byref(ok), ctypes.byref(h)) == 0
+    args = _abi.wn_generate_args()
+    assert d.wn_generate(h, ctypes.byref(args)) == _abi.WN_E_STATE  # no weights yet
+    assert d.wn_load_weights(h, None) == _abi.WN_E_BADARG
+    w = _abi.wn_weight_ptrs()
+    assert d.wn_load_weights(h, ctypes.byref(w)) == _abi.WN_E_BADARG
+    assert d.wn_export_queue(h, 99, 0, None, None, None) == _abi.WN_E_BADARG
+    d.wn_destroy(h)
+    d.wn_destroy(None)  # harmless
+    huge = _abi.wn_config(10, 20, 128, 128, 512, 256, 256, 2, 0, 1, 0, 4, 8)  # 808 workgroups > 256 CUs
+    assert d.wn_create(ctypes.byref(huge), ctypes.byref(h)) == _abi.WN_E_UNSUPPORTED
+    assert b"co-resident" in d.wn_last_error()
+
+
+def test_engine_argument_validation():
+    cfg = _cfg()
+    W = synth.init_weights(cfg, seed=1)
+    eng = engine.Engine(cfg, W, n_streams=2, lib=emu_library())
+    with pytest.raises(ValueError):
+        eng.generate(4, np.array([[1, 2, 300], [1, 2, 3]]))
+    with pytest.raises(ValueError):
+        eng.generate(4, np.zeros((3, 2), dtype=np.int64))
+    with pytest.raises(_abi.WnError):
+        engine.Engine(_cfg(kernel_size=0), W, lib=emu_library())
+
+
+def test_product_library_is_the_only_default(monkeypatch):
+    """The package must fail loudly -- not fall back -- when the HIP library is absent."""
+    monkeypatch.setattr(_abi, "PRODUCT_LIB", "/nonexistent/libwn_mi355.so")
+    monkeypatch.setattr(_abi, "_product", None)
+    with pytest.raises(RuntimeError, match="no CPU/torch fallback"):
+        _abi.load_product_library()

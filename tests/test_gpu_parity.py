@@ -1,0 +1,158 @@
+"""-m gpu: the HIP engine (libwn_mi355.so through the C ABI) against the CPU oracle on a real MI355X.
+
+Sizes are chosen so the oracle finishes in seconds; BASELINE-size behaviour (cfg3, 16000 samples, 64 streams)
+is covered by size-independent properties: determinism, continuation == one-shot, stream independence
+(stream s of a batched run == the same stream run alone), priming == teacher forcing."""
+import numpy as np
+import pytest
+import torch
+
+import c_oracle
+import restated
+from mi355_wavenet import _abi, engine, synth
+from parity_common import check_engine, make_case
+
+pytestmark = pytest.mark.gpu
+
+ODD = dict(layers=4, blocks=2, dilation_channels=10, residual_channels=7, skip_channels=13, end_channels=9,
+           classes=256, kernel_size=2, bias=True)
+K3 = dict(synth.CONFIGS["tiny_bias"], kernel_size=3)
+
+SMALL = [
+    ("tiny", "tiny", dict(), 1, 300, 20),
+    ("tiny_bias_ns3", "tiny_bias", dict(), 3, 200, 33),
+    ("tiny_bias_split", "tiny_bias", dict(layer_split=3, head_split=5), 2, 200, 10),
+    ("odd", ODD, dict(layer_split=3, head_split=2), 2, 150, 17),
+    ("k3", K3, dict(layer_split=2, head_split=2), 1, 150, 30),
+    ("cfg1", "cfg1", dict(), 1, 400, 70),
+    ("cfg1_split_ns4", "cfg1", dict(layer_split=2, head_split=8), 4, 200, 70),
+]
+
+
+def test_library_is_the_hip_build():
+    lib = _abi.load_product_library()
+    assert lib.path.endswith("libwn_mi355.so") and not lib.host_memory
+    assert torch.cuda.is_available()
+    assert "gfx950" in torch.cuda.get_device_properties(0).gcnArchName
+
+
+@pytest.mark.parametrize("label,cfgname,kw,ns,N,n_given", SMALL, ids=[c[0] for c in SMALL])
+def test_small_configs(label, cfgname, kw, ns, N, n_given):
+    cfg, W, first, uniforms = make_case(cfgname, 51, ns, n_given, N)
+    eng = engine.Engine(cfg, W, n_streams=ns, **kw)
+    g = check_engine(eng, cfg, W, N, first, 0.0, 0.0, None, label + " greedy")
+    s = check_engine(eng, cfg, W, N, first, 0.9, 0.001, uniforms, label + " sampled")
+    print(label, "greedy", g, "sampled", s, eng.info())
+    eng.close()
+
+
+BIG = [("cfg2", "cfg2", 1, 150, 64), ("cfg2_ns4", "cfg2", 4, 60, 8), ("cfg3", "cfg3", 1, 100, 40),
+       ("cfg3_ns6", "cfg3", 6, 30, 5), ("chaconne", "chaconne", 1, 80, 20)]
+
+
+@pytest.mark.parametrize("label,cfgname,ns,N,n_given", BIG, ids=[c[0] for c in BIG])
+def test_baseline_configs(label, cfgname, ns, N, n_given):
+    cfg, W, first, uniforms = make_case(cfgname, 52, ns, n_given, N)
+    eng = engine.Engine(cfg, W, n_streams=ns)
+    g = check_engine(eng, cfg, W, N, first, 0.0, 0.0, None, label + " greedy")
+    s = check_engine(eng, cfg, W, N, first, 1.0, 0.0, uniforms, label + " sampled")
+    print(label, "greedy", g, "sampled", s, eng.info())
+    eng.close()
+
+
+def test_cfg1_long_free_running():
+    """>= 1000 free-running steps, greedy bit-exact and sampled identical (SURVEY.md section 8c items 2,3)."""
+    cfg, W, first, uniforms = make_case("cfg1", 53, 1, 63, 3000)
+    eng = engine.Engine(cfg, W)
+    g = check_engine(eng, cfg, W, 3000, first, 0.0, 0.0, None, "cfg1 long greedy")
+    s = check_engine(eng, cfg, W, 3000, first, 1.0, 0.0, uniforms, "cfg1 long sampled")
+    print("cfg1 long", g, s)
+
+
+def test_golden_reference_sequences(golden):
+    """The sampled sequences the REAL reference produced (tests/golden/) reproduced on the GPU."""
+    for case, cname in (("tiny", "tiny"), ("tiny_bias", "tiny_bias"), ("cfg1", "cfg1"), ("cfg1_seed128", "cfg1")):
+        wseed, n_given, n, npseed = [int(v) for v in golden["gen_%s_meta" % case]]
+        temp, regz = [float(v) for v in golden["gen_%s_tr" % case]]
+        cfg = synth.CONFIGS[cname]
+        W = synth.init_weights(cfg, seed=wseed)
+        first = golden["gen_%s_first" % case].astype(np.int64)
+        np.random.seed(npseed)
+        u = np.random.random_sample(n)
+        eng = engine.Engine(cfg, W)
+        idx, logits = eng.generate(n, first, temperature=temp, regularize=regz, uniforms=u[None], want_logits=True)
+        assert np.array_equal(idx[0], golden["gen_%s_idx" % case].astype(np.int32)), case
+        assert np.array_equal(c_oracle.expand(idx[0]), golden["gen_%s_audio" % case]), case
+        rows = golden["gen_%s_logit_rows" % case]
+        ref = golden["gen_%s_logits" % case]
+        assert np.abs(logits[0][rows] - ref).max() <= 1e-5 * max(1.0, float(np.abs(ref).max()))
+        eng.close()
+
+
+def test_export_queue_after_generation():
+    cfg, W, first, _ = make_case("tiny", 54, 1, 12, 40)
+    eng = engine.Engine(cfg, W)
+    idx = eng.generate(40, first, temperature=0.0)
+    r = restated.RestatedWaveNet(cfg, W)
+    _, ridx, _ = r.generate_fast(40, first_samples=first[0], temperature=0.0, return_details=True)
+    assert np.array_equal(idx[0], ridx)
+    for layer in range(cfg["layers"] * cfg["blocks"]):
+        data, ip, op = eng.export_queue(layer)
+        q = r.queues[layer]
+        assert (ip, op) == (q.in_pos, q.out_pos)
+        assert np.allclose(data, q.data.numpy(), rtol=0, atol=2e-6)
+
+
+def test_full_size_properties_cfg3():
+    """BASELINE sizes: cfg3, 16000 samples; properties that need no oracle run of that length."""
+    cfg = synth.CONFIGS["cfg3"]
+    W = synth.init_weights(cfg, seed=55)
+    rs = np.random.RandomState(55)
+    N = 16000
+    first = rs.randint(0, 256, (1, 100))
+    u = rs.random_sample((1, N))
+    eng = engine.Engine(cfg, W)
+    a = eng.generate(N, first, temperature=1.0, uniforms=u)
+    b = eng.generate(N, first, temperature=1.0, uniforms=u)
+    assert np.array_equal(a, b), "not deterministic"
+    assert a.min() >= 0 and a.max() < 256 and len(set(a[0].tolist())) > 20
+    # continuation == one shot
+    c1 = eng.generate(5000, first, temperature=1.0, uniforms=u[:, :5000])
+    c2 = eng.generate(N - 5000, c1[:, -1:], temperature=1.0, uniforms=u[:, 5000:], reset=False)
+    assert np.array_equal(np.concatenate([c1, c2], 1), a)
+    # oracle on the first 300 steps of the same job
+    o_idx, _ = c_oracle.generate(cfg, W, 300, first[0], 1.0, 0.0, u[0, :300])
+    assert np.array_equal(a[0, :300], o_idx)
+    eng.close()
+    # stream independence: stream s of an 8-stream run == that stream alone
+    ns, n = 8, 2000
+    firsts = rs.randint(0, 256, (ns, 50))
+    us = rs.random_sample((ns, n))
+    eng8 = engine.Engine(cfg, W, n_streams=ns)
+    batch = eng8.generate(n, firsts, temperature=1.0, uniforms=us)
+    eng8.close()
+    eng1 = engine.Engine(cfg, W)
+    for s in (0, 5):
+        alone = eng1.generate(n, firsts[s:s + 1], temperature=1.0, uniforms=us[s:s + 1])
+        assert np.array_equal(alone[0], batch[s])
+    eng1.close()
+
+
+def test_two_handles_two_threads():
+    """Distinct handles are usable concurrently from different Python threads (the reference calls
+    generate_fast from a daemon thread while training: model_logging.py:48-58)."""
+    import threading
+    cfg, W, first, uniforms = make_case("cfg1", 56, 1, 30, 1500)
+    ref = engine.Engine(cfg, W).generate(1500, first, temperature=1.0, uniforms=uniforms)
+    out = {}
+
+    def work(i):
+        with torch.cuda.stream(torch.cuda.Stream()):
+            e = engine.Engine(cfg, W)
+            out[i] = e.generate(1500, first, temperature=1.0, uniforms=uniforms)
+            e.close()
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert np.array_equal(out[0], ref) and np.array_equal(out[1], ref)
