@@ -107,6 +107,9 @@ typedef struct wn_info {
     int64_t queue_bytes;     /* dilation-queue rings */
     int64_t handoff_bytes;   /* inter-workgroup granule buffers */
     int64_t evals_done;      /* timesteps evaluated since the last wn_reset (queue time) */
+    int32_t kernel_variant;  /* 1 = generic kernel (weights stationary in LDS, any shape)
+                                2 = latency-optimised kernel (weights stationary in registers, instantiated shapes) */
+    int32_t reserved;
 } wn_info;
 
 typedef struct wn_handle wn_handle;

@@ -1,0 +1,388 @@
+// wn_kernel_v2.h -- latency-optimised generation chain for gfx950 (device only).
+//
+// Same chain, same hand-off protocol and same HBM buffers as the generic kernel (wn_kernel.h, which stays
+// the fallback for arbitrary shapes and the source the CPU emulator tests), re-organised around what the
+// MI355X hand-off probe measured (profiles/r01_handoff_probe.txt): a granule hop costs 0.45-0.75 us no
+// matter what, so everything else must get off the critical path x[t] -> filter/gate -> z -> residual -> x'.
+//
+//   * WEIGHTS LIVE IN REGISTERS.  One workgroup = 4 waves, one per SIMD, so each lane owns up to 512 VGPRs;
+//     a layer slice is 100-200 floats per lane (cfg3: 148).  No LDS traffic for weights at all; LDS only
+//     carries activations (x, z, skip sum) between the lanes of the workgroup.
+//   * compile-time shapes (template <R, DC, S, EC>, k = 2, C = 256): every matvec is a fully unrolled FMA
+//     chain on register operands; row sums are finished with DPP butterflies (no LDS, no barrier).
+//   * the tap-0 half of the dilated conv (W[:,:,0] . x[t-d]) does not depend on the token: it is computed
+//     right after the previous step of the stream (off the critical path) and parked in LDS (prebuf).
+//   * polls are batched: a lane issues all its granule loads, then checks all tags (one round trip per
+//     retry instead of one per granule).
+//   * 2 workgroup barriers per step on the critical path (x staged, z staged); skip 1x1, queue push and the
+//     next step's tap-0 run after x' has been published.
+//   * the queue rings stay in HBM in the reference's DilatedQueue layout (wn_export_queue still works);
+//     they are only touched off the critical path.
+#ifndef WN_KERNEL_V2_H
+#define WN_KERNEL_V2_H
+
+#include "wn_kernel.h"
+
+#ifndef WN_EMU
+
+template <int R_, int DC_, int S_, int EC_>
+struct WnV2Shape {
+    static constexpr int R = R_, DC = DC_, S = S_, EC = EC_, C = 256;
+    static constexpr int G1 = 2 * DC;     // filter+gate rows of this slice
+    static constexpr int T1 = 256 / G1;   // lanes per fg row
+    static constexpr int K1 = R / T1;     // channels per lane per tap
+    static constexpr int T2 = 256 / R;    // lanes per residual row
+    static constexpr int K2 = DC / T2;    // z channels per lane
+    static constexpr int RS = S / 256;    // skip rows per lane (full DC reduction each)
+    static constexpr int T3 = 256 / EC;   // lanes per end_conv_1 row
+    static constexpr int K3 = S / T3;     // skip channels per lane
+    // per-lane register images (floats), stored striped in HBM: image[j*256 + tid]
+    static constexpr int NWL = 2 * K1 + K2 + RS * DC + 2 + RS;  // w1 | w0 | w2 | w3 | bias_fg, bias_res | bias_skip[RS]
+    static constexpr int NWH = K3 + EC + 2;                     // end1 slice | end2 row | b1 | b2
+    static_assert(G1 <= 256 && 256 % G1 == 0 && T1 <= 16, "fg rows must tile 256 lanes");
+    static_assert(R <= 256 && 256 % R == 0 && T2 <= 16, "residual rows must tile 256 lanes");
+    static_assert(R % T1 == 0 && DC % T2 == 0 && S % 256 == 0 && 256 % EC == 0 && S % T3 == 0 && T3 <= 16, "shape");
+};
+
+// ---- DPP butterflies: after wn_reduce<T> every lane of an aligned T-lane group holds the group sum
+template <int CTRL>
+static __device__ __forceinline__ float wn_dpp(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, true));
+}
+template <int LEVEL>  // partner at distance LEVEL inside a group whose lanes all hold the same value
+static __device__ __forceinline__ float wn_partner(float v) {
+    if constexpr (LEVEL == 1) return wn_dpp<0xB1>(v);        // quad_perm [1,0,3,2]
+    else if constexpr (LEVEL == 2) return wn_dpp<0x4E>(v);   // quad_perm [2,3,0,1]
+    else if constexpr (LEVEL == 4) return wn_dpp<0x141>(v);  // row_half_mirror
+    else if constexpr (LEVEL == 8) return wn_dpp<0x140>(v);  // row_mirror
+    else return __shfl_xor(v, LEVEL);
+}
+template <int T>
+static __device__ __forceinline__ float wn_reduce(float v) {
+    if constexpr (T >= 2) v += wn_partner<1>(v);
+    if constexpr (T >= 4) v += wn_partner<2>(v);
+    if constexpr (T >= 8) v += wn_partner<4>(v);
+    if constexpr (T >= 16) v += wn_partner<8>(v);
+    return v;
+}
+
+static __device__ __forceinline__ wn_u64 wn_ld_granule(const wn_u64* g) {
+    return __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Batched poll: loads n (<= NMAX) granules base[j*stride] together until every tag matches; returns their sum
+// in the fixed order j = 0..n-1.
+template <int NMAX>
+static __device__ __forceinline__ float wn_poll_sum(WnCtx& cx, const wn_u64* base, size_t stride, int n, uint32_t tag,
+                                                    int where, long long e, int s) {
+    if (cx.fail) return 0.f;
+    unsigned spins = 0;
+    for (;;) {
+        wn_u64 v[NMAX];
+#pragma unroll
+        for (int j = 0; j < NMAX; ++j) v[j] = j < n ? wn_ld_granule(base + (size_t)j * stride) : ((wn_u64)tag << 32);
+        bool ok = true;
+#pragma unroll
+        for (int j = 0; j < NMAX; ++j) ok = ok && ((uint32_t)(v[j] >> 32) == tag);
+        if (ok) {
+            float sum = 0.f;
+#pragma unroll
+            for (int j = 0; j < NMAX; ++j) sum += j < n ? __uint_as_float((uint32_t)v[j]) : 0.f;
+            return sum;
+        }
+        if ((++spins & 127u) == 0u) {
+            if (__hip_atomic_load(cx.p->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { cx.fail = 1; return 0.f; }
+            if ((long long)wall_clock64() - cx.t_start > cx.r->timeout_ticks) { wn_give_up(cx, where, e, s); return 0.f; }
+        }
+    }
+}
+
+// LDS layout (floats) of the v2 kernel
+template <class SH>
+struct WnV2Lds {
+    static constexpr int xs = 0;                         // [2][R]
+    static constexpr int zs = xs + 2 * SH::R;            // [DC]
+    static constexpr int sk = zs + ((SH::DC + 3) & ~3);  // [S]    head
+    static constexpr int ev = sk + SH::S;                // [EC]   head
+    static constexpr int smp = ev + SH::EC;              // sampler scratch: 64 floats (8-byte aligned)
+    static constexpr int pre = smp + 64;                 // [n_streams][256]
+    static int floats(int n_streams) { return pre + n_streams * 256; }
+};
+
+// ---- sampler (L0): C = 256 classes, one per lane.  Same arithmetic as wn_sample (wn_kernel.h) /
+// wavenet_model.py:280-294, with wave-level reductions.  Returns the class index (uniform over the block).
+static __device__ __forceinline__ int wn_sample_v2(WnCtx& cx, float* scratch, float logit, double u, bool greedy) {
+    const WnRun& r = *cx.r;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    float* fsc = scratch;                                    // [0..3] wave max, [4..7] wave sum
+    int* isc = reinterpret_cast<int*>(scratch + 8);          // [0..3] wave argmax, [4..7] wave count, [8] result
+    double* dsc = reinterpret_cast<double*>(scratch + 24);   // [0..3] wave totals
+    float x = logit;
+    if (r.reg) x -= r.reg[tid];
+    if (!greedy) x = x / r.temperature;
+    // max and first argmax
+    float m = x;
+    int am = tid;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const float om = __shfl_xor(m, off);
+        const int oa = __shfl_xor(am, off);
+        if (om > m || (om == m && oa < am)) { m = om; am = oa; }
+    }
+    if (lane == 0) { fsc[wv] = m; isc[wv] = am; }
+    __syncthreads();
+    float gm = fsc[0];
+    int ga = isc[0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w)
+        if (fsc[w] > gm) { gm = fsc[w]; ga = isc[w]; }  // equal maxima: the lower wave (lower indices) wins
+    if (greedy) { __syncthreads(); return ga; }
+    const float p = expf(x - gm);
+    float ps = p;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) ps += __shfl_xor(ps, off);
+    if (lane == 0) fsc[4 + wv] = ps;
+    __syncthreads();
+    const float tot = ((fsc[4] + fsc[5]) + fsc[6]) + fsc[7];
+    const float inv = 1.0f / tot;
+    const double pd = (double)(p * inv);
+    double run = pd;  // inclusive scan inside the wave (float64, like np.cumsum)
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const double o = __shfl_up(run, off);
+        if (lane >= off) run += o;
+    }
+    if (lane == 63) dsc[wv] = run;
+    __syncthreads();
+    double base = 0.;
+    for (int w = 0; w < wv; ++w) base += dsc[w];
+    const double total = ((dsc[0] + dsc[1]) + dsc[2]) + dsc[3];
+    const bool le = (base + run) / total <= u;  // searchsorted(cdf/cdf[-1], u, side='right')
+    const int cnt = __popcll(__ballot(le));
+    if (lane == 0) isc[4 + wv] = cnt;
+    __syncthreads();
+    int idx = isc[4] + isc[5] + isc[6] + isc[7];
+    if (idx > 255) idx = 255;
+    __syncthreads();
+    return idx;
+}
+
+// ------------------------------------------------------------------------------------------------
+template <class SH>
+static __device__ void wn_v2_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, float* lds, int l, int c) {
+    constexpr int R = SH::R, DC = SH::DC, S = SH::S, T1 = SH::T1, K1 = SH::K1, T2 = SH::T2, K2 = SH::K2, RS = SH::RS;
+    using L = WnV2Lds<SH>;
+    const int tid = threadIdx.x;
+    const int ns = p.n_streams, P = p.P, NL = p.NL;
+    // ---- register-resident weights of this slice
+    float w1[K1], w0[K1], w2[K2], w3[RS][DC], bskip[RS];
+    const float* img = p.blobs + (size_t)cx.w * (SH::NWL * 256) + tid;
+    {
+        int j = 0;
+#pragma unroll
+        for (int k = 0; k < K1; ++k) w1[k] = img[(size_t)(j++) * 256];
+#pragma unroll
+        for (int k = 0; k < K1; ++k) w0[k] = img[(size_t)(j++) * 256];
+#pragma unroll
+        for (int k = 0; k < K2; ++k) w2[k] = img[(size_t)(j++) * 256];
+#pragma unroll
+        for (int q = 0; q < RS; ++q)
+#pragma unroll
+            for (int k = 0; k < DC; ++k) w3[q][k] = img[(size_t)(j++) * 256];
+    }
+    const float bfg = img[(size_t)(2 * K1 + K2 + RS * DC) * 256];
+    const float bres = img[(size_t)(2 * K1 + K2 + RS * DC + 1) * 256];
+#pragma unroll
+    for (int q = 0; q < RS; ++q) bskip[q] = img[(size_t)(2 * K1 + K2 + RS * DC + 2 + q) * 256];
+
+    const int kq1 = tid % T1, grp = tid / T1, ch = grp >> 1, is_gate = grp & 1;
+    const int kq2 = tid % T2, row2 = tid / T2;
+    const int d = p.dil[l];
+    const int ML = d + 1;  // (k-1)*d + 1, k = 2
+    float* xs = lds + L::xs;
+    float* zs = lds + L::zs;
+    float* pre = lds + L::pre;
+    float* smp = lds + L::smp;
+
+    // tap-0 contribution for the first evaluation of every stream: x[t_base - d] from the queue (zeros after reset)
+    for (int s = 0; s < ns; ++s) {
+        const float* ring = p.rings + p.ring_off[l] + ((size_t)c * ns + s) * (size_t)ML * R;
+        long long pos = (r.t_base - d) % ML;
+        if (pos < 0) pos += ML;
+        float acc = kq1 == 0 ? bfg : 0.f;
+#pragma unroll
+        for (int k = 0; k < K1; ++k) acc += w0[k] * ring[(size_t)pos * R + kq1 * K1 + k];
+        pre[s * 256 + tid] = acc;
+    }
+    __syncthreads();
+
+    const long long n_it = r.n_eval + (l == 0 ? 1 : 0);
+    int buf = 0;
+    for (long long e = 0; e < n_it; ++e) {
+        const bool prime = e < r.n_given - 1;
+        const uint32_t tag = (uint32_t)(e + 1);
+        const long long t = r.t_base + e;
+        for (int s = 0; s < ns; ++s, buf ^= 1) {
+            float* xb = xs + buf * R;
+            cx.t_start = (long long)wall_clock64();  // the spin bound is per hand-off wait, not per job
+            // ---- 1. layer input x[t]
+            if (l == 0) {
+                int idx;
+                if (e == 0) {
+                    idx = r.first[(size_t)s * r.n_given];
+                } else {
+                    const float logit = wn_poll_sum<16>(cx, p.gl + (size_t)s * 256 + tid, (size_t)ns * 256, p.PA, (uint32_t)e,
+                                                        WN_W_LOGITS, e, s);
+                    if (__syncthreads_or(cx.fail)) return;
+                    if (e < r.n_given) {
+                        idx = r.first[(size_t)s * r.n_given + e];
+                    } else {
+                        const long long g = e - r.n_given;
+                        if (r.dbg_logits && c == 0) r.dbg_logits[((size_t)s * r.num_samples + g) * 256 + tid] = logit;
+                        const bool greedy = r.greedy != 0;
+                        const double u = greedy ? 0. : r.uniforms[(size_t)s * r.num_samples + g];
+                        idx = wn_sample_v2(cx, smp, logit, u, greedy);
+                        if (c == 0 && tid == 0) r.out_idx[(size_t)s * r.num_samples + g] = idx;
+                    }
+                }
+                if (e == r.n_eval) continue;
+                if (tid < R) xb[tid] = p.start_t[(size_t)idx * R + tid] + (p.start_b ? p.start_b[tid] : 0.f);
+                __syncthreads();
+            } else {
+                if (tid < R) {
+                    const wn_u64* g = p.gx + (((size_t)(l - 1) * P) * ns + s) * R + tid;
+                    xb[tid] = wn_poll_sum<8>(cx, g, (size_t)ns * R, P, tag, WN_W_X, e, s);
+                }
+                if (__syncthreads_or(cx.fail)) return;
+            }
+            // ---- 2. filter/gate: tap 1 on x[t] + parked tap 0, tanh * sigmoid   (wavenet_model.py:147-151)
+            float acc = pre[s * 256 + tid];
+            {
+                const float* xk = xb + kq1 * K1;
+#pragma unroll
+                for (int k = 0; k < K1; ++k) acc += w1[k] * xk[k];
+            }
+            acc = wn_reduce<T1>(acc);
+            const float other = wn_partner<T1>(acc);  // the gate (resp. filter) row of the same channel
+            const float fv = is_gate ? other : acc, gv = is_gate ? acc : other;
+            const float z = tanhf(fv) * (1.0f / (1.0f + expf(-gv)));
+            if (!is_gate && kq1 == 0) zs[ch] = z;
+            __syncthreads();
+            // ---- 3. residual 1x1 partial, published at once                      (wavenet_model.py:164-165)
+            if (l < NL - 1) {
+                float a2 = 0.f;
+                const float* zk = zs + kq2 * K2;
+#pragma unroll
+                for (int k = 0; k < K2; ++k) a2 += w2[k] * zk[k];
+                a2 = wn_reduce<T2>(a2);
+                if (kq2 == 0) {
+                    float v = a2 + bres;
+                    if (c == 0) v += xb[row2];
+                    wn_publish(p.gx + ((size_t)cx.w * ns + s) * R + row2, tag, v);
+                }
+            }
+            // ---- 4. skip 1x1 partial on this lane of the running skip sum          (wavenet_model.py:154-162)
+            wn_u64* gs = p.gs + ((size_t)cx.w * ns + s) * S;
+            if (!prime) {
+#pragma unroll
+                for (int q = 0; q < RS; ++q) {
+                    const int row = tid + 256 * q;
+                    float a3 = bskip[q];
+#pragma unroll
+                    for (int k = 0; k < DC; ++k) a3 += w3[q][k] * zs[k];
+                    if (l > 0)
+                        a3 += wn_poll_sum<1>(cx, p.gs + (((size_t)(l - 1) * P + c) * ns + s) * S + row, 0, 1, tag, WN_W_SKIN, e, s);
+                    wn_publish(gs + row, tag, a3);
+                }
+            } else if (l == NL - 1) {
+#pragma unroll
+                for (int q = 0; q < RS; ++q) wn_publish(gs + tid + 256 * q, tag, 0.f);
+            }
+            // ---- 5. queue push (wavenet_modules.py:55-57) and the next step's tap 0 on x[t+1-d]
+            {
+                float* ring = p.rings + p.ring_off[l] + ((size_t)c * ns + s) * (size_t)ML * R;
+                if (tid < R) ring[(size_t)(t % ML) * R + tid] = xb[tid];
+                float a0 = kq1 == 0 ? bfg : 0.f;
+                if (d == 1) {
+                    const float* xk = xb + kq1 * K1;
+#pragma unroll
+                    for (int k = 0; k < K1; ++k) a0 += w0[k] * xk[k];
+                } else {
+                    long long pos = (t + 1 - d) % ML;
+                    if (pos < 0) pos += ML;
+                    const float* xo = ring + (size_t)pos * R + kq1 * K1;
+#pragma unroll
+                    for (int k = 0; k < K1; ++k) a0 += w0[k] * xo[k];
+                }
+                pre[s * 256 + tid] = a0;
+            }
+        }
+    }
+}
+
+template <class SH>
+static __device__ void wn_v2_head(const WnPlan& p, const WnRun& r, WnCtx& cx, float* lds, int h) {
+    constexpr int S = SH::S, EC = SH::EC, T3 = SH::T3, K3 = SH::K3;
+    using L = WnV2Lds<SH>;
+    const int tid = threadIdx.x, ns = p.n_streams, P = p.P, NL = p.NL;
+    float w4[K3], w5[EC];
+    const float* img = p.blobs + (size_t)NL * P * (SH::NWL * 256) + (size_t)h * (SH::NWH * 256) + tid;
+#pragma unroll
+    for (int k = 0; k < K3; ++k) w4[k] = img[(size_t)k * 256];
+#pragma unroll
+    for (int k = 0; k < EC; ++k) w5[k] = img[(size_t)(K3 + k) * 256];
+    const float b1 = img[(size_t)(K3 + EC) * 256], b2 = img[(size_t)(K3 + EC + 1) * 256];
+    const int kq3 = tid % T3, row3 = tid / T3;
+    float* sk = lds + L::sk;
+    float* ev = lds + L::ev;
+    for (long long e = 0; e < r.n_eval; ++e) {
+        const bool prime = e < r.n_given - 1;
+        const uint32_t tag = (uint32_t)(e + 1);
+        for (int s = 0; s < ns; ++s) {
+            cx.t_start = (long long)wall_clock64();
+#pragma unroll
+            for (int q = 0; q < S / 256; ++q) {
+                const int i = tid + 256 * q;
+                const float v = wn_poll_sum<8>(cx, p.gs + (((size_t)(NL - 1) * P) * ns + s) * S + i, (size_t)ns * S, P, tag, WN_W_HEAD, e, s);
+                sk[i] = v > 0.f ? v : 0.f;  // relu(skip)  wavenet_model.py:167
+            }
+            if (__syncthreads_or(cx.fail)) return;
+            wn_u64* gl = p.gl + ((size_t)h * ns + s) * 256;
+            if (!prime) {
+                float a = 0.f;
+                const float* sp = sk + kq3 * K3;
+#pragma unroll
+                for (int k = 0; k < K3; ++k) a += w4[k] * sp[k];
+                a = wn_reduce<T3>(a);
+                if (kq3 == 0) {
+                    const float v = a + b1;
+                    ev[row3] = v > 0.f ? v : 0.f;  // relu(end_conv_1)  :168
+                }
+                __syncthreads();
+                float o = b2;
+#pragma unroll
+                for (int k = 0; k < EC; ++k) o += w5[k] * ev[k];
+                wn_publish(gl + tid, tag, o);  // partial end_conv_2  :169
+            } else {
+                wn_publish(gl + tid, tag, 0.f);
+            }
+            __syncthreads();
+        }
+    }
+}
+
+template <int R, int DC, int S, int EC>
+__global__ __launch_bounds__(WN_THREADS) void wn_generate_kernel_v2(WnPlan p, WnRun r) {
+    using SH = WnV2Shape<R, DC, S, EC>;
+    extern __shared__ __attribute__((aligned(16))) float wn_lds2[];
+    const int w = p.wg_map[blockIdx.x];
+    WnCtx cx;
+    cx.p = &p; cx.r = &r; cx.lds = wn_lds2; cx.w = w; cx.fail = 0;
+    cx.t_start = (long long)wall_clock64();
+    const int n_layer_wg = p.NL * p.P;
+    if (w < n_layer_wg) wn_v2_layer<SH>(p, r, cx, wn_lds2, w / p.P, w % p.P);
+    else wn_v2_head<SH>(p, r, cx, wn_lds2, w - n_layer_wg);
+}
+
+#endif  // !WN_EMU
+#endif  // WN_KERNEL_V2_H

@@ -17,6 +17,7 @@
 
 #include "../../include/wn_abi.h"
 #include "wn_kernel.h"
+#include "wn_kernel_v2.h"
 
 static thread_local char g_err[512] = "";
 
@@ -71,14 +72,123 @@ __global__ __launch_bounds__(WN_THREADS) void wn_generate_kernel(WnPlan p, WnRun
         const int l = w / p.P, c = w % p.P;
         const long long n_it = r.n_eval + (l == 0 ? 1 : 0);  // L0 runs one sample-only iteration at the end
         for (long long e = 0; e < n_it; ++e)
-            for (int s = 0; s < p.n_streams; ++s)
+            for (int s = 0; s < p.n_streams; ++s) {
+                cx.t_start = (long long)wall_clock64();  // the spin bound is per hand-off wait, not per job
                 if (!wn_layer_item(cx, l, c, e, s)) return;
+            }
     } else {
         const int h = w - n_layer_wg;
         for (long long e = 0; e < r.n_eval; ++e)
-            for (int s = 0; s < p.n_streams; ++s)
+            for (int s = 0; s < p.n_streams; ++s) {
+                cx.t_start = (long long)wall_clock64();
                 if (!wn_head_item(cx, h, e, s)) return;
+            }
     }
+}
+#endif
+
+
+#ifndef WN_EMU
+// ------------------------------------------------------------------------------------------------ v2 (register-resident) variants
+// Shapes the latency-optimised kernel is instantiated for: (R, D/P, S, E/PA).  Anything else runs on the generic
+// LDS-resident kernel above.
+struct WnV2Entry {
+    int R, DC, S, EC, nwl, nwh;
+    const void* fn;
+    int (*lds_floats)(int);
+    void (*launch)(int grid, size_t lds, hipStream_t st, const WnPlan& p, const WnRun& r);
+    void (*pack)(const WnPlan& pl, const WnHostWeights& w, std::vector<float>& out);
+};
+
+template <class SH>
+static void wn_pack_v2(const WnPlan& pl, const WnHostWeights& w, std::vector<float>& out) {
+    constexpr int R = SH::R, DC = SH::DC, S = SH::S, EC = SH::EC, T1 = SH::T1, K1 = SH::K1, T2 = SH::T2, K2 = SH::K2, RS = SH::RS,
+                  T3 = SH::T3, K3 = SH::K3;
+    const int D = pl.D, E = pl.E, C = pl.C, P = pl.P, NL = pl.NL;
+    out.assign((size_t)NL * P * SH::NWL * 256 + (size_t)pl.PA * SH::NWH * 256, 0.f);
+    for (int l = 0; l < NL; ++l)
+        for (int c = 0; c < P; ++c) {
+            float* img = out.data() + ((size_t)l * P + c) * SH::NWL * 256;
+            const float* fw = w.filter_w + (size_t)l * D * R * 2;
+            const float* gw = w.gate_w + (size_t)l * D * R * 2;
+            const float* rw = w.res_w + (size_t)l * R * D;
+            const float* sw = w.skip_w + (size_t)l * S * D;
+            for (int tid = 0; tid < 256; ++tid) {
+                int j = 0;
+                const int kq1 = tid % T1, grp = tid / T1, ch = c * DC + (grp >> 1), gate = grp & 1;
+                const float* cw = gate ? gw : fw;
+                for (int k = 0; k < K1; ++k) img[(size_t)(j++) * 256 + tid] = cw[((size_t)ch * R + kq1 * K1 + k) * 2 + 1];  // tap 1: x[t]
+                for (int k = 0; k < K1; ++k) img[(size_t)(j++) * 256 + tid] = cw[((size_t)ch * R + kq1 * K1 + k) * 2 + 0];  // tap 0: x[t-d]
+                const int kq2 = tid % T2, row2 = tid / T2;
+                for (int k = 0; k < K2; ++k) img[(size_t)(j++) * 256 + tid] = rw[(size_t)row2 * D + c * DC + kq2 * K2 + k];
+                for (int q = 0; q < RS; ++q)
+                    for (int k = 0; k < DC; ++k) img[(size_t)(j++) * 256 + tid] = sw[(size_t)(tid + 256 * q) * D + c * DC + k];
+                float bfg = 0.f, bres = 0.f;
+                if (pl.has_bias) {
+                    if (kq1 == 0) bfg = (gate ? w.gate_b : w.filter_b)[(size_t)l * D + ch];
+                    if (c == 0 && kq2 == 0) bres = w.res_b[(size_t)l * R + row2];
+                }
+                img[(size_t)(j++) * 256 + tid] = bfg;
+                img[(size_t)(j++) * 256 + tid] = bres;
+                for (int q = 0; q < RS; ++q)
+                    img[(size_t)(j++) * 256 + tid] = (pl.has_bias && c == 0) ? w.skip_b[(size_t)l * S + tid + 256 * q] : 0.f;
+            }
+        }
+    for (int h = 0; h < pl.PA; ++h) {
+        float* img = out.data() + (size_t)NL * P * SH::NWL * 256 + (size_t)h * SH::NWH * 256;
+        for (int tid = 0; tid < 256; ++tid) {
+            const int kq3 = tid % T3, row3 = tid / T3, e = h * EC + row3;
+            int j = 0;
+            for (int k = 0; k < K3; ++k) img[(size_t)(j++) * 256 + tid] = w.end1_w[(size_t)e * S + kq3 * K3 + k];
+            for (int k = 0; k < EC; ++k) img[(size_t)(j++) * 256 + tid] = w.end2_w[(size_t)tid * E + h * EC + k];
+            img[(size_t)(j++) * 256 + tid] = kq3 == 0 ? w.end1_b[e] : 0.f;
+            img[(size_t)(j++) * 256 + tid] = h == 0 ? w.end2_b[tid] : 0.f;
+        }
+    }
+    (void)C;
+}
+
+template <int R, int DC, int S, int EC>
+static WnV2Entry wn_v2_entry() {
+    using SH = WnV2Shape<R, DC, S, EC>;
+    WnV2Entry e;
+    e.R = R; e.DC = DC; e.S = S; e.EC = EC; e.nwl = SH::NWL; e.nwh = SH::NWH;
+    e.fn = (const void*)wn_generate_kernel_v2<R, DC, S, EC>;
+    e.lds_floats = [](int ns) { return WnV2Lds<SH>::floats(ns); };
+    e.launch = [](int grid, size_t lds, hipStream_t st, const WnPlan& p, const WnRun& r) {
+        hipLaunchKernelGGL((wn_generate_kernel_v2<R, DC, S, EC>), dim3(grid), dim3(WN_THREADS), lds, st, p, r);
+    };
+    e.pack = wn_pack_v2<SH>;
+    return e;
+}
+
+static const std::vector<WnV2Entry>& wn_v2_table() {
+    static const std::vector<WnV2Entry> t = {
+        wn_v2_entry<128, 32, 512, 64>(),   // cfg3: P=4, PA=4
+        wn_v2_entry<64, 64, 256, 64>(),    // cfg2: P=1, PA=4
+        wn_v2_entry<32, 32, 256, 64>(),    // cfg1: P=1, PA=4
+        wn_v2_entry<32, 32, 1024, 32>(),   // train_script.py chaconne shape: P=1, PA=16
+        wn_v2_entry<64, 32, 256, 64>(),    // cfg2 split in two
+        wn_v2_entry<16, 16, 256, 32>(),    // small test shape
+    };
+    return t;
+}
+
+// picks an instantiated shape for this model; returns its index or -1
+static int wn_v2_choose(const WnPlan& pl, int n_cu, int forced_P, int forced_PA, int* outP, int* outPA) {
+    if (pl.k != 2 || pl.C != 256) return -1;
+    const std::vector<WnV2Entry>& t = wn_v2_table();
+    for (size_t i = 0; i < t.size(); ++i) {
+        const WnV2Entry& e = t[i];
+        if (e.R != pl.R || e.S != pl.S || pl.D % e.DC || pl.E % e.EC) continue;
+        const int P = pl.D / e.DC, PA = pl.E / e.EC;
+        if (P > 8 || PA > 16) continue;
+        if ((forced_P > 0 && forced_P != P) || (forced_PA > 0 && forced_PA != PA)) continue;
+        if (pl.NL * P + PA > n_cu) continue;
+        *outP = P; *outPA = PA;
+        return (int)i;
+    }
+    return -1;
 }
 #endif
 
@@ -91,6 +201,9 @@ struct wn_handle {
     void* last_stream;
     long long t_base;  // evaluations since the last reset
     int n_cu, wall_khz;
+    int variant;   // 1 = generic LDS-resident kernel, 2 = register-resident kernel
+    int v2_index;  // row of wn_v2_table()
+    int lds_bytes;
     // owned device allocations
     float *d_blobs, *d_start_t, *d_start_b, *d_rings;
     int32_t *d_dil, *d_wg_map;
@@ -156,10 +269,27 @@ extern "C" int wn_create(const wn_config* cfg, wn_handle** out) {
     pl.layers = cfg->layers; pl.blocks = cfg->blocks; pl.NL = cfg->layers * cfg->blocks;
     pl.R = cfg->residual_channels; pl.D = cfg->dilation_channels; pl.S = cfg->skip_channels; pl.E = cfg->end_channels;
     pl.C = cfg->classes; pl.k = cfg->kernel_size; pl.has_bias = cfg->bias ? 1 : 0; pl.n_streams = cfg->n_streams;
-    const std::string why = wn_plan_choose(pl, n_cu, cfg->layer_split, cfg->head_split);
-    if (!why.empty()) {
-        delete h;
-        return wn_fail(WN_E_UNSUPPORTED, "wn_create: %s", why.c_str());
+    h->variant = 1; h->v2_index = -1;
+#ifndef WN_EMU
+    {
+        const char* force = getenv("WN_KERNEL");  // "generic" pins the LDS-resident kernel (A/B runs, tests)
+        int P2 = 0, PA2 = 0;
+        const int vi = (force && !strcmp(force, "generic")) ? -1 : wn_v2_choose(pl, n_cu, cfg->layer_split, cfg->head_split, &P2, &PA2);
+        if (vi >= 0) {
+            h->variant = 2; h->v2_index = vi;
+            wn_plan_geometry(pl, P2, PA2);  // fills P, PA, Dc, Ec, n_wg (the LDS-image fields are unused by v2)
+            h->lds_bytes = wn_v2_table()[vi].lds_floats(pl.n_streams) * 4;
+            if (h->lds_bytes > WN_LDS_MAX_BYTES) { h->variant = 1; h->v2_index = -1; }
+        }
+    }
+#endif
+    if (h->variant == 1) {
+        const std::string why = wn_plan_choose(pl, n_cu, cfg->layer_split, cfg->head_split);
+        if (!why.empty()) {
+            delete h;
+            return wn_fail(WN_E_UNSUPPORTED, "wn_create: %s", why.c_str());
+        }
+        h->lds_bytes = pl.lds_floats * 4;
     }
     // tables
     h->dil.resize(pl.NL); h->ring_off.resize(pl.NL);
@@ -178,6 +308,12 @@ extern "C" int wn_create(const wn_config* cfg, wn_handle** out) {
     const size_t gx_n = n_lw * pl.n_streams * pl.R, gs_n = n_lw * pl.n_streams * pl.S, gl_n = (size_t)pl.PA * pl.n_streams * pl.C;
     h->gran_count = gx_n + gs_n + gl_n;
     h->blob_floats = n_lw * pl.blob_layer_floats + (size_t)pl.PA * pl.blob_head_floats;
+#ifndef WN_EMU
+    if (h->variant == 2) {
+        const WnV2Entry& ve = wn_v2_table()[h->v2_index];
+        h->blob_floats = n_lw * (size_t)ve.nwl * 256 + (size_t)pl.PA * ve.nwh * 256;
+    }
+#endif
     h->d_blobs = (float*)rt_malloc(h->blob_floats * 4);
     h->d_start_t = (float*)rt_malloc((size_t)pl.C * pl.R * 4);
     h->d_start_b = (float*)rt_malloc((size_t)pl.R * 4);
@@ -206,7 +342,8 @@ extern "C" int wn_create(const wn_config* cfg, wn_handle** out) {
     pl.gx = h->d_gran; pl.gs = h->d_gran + gx_n; pl.gl = h->d_gran + gx_n + gs_n;
     pl.status = h->d_status;
 #ifndef WN_EMU
-    rc = rt_hip(hipFuncSetAttribute((const void*)wn_generate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, pl.lds_floats * 4),
+    rc = rt_hip(hipFuncSetAttribute(h->variant == 2 ? wn_v2_table()[h->v2_index].fn : (const void*)wn_generate_kernel,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes),
                 "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
     if (rc) { wn_destroy(h); return rc; }
 #endif
@@ -229,7 +366,11 @@ extern "C" int wn_load_weights(wn_handle* h, const wn_weight_ptrs* w) {
     WnHostWeights hw = {w->start_w, w->start_b, w->filter_w, w->filter_b, w->gate_w, w->gate_b, w->res_w,
                         w->res_b, w->skip_w, w->skip_b, w->end1_w, w->end1_b, w->end2_w, w->end2_b};
     std::vector<float> blobs;
-    wn_pack_blobs(pl, hw, blobs);
+#ifndef WN_EMU
+    if (h->variant == 2) wn_v2_table()[h->v2_index].pack(pl, hw, blobs);
+    else
+#endif
+        wn_pack_blobs(pl, hw, blobs);
     if (blobs.size() != h->blob_floats) return wn_fail(WN_E_STATE, "wn_load_weights: internal blob size mismatch");
     std::vector<float> st((size_t)pl.C * pl.R);
     for (int r = 0; r < pl.R; ++r)
@@ -319,8 +460,11 @@ extern "C" int wn_generate(wn_handle* h, const wn_generate_args* a) {
         wn_emu_run(h->plan, r, lds);
     }
 #else
-    hipLaunchKernelGGL(wn_generate_kernel, dim3(h->plan.n_wg), dim3(WN_THREADS), (size_t)h->plan.lds_floats * 4,
-                       (hipStream_t)a->hip_stream, h->plan, r);
+    if (h->variant == 2)
+        wn_v2_table()[h->v2_index].launch(h->plan.n_wg, (size_t)h->lds_bytes, (hipStream_t)a->hip_stream, h->plan, r);
+    else
+        hipLaunchKernelGGL(wn_generate_kernel, dim3(h->plan.n_wg), dim3(WN_THREADS), (size_t)h->lds_bytes,
+                           (hipStream_t)a->hip_stream, h->plan, r);
     rc = rt_hip(hipGetLastError(), "launch wn_generate_kernel");
     if (rc) return rc;
 #endif
@@ -356,7 +500,7 @@ extern "C" int wn_get_info(wn_handle* h, wn_info* out) {
     memset(out, 0, sizeof(*out));
     out->abi_version = WN_ABI_VERSION;
     out->n_layers = pl.NL; out->layer_split = pl.P; out->head_split = pl.PA; out->n_workgroups = pl.n_wg;
-    out->lds_bytes = pl.lds_floats * 4; out->n_compute_units = h->n_cu;
+    out->lds_bytes = h->lds_bytes; out->n_compute_units = h->n_cu; out->kernel_variant = h->variant;
     out->receptive_field = 1 + pl.blocks * (pl.k - 1) * ((1 << pl.layers) - 1);
     out->weight_bytes = (int64_t)h->blob_floats * 4 + (int64_t)pl.C * pl.R * 4;
     out->queue_bytes = (int64_t)h->ring_floats * 4;

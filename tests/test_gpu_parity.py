@@ -36,6 +36,37 @@ def test_library_is_the_hip_build():
     assert "gfx950" in torch.cuda.get_device_properties(0).gcnArchName
 
 
+V2A = dict(layers=3, blocks=2, dilation_channels=16, residual_channels=16, skip_channels=256, end_channels=32,
+           classes=256, kernel_size=2, bias=True)     # v2 shape <16,16,256,32>: P=1, PA=1 (K1=2, K2=1 corner)
+V2B = dict(layers=4, blocks=2, dilation_channels=32, residual_channels=16, skip_channels=256, end_channels=64,
+           classes=256, kernel_size=2, bias=True)     # same shape, P=2 lanes, PA=2
+V2C = dict(synth.CONFIGS["cfg1"], bias=True)
+V2 = [("v2a", V2A, 1, 200, 20), ("v2a_ns3", V2A, 3, 120, 9), ("v2b_ns2", V2B, 2, 150, 30), ("v2c_bias", V2C, 2, 150, 40)]
+
+
+@pytest.mark.parametrize("label,cfg,ns,N,n_given", V2, ids=[c[0] for c in V2])
+def test_register_resident_kernel_shapes(label, cfg, ns, N, n_given):
+    cfg, W, first, uniforms = make_case(cfg, 57, ns, n_given, N)
+    eng = engine.Engine(cfg, W, n_streams=ns)
+    assert eng.info()["kernel_variant"] == 2
+    g = check_engine(eng, cfg, W, N, first, 0.0, 0.0, None, label + " greedy")
+    s = check_engine(eng, cfg, W, N, first, 0.8, 0.002, uniforms, label + " sampled")
+    print(label, g, s, eng.info())
+    eng.close()
+
+
+@pytest.mark.parametrize("cfgname,ns,N,n_given", [("cfg1", 2, 200, 70), ("cfg2", 1, 100, 30), ("cfg3", 2, 60, 10)])
+def test_generic_kernel_on_baseline_configs(cfgname, ns, N, n_given, monkeypatch):
+    """The LDS-resident generic kernel (the fallback for shapes the register kernel is not instantiated for)."""
+    monkeypatch.setenv("WN_KERNEL", "generic")
+    cfg, W, first, uniforms = make_case(cfgname, 58, ns, n_given, N)
+    eng = engine.Engine(cfg, W, n_streams=ns)
+    assert eng.info()["kernel_variant"] == 1
+    check_engine(eng, cfg, W, N, first, 0.0, 0.0, None, cfgname + " generic greedy")
+    check_engine(eng, cfg, W, N, first, 1.0, 0.0, uniforms, cfgname + " generic sampled")
+    eng.close()
+
+
 @pytest.mark.parametrize("label,cfgname,kw,ns,N,n_given", SMALL, ids=[c[0] for c in SMALL])
 def test_small_configs(label, cfgname, kw, ns, N, n_given):
     cfg, W, first, uniforms = make_case(cfgname, 51, ns, n_given, N)
@@ -54,6 +85,7 @@ BIG = [("cfg2", "cfg2", 1, 150, 64), ("cfg2_ns4", "cfg2", 4, 60, 8), ("cfg3", "c
 def test_baseline_configs(label, cfgname, ns, N, n_given):
     cfg, W, first, uniforms = make_case(cfgname, 52, ns, n_given, N)
     eng = engine.Engine(cfg, W, n_streams=ns)
+    assert eng.info()["kernel_variant"] == 2
     g = check_engine(eng, cfg, W, N, first, 0.0, 0.0, None, label + " greedy")
     s = check_engine(eng, cfg, W, N, first, 1.0, 0.0, uniforms, label + " sampled")
     print(label, "greedy", g, "sampled", s, eng.info())
