@@ -147,6 +147,12 @@ int wn_get_info(wn_handle* h, wn_info* out);
  * (wavenet_modules.py:43-57).  For tests and for facade code that inspects model.dilated_queues. */
 int wn_export_queue(wn_handle* h, int32_t layer, int32_t stream, float* host_data, int32_t* in_pos, int32_t* out_pos);
 
+/* Diagnostics: record wall-clock stamps (100 MHz ticks) for the first n_items (evaluation, stream) steps of every
+ * workgroup during the NEXT wn_generate: 4 per step -- start, input staged, x' published, done -- then read them
+ * back as int64 [n_workgroups][n_items][4] (chain order).  Used by tools/profile_chain.py. */
+int wn_profile_next(wn_handle* h, int32_t n_items);
+int wn_profile_read(wn_handle* h, int64_t* host_out, int64_t capacity);
+
 /* Thread-local message for the most recent failing call on this thread ("" if none). */
 const char* wn_last_error(void);
 

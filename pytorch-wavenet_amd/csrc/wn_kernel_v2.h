@@ -97,6 +97,11 @@ static __device__ __forceinline__ float wn_poll_sum(WnCtx& cx, const wn_u64* bas
     }
 }
 
+// diagnostics: wall-clock stamp k (0 item start, 1 input staged, 2 x' published, 3 item done) of this workgroup
+static __device__ __forceinline__ void wn_stamp(const WnRun& r, int w, long long item, int k) {
+    if (r.prof && item < r.prof_items && threadIdx.x == 0) r.prof[((size_t)w * r.prof_items + item) * 4 + k] = (long long)wall_clock64();
+}
+
 // LDS layout (floats) of the v2 kernel
 template <class SH>
 struct WnV2Lds {
@@ -225,6 +230,8 @@ static __device__ void wn_v2_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
         for (int s = 0; s < ns; ++s, buf ^= 1) {
             float* xb = xs + buf * R;
             cx.t_start = (long long)wall_clock64();  // the spin bound is per hand-off wait, not per job
+            const long long item = e * ns + s;
+            wn_stamp(r, cx.w, item, 0);
             // ---- 1. layer input x[t]
             if (l == 0) {
                 int idx;
@@ -255,6 +262,7 @@ static __device__ void wn_v2_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
                 }
                 if (__syncthreads_or(cx.fail)) return;
             }
+            wn_stamp(r, cx.w, item, 1);
             // ---- 2. filter/gate: tap 1 on x[t] + parked tap 0, tanh * sigmoid   (wavenet_model.py:147-151)
             float acc = pre[s * 256 + tid];
             {
@@ -281,6 +289,7 @@ static __device__ void wn_v2_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
                     wn_publish(p.gx + ((size_t)cx.w * ns + s) * R + row2, tag, v);
                 }
             }
+            wn_stamp(r, cx.w, item, 2);
             // ---- 4. skip 1x1 partial on this lane of the running skip sum          (wavenet_model.py:154-162)
             wn_u64* gs = p.gs + ((size_t)cx.w * ns + s) * S;
             if (!prime) {
@@ -316,6 +325,7 @@ static __device__ void wn_v2_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
                 }
                 pre[s * 256 + tid] = a0;
             }
+            wn_stamp(r, cx.w, item, 3);
         }
     }
 }
@@ -340,6 +350,8 @@ static __device__ void wn_v2_head(const WnPlan& p, const WnRun& r, WnCtx& cx, fl
         const uint32_t tag = (uint32_t)(e + 1);
         for (int s = 0; s < ns; ++s) {
             cx.t_start = (long long)wall_clock64();
+            const long long item = e * ns + s;
+            wn_stamp(r, cx.w, item, 0);
 #pragma unroll
             for (int q = 0; q < S / 256; ++q) {
                 const int i = tid + 256 * q;
@@ -347,6 +359,7 @@ static __device__ void wn_v2_head(const WnPlan& p, const WnRun& r, WnCtx& cx, fl
                 sk[i] = v > 0.f ? v : 0.f;  // relu(skip)  wavenet_model.py:167
             }
             if (__syncthreads_or(cx.fail)) return;
+            wn_stamp(r, cx.w, item, 1);
             wn_u64* gl = p.gl + ((size_t)h * ns + s) * 256;
             if (!prime) {
                 float a = 0.f;
@@ -366,7 +379,9 @@ static __device__ void wn_v2_head(const WnPlan& p, const WnRun& r, WnCtx& cx, fl
             } else {
                 wn_publish(gl + tid, tag, 0.f);
             }
+            wn_stamp(r, cx.w, item, 2);
             __syncthreads();
+            wn_stamp(r, cx.w, item, 3);
         }
     }
 }

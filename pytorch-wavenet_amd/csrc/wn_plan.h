@@ -83,6 +83,9 @@ struct WnRun {
     int32_t* out_idx;
     float* dbg_logits;
     int64_t timeout_ticks;  // wall_clock64 ticks
+    long long* prof;        // optional [n_wg][prof_items][4] wall-clock stamps (diagnostics), or NULL
+    int32_t prof_items;
+    int32_t pad;
 };
 
 // ---- host-side planner / packer (plain C++; also parsed, unused, in the device pass) ----

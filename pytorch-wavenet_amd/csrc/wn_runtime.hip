@@ -211,6 +211,9 @@ struct wn_handle {
     wn_u64* d_gran;
     uint32_t* d_status;
     size_t blob_floats, ring_floats, gran_count;
+    long long* d_prof;
+    int prof_items;      // stamps requested for the next job (0 = off)
+    int prof_recorded;   // stamps held in d_prof
     std::vector<int64_t> ring_off;
     std::vector<int32_t> dil;
 };
@@ -225,7 +228,7 @@ extern "C" void wn_destroy(wn_handle* h) {
     if (h->pending) (void)hipStreamSynchronize((hipStream_t)h->last_stream);
 #endif
     rt_free(h->d_blobs); rt_free(h->d_start_t); rt_free(h->d_start_b); rt_free(h->d_rings); rt_free(h->d_dil);
-    rt_free(h->d_wg_map); rt_free(h->d_ring_off); rt_free(h->d_gran); rt_free(h->d_status);
+    rt_free(h->d_wg_map); rt_free(h->d_ring_off); rt_free(h->d_gran); rt_free(h->d_status); rt_free(h->d_prof);
     delete h;
 }
 
@@ -265,6 +268,7 @@ extern "C" int wn_create(const wn_config* cfg, wn_handle** out) {
     h->n_cu = n_cu; h->wall_khz = wall_khz;
     h->d_blobs = h->d_start_t = h->d_start_b = h->d_rings = nullptr;
     h->d_dil = h->d_wg_map = nullptr; h->d_ring_off = nullptr; h->d_gran = nullptr; h->d_status = nullptr;
+    h->d_prof = nullptr; h->prof_items = 0; h->prof_recorded = 0;
     WnPlan& pl = h->plan;
     pl.layers = cfg->layers; pl.blocks = cfg->blocks; pl.NL = cfg->layers * cfg->blocks;
     pl.R = cfg->residual_channels; pl.D = cfg->dilation_channels; pl.S = cfg->skip_channels; pl.E = cfg->end_channels;
@@ -449,6 +453,17 @@ extern "C" int wn_generate(wn_handle* h, const wn_generate_args* a) {
     r.uniforms = a->uniforms; r.out_idx = a->out_idx; r.dbg_logits = a->dbg_logits;
     const long long ms = a->timeout_ms > 0 ? a->timeout_ms : 10000;
     r.timeout_ticks = ms * (long long)h->wall_khz;
+    if (h->prof_items > 0) {
+        rt_free(h->d_prof);
+        const size_t nb = (size_t)h->plan.n_wg * h->prof_items * 4 * sizeof(long long);
+        h->d_prof = (long long*)rt_malloc(nb);
+        if (!h->d_prof) return wn_fail(WN_E_NOMEM, "wn_generate: profile buffer");
+        int prc = rt_memset_async(h->d_prof, 0, nb, a->hip_stream);
+        if (prc) return prc;
+        r.prof = h->d_prof; r.prof_items = h->prof_items;
+        h->prof_recorded = h->prof_items;
+        h->prof_items = 0;
+    }
     // hand-off words restart at tag 1 every call: zero them (and the status word) ahead of the launch
     int rc = rt_memset_async(h->d_gran, 0, h->gran_count * 8, a->hip_stream);
     rc = rc ? rc : rt_memset_async(h->d_status, 0, 32, a->hip_stream);
@@ -529,4 +544,20 @@ extern "C" int wn_export_queue(wn_handle* h, int32_t layer, int32_t stream, floa
     if (in_pos) *in_pos = (int32_t)(h->t_base % ML);  // one enqueue + one dequeue per evaluation
     if (out_pos) *out_pos = (int32_t)(h->t_base % ML);
     return WN_OK;
+}
+
+// Diagnostics (not part of the reference surface): wall-clock stamps of the first n_items (eval, stream) steps of
+// every workgroup of the NEXT wn_generate, 4 stamps each (start, input staged, x' published, done), 100 MHz ticks.
+extern "C" int wn_profile_next(wn_handle* h, int32_t n_items) {
+    if (!h || n_items < 0) return wn_fail(WN_E_BADARG, "wn_profile_next: bad argument");
+    h->prof_items = n_items;
+    return WN_OK;
+}
+
+extern "C" int wn_profile_read(wn_handle* h, int64_t* host_out, int64_t capacity) {
+    if (!h || !host_out) return wn_fail(WN_E_BADARG, "wn_profile_read: NULL argument");
+    if (h->pending) { int rc = wn_wait(h); if (rc) return rc; }
+    const int64_t n = (int64_t)h->plan.n_wg * h->prof_recorded * 4;
+    if (!h->d_prof || n == 0 || capacity < n) return wn_fail(WN_E_STATE, "wn_profile_read: nothing recorded / buffer too small (%lld)", (long long)n);
+    return rt_d2h(host_out, h->d_prof, (size_t)n * 8);
 }

@@ -143,6 +143,16 @@ class Engine:
         self.lib.check(self.lib.dll.wn_export_queue(self._h, layer, stream, data.ctypes.data, ctypes.byref(ip), ctypes.byref(op)))
         return data, ip.value, op.value
 
+    def profile_next(self, n_items):
+        self.lib.check(self.lib.dll.wn_profile_next(self._h, int(n_items)))
+
+    def profile_read(self, n_items):
+        """int64 (n_workgroups, n_items, 4) wall-clock stamps (100 MHz ticks) of the last profiled job."""
+        n_wg = self.info()["n_workgroups"]
+        out = np.zeros((n_wg, n_items, 4), dtype=np.int64)
+        self.lib.check(self.lib.dll.wn_profile_read(self._h, out.ctypes.data, out.size))
+        return out
+
     def launch(self, first_dev, n_given, num_samples, temperature, reg_dev, uni_dev, out_dev, logits_dev, timeout_ms=0):
         """Enqueue one job on the current stream (asynchronous)."""
         a = _abi.wn_generate_args(self.mem.ptr(first_dev), n_given, num_samples, float(temperature), 0,

@@ -1,0 +1,62 @@
+"""Per-hop anatomy of the generation chain from in-kernel wall-clock stamps (wn_profile_next / wn_profile_read).
+
+    python tools/profile_chain.py [cfg3] [n_streams]
+
+Prints, per chain stage: hand-off latency (producer published -> consumer staged), critical compute
+(staged -> x' published), tail (published -> step done) and the loop period.  100 MHz stamps (10 ns).
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "pytorch-wavenet_amd"))
+import numpy as np  # noqa: E402
+
+from mi355_wavenet import engine, synth  # noqa: E402
+
+
+def main():
+    cfgname = sys.argv[1] if len(sys.argv) > 1 else "cfg3"
+    ns = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    cfg = synth.CONFIGS[cfgname]
+    W = synth.init_weights(cfg, seed=0)
+    eng = engine.Engine(cfg, W, n_streams=ns)
+    info = eng.info()
+    P, PA, NL = info["layer_split"], info["head_split"], info["n_layers"]
+    N = 400
+    items = N * ns
+    u = np.random.RandomState(0).random_sample((ns, N))
+    eng.generate(N, None, temperature=1.0, uniforms=u)  # warm-up
+    eng.profile_next(items)
+    eng.generate(N, None, temperature=1.0, uniforms=u)
+    st = eng.profile_read(items).astype(np.float64) * 0.01  # us
+    lo, hi = items // 4, items - ns  # steady state
+    T = st[:, lo:hi, :]
+    lay = T[:NL * P].reshape(NL, P, hi - lo, 4)
+    head = T[NL * P:]
+    period = np.diff(st[0, lo:hi:ns, 1]).mean() if ns == 1 else np.diff(st[0, lo:hi, 1][::ns]).mean()
+    print("%s x%d: variant %d P=%d PA=%d workgroups %d; loop period %.2f us/eval (%.0f evals/s per stream, %.0f samples/s total)" % (
+        cfgname, ns, info["kernel_variant"], P, PA, info["n_workgroups"], period, 1e6 / period, ns * 1e6 / period))
+    # layer hops
+    hop = lay[1:, :, :, 1] - lay[:-1, :, :, 2].max(axis=1)[:, None, :]   # staged(l,c) - max_cc published(l-1,cc)
+    crit = lay[:, :, :, 2] - lay[:, :, :, 1]
+    tail = lay[:, :, :, 3] - lay[:, :, :, 2]
+    wait = lay[:, :, :, 1] - lay[:, :, :, 0]
+    print("layer hand-off (published -> staged): mean %.3f us  p50 %.3f  p95 %.3f  [max over the %d lanes: %.3f]" % (
+        hop.mean(), np.median(hop), np.percentile(hop, 95), P, hop.max(axis=1).mean()))
+    print("layer critical compute (staged -> x' published): mean %.3f us (L0: %.3f)" % (crit[1:].mean(), crit[0].mean()))
+    print("layer tail (published -> done): mean %.3f us;  poll wait inside the step: %.3f us" % (tail.mean(), wait[1:].mean()))
+    per_layer = (lay[1:, :, :, 2].max(axis=1) - lay[:-1, :, :, 2].max(axis=1)).mean(axis=1)
+    print("published(l) - published(l-1): mean %.3f us; by layer %s" % (per_layer.mean(), np.array2string(per_layer, precision=2)))
+    # head: staged - last layer's done (skip lane is published inside the tail)
+    h_in = head[:, :, 1] - lay[-1, :, :, 2].max(axis=0)[None, :]
+    h_c = head[:, :, 2] - head[:, :, 1]
+    print("head: last layer x' published -> head staged %.3f us; head compute %.3f us" % (h_in.mean(), h_c.mean()))
+    # L0: staged(e+1) - head published(e)
+    l0 = lay[0, :, ns:, 1] - head[:, :-ns, 2].max(axis=0)[None, :]
+    print("L0: head published -> L0 input staged (logit hop + sampler + start_conv) %.3f us" % l0.mean())
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()
