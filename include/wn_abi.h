@@ -148,8 +148,8 @@ int wn_get_info(wn_handle* h, wn_info* out);
 int wn_export_queue(wn_handle* h, int32_t layer, int32_t stream, float* host_data, int32_t* in_pos, int32_t* out_pos);
 
 /* Diagnostics: record wall-clock stamps (100 MHz ticks) for the first n_items (evaluation, stream) steps of every
- * workgroup during the NEXT wn_generate: 4 per step -- start, input staged, x' published, done -- then read them
- * back as int64 [n_workgroups][n_items][4] (chain order).  Used by tools/profile_chain.py. */
+ * workgroup during the NEXT wn_generate: 8 slots per step -- 0 start, 1 input staged, 2 x' published, 3 done,
+ * 4 filter/gate sums ready, 5 z staged, 6-7 unused -- then read them back as int64 [n_workgroups][n_items][8].  Used by tools/profile_chain.py. */
 int wn_profile_next(wn_handle* h, int32_t n_items);
 int wn_profile_read(wn_handle* h, int64_t* host_out, int64_t capacity);
 

@@ -70,24 +70,24 @@ static __device__ __forceinline__ wn_u64 wn_ld_granule(const wn_u64* g) {
     return __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// Batched poll: loads n (<= NMAX) granules base[j*stride] together until every tag matches; returns their sum
-// in the fixed order j = 0..n-1.
-template <int NMAX>
-static __device__ __forceinline__ float wn_poll_sum(WnCtx& cx, const wn_u64* base, size_t stride, int n, uint32_t tag,
-                                                    int where, long long e, int s) {
+// Batched poll with a compile-time count: loads the N granules base[j*stride] together until every tag matches;
+// returns their sum in the fixed order j = 0..N-1.
+template <int N>
+static __device__ __forceinline__ float wn_poll_fixed(WnCtx& cx, const wn_u64* base, size_t stride, uint32_t tag, int where,
+                                                      long long e, int s) {
     if (cx.fail) return 0.f;
     unsigned spins = 0;
     for (;;) {
-        wn_u64 v[NMAX];
+        wn_u64 v[N];
 #pragma unroll
-        for (int j = 0; j < NMAX; ++j) v[j] = j < n ? wn_ld_granule(base + (size_t)j * stride) : ((wn_u64)tag << 32);
+        for (int j = 0; j < N; ++j) v[j] = wn_ld_granule(base + (size_t)j * stride);
         bool ok = true;
 #pragma unroll
-        for (int j = 0; j < NMAX; ++j) ok = ok && ((uint32_t)(v[j] >> 32) == tag);
+        for (int j = 0; j < N; ++j) ok = ok && ((uint32_t)(v[j] >> 32) == tag);
         if (ok) {
             float sum = 0.f;
 #pragma unroll
-            for (int j = 0; j < NMAX; ++j) sum += j < n ? __uint_as_float((uint32_t)v[j]) : 0.f;
+            for (int j = 0; j < N; ++j) sum += __uint_as_float((uint32_t)v[j]);
             return sum;
         }
         if ((++spins & 127u) == 0u) {
@@ -97,9 +97,30 @@ static __device__ __forceinline__ float wn_poll_sum(WnCtx& cx, const wn_u64* bas
     }
 }
 
-// diagnostics: wall-clock stamp k (0 item start, 1 input staged, 2 x' published, 3 item done) of this workgroup
+// n is block-uniform and small: dispatch to the unrolled form
+template <int NMAX>
+static __device__ __forceinline__ float wn_poll_sum(WnCtx& cx, const wn_u64* base, size_t stride, int n, uint32_t tag,
+                                                    int where, long long e, int s) {
+    switch (n) {
+        case 1: return wn_poll_fixed<1>(cx, base, stride, tag, where, e, s);
+        case 2: return wn_poll_fixed<2>(cx, base, stride, tag, where, e, s);
+        case 4: return wn_poll_fixed<4>(cx, base, stride, tag, where, e, s);
+        case 8: return wn_poll_fixed<(NMAX >= 8 ? 8 : 1)>(cx, base, stride, tag, where, e, s);
+        case 16: return wn_poll_fixed<(NMAX >= 16 ? 16 : 1)>(cx, base, stride, tag, where, e, s);
+        default: {
+            float sum = 0.f;  // odd fan-in: one granule at a time
+            for (int j = 0; j < n; ++j) sum += wn_poll_fixed<1>(cx, base + (size_t)j * stride, 0, tag, where, e, s);
+            return sum;
+        }
+    }
+}
+
+// diagnostics: wall-clock stamp k of this workgroup's step: 0 start, 1 input staged, 2 x' published, 3 done,
+// 4 filter/gate sums ready, 5 z staged
+#define WN_STAMPS 8
 static __device__ __forceinline__ void wn_stamp(const WnRun& r, int w, long long item, int k) {
-    if (r.prof && item < r.prof_items && threadIdx.x == 0) r.prof[((size_t)w * r.prof_items + item) * 4 + k] = (long long)wall_clock64();
+    if (r.prof && item < r.prof_items && threadIdx.x == 0)
+        r.prof[((size_t)w * r.prof_items + item) * WN_STAMPS + k] = (long long)wall_clock64();
 }
 
 // LDS layout (floats) of the v2 kernel
@@ -109,10 +130,25 @@ struct WnV2Lds {
     static constexpr int zs = xs + 2 * SH::R;            // [DC]
     static constexpr int sk = zs + ((SH::DC + 3) & ~3);  // [S]    head
     static constexpr int ev = sk + SH::S;                // [EC]   head
-    static constexpr int smp = ev + SH::EC;              // sampler scratch: 64 floats (8-byte aligned)
+    static constexpr int smp = ev + SH::EC;              // sampler scratch: 64 floats (8-byte aligned); [48] = fail flag
     static constexpr int pre = smp + 64;                 // [n_streams][256]
     static int floats(int n_streams) { return pre + n_streams * 256; }
 };
+
+// barrier that also tells every lane whether any lane gave up a wait (rare): one s_barrier, one LDS word
+static __device__ __forceinline__ bool wn_barrier_failed(WnCtx& cx, volatile int* flag) {
+    if (cx.fail) *flag = 1;
+    __syncthreads();
+    return *flag != 0;
+}
+
+// Idle workgroups must not hammer the fabric with polls while the token is far away: if the previous wait
+// for this stream was long, sleep through most of it before the first poll.
+static __device__ __forceinline__ void wn_presleep(long long wait_ticks) {
+    // 100 MHz ticks; s_sleep 32 ~ 2048 clocks ~ 1 us.  Sleep 3/4 of the previous wait beyond the first 4 us.
+    long long n = (wait_ticks - 400) * 3 / 400;
+    for (long long i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(32);
+}
 
 // ---- sampler (L0): C = 256 classes, one per lane.  Same arithmetic as wn_sample (wn_kernel.h) /
 // wavenet_model.py:280-294, with wave-level reductions.  Returns the class index (uniform over the block).
@@ -208,6 +244,8 @@ static __device__ void wn_v2_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
     float* zs = lds + L::zs;
     float* pre = lds + L::pre;
     float* smp = lds + L::smp;
+    volatile int* failflag = reinterpret_cast<volatile int*>(smp + 48);
+    if (tid == 0) *failflag = 0;
 
     // tap-0 contribution for the first evaluation of every stream: x[t_base - d] from the queue (zeros after reset)
     for (int s = 0; s < ns; ++s) {
@@ -223,13 +261,15 @@ static __device__ void wn_v2_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
 
     const long long n_it = r.n_eval + (l == 0 ? 1 : 0);
     int buf = 0;
+    long long last_wait = 0;
     for (long long e = 0; e < n_it; ++e) {
         const bool prime = e < r.n_given - 1;
         const uint32_t tag = (uint32_t)(e + 1);
         const long long t = r.t_base + e;
         for (int s = 0; s < ns; ++s, buf ^= 1) {
             float* xb = xs + buf * R;
-            cx.t_start = (long long)wall_clock64();  // the spin bound is per hand-off wait, not per job
+            const long long t_begin = (long long)wall_clock64();
+            cx.t_start = t_begin;  // the spin bound is per hand-off wait, not per job
             const long long item = e * ns + s;
             wn_stamp(r, cx.w, item, 0);
             // ---- 1. layer input x[t]
@@ -238,9 +278,11 @@ static __device__ void wn_v2_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
                 if (e == 0) {
                     idx = r.first[(size_t)s * r.n_given];
                 } else {
+                    if (ns == 1) wn_presleep(last_wait);
                     const float logit = wn_poll_sum<16>(cx, p.gl + (size_t)s * 256 + tid, (size_t)ns * 256, p.PA, (uint32_t)e,
                                                         WN_W_LOGITS, e, s);
-                    if (__syncthreads_or(cx.fail)) return;
+                    if (wn_barrier_failed(cx, failflag)) return;
+                    last_wait = (long long)wall_clock64() - t_begin;
                     if (e < r.n_given) {
                         idx = r.first[(size_t)s * r.n_given + e];
                     } else {
@@ -257,10 +299,12 @@ static __device__ void wn_v2_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
                 __syncthreads();
             } else {
                 if (tid < R) {
+                    if (ns == 1) wn_presleep(last_wait);
                     const wn_u64* g = p.gx + (((size_t)(l - 1) * P) * ns + s) * R + tid;
                     xb[tid] = wn_poll_sum<8>(cx, g, (size_t)ns * R, P, tag, WN_W_X, e, s);
+                    last_wait = (long long)wall_clock64() - t_begin;
                 }
-                if (__syncthreads_or(cx.fail)) return;
+                if (wn_barrier_failed(cx, failflag)) return;
             }
             wn_stamp(r, cx.w, item, 1);
             // ---- 2. filter/gate: tap 1 on x[t] + parked tap 0, tanh * sigmoid   (wavenet_model.py:147-151)
@@ -273,9 +317,11 @@ static __device__ void wn_v2_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
             acc = wn_reduce<T1>(acc);
             const float other = wn_partner<T1>(acc);  // the gate (resp. filter) row of the same channel
             const float fv = is_gate ? other : acc, gv = is_gate ? acc : other;
+            wn_stamp(r, cx.w, item, 4);
             const float z = tanhf(fv) * (1.0f / (1.0f + expf(-gv)));
             if (!is_gate && kq1 == 0) zs[ch] = z;
             __syncthreads();
+            wn_stamp(r, cx.w, item, 5);
             // ---- 3. residual 1x1 partial, published at once                      (wavenet_model.py:164-165)
             if (l < NL - 1) {
                 float a2 = 0.f;
@@ -293,15 +339,30 @@ static __device__ void wn_v2_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
             // ---- 4. skip 1x1 partial on this lane of the running skip sum          (wavenet_model.py:154-162)
             wn_u64* gs = p.gs + ((size_t)cx.w * ns + s) * S;
             if (!prime) {
+                const wn_u64* gin = p.gs + (((size_t)(l - 1) * P + c) * ns + s) * S + tid;  // only read when l > 0
+                wn_u64 sv[RS];
+                if (l > 0) {
+#pragma unroll
+                    for (int q = 0; q < RS; ++q) sv[q] = wn_ld_granule(gin + 256 * q);  // in flight during the FMAs
+                }
+                float a3[RS];
+#pragma unroll
+                for (int q = 0; q < RS; ++q) a3[q] = bskip[q];
+#pragma unroll
+                for (int k = 0; k < DC; ++k) {
+                    const float zk = zs[k];
+#pragma unroll
+                    for (int q = 0; q < RS; ++q) a3[q] += w3[q][k] * zk;
+                }
 #pragma unroll
                 for (int q = 0; q < RS; ++q) {
-                    const int row = tid + 256 * q;
-                    float a3 = bskip[q];
-#pragma unroll
-                    for (int k = 0; k < DC; ++k) a3 += w3[q][k] * zs[k];
-                    if (l > 0)
-                        a3 += wn_poll_sum<1>(cx, p.gs + (((size_t)(l - 1) * P + c) * ns + s) * S + row, 0, 1, tag, WN_W_SKIN, e, s);
-                    wn_publish(gs + row, tag, a3);
+                    if (l > 0) {
+                        float v;
+                        if ((uint32_t)(sv[q] >> 32) == tag) v = __uint_as_float((uint32_t)sv[q]);
+                        else v = wn_poll_fixed<1>(cx, gin + 256 * q, 0, tag, WN_W_SKIN, e, s);
+                        a3[q] += v;
+                    }
+                    wn_publish(gs + tid + 256 * q, tag, a3[q]);
                 }
             } else if (l == NL - 1) {
 #pragma unroll
@@ -332,7 +393,7 @@ static __device__ void wn_v2_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
 
 template <class SH>
 static __device__ void wn_v2_head(const WnPlan& p, const WnRun& r, WnCtx& cx, float* lds, int h) {
-    constexpr int S = SH::S, EC = SH::EC, T3 = SH::T3, K3 = SH::K3;
+    constexpr int S = SH::S, EC = SH::EC, T3 = SH::T3, K3 = SH::K3, QS = S / 256;
     using L = WnV2Lds<SH>;
     const int tid = threadIdx.x, ns = p.n_streams, P = p.P, NL = p.NL;
     float w4[K3], w5[EC];
@@ -345,20 +406,46 @@ static __device__ void wn_v2_head(const WnPlan& p, const WnRun& r, WnCtx& cx, fl
     const int kq3 = tid % T3, row3 = tid / T3;
     float* sk = lds + L::sk;
     float* ev = lds + L::ev;
+    volatile int* failflag = reinterpret_cast<volatile int*>(lds + L::smp + 48);
+    if (tid == 0) *failflag = 0;
+    __syncthreads();
+    long long last_wait = 0;
     for (long long e = 0; e < r.n_eval; ++e) {
         const bool prime = e < r.n_given - 1;
         const uint32_t tag = (uint32_t)(e + 1);
         for (int s = 0; s < ns; ++s) {
-            cx.t_start = (long long)wall_clock64();
+            const long long t_begin = (long long)wall_clock64();
+            cx.t_start = t_begin;
             const long long item = e * ns + s;
             wn_stamp(r, cx.w, item, 0);
+            if (ns == 1) wn_presleep(last_wait);
+            // the P lanes of the running skip sum, all rows of this thread in flight together
+            const wn_u64* gin = p.gs + (((size_t)(NL - 1) * P) * ns + s) * S + tid;
+            if (P == 4) {
+                // first pass: everything at once; rows whose granules were late are re-polled individually
+                wn_u64 v[QS][4];
 #pragma unroll
-            for (int q = 0; q < S / 256; ++q) {
-                const int i = tid + 256 * q;
-                const float v = wn_poll_sum<8>(cx, p.gs + (((size_t)(NL - 1) * P) * ns + s) * S + i, (size_t)ns * S, P, tag, WN_W_HEAD, e, s);
-                sk[i] = v > 0.f ? v : 0.f;  // relu(skip)  wavenet_model.py:167
+                for (int q = 0; q < QS; ++q)
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc) v[q][cc] = wn_ld_granule(gin + 256 * q + (size_t)cc * ns * S);
+#pragma unroll
+                for (int q = 0; q < QS; ++q) {
+                    bool ok = true;
+                    float sum = 0.f;
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc) { ok = ok && ((uint32_t)(v[q][cc] >> 32) == tag); sum += __uint_as_float((uint32_t)v[q][cc]); }
+                    if (!ok) sum = wn_poll_fixed<4>(cx, gin + 256 * q, (size_t)ns * S, tag, WN_W_HEAD, e, s);
+                    sk[tid + 256 * q] = sum > 0.f ? sum : 0.f;  // relu(skip)  wavenet_model.py:167
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < QS; ++q) {
+                    const float v = wn_poll_sum<8>(cx, gin + 256 * q, (size_t)ns * S, P, tag, WN_W_HEAD, e, s);
+                    sk[tid + 256 * q] = v > 0.f ? v : 0.f;
+                }
             }
-            if (__syncthreads_or(cx.fail)) return;
+            if (wn_barrier_failed(cx, failflag)) return;
+            last_wait = (long long)wall_clock64() - t_begin;
             wn_stamp(r, cx.w, item, 1);
             wn_u64* gl = p.gl + ((size_t)h * ns + s) * 256;
             if (!prime) {

@@ -455,7 +455,7 @@ extern "C" int wn_generate(wn_handle* h, const wn_generate_args* a) {
     r.timeout_ticks = ms * (long long)h->wall_khz;
     if (h->prof_items > 0) {
         rt_free(h->d_prof);
-        const size_t nb = (size_t)h->plan.n_wg * h->prof_items * 4 * sizeof(long long);
+        const size_t nb = (size_t)h->plan.n_wg * h->prof_items * 8 * sizeof(long long);
         h->d_prof = (long long*)rt_malloc(nb);
         if (!h->d_prof) return wn_fail(WN_E_NOMEM, "wn_generate: profile buffer");
         int prc = rt_memset_async(h->d_prof, 0, nb, a->hip_stream);
@@ -557,7 +557,7 @@ extern "C" int wn_profile_next(wn_handle* h, int32_t n_items) {
 extern "C" int wn_profile_read(wn_handle* h, int64_t* host_out, int64_t capacity) {
     if (!h || !host_out) return wn_fail(WN_E_BADARG, "wn_profile_read: NULL argument");
     if (h->pending) { int rc = wn_wait(h); if (rc) return rc; }
-    const int64_t n = (int64_t)h->plan.n_wg * h->prof_recorded * 4;
+    const int64_t n = (int64_t)h->plan.n_wg * h->prof_recorded * 8;
     if (!h->d_prof || n == 0 || capacity < n) return wn_fail(WN_E_STATE, "wn_profile_read: nothing recorded / buffer too small (%lld)", (long long)n);
     return rt_d2h(host_out, h->d_prof, (size_t)n * 8);
 }

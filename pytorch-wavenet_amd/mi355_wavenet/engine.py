@@ -147,9 +147,9 @@ class Engine:
         self.lib.check(self.lib.dll.wn_profile_next(self._h, int(n_items)))
 
     def profile_read(self, n_items):
-        """int64 (n_workgroups, n_items, 4) wall-clock stamps (100 MHz ticks) of the last profiled job."""
+        """int64 (n_workgroups, n_items, 8) wall-clock stamps (100 MHz ticks) of the last profiled job."""
         n_wg = self.info()["n_workgroups"]
-        out = np.zeros((n_wg, n_items, 4), dtype=np.int64)
+        out = np.zeros((n_wg, n_items, 8), dtype=np.int64)
         self.lib.check(self.lib.dll.wn_profile_read(self._h, out.ctypes.data, out.size))
         return out
 

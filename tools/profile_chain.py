@@ -32,7 +32,7 @@ def main():
     st = eng.profile_read(items).astype(np.float64) * 0.01  # us
     lo, hi = items // 4, items - ns  # steady state
     T = st[:, lo:hi, :]
-    lay = T[:NL * P].reshape(NL, P, hi - lo, 4)
+    lay = T[:NL * P].reshape(NL, P, hi - lo, 8)
     head = T[NL * P:]
     period = np.diff(st[0, lo:hi:ns, 1]).mean() if ns == 1 else np.diff(st[0, lo:hi, 1][::ns]).mean()
     print("%s x%d: variant %d P=%d PA=%d workgroups %d; loop period %.2f us/eval (%.0f evals/s per stream, %.0f samples/s total)" % (
@@ -45,6 +45,9 @@ def main():
     print("layer hand-off (published -> staged): mean %.3f us  p50 %.3f  p95 %.3f  [max over the %d lanes: %.3f]" % (
         hop.mean(), np.median(hop), np.percentile(hop, 95), P, hop.max(axis=1).mean()))
     print("layer critical compute (staged -> x' published): mean %.3f us (L0: %.3f)" % (crit[1:].mean(), crit[0].mean()))
+    print("  of which: fg matvec+reduce %.3f us, gating+barrier %.3f us, residual+publish %.3f us" % (
+        (lay[1:, :, :, 4] - lay[1:, :, :, 1]).mean(), (lay[1:, :, :, 5] - lay[1:, :, :, 4]).mean(),
+        (lay[1:, :, :, 2] - lay[1:, :, :, 5]).mean()))
     print("layer tail (published -> done): mean %.3f us;  poll wait inside the step: %.3f us" % (tail.mean(), wait[1:].mean()))
     per_layer = (lay[1:, :, :, 2].max(axis=1) - lay[:-1, :, :, 2].max(axis=1)).mean(axis=1)
     print("published(l) - published(l-1): mean %.3f us; by layer %s" % (per_layer.mean(), np.array2string(per_layer, precision=2)))
