@@ -66,6 +66,31 @@ static __device__ __forceinline__ float wn_reduce(float v) {
     return v;
 }
 
+
+// dot(w[0..K), x[0..K)) with x in LDS: float4 reads, four independent FMA chains (K % 4 == 0), else a plain chain
+template <int K>
+static __device__ __forceinline__ float wn_dot_lds(const float (&w)[K], const float* x, float init) {
+    if constexpr (K % 4 == 0) {
+        float a0 = init, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        const float4* x4 = reinterpret_cast<const float4*>(x);
+#pragma unroll
+        for (int k = 0; k < K / 4; ++k) {
+            const float4 v = x4[k];
+            a0 += w[4 * k] * v.x; a1 += w[4 * k + 1] * v.y; a2 += w[4 * k + 2] * v.z; a3 += w[4 * k + 3] * v.w;
+        }
+        return (a0 + a1) + (a2 + a3);
+    } else {
+        float a = init;
+#pragma unroll
+        for (int k = 0; k < K; ++k) a += w[k] * x[k];
+        return a;
+    }
+}
+
+// sigmoid with the accurate expf and a 1-ulp reciprocal; tanh(x) = 2*sigmoid(2x) - 1 (absolute error ~1e-7, the
+// same size as the fp32 rounding of the dot products that consume it)
+static __device__ __forceinline__ float wn_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + expf(-x)); }
+
 static __device__ __forceinline__ wn_u64 wn_ld_granule(const wn_u64* g) {
     return __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -308,32 +333,21 @@ static __device__ void wn_v2_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
             }
             wn_stamp(r, cx.w, item, 1);
             // ---- 2. filter/gate: tap 1 on x[t] + parked tap 0, tanh * sigmoid   (wavenet_model.py:147-151)
-            float acc = pre[s * 256 + tid];
-            {
-                const float* xk = xb + kq1 * K1;
-#pragma unroll
-                for (int k = 0; k < K1; ++k) acc += w1[k] * xk[k];
-            }
+            const float xres = (c == 0 && kq2 == 0) ? xb[row2] : 0.f;  // newest tap for the residual add, fetched early
+            float acc = wn_dot_lds<K1>(w1, xb + kq1 * K1, pre[s * 256 + tid]);
             acc = wn_reduce<T1>(acc);
             const float other = wn_partner<T1>(acc);  // the gate (resp. filter) row of the same channel
             const float fv = is_gate ? other : acc, gv = is_gate ? acc : other;
             wn_stamp(r, cx.w, item, 4);
-            const float z = tanhf(fv) * (1.0f / (1.0f + expf(-gv)));
+            const float z = (2.0f * wn_sigmoid(2.0f * fv) - 1.0f) * wn_sigmoid(gv);
             if (!is_gate && kq1 == 0) zs[ch] = z;
             __syncthreads();
             wn_stamp(r, cx.w, item, 5);
             // ---- 3. residual 1x1 partial, published at once                      (wavenet_model.py:164-165)
             if (l < NL - 1) {
-                float a2 = 0.f;
-                const float* zk = zs + kq2 * K2;
-#pragma unroll
-                for (int k = 0; k < K2; ++k) a2 += w2[k] * zk[k];
+                float a2 = wn_dot_lds<K2>(w2, zs + kq2 * K2, 0.f);
                 a2 = wn_reduce<T2>(a2);
-                if (kq2 == 0) {
-                    float v = a2 + bres;
-                    if (c == 0) v += xb[row2];
-                    wn_publish(p.gx + ((size_t)cx.w * ns + s) * R + row2, tag, v);
-                }
+                if (kq2 == 0) wn_publish(p.gx + ((size_t)cx.w * ns + s) * R + row2, tag, (a2 + bres) + xres);
             }
             wn_stamp(r, cx.w, item, 2);
             // ---- 4. skip 1x1 partial on this lane of the running skip sum          (wavenet_model.py:154-162)
@@ -374,9 +388,7 @@ static __device__ void wn_v2_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
                 if (tid < R) ring[(size_t)(t % ML) * R + tid] = xb[tid];
                 float a0 = kq1 == 0 ? bfg : 0.f;
                 if (d == 1) {
-                    const float* xk = xb + kq1 * K1;
-#pragma unroll
-                    for (int k = 0; k < K1; ++k) a0 += w0[k] * xk[k];
+                    a0 = wn_dot_lds<K1>(w0, xb + kq1 * K1, a0);
                 } else {
                     long long pos = (t + 1 - d) % ML;
                     if (pos < 0) pos += ML;
@@ -449,20 +461,14 @@ static __device__ void wn_v2_head(const WnPlan& p, const WnRun& r, WnCtx& cx, fl
             wn_stamp(r, cx.w, item, 1);
             wn_u64* gl = p.gl + ((size_t)h * ns + s) * 256;
             if (!prime) {
-                float a = 0.f;
-                const float* sp = sk + kq3 * K3;
-#pragma unroll
-                for (int k = 0; k < K3; ++k) a += w4[k] * sp[k];
+                float a = wn_dot_lds<K3>(w4, sk + kq3 * K3, 0.f);
                 a = wn_reduce<T3>(a);
                 if (kq3 == 0) {
                     const float v = a + b1;
                     ev[row3] = v > 0.f ? v : 0.f;  // relu(end_conv_1)  :168
                 }
                 __syncthreads();
-                float o = b2;
-#pragma unroll
-                for (int k = 0; k < EC; ++k) o += w5[k] * ev[k];
-                wn_publish(gl + tid, tag, o);  // partial end_conv_2  :169
+                wn_publish(gl + tid, tag, wn_dot_lds<EC>(w5, ev, b2));  // partial end_conv_2  :169
             } else {
                 wn_publish(gl + tid, tag, 0.f);
             }
