@@ -143,9 +143,17 @@ static __device__ __forceinline__ float wn_poll_sum(WnCtx& cx, const wn_u64* bas
 // diagnostics: wall-clock stamp k of this workgroup's step: 0 start, 1 input staged, 2 x' published, 3 done,
 // 4 filter/gate sums ready, 5 z staged
 #define WN_STAMPS 8
-static __device__ __forceinline__ void wn_stamp(const WnRun& r, int w, long long item, int k) {
-    if (r.prof && item < r.prof_items && threadIdx.x == 0)
-        r.prof[((size_t)w * r.prof_items + item) * WN_STAMPS + k] = (long long)wall_clock64();
+// Stamps are parked in LDS (one ds_write, no vector-memory traffic on the critical path) and flushed to HBM by
+// wn_stamp_flush at the end of the step.
+static __device__ __forceinline__ void wn_stamp(const WnRun& r, long long* park, long long item, int k) {
+    if (r.prof && item < r.prof_items && threadIdx.x == 0) park[k] = (long long)wall_clock64();
+}
+static __device__ __forceinline__ void wn_stamp_flush(const WnRun& r, const long long* park, int w, long long item) {
+    if (r.prof && item < r.prof_items && threadIdx.x == 0) {
+        long long* dst = r.prof + ((size_t)w * r.prof_items + item) * WN_STAMPS;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) dst[k] = park[k];
+    }
 }
 
 // LDS layout (floats) of the v2 kernel
@@ -156,7 +164,8 @@ struct WnV2Lds {
     static constexpr int sk = zs + ((SH::DC + 3) & ~3);  // [S]    head
     static constexpr int ev = sk + SH::S;                // [EC]   head
     static constexpr int smp = ev + SH::EC;              // sampler scratch: 64 floats (8-byte aligned); [48] = fail flag
-    static constexpr int pre = smp + 64;                 // [n_streams][256]
+    static constexpr int park = smp + 64;                // 8 parked int64 stamps
+    static constexpr int pre = park + 16;                 // [n_streams][256]
     static int floats(int n_streams) { return pre + n_streams * 256; }
 };
 
@@ -270,6 +279,7 @@ static __device__ void wn_v2_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
     float* pre = lds + L::pre;
     float* smp = lds + L::smp;
     volatile int* failflag = reinterpret_cast<volatile int*>(smp + 48);
+    long long* park = reinterpret_cast<long long*>(lds + L::park);
     if (tid == 0) *failflag = 0;
 
     // tap-0 contribution for the first evaluation of every stream: x[t_base - d] from the queue (zeros after reset)
@@ -296,7 +306,7 @@ static __device__ void wn_v2_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
             const long long t_begin = (long long)wall_clock64();
             cx.t_start = t_begin;  // the spin bound is per hand-off wait, not per job
             const long long item = e * ns + s;
-            wn_stamp(r, cx.w, item, 0);
+            wn_stamp(r, park, item, 0);
             // ---- 1. layer input x[t]
             if (l == 0) {
                 int idx;
@@ -331,25 +341,25 @@ static __device__ void wn_v2_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
                 }
                 if (wn_barrier_failed(cx, failflag)) return;
             }
-            wn_stamp(r, cx.w, item, 1);
+            wn_stamp(r, park, item, 1);
             // ---- 2. filter/gate: tap 1 on x[t] + parked tap 0, tanh * sigmoid   (wavenet_model.py:147-151)
             const float xres = (c == 0 && kq2 == 0) ? xb[row2] : 0.f;  // newest tap for the residual add, fetched early
             float acc = wn_dot_lds<K1>(w1, xb + kq1 * K1, pre[s * 256 + tid]);
             acc = wn_reduce<T1>(acc);
             const float other = wn_partner<T1>(acc);  // the gate (resp. filter) row of the same channel
             const float fv = is_gate ? other : acc, gv = is_gate ? acc : other;
-            wn_stamp(r, cx.w, item, 4);
+            wn_stamp(r, park, item, 4);
             const float z = (2.0f * wn_sigmoid(2.0f * fv) - 1.0f) * wn_sigmoid(gv);
             if (!is_gate && kq1 == 0) zs[ch] = z;
             __syncthreads();
-            wn_stamp(r, cx.w, item, 5);
+            wn_stamp(r, park, item, 5);
             // ---- 3. residual 1x1 partial, published at once                      (wavenet_model.py:164-165)
             if (l < NL - 1) {
                 float a2 = wn_dot_lds<K2>(w2, zs + kq2 * K2, 0.f);
                 a2 = wn_reduce<T2>(a2);
                 if (kq2 == 0) wn_publish(p.gx + ((size_t)cx.w * ns + s) * R + row2, tag, (a2 + bres) + xres);
             }
-            wn_stamp(r, cx.w, item, 2);
+            wn_stamp(r, park, item, 2);
             // ---- 4. skip 1x1 partial on this lane of the running skip sum          (wavenet_model.py:154-162)
             wn_u64* gs = p.gs + ((size_t)cx.w * ns + s) * S;
             if (!prime) {
@@ -398,7 +408,8 @@ static __device__ void wn_v2_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
                 }
                 pre[s * 256 + tid] = a0;
             }
-            wn_stamp(r, cx.w, item, 3);
+            wn_stamp(r, park, item, 3);
+            wn_stamp_flush(r, park, cx.w, item);
         }
     }
 }
@@ -419,6 +430,7 @@ static __device__ void wn_v2_head(const WnPlan& p, const WnRun& r, WnCtx& cx, fl
     float* sk = lds + L::sk;
     float* ev = lds + L::ev;
     volatile int* failflag = reinterpret_cast<volatile int*>(lds + L::smp + 48);
+    long long* park = reinterpret_cast<long long*>(lds + L::park);
     if (tid == 0) *failflag = 0;
     __syncthreads();
     long long last_wait = 0;
@@ -429,7 +441,7 @@ static __device__ void wn_v2_head(const WnPlan& p, const WnRun& r, WnCtx& cx, fl
             const long long t_begin = (long long)wall_clock64();
             cx.t_start = t_begin;
             const long long item = e * ns + s;
-            wn_stamp(r, cx.w, item, 0);
+            wn_stamp(r, park, item, 0);
             if (ns == 1) wn_presleep(last_wait);
             // the P lanes of the running skip sum, all rows of this thread in flight together
             const wn_u64* gin = p.gs + (((size_t)(NL - 1) * P) * ns + s) * S + tid;
@@ -458,7 +470,7 @@ static __device__ void wn_v2_head(const WnPlan& p, const WnRun& r, WnCtx& cx, fl
             }
             if (wn_barrier_failed(cx, failflag)) return;
             last_wait = (long long)wall_clock64() - t_begin;
-            wn_stamp(r, cx.w, item, 1);
+            wn_stamp(r, park, item, 1);
             wn_u64* gl = p.gl + ((size_t)h * ns + s) * 256;
             if (!prime) {
                 float a = wn_dot_lds<K3>(w4, sk + kq3 * K3, 0.f);
@@ -472,9 +484,10 @@ static __device__ void wn_v2_head(const WnPlan& p, const WnRun& r, WnCtx& cx, fl
             } else {
                 wn_publish(gl + tid, tag, 0.f);
             }
-            wn_stamp(r, cx.w, item, 2);
+            wn_stamp(r, park, item, 2);
             __syncthreads();
-            wn_stamp(r, cx.w, item, 3);
+            wn_stamp(r, park, item, 3);
+            wn_stamp_flush(r, park, cx.w, item);
         }
     }
 }
