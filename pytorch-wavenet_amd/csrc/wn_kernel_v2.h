@@ -25,6 +25,10 @@
 
 #ifndef WN_EMU
 
+#ifndef WN_ABL
+#define WN_ABL 0  // timing ablations for tools/ablate.sh (results are wrong when != 0): 1 no fg dot, 2 cheap gating, 3 no res dot, 5 all
+#endif
+
 template <int R_, int DC_, int S_, int EC_>
 struct WnV2Shape {
     static constexpr int R = R_, DC = DC_, S = S_, EC = EC_, C = 256;
@@ -146,13 +150,16 @@ static __device__ __forceinline__ float wn_poll_sum(WnCtx& cx, const wn_u64* bas
 // Stamps are parked in LDS (one ds_write, no vector-memory traffic on the critical path) and flushed to HBM by
 // wn_stamp_flush at the end of the step.
 static __device__ __forceinline__ void wn_stamp(const WnRun& r, long long* park, long long item, int k) {
-    if (r.prof && item < r.prof_items && threadIdx.x == 0) park[k] = (long long)wall_clock64();
+    if (r.prof && item < r.prof_items && threadIdx.x == 0) {
+        park[k] = (long long)wall_clock64();
+        if (k == 0) park[6] = (long long)clock64();  // shader clock, to read the effective MHz off the stamps
+    }
 }
 static __device__ __forceinline__ void wn_stamp_flush(const WnRun& r, const long long* park, int w, long long item) {
     if (r.prof && item < r.prof_items && threadIdx.x == 0) {
         long long* dst = r.prof + ((size_t)w * r.prof_items + item) * WN_STAMPS;
 #pragma unroll
-        for (int k = 0; k < 6; ++k) dst[k] = park[k];
+        for (int k = 0; k < 7; ++k) dst[k] = park[k];
     }
 }
 
@@ -344,18 +351,18 @@ static __device__ void wn_v2_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
             wn_stamp(r, park, item, 1);
             // ---- 2. filter/gate: tap 1 on x[t] + parked tap 0, tanh * sigmoid   (wavenet_model.py:147-151)
             const float xres = (c == 0 && kq2 == 0) ? xb[row2] : 0.f;  // newest tap for the residual add, fetched early
-            float acc = wn_dot_lds<K1>(w1, xb + kq1 * K1, pre[s * 256 + tid]);
+            float acc = (WN_ABL == 1 || WN_ABL == 5) ? pre[s * 256 + tid] + w1[0] : wn_dot_lds<K1>(w1, xb + kq1 * K1, pre[s * 256 + tid]);
             acc = wn_reduce<T1>(acc);
             const float other = wn_partner<T1>(acc);  // the gate (resp. filter) row of the same channel
             const float fv = is_gate ? other : acc, gv = is_gate ? acc : other;
             wn_stamp(r, park, item, 4);
-            const float z = (2.0f * wn_sigmoid(2.0f * fv) - 1.0f) * wn_sigmoid(gv);
+            const float z = (WN_ABL == 2 || WN_ABL == 5) ? fv * gv * 0.001f : (2.0f * wn_sigmoid(2.0f * fv) - 1.0f) * wn_sigmoid(gv);
             if (!is_gate && kq1 == 0) zs[ch] = z;
             __syncthreads();
             wn_stamp(r, park, item, 5);
             // ---- 3. residual 1x1 partial, published at once                      (wavenet_model.py:164-165)
             if (l < NL - 1) {
-                float a2 = wn_dot_lds<K2>(w2, zs + kq2 * K2, 0.f);
+                float a2 = (WN_ABL == 3 || WN_ABL == 5) ? zs[kq2 * K2] * w2[0] : wn_dot_lds<K2>(w2, zs + kq2 * K2, 0.f);
                 a2 = wn_reduce<T2>(a2);
                 if (kq2 == 0) wn_publish(p.gx + ((size_t)cx.w * ns + s) * R + row2, tag, (a2 + bres) + xres);
             }

@@ -12,7 +12,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "pytorch-wavenet_amd"))
 import numpy as np  # noqa: E402
 
-from mi355_wavenet import engine, synth  # noqa: E402
+from mi355_wavenet import _abi, engine, synth  # noqa: E402
+
+if os.environ.get("WN_DEV_LIB"):  # dev only: an ablation build of the same source (tools/ablate.sh)
+    _abi.PRODUCT_LIB = os.environ["WN_DEV_LIB"]
 
 
 def main():
@@ -29,7 +32,10 @@ def main():
     eng.generate(N, None, temperature=1.0, uniforms=u)  # warm-up
     eng.profile_next(items)
     eng.generate(N, None, temperature=1.0, uniforms=u)
-    st = eng.profile_read(items).astype(np.float64) * 0.01  # us
+    raw = eng.profile_read(items)
+    mhz = (raw[0, items - 1, 6] - raw[0, items // 2, 6]) / ((raw[0, items - 1, 0] - raw[0, items // 2, 0]) * 0.01)
+    print("shader clock during the job: %.0f MHz" % mhz)
+    st = raw.astype(np.float64) * 0.01  # us
     lo, hi = items // 4, items - ns  # steady state
     T = st[:, lo:hi, :]
     lay = T[:NL * P].reshape(NL, P, hi - lo, 8)
