@@ -69,6 +69,16 @@ WN_DEV void wn_publish(wn_u64* g, uint32_t tag, float v) {
 #endif
 }
 
+#ifndef WN_EMU
+// `local` = every consumer of this granule sits on the producer's XCD (checked at run time from the XCC ids): the
+// store may then stay in that XCD's L2 -- the coherence point of all its CUs -- instead of writing through to the
+// fabric; consumers read it with the same L1-bypassing loads.  Decided per producer, never assumed.
+WN_DEV void wn_publish_at(wn_u64* g, uint32_t tag, float v, bool local) {
+    if (local) __hip_atomic_store(g, wn_pack_granule(tag, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else __hip_atomic_store(g, wn_pack_granule(tag, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+#endif
+
 WN_DEV void wn_give_up(WnCtx& cx, int where, long long e, int s) {
     cx.fail = 1;
 #ifdef WN_EMU

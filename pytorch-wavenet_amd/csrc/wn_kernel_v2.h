@@ -176,6 +176,23 @@ struct WnV2Lds {
     static int floats(int n_streams) { return pre + n_streams * 256; }
 };
 
+// XCC id of this workgroup's CU (HW_REG_XCC_ID, 4 bits)
+static __device__ __forceinline__ int wn_xcc_id() { return (int)(__builtin_amdgcn_s_getreg(((4 - 1) << 11) | 20) & 0xf); }
+
+// true iff every chain position in [first, first+count) reports the same XCC as `mine` (bounded wait for their entry)
+static __device__ bool wn_same_xcd(WnCtx& cx, int mine, int first, int count) {
+    bool same = true;
+    for (int q = first; q < first + count; ++q) {
+        unsigned v = 0, spins = 0;
+        while ((v = __hip_atomic_load(cx.p->xcc_tab + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0u) {
+            if ((++spins & 63u) == 0u && (long long)wall_clock64() - cx.t_start > cx.r->timeout_ticks) return false;
+            __builtin_amdgcn_s_sleep(8);
+        }
+        same = same && ((int)v - 1 == mine);
+    }
+    return same;
+}
+
 // barrier that also tells every lane whether any lane gave up a wait (rare): one s_barrier, one LDS word
 static __device__ __forceinline__ bool wn_barrier_failed(WnCtx& cx, volatile int* flag) {
     if (cx.fail) *flag = 1;
@@ -287,7 +304,24 @@ static __device__ void wn_v2_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
     float* smp = lds + L::smp;
     volatile int* failflag = reinterpret_cast<volatile int*>(smp + 48);
     long long* park = reinterpret_cast<long long*>(lds + L::park);
-    if (tid == 0) *failflag = 0;
+    volatile int* locflags = reinterpret_cast<volatile int*>(smp + 52);
+    if (tid == 0) {
+        *failflag = 0;
+        const int mine = wn_xcc_id();
+        __hip_atomic_store(p.xcc_tab + cx.w, (unsigned)(mine + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int lx = 0, lsk = 0;
+        if (p.allow_plain) {
+            if (l < NL - 1) {
+                lx = wn_same_xcd(cx, mine, (l + 1) * P, P);         // x' partials feed every slice of layer l+1
+                lsk = wn_same_xcd(cx, mine, (l + 1) * P + c, 1);    // the skip lane feeds slice c of layer l+1
+            } else {
+                lsk = wn_same_xcd(cx, mine, NL * P, p.PA);          // ... or every head workgroup
+            }
+        }
+        locflags[0] = lx; locflags[1] = lsk;
+    }
+    __syncthreads();
+    const bool local_x = locflags[0] != 0, local_s = locflags[1] != 0;
 
     // tap-0 contribution for the first evaluation of every stream: x[t_base - d] from the queue (zeros after reset)
     for (int s = 0; s < ns; ++s) {
@@ -364,7 +398,7 @@ static __device__ void wn_v2_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
             if (l < NL - 1) {
                 float a2 = (WN_ABL == 3 || WN_ABL == 5) ? zs[kq2 * K2] * w2[0] : wn_dot_lds<K2>(w2, zs + kq2 * K2, 0.f);
                 a2 = wn_reduce<T2>(a2);
-                if (kq2 == 0) wn_publish(p.gx + ((size_t)cx.w * ns + s) * R + row2, tag, (a2 + bres) + xres);
+                if (kq2 == 0) wn_publish_at(p.gx + ((size_t)cx.w * ns + s) * R + row2, tag, (a2 + bres) + xres, local_x);
             }
             wn_stamp(r, park, item, 2);
             // ---- 4. skip 1x1 partial on this lane of the running skip sum          (wavenet_model.py:154-162)
@@ -393,11 +427,11 @@ static __device__ void wn_v2_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
                         else v = wn_poll_fixed<1>(cx, gin + 256 * q, 0, tag, WN_W_SKIN, e, s);
                         a3[q] += v;
                     }
-                    wn_publish(gs + tid + 256 * q, tag, a3[q]);
+                    wn_publish_at(gs + tid + 256 * q, tag, a3[q], local_s);
                 }
             } else if (l == NL - 1) {
 #pragma unroll
-                for (int q = 0; q < RS; ++q) wn_publish(gs + tid + 256 * q, tag, 0.f);
+                for (int q = 0; q < RS; ++q) wn_publish_at(gs + tid + 256 * q, tag, 0.f, local_s);
             }
             // ---- 5. queue push (wavenet_modules.py:55-57) and the next step's tap 0 on x[t+1-d]
             {
@@ -438,8 +472,15 @@ static __device__ void wn_v2_head(const WnPlan& p, const WnRun& r, WnCtx& cx, fl
     float* ev = lds + L::ev;
     volatile int* failflag = reinterpret_cast<volatile int*>(lds + L::smp + 48);
     long long* park = reinterpret_cast<long long*>(lds + L::park);
-    if (tid == 0) *failflag = 0;
+    volatile int* locflags = reinterpret_cast<volatile int*>(lds + L::smp + 52);
+    if (tid == 0) {
+        *failflag = 0;
+        const int mine = wn_xcc_id();
+        __hip_atomic_store(p.xcc_tab + cx.w, (unsigned)(mine + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        locflags[0] = p.allow_plain ? (int)wn_same_xcd(cx, mine, 0, P) : 0;  // partial logits feed every slice of layer 0
+    }
     __syncthreads();
+    const bool local_l = locflags[0] != 0;
     long long last_wait = 0;
     for (long long e = 0; e < r.n_eval; ++e) {
         const bool prime = e < r.n_given - 1;
@@ -487,9 +528,9 @@ static __device__ void wn_v2_head(const WnPlan& p, const WnRun& r, WnCtx& cx, fl
                     ev[row3] = v > 0.f ? v : 0.f;  // relu(end_conv_1)  :168
                 }
                 __syncthreads();
-                wn_publish(gl + tid, tag, wn_dot_lds<EC>(w5, ev, b2));  // partial end_conv_2  :169
+                wn_publish_at(gl + tid, tag, wn_dot_lds<EC>(w5, ev, b2), local_l);  // partial end_conv_2  :169
             } else {
-                wn_publish(gl + tid, tag, 0.f);
+                wn_publish_at(gl + tid, tag, 0.f, local_l);
             }
             wn_stamp(r, park, item, 2);
             __syncthreads();
@@ -504,6 +545,7 @@ __global__ __launch_bounds__(WN_THREADS) void wn_generate_kernel_v2(WnPlan p, Wn
     using SH = WnV2Shape<R, DC, S, EC>;
     extern __shared__ __attribute__((aligned(16))) float wn_lds2[];
     const int w = p.wg_map[blockIdx.x];
+    if (w < 0) return;  // bystander block of the XCD-aligned placement
     WnCtx cx;
     cx.p = &p; cx.r = &r; cx.lds = wn_lds2; cx.w = w; cx.fail = 0;
     cx.t_start = (long long)wall_clock64();

@@ -71,6 +71,9 @@ struct WnPlan {
     wn_u64* gs;               // skip lanes    [(NL*P)][n_streams][S]
     wn_u64* gl;               // partial logits[PA][n_streams][C]
     uint32_t* status;         // [8] 0: abort code, 1: chain position, 2: eval, 3: stream, 4: where
+    uint32_t* xcc_tab;        // [n_wg] XCC id + 1 of every chain position, written by the workgroups at start
+    int32_t n_blocks;         // grid size (>= n_wg; blocks mapped to -1 exit at once)
+    int32_t allow_plain;      // same-XCD producers may publish with L2-resident (non write-through) stores
 };
 
 struct WnRun {
@@ -289,5 +292,32 @@ static inline void wn_make_wg_map(int n_wg, int n_xcd, std::vector<int32_t>& map
     for (int b = 0; b < n_wg; ++b) cnt[b % n_xcd]++;
     for (int x = 0; x < n_xcd; ++x) pre[x + 1] = pre[x] + cnt[x];
     for (int b = 0; b < n_wg; ++b) map[b] = pre[b % n_xcd] + b / n_xcd;
+}
+
+// Layer-aligned placement: every layer's P workgroups (and the head's PA) sit on ONE XCD, so that most hand-offs
+// stay inside one XCD's L2.  XCD 0 hosts the head and the first layers (head -> L0 stays local too).
+// map[b] = chain position of block b, or -1 (bystander).  Returns false if the layers do not fit that way.
+static inline bool wn_make_wg_map_layers(int NL, int P, int PA, int n_xcd, int cu_per_xcd, std::vector<int32_t>& map,
+                                         int* n_blocks) {
+    std::vector<std::vector<int>> S(n_xcd);
+    if (PA > cu_per_xcd) return false;
+    for (int h = 0; h < PA; ++h) S[0].push_back(NL * P + h);
+    int next = 0;
+    for (int x = 0; x < n_xcd; ++x) {
+        const int cap = (cu_per_xcd - (int)S[x].size()) / P;
+        const int want = wn_cdiv(NL - next, n_xcd - x);
+        const int take = want < cap ? want : cap;
+        for (int l = next; l < next + take; ++l)
+            for (int c = 0; c < P; ++c) S[x].push_back(l * P + c);
+        next += take;
+    }
+    if (next < NL) return false;
+    size_t per = 0;
+    for (int x = 0; x < n_xcd; ++x) per = S[x].size() > per ? S[x].size() : per;
+    *n_blocks = (int)per * n_xcd;
+    map.assign(*n_blocks, -1);
+    for (int b = 0; b < *n_blocks; ++b)
+        if ((size_t)(b / n_xcd) < S[b % n_xcd].size()) map[b] = S[b % n_xcd][b / n_xcd];
+    return true;
 }
 #endif  // WN_PLAN_H

@@ -63,6 +63,7 @@ static int rt_sync(void* stream) { return rt_hip(hipStreamSynchronize((hipStream
 __global__ __launch_bounds__(WN_THREADS) void wn_generate_kernel(WnPlan p, WnRun r) {
     extern __shared__ __attribute__((aligned(16))) float wn_lds[];
     const int w = p.wg_map[blockIdx.x];
+    if (w < 0) return;
     wn_load_lds(p, w, wn_lds);
     WnCtx cx;
     cx.p = &p; cx.r = &r; cx.lds = wn_lds; cx.w = w; cx.fail = 0;
@@ -307,7 +308,14 @@ extern "C" int wn_create(const wn_config* cfg, wn_handle** out) {
     }
     h->ring_floats = (size_t)off;
     std::vector<int32_t> wg_map;
-    wn_make_wg_map(pl.n_wg, 8, wg_map);
+    pl.n_blocks = pl.n_wg;
+    pl.allow_plain = 0;
+    if (h->variant == 2 && n_cu % 8 == 0 && wn_make_wg_map_layers(pl.NL, pl.P, pl.PA, 8, n_cu / 8, wg_map, &pl.n_blocks)) {
+        const char* np = getenv("WN_NO_LOCAL_STORES");
+        pl.allow_plain = (np && np[0] == '1') ? 0 : 1;
+    } else {
+        wn_make_wg_map(pl.n_wg, 8, wg_map);
+    }
     const size_t n_lw = (size_t)pl.NL * pl.P;
     const size_t gx_n = n_lw * pl.n_streams * pl.R, gs_n = n_lw * pl.n_streams * pl.S, gl_n = (size_t)pl.PA * pl.n_streams * pl.C;
     h->gran_count = gx_n + gs_n + gl_n;
@@ -324,9 +332,9 @@ extern "C" int wn_create(const wn_config* cfg, wn_handle** out) {
     h->d_rings = (float*)rt_malloc(h->ring_floats * 4);
     h->d_dil = (int32_t*)rt_malloc((size_t)pl.NL * 4);
     h->d_ring_off = (int64_t*)rt_malloc((size_t)pl.NL * 8);
-    h->d_wg_map = (int32_t*)rt_malloc((size_t)pl.n_wg * 4);
+    h->d_wg_map = (int32_t*)rt_malloc((size_t)pl.n_blocks * 4);
     h->d_gran = (wn_u64*)rt_malloc(h->gran_count * 8);
-    h->d_status = (uint32_t*)rt_malloc(8 * 4);
+    h->d_status = (uint32_t*)rt_malloc((size_t)(8 + pl.n_wg) * 4);
     if (!h->d_blobs || !h->d_start_t || !h->d_start_b || !h->d_rings || !h->d_dil || !h->d_ring_off || !h->d_wg_map ||
         !h->d_gran || !h->d_status) {
         wn_destroy(h);
@@ -336,15 +344,16 @@ extern "C" int wn_create(const wn_config* cfg, wn_handle** out) {
     int rc = 0;
     rc = rc ? rc : rt_h2d(h->d_dil, h->dil.data(), (size_t)pl.NL * 4);
     rc = rc ? rc : rt_h2d(h->d_ring_off, h->ring_off.data(), (size_t)pl.NL * 8);
-    rc = rc ? rc : rt_h2d(h->d_wg_map, wg_map.data(), (size_t)pl.n_wg * 4);
+    rc = rc ? rc : rt_h2d(h->d_wg_map, wg_map.data(), (size_t)pl.n_blocks * 4);
     rc = rc ? rc : rt_memset_async(h->d_rings, 0, h->ring_floats * 4, nullptr);
-    rc = rc ? rc : rt_memset_async(h->d_status, 0, 32, nullptr);
+    rc = rc ? rc : rt_memset_async(h->d_status, 0, (size_t)(8 + pl.n_wg) * 4, nullptr);
     rc = rc ? rc : rt_sync(nullptr);
     if (rc) { wn_destroy(h); return rc; }
     pl.blobs = h->d_blobs; pl.start_t = h->d_start_t; pl.start_b = nullptr;
     pl.dil = h->d_dil; pl.ring_off = h->d_ring_off; pl.wg_map = h->d_wg_map; pl.rings = h->d_rings;
     pl.gx = h->d_gran; pl.gs = h->d_gran + gx_n; pl.gl = h->d_gran + gx_n + gs_n;
     pl.status = h->d_status;
+    pl.xcc_tab = h->d_status + 8;
 #ifndef WN_EMU
     rc = rt_hip(hipFuncSetAttribute(h->variant == 2 ? wn_v2_table()[h->v2_index].fn : (const void*)wn_generate_kernel,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes),
@@ -466,7 +475,7 @@ extern "C" int wn_generate(wn_handle* h, const wn_generate_args* a) {
     }
     // hand-off words restart at tag 1 every call: zero them (and the status word) ahead of the launch
     int rc = rt_memset_async(h->d_gran, 0, h->gran_count * 8, a->hip_stream);
-    rc = rc ? rc : rt_memset_async(h->d_status, 0, 32, a->hip_stream);
+    rc = rc ? rc : rt_memset_async(h->d_status, 0, (size_t)(8 + h->plan.n_wg) * 4, a->hip_stream);
     if (rc) return rc;
 #ifdef WN_EMU
     {
@@ -476,9 +485,9 @@ extern "C" int wn_generate(wn_handle* h, const wn_generate_args* a) {
     }
 #else
     if (h->variant == 2)
-        wn_v2_table()[h->v2_index].launch(h->plan.n_wg, (size_t)h->lds_bytes, (hipStream_t)a->hip_stream, h->plan, r);
+        wn_v2_table()[h->v2_index].launch(h->plan.n_blocks, (size_t)h->lds_bytes, (hipStream_t)a->hip_stream, h->plan, r);
     else
-        hipLaunchKernelGGL(wn_generate_kernel, dim3(h->plan.n_wg), dim3(WN_THREADS), (size_t)h->lds_bytes,
+        hipLaunchKernelGGL(wn_generate_kernel, dim3(h->plan.n_blocks), dim3(WN_THREADS), (size_t)h->lds_bytes,
                            (hipStream_t)a->hip_stream, h->plan, r);
     rc = rt_hip(hipGetLastError(), "launch wn_generate_kernel");
     if (rc) return rc;
