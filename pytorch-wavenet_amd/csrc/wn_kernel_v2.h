@@ -91,9 +91,24 @@ static __device__ __forceinline__ float wn_dot_lds(const float (&w)[K], const fl
     }
 }
 
-// sigmoid with the accurate expf and a 1-ulp reciprocal; tanh(x) = 2*sigmoid(2x) - 1 (absolute error ~1e-7, the
-// same size as the fp32 rounding of the dot products that consume it)
-static __device__ __forceinline__ float wn_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + expf(-x)); }
+// e^x with the accuracy of the library expf (product x*log2(e) carried in two floats, v_exp_f32 on the reduced
+// argument, v_ldexp_f32) but branch-free and without its range clamps -- v_exp/v_ldexp saturate to 0 / inf by
+// themselves -- so that the two exponentials of a gated unit schedule as two interleaved dependency chains.
+static __device__ __forceinline__ float wn_exp(float x) {
+    const float p = x * 1.44269504088896341f;
+    float lo = fmaf(x, 1.44269504088896341f, -p);  // exact rounding error of the product
+    lo = fmaf(x, 1.92596299112661746e-8f, lo);     // + x * (log2(e) - float(log2(e)))
+    const float n = rintf(p);
+    return ldexpf(__builtin_amdgcn_exp2f((p - n) + lo), (int)n);
+}
+
+// z = tanh(f) * sigmoid(g) with tanh(f) = 2*sigmoid(2f) - 1 (absolute error ~1e-7, the size of the fp32 rounding of
+// the dot products that consume z) and 1-ulp reciprocals
+static __device__ __forceinline__ float wn_gate(float f, float g) {
+    const float e1 = wn_exp(-2.0f * f), e2 = wn_exp(-g);
+    const float r1 = __builtin_amdgcn_rcpf(1.0f + e1), r2 = __builtin_amdgcn_rcpf(1.0f + e2);
+    return fmaf(2.0f, r1, -1.0f) * r2;
+}
 
 static __device__ __forceinline__ wn_u64 wn_ld_granule(const wn_u64* g) {
     return __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -390,7 +405,7 @@ static __device__ void wn_v2_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
             const float other = wn_partner<T1>(acc);  // the gate (resp. filter) row of the same channel
             const float fv = is_gate ? other : acc, gv = is_gate ? acc : other;
             wn_stamp(r, park, item, 4);
-            const float z = (WN_ABL == 2 || WN_ABL == 5) ? fv * gv * 0.001f : (2.0f * wn_sigmoid(2.0f * fv) - 1.0f) * wn_sigmoid(gv);
+            const float z = (WN_ABL == 2 || WN_ABL == 5) ? fv * gv * 0.001f : wn_gate(fv, gv);
             if (!is_gate && kq1 == 0) zs[ch] = z;
             __syncthreads();
             wn_stamp(r, park, item, 5);
