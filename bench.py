@@ -78,28 +78,40 @@ def time_workload(cfgname, n_streams, samples, steps, warmup, dist, device):
     return t1 - t0, kernel_ms, info, cfg
 
 
-def cpu_baseline(cfgname, budget_s=12.0):
+def cpu_baseline(cfgname, budget_s=10.0):
     """The reference's CPU path (torch restatement of generate_fast, oracle/restated.py, proven bit-equal to the real
-    reference in tests/test_oracle_pinning.py) timed on this box's host cores: a bounded single-stream sample."""
+    reference in tests/test_oracle_pinning.py) timed on this box's host cores: a bounded single-stream sample.  The path
+    is framework-dispatch bound (203 tiny conv1d calls per sample), so it is timed with 1 thread and with torch's default
+    thread count and the faster of the two is reported."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import restated
     from mi355_wavenet import synth
     cfg = synth.CONFIGS[cfgname]
     W = synth.init_weights(cfg, seed=0)
     r = restated.RestatedWaveNet(cfg, W)
-    np.random.seed(0)
-    r.generate_fast(20, temperature=1.0, return_details=True)  # warm-up
-    n = 100
-    t0 = time.perf_counter()
-    r.generate_fast(n, temperature=1.0, return_details=True)
-    dt = time.perf_counter() - t0
-    n2 = int(max(100, min(3000, budget_s / (dt / n))))
-    t0 = time.perf_counter()
-    r.generate_fast(n2, temperature=1.0, return_details=True)
-    dt2 = time.perf_counter() - t0
-    return {"value": round(n2 / dt2, 2), "unit": "samples/s", "cores": int(torch.get_num_threads()), "kind": "port",
+    default_threads = torch.get_num_threads()
+    best = None
+    for threads in (1, default_threads):
+        torch.set_num_threads(threads)
+        np.random.seed(0)
+        r.generate_fast(10, temperature=1.0, return_details=True)  # warm-up
+        n = 40
+        t0 = time.perf_counter()
+        r.generate_fast(n, temperature=1.0, return_details=True)
+        dt = time.perf_counter() - t0
+        n2 = int(max(50, min(3000, budget_s / (dt / n))))
+        t0 = time.perf_counter()
+        r.generate_fast(n2, temperature=1.0, return_details=True)
+        rate = n2 / (time.perf_counter() - t0)
+        if best is None or rate > best[0]:
+            best = (rate, threads, n2)
+        if default_threads == 1:
+            break
+    torch.set_num_threads(default_threads)
+    return {"value": round(best[0], 2), "unit": "samples/s", "cores": int(best[1]), "kind": "port",
             "sample": "%s single stream, %d samples of generate_fast(temperature=1.0) through oracle/restated.py "
-                      "(op-for-op torch restatement of the reference's CPU path)" % (cfgname, n2)}
+                      "(op-for-op torch restatement of the reference's CPU path; best of 1 and %d torch threads, "
+                      "host has %d logical cores)" % (cfgname, best[2], default_threads, os.cpu_count())}
 
 
 def main():
@@ -155,10 +167,10 @@ def main():
                                "temperature 1.0" % (a.workload, ", ".join("%s=%s" % kv for kv in cfg.items()), per_gpu, a.samples),
                    "streams_per_gpu": per_gpu, "samples_per_stream_per_step": a.samples,
                    "per_stream_samples_per_s": round(value / (n_gpus * per_gpu), 1),
-                   "chain": {k: info[k] for k in ("layer_split", "head_split", "n_workgroups", "lds_bytes")}},
+                   "chain": {k: info[k] for k in ("kernel_variant", "layer_split", "head_split", "n_workgroups", "lds_bytes")}},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                     "kernel": "wn_generate_kernel", "kernel_ms_per_launch": round(kernel_ms, 3),
+                     "kernel": "wn_generate_kernel_v2" if info["kernel_variant"] == 2 else "wn_generate_kernel", "kernel_ms_per_launch": round(kernel_ms, 3),
                      "algorithmic_bytes_per_launch": int(bytes_per_launch),
                      "algorithmic_bytes_per_timestep": int(bytes_per_tstep), "launches_per_step": 1},
     }
