@@ -158,6 +158,12 @@ def main():
     bytes_per_tstep = synth.algorithmic_bytes_per_step(cfg, per_gpu)   # W_touched + streams*(Q+8)
     bytes_per_launch = bytes_per_tstep * a.samples
     achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
+    traffic = None
+    pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, committed
+    if os.path.exists(pmc_path):
+        pmc = json.load(open(pmc_path)).get(a.workload)
+        if pmc:  # hand-off traffic is linear in the number of timesteps: scale to this launch
+            traffic = int((pmc["fetch_kib"] + pmc["write_kib"]) * 1024 * a.samples / pmc["samples_per_launch"])
     line = {
         "metric": "generate_fast() audio samples/sec (256-class mu-law), whole job over all GPUs",
         "value": round(value, 1), "unit": "samples/s", "n_gpus": n_gpus, "steps": a.steps, "warmup": a.warmup,
@@ -169,7 +175,7 @@ def main():
                    "per_stream_samples_per_s": round(value / (n_gpus * per_gpu), 1),
                    "chain": {k: info[k] for k in ("kernel_variant", "layer_split", "head_split", "n_workgroups", "lds_bytes")}},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                      "kernel": "wn_generate_kernel_v2" if info["kernel_variant"] == 2 else "wn_generate_kernel", "kernel_ms_per_launch": round(kernel_ms, 3),
                      "algorithmic_bytes_per_launch": int(bytes_per_launch),
                      "algorithmic_bytes_per_timestep": int(bytes_per_tstep), "launches_per_step": 1},
