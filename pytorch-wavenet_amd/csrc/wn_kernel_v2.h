@@ -555,6 +555,352 @@ static __device__ void wn_v2_head(const WnPlan& p, const WnRun& r, WnCtx& cx, fl
     }
 }
 
+
+// ================================================================================================
+// Multi-stream variant (n_streams >= 2): the same chain run as a PIPELINE over streams.  Per (step, stream) item a
+// workgroup must not pay any memory round trip, so everything it will need for the NEXT item is requested while
+// it works on the current one and only checked (tags) when due:
+//   * the x' partials / skip lane / skip lanes of the next item are loaded into registers one item ahead; a stale
+//     tag falls back to the polling loop (start-up, pipeline bubbles);
+//   * the queue tap x[t+1-d] of the current stream is requested at the top of the item and consumed in its tail;
+//   * sampling is moved off L0 onto NSMP dedicated sampler workgroups (chain positions after the head): they turn
+//     partial logits into a class index per stream and publish it as an index granule gi[s]; L0 only gathers.
+template <class SH>
+static __device__ void wn_v2_layer_multi(const WnPlan& p, const WnRun& r, WnCtx& cx, float* lds, int l, int c) {
+    constexpr int R = SH::R, DC = SH::DC, S = SH::S, T1 = SH::T1, K1 = SH::K1, T2 = SH::T2, K2 = SH::K2, RS = SH::RS;
+    using L = WnV2Lds<SH>;
+    const int tid = threadIdx.x;
+    const int ns = p.n_streams, P = p.P, NL = p.NL;
+    float w1[K1], w0[K1], w2[K2], w3[RS][DC], bskip[RS];
+    const float* img = p.blobs + (size_t)cx.w * (SH::NWL * 256) + tid;
+    {
+        int j = 0;
+#pragma unroll
+        for (int k = 0; k < K1; ++k) w1[k] = img[(size_t)(j++) * 256];
+#pragma unroll
+        for (int k = 0; k < K1; ++k) w0[k] = img[(size_t)(j++) * 256];
+#pragma unroll
+        for (int k = 0; k < K2; ++k) w2[k] = img[(size_t)(j++) * 256];
+#pragma unroll
+        for (int q = 0; q < RS; ++q)
+#pragma unroll
+            for (int k = 0; k < DC; ++k) w3[q][k] = img[(size_t)(j++) * 256];
+    }
+    const float bfg = img[(size_t)(2 * K1 + K2 + RS * DC) * 256];
+    const float bres = img[(size_t)(2 * K1 + K2 + RS * DC + 1) * 256];
+#pragma unroll
+    for (int q = 0; q < RS; ++q) bskip[q] = img[(size_t)(2 * K1 + K2 + RS * DC + 2 + q) * 256];
+
+    const int kq1 = tid % T1, grp = tid / T1, ch = grp >> 1, is_gate = grp & 1;
+    const int kq2 = tid % T2, row2 = tid / T2;
+    const int d = p.dil[l];
+    const int ML = d + 1;
+    float* xs = lds + L::xs;
+    float* zs = lds + L::zs;
+    float* pre = lds + L::pre;
+    float* smp = lds + L::smp;
+    volatile int* failflag = reinterpret_cast<volatile int*>(smp + 48);
+    volatile int* locflags = reinterpret_cast<volatile int*>(smp + 52);
+    if (tid == 0) {
+        *failflag = 0;
+        const int mine = wn_xcc_id();
+        __hip_atomic_store(p.xcc_tab + cx.w, (unsigned)(mine + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int lx = 0, lsk = 0;
+        if (p.allow_plain) {
+            if (l < NL - 1) {
+                lx = wn_same_xcd(cx, mine, (l + 1) * P, P);
+                lsk = wn_same_xcd(cx, mine, (l + 1) * P + c, 1);
+            } else {
+                lsk = wn_same_xcd(cx, mine, NL * P, p.PA);
+            }
+        }
+        locflags[0] = lx; locflags[1] = lsk;
+    }
+    __syncthreads();
+    const bool local_x = locflags[0] != 0, local_s = locflags[1] != 0;
+
+    for (int s = 0; s < ns; ++s) {  // tap 0 of the first evaluation of every stream
+        const float* ring = p.rings + p.ring_off[l] + ((size_t)c * ns + s) * (size_t)ML * R;
+        long long pos = (r.t_base - d) % ML;
+        if (pos < 0) pos += ML;
+        float acc = kq1 == 0 ? bfg : 0.f;
+#pragma unroll
+        for (int k = 0; k < K1; ++k) acc += w0[k] * ring[(size_t)pos * R + kq1 * K1 + k];
+        pre[s * 256 + tid] = acc;
+    }
+    __syncthreads();
+
+    // one-item-ahead request registers
+    wn_u64 nx[8];    // l > 0, tid < R: the P x' partials of the next item;  l == 0: nx[0] = index granule
+    wn_u64 nsk[RS];  // l > 0: this slice's skip lane of the next item
+#pragma unroll
+    for (int j = 0; j < 8; ++j) nx[j] = 0;
+#pragma unroll
+    for (int q = 0; q < RS; ++q) nsk[q] = 0;
+    auto request = [&](long long e2, int s2) {  // issue the loads for item (e2, s2)
+        if (e2 >= r.n_eval) return;
+        if (l == 0) {
+            if (e2 > 0) nx[0] = wn_ld_granule(p.gi + s2);
+        } else {
+            if (tid < R) {
+                const wn_u64* g = p.gx + (((size_t)(l - 1) * P) * ns + s2) * R + tid;
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (j < P) nx[j] = wn_ld_granule(g + (size_t)j * ns * R);
+            }
+            if (e2 >= r.n_given - 1) {
+                const wn_u64* gin = p.gs + (((size_t)(l - 1) * P + c) * ns + s2) * S + tid;
+#pragma unroll
+                for (int q = 0; q < RS; ++q) nsk[q] = wn_ld_granule(gin + 256 * q);
+            }
+        }
+    };
+    request(0, 0);
+
+    int buf = 0;
+    for (long long e = 0; e < r.n_eval; ++e) {
+        const bool prime = e < r.n_given - 1;
+        const uint32_t tag = (uint32_t)(e + 1);
+        const long long t = r.t_base + e;
+        for (int s = 0; s < ns; ++s, buf ^= 1) {
+            float* xb = xs + buf * R;
+            cx.t_start = (long long)wall_clock64();
+            float* ring = p.rings + p.ring_off[l] + ((size_t)c * ns + s) * (size_t)ML * R;
+            // queue tap of the NEXT step of this stream, requested now, consumed in the tail
+            float xo[K1];
+            if (d != 1) {
+                long long pos = (t + 1 - d) % ML;
+                if (pos < 0) pos += ML;
+                const float* src = ring + (size_t)pos * R + kq1 * K1;
+#pragma unroll
+                for (int k = 0; k < K1; ++k) xo[k] = src[k];
+            }
+            // ---- 1. layer input x[t] from the registers requested one item ago
+            wn_u64 sk_now[RS];
+#pragma unroll
+            for (int q = 0; q < RS; ++q) sk_now[q] = nsk[q];
+            if (l == 0) {
+                int idx;
+                if (e == 0) {
+                    idx = r.first[(size_t)s * r.n_given];
+                } else {
+                    wn_u64 g = nx[0];
+                    if ((uint32_t)(g >> 32) != (uint32_t)e) {
+                        unsigned spins = 0;
+                        while ((uint32_t)((g = wn_ld_granule(p.gi + s)) >> 32) != (uint32_t)e) {
+                            if ((++spins & 127u) == 0u) {
+                                if (__hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { cx.fail = 1; break; }
+                                if ((long long)wall_clock64() - cx.t_start > r.timeout_ticks) { wn_give_up(cx, WN_W_LOGITS, e, s); break; }
+                            }
+                        }
+                    }
+                    idx = (int)(uint32_t)g & 255;
+                }
+                if (tid < R) xb[tid] = p.start_t[(size_t)idx * R + tid] + (p.start_b ? p.start_b[tid] : 0.f);
+            } else if (tid < R) {
+                bool ok = true;
+                float sum = 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (j < P) { ok = ok && ((uint32_t)(nx[j] >> 32) == tag); sum += __uint_as_float((uint32_t)nx[j]); }
+                if (!ok) sum = wn_poll_sum<8>(cx, p.gx + (((size_t)(l - 1) * P) * ns + s) * R + tid, (size_t)ns * R, P, tag, WN_W_X, e, s);
+                xb[tid] = sum;
+            }
+            {   // request the next item's inputs now; they land while this item computes
+                const int s2 = s + 1 < ns ? s + 1 : 0;
+                request(s2 ? e : e + 1, s2);
+            }
+            if (wn_barrier_failed(cx, failflag)) return;
+            // ---- 2. filter/gate
+            const float xres = (c == 0 && kq2 == 0) ? xb[row2] : 0.f;
+            float acc = wn_dot_lds<K1>(w1, xb + kq1 * K1, pre[s * 256 + tid]);
+            acc = wn_reduce<T1>(acc);
+            const float other = wn_partner<T1>(acc);
+            const float fv = is_gate ? other : acc, gv = is_gate ? acc : other;
+            const float z = wn_gate(fv, gv);
+            if (!is_gate && kq1 == 0) zs[ch] = z;
+            __syncthreads();
+            // ---- 3. residual partial
+            if (l < NL - 1) {
+                float a2 = wn_dot_lds<K2>(w2, zs + kq2 * K2, 0.f);
+                a2 = wn_reduce<T2>(a2);
+                if (kq2 == 0) wn_publish_at(p.gx + ((size_t)cx.w * ns + s) * R + row2, tag, (a2 + bres) + xres, local_x);
+            }
+            // ---- 4. skip partial on this lane of the running skip sum
+            wn_u64* gs = p.gs + ((size_t)cx.w * ns + s) * S;
+            if (!prime) {
+                float a3[RS];
+#pragma unroll
+                for (int q = 0; q < RS; ++q) a3[q] = bskip[q];
+#pragma unroll
+                for (int k = 0; k < DC; ++k) {
+                    const float zk = zs[k];
+#pragma unroll
+                    for (int q = 0; q < RS; ++q) a3[q] += w3[q][k] * zk;
+                }
+#pragma unroll
+                for (int q = 0; q < RS; ++q) {
+                    if (l > 0) {
+                        float v;
+                        if ((uint32_t)(sk_now[q] >> 32) == tag) v = __uint_as_float((uint32_t)sk_now[q]);
+                        else v = wn_poll_fixed<1>(cx, p.gs + (((size_t)(l - 1) * P + c) * ns + s) * S + tid + 256 * q, 0, tag, WN_W_SKIN, e, s);
+                        a3[q] += v;
+                    }
+                    wn_publish_at(gs + tid + 256 * q, tag, a3[q], local_s);
+                }
+            } else if (l == NL - 1) {
+#pragma unroll
+                for (int q = 0; q < RS; ++q) wn_publish_at(gs + tid + 256 * q, tag, 0.f, local_s);
+            }
+            // ---- 5. queue push and the next step's tap 0
+            {
+                if (tid < R) ring[(size_t)(t % ML) * R + tid] = xb[tid];
+                float a0 = kq1 == 0 ? bfg : 0.f;
+                if (d == 1) {
+                    a0 = wn_dot_lds<K1>(w0, xb + kq1 * K1, a0);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < K1; ++k) a0 += w0[k] * xo[k];
+                }
+                pre[s * 256 + tid] = a0;
+            }
+        }
+    }
+}
+
+template <class SH>
+static __device__ void wn_v2_head_multi(const WnPlan& p, const WnRun& r, WnCtx& cx, float* lds, int h) {
+    constexpr int S = SH::S, EC = SH::EC, T3 = SH::T3, K3 = SH::K3, QS = S / 256;
+    using L = WnV2Lds<SH>;
+    const int tid = threadIdx.x, ns = p.n_streams, P = p.P, NL = p.NL;
+    float w4[K3], w5[EC];
+    const float* img = p.blobs + (size_t)NL * P * (SH::NWL * 256) + (size_t)h * (SH::NWH * 256) + tid;
+#pragma unroll
+    for (int k = 0; k < K3; ++k) w4[k] = img[(size_t)k * 256];
+#pragma unroll
+    for (int k = 0; k < EC; ++k) w5[k] = img[(size_t)(K3 + k) * 256];
+    const float b1 = img[(size_t)(K3 + EC) * 256], b2 = img[(size_t)(K3 + EC + 1) * 256];
+    const int kq3 = tid % T3, row3 = tid / T3;
+    float* sk = lds + L::sk;
+    float* ev = lds + L::ev;
+    volatile int* failflag = reinterpret_cast<volatile int*>(lds + L::smp + 48);
+    volatile int* locflags = reinterpret_cast<volatile int*>(lds + L::smp + 52);
+    if (tid == 0) {
+        *failflag = 0;
+        const int mine = wn_xcc_id();
+        __hip_atomic_store(p.xcc_tab + cx.w, (unsigned)(mine + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        locflags[0] = p.allow_plain ? (int)wn_same_xcd(cx, mine, NL * P + p.PA, p.n_smp) : 0;  // logits feed the samplers
+    }
+    __syncthreads();
+    const bool local_l = locflags[0] != 0;
+    wn_u64 ng[QS][8];
+    auto request = [&](long long e2, int s2) {
+        if (e2 >= r.n_eval) return;
+        const wn_u64* gin = p.gs + (((size_t)(NL - 1) * P) * ns + s2) * S + tid;
+#pragma unroll
+        for (int q = 0; q < QS; ++q)
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (j < P) ng[q][j] = wn_ld_granule(gin + 256 * q + (size_t)j * ns * S);
+    };
+#pragma unroll
+    for (int q = 0; q < QS; ++q)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ng[q][j] = 0;
+    request(0, 0);
+    for (long long e = 0; e < r.n_eval; ++e) {
+        const bool prime = e < r.n_given - 1;
+        const uint32_t tag = (uint32_t)(e + 1);
+        for (int s = 0; s < ns; ++s) {
+            cx.t_start = (long long)wall_clock64();
+#pragma unroll
+            for (int q = 0; q < QS; ++q) {
+                bool ok = true;
+                float sum = 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (j < P) { ok = ok && ((uint32_t)(ng[q][j] >> 32) == tag); sum += __uint_as_float((uint32_t)ng[q][j]); }
+                if (!ok) sum = wn_poll_sum<8>(cx, p.gs + (((size_t)(NL - 1) * P) * ns + s) * S + tid + 256 * q, (size_t)ns * S, P, tag, WN_W_HEAD, e, s);
+                sk[tid + 256 * q] = sum > 0.f ? sum : 0.f;
+            }
+            {
+                const int s2 = s + 1 < ns ? s + 1 : 0;
+                request(s2 ? e : e + 1, s2);
+            }
+            if (wn_barrier_failed(cx, failflag)) return;
+            wn_u64* gl = p.gl + ((size_t)h * ns + s) * 256;
+            if (!prime) {
+                float a = wn_dot_lds<K3>(w4, sk + kq3 * K3, 0.f);
+                a = wn_reduce<T3>(a);
+                if (kq3 == 0) {
+                    const float v = a + b1;
+                    ev[row3] = v > 0.f ? v : 0.f;
+                }
+                __syncthreads();
+                wn_publish_at(gl + tid, tag, wn_dot_lds<EC>(w5, ev, b2), local_l);
+            } else {
+                wn_publish_at(gl + tid, tag, 0.f, local_l);
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// Sampler workgroup j of n_smp (multi-stream only): for its streams, turns the head's partial logits of evaluation
+// e-1 into the class index that enters evaluation e (teacher forced while priming) and publishes it as gi[s].
+static __device__ void wn_v2_sampler(const WnPlan& p, const WnRun& r, WnCtx& cx, float* lds_smp, int j) {
+    const int tid = threadIdx.x, ns = p.n_streams;
+    volatile int* failflag = reinterpret_cast<volatile int*>(lds_smp + 48);
+    volatile int* locflags = reinterpret_cast<volatile int*>(lds_smp + 52);
+    if (tid == 0) {
+        *failflag = 0;
+        const int mine = wn_xcc_id();
+        __hip_atomic_store(p.xcc_tab + cx.w, (unsigned)(mine + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        locflags[0] = p.allow_plain ? (int)wn_same_xcd(cx, mine, 0, p.P) : 0;  // the index feeds every slice of layer 0
+    }
+    __syncthreads();
+    const bool local_i = locflags[0] != 0;
+    for (long long e = 1; e <= r.n_eval; ++e) {
+        for (int s = j; s < ns; s += p.n_smp) {
+            cx.t_start = (long long)wall_clock64();
+            const float logit = wn_poll_sum<16>(cx, p.gl + (size_t)s * 256 + tid, (size_t)ns * 256, p.PA, (uint32_t)e, WN_W_LOGITS, e, s);
+            if (wn_barrier_failed(cx, failflag)) return;
+            int idx;
+            if (e < r.n_given) {
+                idx = r.first[(size_t)s * r.n_given + e];
+            } else {
+                const long long g = e - r.n_given;
+                if (r.dbg_logits) r.dbg_logits[((size_t)s * r.num_samples + g) * 256 + tid] = logit;
+                const bool greedy = r.greedy != 0;
+                const double u = greedy ? 0. : r.uniforms[(size_t)s * r.num_samples + g];
+                idx = wn_sample_v2(cx, lds_smp, logit, u, greedy);
+                if (tid == 0) r.out_idx[(size_t)s * r.num_samples + g] = idx;
+            }
+            if (e < r.n_eval && tid == 0) {
+                const wn_u64 v = ((wn_u64)(uint32_t)e << 32) | (wn_u64)(uint32_t)idx;
+                if (local_i) __hip_atomic_store(p.gi + s, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                else __hip_atomic_store(p.gi + s, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __syncthreads();
+        }
+    }
+}
+
+template <int R, int DC, int S, int EC>
+__global__ __launch_bounds__(WN_THREADS) void wn_generate_kernel_v2m(WnPlan p, WnRun r) {
+    using SH = WnV2Shape<R, DC, S, EC>;
+    extern __shared__ __attribute__((aligned(16))) float wn_lds2m[];
+    const int w = p.wg_map[blockIdx.x];
+    if (w < 0) return;
+    WnCtx cx;
+    cx.p = &p; cx.r = &r; cx.lds = wn_lds2m; cx.w = w; cx.fail = 0;
+    cx.t_start = (long long)wall_clock64();
+    const int n_layer_wg = p.NL * p.P;
+    if (w < n_layer_wg) wn_v2_layer_multi<SH>(p, r, cx, wn_lds2m, w / p.P, w % p.P);
+    else if (w < n_layer_wg + p.PA) wn_v2_head_multi<SH>(p, r, cx, wn_lds2m, w - n_layer_wg);
+    else wn_v2_sampler(p, r, cx, wn_lds2m + WnV2Lds<SH>::smp, w - n_layer_wg - p.PA);
+}
+
 template <int R, int DC, int S, int EC>
 __global__ __launch_bounds__(WN_THREADS) void wn_generate_kernel_v2(WnPlan p, WnRun r) {
     using SH = WnV2Shape<R, DC, S, EC>;

@@ -70,6 +70,9 @@ struct WnPlan {
     wn_u64* gx;               // x' partials   [(NL*P)][n_streams][R]
     wn_u64* gs;               // skip lanes    [(NL*P)][n_streams][S]
     wn_u64* gl;               // partial logits[PA][n_streams][C]
+    wn_u64* gi;               // sampled class index per stream [n_streams] (multi-stream kernel: samplers -> L0)
+    int32_t n_smp;            // dedicated sampler workgroups (0 in the single-stream kernels)
+    int32_t pad0;
     uint32_t* status;         // [8] 0: abort code, 1: chain position, 2: eval, 3: stream, 4: where
     uint32_t* xcc_tab;        // [n_wg] XCC id + 1 of every chain position, written by the workgroups at start
     int32_t n_blocks;         // grid size (>= n_wg; blocks mapped to -1 exit at once)
@@ -297,11 +300,11 @@ static inline void wn_make_wg_map(int n_wg, int n_xcd, std::vector<int32_t>& map
 // Layer-aligned placement: every layer's P workgroups (and the head's PA) sit on ONE XCD, so that most hand-offs
 // stay inside one XCD's L2.  XCD 0 hosts the head and the first layers (head -> L0 stays local too).
 // map[b] = chain position of block b, or -1 (bystander).  Returns false if the layers do not fit that way.
-static inline bool wn_make_wg_map_layers(int NL, int P, int PA, int n_xcd, int cu_per_xcd, std::vector<int32_t>& map,
+static inline bool wn_make_wg_map_layers(int NL, int P, int PA, int n_smp, int n_xcd, int cu_per_xcd, std::vector<int32_t>& map,
                                          int* n_blocks) {
     std::vector<std::vector<int>> S(n_xcd);
-    if (PA > cu_per_xcd) return false;
-    for (int h = 0; h < PA; ++h) S[0].push_back(NL * P + h);
+    if (PA + n_smp > cu_per_xcd) return false;
+    for (int h = 0; h < PA + n_smp; ++h) S[0].push_back(NL * P + h);  // head, then samplers
     int next = 0;
     for (int x = 0; x < n_xcd; ++x) {
         const int cap = (cu_per_xcd - (int)S[x].size()) / P;

@@ -96,8 +96,10 @@ __global__ __launch_bounds__(WN_THREADS) void wn_generate_kernel(WnPlan p, WnRun
 struct WnV2Entry {
     int R, DC, S, EC, nwl, nwh;
     const void* fn;
+    const void* fn_multi;
     int (*lds_floats)(int);
     void (*launch)(int grid, size_t lds, hipStream_t st, const WnPlan& p, const WnRun& r);
+    void (*launch_multi)(int grid, size_t lds, hipStream_t st, const WnPlan& p, const WnRun& r);
     void (*pack)(const WnPlan& pl, const WnHostWeights& w, std::vector<float>& out);
 };
 
@@ -155,6 +157,10 @@ static WnV2Entry wn_v2_entry() {
     WnV2Entry e;
     e.R = R; e.DC = DC; e.S = S; e.EC = EC; e.nwl = SH::NWL; e.nwh = SH::NWH;
     e.fn = (const void*)wn_generate_kernel_v2<R, DC, S, EC>;
+    e.fn_multi = (const void*)wn_generate_kernel_v2m<R, DC, S, EC>;
+    e.launch_multi = [](int grid, size_t lds, hipStream_t st, const WnPlan& p, const WnRun& r) {
+        hipLaunchKernelGGL((wn_generate_kernel_v2m<R, DC, S, EC>), dim3(grid), dim3(WN_THREADS), lds, st, p, r);
+    };
     e.lds_floats = [](int ns) { return WnV2Lds<SH>::floats(ns); };
     e.launch = [](int grid, size_t lds, hipStream_t st, const WnPlan& p, const WnRun& r) {
         hipLaunchKernelGGL((wn_generate_kernel_v2<R, DC, S, EC>), dim3(grid), dim3(WN_THREADS), lds, st, p, r);
@@ -176,7 +182,7 @@ static const std::vector<WnV2Entry>& wn_v2_table() {
 }
 
 // picks an instantiated shape for this model; returns its index or -1
-static int wn_v2_choose(const WnPlan& pl, int n_cu, int forced_P, int forced_PA, int* outP, int* outPA) {
+static int wn_v2_choose(const WnPlan& pl, int n_cu, int n_smp, int forced_P, int forced_PA, int* outP, int* outPA) {
     if (pl.k != 2 || pl.C != 256) return -1;
     const std::vector<WnV2Entry>& t = wn_v2_table();
     for (size_t i = 0; i < t.size(); ++i) {
@@ -185,7 +191,7 @@ static int wn_v2_choose(const WnPlan& pl, int n_cu, int forced_P, int forced_PA,
         const int P = pl.D / e.DC, PA = pl.E / e.EC;
         if (P > 8 || PA > 16) continue;
         if ((forced_P > 0 && forced_P != P) || (forced_PA > 0 && forced_PA != PA)) continue;
-        if (pl.NL * P + PA > n_cu) continue;
+        if (pl.NL * P + PA + n_smp > n_cu) continue;
         *outP = P; *outPA = PA;
         return (int)i;
     }
@@ -279,12 +285,15 @@ extern "C" int wn_create(const wn_config* cfg, wn_handle** out) {
     {
         const char* force = getenv("WN_KERNEL");  // "generic" pins the LDS-resident kernel (A/B runs, tests)
         int P2 = 0, PA2 = 0;
-        const int vi = (force && !strcmp(force, "generic")) ? -1 : wn_v2_choose(pl, n_cu, cfg->layer_split, cfg->head_split, &P2, &PA2);
+        const int n_smp = cfg->n_streams > 1 ? (cfg->n_streams < 4 ? cfg->n_streams : 4) : 0;
+        const int vi = (force && !strcmp(force, "generic")) ? -1 : wn_v2_choose(pl, n_cu, n_smp, cfg->layer_split, cfg->head_split, &P2, &PA2);
         if (vi >= 0) {
             h->variant = 2; h->v2_index = vi;
             wn_plan_geometry(pl, P2, PA2);  // fills P, PA, Dc, Ec, n_wg (the LDS-image fields are unused by v2)
+            pl.n_smp = n_smp;
+            pl.n_wg += n_smp;               // sampler workgroups follow the head in the chain
             h->lds_bytes = wn_v2_table()[vi].lds_floats(pl.n_streams) * 4;
-            if (h->lds_bytes > WN_LDS_MAX_BYTES) { h->variant = 1; h->v2_index = -1; }
+            if (h->lds_bytes > WN_LDS_MAX_BYTES) { h->variant = 1; h->v2_index = -1; pl.n_smp = 0; }
         }
     }
 #endif
@@ -310,7 +319,7 @@ extern "C" int wn_create(const wn_config* cfg, wn_handle** out) {
     std::vector<int32_t> wg_map;
     pl.n_blocks = pl.n_wg;
     pl.allow_plain = 0;
-    if (h->variant == 2 && n_cu % 8 == 0 && wn_make_wg_map_layers(pl.NL, pl.P, pl.PA, 8, n_cu / 8, wg_map, &pl.n_blocks)) {
+    if (h->variant == 2 && n_cu % 8 == 0 && wn_make_wg_map_layers(pl.NL, pl.P, pl.PA, pl.n_smp, 8, n_cu / 8, wg_map, &pl.n_blocks)) {
         const char* np = getenv("WN_NO_LOCAL_STORES");
         pl.allow_plain = (np && np[0] == '1') ? 0 : 1;
     } else {
@@ -318,7 +327,7 @@ extern "C" int wn_create(const wn_config* cfg, wn_handle** out) {
     }
     const size_t n_lw = (size_t)pl.NL * pl.P;
     const size_t gx_n = n_lw * pl.n_streams * pl.R, gs_n = n_lw * pl.n_streams * pl.S, gl_n = (size_t)pl.PA * pl.n_streams * pl.C;
-    h->gran_count = gx_n + gs_n + gl_n;
+    h->gran_count = gx_n + gs_n + gl_n + (size_t)pl.n_streams;
     h->blob_floats = n_lw * pl.blob_layer_floats + (size_t)pl.PA * pl.blob_head_floats;
 #ifndef WN_EMU
     if (h->variant == 2) {
@@ -351,11 +360,12 @@ extern "C" int wn_create(const wn_config* cfg, wn_handle** out) {
     if (rc) { wn_destroy(h); return rc; }
     pl.blobs = h->d_blobs; pl.start_t = h->d_start_t; pl.start_b = nullptr;
     pl.dil = h->d_dil; pl.ring_off = h->d_ring_off; pl.wg_map = h->d_wg_map; pl.rings = h->d_rings;
-    pl.gx = h->d_gran; pl.gs = h->d_gran + gx_n; pl.gl = h->d_gran + gx_n + gs_n;
+    pl.gx = h->d_gran; pl.gs = h->d_gran + gx_n; pl.gl = h->d_gran + gx_n + gs_n; pl.gi = h->d_gran + gx_n + gs_n + gl_n;
     pl.status = h->d_status;
     pl.xcc_tab = h->d_status + 8;
 #ifndef WN_EMU
-    rc = rt_hip(hipFuncSetAttribute(h->variant == 2 ? wn_v2_table()[h->v2_index].fn : (const void*)wn_generate_kernel,
+    rc = rt_hip(hipFuncSetAttribute(h->variant == 2 ? (pl.n_smp > 0 ? wn_v2_table()[h->v2_index].fn_multi : wn_v2_table()[h->v2_index].fn)
+                                                    : (const void*)wn_generate_kernel,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes),
                 "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
     if (rc) { wn_destroy(h); return rc; }
@@ -484,7 +494,9 @@ extern "C" int wn_generate(wn_handle* h, const wn_generate_args* a) {
         wn_emu_run(h->plan, r, lds);
     }
 #else
-    if (h->variant == 2)
+    if (h->variant == 2 && h->plan.n_smp > 0)
+        wn_v2_table()[h->v2_index].launch_multi(h->plan.n_blocks, (size_t)h->lds_bytes, (hipStream_t)a->hip_stream, h->plan, r);
+    else if (h->variant == 2)
         wn_v2_table()[h->v2_index].launch(h->plan.n_blocks, (size_t)h->lds_bytes, (hipStream_t)a->hip_stream, h->plan, r);
     else
         hipLaunchKernelGGL(wn_generate_kernel, dim3(h->plan.n_blocks), dim3(WN_THREADS), (size_t)h->lds_bytes,
