@@ -208,10 +208,17 @@ static __device__ bool wn_same_xcd(WnCtx& cx, int mine, int first, int count) {
     return same;
 }
 
+// Workgroup barrier for data exchanged through LDS ONLY.  __syncthreads() also drains every outstanding vector
+// memory operation (s_waitcnt vmcnt(0)): with request loads, queue taps and write-through stores in flight that
+// costs ~1.4 us per step in the multi-stream pipeline.  Here only the LDS counter is waited for.
+static __device__ __forceinline__ void wn_lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // barrier that also tells every lane whether any lane gave up a wait (rare): one s_barrier, one LDS word
 static __device__ __forceinline__ bool wn_barrier_failed(WnCtx& cx, volatile int* flag) {
     if (cx.fail) *flag = 1;
-    __syncthreads();
+    wn_lds_barrier();
     return *flag != 0;
 }
 
@@ -244,19 +251,19 @@ static __device__ __forceinline__ int wn_sample_v2(WnCtx& cx, float* scratch, fl
         if (om > m || (om == m && oa < am)) { m = om; am = oa; }
     }
     if (lane == 0) { fsc[wv] = m; isc[wv] = am; }
-    __syncthreads();
+    wn_lds_barrier();
     float gm = fsc[0];
     int ga = isc[0];
 #pragma unroll
     for (int w = 1; w < 4; ++w)
         if (fsc[w] > gm) { gm = fsc[w]; ga = isc[w]; }  // equal maxima: the lower wave (lower indices) wins
-    if (greedy) { __syncthreads(); return ga; }
+    if (greedy) { wn_lds_barrier(); return ga; }
     const float p = expf(x - gm);
     float ps = p;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) ps += __shfl_xor(ps, off);
     if (lane == 0) fsc[4 + wv] = ps;
-    __syncthreads();
+    wn_lds_barrier();
     const float tot = ((fsc[4] + fsc[5]) + fsc[6]) + fsc[7];
     const float inv = 1.0f / tot;
     const double pd = (double)(p * inv);
@@ -267,17 +274,17 @@ static __device__ __forceinline__ int wn_sample_v2(WnCtx& cx, float* scratch, fl
         if (lane >= off) run += o;
     }
     if (lane == 63) dsc[wv] = run;
-    __syncthreads();
+    wn_lds_barrier();
     double base = 0.;
     for (int w = 0; w < wv; ++w) base += dsc[w];
     const double total = ((dsc[0] + dsc[1]) + dsc[2]) + dsc[3];
     const bool le = (base + run) / total <= u;  // searchsorted(cdf/cdf[-1], u, side='right')
     const int cnt = __popcll(__ballot(le));
     if (lane == 0) isc[4 + wv] = cnt;
-    __syncthreads();
+    wn_lds_barrier();
     int idx = isc[4] + isc[5] + isc[6] + isc[7];
     if (idx > 255) idx = 255;
-    __syncthreads();
+    wn_lds_barrier();
     return idx;
 }
 
@@ -387,7 +394,7 @@ static __device__ void wn_v2_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
                 }
                 if (e == r.n_eval) continue;
                 if (tid < R) xb[tid] = p.start_t[(size_t)idx * R + tid] + (p.start_b ? p.start_b[tid] : 0.f);
-                __syncthreads();
+                wn_lds_barrier();
             } else {
                 if (tid < R) {
                     if (ns == 1) wn_presleep(last_wait);
@@ -407,7 +414,7 @@ static __device__ void wn_v2_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
             wn_stamp(r, park, item, 4);
             const float z = (WN_ABL == 2 || WN_ABL == 5) ? fv * gv * 0.001f : wn_gate(fv, gv);
             if (!is_gate && kq1 == 0) zs[ch] = z;
-            __syncthreads();
+            wn_lds_barrier();
             wn_stamp(r, park, item, 5);
             // ---- 3. residual 1x1 partial, published at once                      (wavenet_model.py:164-165)
             if (l < NL - 1) {
@@ -542,13 +549,13 @@ static __device__ void wn_v2_head(const WnPlan& p, const WnRun& r, WnCtx& cx, fl
                     const float v = a + b1;
                     ev[row3] = v > 0.f ? v : 0.f;  // relu(end_conv_1)  :168
                 }
-                __syncthreads();
+                wn_lds_barrier();
                 wn_publish_at(gl + tid, tag, wn_dot_lds<EC>(w5, ev, b2), local_l);  // partial end_conv_2  :169
             } else {
                 wn_publish_at(gl + tid, tag, 0.f, local_l);
             }
             wn_stamp(r, park, item, 2);
-            __syncthreads();
+            wn_lds_barrier();
             wn_stamp(r, park, item, 3);
             wn_stamp_flush(r, park, cx.w, item);
         }
@@ -601,6 +608,7 @@ static __device__ void wn_v2_layer_multi(const WnPlan& p, const WnRun& r, WnCtx&
     float* smp = lds + L::smp;
     volatile int* failflag = reinterpret_cast<volatile int*>(smp + 48);
     volatile int* locflags = reinterpret_cast<volatile int*>(smp + 52);
+    long long* park = reinterpret_cast<long long*>(lds + L::park);
     if (tid == 0) {
         *failflag = 0;
         const int mine = wn_xcc_id();
@@ -658,6 +666,7 @@ static __device__ void wn_v2_layer_multi(const WnPlan& p, const WnRun& r, WnCtx&
     request(0, 0);
 
     int buf = 0;
+    long long misses = 0;
     for (long long e = 0; e < r.n_eval; ++e) {
         const bool prime = e < r.n_given - 1;
         const uint32_t tag = (uint32_t)(e + 1);
@@ -665,16 +674,9 @@ static __device__ void wn_v2_layer_multi(const WnPlan& p, const WnRun& r, WnCtx&
         for (int s = 0; s < ns; ++s, buf ^= 1) {
             float* xb = xs + buf * R;
             cx.t_start = (long long)wall_clock64();
+            const long long item = e * ns + s;
+            wn_stamp(r, park, item, 0);
             float* ring = p.rings + p.ring_off[l] + ((size_t)c * ns + s) * (size_t)ML * R;
-            // queue tap of the NEXT step of this stream, requested now, consumed in the tail
-            float xo[K1];
-            if (d != 1) {
-                long long pos = (t + 1 - d) % ML;
-                if (pos < 0) pos += ML;
-                const float* src = ring + (size_t)pos * R + kq1 * K1;
-#pragma unroll
-                for (int k = 0; k < K1; ++k) xo[k] = src[k];
-            }
             // ---- 1. layer input x[t] from the registers requested one item ago
             wn_u64 sk_now[RS];
 #pragma unroll
@@ -703,14 +705,26 @@ static __device__ void wn_v2_layer_multi(const WnPlan& p, const WnRun& r, WnCtx&
 #pragma unroll
                 for (int j = 0; j < 8; ++j)
                     if (j < P) { ok = ok && ((uint32_t)(nx[j] >> 32) == tag); sum += __uint_as_float((uint32_t)nx[j]); }
-                if (!ok) sum = wn_poll_sum<8>(cx, p.gx + (((size_t)(l - 1) * P) * ns + s) * R + tid, (size_t)ns * R, P, tag, WN_W_X, e, s);
+                if (!ok) { sum = wn_poll_sum<8>(cx, p.gx + (((size_t)(l - 1) * P) * ns + s) * R + tid, (size_t)ns * R, P, tag, WN_W_X, e, s); if (tid == 0) ++misses; }
                 xb[tid] = sum;
             }
+            wn_stamp(r, park, item, 4);
             {   // request the next item's inputs now; they land while this item computes
                 const int s2 = s + 1 < ns ? s + 1 : 0;
                 request(s2 ? e : e + 1, s2);
             }
+            // queue tap x[t+1-d] of this stream, consumed in the tail.  Requested only now: vector loads return in
+            // order, so an HBM miss issued ahead of the polls would have stalled every poll behind it.
+            float xo[K1];
+            if (d != 1) {
+                long long pos = (t + 1 - d) % ML;
+                if (pos < 0) pos += ML;
+                const float* src = ring + (size_t)pos * R + kq1 * K1;
+#pragma unroll
+                for (int k = 0; k < K1; ++k) xo[k] = src[k];
+            }
             if (wn_barrier_failed(cx, failflag)) return;
+            wn_stamp(r, park, item, 1);
             // ---- 2. filter/gate
             const float xres = (c == 0 && kq2 == 0) ? xb[row2] : 0.f;
             float acc = wn_dot_lds<K1>(w1, xb + kq1 * K1, pre[s * 256 + tid]);
@@ -719,13 +733,14 @@ static __device__ void wn_v2_layer_multi(const WnPlan& p, const WnRun& r, WnCtx&
             const float fv = is_gate ? other : acc, gv = is_gate ? acc : other;
             const float z = wn_gate(fv, gv);
             if (!is_gate && kq1 == 0) zs[ch] = z;
-            __syncthreads();
+            wn_lds_barrier();
             // ---- 3. residual partial
             if (l < NL - 1) {
                 float a2 = wn_dot_lds<K2>(w2, zs + kq2 * K2, 0.f);
                 a2 = wn_reduce<T2>(a2);
                 if (kq2 == 0) wn_publish_at(p.gx + ((size_t)cx.w * ns + s) * R + row2, tag, (a2 + bres) + xres, local_x);
             }
+            wn_stamp(r, park, item, 2);
             // ---- 4. skip partial on this lane of the running skip sum
             wn_u64* gs = p.gs + ((size_t)cx.w * ns + s) * S;
             if (!prime) {
@@ -764,6 +779,9 @@ static __device__ void wn_v2_layer_multi(const WnPlan& p, const WnRun& r, WnCtx&
                 }
                 pre[s * 256 + tid] = a0;
             }
+            wn_stamp(r, park, item, 3);
+            if (r.prof && tid == 0) park[5] = misses;
+            wn_stamp_flush(r, park, cx.w, item);
         }
     }
 }
@@ -785,6 +803,7 @@ static __device__ void wn_v2_head_multi(const WnPlan& p, const WnRun& r, WnCtx& 
     float* ev = lds + L::ev;
     volatile int* failflag = reinterpret_cast<volatile int*>(lds + L::smp + 48);
     volatile int* locflags = reinterpret_cast<volatile int*>(lds + L::smp + 52);
+    long long* park = reinterpret_cast<long long*>(lds + L::park);
     if (tid == 0) {
         *failflag = 0;
         const int mine = wn_xcc_id();
@@ -813,6 +832,8 @@ static __device__ void wn_v2_head_multi(const WnPlan& p, const WnRun& r, WnCtx& 
         const uint32_t tag = (uint32_t)(e + 1);
         for (int s = 0; s < ns; ++s) {
             cx.t_start = (long long)wall_clock64();
+            const long long item = e * ns + s;
+            wn_stamp(r, park, item, 0);
 #pragma unroll
             for (int q = 0; q < QS; ++q) {
                 bool ok = true;
@@ -828,6 +849,7 @@ static __device__ void wn_v2_head_multi(const WnPlan& p, const WnRun& r, WnCtx& 
                 request(s2 ? e : e + 1, s2);
             }
             if (wn_barrier_failed(cx, failflag)) return;
+            wn_stamp(r, park, item, 1);
             wn_u64* gl = p.gl + ((size_t)h * ns + s) * 256;
             if (!prime) {
                 float a = wn_dot_lds<K3>(w4, sk + kq3 * K3, 0.f);
@@ -836,12 +858,15 @@ static __device__ void wn_v2_head_multi(const WnPlan& p, const WnRun& r, WnCtx& 
                     const float v = a + b1;
                     ev[row3] = v > 0.f ? v : 0.f;
                 }
-                __syncthreads();
+                wn_lds_barrier();
                 wn_publish_at(gl + tid, tag, wn_dot_lds<EC>(w5, ev, b2), local_l);
             } else {
                 wn_publish_at(gl + tid, tag, 0.f, local_l);
             }
-            __syncthreads();
+            wn_stamp(r, park, item, 2);
+            wn_lds_barrier();
+            wn_stamp(r, park, item, 3);
+            wn_stamp_flush(r, park, cx.w, item);
         }
     }
 }
@@ -881,7 +906,7 @@ static __device__ void wn_v2_sampler(const WnPlan& p, const WnRun& r, WnCtx& cx,
                 if (local_i) __hip_atomic_store(p.gi + s, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 else __hip_atomic_store(p.gi + s, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            __syncthreads();
+            wn_lds_barrier();
         }
     }
 }

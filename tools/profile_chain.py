@@ -26,7 +26,7 @@ def main():
     eng = engine.Engine(cfg, W, n_streams=ns)
     info = eng.info()
     P, PA, NL = info["layer_split"], info["head_split"], info["n_layers"]
-    N = 400
+    N = 400 if ns == 1 else 60
     items = N * ns
     u = np.random.RandomState(0).random_sample((ns, N))
     eng.generate(N, None, temperature=1.0, uniforms=u)  # warm-up
@@ -43,6 +43,22 @@ def main():
     period = np.diff(st[0, lo:hi:ns, 1]).mean() if ns == 1 else np.diff(st[0, lo:hi, 1][::ns]).mean()
     print("%s x%d: variant %d P=%d PA=%d workgroups %d; loop period %.2f us/eval (%.0f evals/s per stream, %.0f samples/s total)" % (
         cfgname, ns, info["kernel_variant"], P, PA, info["n_workgroups"], period, 1e6 / period, ns * 1e6 / period))
+    if ns > 1:  # pipeline view: who is busy, who waits
+        busy = (T[:, :, 3] - T[:, :, 1]).mean(axis=1)
+        wait = (T[:, :, 1] - T[:, :, 0]).mean(axis=1)
+        per = np.diff(T[:, :, 0], axis=1).mean(axis=1)
+        nlw = NL * P
+        print("per-item period %.3f us.  stage: busy (staged->done) / wait (start->staged), us" % per[:nlw].mean())
+        for l in list(range(0, NL, max(1, NL // 10))) + [NL - 1]:
+            print("  layer %2d: busy %s  wait %s" % (l, np.array2string(busy[l * P:(l + 1) * P], precision=2), np.array2string(wait[l * P:(l + 1) * P], precision=2)))
+        print("  head    : busy %s  wait %s" % (np.array2string(busy[nlw:nlw + PA], precision=2), np.array2string(wait[nlw:nlw + PA], precision=2)))
+        crit = (T[:nlw, :, 2] - T[:nlw, :, 1]).mean()
+        print("  layer staged->published %.3f us, published->done %.3f us" % (crit, (T[:nlw, :, 3] - T[:nlw, :, 2]).mean()))
+        inp = (T[P:nlw, :, 4] - T[P:nlw, :, 0]).mean()
+        print("  layers>0: start->input in registers %.3f us, ->barrier passed %.3f us; request misses %.0f%% of items" % (
+            inp, (T[P:nlw, :, 1] - T[P:nlw, :, 4]).mean(), 100.0 * (st[P:nlw, hi - 1, 5] - st[P:nlw, lo, 5]).mean() / 0.01 / (hi - 1 - lo)))
+        eng.close()
+        return
     # layer hops
     hop = lay[1:, :, :, 1] - lay[:-1, :, :, 2].max(axis=1)[:, None, :]   # staged(l,c) - max_cc published(l-1,cc)
     crit = lay[:, :, :, 2] - lay[:, :, :, 1]
