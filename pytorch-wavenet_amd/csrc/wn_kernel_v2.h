@@ -164,17 +164,17 @@ static __device__ __forceinline__ float wn_poll_sum(WnCtx& cx, const wn_u64* bas
 #define WN_STAMPS 8
 // Stamps are parked in LDS (one ds_write, no vector-memory traffic on the critical path) and flushed to HBM by
 // wn_stamp_flush at the end of the step.
-static __device__ __forceinline__ void wn_stamp(const WnRun& r, long long* park, long long item, int k) {
+static __device__ __forceinline__ void wn_stamp(const WnRun& r, long long* park, long long item, int k, bool cx_single = false) {
     if (r.prof && item < r.prof_items && threadIdx.x == 0) {
         park[k] = (long long)wall_clock64();
-        if (k == 0) park[6] = (long long)clock64();  // shader clock, to read the effective MHz off the stamps
+        if (k == 0 && cx_single) park[6] = (long long)clock64();  // shader clock, to read the effective MHz off the stamps
     }
 }
 static __device__ __forceinline__ void wn_stamp_flush(const WnRun& r, const long long* park, int w, long long item) {
     if (r.prof && item < r.prof_items && threadIdx.x == 0) {
         long long* dst = r.prof + ((size_t)w * r.prof_items + item) * WN_STAMPS;
 #pragma unroll
-        for (int k = 0; k < 7; ++k) dst[k] = park[k];
+        for (int k = 0; k < 8; ++k) dst[k] = park[k];
     }
 }
 
@@ -216,7 +216,8 @@ static __device__ __forceinline__ void wn_lds_barrier() {
 }
 
 // barrier that also tells every lane whether any lane gave up a wait (rare): one s_barrier, one LDS word
-static __device__ __forceinline__ bool wn_barrier_failed(WnCtx& cx, volatile int* flag) {
+static __device__ __forceinline__ bool wn_barrier_failed(WnCtx& cx, int* flag) {  // NOT volatile: a volatile generic
+    // pointer is compiled to FLAT accesses, and a flat load waits for every outstanding vector-memory operation
     if (cx.fail) *flag = 1;
     wn_lds_barrier();
     return *flag != 0;
@@ -324,9 +325,9 @@ static __device__ void wn_v2_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
     float* zs = lds + L::zs;
     float* pre = lds + L::pre;
     float* smp = lds + L::smp;
-    volatile int* failflag = reinterpret_cast<volatile int*>(smp + 48);
+    int* failflag = reinterpret_cast<int*>(smp + 48);
     long long* park = reinterpret_cast<long long*>(lds + L::park);
-    volatile int* locflags = reinterpret_cast<volatile int*>(smp + 52);
+    int* locflags = reinterpret_cast<int*>(smp + 52);
     if (tid == 0) {
         *failflag = 0;
         const int mine = wn_xcc_id();
@@ -492,9 +493,9 @@ static __device__ void wn_v2_head(const WnPlan& p, const WnRun& r, WnCtx& cx, fl
     const int kq3 = tid % T3, row3 = tid / T3;
     float* sk = lds + L::sk;
     float* ev = lds + L::ev;
-    volatile int* failflag = reinterpret_cast<volatile int*>(lds + L::smp + 48);
+    int* failflag = reinterpret_cast<int*>(lds + L::smp + 48);
     long long* park = reinterpret_cast<long long*>(lds + L::park);
-    volatile int* locflags = reinterpret_cast<volatile int*>(lds + L::smp + 52);
+    int* locflags = reinterpret_cast<int*>(lds + L::smp + 52);
     if (tid == 0) {
         *failflag = 0;
         const int mine = wn_xcc_id();
@@ -606,8 +607,8 @@ static __device__ void wn_v2_layer_multi(const WnPlan& p, const WnRun& r, WnCtx&
     float* zs = lds + L::zs;
     float* pre = lds + L::pre;
     float* smp = lds + L::smp;
-    volatile int* failflag = reinterpret_cast<volatile int*>(smp + 48);
-    volatile int* locflags = reinterpret_cast<volatile int*>(smp + 52);
+    int* failflag = reinterpret_cast<int*>(smp + 48);
+    int* locflags = reinterpret_cast<int*>(smp + 52);
     long long* park = reinterpret_cast<long long*>(lds + L::park);
     if (tid == 0) {
         *failflag = 0;
@@ -709,6 +710,7 @@ static __device__ void wn_v2_layer_multi(const WnPlan& p, const WnRun& r, WnCtx&
                 xb[tid] = sum;
             }
             wn_stamp(r, park, item, 4);
+            if (r.prof && item < r.prof_items && tid == 64) park[7] = (long long)wall_clock64();  // wave 1 has its input
             {   // request the next item's inputs now; they land while this item computes
                 const int s2 = s + 1 < ns ? s + 1 : 0;
                 request(s2 ? e : e + 1, s2);
@@ -741,6 +743,7 @@ static __device__ void wn_v2_layer_multi(const WnPlan& p, const WnRun& r, WnCtx&
                 if (kq2 == 0) wn_publish_at(p.gx + ((size_t)cx.w * ns + s) * R + row2, tag, (a2 + bres) + xres, local_x);
             }
             wn_stamp(r, park, item, 2);
+            if (r.prof && item < r.prof_items && tid == 192) park[6] = (long long)wall_clock64();  // wave 3 has published
             // ---- 4. skip partial on this lane of the running skip sum
             wn_u64* gs = p.gs + ((size_t)cx.w * ns + s) * S;
             if (!prime) {
@@ -801,8 +804,8 @@ static __device__ void wn_v2_head_multi(const WnPlan& p, const WnRun& r, WnCtx& 
     const int kq3 = tid % T3, row3 = tid / T3;
     float* sk = lds + L::sk;
     float* ev = lds + L::ev;
-    volatile int* failflag = reinterpret_cast<volatile int*>(lds + L::smp + 48);
-    volatile int* locflags = reinterpret_cast<volatile int*>(lds + L::smp + 52);
+    int* failflag = reinterpret_cast<int*>(lds + L::smp + 48);
+    int* locflags = reinterpret_cast<int*>(lds + L::smp + 52);
     long long* park = reinterpret_cast<long long*>(lds + L::park);
     if (tid == 0) {
         *failflag = 0;
@@ -875,8 +878,8 @@ static __device__ void wn_v2_head_multi(const WnPlan& p, const WnRun& r, WnCtx& 
 // e-1 into the class index that enters evaluation e (teacher forced while priming) and publishes it as gi[s].
 static __device__ void wn_v2_sampler(const WnPlan& p, const WnRun& r, WnCtx& cx, float* lds_smp, int j) {
     const int tid = threadIdx.x, ns = p.n_streams;
-    volatile int* failflag = reinterpret_cast<volatile int*>(lds_smp + 48);
-    volatile int* locflags = reinterpret_cast<volatile int*>(lds_smp + 52);
+    int* failflag = reinterpret_cast<int*>(lds_smp + 48);
+    int* locflags = reinterpret_cast<int*>(lds_smp + 52);
     if (tid == 0) {
         *failflag = 0;
         const int mine = wn_xcc_id();

@@ -33,8 +33,11 @@ def main():
     eng.profile_next(items)
     eng.generate(N, None, temperature=1.0, uniforms=u)
     raw = eng.profile_read(items)
-    mhz = (raw[0, items - 1, 6] - raw[0, items // 2, 6]) / ((raw[0, items - 1, 0] - raw[0, items // 2, 0]) * 0.01)
-    print("shader clock during the job: %.0f MHz" % mhz)
+    if ns > 1:
+        tt = raw[P:NL * P, items // 4:items - ns].astype(np.float64) * 0.01
+        print("multi: wave0 input ready %.3f us after start, wave1 input ready %.3f us, barrier passed %.3f us; wave0 published %.3f, wave3 published %.3f" % (
+            (tt[:, :, 4] - tt[:, :, 0]).mean(), (tt[:, :, 7] - tt[:, :, 0]).mean(), (tt[:, :, 1] - tt[:, :, 0]).mean(),
+            (tt[:, :, 2] - tt[:, :, 0]).mean(), (tt[:, :, 6] - tt[:, :, 0]).mean()))
     st = raw.astype(np.float64) * 0.01  # us
     lo, hi = items // 4, items - ns  # steady state
     T = st[:, lo:hi, :]
