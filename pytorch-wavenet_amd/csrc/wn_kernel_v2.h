@@ -361,10 +361,11 @@ static __device__ void wn_v2_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
     const long long n_it = r.n_eval + (l == 0 ? 1 : 0);
     int buf = 0;
     long long last_wait = 0;
-    for (long long e = 0; e < n_it; ++e) {
+    int tmod = (int)(r.t_base % ML);  // queue slot of x[t]; kept incrementally (a 64-bit modulo costs ~100 scalar ops)
+    for (long long e = 0; e < n_it; ++e, tmod = (tmod + 1 == ML) ? 0 : tmod + 1) {
         const bool prime = e < r.n_given - 1;
         const uint32_t tag = (uint32_t)(e + 1);
-        const long long t = r.t_base + e;
+        const int tapmod = tmod + 2 >= ML ? tmod + 2 - ML : tmod + 2;  // slot of x[t+1-d]: (t+1-d) mod (d+1) = (t+2) mod (d+1)
         for (int s = 0; s < ns; ++s, buf ^= 1) {
             float* xb = xs + buf * R;
             const long long t_begin = (long long)wall_clock64();
@@ -459,14 +460,12 @@ static __device__ void wn_v2_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
             // ---- 5. queue push (wavenet_modules.py:55-57) and the next step's tap 0 on x[t+1-d]
             {
                 float* ring = p.rings + p.ring_off[l] + ((size_t)c * ns + s) * (size_t)ML * R;
-                if (tid < R) ring[(size_t)(t % ML) * R + tid] = xb[tid];
+                if (tid < R) ring[(size_t)tmod * R + tid] = xb[tid];
                 float a0 = kq1 == 0 ? bfg : 0.f;
                 if (d == 1) {
                     a0 = wn_dot_lds<K1>(w0, xb + kq1 * K1, a0);
                 } else {
-                    long long pos = (t + 1 - d) % ML;
-                    if (pos < 0) pos += ML;
-                    const float* xo = ring + (size_t)pos * R + kq1 * K1;
+                    const float* xo = ring + (size_t)tapmod * R + kq1 * K1;
 #pragma unroll
                     for (int k = 0; k < K1; ++k) a0 += w0[k] * xo[k];
                 }
@@ -668,10 +667,11 @@ static __device__ void wn_v2_layer_multi(const WnPlan& p, const WnRun& r, WnCtx&
 
     int buf = 0;
     long long misses = 0;
-    for (long long e = 0; e < r.n_eval; ++e) {
+    int tmod = (int)(r.t_base % ML);  // queue slot of x[t], kept incrementally
+    for (long long e = 0; e < r.n_eval; ++e, tmod = (tmod + 1 == ML) ? 0 : tmod + 1) {
         const bool prime = e < r.n_given - 1;
         const uint32_t tag = (uint32_t)(e + 1);
-        const long long t = r.t_base + e;
+        const int tapmod = tmod + 2 >= ML ? tmod + 2 - ML : tmod + 2;  // slot of x[t+1-d]
         for (int s = 0; s < ns; ++s, buf ^= 1) {
             float* xb = xs + buf * R;
             cx.t_start = (long long)wall_clock64();
@@ -719,9 +719,7 @@ static __device__ void wn_v2_layer_multi(const WnPlan& p, const WnRun& r, WnCtx&
             // order, so an HBM miss issued ahead of the polls would have stalled every poll behind it.
             float xo[K1];
             if (d != 1) {
-                long long pos = (t + 1 - d) % ML;
-                if (pos < 0) pos += ML;
-                const float* src = ring + (size_t)pos * R + kq1 * K1;
+                const float* src = ring + (size_t)tapmod * R + kq1 * K1;
 #pragma unroll
                 for (int k = 0; k < K1; ++k) xo[k] = src[k];
             }
@@ -772,7 +770,7 @@ static __device__ void wn_v2_layer_multi(const WnPlan& p, const WnRun& r, WnCtx&
             }
             // ---- 5. queue push and the next step's tap 0
             {
-                if (tid < R) ring[(size_t)(t % ML) * R + tid] = xb[tid];
+                if (tid < R) ring[(size_t)tmod * R + tid] = xb[tid];
                 float a0 = kq1 == 0 ? bfg : 0.f;
                 if (d == 1) {
                     a0 = wn_dot_lds<K1>(w0, xb + kq1 * K1, a0);
