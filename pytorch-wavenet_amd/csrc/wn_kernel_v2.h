@@ -572,12 +572,12 @@ static __device__ void wn_v2_head(const WnPlan& p, const WnRun& r, WnCtx& cx, fl
 //   * the queue tap x[t+1-d] of the current stream is requested at the top of the item and consumed in its tail;
 //   * sampling is moved off L0 onto NSMP dedicated sampler workgroups (chain positions after the head): they turn
 //     partial logits into a class index per stream and publish it as an index granule gi[s]; L0 only gathers.
-template <class SH>
+template <class SH, int P>
 static __device__ void wn_v2_layer_multi(const WnPlan& p, const WnRun& r, WnCtx& cx, float* lds, int l, int c) {
     constexpr int R = SH::R, DC = SH::DC, S = SH::S, T1 = SH::T1, K1 = SH::K1, T2 = SH::T2, K2 = SH::K2, RS = SH::RS;
     using L = WnV2Lds<SH>;
     const int tid = threadIdx.x;
-    const int ns = p.n_streams, P = p.P, NL = p.NL;
+    const int ns = p.n_streams, NL = p.NL;
     float w1[K1], w0[K1], w2[K2], w3[RS][DC], bskip[RS];
     const float* img = p.blobs + (size_t)cx.w * (SH::NWL * 256) + tid;
     {
@@ -638,32 +638,20 @@ static __device__ void wn_v2_layer_multi(const WnPlan& p, const WnRun& r, WnCtx&
     }
     __syncthreads();
 
-    // one-item-ahead request registers
-    wn_u64 nx[8];    // l > 0, tid < R: the P x' partials of the next item;  l == 0: nx[0] = index granule
-    wn_u64 nsk[RS];  // l > 0: this slice's skip lane of the next item
+    // One-item-ahead request registers.  The request code is branch-free with a compile-time load count: a load
+    // destination that is merged across control flow gets copied, and the copy waits for the load.
+    wn_u64 nx[P];    // l > 0, tid < R: the P x' partials of the next item;  l == 0: the index granule (P copies)
+    wn_u64 nsk[RS];  // this slice's skip lane of the next item (ignored on layer 0 and while priming)
+    const wn_u64* xbase = l == 0 ? p.gi : p.gx + ((size_t)(l - 1) * P) * ns * R + (tid < R ? tid : 0);
+    const size_t xstep_s = l == 0 ? 1 : R, xstep_j = l == 0 ? 0 : (size_t)ns * R;
+    const wn_u64* sbase = p.gs + (((size_t)(l > 0 ? l - 1 : 0) * P + c) * ns) * S + tid;
+    auto request = [&](int s2) {  // issue the loads for the item of stream s2 that comes next
 #pragma unroll
-    for (int j = 0; j < 8; ++j) nx[j] = 0;
+        for (int j = 0; j < P; ++j) nx[j] = wn_ld_granule(xbase + (size_t)s2 * xstep_s + (size_t)j * xstep_j);
 #pragma unroll
-    for (int q = 0; q < RS; ++q) nsk[q] = 0;
-    auto request = [&](long long e2, int s2) {  // issue the loads for item (e2, s2)
-        if (e2 >= r.n_eval) return;
-        if (l == 0) {
-            if (e2 > 0) nx[0] = wn_ld_granule(p.gi + s2);
-        } else {
-            if (tid < R) {
-                const wn_u64* g = p.gx + (((size_t)(l - 1) * P) * ns + s2) * R + tid;
-#pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    if (j < P) nx[j] = wn_ld_granule(g + (size_t)j * ns * R);
-            }
-            if (e2 >= r.n_given - 1) {
-                const wn_u64* gin = p.gs + (((size_t)(l - 1) * P + c) * ns + s2) * S + tid;
-#pragma unroll
-                for (int q = 0; q < RS; ++q) nsk[q] = wn_ld_granule(gin + 256 * q);
-            }
-        }
+        for (int q = 0; q < RS; ++q) nsk[q] = wn_ld_granule(sbase + (size_t)s2 * S + 256 * q);
     };
-    request(0, 0);
+    request(0);
 
     int buf = 0;
     long long misses = 0;
@@ -704,16 +692,14 @@ static __device__ void wn_v2_layer_multi(const WnPlan& p, const WnRun& r, WnCtx&
                 bool ok = true;
                 float sum = 0.f;
 #pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    if (j < P) { ok = ok && ((uint32_t)(nx[j] >> 32) == tag); sum += __uint_as_float((uint32_t)nx[j]); }
-                if (!ok) { sum = wn_poll_sum<8>(cx, p.gx + (((size_t)(l - 1) * P) * ns + s) * R + tid, (size_t)ns * R, P, tag, WN_W_X, e, s); if (tid == 0) ++misses; }
+                for (int j = 0; j < P; ++j) { ok = ok && ((uint32_t)(nx[j] >> 32) == tag); sum += __uint_as_float((uint32_t)nx[j]); }
+                if (!ok) { sum = wn_poll_fixed<P>(cx, p.gx + (((size_t)(l - 1) * P) * ns + s) * R + tid, (size_t)ns * R, tag, WN_W_X, e, s); if (tid == 0) ++misses; }
                 xb[tid] = sum;
             }
             wn_stamp(r, park, item, 4);
             if (r.prof && item < r.prof_items && tid == 64) park[7] = (long long)wall_clock64();  // wave 1 has its input
             {   // request the next item's inputs now; they land while this item computes
-                const int s2 = s + 1 < ns ? s + 1 : 0;
-                request(s2 ? e : e + 1, s2);
+                request(s + 1 < ns ? s + 1 : 0);
             }
             // queue tap x[t+1-d] of this stream, consumed in the tail.  Requested only now: vector loads return in
             // order, so an HBM miss issued ahead of the polls would have stalled every poll behind it.
@@ -787,11 +773,11 @@ static __device__ void wn_v2_layer_multi(const WnPlan& p, const WnRun& r, WnCtx&
     }
 }
 
-template <class SH>
+template <class SH, int P>
 static __device__ void wn_v2_head_multi(const WnPlan& p, const WnRun& r, WnCtx& cx, float* lds, int h) {
     constexpr int S = SH::S, EC = SH::EC, T3 = SH::T3, K3 = SH::K3, QS = S / 256;
     using L = WnV2Lds<SH>;
-    const int tid = threadIdx.x, ns = p.n_streams, P = p.P, NL = p.NL;
+    const int tid = threadIdx.x, ns = p.n_streams, NL = p.NL;
     float w4[K3], w5[EC];
     const float* img = p.blobs + (size_t)NL * P * (SH::NWL * 256) + (size_t)h * (SH::NWH * 256) + tid;
 #pragma unroll
@@ -813,21 +799,15 @@ static __device__ void wn_v2_head_multi(const WnPlan& p, const WnRun& r, WnCtx& 
     }
     __syncthreads();
     const bool local_l = locflags[0] != 0;
-    wn_u64 ng[QS][8];
-    auto request = [&](long long e2, int s2) {
-        if (e2 >= r.n_eval) return;
-        const wn_u64* gin = p.gs + (((size_t)(NL - 1) * P) * ns + s2) * S + tid;
+    wn_u64 ng[QS][P];
+    const wn_u64* gbase = p.gs + ((size_t)(NL - 1) * P) * ns * S + tid;
+    auto request = [&](int s2) {  // branch-free, compile-time count (see wn_v2_layer_multi)
 #pragma unroll
         for (int q = 0; q < QS; ++q)
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
-                if (j < P) ng[q][j] = wn_ld_granule(gin + 256 * q + (size_t)j * ns * S);
+            for (int j = 0; j < P; ++j) ng[q][j] = wn_ld_granule(gbase + (size_t)s2 * S + 256 * q + (size_t)j * ns * S);
     };
-#pragma unroll
-    for (int q = 0; q < QS; ++q)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) ng[q][j] = 0;
-    request(0, 0);
+    request(0);
     for (long long e = 0; e < r.n_eval; ++e) {
         const bool prime = e < r.n_given - 1;
         const uint32_t tag = (uint32_t)(e + 1);
@@ -840,14 +820,12 @@ static __device__ void wn_v2_head_multi(const WnPlan& p, const WnRun& r, WnCtx& 
                 bool ok = true;
                 float sum = 0.f;
 #pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    if (j < P) { ok = ok && ((uint32_t)(ng[q][j] >> 32) == tag); sum += __uint_as_float((uint32_t)ng[q][j]); }
-                if (!ok) sum = wn_poll_sum<8>(cx, p.gs + (((size_t)(NL - 1) * P) * ns + s) * S + tid + 256 * q, (size_t)ns * S, P, tag, WN_W_HEAD, e, s);
+                for (int j = 0; j < P; ++j) { ok = ok && ((uint32_t)(ng[q][j] >> 32) == tag); sum += __uint_as_float((uint32_t)ng[q][j]); }
+                if (!ok) sum = wn_poll_fixed<P>(cx, p.gs + (((size_t)(NL - 1) * P) * ns + s) * S + tid + 256 * q, (size_t)ns * S, tag, WN_W_HEAD, e, s);
                 sk[tid + 256 * q] = sum > 0.f ? sum : 0.f;
             }
             {
-                const int s2 = s + 1 < ns ? s + 1 : 0;
-                request(s2 ? e : e + 1, s2);
+                request(s + 1 < ns ? s + 1 : 0);
             }
             if (wn_barrier_failed(cx, failflag)) return;
             wn_stamp(r, park, item, 1);
@@ -912,7 +890,7 @@ static __device__ void wn_v2_sampler(const WnPlan& p, const WnRun& r, WnCtx& cx,
     }
 }
 
-template <int R, int DC, int S, int EC>
+template <int R, int DC, int S, int EC, int P>
 __global__ __launch_bounds__(WN_THREADS) void wn_generate_kernel_v2m(WnPlan p, WnRun r) {
     using SH = WnV2Shape<R, DC, S, EC>;
     extern __shared__ __attribute__((aligned(16))) float wn_lds2m[];
@@ -922,8 +900,8 @@ __global__ __launch_bounds__(WN_THREADS) void wn_generate_kernel_v2m(WnPlan p, W
     cx.p = &p; cx.r = &r; cx.lds = wn_lds2m; cx.w = w; cx.fail = 0;
     cx.t_start = (long long)wall_clock64();
     const int n_layer_wg = p.NL * p.P;
-    if (w < n_layer_wg) wn_v2_layer_multi<SH>(p, r, cx, wn_lds2m, w / p.P, w % p.P);
-    else if (w < n_layer_wg + p.PA) wn_v2_head_multi<SH>(p, r, cx, wn_lds2m, w - n_layer_wg);
+    if (w < n_layer_wg) wn_v2_layer_multi<SH, P>(p, r, cx, wn_lds2m, w / P, w % P);
+    else if (w < n_layer_wg + p.PA) wn_v2_head_multi<SH, P>(p, r, cx, wn_lds2m, w - n_layer_wg);
     else wn_v2_sampler(p, r, cx, wn_lds2m + WnV2Lds<SH>::smp, w - n_layer_wg - p.PA);
 }
 

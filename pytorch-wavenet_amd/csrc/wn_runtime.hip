@@ -95,6 +95,7 @@ __global__ __launch_bounds__(WN_THREADS) void wn_generate_kernel(WnPlan p, WnRun
 // LDS-resident kernel above.
 struct WnV2Entry {
     int R, DC, S, EC, nwl, nwh;
+    int Pm;  // layer split the multi-stream kernel is compiled for (its request code is unrolled over it)
     const void* fn;
     const void* fn_multi;
     int (*lds_floats)(int);
@@ -151,15 +152,15 @@ static void wn_pack_v2(const WnPlan& pl, const WnHostWeights& w, std::vector<flo
     (void)C;
 }
 
-template <int R, int DC, int S, int EC>
+template <int R, int DC, int S, int EC, int PM>
 static WnV2Entry wn_v2_entry() {
     using SH = WnV2Shape<R, DC, S, EC>;
     WnV2Entry e;
-    e.R = R; e.DC = DC; e.S = S; e.EC = EC; e.nwl = SH::NWL; e.nwh = SH::NWH;
+    e.R = R; e.DC = DC; e.S = S; e.EC = EC; e.nwl = SH::NWL; e.nwh = SH::NWH; e.Pm = PM;
     e.fn = (const void*)wn_generate_kernel_v2<R, DC, S, EC>;
-    e.fn_multi = (const void*)wn_generate_kernel_v2m<R, DC, S, EC>;
+    e.fn_multi = (const void*)wn_generate_kernel_v2m<R, DC, S, EC, PM>;
     e.launch_multi = [](int grid, size_t lds, hipStream_t st, const WnPlan& p, const WnRun& r) {
-        hipLaunchKernelGGL((wn_generate_kernel_v2m<R, DC, S, EC>), dim3(grid), dim3(WN_THREADS), lds, st, p, r);
+        hipLaunchKernelGGL((wn_generate_kernel_v2m<R, DC, S, EC, PM>), dim3(grid), dim3(WN_THREADS), lds, st, p, r);
     };
     e.lds_floats = [](int ns) { return WnV2Lds<SH>::floats(ns); };
     e.launch = [](int grid, size_t lds, hipStream_t st, const WnPlan& p, const WnRun& r) {
@@ -171,12 +172,13 @@ static WnV2Entry wn_v2_entry() {
 
 static const std::vector<WnV2Entry>& wn_v2_table() {
     static const std::vector<WnV2Entry> t = {
-        wn_v2_entry<128, 32, 512, 64>(),   // cfg3: P=4, PA=4
-        wn_v2_entry<64, 64, 256, 64>(),    // cfg2: P=1, PA=4
-        wn_v2_entry<32, 32, 256, 64>(),    // cfg1: P=1, PA=4
-        wn_v2_entry<32, 32, 1024, 32>(),   // train_script.py chaconne shape: P=1, PA=16
-        wn_v2_entry<64, 32, 256, 64>(),    // cfg2 split in two
-        wn_v2_entry<16, 16, 256, 32>(),    // small test shape
+        wn_v2_entry<128, 32, 512, 64, 4>(),   // cfg3: P=4, PA=4
+        wn_v2_entry<64, 64, 256, 64, 1>(),    // cfg2: P=1, PA=4
+        wn_v2_entry<32, 32, 256, 64, 1>(),    // cfg1: P=1, PA=4
+        wn_v2_entry<32, 32, 1024, 32, 1>(),   // train_script.py chaconne shape: P=1, PA=16
+        wn_v2_entry<64, 32, 256, 64, 2>(),    // cfg2 split in two
+        wn_v2_entry<16, 16, 256, 32, 1>(),    // small test shape (P = 1; P = 2 with D = 32 runs single-stream only)
+        wn_v2_entry<16, 16, 256, 32, 2>(),    // ... and its two-slice form for multi-stream
     };
     return t;
 }
@@ -191,6 +193,7 @@ static int wn_v2_choose(const WnPlan& pl, int n_cu, int n_smp, int forced_P, int
         const int P = pl.D / e.DC, PA = pl.E / e.EC;
         if (P > 8 || PA > 16) continue;
         if ((forced_P > 0 && forced_P != P) || (forced_PA > 0 && forced_PA != PA)) continue;
+        if (n_smp > 0 && e.Pm != P) continue;  // the multi-stream kernel is compiled per layer split
         if (pl.NL * P + PA + n_smp > n_cu) continue;
         *outP = P; *outPA = PA;
         return (int)i;
