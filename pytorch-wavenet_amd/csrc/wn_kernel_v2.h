@@ -641,15 +641,12 @@ static __device__ void wn_v2_layer_multi(const WnPlan& p, const WnRun& r, WnCtx&
     // One-item-ahead request registers.  The request code is branch-free with a compile-time load count: a load
     // destination that is merged across control flow gets copied, and the copy waits for the load.
     wn_u64 nx[P];    // l > 0, tid < R: the P x' partials of the next item;  l == 0: the index granule (P copies)
-    wn_u64 nsk[RS];  // this slice's skip lane of the next item (ignored on layer 0 and while priming)
     const wn_u64* xbase = l == 0 ? p.gi : p.gx + ((size_t)(l - 1) * P) * ns * R + (tid < R ? tid : 0);
     const size_t xstep_s = l == 0 ? 1 : R, xstep_j = l == 0 ? 0 : (size_t)ns * R;
     const wn_u64* sbase = p.gs + (((size_t)(l > 0 ? l - 1 : 0) * P + c) * ns) * S + tid;
     auto request = [&](int s2) {  // issue the loads for the item of stream s2 that comes next
 #pragma unroll
         for (int j = 0; j < P; ++j) nx[j] = wn_ld_granule(xbase + (size_t)s2 * xstep_s + (size_t)j * xstep_j);
-#pragma unroll
-        for (int q = 0; q < RS; ++q) nsk[q] = wn_ld_granule(sbase + (size_t)s2 * S + 256 * q);
     };
     request(0);
 
@@ -667,9 +664,6 @@ static __device__ void wn_v2_layer_multi(const WnPlan& p, const WnRun& r, WnCtx&
             wn_stamp(r, park, item, 0);
             float* ring = p.rings + p.ring_off[l] + ((size_t)c * ns + s) * (size_t)ML * R;
             // ---- 1. layer input x[t] from the registers requested one item ago
-            wn_u64 sk_now[RS];
-#pragma unroll
-            for (int q = 0; q < RS; ++q) sk_now[q] = nsk[q];
             if (l == 0) {
                 int idx;
                 if (e == 0) {
@@ -698,9 +692,11 @@ static __device__ void wn_v2_layer_multi(const WnPlan& p, const WnRun& r, WnCtx&
             }
             wn_stamp(r, park, item, 4);
             if (r.prof && item < r.prof_items && tid == 64) park[7] = (long long)wall_clock64();  // wave 1 has its input
-            {   // request the next item's inputs now; they land while this item computes
-                request(s + 1 < ns ? s + 1 : 0);
-            }
+            // this item's skip lane: the upstream published it a little after the x' we just consumed, so a load
+            // issued now lands while the gated unit computes and is checked in the tail
+            wn_u64 sk_now[RS];
+#pragma unroll
+            for (int q = 0; q < RS; ++q) sk_now[q] = wn_ld_granule(sbase + (size_t)s * S + 256 * q);
             // queue tap x[t+1-d] of this stream, consumed in the tail.  Requested only now: vector loads return in
             // order, so an HBM miss issued ahead of the polls would have stalled every poll behind it.
             float xo[K1];
@@ -728,6 +724,10 @@ static __device__ void wn_v2_layer_multi(const WnPlan& p, const WnRun& r, WnCtx&
             }
             wn_stamp(r, park, item, 2);
             if (r.prof && item < r.prof_items && tid == 192) park[6] = (long long)wall_clock64();  // wave 3 has published
+            // Request the NEXT item's x' partials only now: in the stage-bound steady state the upstream slice starts
+            // that item less than one gated unit before us, so a request issued at staging time would come back stale
+            // (measured: 71 % misses) and put a full poll round trip on the next item's critical path.
+            request(s + 1 < ns ? s + 1 : 0);
             // ---- 4. skip partial on this lane of the running skip sum
             wn_u64* gs = p.gs + ((size_t)cx.w * ns + s) * S;
             if (!prime) {

@@ -172,7 +172,8 @@ static WnV2Entry wn_v2_entry() {
 
 static const std::vector<WnV2Entry>& wn_v2_table() {
     static const std::vector<WnV2Entry> t = {
-        wn_v2_entry<128, 32, 512, 64, 4>(),   // cfg3: P=4, PA=4
+        wn_v2_entry<128, 32, 512, 32, 4>(),   // cfg3: P=4, PA=8 (a 64-row head slice is the slowest pipeline stage)
+        wn_v2_entry<128, 32, 512, 64, 4>(),   // cfg3 with PA=4 (head_split=4)
         wn_v2_entry<64, 64, 256, 64, 1>(),    // cfg2: P=1, PA=4
         wn_v2_entry<32, 32, 256, 64, 1>(),    // cfg1: P=1, PA=4
         wn_v2_entry<32, 32, 1024, 32, 1>(),   // train_script.py chaconne shape: P=1, PA=16
