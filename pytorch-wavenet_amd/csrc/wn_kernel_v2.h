@@ -71,16 +71,19 @@ static __device__ __forceinline__ float wn_reduce(float v) {
 }
 
 
-// dot(w[0..K), x[0..K)) with x in LDS: float4 reads, four independent FMA chains (K % 4 == 0), else a plain chain
+// dot(w[0..K), x[0..K)) with x in LDS: all float4 reads issued up front (one LDS latency, not K/16 of them), then
+// four independent FMA chains (K % 4 == 0); else a plain chain
 template <int K>
 static __device__ __forceinline__ float wn_dot_lds(const float (&w)[K], const float* x, float init) {
     if constexpr (K % 4 == 0) {
-        float a0 = init, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        float4 v[K / 4];
         const float4* x4 = reinterpret_cast<const float4*>(x);
 #pragma unroll
+        for (int k = 0; k < K / 4; ++k) v[k] = x4[k];
+        float a0 = init, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
         for (int k = 0; k < K / 4; ++k) {
-            const float4 v = x4[k];
-            a0 += w[4 * k] * v.x; a1 += w[4 * k + 1] * v.y; a2 += w[4 * k + 2] * v.z; a3 += w[4 * k + 3] * v.w;
+            a0 += w[4 * k] * v[k].x; a1 += w[4 * k + 1] * v[k].y; a2 += w[4 * k + 2] * v[k].z; a3 += w[4 * k + 3] * v[k].w;
         }
         return (a0 + a1) + (a2 + a3);
     } else {
