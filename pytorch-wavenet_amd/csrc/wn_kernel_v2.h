@@ -191,7 +191,9 @@ struct WnV2Lds {
     static constexpr int smp = ev + SH::EC;              // sampler scratch: 64 floats (8-byte aligned); [48] = fail flag
     static constexpr int park = smp + 64;                // 8 parked int64 stamps
     static constexpr int pre = park + 16;                 // [n_streams][256]
-    static int floats(int n_streams) { return pre + n_streams * 256; }
+    static __host__ __device__ int floats(int n_streams) { return pre + n_streams * 256; }
+    // single-stream kernel: layer 0 keeps start_conv^T ([C][R]) behind the pre buffer when it fits (p.start_in_lds)
+    static __host__ __device__ int floats_with_start(int n_streams) { return floats(n_streams) + 256 * SH::R; }
 };
 
 // XCC id of this workgroup's CU (HW_REG_XCC_ID, 4 bits)
@@ -234,55 +236,76 @@ static __device__ __forceinline__ void wn_presleep(long long wait_ticks) {
     for (long long i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(32);
 }
 
-// ---- sampler (L0): C = 256 classes, one per lane.  Same arithmetic as wn_sample (wn_kernel.h) /
-// wavenet_model.py:280-294, with wave-level reductions.  Returns the class index (uniform over the block).
+// ---- wave-level helpers for the sampler: 16-lane rows with DPP butterflies, the 4 rows combined through
+// v_readlane (uniform values) -- no ds_bpermute chains (a 6-step __shfl reduction costs ~0.3 us of pure latency).
+static __device__ __forceinline__ float wn_lane_f(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
+static __device__ __forceinline__ float wn_wave_max(float v) {
+    v = fmaxf(v, wn_dpp<0xB1>(v)); v = fmaxf(v, wn_dpp<0x4E>(v)); v = fmaxf(v, wn_dpp<0x141>(v)); v = fmaxf(v, wn_dpp<0x140>(v));
+    return fmaxf(fmaxf(wn_lane_f(v, 0), wn_lane_f(v, 16)), fmaxf(wn_lane_f(v, 32), wn_lane_f(v, 48)));
+}
+static __device__ __forceinline__ float wn_wave_sum(float v) {
+    v += wn_dpp<0xB1>(v); v += wn_dpp<0x4E>(v); v += wn_dpp<0x141>(v); v += wn_dpp<0x140>(v);
+    return (wn_lane_f(v, 0) + wn_lane_f(v, 16)) + (wn_lane_f(v, 32) + wn_lane_f(v, 48));
+}
+template <int CTRL>
+static __device__ __forceinline__ int wn_dpp_i(int x) { return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xf, 0xf, true); }
+static __device__ __forceinline__ int wn_wave_min_i(int v) {
+    v = min(v, wn_dpp_i<0xB1>(v)); v = min(v, wn_dpp_i<0x4E>(v)); v = min(v, wn_dpp_i<0x141>(v)); v = min(v, wn_dpp_i<0x140>(v));
+    return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+               min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+template <int N>  // value held by lane-N of the same 16-lane row, 0.0 where there is none (row_shr:N)
+static __device__ __forceinline__ double wn_row_shr_f64(double v) {
+    const int lo = wn_dpp_i<0x110 + N>(__double2loint(v)), hi = wn_dpp_i<0x110 + N>(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+static __device__ __forceinline__ double wn_lane_d(double v, int lane) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+
+// ---- sampler: C = 256 classes, one per lane.  Same arithmetic as wn_sample (wn_kernel.h) /
+// wavenet_model.py:280-294.  Returns the class index (uniform over the block).
 static __device__ __forceinline__ int wn_sample_v2(WnCtx& cx, float* scratch, float logit, double u, bool greedy) {
     const WnRun& r = *cx.r;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     float* fsc = scratch;                                    // [0..3] wave max, [4..7] wave sum
-    int* isc = reinterpret_cast<int*>(scratch + 8);          // [0..3] wave argmax, [4..7] wave count, [8] result
+    int* isc = reinterpret_cast<int*>(scratch + 8);          // [0..3] wave argmax, [4..7] wave count
     double* dsc = reinterpret_cast<double*>(scratch + 24);   // [0..3] wave totals
     float x = logit;
     if (r.reg) x -= r.reg[tid];
     if (!greedy) x = x / r.temperature;
-    // max and first argmax
-    float m = x;
-    int am = tid;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const float om = __shfl_xor(m, off);
-        const int oa = __shfl_xor(am, off);
-        if (om > m || (om == m && oa < am)) { m = om; am = oa; }
-    }
-    if (lane == 0) { fsc[wv] = m; isc[wv] = am; }
+    const float wm = wn_wave_max(x);
+    if (lane == 0) fsc[wv] = wm;
     wn_lds_barrier();
-    float gm = fsc[0];
-    int ga = isc[0];
-#pragma unroll
-    for (int w = 1; w < 4; ++w)
-        if (fsc[w] > gm) { gm = fsc[w]; ga = isc[w]; }  // equal maxima: the lower wave (lower indices) wins
-    if (greedy) { wn_lds_barrier(); return ga; }
+    const float gm = fmaxf(fmaxf(fsc[0], fsc[1]), fmaxf(fsc[2], fsc[3]));
+    if (greedy) {  // first index of the maximum (torch.max semantics)
+        const int wa = wn_wave_min_i(x == gm ? tid : 0x7fffffff);
+        if (lane == 0) isc[wv] = wa;
+        wn_lds_barrier();
+        const int ga = min(min(isc[0], isc[1]), min(isc[2], isc[3]));
+        wn_lds_barrier();
+        return ga;
+    }
     const float p = expf(x - gm);
-    float ps = p;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) ps += __shfl_xor(ps, off);
-    if (lane == 0) fsc[4 + wv] = ps;
+    const float ws = wn_wave_sum(p);
+    if (lane == 0) fsc[4 + wv] = ws;
     wn_lds_barrier();
     const float tot = ((fsc[4] + fsc[5]) + fsc[6]) + fsc[7];
     const float inv = 1.0f / tot;
-    const double pd = (double)(p * inv);
-    double run = pd;  // inclusive scan inside the wave (float64, like np.cumsum)
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const double o = __shfl_up(run, off);
-        if (lane >= off) run += o;
-    }
-    if (lane == 63) dsc[wv] = run;
+    double run = (double)(p * inv);  // inclusive float64 scan (np.cumsum): rows by DPP, rows joined by readlane
+    run += wn_row_shr_f64<1>(run);
+    run += wn_row_shr_f64<2>(run);
+    run += wn_row_shr_f64<4>(run);
+    run += wn_row_shr_f64<8>(run);
+    const double r0 = wn_lane_d(run, 15), r1 = wn_lane_d(run, 31), r2 = wn_lane_d(run, 47), r3 = wn_lane_d(run, 63);
+    const int row = lane >> 4;
+    run += row == 0 ? 0. : row == 1 ? r0 : row == 2 ? r0 + r1 : (r0 + r1) + r2;
+    if (lane == 0) dsc[wv] = ((r0 + r1) + r2) + r3;
     wn_lds_barrier();
     double base = 0.;
     for (int w = 0; w < wv; ++w) base += dsc[w];
     const double total = ((dsc[0] + dsc[1]) + dsc[2]) + dsc[3];
-    const bool le = (base + run) / total <= u;  // searchsorted(cdf/cdf[-1], u, side='right')
+    const bool le = (base + run) / total <= u;  // searchsorted(cdf / cdf[-1], u, side='right')
     const int cnt = __popcll(__ballot(le));
     if (lane == 0) isc[4 + wv] = cnt;
     wn_lds_barrier();
@@ -349,6 +372,13 @@ static __device__ void wn_v2_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
     __syncthreads();
     const bool local_x = locflags[0] != 0, local_s = locflags[1] != 0;
 
+    // layer 0: the start_conv column gather (wavenet_model.py:127) reads LDS instead of L2/HBM when the table fits
+    const float* start_tab = p.start_t;
+    if (l == 0 && p.start_in_lds) {
+        float* st = lds + L::floats(ns);
+        for (int i = tid; i < 256 * R; i += 256) st[i] = p.start_t[i];
+        start_tab = st;
+    }
     // tap-0 contribution for the first evaluation of every stream: x[t_base - d] from the queue (zeros after reset)
     for (int s = 0; s < ns; ++s) {
         const float* ring = p.rings + p.ring_off[l] + ((size_t)c * ns + s) * (size_t)ML * R;
@@ -398,7 +428,7 @@ static __device__ void wn_v2_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
                     }
                 }
                 if (e == r.n_eval) continue;
-                if (tid < R) xb[tid] = p.start_t[(size_t)idx * R + tid] + (p.start_b ? p.start_b[tid] : 0.f);
+                if (tid < R) xb[tid] = start_tab[(size_t)idx * R + tid] + (p.start_b ? p.start_b[tid] : 0.f);
                 wn_lds_barrier();
             } else {
                 if (tid < R) {

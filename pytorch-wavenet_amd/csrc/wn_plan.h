@@ -72,7 +72,7 @@ struct WnPlan {
     wn_u64* gl;               // partial logits[PA][n_streams][C]
     wn_u64* gi;               // sampled class index per stream [n_streams] (multi-stream kernel: samplers -> L0)
     int32_t n_smp;            // dedicated sampler workgroups (0 in the single-stream kernels)
-    int32_t pad0;
+    int32_t start_in_lds;     // v2 single-stream: layer 0 holds start_conv^T in LDS
     uint32_t* status;         // [8] 0: abort code, 1: chain position, 2: eval, 3: stream, 4: where
     uint32_t* xcc_tab;        // [n_wg] XCC id + 1 of every chain position, written by the workgroups at start
     int32_t n_blocks;         // grid size (>= n_wg; blocks mapped to -1 exit at once)

@@ -99,6 +99,7 @@ struct WnV2Entry {
     const void* fn;
     const void* fn_multi;
     int (*lds_floats)(int);
+    int (*lds_floats_with_start)(int);
     void (*launch)(int grid, size_t lds, hipStream_t st, const WnPlan& p, const WnRun& r);
     void (*launch_multi)(int grid, size_t lds, hipStream_t st, const WnPlan& p, const WnRun& r);
     void (*pack)(const WnPlan& pl, const WnHostWeights& w, std::vector<float>& out);
@@ -163,6 +164,7 @@ static WnV2Entry wn_v2_entry() {
         hipLaunchKernelGGL((wn_generate_kernel_v2m<R, DC, S, EC, PM>), dim3(grid), dim3(WN_THREADS), lds, st, p, r);
     };
     e.lds_floats = [](int ns) { return WnV2Lds<SH>::floats(ns); };
+    e.lds_floats_with_start = [](int ns) { return WnV2Lds<SH>::floats_with_start(ns); };
     e.launch = [](int grid, size_t lds, hipStream_t st, const WnPlan& p, const WnRun& r) {
         hipLaunchKernelGGL((wn_generate_kernel_v2<R, DC, S, EC>), dim3(grid), dim3(WN_THREADS), lds, st, p, r);
     };
@@ -297,6 +299,11 @@ extern "C" int wn_create(const wn_config* cfg, wn_handle** out) {
             pl.n_smp = n_smp;
             pl.n_wg += n_smp;               // sampler workgroups follow the head in the chain
             h->lds_bytes = wn_v2_table()[vi].lds_floats(pl.n_streams) * 4;
+            pl.start_in_lds = 0;
+            if (n_smp == 0 && wn_v2_table()[vi].lds_floats_with_start(pl.n_streams) * 4 <= WN_LDS_MAX_BYTES) {
+                pl.start_in_lds = 1;
+                h->lds_bytes = wn_v2_table()[vi].lds_floats_with_start(pl.n_streams) * 4;
+            }
             if (h->lds_bytes > WN_LDS_MAX_BYTES) { h->variant = 1; h->v2_index = -1; pl.n_smp = 0; }
         }
     }
