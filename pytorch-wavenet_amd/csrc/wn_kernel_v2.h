@@ -43,6 +43,8 @@ struct WnV2Shape {
     // per-lane register images (floats), stored striped in HBM: image[j*256 + tid]
     static constexpr int NWL = 2 * K1 + K2 + RS * DC + 2 + RS;  // w1 | w0 | w2 | w3 | bias_fg, bias_res | bias_skip[RS]
     static constexpr int NWH = K3 + EC + 2;                     // end1 slice | end2 row | b1 | b2
+    static __host__ __device__ constexpr int xpad(int ch) { return ch + 4 * (ch / K1); }    // LDS index of x[ch]
+    static __host__ __device__ constexpr int skpad(int i) { return i + 4 * (i / K3); }      // LDS index of skip[i]
     static_assert(G1 <= 256 && 256 % G1 == 0 && T1 <= 16, "fg rows must tile 256 lanes");
     static_assert(R <= 256 && 256 % R == 0 && T2 <= 16, "residual rows must tile 256 lanes");
     static_assert(R % T1 == 0 && DC % T2 == 0 && S % 256 == 0 && 256 % EC == 0 && S % T3 == 0 && T3 <= 16, "shape");
@@ -184,10 +186,14 @@ static __device__ __forceinline__ void wn_stamp_flush(const WnRun& r, const long
 // LDS layout (floats) of the v2 kernel
 template <class SH>
 struct WnV2Lds {
-    static constexpr int xs = 0;                         // [2][R]
-    static constexpr int zs = xs + 2 * SH::R;            // [DC]
-    static constexpr int sk = zs + ((SH::DC + 3) & ~3);  // [S]    head
-    static constexpr int ev = sk + SH::S;                // [EC]   head
+    // k-slices that different lanes of a wave read with ds_read_b128 are spaced K+4 floats apart: at a power-of-two
+    // spacing they start on the same banks (8-way conflicts on the head's 256-byte slices, 2-way on the layer's)
+    static constexpr int XR = SH::R + 4 * SH::T1;        // padded length of one x buffer
+    static constexpr int SKP = SH::S + 4 * SH::T3;       // padded length of the head's skip vector
+    static constexpr int xs = 0;                         // [2][XR]
+    static constexpr int zs = xs + 2 * XR;               // [DC]
+    static constexpr int sk = zs + ((SH::DC + 3) & ~3);  // [SKP]  head
+    static constexpr int ev = sk + SKP;                  // [EC]   head
     static constexpr int smp = ev + SH::EC;              // sampler scratch: 64 floats (8-byte aligned); [48] = fail flag
     static constexpr int park = smp + 64;                // 8 parked int64 stamps
     static constexpr int pre = park + 16;                 // [n_streams][256]
@@ -400,7 +406,7 @@ static __device__ void wn_v2_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
         const uint32_t tag = (uint32_t)(e + 1);
         const int tapmod = tmod + 2 >= ML ? tmod + 2 - ML : tmod + 2;  // slot of x[t+1-d]: (t+1-d) mod (d+1) = (t+2) mod (d+1)
         for (int s = 0; s < ns; ++s, buf ^= 1) {
-            float* xb = xs + buf * R;
+            float* xb = xs + buf * L::XR;
             const long long t_begin = (long long)wall_clock64();
             cx.t_start = t_begin;  // the spin bound is per hand-off wait, not per job
             const long long item = e * ns + s;
@@ -428,21 +434,21 @@ static __device__ void wn_v2_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
                     }
                 }
                 if (e == r.n_eval) continue;
-                if (tid < R) xb[tid] = start_tab[(size_t)idx * R + tid] + (p.start_b ? p.start_b[tid] : 0.f);
+                if (tid < R) xb[SH::xpad(tid)] = start_tab[(size_t)idx * R + tid] + (p.start_b ? p.start_b[tid] : 0.f);
                 wn_lds_barrier();
             } else {
                 if (tid < R) {
                     if (ns == 1) wn_presleep(last_wait);
                     const wn_u64* g = p.gx + (((size_t)(l - 1) * P) * ns + s) * R + tid;
-                    xb[tid] = wn_poll_sum<8>(cx, g, (size_t)ns * R, P, tag, WN_W_X, e, s);
+                    xb[SH::xpad(tid)] = wn_poll_sum<8>(cx, g, (size_t)ns * R, P, tag, WN_W_X, e, s);
                     last_wait = (long long)wall_clock64() - t_begin;
                 }
                 if (wn_barrier_failed(cx, failflag)) return;
             }
             wn_stamp(r, park, item, 1);
             // ---- 2. filter/gate: tap 1 on x[t] + parked tap 0, tanh * sigmoid   (wavenet_model.py:147-151)
-            const float xres = (c == 0 && kq2 == 0) ? xb[row2] : 0.f;  // newest tap for the residual add, fetched early
-            float acc = (WN_ABL == 1 || WN_ABL == 5) ? pre[s * 256 + tid] + w1[0] : wn_dot_lds<K1>(w1, xb + kq1 * K1, pre[s * 256 + tid]);
+            const float xres = (c == 0 && kq2 == 0) ? xb[SH::xpad(row2)] : 0.f;  // newest tap for the residual add, fetched early
+            float acc = (WN_ABL == 1 || WN_ABL == 5) ? pre[s * 256 + tid] + w1[0] : wn_dot_lds<K1>(w1, xb + kq1 * (K1 + 4), pre[s * 256 + tid]);
             acc = wn_reduce<T1>(acc);
             const float other = wn_partner<T1>(acc);  // the gate (resp. filter) row of the same channel
             const float fv = is_gate ? other : acc, gv = is_gate ? acc : other;
@@ -493,10 +499,10 @@ static __device__ void wn_v2_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
             // ---- 5. queue push (wavenet_modules.py:55-57) and the next step's tap 0 on x[t+1-d]
             {
                 float* ring = p.rings + p.ring_off[l] + ((size_t)c * ns + s) * (size_t)ML * R;
-                if (tid < R) ring[(size_t)tmod * R + tid] = xb[tid];
+                if (tid < R) ring[(size_t)tmod * R + tid] = xb[SH::xpad(tid)];
                 float a0 = kq1 == 0 ? bfg : 0.f;
                 if (d == 1) {
-                    a0 = wn_dot_lds<K1>(w0, xb + kq1 * K1, a0);
+                    a0 = wn_dot_lds<K1>(w0, xb + kq1 * (K1 + 4), a0);
                 } else {
                     const float* xo = ring + (size_t)tapmod * R + kq1 * K1;
 #pragma unroll
@@ -562,13 +568,13 @@ static __device__ void wn_v2_head(const WnPlan& p, const WnRun& r, WnCtx& cx, fl
 #pragma unroll
                     for (int cc = 0; cc < 4; ++cc) { ok = ok && ((uint32_t)(v[q][cc] >> 32) == tag); sum += __uint_as_float((uint32_t)v[q][cc]); }
                     if (!ok) sum = wn_poll_fixed<4>(cx, gin + 256 * q, (size_t)ns * S, tag, WN_W_HEAD, e, s);
-                    sk[tid + 256 * q] = sum > 0.f ? sum : 0.f;  // relu(skip)  wavenet_model.py:167
+                    sk[SH::skpad(tid + 256 * q)] = sum > 0.f ? sum : 0.f;  // relu(skip)  wavenet_model.py:167
                 }
             } else {
 #pragma unroll
                 for (int q = 0; q < QS; ++q) {
                     const float v = wn_poll_sum<8>(cx, gin + 256 * q, (size_t)ns * S, P, tag, WN_W_HEAD, e, s);
-                    sk[tid + 256 * q] = v > 0.f ? v : 0.f;
+                    sk[SH::skpad(tid + 256 * q)] = v > 0.f ? v : 0.f;
                 }
             }
             if (wn_barrier_failed(cx, failflag)) return;
@@ -576,7 +582,7 @@ static __device__ void wn_v2_head(const WnPlan& p, const WnRun& r, WnCtx& cx, fl
             wn_stamp(r, park, item, 1);
             wn_u64* gl = p.gl + ((size_t)h * ns + s) * 256;
             if (!prime) {
-                float a = wn_dot_lds<K3>(w4, sk + kq3 * K3, 0.f);
+                float a = wn_dot_lds<K3>(w4, sk + kq3 * (K3 + 4), 0.f);
                 a = wn_reduce<T3>(a);
                 if (kq3 == 0) {
                     const float v = a + b1;
@@ -691,7 +697,7 @@ static __device__ void wn_v2_layer_multi(const WnPlan& p, const WnRun& r, WnCtx&
         const uint32_t tag = (uint32_t)(e + 1);
         const int tapmod = tmod + 2 >= ML ? tmod + 2 - ML : tmod + 2;  // slot of x[t+1-d]
         for (int s = 0; s < ns; ++s, buf ^= 1) {
-            float* xb = xs + buf * R;
+            float* xb = xs + buf * L::XR;
             cx.t_start = (long long)wall_clock64();
             const long long item = e * ns + s;
             wn_stamp(r, park, item, 0);
@@ -714,14 +720,14 @@ static __device__ void wn_v2_layer_multi(const WnPlan& p, const WnRun& r, WnCtx&
                     }
                     idx = (int)(uint32_t)g & 255;
                 }
-                if (tid < R) xb[tid] = p.start_t[(size_t)idx * R + tid] + (p.start_b ? p.start_b[tid] : 0.f);
+                if (tid < R) xb[SH::xpad(tid)] = p.start_t[(size_t)idx * R + tid] + (p.start_b ? p.start_b[tid] : 0.f);
             } else if (tid < R) {
                 bool ok = true;
                 float sum = 0.f;
 #pragma unroll
                 for (int j = 0; j < P; ++j) { ok = ok && ((uint32_t)(nx[j] >> 32) == tag); sum += __uint_as_float((uint32_t)nx[j]); }
                 if (!ok) { sum = wn_poll_fixed<P>(cx, p.gx + (((size_t)(l - 1) * P) * ns + s) * R + tid, (size_t)ns * R, tag, WN_W_X, e, s); if (tid == 0) ++misses; }
-                xb[tid] = sum;
+                xb[SH::xpad(tid)] = sum;
             }
             wn_stamp(r, park, item, 4);
             if (r.prof && item < r.prof_items && tid == 64) park[7] = (long long)wall_clock64();  // wave 1 has its input
@@ -741,8 +747,8 @@ static __device__ void wn_v2_layer_multi(const WnPlan& p, const WnRun& r, WnCtx&
             if (wn_barrier_failed(cx, failflag)) return;
             wn_stamp(r, park, item, 1);
             // ---- 2. filter/gate
-            const float xres = (c == 0 && kq2 == 0) ? xb[row2] : 0.f;
-            float acc = wn_dot_lds<K1>(w1, xb + kq1 * K1, pre[s * 256 + tid]);
+            const float xres = (c == 0 && kq2 == 0) ? xb[SH::xpad(row2)] : 0.f;
+            float acc = wn_dot_lds<K1>(w1, xb + kq1 * (K1 + 4), pre[s * 256 + tid]);
             acc = wn_reduce<T1>(acc);
             const float other = wn_partner<T1>(acc);
             const float fv = is_gate ? other : acc, gv = is_gate ? acc : other;
@@ -789,10 +795,10 @@ static __device__ void wn_v2_layer_multi(const WnPlan& p, const WnRun& r, WnCtx&
             }
             // ---- 5. queue push and the next step's tap 0
             {
-                if (tid < R) ring[(size_t)tmod * R + tid] = xb[tid];
+                if (tid < R) ring[(size_t)tmod * R + tid] = xb[SH::xpad(tid)];
                 float a0 = kq1 == 0 ? bfg : 0.f;
                 if (d == 1) {
-                    a0 = wn_dot_lds<K1>(w0, xb + kq1 * K1, a0);
+                    a0 = wn_dot_lds<K1>(w0, xb + kq1 * (K1 + 4), a0);
                 } else {
 #pragma unroll
                     for (int k = 0; k < K1; ++k) a0 += w0[k] * xo[k];
@@ -855,7 +861,7 @@ static __device__ void wn_v2_head_multi(const WnPlan& p, const WnRun& r, WnCtx& 
 #pragma unroll
                 for (int j = 0; j < P; ++j) { ok = ok && ((uint32_t)(ng[q][j] >> 32) == tag); sum += __uint_as_float((uint32_t)ng[q][j]); }
                 if (!ok) sum = wn_poll_fixed<P>(cx, p.gs + (((size_t)(NL - 1) * P) * ns + s) * S + tid + 256 * q, (size_t)ns * S, tag, WN_W_HEAD, e, s);
-                sk[tid + 256 * q] = sum > 0.f ? sum : 0.f;
+                sk[SH::skpad(tid + 256 * q)] = sum > 0.f ? sum : 0.f;
             }
             {
                 request(s + 1 < ns ? s + 1 : 0);
@@ -864,7 +870,7 @@ static __device__ void wn_v2_head_multi(const WnPlan& p, const WnRun& r, WnCtx& 
             wn_stamp(r, park, item, 1);
             wn_u64* gl = p.gl + ((size_t)h * ns + s) * 256;
             if (!prime) {
-                float a = wn_dot_lds<K3>(w4, sk + kq3 * K3, 0.f);
+                float a = wn_dot_lds<K3>(w4, sk + kq3 * (K3 + 4), 0.f);
                 a = wn_reduce<T3>(a);
                 if (kq3 == 0) {
                     const float v = a + b1;
