@@ -469,9 +469,10 @@ static __device__ void wn_v2_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
             if (!prime) {
                 const wn_u64* gin = p.gs + (((size_t)(l - 1) * P + c) * ns + s) * S + tid;  // only read when l > 0
                 wn_u64 sv[RS];
-                if (l > 0) {
+                if (l > 0) {  // (requested only now: the compiler joins every outstanding load at the top of the gated
+                              //  unit with s_waitcnt vmcnt(0), an earlier request would stall the critical path)
 #pragma unroll
-                    for (int q = 0; q < RS; ++q) sv[q] = wn_ld_granule(gin + 256 * q);  // in flight during the FMAs
+                    for (int q = 0; q < RS; ++q) sv[q] = wn_ld_granule(gin + 256 * q);
                 }
                 float a3[RS];
 #pragma unroll

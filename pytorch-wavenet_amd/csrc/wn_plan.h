@@ -302,25 +302,29 @@ static inline void wn_make_wg_map(int n_wg, int n_xcd, std::vector<int32_t>& map
 // map[b] = chain position of block b, or -1 (bystander).  Returns false if the layers do not fit that way.
 static inline bool wn_make_wg_map_layers(int NL, int P, int PA, int n_smp, int n_xcd, int cu_per_xcd, std::vector<int32_t>& map,
                                          int* n_blocks) {
-    std::vector<std::vector<int>> S(n_xcd);
     if (PA + n_smp > cu_per_xcd) return false;
-    for (int h = 0; h < PA + n_smp; ++h) S[0].push_back(NL * P + h);  // head, then samplers
-    int next = 0;
-    for (int x = 0; x < n_xcd; ++x) {
-        const int cap = (cu_per_xcd - (int)S[x].size()) / P;
-        const int want = wn_cdiv(NL - next, n_xcd - x);
-        const int take = want < cap ? want : cap;
-        for (int l = next; l < next + take; ++l)
-            for (int c = 0; c < P; ++c) S[x].push_back(l * P + c);
-        next += take;
+    // use as FEW XCDs as hold the chain: every XCD boundary the token crosses costs ~0.4 us more than a local hop
+    for (int used = 1; used <= n_xcd; ++used) {
+        std::vector<std::vector<int>> S(n_xcd);
+        for (int h = 0; h < PA + n_smp; ++h) S[0].push_back(NL * P + h);  // head, then samplers
+        int next = 0;
+        for (int x = 0; x < used; ++x) {
+            const int cap = (cu_per_xcd - (int)S[x].size()) / P;
+            const int want = wn_cdiv(NL - next, used - x);
+            const int take = want < cap ? want : cap;
+            for (int l = next; l < next + take; ++l)
+                for (int c = 0; c < P; ++c) S[x].push_back(l * P + c);
+            next += take;
+        }
+        if (next < NL) continue;
+        size_t per = 0;
+        for (int x = 0; x < n_xcd; ++x) per = S[x].size() > per ? S[x].size() : per;
+        *n_blocks = (int)per * n_xcd;
+        map.assign(*n_blocks, -1);
+        for (int b = 0; b < *n_blocks; ++b)
+            if ((size_t)(b / n_xcd) < S[b % n_xcd].size()) map[b] = S[b % n_xcd][b / n_xcd];
+        return true;
     }
-    if (next < NL) return false;
-    size_t per = 0;
-    for (int x = 0; x < n_xcd; ++x) per = S[x].size() > per ? S[x].size() : per;
-    *n_blocks = (int)per * n_xcd;
-    map.assign(*n_blocks, -1);
-    for (int b = 0; b < *n_blocks; ++b)
-        if ((size_t)(b / n_xcd) < S[b % n_xcd].size()) map[b] = S[b % n_xcd][b / n_xcd];
-    return true;
+    return false;
 }
 #endif  // WN_PLAN_H
