@@ -176,7 +176,7 @@ def main():
                    "chain": {k: info[k] for k in ("kernel_variant", "layer_split", "head_split", "n_workgroups", "lds_bytes")}},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                     "kernel": "wn_generate_kernel_v2" if info["kernel_variant"] == 2 else "wn_generate_kernel", "kernel_ms_per_launch": round(kernel_ms, 3),
+                     "kernel": ("wn_generate_kernel_v2m" if per_gpu > 1 else "wn_generate_kernel_v2") if info["kernel_variant"] == 2 else "wn_generate_kernel", "kernel_ms_per_launch": round(kernel_ms, 3),
                      "algorithmic_bytes_per_launch": int(bytes_per_launch),
                      "algorithmic_bytes_per_timestep": int(bytes_per_tstep), "launches_per_step": 1},
     }

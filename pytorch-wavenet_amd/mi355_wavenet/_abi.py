@@ -59,6 +59,11 @@ class Library:
     def __init__(self, path, host_memory=False):
         self.path = path
         self.host_memory = host_memory
+        if not host_memory:
+            # One HIP runtime per process: torch bundles its own libamdhip64.so.7; importing torch FIRST makes the loader
+            # resolve our DT_NEEDED libamdhip64.so.7 to that already-loaded copy, so torch's device pointers and streams
+            # are valid in our launches (two runtimes in one process cannot even both open the device).
+            import torch  # noqa: F401
         self.dll = ctypes.CDLL(path)
         d = self.dll
         for name in EXPORTS:
@@ -103,9 +108,5 @@ def load_product_library():
             raise RuntimeError(
                 "mi355_wavenet: %s not found. Build it with `python pytorch-wavenet_amd/build.py` (needs hipcc, "
                 "targets gfx950). The generation path has no CPU/torch fallback." % PRODUCT_LIB)
-        # One HIP runtime per process: torch bundles its own libamdhip64.so.7; importing torch FIRST makes the
-        # loader resolve our DT_NEEDED libamdhip64.so.7 to that already-loaded copy, so torch's device pointers and
-        # streams are valid in our launches (two runtimes in one process cannot even both open the device).
-        import torch  # noqa: F401
         _product = Library(PRODUCT_LIB, host_memory=False)
     return _product
