@@ -147,6 +147,14 @@ int wn_get_info(wn_handle* h, wn_info* out);
  * (wavenet_modules.py:43-57).  For tests and for facade code that inspects model.dilated_queues. */
 int wn_export_queue(wn_handle* h, int32_t layer, int32_t stream, float* host_data, int32_t* in_pos, int32_t* out_pos);
 
+/* WaveNetModel.forward() (wavenet_model.py:186-196) for one-hot inputs given as class indices: `indices` is a DEVICE
+ * pointer to int32 [N][L]; writes fp32 logits [N*output_length][classes] (row = n*output_length + t, like the reference's
+ * transpose+view at :194-196) to the DEVICE pointer `logits`.  The dilated-conv stack runs as fp32 matrix-core GEMMs
+ * (csrc/wn_forward.h).  Asynchronous on hip_stream.  WN_E_UNSUPPORTED when L < receptive_field + output_length - 1 (the
+ * reference then zero-pads activations, Appendix A item 18 of SURVEY.md), kernel_size != 2, or channel counts that are not
+ * multiples of 32: callers use the torch path for those. */
+int wn_forward(wn_handle* h, const int32_t* indices, int64_t N, int64_t L, int64_t output_length, float* logits, void* hip_stream);
+
 /* Diagnostics: record wall-clock stamps (100 MHz ticks) for the first n_items (evaluation, stream) steps of every
  * workgroup during the NEXT wn_generate: 8 slots per step -- 0 start, 1 input staged, 2 x' published, 3 done,
  * 4 filter/gate sums ready, 5 z staged, 6-7 unused -- then read them back as int64 [n_workgroups][n_items][8].  Used by tools/profile_chain.py. */

@@ -1,0 +1,172 @@
+// wn_forward.h -- batched (training-time) forward of the dilated-conv stack on the matrix cores (gfx950, device only).
+//
+// Reference: WaveNetModel.forward() = wavenet() with wavenet_dilate (wavenet_model.py:125-196, wavenet_modules.py:10-39).
+// The reference turns every dilated conv into a dense k=2 conv by folding time into the batch dimension (two full
+// tensor copies per layer) and evaluates the skip conv on every position of every layer.  Here each layer is three
+// GEMMs on the time-major activation matrix X[(n,t)][channels] (fp32 in HBM, channels contiguous):
+//
+//     z      = tanh(F) * sigmoid(G),  [F | G] = [X(t-d) | X(t)] . Wfg^T (+b)      K = 2R  (the two taps are two row-shifted
+//                                                                                 views of the same matrix: no copy)
+//     X'     = z . Wres^T (+b) + X(t)                                            K = D
+//     SKIP  += z(last output_length positions only) . Wskip^T (+b)               K = D
+//
+// evaluated only on the positions that can still reach the returned outputs (need_i = output_length + sum of the
+// dilations above layer i), then  logits = W2 . relu(W1 . relu(SKIP) + b1) + b2  on the last output_length positions.
+// All GEMMs run on v_mfma_f32_32x32x2_f32: fp32 in, fp32 accumulate, bit-for-bit an fmaf chain (MI355X guide), so the
+// result matches the reference's fp32 forward to rounding (tests: 1e-4).  bf16 operands are the obvious next step.
+//
+// Valid when every returned position has a full receptive field: L >= receptive_field + output_length - 1 (the
+// reference's own training shape, train_script.py:39).  Shorter inputs hit the reference's zero-padding quirk
+//  and are served by the torch path of the facade.
+#ifndef WN_FORWARD_H
+#define WN_FORWARD_H
+#ifndef WN_EMU
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float wn_f16v __attribute__((ext_vector_type(16)));
+
+// address of logical row m of a (batch, time) matrix: base + (m / rows_per_batch) * batch_stride + (t0 + m % rows_per_batch) * row_stride
+struct WnRowMap {
+    const float* base;
+    long long batch_stride, row_stride, t0;
+};
+static __device__ __forceinline__ const float* wn_row(const WnRowMap& r, long long m, int rows_per_batch) {
+    return r.base + (m / rows_per_batch) * r.batch_stride + (r.t0 + m % rows_per_batch) * r.row_stride;
+}
+
+enum { WN_EPI_PLAIN = 0, WN_EPI_GATE = 1 };
+
+struct WnGemmArgs {
+    WnRowMap a0, a1;      // A = [a0 (k < k_split) | a1 (k >= k_split)], rows of K floats in total
+    int k_split, K;       // K % 32 == 0, k_split % 32 == 0
+    const float* bt;      // B^T [K][N] row-major (N = logical output columns, N % 32 == 0; % 64 with WN_EPI_GATE)
+    int N;
+    const float* bias;    // [N] or NULL
+    WnRowMap cin;         // optional addend (residual / accumulate): row of N_out floats, base == NULL -> none
+    WnRowMap c;           // output rows of N_out floats (N_out = N, or N/2 with WN_EPI_GATE)
+    long long M;          // logical rows
+    int rows_per_batch;
+    int relu_a, relu_c;
+};
+
+// C[M][N] (+)= A[M][K] . B^T[K][N]; 128 x 128 tile per workgroup, 4 waves, wave w owns rows 32w..32w+31 and all 128
+// columns (4 accumulator tiles of 32x32).  WN_EPI_GATE: the 128 columns are [F(32) | G(32) | F(32) | G(32)] and the tile
+// emits 64 columns of tanh(F+bf) * sigmoid(G+bg).
+template <int EPI>
+__global__ __launch_bounds__(256) void wn_fwd_gemm(WnGemmArgs g) {
+    constexpr int TM = 128, TN = 128, KC = 32, AP = TM + 1;  // AP: padded row length of the transposed A chunk
+    __shared__ float a_t[2][KC * AP];                         // [k][row]
+    __shared__ float b_s[2][KC * TN];                         // [k][col]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const long long m0 = (long long)blockIdx.x * TM;
+    const int n0 = blockIdx.y * TN;
+    wn_f16v acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
+
+    // loader roles: A chunk = 128 rows x 32 floats: thread -> row tid/2, 16 floats (4 float4) ; B chunk = 32 x 128: 4 float4 each
+    const int arow = tid >> 1, ahalf = tid & 1;
+    const long long am = m0 + arow;
+    const bool arow_ok = am < g.M;
+    const float* a0p = arow_ok ? wn_row(g.a0, am, g.rows_per_batch) : nullptr;
+    const float* a1p = arow_ok ? wn_row(g.a1, am, g.rows_per_batch) : nullptr;
+    const int brow = tid >> 3, bcol = (tid & 7) * 16;
+
+    float4 va[4], vb[4];  // staging registers of the chunk in flight
+    auto fetch = [&](int kc) {  // global -> registers (issued before the multiply of the current chunk)
+        const int k0 = kc * KC;
+        const float* src = k0 < g.k_split ? a0p + k0 : a1p + (k0 - g.k_split);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) va[q] = arow_ok ? *reinterpret_cast<const float4*>(src + ahalf * 16 + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float* bsrc = g.bt + (size_t)(k0 + brow) * g.N + n0 + bcol;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            vb[q] = (n0 + bcol + q * 4 < g.N) ? *reinterpret_cast<const float4*>(bsrc + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    auto stash = [&](int buf) {  // registers -> LDS (A transposed to [k][row])
+        float* at = a_t[buf];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float4 x = va[q];
+            if (g.relu_a) { x.x = fmaxf(x.x, 0.f); x.y = fmaxf(x.y, 0.f); x.z = fmaxf(x.z, 0.f); x.w = fmaxf(x.w, 0.f); }
+            const int k = ahalf * 16 + q * 4;
+            at[(k + 0) * AP + arow] = x.x; at[(k + 1) * AP + arow] = x.y; at[(k + 2) * AP + arow] = x.z; at[(k + 3) * AP + arow] = x.w;
+        }
+        float* bs = b_s[buf] + brow * TN + bcol;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(bs + q * 4) = vb[q];
+    };
+
+    const int nchunks = g.K / KC;
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    for (int kc = 0; kc < nchunks; ++kc) {
+        const int buf = kc & 1;
+        if (kc + 1 < nchunks) fetch(kc + 1);  // lands while this chunk is multiplied
+        const float* at = a_t[buf] + 32 * wv + (lane & 31);
+        const float* bs = b_s[buf] + (lane & 31);
+        const int kh = lane >> 5;
+#pragma unroll
+        for (int ks = 0; ks < KC / 2; ++ks) {
+            const float a = at[(2 * ks + kh) * AP];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float b = bs[(2 * ks + kh) * TN + 32 * j];
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[j], 0, 0, 0);
+            }
+        }
+        if (kc + 1 < nchunks) stash(buf ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue.  C/D layout of 32x32: col = lane & 31, row = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5)
+    const int col = lane & 31;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int r = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+        const long long m = m0 + 32 * wv + r;
+        if (m >= g.M) continue;
+        float* crow = const_cast<float*>(wn_row(g.c, m, g.rows_per_batch));
+        const float* addrow = g.cin.base ? wn_row(g.cin, m, g.rows_per_batch) : nullptr;
+        if (EPI == WN_EPI_GATE) {
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const int nf = n0 + 64 * p + col, ng = nf + 32;  // logical columns of F and G
+                if (ng >= g.N) continue;
+                const float f = acc[2 * p][i] + (g.bias ? g.bias[nf] : 0.f);
+                const float gg = acc[2 * p + 1][i] + (g.bias ? g.bias[ng] : 0.f);
+                const float z = tanhf(f) * (1.0f / (1.0f + expf(-gg)));
+                crow[(n0 >> 1) + 32 * p + col] = z;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = n0 + 32 * j + col;
+                if (n >= g.N) continue;
+                float v = acc[j][i] + (g.bias ? g.bias[n] : 0.f);
+                if (addrow) v += addrow[n];
+                if (g.relu_c) v = fmaxf(v, 0.f);
+                crow[n] = v;
+            }
+        }
+    }
+}
+
+// x0[(n,t)][r] = start_conv.weight[r][idx[n][t]] (+ bias): the one-hot input makes start_conv a column gather (wavenet_model.py:127)
+__global__ void wn_fwd_start(const int32_t* idx, const float* start_t, const float* start_b, float* x, long long rows, int R) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long row = i / (R / 4);
+    const int q = (int)(i % (R / 4));
+    if (row >= rows) return;
+    float4 v = *reinterpret_cast<const float4*>(start_t + (size_t)idx[row] * R + q * 4);
+    if (start_b) { v.x += start_b[q * 4]; v.y += start_b[q * 4 + 1]; v.z += start_b[q * 4 + 2]; v.w += start_b[q * 4 + 3]; }
+    *reinterpret_cast<float4*>(x + row * R + q * 4) = v;
+}
+
+#endif  // !WN_EMU
+#endif  // WN_FORWARD_H

@@ -18,6 +18,7 @@
 #include "../../include/wn_abi.h"
 #include "wn_kernel.h"
 #include "wn_kernel_v2.h"
+#include "wn_forward.h"
 
 static thread_local char g_err[512] = "";
 
@@ -225,6 +226,10 @@ struct wn_handle {
     uint32_t* d_status;
     size_t blob_floats, ring_floats, gran_count;
     long long* d_prof;
+    // batched forward (wn_forward): GEMM-ready weight banks and a workspace that grows on demand
+    float* d_fw; size_t fw_floats; bool fw_ok;
+    size_t fw_off_fg, fw_off_bfg, fw_off_res, fw_off_bres, fw_off_skip, fw_off_bskip, fw_off_w1, fw_off_b1, fw_off_w2, fw_off_b2;
+    float* d_ws; size_t ws_floats;
     int prof_items;      // stamps requested for the next job (0 = off)
     int prof_recorded;   // stamps held in d_prof
     std::vector<int64_t> ring_off;
@@ -241,7 +246,7 @@ extern "C" void wn_destroy(wn_handle* h) {
     if (h->pending) (void)hipStreamSynchronize((hipStream_t)h->last_stream);
 #endif
     rt_free(h->d_blobs); rt_free(h->d_start_t); rt_free(h->d_start_b); rt_free(h->d_rings); rt_free(h->d_dil);
-    rt_free(h->d_wg_map); rt_free(h->d_ring_off); rt_free(h->d_gran); rt_free(h->d_status); rt_free(h->d_prof);
+    rt_free(h->d_wg_map); rt_free(h->d_ring_off); rt_free(h->d_gran); rt_free(h->d_status); rt_free(h->d_prof); rt_free(h->d_fw); rt_free(h->d_ws);
     delete h;
 }
 
@@ -282,6 +287,7 @@ extern "C" int wn_create(const wn_config* cfg, wn_handle** out) {
     h->d_blobs = h->d_start_t = h->d_start_b = h->d_rings = nullptr;
     h->d_dil = h->d_wg_map = nullptr; h->d_ring_off = nullptr; h->d_gran = nullptr; h->d_status = nullptr;
     h->d_prof = nullptr; h->prof_items = 0; h->prof_recorded = 0;
+    h->d_fw = nullptr; h->fw_floats = 0; h->fw_ok = false; h->d_ws = nullptr; h->ws_floats = 0;
     WnPlan& pl = h->plan;
     pl.layers = cfg->layers; pl.blocks = cfg->blocks; pl.NL = cfg->layers * cfg->blocks;
     pl.R = cfg->residual_channels; pl.D = cfg->dilation_channels; pl.S = cfg->skip_channels; pl.E = cfg->end_channels;
@@ -418,6 +424,59 @@ extern "C" int wn_load_weights(wn_handle* h, const wn_weight_ptrs* w) {
         h->plan.start_b = nullptr;
     }
     if (rc) return rc;
+#ifndef WN_EMU
+    {   // GEMM-ready banks for wn_forward: B^T [K][N] row-major per layer (see wn_forward.h)
+        const int R = pl.R, D = pl.D, S = pl.S, E = pl.E, C = pl.C, NL = pl.NL;
+        h->fw_ok = pl.k == 2 && R % 32 == 0 && D % 32 == 0 && S % 32 == 0 && E % 32 == 0 && C % 32 == 0;
+        if (h->fw_ok) {
+            size_t o = 0;
+            h->fw_off_fg = o; o += (size_t)NL * 2 * R * 2 * D;
+            h->fw_off_bfg = o; o += (size_t)NL * 2 * D;
+            h->fw_off_res = o; o += (size_t)NL * D * R;
+            h->fw_off_bres = o; o += (size_t)NL * R;
+            h->fw_off_skip = o; o += (size_t)NL * D * S;
+            h->fw_off_bskip = o; o += (size_t)NL * S;
+            h->fw_off_w1 = o; o += (size_t)S * E;
+            h->fw_off_b1 = o; o += (size_t)E;
+            h->fw_off_w2 = o; o += (size_t)E * C;
+            h->fw_off_b2 = o; o += (size_t)C;
+            std::vector<float> fw(o, 0.f);
+            for (int l = 0; l < NL; ++l) {
+                float* fg = fw.data() + h->fw_off_fg + (size_t)l * 2 * R * 2 * D;
+                for (int ch = 0; ch < D; ++ch) {
+                    const int nf = 64 * (ch / 32) + (ch % 32), ng = nf + 32;  // column order [F(32) | G(32)] per 32-channel group
+                    for (int tap = 0; tap < 2; ++tap)
+                        for (int r = 0; r < R; ++r) {
+                            fg[(size_t)(tap * R + r) * 2 * D + nf] = w->filter_w[(((size_t)l * D + ch) * R + r) * 2 + tap];
+                            fg[(size_t)(tap * R + r) * 2 * D + ng] = w->gate_w[(((size_t)l * D + ch) * R + r) * 2 + tap];
+                        }
+                    if (pl.has_bias) {
+                        fw[h->fw_off_bfg + (size_t)l * 2 * D + nf] = w->filter_b[(size_t)l * D + ch];
+                        fw[h->fw_off_bfg + (size_t)l * 2 * D + ng] = w->gate_b[(size_t)l * D + ch];
+                    }
+                }
+                for (int dch = 0; dch < D; ++dch) {
+                    for (int r = 0; r < R; ++r) fw[h->fw_off_res + ((size_t)l * D + dch) * R + r] = w->res_w[((size_t)l * R + r) * D + dch];
+                    for (int sc = 0; sc < S; ++sc) fw[h->fw_off_skip + ((size_t)l * D + dch) * S + sc] = w->skip_w[((size_t)l * S + sc) * D + dch];
+                }
+                if (pl.has_bias) {
+                    for (int r = 0; r < R; ++r) fw[h->fw_off_bres + (size_t)l * R + r] = w->res_b[(size_t)l * R + r];
+                    for (int sc = 0; sc < S; ++sc) fw[h->fw_off_bskip + (size_t)l * S + sc] = w->skip_b[(size_t)l * S + sc];
+                }
+            }
+            for (int sc = 0; sc < S; ++sc)
+                for (int e = 0; e < E; ++e) fw[h->fw_off_w1 + (size_t)sc * E + e] = w->end1_w[(size_t)e * S + sc];
+            for (int e = 0; e < E; ++e) fw[h->fw_off_b1 + e] = w->end1_b[e];
+            for (int e = 0; e < E; ++e)
+                for (int c = 0; c < C; ++c) fw[h->fw_off_w2 + (size_t)e * C + c] = w->end2_w[(size_t)c * E + e];
+            for (int c = 0; c < C; ++c) fw[h->fw_off_b2 + c] = w->end2_b[c];
+            if (h->fw_floats != o) { rt_free(h->d_fw); h->d_fw = (float*)rt_malloc(o * 4); h->fw_floats = o; }
+            if (!h->d_fw) return wn_fail(WN_E_NOMEM, "wn_load_weights: forward weight banks (%.1f MB)", o * 4e-6);
+            rc = rt_h2d(h->d_fw, fw.data(), o * 4);
+            if (rc) return rc;
+        }
+    }
+#endif
     h->have_weights = true;
     return WN_OK;
 }
@@ -592,4 +651,102 @@ extern "C" int wn_profile_read(wn_handle* h, int64_t* host_out, int64_t capacity
     const int64_t n = (int64_t)h->plan.n_wg * h->prof_recorded * 8;
     if (!h->d_prof || n == 0 || capacity < n) return wn_fail(WN_E_STATE, "wn_profile_read: nothing recorded / buffer too small (%lld)", (long long)n);
     return rt_d2h(host_out, h->d_prof, (size_t)n * 8);
+}
+
+// WaveNetModel.forward() for one-hot inputs (class indices), see wn_forward.h.  Asynchronous on hip_stream.
+extern "C" int wn_forward(wn_handle* h, const int32_t* indices, int64_t N, int64_t L, int64_t out_len, float* logits, void* hip_stream) {
+    g_err[0] = 0;
+    if (!h || !indices || !logits) return wn_fail(WN_E_BADARG, "wn_forward: NULL argument");
+    if (!h->have_weights) return wn_fail(WN_E_STATE, "wn_forward: wn_load_weights has not been called");
+    if (N < 1 || out_len < 1) return wn_fail(WN_E_BADARG, "wn_forward: N and output_length must be >= 1");
+#ifdef WN_EMU
+    (void)L; (void)hip_stream;
+    return wn_fail(WN_E_UNSUPPORTED, "wn_forward: the matrix-core forward exists on the GPU only");
+#else
+    const WnPlan& pl = h->plan;
+    const int R = pl.R, D = pl.D, S = pl.S, E = pl.E, C = pl.C, NL = pl.NL;
+    if (!h->fw_ok) return wn_fail(WN_E_UNSUPPORTED, "wn_forward: needs kernel_size 2 and channel counts that are multiples of 32");
+    const long long rf = 1 + (long long)pl.blocks * ((1 << pl.layers) - 1);
+    if (L < rf + out_len - 1)
+        return wn_fail(WN_E_UNSUPPORTED, "wn_forward: L=%lld < receptive_field + output_length - 1 = %lld (the reference zero-pads "
+                       "activations there; use the torch path)", (long long)L, (long long)(rf + out_len - 1));
+    { int rc = rt_hip(hipSetDevice(h->cfg.device_id), "hipSetDevice"); if (rc) return rc; }
+    std::vector<long long> need(NL + 1);
+    need[NL] = out_len;
+    for (int l = NL - 1; l >= 0; --l) need[l] = need[l + 1] + h->dil[l];
+    const size_t x_fl = (size_t)N * L * R, z_fl = (size_t)N * need[1 < NL ? 1 : NL] * D > (size_t)N * need[NL] * D ? (size_t)N * need[1 < NL ? 1 : NL] * D : (size_t)N * need[NL] * D;
+    const size_t skip_fl = (size_t)N * out_len * S, e_fl = (size_t)N * out_len * E;
+    const size_t total = 2 * x_fl + z_fl + skip_fl + e_fl;
+    if (h->ws_floats < total) {
+        if (h->pending) { int rc = wn_wait(h); if (rc) return rc; }
+        rt_free(h->d_ws);
+        h->d_ws = (float*)rt_malloc(total * 4);
+        h->ws_floats = h->d_ws ? total : 0;
+        if (!h->d_ws) return wn_fail(WN_E_NOMEM, "wn_forward: workspace of %.1f MB", total * 4e-6);
+    }
+    float* xa = h->d_ws; float* xb = xa + x_fl; float* z = xb + x_fl; float* skip = z + z_fl; float* ev = skip + skip_fl;
+    hipStream_t st = (hipStream_t)hip_stream;
+    {
+        const long long rows = N * L;
+        const long long work = rows * (R / 4);
+        hipLaunchKernelGGL(wn_fwd_start, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, indices, h->d_start_t,
+                           pl.has_bias ? h->d_start_b : nullptr, xa, rows, R);
+    }
+    auto launch = [&](int epi, const WnGemmArgs& a) {
+        dim3 grid((unsigned)((a.M + 127) / 128), (unsigned)((a.N + 127) / 128));
+        if (epi == WN_EPI_GATE) hipLaunchKernelGGL(wn_fwd_gemm<WN_EPI_GATE>, grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(wn_fwd_gemm<WN_EPI_PLAIN>, grid, dim3(256), 0, st, a);
+    };
+    const float* fw = h->d_fw;
+    float* xin = xa; float* xout = xb;
+    for (int l = 0; l < NL; ++l) {
+        const long long d = h->dil[l], rows = need[l + 1], t0 = L - rows;
+        WnGemmArgs a;
+        memset(&a, 0, sizeof(a));
+        // z = gate([x(t-d) | x(t)] . Wfg^T)
+        a.a0 = WnRowMap{xin, (long long)L * R, R, t0 - d};
+        a.a1 = WnRowMap{xin, (long long)L * R, R, t0};
+        a.k_split = R; a.K = 2 * R; a.bt = fw + h->fw_off_fg + (size_t)l * 2 * R * 2 * D; a.N = 2 * D;
+        a.bias = pl.has_bias ? fw + h->fw_off_bfg + (size_t)l * 2 * D : nullptr;
+        a.c = WnRowMap{z, rows * D, D, 0};
+        a.M = N * rows; a.rows_per_batch = (int)rows;
+        launch(WN_EPI_GATE, a);
+        if (l < NL - 1) {  // x' = z . Wres^T + x(t)   (the last layer's residual output is never consumed, also upstream)
+            memset(&a, 0, sizeof(a));
+            a.a0 = a.a1 = WnRowMap{z, rows * D, D, 0};
+            a.k_split = D; a.K = D; a.bt = fw + h->fw_off_res + (size_t)l * D * R; a.N = R;
+            a.bias = pl.has_bias ? fw + h->fw_off_bres + (size_t)l * R : nullptr;
+            a.cin = WnRowMap{xin, (long long)L * R, R, t0};
+            a.c = WnRowMap{xout, (long long)L * R, R, t0};
+            a.M = N * rows; a.rows_per_batch = (int)rows;
+            launch(WN_EPI_PLAIN, a);
+        }
+        // skip (+)= z(last output_length positions) . Wskip^T
+        memset(&a, 0, sizeof(a));
+        a.a0 = a.a1 = WnRowMap{z, rows * D, D, rows - out_len};
+        a.k_split = D; a.K = D; a.bt = fw + h->fw_off_skip + (size_t)l * D * S; a.N = S;
+        a.bias = pl.has_bias ? fw + h->fw_off_bskip + (size_t)l * S : nullptr;
+        if (l > 0) a.cin = WnRowMap{skip, out_len * S, S, 0};
+        a.c = WnRowMap{skip, out_len * S, S, 0};
+        a.M = N * out_len; a.rows_per_batch = (int)out_len;
+        launch(WN_EPI_PLAIN, a);
+        float* t = xin; xin = xout; xout = t;
+    }
+    {   // head: relu(skip) -> end_conv_1 (+b, relu) -> end_conv_2 (+b)     wavenet_model.py:167-169
+        WnGemmArgs a;
+        memset(&a, 0, sizeof(a));
+        a.a0 = a.a1 = WnRowMap{skip, out_len * S, S, 0};
+        a.k_split = S; a.K = S; a.bt = fw + h->fw_off_w1; a.N = E; a.bias = fw + h->fw_off_b1;
+        a.c = WnRowMap{ev, out_len * E, E, 0};
+        a.M = N * out_len; a.rows_per_batch = (int)out_len; a.relu_a = 1; a.relu_c = 1;
+        launch(WN_EPI_PLAIN, a);
+        memset(&a, 0, sizeof(a));
+        a.a0 = a.a1 = WnRowMap{ev, out_len * E, E, 0};
+        a.k_split = E; a.K = E; a.bt = fw + h->fw_off_w2; a.N = C; a.bias = fw + h->fw_off_b2;
+        a.c = WnRowMap{logits, out_len * C, C, 0};
+        a.M = N * out_len; a.rows_per_batch = (int)out_len;
+        launch(WN_EPI_PLAIN, a);
+    }
+    return rt_hip(hipGetLastError(), "wn_forward launches");
+#endif
 }

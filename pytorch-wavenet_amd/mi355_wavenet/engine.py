@@ -143,6 +143,16 @@ class Engine:
         self.lib.check(self.lib.dll.wn_export_queue(self._h, layer, stream, data.ctypes.data, ctypes.byref(ip), ctypes.byref(op)))
         return data, ip.value, op.value
 
+    def forward_indices(self, indices, output_length):
+        """WaveNetModel.forward() on class indices: int tensor/array (N, L) -> float32 (N*output_length, classes) on the
+        engine's device (a torch tensor; numpy for the emulator is not available: GPU only).  Asynchronous."""
+        import torch
+        idx = torch.as_tensor(indices).to(self.mem.device, torch.int32).contiguous()
+        N, L = idx.shape
+        out = torch.empty(N * output_length, self.classes, dtype=torch.float32, device=self.mem.device)
+        self.lib.check(self.lib.dll.wn_forward(self._h, idx.data_ptr(), N, L, int(output_length), out.data_ptr(), self.mem.stream()))
+        return out
+
     def profile_next(self, n_items):
         self.lib.check(self.lib.dll.wn_profile_next(self._h, int(n_items)))
 
