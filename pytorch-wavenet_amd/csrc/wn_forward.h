@@ -33,7 +33,9 @@ struct WnRowMap {
     long long batch_stride, row_stride, t0;
 };
 static __device__ __forceinline__ const float* wn_row(const WnRowMap& r, long long m, int rows_per_batch) {
-    return r.base + (m / rows_per_batch) * r.batch_stride + (r.t0 + m % rows_per_batch) * r.row_stride;
+    // M < 2^31 (checked on the host): 32-bit division, a 64-bit one is ~100 instructions and the epilogue does 32 of them
+    const unsigned q = (unsigned)m / (unsigned)rows_per_batch, rem = (unsigned)m - q * (unsigned)rows_per_batch;
+    return r.base + (long long)q * r.batch_stride + (r.t0 + (long long)rem) * r.row_stride;
 }
 
 enum { WN_EPI_PLAIN = 0, WN_EPI_GATE = 1 };

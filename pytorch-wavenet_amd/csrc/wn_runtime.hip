@@ -670,6 +670,7 @@ extern "C" int wn_forward(wn_handle* h, const int32_t* indices, int64_t N, int64
     if (L < rf + out_len - 1)
         return wn_fail(WN_E_UNSUPPORTED, "wn_forward: L=%lld < receptive_field + output_length - 1 = %lld (the reference zero-pads "
                        "activations there; use the torch path)", (long long)L, (long long)(rf + out_len - 1));
+    if ((long long)N * L >= 0x7fffffffll) return wn_fail(WN_E_UNSUPPORTED, "wn_forward: N*L must stay below 2^31 rows");
     { int rc = rt_hip(hipSetDevice(h->cfg.device_id), "hipSetDevice"); if (rc) return rc; }
     std::vector<long long> need(NL + 1);
     need[NL] = out_len;
