@@ -155,6 +155,14 @@ int wn_export_queue(wn_handle* h, int32_t layer, int32_t stream, float* host_dat
  * multiples of 32: callers use the torch path for those. */
 int wn_forward(wn_handle* h, const int32_t* indices, int64_t N, int64_t L, int64_t output_length, float* logits, void* hip_stream);
 
+/* The priming loop of generate_fast (wavenet_model.py:259-269) for ALL given samples at once: `first_samples` is a DEVICE
+ * pointer to int32 [n_streams][row_stride]; the first n_prime (= n_given - 1) samples of every stream are evaluated teacher
+ * forced with the forward GEMM kernels (no skip / head work: the reference discards those outputs) and the queues are left
+ * exactly as n_prime single evaluations would leave them.  Needs freshly reset queues (wn_reset); follow with
+ * wn_generate(n_given = 1, first_samples = the last given sample).  WN_E_UNSUPPORTED under the same shape limits as
+ * wn_forward: callers then prime through wn_generate.  Asynchronous on hip_stream. */
+int wn_prime(wn_handle* h, const int32_t* first_samples, int64_t n_prime, int64_t row_stride, void* hip_stream);
+
 /* Diagnostics: record wall-clock stamps (100 MHz ticks) for the first n_items (evaluation, stream) steps of every
  * workgroup during the NEXT wn_generate: 8 slots per step -- 0 start, 1 input staged, 2 x' published, 3 done,
  * 4 filter/gate sums ready, 5 z staged, 6-7 unused -- then read them back as int64 [n_workgroups][n_items][8].  Used by tools/profile_chain.py. */

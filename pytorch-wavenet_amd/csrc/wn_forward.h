@@ -170,5 +170,23 @@ __global__ void wn_fwd_start(const int32_t* idx, const float* start_t, const flo
     *reinterpret_cast<float4*>(x + row * R + q * 4) = v;
 }
 
+// Batched priming: copies the newest `count` time steps of a layer's input x (time-major rows of R floats; `x` points at
+// time 0 of stream 0, streams `x_batch_stride` floats apart) into the layer's dilation-queue rings -- slot = t mod ML, the
+// reference's DilatedQueue layout (wavenet_modules.py:55-57) -- for every stream and every one of the P slice copies.
+__global__ void wn_fill_ring(const float* x, long long x_batch_stride, float* ring, int R, int ML, int n_streams, int P, long long n_time,
+                             int count) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int r4 = R / 4;
+    const long long per_stream = (long long)count * r4;
+    if (i >= per_stream * n_streams) return;
+    const int s = (int)(i / per_stream);
+    const long long rem = i % per_stream;
+    const long long t = n_time - count + rem / r4;
+    const int q = (int)(rem % r4);
+    const float4 v = *reinterpret_cast<const float4*>(x + (long long)s * x_batch_stride + t * R + q * 4);
+    for (int c = 0; c < P; ++c)
+        *reinterpret_cast<float4*>(ring + (((long long)c * n_streams + s) * ML + (t % ML)) * R + q * 4) = v;
+}
+
 #endif  // !WN_EMU
 #endif  // WN_FORWARD_H

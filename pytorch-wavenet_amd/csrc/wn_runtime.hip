@@ -751,3 +751,101 @@ extern "C" int wn_forward(wn_handle* h, const int32_t* indices, int64_t N, int64
     return rt_hip(hipGetLastError(), "wn_forward launches");
 #endif
 }
+
+// Batched (teacher-forced) priming: the n_prime = n_given - 1 priming evaluations of generate_fast (wavenet_model.py:259-269)
+// as GEMMs over all given positions at once instead of one chain pass per sample: the layer
+// inputs of the whole window are computed with the forward kernels (no skip / head work -- the reference discards those
+// outputs) and the newest d+1 columns of every layer are written straight into the queues.  Requires freshly reset queues
+// (queue time 0); activations before the stream start are zero at every layer, like DilatedQueue.reset().
+extern "C" int wn_prime(wn_handle* h, const int32_t* first_samples, int64_t n_prime, int64_t row_stride, void* hip_stream) {
+    g_err[0] = 0;
+    if (!h || !first_samples) return wn_fail(WN_E_BADARG, "wn_prime: NULL argument");
+    if (!h->have_weights) return wn_fail(WN_E_STATE, "wn_prime: wn_load_weights has not been called");
+    if (n_prime < 0 || row_stride < n_prime) return wn_fail(WN_E_BADARG, "wn_prime: bad n_prime / row_stride");
+    if (n_prime == 0) return WN_OK;
+#ifdef WN_EMU
+    (void)hip_stream;
+    return wn_fail(WN_E_UNSUPPORTED, "wn_prime: the batched priming path exists on the GPU only");
+#else
+    const WnPlan& pl = h->plan;
+    const int R = pl.R, D = pl.D, NL = pl.NL, ns = pl.n_streams;
+    if (!h->fw_ok) return wn_fail(WN_E_UNSUPPORTED, "wn_prime: needs kernel_size 2 and channel counts that are multiples of 32");
+    if (h->pending) { int rc = wn_wait(h); if (rc) return rc; }
+    if (h->t_base != 0) return wn_fail(WN_E_STATE, "wn_prime: queues must be freshly reset (queue time is %lld)", h->t_base);
+    if (row_stride != n_prime && ns > 1) { /* strided rows are fine: handled by the gather below */ }
+    { int rc = rt_hip(hipSetDevice(h->cfg.device_id), "hipSetDevice"); if (rc) return rc; }
+    const long long n = n_prime;
+    if ((long long)ns * n >= 0x7fffffffll) return wn_fail(WN_E_UNSUPPORTED, "wn_prime: too many rows");
+    // q[i] = trailing positions of layer i's input that are needed (its own queue: d+1, and what the layers above need)
+    std::vector<long long> q(NL + 1, 0);
+    for (int l = NL - 1; l >= 0; --l) {
+        const long long d = h->dil[l];
+        long long v = q[l + 1] > 0 ? q[l + 1] + d : 0;
+        if (v < d + 1) v = d + 1;
+        q[l] = v < n ? v : n;
+    }
+    long long max_d = 1;
+    for (int l = 0; l < NL; ++l) max_d = h->dil[l] > max_d ? h->dil[l] : max_d;
+    const long long Lp = max_d, Lt = Lp + n;  // every stream's activation rows are preceded by Lp rows of zeros (t < 0)
+    const size_t x_fl = (size_t)ns * Lt * R, z_fl = (size_t)ns * n * D;
+    const size_t total = 2 * x_fl + z_fl;
+    if (h->ws_floats < total) {
+        rt_free(h->d_ws);
+        h->d_ws = (float*)rt_malloc(total * 4);
+        h->ws_floats = h->d_ws ? total : 0;
+        if (!h->d_ws) return wn_fail(WN_E_NOMEM, "wn_prime: workspace of %.1f MB", total * 4e-6);
+    }
+    float* xa = h->d_ws; float* xb = xa + x_fl; float* z = xb + x_fl;
+    hipStream_t st = (hipStream_t)hip_stream;
+    int rc = rt_hip(hipMemsetAsync(xa, 0, 2 * x_fl * 4, st), "hipMemsetAsync(prime workspace)");
+    if (rc) return rc;
+    // x0 = start_conv column gather over all given positions; rows of stream s start at xa + s*Lt*R + Lp*R
+    for (int s = 0; s < ns; ++s) {
+        const long long work = n * (R / 4);
+        hipLaunchKernelGGL(wn_fwd_start, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, first_samples + (size_t)s * row_stride,
+                           h->d_start_t, pl.has_bias ? h->d_start_b : nullptr, xa + ((size_t)s * Lt + Lp) * R, n, R);
+    }
+    auto launch = [&](int epi, const WnGemmArgs& a) {
+        dim3 grid((unsigned)((a.M + 127) / 128), (unsigned)((a.N + 127) / 128));
+        if (epi == WN_EPI_GATE) hipLaunchKernelGGL(wn_fwd_gemm<WN_EPI_GATE>, grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(wn_fwd_gemm<WN_EPI_PLAIN>, grid, dim3(256), 0, st, a);
+    };
+    const float* fw = h->d_fw;
+    float* xin = xa; float* xout = xb;
+    for (int l = 0; l < NL; ++l) {
+        const long long d = h->dil[l];
+        const int ML = (int)d + 1;
+        {   // queue of layer l <- newest min(d+1, n) columns of its input
+            const int count = (int)(ML < n ? ML : n);
+            const long long work = (long long)ns * count * (R / 4);
+            hipLaunchKernelGGL(wn_fill_ring, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, xin + Lp * R, Lt * R,
+                               h->d_rings + h->ring_off[l], R, ML, ns, pl.P, n, count);
+        }
+        const long long rows = q[l + 1];
+        if (l == NL - 1 || rows <= 0) break;
+        const long long t0 = n - rows;
+        WnGemmArgs a;
+        memset(&a, 0, sizeof(a));
+        a.a0 = WnRowMap{xin + Lp * R, Lt * R, R, t0 - d};  // t - d may be negative: those rows are the zero prefix
+        a.a1 = WnRowMap{xin + Lp * R, Lt * R, R, t0};
+        a.k_split = R; a.K = 2 * R; a.bt = fw + h->fw_off_fg + (size_t)l * 2 * R * 2 * D; a.N = 2 * D;
+        a.bias = pl.has_bias ? fw + h->fw_off_bfg + (size_t)l * 2 * D : nullptr;
+        a.c = WnRowMap{z, rows * D, D, 0};
+        a.M = ns * rows; a.rows_per_batch = (int)rows;
+        launch(WN_EPI_GATE, a);
+        memset(&a, 0, sizeof(a));
+        a.a0 = a.a1 = WnRowMap{z, rows * D, D, 0};
+        a.k_split = D; a.K = D; a.bt = fw + h->fw_off_res + (size_t)l * D * R; a.N = R;
+        a.bias = pl.has_bias ? fw + h->fw_off_bres + (size_t)l * R : nullptr;
+        a.cin = WnRowMap{xin + Lp * R, Lt * R, R, t0};
+        a.c = WnRowMap{xout + Lp * R, Lt * R, R, t0};
+        a.M = ns * rows; a.rows_per_batch = (int)rows;
+        launch(WN_EPI_PLAIN, a);
+        float* t = xin; xin = xout; xout = t;
+    }
+    rc = rt_hip(hipGetLastError(), "wn_prime launches");
+    if (rc) return rc;
+    h->t_base = n;
+    return WN_OK;
+#endif
+}

@@ -173,9 +173,20 @@ class Engine:
     def wait(self):
         self.lib.check(self.lib.dll.wn_wait(self._h))
 
+    def prime(self, first_dev, n_prime, row_stride):
+        """Batched teacher-forced priming of freshly reset queues (wn_prime).  Returns False when the engine cannot
+        (shape limits / emulator): the caller then primes through wn_generate, one chain pass per sample."""
+        rc = self.lib.dll.wn_prime(self._h, self.mem.ptr(first_dev), int(n_prime), int(row_stride), self.mem.stream())
+        if rc == _abi.WN_E_UNSUPPORTED:
+            return False
+        self.lib.check(rc)
+        return True
+
     # -- convenience: one synchronous generate_fast-shaped job
+    PRIME_BATCH_MIN = 64  # given samples from which the GEMM priming path beats the per-sample chain passes
+
     def generate(self, num_samples, first_samples=None, temperature=1.0, regularize=0.0, uniforms=None,
-                 want_logits=False, reset=True, timeout_ms=0):
+                 want_logits=False, reset=True, timeout_ms=0, batched_prime=True):
         """first_samples: (n_streams, n_given) or (n_given,) ints (broadcast to every stream) or None -> classes//2.
         uniforms: float64 (n_streams, num_samples) (np.random.random_sample draws) or None -> greedy.
         Returns indices int32 (n_streams, num_samples) [, logits float32 (n_streams, num_samples, classes)]."""
@@ -199,9 +210,13 @@ class Engine:
         first_dev = self.mem.upload(fs)
         out_dev = self.mem.empty((ns, max(num_samples, 1)), np.int32)
         logits_dev = self.mem.empty((ns, max(num_samples, 1), C), np.float32) if want_logits else None
+        n_given = fs.shape[1]
         if reset:
             self.reset()
-        self.launch(first_dev, fs.shape[1], num_samples, temperature, reg_dev, uni_dev, out_dev, logits_dev, timeout_ms)
+            if batched_prime and n_given - 1 >= self.PRIME_BATCH_MIN and self.prime(first_dev, n_given - 1, n_given):
+                first_dev = self.mem.upload(np.ascontiguousarray(fs[:, -1:]))  # the last given sample is the next input
+                n_given = 1
+        self.launch(first_dev, n_given, num_samples, temperature, reg_dev, uni_dev, out_dev, logits_dev, timeout_ms)
         self.wait()
         idx = self.mem.download(out_dev)[:, :num_samples]
         if want_logits:

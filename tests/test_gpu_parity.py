@@ -188,3 +188,24 @@ def test_two_handles_two_threads():
     [t.start() for t in ts]
     [t.join() for t in ts]
     assert np.array_equal(out[0], ref) and np.array_equal(out[1], ref)
+
+
+@pytest.mark.parametrize("cfgname,ns,n_given", [("cfg1", 2, 200), ("cfg2", 1, 3100), ("cfg3", 2, 700), ("cfg3", 1, 5200)])
+def test_batched_priming_equals_chain_priming(cfgname, ns, n_given):
+    """wn_prime (GEMM priming) leaves the queues exactly where n_given-1 single evaluations
+    leave them: same generated indices as the per-sample chain priming and as the oracle, same queue contents."""
+    N = 120
+    cfg, W, first, uniforms = make_case(cfgname, 59, ns, n_given, N)
+    eng = engine.Engine(cfg, W, n_streams=ns)
+    a = eng.generate(N, first, temperature=1.0, uniforms=uniforms, batched_prime=True)
+    qa = [eng.export_queue(l, stream=ns - 1) for l in (0, 3, cfg["layers"] - 1, cfg["layers"] * cfg["blocks"] - 1)]
+    assert eng.info()["evals_done"] == n_given - 1 + N
+    b = eng.generate(N, first, temperature=1.0, uniforms=uniforms, batched_prime=False)
+    qb = [eng.export_queue(l, stream=ns - 1) for l in (0, 3, cfg["layers"] - 1, cfg["layers"] * cfg["blocks"] - 1)]
+    assert np.array_equal(a, b)
+    for (da, ia, oa), (db, ib, ob) in zip(qa, qb):
+        assert (ia, oa) == (ib, ob)
+        assert np.allclose(da, db, rtol=0, atol=5e-6)
+    o_idx, _ = c_oracle.generate(cfg, W, N, first[0], 1.0, 0.0, uniforms[0])
+    assert np.array_equal(a[0], o_idx)
+    eng.close()
