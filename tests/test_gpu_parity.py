@@ -205,7 +205,7 @@ def test_batched_priming_equals_chain_priming(cfgname, ns, n_given):
     assert np.array_equal(a, b)
     for (da, ia, oa), (db, ib, ob) in zip(qa, qb):
         assert (ia, oa) == (ib, ob)
-        assert np.allclose(da, db, rtol=0, atol=5e-6)
+        assert np.abs(da - db).max() <= 1e-5 * max(1.0, float(np.abs(db).max()))  # two fp32 summation orders, 50 layers deep
     o_idx, _ = c_oracle.generate(cfg, W, N, first[0], 1.0, 0.0, uniforms[0])
     assert np.array_equal(a[0], o_idx)
     eng.close()
