@@ -196,7 +196,8 @@ struct WnV2Lds {
     static constexpr int ev = sk + SKP;                  // [EC]   head
     static constexpr int smp = ev + SH::EC;              // sampler scratch: 64 floats (8-byte aligned); [48] = fail flag
     static constexpr int park = smp + 64;                // 8 parked int64 stamps
-    static constexpr int pre = park + 16;                 // [n_streams][256]
+    static constexpr int xo = park + 16;                 // [XR] multi-stream: queue tap x[t+1-d] of the current item
+    static constexpr int pre = xo + XR;                 // [n_streams][256]
     static __host__ __device__ int floats(int n_streams) { return pre + n_streams * 256; }
     // single-stream kernel: layer 0 keeps start_conv^T ([C][R]) behind the pre buffer when it fits (p.start_in_lds)
     static __host__ __device__ int floats_with_start(int n_streams) { return floats(n_streams) + 256 * SH::R; }
@@ -737,14 +738,11 @@ static __device__ void wn_v2_layer_multi(const WnPlan& p, const WnRun& r, WnCtx&
             wn_u64 sk_now[RS];
 #pragma unroll
             for (int q = 0; q < RS; ++q) sk_now[q] = wn_ld_granule(sbase + (size_t)s * S + 256 * q);
-            // queue tap x[t+1-d] of this stream, consumed in the tail.  Requested only now: vector loads return in
-            // order, so an HBM miss issued ahead of the polls would have stalled every poll behind it.
-            float xo[K1];
-            if (d != 1) {
-                const float* src = ring + (size_t)tapmod * R + kq1 * K1;
-#pragma unroll
-                for (int k = 0; k < K1; ++k) xo[k] = src[k];
-            }
+            // queue tap x[t+1-d] of this stream, consumed in the tail: ONE coalesced row load by the first R lanes (the
+            // row is shared by all 256 lanes; 8 x 16-byte loads per lane cost 12 % of the item).  Requested only now:
+            // vector loads return in order, an HBM miss issued ahead of the polls would have stalled every poll behind it.
+            float xo_v = 0.f;
+            if (d != 1 && tid < R) xo_v = (WN_ABL == 7) ? 0.f : ring[(size_t)tapmod * R + tid];
             if (wn_barrier_failed(cx, failflag)) return;
             wn_stamp(r, park, item, 1);
             // ---- 2. filter/gate
@@ -801,8 +799,10 @@ static __device__ void wn_v2_layer_multi(const WnPlan& p, const WnRun& r, WnCtx&
                 if (d == 1) {
                     a0 = wn_dot_lds<K1>(w0, xb + kq1 * (K1 + 4), a0);
                 } else {
-#pragma unroll
-                    for (int k = 0; k < K1; ++k) a0 += w0[k] * xo[k];
+                    float* xol = lds + L::xo;
+                    if (tid < R) xol[SH::xpad(tid)] = xo_v;
+                    wn_lds_barrier();
+                    a0 = wn_dot_lds<K1>(w0, xol + kq1 * (K1 + 4), a0);
                 }
                 pre[s * 256 + tid] = a0;
             }
