@@ -51,6 +51,9 @@ struct WnGemmArgs {
     long long M;          // logical rows
     int rows_per_batch;
     int relu_a, relu_c;
+    WnRowMap c2;          // WN_EPI_GATE only: rows whose index inside the batch entry is >= c2_first_row are ALSO written here
+    int c2_first_row;     //   (at row index - c2_first_row): the z block the grouped skip GEMM consumes.  base == NULL -> off
+    int pad;
 };
 
 // C[M][N] (+)= A[M][K] . B^T[K][N]; 128 x 128 tile per workgroup, 4 waves, wave w owns rows 32w..32w+31 and all 128
@@ -136,6 +139,12 @@ __global__ __launch_bounds__(256) void wn_fwd_gemm(WnGemmArgs g) {
         float* crow = const_cast<float*>(wn_row(g.c, m, g.rows_per_batch));
         const float* addrow = g.cin.base ? wn_row(g.cin, m, g.rows_per_batch) : nullptr;
         if (EPI == WN_EPI_GATE) {
+            float* c2row = nullptr;
+            if (g.c2.base) {
+                const unsigned q = (unsigned)m / (unsigned)g.rows_per_batch, rem = (unsigned)m - q * (unsigned)g.rows_per_batch;
+                if ((int)rem >= g.c2_first_row)
+                    c2row = const_cast<float*>(g.c2.base) + (long long)q * g.c2.batch_stride + (g.c2.t0 + (long long)rem - g.c2_first_row) * g.c2.row_stride;
+            }
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
                 const int nf = n0 + 64 * p + col, ng = nf + 32;  // logical columns of F and G
@@ -144,6 +153,7 @@ __global__ __launch_bounds__(256) void wn_fwd_gemm(WnGemmArgs g) {
                 const float gg = acc[2 * p + 1][i] + (g.bias ? g.bias[ng] : 0.f);
                 const float z = tanhf(f) * (1.0f / (1.0f + expf(-gg)));
                 crow[(n0 >> 1) + 32 * p + col] = z;
+                if (c2row) c2row[(n0 >> 1) + 32 * p + col] = z;
             }
         } else {
 #pragma unroll

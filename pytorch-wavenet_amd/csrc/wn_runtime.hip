@@ -228,7 +228,7 @@ struct wn_handle {
     long long* d_prof;
     // batched forward (wn_forward): GEMM-ready weight banks and a workspace that grows on demand
     float* d_fw; size_t fw_floats; bool fw_ok;
-    size_t fw_off_fg, fw_off_bfg, fw_off_res, fw_off_bres, fw_off_skip, fw_off_bskip, fw_off_w1, fw_off_b1, fw_off_w2, fw_off_b2;
+    size_t fw_off_fg, fw_off_bfg, fw_off_res, fw_off_bres, fw_off_skip, fw_off_bskip, fw_off_bskip_total, fw_off_w1, fw_off_b1, fw_off_w2, fw_off_b2;
     float* d_ws; size_t ws_floats;
     int prof_items;      // stamps requested for the next job (0 = off)
     int prof_recorded;   // stamps held in d_prof
@@ -436,6 +436,7 @@ extern "C" int wn_load_weights(wn_handle* h, const wn_weight_ptrs* w) {
             h->fw_off_bres = o; o += (size_t)NL * R;
             h->fw_off_skip = o; o += (size_t)NL * D * S;
             h->fw_off_bskip = o; o += (size_t)NL * S;
+            h->fw_off_bskip_total = o; o += (size_t)S;
             h->fw_off_w1 = o; o += (size_t)S * E;
             h->fw_off_b1 = o; o += (size_t)E;
             h->fw_off_w2 = o; o += (size_t)E * C;
@@ -461,7 +462,10 @@ extern "C" int wn_load_weights(wn_handle* h, const wn_weight_ptrs* w) {
                 }
                 if (pl.has_bias) {
                     for (int r = 0; r < R; ++r) fw[h->fw_off_bres + (size_t)l * R + r] = w->res_b[(size_t)l * R + r];
-                    for (int sc = 0; sc < S; ++sc) fw[h->fw_off_bskip + (size_t)l * S + sc] = w->skip_b[(size_t)l * S + sc];
+                    for (int sc = 0; sc < S; ++sc) {
+                        fw[h->fw_off_bskip + (size_t)l * S + sc] = w->skip_b[(size_t)l * S + sc];
+                        fw[h->fw_off_bskip_total + sc] += w->skip_b[(size_t)l * S + sc];  // the grouped skip GEMM adds all biases once
+                    }
                 }
             }
             for (int sc = 0; sc < S; ++sc)
@@ -676,8 +680,12 @@ extern "C" int wn_forward(wn_handle* h, const int32_t* indices, int64_t N, int64
     need[NL] = out_len;
     for (int l = NL - 1; l >= 0; --l) need[l] = need[l + 1] + h->dil[l];
     const size_t x_fl = (size_t)N * L * R, z_fl = (size_t)N * need[1 < NL ? 1 : NL] * D > (size_t)N * need[NL] * D ? (size_t)N * need[1 < NL ? 1 : NL] * D : (size_t)N * need[NL] * D;
-    const size_t skip_fl = (size_t)N * out_len * S, e_fl = (size_t)N * out_len * E;
-    const size_t total = 2 * x_fl + z_fl + skip_fl + e_fl;
+    // The skip sum over layers is accumulated G layers at a time: the gate epilogue also drops z (last output_length rows)
+    // into column block (l mod G) of ZG [N*out_len][G*D], and one GEMM with K = G*D adds the group to SKIP -- instead of a
+    // read-modify-write of the whole SKIP matrix per layer (1.4 GB per layer at config 5).
+    const int G = pl.layers < NL ? pl.layers : NL;
+    const size_t skip_fl = (size_t)N * out_len * S, e_fl = (size_t)N * out_len * E, zg_fl = (size_t)N * out_len * G * D;
+    const size_t total = 2 * x_fl + z_fl + skip_fl + e_fl + zg_fl;
     if (h->ws_floats < total) {
         if (h->pending) { int rc = wn_wait(h); if (rc) return rc; }
         rt_free(h->d_ws);
@@ -686,6 +694,7 @@ extern "C" int wn_forward(wn_handle* h, const int32_t* indices, int64_t N, int64
         if (!h->d_ws) return wn_fail(WN_E_NOMEM, "wn_forward: workspace of %.1f MB", total * 4e-6);
     }
     float* xa = h->d_ws; float* xb = xa + x_fl; float* z = xb + x_fl; float* skip = z + z_fl; float* ev = skip + skip_fl;
+    float* zg = ev + e_fl;
     hipStream_t st = (hipStream_t)hip_stream;
     {
         const long long rows = N * L;
@@ -702,6 +711,7 @@ extern "C" int wn_forward(wn_handle* h, const int32_t* indices, int64_t N, int64
     float* xin = xa; float* xout = xb;
     for (int l = 0; l < NL; ++l) {
         const long long d = h->dil[l], rows = need[l + 1], t0 = L - rows;
+        const int gi = l % G;
         WnGemmArgs a;
         memset(&a, 0, sizeof(a));
         // z = gate([x(t-d) | x(t)] . Wfg^T)
@@ -710,6 +720,8 @@ extern "C" int wn_forward(wn_handle* h, const int32_t* indices, int64_t N, int64
         a.k_split = R; a.K = 2 * R; a.bt = fw + h->fw_off_fg + (size_t)l * 2 * R * 2 * D; a.N = 2 * D;
         a.bias = pl.has_bias ? fw + h->fw_off_bfg + (size_t)l * 2 * D : nullptr;
         a.c = WnRowMap{z, rows * D, D, 0};
+        a.c2 = WnRowMap{zg + (size_t)gi * D, out_len * (long long)G * D, (long long)G * D, 0};
+        a.c2_first_row = (int)(rows - out_len);
         a.M = N * rows; a.rows_per_batch = (int)rows;
         launch(WN_EPI_GATE, a);
         if (l < NL - 1) {  // x' = z . Wres^T + x(t)   (the last layer's residual output is never consumed, also upstream)
@@ -722,15 +734,17 @@ extern "C" int wn_forward(wn_handle* h, const int32_t* indices, int64_t N, int64
             a.M = N * rows; a.rows_per_batch = (int)rows;
             launch(WN_EPI_PLAIN, a);
         }
-        // skip (+)= z(last output_length positions) . Wskip^T
-        memset(&a, 0, sizeof(a));
-        a.a0 = a.a1 = WnRowMap{z, rows * D, D, rows - out_len};
-        a.k_split = D; a.K = D; a.bt = fw + h->fw_off_skip + (size_t)l * D * S; a.N = S;
-        a.bias = pl.has_bias ? fw + h->fw_off_bskip + (size_t)l * S : nullptr;
-        if (l > 0) a.cin = WnRowMap{skip, out_len * S, S, 0};
-        a.c = WnRowMap{skip, out_len * S, S, 0};
-        a.M = N * out_len; a.rows_per_batch = (int)out_len;
-        launch(WN_EPI_PLAIN, a);
+        if (gi == G - 1 || l == NL - 1) {  // skip (+)= ZG . [Wskip of the group's layers]^T   (K = layers_in_group * D)
+            const int first = l - gi, cnt = gi + 1;
+            memset(&a, 0, sizeof(a));
+            a.a0 = a.a1 = WnRowMap{zg, out_len * (long long)G * D, (long long)G * D, 0};
+            a.k_split = cnt * D; a.K = cnt * D; a.bt = fw + h->fw_off_skip + (size_t)first * D * S; a.N = S;
+            a.bias = (pl.has_bias && first == 0) ? fw + h->fw_off_bskip_total : nullptr;
+            if (first > 0) a.cin = WnRowMap{skip, out_len * S, S, 0};
+            a.c = WnRowMap{skip, out_len * S, S, 0};
+            a.M = N * out_len; a.rows_per_batch = (int)out_len;
+            launch(WN_EPI_PLAIN, a);
+        }
         float* t = xin; xin = xout; xout = t;
     }
     {   // head: relu(skip) -> end_conv_1 (+b, relu) -> end_conv_2 (+b)     wavenet_model.py:167-169

@@ -143,6 +143,13 @@ class WaveNetModel(nn.Module):
         self._wn_forward_calls = getattr(self, "_wn_forward_calls", 0) + 1
         return out.to(input.dtype)
 
+    def forward_indices(self, indices):
+        """Extension: forward() on class indices (N, L) instead of a one-hot (N, classes, L) tensor -- what the
+        dataset holds before audio_data.py:119-121 inflates it 256x.  Inference only (matrix-core path, no autograd)."""
+        out = self._engine(1).forward_indices(indices, self.output_length)
+        self._wn_forward_calls = getattr(self, "_wn_forward_calls", 0) + 1
+        return out
+
     def forward(self, input):
         """(N, classes, L) one-hot -> (N*output_length, classes) logits (wavenet_model.py:186-196)."""
         native = self._native_forward(input)
