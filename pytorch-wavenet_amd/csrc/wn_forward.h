@@ -169,6 +169,136 @@ __global__ __launch_bounds__(256) void wn_fwd_gemm(WnGemmArgs g) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------ bf16 operands
+// Same GEMM with bf16 MFMA operands and fp32 accumulation (v_mfma_f32_32x32x16_bf16, 16x the fp32 matrix rate): the fp32
+// activation rows are rounded to bf16 (RNE) while they are staged into LDS, the weights are pre-converted.  The residual
+// stream X and all accumulators stay fp32.  Opt-in (wn_set_forward_precision): results differ from the fp32 reference at
+// the 1e-2 level of the logit scale -- the usual bf16 training trade -- so the fp32 kernel stays the parity default.
+typedef __bf16 wn_bf16x8 __attribute__((ext_vector_type(8)));
+
+static __device__ __forceinline__ unsigned wn_pack_bf16(float lo, float hi) {  // two RNE-rounded bf16 in one dword
+    unsigned a = __float_as_uint(lo), b = __float_as_uint(hi);
+    a += 0x7fffu + ((a >> 16) & 1u);
+    b += 0x7fffu + ((b >> 16) & 1u);
+    return (a >> 16) | (b & 0xffff0000u);
+}
+
+struct WnGemmArgsBf16 {
+    WnGemmArgs g;              // as the fp32 kernel; g.bt unused
+    const unsigned short* bn;  // B as bf16 [N][K] row-major (K contiguous: the weights' natural (out, in) layout)
+};
+
+template <int EPI>
+__global__ __launch_bounds__(256) void wn_fwd_gemm_bf16(WnGemmArgsBf16 ga) {
+    const WnGemmArgs& g = ga.g;
+    constexpr int TM = 128, TN = 128, KC = 64, LD = KC + 8;  // LD: padded row length (bf16) -> 144-byte rows, conflict-free b128 reads
+    __shared__ __attribute__((aligned(16))) unsigned short a_s[2][TM * LD];
+    __shared__ __attribute__((aligned(16))) unsigned short b_s[2][TN * LD];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const long long m0 = (long long)blockIdx.x * TM;
+    const int n0 = blockIdx.y * TN;
+    wn_f16v acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
+    const int lrow = tid >> 1, lhalf = tid & 1;  // loader: row (A) / column (B) tid/2, 32 of the 64 k each
+    const long long am = m0 + lrow;
+    const bool arow_ok = am < g.M;
+    const float* a0p = arow_ok ? wn_row(g.a0, am, g.rows_per_batch) : nullptr;
+    const float* a1p = arow_ok ? wn_row(g.a1, am, g.rows_per_batch) : nullptr;
+    const bool bcol_ok = n0 + lrow < g.N;
+    const unsigned short* bp = ga.bn + (size_t)(n0 + lrow) * g.K;
+
+    float4 va[8];
+    uint4 vb[4];
+    auto fetch = [&](int kc) {
+        const int k0 = kc * KC;
+        const float* src = (k0 < g.k_split ? a0p + k0 : a1p + (k0 - g.k_split)) + lhalf * 32;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) va[q] = arow_ok ? *reinterpret_cast<const float4*>(src + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const uint4* bsrc = reinterpret_cast<const uint4*>(bp + k0 + lhalf * 32);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) vb[q] = bcol_ok ? bsrc[q] : make_uint4(0u, 0u, 0u, 0u);
+    };
+    auto stash = [&](int buf) {
+        uint4* ad = reinterpret_cast<uint4*>(a_s[buf] + lrow * LD + lhalf * 32);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float4 x = va[2 * q], y = va[2 * q + 1];
+            if (g.relu_a) {
+                x.x = fmaxf(x.x, 0.f); x.y = fmaxf(x.y, 0.f); x.z = fmaxf(x.z, 0.f); x.w = fmaxf(x.w, 0.f);
+                y.x = fmaxf(y.x, 0.f); y.y = fmaxf(y.y, 0.f); y.z = fmaxf(y.z, 0.f); y.w = fmaxf(y.w, 0.f);
+            }
+            ad[q] = make_uint4(wn_pack_bf16(x.x, x.y), wn_pack_bf16(x.z, x.w), wn_pack_bf16(y.x, y.y), wn_pack_bf16(y.z, y.w));
+        }
+        uint4* bd = reinterpret_cast<uint4*>(b_s[buf] + lrow * LD + lhalf * 32);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bd[q] = vb[q];
+    };
+
+    const int nchunks = g.K / KC;
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    for (int kc = 0; kc < nchunks; ++kc) {
+        const int buf = kc & 1;
+        if (kc + 1 < nchunks) fetch(kc + 1);
+        const unsigned short* ar = a_s[buf] + (32 * wv + (lane & 31)) * LD + 8 * (lane >> 5);
+        const unsigned short* br = b_s[buf] + (lane & 31) * LD + 8 * (lane >> 5);
+#pragma unroll
+        for (int ks = 0; ks < KC / 16; ++ks) {
+            const wn_bf16x8 a = *reinterpret_cast<const wn_bf16x8*>(ar + 16 * ks);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const wn_bf16x8 b = *reinterpret_cast<const wn_bf16x8*>(br + 32 * j * LD + 16 * ks);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[j], 0, 0, 0);
+            }
+        }
+        if (kc + 1 < nchunks) stash(buf ^ 1);
+        __syncthreads();
+    }
+
+    const int col = lane & 31;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int r = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+        const long long m = m0 + 32 * wv + r;
+        if (m >= g.M) continue;
+        float* crow = const_cast<float*>(wn_row(g.c, m, g.rows_per_batch));
+        const float* addrow = g.cin.base ? wn_row(g.cin, m, g.rows_per_batch) : nullptr;
+        if (EPI == WN_EPI_GATE) {
+            float* c2row = nullptr;
+            if (g.c2.base) {
+                const unsigned q = (unsigned)m / (unsigned)g.rows_per_batch, rem = (unsigned)m - q * (unsigned)g.rows_per_batch;
+                if ((int)rem >= g.c2_first_row)
+                    c2row = const_cast<float*>(g.c2.base) + (long long)q * g.c2.batch_stride + (g.c2.t0 + (long long)rem - g.c2_first_row) * g.c2.row_stride;
+            }
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const int nf = n0 + 64 * p + col, ng = nf + 32;
+                if (ng >= g.N) continue;
+                const float f = acc[2 * p][i] + (g.bias ? g.bias[nf] : 0.f);
+                const float gg = acc[2 * p + 1][i] + (g.bias ? g.bias[ng] : 0.f);
+                const float z = tanhf(f) * (1.0f / (1.0f + expf(-gg)));
+                crow[(n0 >> 1) + 32 * p + col] = z;
+                if (c2row) c2row[(n0 >> 1) + 32 * p + col] = z;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = n0 + 32 * j + col;
+                if (n >= g.N) continue;
+                float v = acc[j][i] + (g.bias ? g.bias[n] : 0.f);
+                if (addrow) v += addrow[n];
+                if (g.relu_c) v = fmaxf(v, 0.f);
+                crow[n] = v;
+            }
+        }
+    }
+}
+
 // x0[(n,t)][r] = start_conv.weight[r][idx[n][t]] (+ bias): the one-hot input makes start_conv a column gather (wavenet_model.py:127)
 __global__ void wn_fwd_start(const int32_t* idx, const float* start_t, const float* start_b, float* x, long long rows, int R) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;

@@ -230,6 +230,8 @@ struct wn_handle {
     float* d_fw; size_t fw_floats; bool fw_ok;
     size_t fw_off_fg, fw_off_bfg, fw_off_res, fw_off_bres, fw_off_skip, fw_off_bskip, fw_off_bskip_total, fw_off_w1, fw_off_b1, fw_off_w2, fw_off_b2;
     float* d_ws; size_t ws_floats;
+    unsigned short* d_fwb; size_t fwb_elems; bool fwb_ok; int fw_bf16;  // bf16 copies of the forward banks, [N][K] row-major
+    size_t fwb_off_fg, fwb_off_res, fwb_off_skip, fwb_off_w1, fwb_off_w2;
     int prof_items;      // stamps requested for the next job (0 = off)
     int prof_recorded;   // stamps held in d_prof
     std::vector<int64_t> ring_off;
@@ -246,7 +248,7 @@ extern "C" void wn_destroy(wn_handle* h) {
     if (h->pending) (void)hipStreamSynchronize((hipStream_t)h->last_stream);
 #endif
     rt_free(h->d_blobs); rt_free(h->d_start_t); rt_free(h->d_start_b); rt_free(h->d_rings); rt_free(h->d_dil);
-    rt_free(h->d_wg_map); rt_free(h->d_ring_off); rt_free(h->d_gran); rt_free(h->d_status); rt_free(h->d_prof); rt_free(h->d_fw); rt_free(h->d_ws);
+    rt_free(h->d_wg_map); rt_free(h->d_ring_off); rt_free(h->d_gran); rt_free(h->d_status); rt_free(h->d_prof); rt_free(h->d_fw); rt_free(h->d_ws); rt_free(h->d_fwb);
     delete h;
 }
 
@@ -288,6 +290,7 @@ extern "C" int wn_create(const wn_config* cfg, wn_handle** out) {
     h->d_dil = h->d_wg_map = nullptr; h->d_ring_off = nullptr; h->d_gran = nullptr; h->d_status = nullptr;
     h->d_prof = nullptr; h->prof_items = 0; h->prof_recorded = 0;
     h->d_fw = nullptr; h->fw_floats = 0; h->fw_ok = false; h->d_ws = nullptr; h->ws_floats = 0;
+    h->d_fwb = nullptr; h->fwb_elems = 0; h->fwb_ok = false; h->fw_bf16 = 0;
     WnPlan& pl = h->plan;
     pl.layers = cfg->layers; pl.blocks = cfg->blocks; pl.NL = cfg->layers * cfg->blocks;
     pl.R = cfg->residual_channels; pl.D = cfg->dilation_channels; pl.S = cfg->skip_channels; pl.E = cfg->end_channels;
@@ -478,6 +481,40 @@ extern "C" int wn_load_weights(wn_handle* h, const wn_weight_ptrs* w) {
             if (!h->d_fw) return wn_fail(WN_E_NOMEM, "wn_load_weights: forward weight banks (%.1f MB)", o * 4e-6);
             rc = rt_h2d(h->d_fw, fw.data(), o * 4);
             if (rc) return rc;
+            // bf16 copies for wn_set_forward_precision(1): B as [N][K] row-major (K contiguous), K a multiple of 64
+            const int G = pl.layers < NL ? pl.layers : NL;
+            h->fwb_ok = R % 64 == 0 && D % 64 == 0 && S % 64 == 0 && E % 64 == 0 && NL % G == 0;
+            if (h->fwb_ok) {
+                auto bf = [](float x) -> unsigned short {
+                    unsigned u; memcpy(&u, &x, 4);
+                    u += 0x7fffu + ((u >> 16) & 1u);
+                    return (unsigned short)(u >> 16);
+                };
+                size_t ob = 0;
+                h->fwb_off_fg = ob; ob += (size_t)NL * 2 * D * 2 * R;
+                h->fwb_off_res = ob; ob += (size_t)NL * R * D;
+                h->fwb_off_skip = ob; ob += (size_t)NL * D * S;
+                h->fwb_off_w1 = ob; ob += (size_t)E * S;
+                h->fwb_off_w2 = ob; ob += (size_t)C * E;
+                std::vector<unsigned short> wb(ob, 0);
+                for (int l = 0; l < NL; ++l) {
+                    for (int n = 0; n < 2 * D; ++n)  // packed column n of layer l = row n here; k = tap*R + ch
+                        for (int k = 0; k < 2 * R; ++k)
+                            wb[h->fwb_off_fg + ((size_t)l * 2 * D + n) * 2 * R + k] = bf(fw[h->fw_off_fg + (size_t)l * 2 * R * 2 * D + (size_t)k * 2 * D + n]);
+                    for (int r = 0; r < R; ++r)
+                        for (int dch = 0; dch < D; ++dch) wb[h->fwb_off_res + ((size_t)l * R + r) * D + dch] = bf(w->res_w[((size_t)l * R + r) * D + dch]);
+                    const int blk = l / G, li = l % G;  // skip banks are grouped per block: [block][S][G*D]
+                    for (int sc = 0; sc < S; ++sc)
+                        for (int dch = 0; dch < D; ++dch)
+                            wb[h->fwb_off_skip + ((size_t)blk * S + sc) * G * D + (size_t)li * D + dch] = bf(w->skip_w[((size_t)l * S + sc) * D + dch]);
+                }
+                for (size_t i = 0; i < (size_t)E * S; ++i) wb[h->fwb_off_w1 + i] = bf(w->end1_w[i]);
+                for (size_t i = 0; i < (size_t)C * E; ++i) wb[h->fwb_off_w2 + i] = bf(w->end2_w[i]);
+                if (h->fwb_elems != ob) { rt_free(h->d_fwb); h->d_fwb = (unsigned short*)rt_malloc(ob * 2); h->fwb_elems = ob; }
+                if (!h->d_fwb) return wn_fail(WN_E_NOMEM, "wn_load_weights: bf16 forward banks");
+                rc = rt_h2d(h->d_fwb, wb.data(), ob * 2);
+                if (rc) return rc;
+            }
         }
     }
 #endif
@@ -702,11 +739,18 @@ extern "C" int wn_forward(wn_handle* h, const int32_t* indices, int64_t N, int64
         hipLaunchKernelGGL(wn_fwd_start, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, indices, h->d_start_t,
                            pl.has_bias ? h->d_start_b : nullptr, xa, rows, R);
     }
-    auto launch = [&](int epi, const WnGemmArgs& a) {
+    const bool bf16 = h->fw_bf16 && h->fwb_ok;
+    auto launch = [&](int epi, const WnGemmArgs& a, const unsigned short* bn) {
         dim3 grid((unsigned)((a.M + 127) / 128), (unsigned)((a.N + 127) / 128));
-        if (epi == WN_EPI_GATE) hipLaunchKernelGGL(wn_fwd_gemm<WN_EPI_GATE>, grid, dim3(256), 0, st, a);
+        if (bf16) {
+            WnGemmArgsBf16 b;
+            b.g = a; b.bn = bn;
+            if (epi == WN_EPI_GATE) hipLaunchKernelGGL(wn_fwd_gemm_bf16<WN_EPI_GATE>, grid, dim3(256), 0, st, b);
+            else hipLaunchKernelGGL(wn_fwd_gemm_bf16<WN_EPI_PLAIN>, grid, dim3(256), 0, st, b);
+        } else if (epi == WN_EPI_GATE) hipLaunchKernelGGL(wn_fwd_gemm<WN_EPI_GATE>, grid, dim3(256), 0, st, a);
         else hipLaunchKernelGGL(wn_fwd_gemm<WN_EPI_PLAIN>, grid, dim3(256), 0, st, a);
     };
+    const unsigned short* fwb = h->d_fwb;
     const float* fw = h->d_fw;
     float* xin = xa; float* xout = xb;
     for (int l = 0; l < NL; ++l) {
@@ -723,7 +767,7 @@ extern "C" int wn_forward(wn_handle* h, const int32_t* indices, int64_t N, int64
         a.c2 = WnRowMap{zg + (size_t)gi * D, out_len * (long long)G * D, (long long)G * D, 0};
         a.c2_first_row = (int)(rows - out_len);
         a.M = N * rows; a.rows_per_batch = (int)rows;
-        launch(WN_EPI_GATE, a);
+        launch(WN_EPI_GATE, a, bf16 ? fwb + h->fwb_off_fg + (size_t)l * 2 * D * 2 * R : nullptr);
         if (l < NL - 1) {  // x' = z . Wres^T + x(t)   (the last layer's residual output is never consumed, also upstream)
             memset(&a, 0, sizeof(a));
             a.a0 = a.a1 = WnRowMap{z, rows * D, D, 0};
@@ -732,7 +776,7 @@ extern "C" int wn_forward(wn_handle* h, const int32_t* indices, int64_t N, int64
             a.cin = WnRowMap{xin, (long long)L * R, R, t0};
             a.c = WnRowMap{xout, (long long)L * R, R, t0};
             a.M = N * rows; a.rows_per_batch = (int)rows;
-            launch(WN_EPI_PLAIN, a);
+            launch(WN_EPI_PLAIN, a, bf16 ? fwb + h->fwb_off_res + (size_t)l * R * D : nullptr);
         }
         if (gi == G - 1 || l == NL - 1) {  // skip (+)= ZG . [Wskip of the group's layers]^T   (K = layers_in_group * D)
             const int first = l - gi, cnt = gi + 1;
@@ -743,7 +787,7 @@ extern "C" int wn_forward(wn_handle* h, const int32_t* indices, int64_t N, int64
             if (first > 0) a.cin = WnRowMap{skip, out_len * S, S, 0};
             a.c = WnRowMap{skip, out_len * S, S, 0};
             a.M = N * out_len; a.rows_per_batch = (int)out_len;
-            launch(WN_EPI_PLAIN, a);
+            launch(WN_EPI_PLAIN, a, bf16 ? fwb + h->fwb_off_skip + (size_t)(first / G) * S * G * D : nullptr);
         }
         float* t = xin; xin = xout; xout = t;
     }
@@ -754,13 +798,13 @@ extern "C" int wn_forward(wn_handle* h, const int32_t* indices, int64_t N, int64
         a.k_split = S; a.K = S; a.bt = fw + h->fw_off_w1; a.N = E; a.bias = fw + h->fw_off_b1;
         a.c = WnRowMap{ev, out_len * E, E, 0};
         a.M = N * out_len; a.rows_per_batch = (int)out_len; a.relu_a = 1; a.relu_c = 1;
-        launch(WN_EPI_PLAIN, a);
+        launch(WN_EPI_PLAIN, a, bf16 ? fwb + h->fwb_off_w1 : nullptr);
         memset(&a, 0, sizeof(a));
         a.a0 = a.a1 = WnRowMap{ev, out_len * E, E, 0};
         a.k_split = E; a.K = E; a.bt = fw + h->fw_off_w2; a.N = C; a.bias = fw + h->fw_off_b2;
         a.c = WnRowMap{logits, out_len * C, C, 0};
         a.M = N * out_len; a.rows_per_batch = (int)out_len;
-        launch(WN_EPI_PLAIN, a);
+        launch(WN_EPI_PLAIN, a, bf16 ? fwb + h->fwb_off_w2 : nullptr);
     }
     return rt_hip(hipGetLastError(), "wn_forward launches");
 #endif
@@ -860,6 +904,22 @@ extern "C" int wn_prime(wn_handle* h, const int32_t* first_samples, int64_t n_pr
     rc = rt_hip(hipGetLastError(), "wn_prime launches");
     if (rc) return rc;
     h->t_base = n;
+    return WN_OK;
+#endif
+}
+
+// Operand precision of wn_forward's GEMMs: 0 = fp32 (default; matches the reference's fp32 forward to rounding),
+// 1 = bf16 operands with fp32 accumulation (the residual stream and all sums stay fp32).  wn_prime always runs fp32.
+extern "C" int wn_set_forward_precision(wn_handle* h, int32_t bf16) {
+    g_err[0] = 0;
+    if (!h) return wn_fail(WN_E_BADARG, "wn_set_forward_precision: NULL handle");
+#ifdef WN_EMU
+    (void)bf16;
+    return wn_fail(WN_E_UNSUPPORTED, "wn_set_forward_precision: GPU only");
+#else
+    if (bf16 && !h->have_weights) return wn_fail(WN_E_STATE, "wn_set_forward_precision: load the weights first");
+    if (bf16 && !h->fwb_ok) return wn_fail(WN_E_UNSUPPORTED, "wn_set_forward_precision: bf16 needs R, D, S, E to be multiples of 64");
+    h->fw_bf16 = bf16 ? 1 : 0;
     return WN_OK;
 #endif
 }

@@ -50,7 +50,7 @@ class wn_info(ctypes.Structure):
 
 
 EXPORTS = ["wn_abi_version", "wn_create", "wn_destroy", "wn_load_weights", "wn_reset", "wn_generate", "wn_wait",
-           "wn_get_info", "wn_export_queue", "wn_forward", "wn_prime", "wn_profile_next", "wn_profile_read", "wn_last_error"]
+           "wn_get_info", "wn_export_queue", "wn_forward", "wn_set_forward_precision", "wn_prime", "wn_profile_next", "wn_profile_read", "wn_last_error"]
 
 
 class Library:
@@ -82,6 +82,7 @@ class Library:
         d.wn_export_queue.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p,
                                       ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]
         d.wn_forward.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]
+        d.wn_set_forward_precision.argtypes = [ctypes.c_void_p, ctypes.c_int32]
         d.wn_prime.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p]
         d.wn_profile_next.argtypes = [ctypes.c_void_p, ctypes.c_int32]
         d.wn_profile_read.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64]

@@ -143,6 +143,10 @@ class Engine:
         self.lib.check(self.lib.dll.wn_export_queue(self._h, layer, stream, data.ctypes.data, ctypes.byref(ip), ctypes.byref(op)))
         return data, ip.value, op.value
 
+    def set_forward_precision(self, bf16):
+        """bf16 operands (fp32 accumulation) for forward_indices; fp32 is the parity default."""
+        self.lib.check(self.lib.dll.wn_set_forward_precision(self._h, 1 if bf16 else 0))
+
     def forward_indices(self, indices, output_length):
         """WaveNetModel.forward() on class indices: int tensor/array (N, L) -> float32 (N*output_length, classes) on the
         engine's device (a torch tensor; numpy for the emulator is not available: GPU only).  Asynchronous."""

@@ -74,3 +74,45 @@ def test_forward_refuses_padded_regime_and_facade_uses_it_when_valid():
     assert np.abs(y.cpu().numpy() - ref).max() <= TOL
     y2 = mg(x.cuda())  # autograd on: torch path (backward is not native yet)
     assert mg._wn_forward_calls == 1 and y2.requires_grad
+
+
+@pytest.mark.parametrize("cfgname,N,out_len", [("cfg2", 2, 40), ("cfg3", 2, 64)])
+def test_forward_bf16_operands_close_to_fp32(cfgname, N, out_len):
+    """Opt-in bf16 MFMA operands (fp32 accumulation, fp32 residual stream): the usual bf16 trade, not a parity path --
+    logits within 3e-2 of the logit scale of the fp32 kernel, argmax agreement on clearly separated rows."""
+    cfg = synth.CONFIGS[cfgname]
+    W = synth.init_weights(cfg, seed=93)
+    eng = engine.Engine(cfg, W)
+    L = synth.receptive_field(cfg) + out_len - 1
+    ids = np.random.RandomState(93).randint(0, 256, (N, L))
+    y32 = eng.forward_indices(ids, out_len).cpu().numpy()
+    eng.set_forward_precision(True)
+    y16 = eng.forward_indices(ids, out_len).cpu().numpy()
+    eng.set_forward_precision(False)
+    again = eng.forward_indices(ids, out_len).cpu().numpy()
+    assert np.array_equal(again, y32)
+    scale = float(np.abs(y32).max())
+    dev = float(np.abs(y16 - y32).max())
+    print(cfgname, "bf16 vs fp32 max |dlogit|", dev, "scale", scale)
+    assert 0 < dev <= 3e-2 * scale
+    top2 = np.sort(y32, axis=1)
+    clear = (top2[:, -1] - top2[:, -2]) > 4 * dev
+    assert np.array_equal(y16.argmax(1)[clear], y32.argmax(1)[clear])
+
+
+def test_forward_bf16_refused_for_small_channel_counts():
+    cfg = synth.CONFIGS["cfg1"]
+    eng = engine.Engine(cfg, synth.init_weights(cfg, seed=1))
+    with pytest.raises(_abi.WnError) as ei:
+        eng.set_forward_precision(True)
+    assert ei.value.code == _abi.WN_E_UNSUPPORTED
+
+
+def test_forward_indices_extension():
+    cfg = synth.CONFIGS["cfg1"]
+    m, W = _model(cfg, 94, 6)
+    ids = np.random.RandomState(94).randint(0, 256, (2, m.receptive_field + 5))
+    with torch.no_grad():
+        ref = m(_onehot(ids)).numpy()
+    y = m.forward_indices(torch.from_numpy(ids)).cpu().numpy()
+    assert np.abs(y - ref).max() <= TOL

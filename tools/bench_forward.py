@@ -46,6 +46,22 @@ def main():
     ms = ev0.elapsed_time(ev1) / reps
     print("wn_forward N=%d L=%d out_len=%d: %.2f ms, %.2f TFLOP executed -> %.1f TFLOP/s fp32 MFMA (peak 157.3; frac %.3f)" % (
         N, L, out_len, ms, flops / 1e12, flops / ms / 1e9, flops / ms / 1e9 / 157.3))
+    try:
+        eng.set_forward_precision(True)
+        for _ in range(2):
+            yb = eng.forward_indices(ids, out_len)
+        torch.cuda.synchronize()
+        ev0.record()
+        for _ in range(reps):
+            yb = eng.forward_indices(ids, out_len)
+        ev1.record()
+        torch.cuda.synchronize()
+        msb = ev0.elapsed_time(ev1) / reps
+        print("wn_forward bf16 operands: %.2f ms -> %.1f TFLOP/s (bf16 dense peak 2500; frac %.3f); max |dlogit| vs fp32 kernel %.3g (scale %.3g)" % (
+            msb, flops / msb / 1e9, flops / msb / 1e9 / 2500, float((yb - y).abs().max()), float(y.abs().max())))
+        eng.set_forward_precision(False)
+    except Exception as e:  # noqa: BLE001
+        print("bf16 path unavailable:", e)
     # torch path of the facade on the same GPU (the reference's algorithm with ATen/MIOpen ops)
     m = wavenet_model.WaveNetModel(output_length=out_len, **cfg)
     m.load_state_dict({k: torch.from_numpy(v) for k, v in W.items()})
