@@ -34,11 +34,18 @@ struct wn_f4 { float x, y, z, w; };
 #define WN_DEV static __device__ __forceinline__
 #define WN_TID_BEGIN ((int)threadIdx.x)
 #define WN_TID_STEP WN_THREADS
-#define WN_SYNC() __syncthreads()
+// the phases exchange data through LDS only: wait for the LDS counter, not for every outstanding vector-memory operation
+// (__syncthreads() would also drain in-flight polls and write-through stores)
+#define WN_SYNC() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 typedef float4 wn_f4;
 #endif
 
 #define WN_PHASE for (int tid = WN_TID_BEGIN; tid < WN_THREADS; tid += WN_TID_STEP)
+#ifdef WN_EMU
+#define WN_UNROLL
+#else
+#define WN_UNROLL _Pragma("unroll")
+#endif
 
 // where-codes reported in status[4] when a hand-off wait gives up
 enum { WN_W_LOGITS = 1, WN_W_X = 2, WN_W_SKIN = 3, WN_W_HEAD = 4 };
@@ -118,12 +125,44 @@ WN_DEV float wn_wait_granule(WnCtx& cx, const wn_u64* g, uint32_t tag, int where
 #endif
 }
 
+// unchecked read of a granule (the caller looks at the tag)
+WN_DEV wn_u64 wn_peek(const wn_u64* g) {
+#ifdef WN_EMU
+    return *g;
+#else
+    return __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+WN_DEV float wn_granule_value(wn_u64 v) {
+    union { float f; uint32_t u; } c;
+    c.u = (uint32_t)v;
+    return c.f;
+}
+
+// Sum of the n (<= WN_MAX_FANIN) granules base[j*stride] in the fixed order j = 0..n-1.  All loads are issued together
+// and only the ones whose tag is not there yet are waited for one by one: one round trip instead of n.
+#define WN_MAX_FANIN 16
+WN_DEV float wn_gather_sum(WnCtx& cx, const wn_u64* base, size_t stride, int n, uint32_t tag, int where, long long e, int s) {
+    wn_u64 v[WN_MAX_FANIN];
+WN_UNROLL
+    for (int j = 0; j < WN_MAX_FANIN; ++j) v[j] = j < n ? wn_peek(base + (size_t)j * stride) : 0;
+    float sum = 0.f;
+WN_UNROLL
+    for (int j = 0; j < WN_MAX_FANIN; ++j) {
+        if (j < n) sum += ((uint32_t)(v[j] >> 32) == tag) ? wn_granule_value(v[j]) : wn_wait_granule(cx, base + (size_t)j * stride, tag, where, e, s);
+    }
+    return sum;
+}
+
 // true if any thread of the workgroup failed; doubles as a barrier
 WN_DEV bool wn_any_failed(WnCtx& cx) {
 #ifdef WN_EMU
     return cx.fail != 0;
 #else
-    return __syncthreads_or(cx.fail) != 0;
+    int* flag = reinterpret_cast<int*>(cx.lds + cx.p->lds_floats);  // one LDS word behind the layout, zeroed by wn_load_lds
+    if (cx.fail) *flag = 1;
+    WN_SYNC();
+    return *flag != 0;
 #endif
 }
 
@@ -317,10 +356,7 @@ WN_DEV bool wn_l0_input(WnCtx& cx, int c, long long e, int s) {
         const uint32_t tag = (uint32_t)e;
         WN_PHASE {
             for (int i = tid; i < p.C; i += WN_THREADS) {
-                float sum = 0.f;
-                for (int h = 0; h < p.PA; ++h)
-                    sum += wn_wait_granule(cx, p.gl + ((size_t)h * p.n_streams + s) * p.C + i, tag, WN_W_LOGITS, e, s);
-                sm.lgt[i] = sum;
+                sm.lgt[i] = wn_gather_sum(cx, p.gl + (size_t)s * p.C + i, (size_t)p.n_streams * p.C, p.PA, tag, WN_W_LOGITS, e, s);
             }
         }
         if (wn_any_failed(cx)) return false;
@@ -353,7 +389,7 @@ WN_DEV bool wn_l0_input(WnCtx& cx, int c, long long e, int s) {
 }
 
 // One (evaluation e, stream s) step of the workgroup that owns slice c of layer l.
-WN_DEV bool wn_layer_item(WnCtx& cx, int l, int c, long long e, int s) {
+WN_DEV bool wn_layer_item(WnCtx& cx, int l, int c, long long e, int s, int tmod) {  // tmod = (t_base + e) mod max_length of this layer's queue
     const WnPlan& p = *cx.p;
     const WnRun& r = *cx.r;
     float* lds = cx.lds;
@@ -368,10 +404,8 @@ WN_DEV bool wn_layer_item(WnCtx& cx, int l, int c, long long e, int s) {
     } else {
         WN_PHASE {
             for (int i = tid; i < R; i += WN_THREADS) {
-                float sum = 0.f;  // x = sum of the P partials of layer l-1, fixed order
-                for (int cc = 0; cc < P; ++cc)
-                    sum += wn_wait_granule(cx, p.gx + (((size_t)(l - 1) * P + cc) * ns + s) * R + i, tag, WN_W_X, e, s);
-                xt[i] = sum;
+                // x = sum of the P partials of layer l-1, fixed order
+                xt[i] = wn_gather_sum(cx, p.gx + (((size_t)(l - 1) * P) * ns + s) * R + i, (size_t)ns * R, P, tag, WN_W_X, e, s);
             }
             if (!prime)
                 for (int i = tid; i < S; i += WN_THREADS)
@@ -383,15 +417,14 @@ WN_DEV bool wn_layer_item(WnCtx& cx, int l, int c, long long e, int s) {
     {
         const int d = p.dil[l];
         const int ML = (k - 1) * d + 1;  // wavenet_model.py:78
-        const long long t = r.t_base + e;
         float* ring = p.rings + p.ring_off[l] + ((size_t)c * ns + s) * (size_t)ML * R;
         WN_PHASE {
             for (int i = tid; i < R; i += WN_THREADS) {
                 const float x = xt[i];
-                ring[(size_t)(t % ML) * R + i] = x;  // enqueue at in_pos = t mod ML (wavenet_modules.py:55-57)
+                ring[(size_t)tmod * R + i] = x;  // enqueue at in_pos = t mod ML (wavenet_modules.py:55-57)
                 xs[(k - 1) * R + i] = x;
-                for (int j = 1; j < k; ++j) {  // tap k-1-j is x[t - j*d]; zeros before the stream start
-                    long long pos = (t - (long long)j * d) % ML;
+                for (int j = 1; j < k; ++j) {  // tap k-1-j is x[t - j*d]; zeros before the stream start.  j*d < ML
+                    int pos = tmod - j * d;
                     if (pos < 0) pos += ML;
                     xs[(k - 1 - j) * R + i] = ring[(size_t)pos * R + i];
                 }
@@ -448,9 +481,7 @@ WN_DEV bool wn_head_item(WnCtx& cx, int h, long long e, int s) {
     const int S = p.S, P = p.P, ns = p.n_streams;
     WN_PHASE {
         for (int i = tid; i < S; i += WN_THREADS) {
-            float sum = 0.f;
-            for (int cc = 0; cc < P; ++cc)
-                sum += wn_wait_granule(cx, p.gs + (((size_t)(p.NL - 1) * P + cc) * ns + s) * S + i, tag, WN_W_HEAD, e, s);
+            const float sum = wn_gather_sum(cx, p.gs + (((size_t)(p.NL - 1) * P) * ns + s) * S + i, (size_t)ns * S, P, tag, WN_W_HEAD, e, s);
             sk[i] = sum > 0.f ? sum : 0.f;  // relu(skip) :167
         }
     }
@@ -477,7 +508,7 @@ WN_DEV void wn_load_lds(const WnPlan& p, int w, float* lds) {
     const float* src = is_layer ? p.blobs + (size_t)w * p.blob_layer_floats
                                 : p.blobs + (size_t)p.NL * p.P * p.blob_layer_floats + (size_t)(w - p.NL * p.P) * p.blob_head_floats;
     const int n4 = (is_layer ? p.blob_layer_floats : p.blob_head_floats) / 4;
-    const int tot4 = (p.lds_floats + 3) / 4;
+    const int tot4 = (p.lds_floats + 3) / 4 + 1;  // + the fail-flag word behind the layout
     WN_PHASE {
         const wn_f4* s4 = reinterpret_cast<const wn_f4*>(src);
         wn_f4* d4 = reinterpret_cast<wn_f4*>(lds);

@@ -73,10 +73,12 @@ __global__ __launch_bounds__(WN_THREADS) void wn_generate_kernel(WnPlan p, WnRun
     if (w < n_layer_wg) {
         const int l = w / p.P, c = w % p.P;
         const long long n_it = r.n_eval + (l == 0 ? 1 : 0);  // L0 runs one sample-only iteration at the end
-        for (long long e = 0; e < n_it; ++e)
+        const int ML = (p.k - 1) * p.dil[l] + 1;
+        int tmod = (int)(r.t_base % ML);  // queue slot of x[t], kept incrementally (a 64-bit modulo is ~100 scalar instructions)
+        for (long long e = 0; e < n_it; ++e, tmod = tmod + 1 == ML ? 0 : tmod + 1)
             for (int s = 0; s < p.n_streams; ++s) {
                 cx.t_start = (long long)wall_clock64();  // the spin bound is per hand-off wait, not per job
-                if (!wn_layer_item(cx, l, c, e, s)) return;
+                if (!wn_layer_item(cx, l, c, e, s, tmod)) return;
             }
     } else {
         const int h = w - n_layer_wg;
@@ -323,7 +325,7 @@ extern "C" int wn_create(const wn_config* cfg, wn_handle** out) {
             delete h;
             return wn_fail(WN_E_UNSUPPORTED, "wn_create: %s", why.c_str());
         }
-        h->lds_bytes = pl.lds_floats * 4;
+        h->lds_bytes = (pl.lds_floats + 8) * 4;  // + the fail-flag word (wn_any_failed)
     }
     // tables
     h->dil.resize(pl.NL); h->ring_off.resize(pl.NL);
@@ -537,6 +539,7 @@ extern "C" int wn_reset(wn_handle* h, void* hip_stream) {
 // Sequential schedule honouring the chain's dependencies: for every evaluation and stream run L0..L(NL-1)
 // (all slices), then the head slices; finally L0's sample-only iteration.
 static void wn_emu_run(const WnPlan& p, const WnRun& r, std::vector<std::vector<float>>& lds) {
+    const int32_t* dil_host = p.dil;  // host memory in the emulator build
     const int n_lw = p.NL * p.P;
     auto ctx = [&](int w) {
         WnCtx cx;
@@ -549,7 +552,8 @@ static void wn_emu_run(const WnPlan& p, const WnRun& r, std::vector<std::vector<
                 const int l = w / p.P, c = w % p.P;
                 if (e == r.n_eval && l != 0) continue;
                 WnCtx cx = ctx(w);
-                if (!wn_layer_item(cx, l, c, e, s)) return;
+                const int ML = (p.k - 1) * dil_host[l] + 1;
+                if (!wn_layer_item(cx, l, c, e, s, (int)((r.t_base + e) % ML))) return;
             }
             if (e == r.n_eval) continue;
             for (int hh = 0; hh < p.PA; ++hh) {
@@ -600,7 +604,7 @@ extern "C" int wn_generate(wn_handle* h, const wn_generate_args* a) {
     if (rc) return rc;
 #ifdef WN_EMU
     {
-        std::vector<std::vector<float>> lds(h->plan.n_wg, std::vector<float>((size_t)h->plan.lds_floats + 4, 0.f));
+        std::vector<std::vector<float>> lds(h->plan.n_wg, std::vector<float>((size_t)h->plan.lds_floats + 8, 0.f));
         for (int w = 0; w < h->plan.n_wg; ++w) wn_load_lds(h->plan, w, lds[w].data());
         wn_emu_run(h->plan, r, lds);
     }
