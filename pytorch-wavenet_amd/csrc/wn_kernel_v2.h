@@ -25,6 +25,9 @@
 
 #ifndef WN_EMU
 
+#ifndef WN_MULTI_SLEEP
+#define WN_MULTI_SLEEP 0
+#endif
 #ifndef WN_ABL
 #define WN_ABL 0  // timing ablations for tools/ablate.sh (results are wrong when != 0): 1 no fg dot, 2 cheap gating, 3 no res dot, 5 all
 #endif
@@ -121,7 +124,7 @@ static __device__ __forceinline__ wn_u64 wn_ld_granule(const wn_u64* g) {
 
 // Batched poll with a compile-time count: loads the N granules base[j*stride] together until every tag matches;
 // returns their sum in the fixed order j = 0..N-1.
-template <int N>
+template <int N, int SLEEP = 0>  // SLEEP > 0: s_sleep between retries (multi-stream fallback: keep poll pressure off the fabric)
 static __device__ __forceinline__ float wn_poll_fixed(WnCtx& cx, const wn_u64* base, size_t stride, uint32_t tag, int where,
                                                       long long e, int s) {
     if (cx.fail) return 0.f;
@@ -143,6 +146,7 @@ static __device__ __forceinline__ float wn_poll_fixed(WnCtx& cx, const wn_u64* b
             if (__hip_atomic_load(cx.p->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { cx.fail = 1; return 0.f; }
             if ((long long)wall_clock64() - cx.t_start > cx.r->timeout_ticks) { wn_give_up(cx, where, e, s); return 0.f; }
         }
+        if constexpr (SLEEP > 0) __builtin_amdgcn_s_sleep(SLEEP);
     }
 }
 
@@ -613,12 +617,57 @@ static __device__ void wn_v2_head(const WnPlan& p, const WnRun& r, WnCtx& cx, fl
 //   * the queue tap x[t+1-d] of the current stream is requested at the top of the item and consumed in its tail;
 //   * sampling is moved off L0 onto NSMP dedicated sampler workgroups (chain positions after the head): they turn
 //     partial logits into a class index per stream and publish it as an index granule gi[s]; L0 only gathers.
-template <class SH, int P>
+// LDS layout (floats) of the multi-stream kernel: G streams are processed per pipeline item
+template <class SH, int G>
+struct WnV2LdsM {
+    static constexpr int XR = SH::R + 4 * SH::T1, SKP = SH::S + 4 * SH::T3, DCP = (SH::DC + 3) & ~3;
+    static constexpr int xs = 0;                   // [2][G][XR]
+    static constexpr int zs = xs + 2 * G * XR;     // [G][DCP]
+    static constexpr int xo = zs + G * DCP;        // [G][XR]  queue taps of the item
+    static constexpr int sk = xo + G * XR;         // [G][SKP] head
+    static constexpr int ev = sk + G * SKP;        // [G][EC]  head
+    static constexpr int smp = ev + G * SH::EC;    // sampler scratch (64 floats); [48] fail flag, [52..] flags
+    static constexpr int park = smp + 64;          // 8 parked int64 stamps
+    static constexpr int pre = park + 16;          // [n_streams][256]
+    static __host__ __device__ int floats(int n_streams) { return pre + n_streams * 256; }
+};
+
+// dot of one register weight vector with G LDS vectors (G items share every weight operand)
+template <int K, int G>
+static __device__ __forceinline__ void wn_dot_lds_g(const float (&w)[K], const float* x, int xstride, const float (&init)[G], float (&out)[G]) {
+    static_assert(K % 4 == 0 || G >= 1, "");
+    if constexpr (K % 4 == 0) {
+        float4 v[G][K / 4];
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int k = 0; k < K / 4; ++k) v[g][k] = reinterpret_cast<const float4*>(x + g * xstride)[k];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            float a0 = init[g], a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+            for (int k = 0; k < K / 4; ++k) {
+                a0 += w[4 * k] * v[g][k].x; a1 += w[4 * k + 1] * v[g][k].y; a2 += w[4 * k + 2] * v[g][k].z; a3 += w[4 * k + 3] * v[g][k].w;
+            }
+            out[g] = (a0 + a1) + (a2 + a3);
+        }
+    } else {
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            float a = init[g];
+#pragma unroll
+            for (int k = 0; k < K; ++k) a += w[k] * x[g * xstride + k];
+            out[g] = a;
+        }
+    }
+}
+
+template <class SH, int P, int G>
 static __device__ void wn_v2_layer_multi(const WnPlan& p, const WnRun& r, WnCtx& cx, float* lds, int l, int c) {
     constexpr int R = SH::R, DC = SH::DC, S = SH::S, T1 = SH::T1, K1 = SH::K1, T2 = SH::T2, K2 = SH::K2, RS = SH::RS;
-    using L = WnV2Lds<SH>;
+    using L = WnV2LdsM<SH, G>;
     const int tid = threadIdx.x;
-    const int ns = p.n_streams, NL = p.NL;
+    const int ns = p.n_streams, NL = p.NL, ni = ns / G;  // ni items (of G streams) per evaluation
     float w1[K1], w0[K1], w2[K2], w3[RS][DC], bskip[RS];
     const float* img = p.blobs + (size_t)cx.w * (SH::NWL * 256) + tid;
     {
@@ -645,6 +694,7 @@ static __device__ void wn_v2_layer_multi(const WnPlan& p, const WnRun& r, WnCtx&
     const int ML = d + 1;
     float* xs = lds + L::xs;
     float* zs = lds + L::zs;
+    float* xol = lds + L::xo;
     float* pre = lds + L::pre;
     float* smp = lds + L::smp;
     int* failflag = reinterpret_cast<int*>(smp + 48);
@@ -681,13 +731,15 @@ static __device__ void wn_v2_layer_multi(const WnPlan& p, const WnRun& r, WnCtx&
 
     // One-item-ahead request registers.  The request code is branch-free with a compile-time load count: a load
     // destination that is merged across control flow gets copied, and the copy waits for the load.
-    wn_u64 nx[P];    // l > 0, tid < R: the P x' partials of the next item;  l == 0: the index granule (P copies)
+    wn_u64 nx[G][P];  // l > 0, tid < R: the P x' partials of each stream of the next item;  l == 0: the index granules
     const wn_u64* xbase = l == 0 ? p.gi : p.gx + ((size_t)(l - 1) * P) * ns * R + (tid < R ? tid : 0);
     const size_t xstep_s = l == 0 ? 1 : R, xstep_j = l == 0 ? 0 : (size_t)ns * R;
     const wn_u64* sbase = p.gs + (((size_t)(l > 0 ? l - 1 : 0) * P + c) * ns) * S + tid;
-    auto request = [&](int s2) {  // issue the loads for the item of stream s2 that comes next
+    auto request = [&](int it2) {  // issue the loads for item it2 (streams it2*G .. it2*G+G-1)
 #pragma unroll
-        for (int j = 0; j < P; ++j) nx[j] = wn_ld_granule(xbase + (size_t)s2 * xstep_s + (size_t)j * xstep_j);
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int j = 0; j < P; ++j) nx[g][j] = wn_ld_granule(xbase + (size_t)(it2 * G + g) * xstep_s + (size_t)j * xstep_j);
     };
     request(0);
 
@@ -698,113 +750,154 @@ static __device__ void wn_v2_layer_multi(const WnPlan& p, const WnRun& r, WnCtx&
         const bool prime = e < r.n_given - 1;
         const uint32_t tag = (uint32_t)(e + 1);
         const int tapmod = tmod + 2 >= ML ? tmod + 2 - ML : tmod + 2;  // slot of x[t+1-d]
-        for (int s = 0; s < ns; ++s, buf ^= 1) {
-            float* xb = xs + buf * L::XR;
+        for (int it = 0; it < ni; ++it, buf ^= 1) {
+            const int s0 = it * G;
+            float* xb = xs + buf * (G * L::XR);  // [G][XR]
             cx.t_start = (long long)wall_clock64();
-            const long long item = e * ns + s;
+            const long long item = e * ni + it;
             wn_stamp(r, park, item, 0);
-            float* ring = p.rings + p.ring_off[l] + ((size_t)c * ns + s) * (size_t)ML * R;
-            // ---- 1. layer input x[t] from the registers requested one item ago
+            float* ring0 = p.rings + p.ring_off[l] + ((size_t)c * ns + s0) * (size_t)ML * R;  // rings of consecutive streams are ML*R apart
+            // ---- 1. layer inputs x[t] of the G streams from the registers requested one item ago
             if (l == 0) {
-                int idx;
-                if (e == 0) {
-                    idx = r.first[(size_t)s * r.n_given];
-                } else {
-                    wn_u64 g = nx[0];
-                    if ((uint32_t)(g >> 32) != (uint32_t)e) {
-                        unsigned spins = 0;
-                        while ((uint32_t)((g = wn_ld_granule(p.gi + s)) >> 32) != (uint32_t)e) {
-                            if ((++spins & 127u) == 0u) {
-                                if (__hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { cx.fail = 1; break; }
-                                if ((long long)wall_clock64() - cx.t_start > r.timeout_ticks) { wn_give_up(cx, WN_W_LOGITS, e, s); break; }
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    const int s = s0 + g;
+                    int idx;
+                    if (e == 0) {
+                        idx = r.first[(size_t)s * r.n_given];
+                    } else {
+                        wn_u64 gv = nx[g][0];
+                        if ((uint32_t)(gv >> 32) != (uint32_t)e) {
+                            unsigned spins = 0;
+                            while ((uint32_t)((gv = wn_ld_granule(p.gi + s)) >> 32) != (uint32_t)e) {
+                                if ((++spins & 127u) == 0u) {
+                                    if (__hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { cx.fail = 1; break; }
+                                    if ((long long)wall_clock64() - cx.t_start > r.timeout_ticks) { wn_give_up(cx, WN_W_LOGITS, e, s); break; }
+                                }
                             }
                         }
+                        idx = (int)(uint32_t)gv & 255;
                     }
-                    idx = (int)(uint32_t)g & 255;
+                    if (tid < R) xb[g * L::XR + SH::xpad(tid)] = p.start_t[(size_t)idx * R + tid] + (p.start_b ? p.start_b[tid] : 0.f);
                 }
-                if (tid < R) xb[SH::xpad(tid)] = p.start_t[(size_t)idx * R + tid] + (p.start_b ? p.start_b[tid] : 0.f);
             } else if (tid < R) {
-                bool ok = true;
-                float sum = 0.f;
 #pragma unroll
-                for (int j = 0; j < P; ++j) { ok = ok && ((uint32_t)(nx[j] >> 32) == tag); sum += __uint_as_float((uint32_t)nx[j]); }
-                if (!ok) { sum = wn_poll_fixed<P>(cx, p.gx + (((size_t)(l - 1) * P) * ns + s) * R + tid, (size_t)ns * R, tag, WN_W_X, e, s); if (tid == 0) ++misses; }
-                xb[SH::xpad(tid)] = sum;
+                for (int g = 0; g < G; ++g) {
+                    bool ok = true;
+                    float sum = 0.f;
+#pragma unroll
+                    for (int j = 0; j < P; ++j) { ok = ok && ((uint32_t)(nx[g][j] >> 32) == tag); sum += __uint_as_float((uint32_t)nx[g][j]); }
+                    if (!ok) {
+                        sum = wn_poll_fixed<P, WN_MULTI_SLEEP>(cx, p.gx + (((size_t)(l - 1) * P) * ns + s0 + g) * R + tid, (size_t)ns * R, tag, WN_W_X, e, s0 + g);
+                        if (tid == 0) ++misses;
+                    }
+                    xb[g * L::XR + SH::xpad(tid)] = sum;
+                }
             }
             wn_stamp(r, park, item, 4);
-            if (r.prof && item < r.prof_items && tid == 64) park[7] = (long long)wall_clock64();  // wave 1 has its input
-            // this item's skip lane: the upstream published it a little after the x' we just consumed, so a load
-            // issued now lands while the gated unit computes and is checked in the tail
-            wn_u64 sk_now[RS];
+            // this item's skip lanes: the upstream published them a little after the x' we just consumed, so loads
+            // issued now land while the gated units compute and are checked in the tail
+            wn_u64 sk_now[G][RS];
 #pragma unroll
-            for (int q = 0; q < RS; ++q) sk_now[q] = wn_ld_granule(sbase + (size_t)s * S + 256 * q);
-            // queue tap x[t+1-d] of this stream, consumed in the tail: ONE coalesced row load by the first R lanes (the
-            // row is shared by all 256 lanes; 8 x 16-byte loads per lane cost 12 % of the item).  Requested only now:
-            // vector loads return in order, an HBM miss issued ahead of the polls would have stalled every poll behind it.
-            float xo_v = 0.f;
-            if (d != 1 && tid < R) xo_v = (WN_ABL == 7) ? 0.f : ring[(size_t)tapmod * R + tid];
+            for (int g = 0; g < G; ++g)
+#pragma unroll
+                for (int q = 0; q < RS; ++q) sk_now[g][q] = wn_ld_granule(sbase + (size_t)(s0 + g) * S + 256 * q);
+            // queue taps x[t+1-d], consumed in the tail: ONE coalesced row load per stream by the first R lanes.
+            // Requested only now: vector loads return in order, an HBM miss ahead of the polls would stall every poll.
+            float xo_v[G];
+#pragma unroll
+            for (int g = 0; g < G; ++g) xo_v[g] = (d != 1 && tid < R) ? ring0[((size_t)g * ML + tapmod) * R + tid] : 0.f;
             if (wn_barrier_failed(cx, failflag)) return;
             wn_stamp(r, park, item, 1);
-            // ---- 2. filter/gate
-            const float xres = (c == 0 && kq2 == 0) ? xb[SH::xpad(row2)] : 0.f;
-            float acc = wn_dot_lds<K1>(w1, xb + kq1 * (K1 + 4), pre[s * 256 + tid]);
-            acc = wn_reduce<T1>(acc);
-            const float other = wn_partner<T1>(acc);
-            const float fv = is_gate ? other : acc, gv = is_gate ? acc : other;
-            const float z = wn_gate(fv, gv);
-            if (!is_gate && kq1 == 0) zs[ch] = z;
+            // ---- 2. filter/gate of the G streams: every weight operand is used G times
+            float xres[G], pin[G], acc[G];
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                xres[g] = (c == 0 && kq2 == 0) ? xb[g * L::XR + SH::xpad(row2)] : 0.f;
+                pin[g] = pre[(s0 + g) * 256 + tid];
+            }
+            wn_dot_lds_g<K1, G>(w1, xb + kq1 * (K1 + 4), L::XR, pin, acc);
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const float a = wn_reduce<T1>(acc[g]);
+                const float other = wn_partner<T1>(a);
+                const float fv = is_gate ? other : a, gv = is_gate ? a : other;
+                const float z = wn_gate(fv, gv);
+                if (!is_gate && kq1 == 0) zs[g * L::DCP + ch] = z;
+            }
             wn_lds_barrier();
-            // ---- 3. residual partial
+            // ---- 3. residual partials
             if (l < NL - 1) {
-                float a2 = wn_dot_lds<K2>(w2, zs + kq2 * K2, 0.f);
-                a2 = wn_reduce<T2>(a2);
-                if (kq2 == 0) wn_publish_at(p.gx + ((size_t)cx.w * ns + s) * R + row2, tag, (a2 + bres) + xres, local_x);
+                float zero[G], a2[G];
+#pragma unroll
+                for (int g = 0; g < G; ++g) zero[g] = 0.f;
+                wn_dot_lds_g<K2, G>(w2, zs + kq2 * K2, L::DCP, zero, a2);
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    const float v = wn_reduce<T2>(a2[g]);
+                    if (kq2 == 0) wn_publish_at(p.gx + ((size_t)cx.w * ns + s0 + g) * R + row2, tag, (v + bres) + xres[g], local_x);
+                }
             }
             wn_stamp(r, park, item, 2);
-            if (r.prof && item < r.prof_items && tid == 192) park[6] = (long long)wall_clock64();  // wave 3 has published
             // Request the NEXT item's x' partials only now: in the stage-bound steady state the upstream slice starts
             // that item less than one gated unit before us, so a request issued at staging time would come back stale
             // (measured: 71 % misses) and put a full poll round trip on the next item's critical path.
-            request(s + 1 < ns ? s + 1 : 0);
-            // ---- 4. skip partial on this lane of the running skip sum
-            wn_u64* gs = p.gs + ((size_t)cx.w * ns + s) * S;
+            request(it + 1 < ni ? it + 1 : 0);
+            // ---- 4. skip partials on this lane of the running skip sums
             if (!prime) {
-                float a3[RS];
+                float a3[G][RS];
 #pragma unroll
-                for (int q = 0; q < RS; ++q) a3[q] = bskip[q];
+                for (int g = 0; g < G; ++g)
+#pragma unroll
+                    for (int q = 0; q < RS; ++q) a3[g][q] = bskip[q];
 #pragma unroll
                 for (int k = 0; k < DC; ++k) {
-                    const float zk = zs[k];
 #pragma unroll
-                    for (int q = 0; q < RS; ++q) a3[q] += w3[q][k] * zk;
+                    for (int g = 0; g < G; ++g) {
+                        const float zk = zs[g * L::DCP + k];
+#pragma unroll
+                        for (int q = 0; q < RS; ++q) a3[g][q] += w3[q][k] * zk;
+                    }
                 }
 #pragma unroll
-                for (int q = 0; q < RS; ++q) {
-                    if (l > 0) {
-                        float v;
-                        if ((uint32_t)(sk_now[q] >> 32) == tag) v = __uint_as_float((uint32_t)sk_now[q]);
-                        else v = wn_poll_fixed<1>(cx, p.gs + (((size_t)(l - 1) * P + c) * ns + s) * S + tid + 256 * q, 0, tag, WN_W_SKIN, e, s);
-                        a3[q] += v;
+                for (int g = 0; g < G; ++g) {
+                    wn_u64* gs = p.gs + ((size_t)cx.w * ns + s0 + g) * S;
+#pragma unroll
+                    for (int q = 0; q < RS; ++q) {
+                        if (l > 0) {
+                            float v;
+                            if ((uint32_t)(sk_now[g][q] >> 32) == tag) v = __uint_as_float((uint32_t)sk_now[g][q]);
+                            else v = wn_poll_fixed<1>(cx, p.gs + (((size_t)(l - 1) * P + c) * ns + s0 + g) * S + tid + 256 * q, 0, tag, WN_W_SKIN, e, s0 + g);
+                            a3[g][q] += v;
+                        }
+                        wn_publish_at(gs + tid + 256 * q, tag, a3[g][q], local_s);
                     }
-                    wn_publish_at(gs + tid + 256 * q, tag, a3[q], local_s);
                 }
             } else if (l == NL - 1) {
 #pragma unroll
-                for (int q = 0; q < RS; ++q) wn_publish_at(gs + tid + 256 * q, tag, 0.f, local_s);
+                for (int g = 0; g < G; ++g)
+#pragma unroll
+                    for (int q = 0; q < RS; ++q) wn_publish_at(p.gs + ((size_t)cx.w * ns + s0 + g) * S + tid + 256 * q, tag, 0.f, local_s);
             }
-            // ---- 5. queue push and the next step's tap 0
+            // ---- 5. queue pushes and the next step's tap 0
             {
-                if (tid < R) ring[(size_t)tmod * R + tid] = xb[SH::xpad(tid)];
-                float a0 = kq1 == 0 ? bfg : 0.f;
-                if (d == 1) {
-                    a0 = wn_dot_lds<K1>(w0, xb + kq1 * (K1 + 4), a0);
-                } else {
-                    float* xol = lds + L::xo;
-                    if (tid < R) xol[SH::xpad(tid)] = xo_v;
-                    wn_lds_barrier();
-                    a0 = wn_dot_lds<K1>(w0, xol + kq1 * (K1 + 4), a0);
+                float a0i[G], a0[G];
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    if (tid < R) ring0[((size_t)g * ML + tmod) * R + tid] = xb[g * L::XR + SH::xpad(tid)];
+                    a0i[g] = kq1 == 0 ? bfg : 0.f;
                 }
-                pre[s * 256 + tid] = a0;
+                if (d == 1) {
+                    wn_dot_lds_g<K1, G>(w0, xb + kq1 * (K1 + 4), L::XR, a0i, a0);
+                } else {
+#pragma unroll
+                    for (int g = 0; g < G; ++g)
+                        if (tid < R) xol[g * L::XR + SH::xpad(tid)] = xo_v[g];
+                    wn_lds_barrier();
+                    wn_dot_lds_g<K1, G>(w0, xol + kq1 * (K1 + 4), L::XR, a0i, a0);
+                }
+#pragma unroll
+                for (int g = 0; g < G; ++g) pre[(s0 + g) * 256 + tid] = a0[g];
             }
             wn_stamp(r, park, item, 3);
             if (r.prof && tid == 0) park[5] = misses;
@@ -813,11 +906,11 @@ static __device__ void wn_v2_layer_multi(const WnPlan& p, const WnRun& r, WnCtx&
     }
 }
 
-template <class SH, int P>
+template <class SH, int P, int G>
 static __device__ void wn_v2_head_multi(const WnPlan& p, const WnRun& r, WnCtx& cx, float* lds, int h) {
     constexpr int S = SH::S, EC = SH::EC, T3 = SH::T3, K3 = SH::K3, QS = S / 256;
-    using L = WnV2Lds<SH>;
-    const int tid = threadIdx.x, ns = p.n_streams, NL = p.NL;
+    using L = WnV2LdsM<SH, G>;
+    const int tid = threadIdx.x, ns = p.n_streams, NL = p.NL, ni = ns / G;
     float w4[K3], w5[EC];
     const float* img = p.blobs + (size_t)NL * P * (SH::NWL * 256) + (size_t)h * (SH::NWH * 256) + tid;
 #pragma unroll
@@ -839,48 +932,59 @@ static __device__ void wn_v2_head_multi(const WnPlan& p, const WnRun& r, WnCtx& 
     }
     __syncthreads();
     const bool local_l = locflags[0] != 0;
-    wn_u64 ng[QS][P];
+    wn_u64 ng[G][QS][P];
     const wn_u64* gbase = p.gs + ((size_t)(NL - 1) * P) * ns * S + tid;
-    auto request = [&](int s2) {  // branch-free, compile-time count (see wn_v2_layer_multi)
+    auto request = [&](int it2) {  // branch-free, compile-time count (see wn_v2_layer_multi)
 #pragma unroll
-        for (int q = 0; q < QS; ++q)
+        for (int g = 0; g < G; ++g)
 #pragma unroll
-            for (int j = 0; j < P; ++j) ng[q][j] = wn_ld_granule(gbase + (size_t)s2 * S + 256 * q + (size_t)j * ns * S);
+            for (int q = 0; q < QS; ++q)
+#pragma unroll
+                for (int j = 0; j < P; ++j) ng[g][q][j] = wn_ld_granule(gbase + (size_t)(it2 * G + g) * S + 256 * q + (size_t)j * ns * S);
     };
     request(0);
     for (long long e = 0; e < r.n_eval; ++e) {
         const bool prime = e < r.n_given - 1;
         const uint32_t tag = (uint32_t)(e + 1);
-        for (int s = 0; s < ns; ++s) {
+        for (int it = 0; it < ni; ++it) {
+            const int s0 = it * G;
             cx.t_start = (long long)wall_clock64();
-            const long long item = e * ns + s;
+            const long long item = e * ni + it;
             wn_stamp(r, park, item, 0);
 #pragma unroll
-            for (int q = 0; q < QS; ++q) {
-                bool ok = true;
-                float sum = 0.f;
+            for (int g = 0; g < G; ++g)
 #pragma unroll
-                for (int j = 0; j < P; ++j) { ok = ok && ((uint32_t)(ng[q][j] >> 32) == tag); sum += __uint_as_float((uint32_t)ng[q][j]); }
-                if (!ok) sum = wn_poll_fixed<P>(cx, p.gs + (((size_t)(NL - 1) * P) * ns + s) * S + tid + 256 * q, (size_t)ns * S, tag, WN_W_HEAD, e, s);
-                sk[SH::skpad(tid + 256 * q)] = sum > 0.f ? sum : 0.f;
-            }
-            {
-                request(s + 1 < ns ? s + 1 : 0);
-            }
+                for (int q = 0; q < QS; ++q) {
+                    bool ok = true;
+                    float sum = 0.f;
+#pragma unroll
+                    for (int j = 0; j < P; ++j) { ok = ok && ((uint32_t)(ng[g][q][j] >> 32) == tag); sum += __uint_as_float((uint32_t)ng[g][q][j]); }
+                    if (!ok) sum = wn_poll_fixed<P>(cx, p.gs + (((size_t)(NL - 1) * P) * ns + s0 + g) * S + tid + 256 * q, (size_t)ns * S, tag, WN_W_HEAD, e, s0 + g);
+                    sk[g * L::SKP + SH::skpad(tid + 256 * q)] = sum > 0.f ? sum : 0.f;
+                }
+            request(it + 1 < ni ? it + 1 : 0);
             if (wn_barrier_failed(cx, failflag)) return;
             wn_stamp(r, park, item, 1);
-            wn_u64* gl = p.gl + ((size_t)h * ns + s) * 256;
             if (!prime) {
-                float a = wn_dot_lds<K3>(w4, sk + kq3 * (K3 + 4), 0.f);
-                a = wn_reduce<T3>(a);
-                if (kq3 == 0) {
-                    const float v = a + b1;
-                    ev[row3] = v > 0.f ? v : 0.f;
+                float zero[G], a[G];
+#pragma unroll
+                for (int g = 0; g < G; ++g) zero[g] = 0.f;
+                wn_dot_lds_g<K3, G>(w4, sk + kq3 * (K3 + 4), L::SKP, zero, a);
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    const float v = wn_reduce<T3>(a[g]) + b1;
+                    if (kq3 == 0) ev[g * EC + row3] = v > 0.f ? v : 0.f;
                 }
                 wn_lds_barrier();
-                wn_publish_at(gl + tid, tag, wn_dot_lds<EC>(w5, ev, b2), local_l);
+                float bb[G], o[G];
+#pragma unroll
+                for (int g = 0; g < G; ++g) bb[g] = b2;
+                wn_dot_lds_g<EC, G>(w5, ev, EC, bb, o);
+#pragma unroll
+                for (int g = 0; g < G; ++g) wn_publish_at(p.gl + ((size_t)h * ns + s0 + g) * 256 + tid, tag, o[g], local_l);
             } else {
-                wn_publish_at(gl + tid, tag, 0.f, local_l);
+#pragma unroll
+                for (int g = 0; g < G; ++g) wn_publish_at(p.gl + ((size_t)h * ns + s0 + g) * 256 + tid, tag, 0.f, local_l);
             }
             wn_stamp(r, park, item, 2);
             wn_lds_barrier();
@@ -930,7 +1034,7 @@ static __device__ void wn_v2_sampler(const WnPlan& p, const WnRun& r, WnCtx& cx,
     }
 }
 
-template <int R, int DC, int S, int EC, int P>
+template <int R, int DC, int S, int EC, int P, int G>
 __global__ __launch_bounds__(WN_THREADS) void wn_generate_kernel_v2m(WnPlan p, WnRun r) {
     using SH = WnV2Shape<R, DC, S, EC>;
     extern __shared__ __attribute__((aligned(16))) float wn_lds2m[];
@@ -940,9 +1044,9 @@ __global__ __launch_bounds__(WN_THREADS) void wn_generate_kernel_v2m(WnPlan p, W
     cx.p = &p; cx.r = &r; cx.lds = wn_lds2m; cx.w = w; cx.fail = 0;
     cx.t_start = (long long)wall_clock64();
     const int n_layer_wg = p.NL * p.P;
-    if (w < n_layer_wg) wn_v2_layer_multi<SH, P>(p, r, cx, wn_lds2m, w / P, w % P);
-    else if (w < n_layer_wg + p.PA) wn_v2_head_multi<SH, P>(p, r, cx, wn_lds2m, w - n_layer_wg);
-    else wn_v2_sampler(p, r, cx, wn_lds2m + WnV2Lds<SH>::smp, w - n_layer_wg - p.PA);
+    if (w < n_layer_wg) wn_v2_layer_multi<SH, P, G>(p, r, cx, wn_lds2m, w / P, w % P);
+    else if (w < n_layer_wg + p.PA) wn_v2_head_multi<SH, P, G>(p, r, cx, wn_lds2m, w - n_layer_wg);
+    else wn_v2_sampler(p, r, cx, wn_lds2m + WnV2LdsM<SH, G>::smp, w - n_layer_wg - p.PA);
 }
 
 template <int R, int DC, int S, int EC>

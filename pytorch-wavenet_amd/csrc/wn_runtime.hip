@@ -100,11 +100,13 @@ struct WnV2Entry {
     int R, DC, S, EC, nwl, nwh;
     int Pm;  // layer split the multi-stream kernel is compiled for (its request code is unrolled over it)
     const void* fn;
-    const void* fn_multi;
+    const void* fn_multi;   // one stream per pipeline item
+    const void* fn_multi2;  // two streams per pipeline item (even stream counts)
     int (*lds_floats)(int);
     int (*lds_floats_with_start)(int);
+    int (*lds_floats_multi)(int ns, int g);
     void (*launch)(int grid, size_t lds, hipStream_t st, const WnPlan& p, const WnRun& r);
-    void (*launch_multi)(int grid, size_t lds, hipStream_t st, const WnPlan& p, const WnRun& r);
+    void (*launch_multi)(int g, int grid, size_t lds, hipStream_t st, const WnPlan& p, const WnRun& r);
     void (*pack)(const WnPlan& pl, const WnHostWeights& w, std::vector<float>& out);
 };
 
@@ -162,9 +164,12 @@ static WnV2Entry wn_v2_entry() {
     WnV2Entry e;
     e.R = R; e.DC = DC; e.S = S; e.EC = EC; e.nwl = SH::NWL; e.nwh = SH::NWH; e.Pm = PM;
     e.fn = (const void*)wn_generate_kernel_v2<R, DC, S, EC>;
-    e.fn_multi = (const void*)wn_generate_kernel_v2m<R, DC, S, EC, PM>;
-    e.launch_multi = [](int grid, size_t lds, hipStream_t st, const WnPlan& p, const WnRun& r) {
-        hipLaunchKernelGGL((wn_generate_kernel_v2m<R, DC, S, EC, PM>), dim3(grid), dim3(WN_THREADS), lds, st, p, r);
+    e.fn_multi = (const void*)wn_generate_kernel_v2m<R, DC, S, EC, PM, 1>;
+    e.fn_multi2 = (const void*)wn_generate_kernel_v2m<R, DC, S, EC, PM, 2>;
+    e.lds_floats_multi = [](int ns, int g) { return g == 2 ? WnV2LdsM<SH, 2>::floats(ns) : WnV2LdsM<SH, 1>::floats(ns); };
+    e.launch_multi = [](int g, int grid, size_t lds, hipStream_t st, const WnPlan& p, const WnRun& r) {
+        if (g == 2) hipLaunchKernelGGL((wn_generate_kernel_v2m<R, DC, S, EC, PM, 2>), dim3(grid), dim3(WN_THREADS), lds, st, p, r);
+        else hipLaunchKernelGGL((wn_generate_kernel_v2m<R, DC, S, EC, PM, 1>), dim3(grid), dim3(WN_THREADS), lds, st, p, r);
     };
     e.lds_floats = [](int ns) { return WnV2Lds<SH>::floats(ns); };
     e.lds_floats_with_start = [](int ns) { return WnV2Lds<SH>::floats_with_start(ns); };
@@ -220,6 +225,7 @@ struct wn_handle {
     int variant;   // 1 = generic LDS-resident kernel, 2 = register-resident kernel
     int v2_index;  // row of wn_v2_table()
     int lds_bytes;
+    int multi_g;   // streams per pipeline item of the multi-stream kernel (1 or 2)
     // owned device allocations
     float *d_blobs, *d_start_t, *d_start_b, *d_rings;
     int32_t *d_dil, *d_wg_map;
@@ -310,6 +316,16 @@ extern "C" int wn_create(const wn_config* cfg, wn_handle** out) {
             pl.n_smp = n_smp;
             pl.n_wg += n_smp;               // sampler workgroups follow the head in the chain
             h->lds_bytes = wn_v2_table()[vi].lds_floats(pl.n_streams) * 4;
+            h->multi_g = 1;
+            if (n_smp > 0) {
+                // Streams per pipeline item.  Two per item halve the hand-offs per evaluation, but measured on cfg3 x 64 it is
+                // slower (492 k vs 557 k samples/s): the skip lane is a second dependency chain through the stages' tails and a
+                // tail twice as long delays every downstream lane.  Kept selectable (WN_MULTI_G=2) for experiments.
+                const char* fg = getenv("WN_MULTI_G");
+                h->multi_g = 1;
+                if (fg && fg[0] == '2' && cfg->n_streams % 2 == 0) h->multi_g = 2;
+                h->lds_bytes = wn_v2_table()[vi].lds_floats_multi(pl.n_streams, h->multi_g) * 4;
+            }
             pl.start_in_lds = 0;
             if (n_smp == 0 && wn_v2_table()[vi].lds_floats_with_start(pl.n_streams) * 4 <= WN_LDS_MAX_BYTES) {
                 pl.start_in_lds = 1;
@@ -386,7 +402,7 @@ extern "C" int wn_create(const wn_config* cfg, wn_handle** out) {
     pl.status = h->d_status;
     pl.xcc_tab = h->d_status + 8;
 #ifndef WN_EMU
-    rc = rt_hip(hipFuncSetAttribute(h->variant == 2 ? (pl.n_smp > 0 ? wn_v2_table()[h->v2_index].fn_multi : wn_v2_table()[h->v2_index].fn)
+    rc = rt_hip(hipFuncSetAttribute(h->variant == 2 ? (pl.n_smp > 0 ? (h->multi_g == 2 ? wn_v2_table()[h->v2_index].fn_multi2 : wn_v2_table()[h->v2_index].fn_multi) : wn_v2_table()[h->v2_index].fn)
                                                     : (const void*)wn_generate_kernel,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes),
                 "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
@@ -610,7 +626,7 @@ extern "C" int wn_generate(wn_handle* h, const wn_generate_args* a) {
     }
 #else
     if (h->variant == 2 && h->plan.n_smp > 0)
-        wn_v2_table()[h->v2_index].launch_multi(h->plan.n_blocks, (size_t)h->lds_bytes, (hipStream_t)a->hip_stream, h->plan, r);
+        wn_v2_table()[h->v2_index].launch_multi(h->multi_g, h->plan.n_blocks, (size_t)h->lds_bytes, (hipStream_t)a->hip_stream, h->plan, r);
     else if (h->variant == 2)
         wn_v2_table()[h->v2_index].launch(h->plan.n_blocks, (size_t)h->lds_bytes, (hipStream_t)a->hip_stream, h->plan, r);
     else

@@ -209,3 +209,13 @@ def test_batched_priming_equals_chain_priming(cfgname, ns, n_given):
     o_idx, _ = c_oracle.generate(cfg, W, N, first[0], 1.0, 0.0, uniforms[0])
     assert np.array_equal(a[0], o_idx)
     eng.close()
+
+
+def test_two_streams_per_pipeline_item(monkeypatch):
+    """The experimental WN_MULTI_G=2 form of the multi-stream kernel (two streams per pipeline item) stays correct."""
+    monkeypatch.setenv("WN_MULTI_G", "2")
+    cfg, W, first, uniforms = make_case("cfg3", 60, 4, 12, 80)
+    eng = engine.Engine(cfg, W, n_streams=4)
+    check_engine(eng, cfg, W, 80, first, 1.0, 0.0, uniforms, "cfg3 G=2 sampled")
+    check_engine(eng, cfg, W, 80, first, 0.0, 0.0, None, "cfg3 G=2 greedy")
+    eng.close()

@@ -27,23 +27,24 @@ def main():
     info = eng.info()
     P, PA, NL = info["layer_split"], info["head_split"], info["n_layers"]
     N = 400 if ns == 1 else 60
-    items = N * ns
+    G = int(os.environ.get("WN_MULTI_G", "1")) if ns > 1 else 1
+    items = N * ns // G  # pipeline items: G streams each in the multi-stream kernel
     u = np.random.RandomState(0).random_sample((ns, N))
     eng.generate(N, None, temperature=1.0, uniforms=u)  # warm-up
     eng.profile_next(items)
     eng.generate(N, None, temperature=1.0, uniforms=u)
     raw = eng.profile_read(items)
     if ns > 1:
-        tt = raw[P:NL * P, items // 4:items - ns].astype(np.float64) * 0.01
+        tt = raw[P:NL * P, items // 4:items - ns // G].astype(np.float64) * 0.01
         print("multi: wave0 input ready %.3f us after start, wave1 input ready %.3f us, barrier passed %.3f us; wave0 published %.3f, wave3 published %.3f" % (
             (tt[:, :, 4] - tt[:, :, 0]).mean(), (tt[:, :, 7] - tt[:, :, 0]).mean(), (tt[:, :, 1] - tt[:, :, 0]).mean(),
             (tt[:, :, 2] - tt[:, :, 0]).mean(), (tt[:, :, 6] - tt[:, :, 0]).mean()))
     st = raw.astype(np.float64) * 0.01  # us
-    lo, hi = items // 4, items - ns  # steady state
+    lo, hi = items // 4, items - ns // G  # steady state
     T = st[:, lo:hi, :]
     lay = T[:NL * P].reshape(NL, P, hi - lo, 8)
     head = T[NL * P:]
-    period = np.diff(st[0, lo:hi:ns, 1]).mean() if ns == 1 else np.diff(st[0, lo:hi, 1][::ns]).mean()
+    period = np.diff(st[0, lo:hi:ns, 1]).mean() if ns == 1 else np.diff(st[0, lo:hi, 1][::ns // G]).mean()
     print("%s x%d: variant %d P=%d PA=%d workgroups %d; loop period %.2f us/eval (%.0f evals/s per stream, %.0f samples/s total)" % (
         cfgname, ns, info["kernel_variant"], P, PA, info["n_workgroups"], period, 1e6 / period, ns * 1e6 / period))
     if ns > 1:  # pipeline view: who is busy, who waits
@@ -51,7 +52,7 @@ def main():
         wait = (T[:, :, 1] - T[:, :, 0]).mean(axis=1)
         per = np.diff(T[:, :, 0], axis=1).mean(axis=1)
         nlw = NL * P
-        print("per-item period %.3f us.  stage: busy (staged->done) / wait (start->staged), us" % per[:nlw].mean())
+        print("G=%d streams per item; per-item period %.3f us (%.3f us per stream-step).  stage: busy (staged->done) / wait (start->staged), us" % (G, per[:nlw].mean(), per[:nlw].mean() / G))
         for l in list(range(0, NL, max(1, NL // 10))) + [NL - 1]:
             print("  layer %2d: busy %s  wait %s" % (l, np.array2string(busy[l * P:(l + 1) * P], precision=2), np.array2string(wait[l * P:(l + 1) * P], precision=2)))
         print("  head    : busy %s  wait %s" % (np.array2string(busy[nlw:nlw + PA], precision=2), np.array2string(wait[nlw:nlw + PA], precision=2)))
