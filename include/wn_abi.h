@@ -168,6 +168,40 @@ int wn_set_forward_precision(wn_handle* h, int32_t bf16);
  * wn_forward: callers then prime through wn_generate.  Asynchronous on hip_stream. */
 int wn_prime(wn_handle* h, const int32_t* first_samples, int64_t n_prime, int64_t row_stride, void* hip_stream);
 
+/* ---- training step (WavenetTrainer.train, wavenet_training.py:58-107: output = model(x); loss = cross_entropy; loss.backward()) ----
+ * The dilated-conv stack's forward AND backward run as fp32 matrix-core GEMMs; the caller owns the parameters as ONE flat
+ * fp32 DEVICE array in the packed layout described by wn_train_layout (each reference parameter appears exactly once, so
+ * any element-wise optimiser can step on the flat array directly), plus a same-shaped gradient array.  The loss (and its
+ * gradient w.r.t. the logits) stays with the caller -- the reference computes it with F.cross_entropy (wavenet_training.py:83).
+ * Offsets are in floats.  Packed layouts (NL layers, R/D/S/E/C channel counts, k = 2 taps):
+ *   fg    [NL][2R][2D]  row = tap*R + r (tap 0 = x[t-d], tap 1 = x[t]); column = 64*(ch/32) + 32*gate + ch%32, gate 0 = filter
+ *                       (filter_convs.l.weight[ch][r][tap], gate_convs.l.weight[ch][r][tap])       bfg [NL][2D] same columns
+ *   res   [NL][D][R]    residual_convs.l.weight[r][d][0] transposed                                 bres [NL][R]
+ *   skip  [NL][D][S]    skip_convs.l.weight[s][d][0] transposed                                     bskip [NL][S]
+ *   bskip_total [S]     scratch (derived; its gradient is 0)
+ *   w1 [S][E], b1 [E]   end_conv_1 transposed;   w2 [E][C], b2 [C]   end_conv_2 transposed
+ *   start_t [C][R], start_b [R]   start_conv.weight[r][c][0] transposed
+ * Bias sections exist (and are zero) also when the model has bias=False; their gradients are then left at 0. */
+typedef struct wn_train_layout {
+    int64_t total;
+    int64_t fg, bfg, res, bres, skip, bskip, bskip_total, w1, b1, w2, b2, start_t, start_b;
+} wn_train_layout;
+
+int wn_train_get_layout(wn_handle* h, wn_train_layout* out);
+
+/* Copies the parameters last given to wn_load_weights into `params` (DEVICE, layout.total floats). */
+int wn_train_export_params(wn_handle* h, float* params, void* hip_stream);
+
+/* model(x) for training: like wn_forward (fp32) but reads the parameters from `params` and keeps every layer's input, gate
+ * activations and the head's intermediates in a workspace owned by the handle for the following wn_train_backward. */
+int wn_train_forward(wn_handle* h, const float* params, const int32_t* indices, int64_t N, int64_t L, int64_t output_length,
+                     float* logits, void* hip_stream);
+
+/* loss.backward(): `dlogits` [N*output_length][classes] (DEVICE) is dLoss/dlogits for the logits of the last
+ * wn_train_forward on this handle; writes dLoss/dparams into `grads` (DEVICE, layout.total floats, overwritten).
+ * Sums over rows are accumulated with fp32 atomics: results are reproducible to rounding, not bit for bit. */
+int wn_train_backward(wn_handle* h, const float* params, const float* dlogits, float* grads, void* hip_stream);
+
 /* Diagnostics: record wall-clock stamps (100 MHz ticks) for the first n_items (evaluation, stream) steps of every
  * workgroup during the NEXT wn_generate: 8 slots per step -- 0 start, 1 input staged, 2 x' published, 3 done,
  * 4 filter/gate sums ready, 5 z staged, 6-7 unused -- then read them back as int64 [n_workgroups][n_items][8].  Used by tools/profile_chain.py. */

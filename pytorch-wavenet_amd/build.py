@@ -16,7 +16,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "mi355_wavenet", "libwn_mi355.so")
 SOURCES = [os.path.join(CSRC, "wn_runtime.hip")]
-DEPS = SOURCES + [os.path.join(CSRC, "wn_kernel.h"), os.path.join(CSRC, "wn_plan.h"), os.path.join(ROOT, "include", "wn_abi.h")]
+DEPS = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h", ".inl"))) + [os.path.join(ROOT, "include", "wn_abi.h")]
 
 
 def _stale(out, deps):

@@ -51,6 +51,9 @@ struct WnGemmArgs {
     long long M;          // logical rows
     int rows_per_batch;
     int relu_a, relu_c;
+    const float* mask;    // WN_EPI_PLAIN: optional [rows of N floats, laid out like c]: output forced to 0 where mask <= 0 (ReLU backward)
+    float* gate_t;        // WN_EPI_GATE: optional [M][N/2] dense copies of tanh(F) and sigmoid(G) for the backward pass (row = m)
+    float* gate_g;
     WnRowMap c2;          // WN_EPI_GATE only: rows whose index inside the batch entry is >= c2_first_row are ALSO written here
     int c2_first_row;     //   (at row index - c2_first_row): the z block the grouped skip GEMM consumes.  base == NULL -> off
     int pad;
@@ -151,11 +154,17 @@ __global__ __launch_bounds__(256) void wn_fwd_gemm(WnGemmArgs g) {
                 if (ng >= g.N) continue;
                 const float f = acc[2 * p][i] + (g.bias ? g.bias[nf] : 0.f);
                 const float gg = acc[2 * p + 1][i] + (g.bias ? g.bias[ng] : 0.f);
-                const float z = tanhf(f) * (1.0f / (1.0f + expf(-gg)));
+                const float th = tanhf(f), sg = 1.0f / (1.0f + expf(-gg));
+                const float z = th * sg;
                 crow[(n0 >> 1) + 32 * p + col] = z;
                 if (c2row) c2row[(n0 >> 1) + 32 * p + col] = z;
+                if (g.gate_t) {
+                    g.gate_t[m * (g.N >> 1) + (n0 >> 1) + 32 * p + col] = th;
+                    g.gate_g[m * (g.N >> 1) + (n0 >> 1) + 32 * p + col] = sg;
+                }
             }
         } else {
+            const float* mrow = g.mask ? g.mask + (crow - g.c.base) : nullptr;  // the mask shares the output's row layout
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int n = n0 + 32 * j + col;
@@ -163,6 +172,7 @@ __global__ __launch_bounds__(256) void wn_fwd_gemm(WnGemmArgs g) {
                 float v = acc[j][i] + (g.bias ? g.bias[n] : 0.f);
                 if (addrow) v += addrow[n];
                 if (g.relu_c) v = fmaxf(v, 0.f);
+                if (mrow && !(mrow[n] > 0.f)) v = 0.f;
                 crow[n] = v;
             }
         }
@@ -308,6 +318,144 @@ __global__ void wn_fwd_start(const int32_t* idx, const float* start_t, const flo
     float4 v = *reinterpret_cast<const float4*>(start_t + (size_t)idx[row] * R + q * 4);
     if (start_b) { v.x += start_b[q * 4]; v.y += start_b[q * 4 + 1]; v.z += start_b[q * 4 + 2]; v.w += start_b[q * 4 + 3]; }
     *reinterpret_cast<float4*>(x + row * R + q * 4) = v;
+}
+
+
+// ------------------------------------------------------------------------------------------------ backward pass
+// Weight gradients: C[Ka][Nb] += sum_m A[m][ka] * B[m][nb]  ("TN": the contraction runs over the rows).  Grid
+// (Ka/128, Nb/128, splits): every workgroup reduces its slice of the rows into a 128x128 register tile (4 waves x 4
+// accumulator tiles, fp32 MFMA) and adds it to C with fp32 atomics (the order of the splits is not fixed: gradients are
+// reproducible to rounding, not bitwise).  A may be a one-hot matrix given by class indices (start_conv's gradient).
+struct WnGemmTnArgs {
+    WnRowMap a;            // rows of >= ka0+128 floats (ignored when a_idx != NULL)
+    const int32_t* a_idx;  // A[m][k] = (a_idx[row(m)] == k): one-hot rows addressed through `a` (base = NULL offset trick: see loader)
+    WnRowMap b;
+    int Ka, Nb;            // logical sizes (multiples of 32); C is [Ka][ldc]
+    float* c;
+    int ldc;
+    long long M;
+    int rows_per_batch;
+    int relu_a;            // A := max(A, 0)
+    long long rows_per_split;
+};
+
+__global__ __launch_bounds__(256) void wn_bwd_gemm_tn(WnGemmTnArgs g) {
+    constexpr int T = 128, KC = 32;
+    __shared__ float a_s[2][KC * T];  // [m][ka]
+    __shared__ float b_s[2][KC * T];  // [m][nb]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int ka0 = blockIdx.x * T, nb0 = blockIdx.y * T;
+    const long long m_begin = (long long)blockIdx.z * g.rows_per_split;
+    long long m_end = m_begin + g.rows_per_split;
+    if (m_end > g.M) m_end = g.M;
+    if (m_begin >= m_end) return;
+    wn_f16v acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
+    const int lrow = tid >> 3, lcol = (tid & 7) * 16;  // loader: row of the chunk, 16 floats of its 128
+    float4 va[4], vb[4];
+    auto fetch = [&](long long mc) {
+        const long long m = mc + lrow;
+        const bool ok = m < m_end;
+        if (g.a_idx) {
+            int cls = -1;
+            if (ok) {  // the row map of `a` addresses the index array: base holds no data, strides are in elements
+                const unsigned q = (unsigned)m / (unsigned)g.rows_per_batch, rem = (unsigned)m - q * (unsigned)g.rows_per_batch;
+                cls = g.a_idx[(long long)q * g.a.batch_stride + (g.a.t0 + (long long)rem) * g.a.row_stride];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int k = ka0 + lcol + q * 4;
+                va[q] = make_float4(cls == k ? 1.f : 0.f, cls == k + 1 ? 1.f : 0.f, cls == k + 2 ? 1.f : 0.f, cls == k + 3 ? 1.f : 0.f);
+            }
+        } else {
+            const float* ap = ok ? wn_row(g.a, m, g.rows_per_batch) + ka0 + lcol : nullptr;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) va[q] = (ok && ka0 + lcol + q * 4 < g.Ka) ? *reinterpret_cast<const float4*>(ap + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        const float* bp = ok ? wn_row(g.b, m, g.rows_per_batch) + nb0 + lcol : nullptr;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) vb[q] = (ok && nb0 + lcol + q * 4 < g.Nb) ? *reinterpret_cast<const float4*>(bp + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    auto stash = [&](int buf) {
+        float* ad = a_s[buf] + lrow * T + lcol;
+        float* bd = b_s[buf] + lrow * T + lcol;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float4 x = va[q];
+            if (g.relu_a) { x.x = fmaxf(x.x, 0.f); x.y = fmaxf(x.y, 0.f); x.z = fmaxf(x.z, 0.f); x.w = fmaxf(x.w, 0.f); }
+            *reinterpret_cast<float4*>(ad + q * 4) = x;
+            *reinterpret_cast<float4*>(bd + q * 4) = vb[q];
+        }
+    };
+    fetch(m_begin);
+    stash(0);
+    __syncthreads();
+    int buf = 0;
+    for (long long mc = m_begin; mc < m_end; mc += KC, buf ^= 1) {
+        if (mc + KC < m_end) fetch(mc + KC);
+        const float* as = a_s[buf] + 32 * wv + (lane & 31);
+        const float* bs = b_s[buf] + (lane & 31);
+        const int kh = lane >> 5;
+#pragma unroll
+        for (int ks = 0; ks < KC / 2; ++ks) {
+            const float a = as[(2 * ks + kh) * T];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bs[(2 * ks + kh) * T + 32 * j], acc[j], 0, 0, 0);
+        }
+        if (mc + KC < m_end) stash(buf ^ 1);
+        __syncthreads();
+    }
+    const int col = lane & 31;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int ka = ka0 + 32 * wv + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+        if (ka >= g.Ka) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int nb = nb0 + 32 * j + col;
+            if (nb < g.Nb) unsafeAtomicAdd(g.c + (size_t)ka * g.ldc + nb, acc[j][i]);
+        }
+    }
+}
+
+// dF = dz * G * (1 - T^2), dG = dz * T * G * (1 - G), written in the packed [F(32) | G(32)] column order of Wfg^T
+__global__ void wn_bwd_gate(const float* dz, const float* th, const float* sg, float* dfg, long long M, int D) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M * D) return;
+    const long long m = i / D;
+    const int ch = (int)(i % D);
+    const float d = dz[i], t = th[i], s = sg[i];
+    const int nf = 64 * (ch >> 5) + (ch & 31);
+    dfg[m * 2 * D + nf] = d * s * (1.f - t * t);
+    dfg[m * 2 * D + nf + 32] = d * t * s * (1.f - s);
+}
+
+// out[n] += sum over rows of x[row][n]   (bias gradients); x rows addressed through a row map
+__global__ void wn_bwd_colsum(WnRowMap x, long long M, int rows_per_batch, int N, float* out) {
+    const int n = blockIdx.y * blockDim.x + threadIdx.x;
+    const long long m0 = (long long)blockIdx.x * 512;
+    if (n >= N) return;
+    float s = 0.f;
+    for (long long m = m0; m < m0 + 512 && m < M; ++m) s += wn_row(x, m, rows_per_batch)[n];
+    unsafeAtomicAdd(out + n, s);
+}
+
+
+// out[b][c][r] = in[b][r][c]  (in: `rows` x `cols` blocks spaced in_batch_stride floats apart): rebuilds the operand
+// layouts the backward GEMMs want from the forward banks after every parameter update
+__global__ void wn_transpose_batched(const float* in, long long in_batch_stride, float* out, int rows, int cols) {
+    __shared__ float tile[32][33];
+    const float* ib = in + (long long)blockIdx.z * in_batch_stride;
+    float* ob = out + (long long)blockIdx.z * rows * cols;
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 256 threads: 8 rows per pass
+    for (int i = ty; i < 32; i += 8)
+        if (r0 + i < rows && c0 + tx < cols) tile[i][tx] = ib[(long long)(r0 + i) * cols + c0 + tx];
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8)
+        if (c0 + i < cols && r0 + tx < rows) ob[(long long)(c0 + i) * rows + r0 + tx] = tile[tx][i];
 }
 
 // Batched priming: copies the newest `count` time steps of a layer's input x (time-major rows of R floats; `x` points at

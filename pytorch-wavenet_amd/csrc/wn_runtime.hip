@@ -214,6 +214,15 @@ static int wn_v2_choose(const WnPlan& pl, int n_cu, int n_smp, int forced_P, int
 #endif
 
 // ------------------------------------------------------------------------------------------------ handle
+#ifndef WN_EMU
+struct WnTrainLay {
+    long long N, L, out_len;
+    std::vector<long long> need;          // need[l] = trailing time steps of layer l's input the loss depends on
+    std::vector<size_t> x, z, th, sg;     // per layer offsets (floats) into the training workspace
+    size_t skip, ev, zg, bskip_total, res_o, skip_o, w1_o, w2_o, fgb0, fgb1, dskip, de, dz, dfg, dxa, dxb, colsum_tmp, idx, total;
+    int G;
+};
+#endif
 struct wn_handle {
     wn_config cfg;
     WnPlan plan;
@@ -237,6 +246,7 @@ struct wn_handle {
     // batched forward (wn_forward): GEMM-ready weight banks and a workspace that grows on demand
     float* d_fw; size_t fw_floats; bool fw_ok;
     size_t fw_off_fg, fw_off_bfg, fw_off_res, fw_off_bres, fw_off_skip, fw_off_bskip, fw_off_bskip_total, fw_off_w1, fw_off_b1, fw_off_w2, fw_off_b2;
+    size_t fw_off_start_t, fw_off_start_b;  // training only: wn_forward / wn_prime read d_start_t / d_start_b
     float* d_ws; size_t ws_floats;
     unsigned short* d_fwb; size_t fwb_elems; bool fwb_ok; int fw_bf16;  // bf16 copies of the forward banks, [N][K] row-major
     size_t fwb_off_fg, fwb_off_res, fwb_off_skip, fwb_off_w1, fwb_off_w2;
@@ -244,6 +254,10 @@ struct wn_handle {
     int prof_recorded;   // stamps held in d_prof
     std::vector<int64_t> ring_off;
     std::vector<int32_t> dil;
+#ifndef WN_EMU
+    float* d_tws; size_t tws_floats;  // training workspace (saved activations + backward temporaries)
+    WnTrainLay train; bool train_valid;
+#endif
 };
 
 extern "C" int wn_abi_version(void) { return WN_ABI_VERSION; }
@@ -257,6 +271,9 @@ extern "C" void wn_destroy(wn_handle* h) {
 #endif
     rt_free(h->d_blobs); rt_free(h->d_start_t); rt_free(h->d_start_b); rt_free(h->d_rings); rt_free(h->d_dil);
     rt_free(h->d_wg_map); rt_free(h->d_ring_off); rt_free(h->d_gran); rt_free(h->d_status); rt_free(h->d_prof); rt_free(h->d_fw); rt_free(h->d_ws); rt_free(h->d_fwb);
+#ifndef WN_EMU
+    rt_free(h->d_tws);
+#endif
     delete h;
 }
 
@@ -299,6 +316,9 @@ extern "C" int wn_create(const wn_config* cfg, wn_handle** out) {
     h->d_prof = nullptr; h->prof_items = 0; h->prof_recorded = 0;
     h->d_fw = nullptr; h->fw_floats = 0; h->fw_ok = false; h->d_ws = nullptr; h->ws_floats = 0;
     h->d_fwb = nullptr; h->fwb_elems = 0; h->fwb_ok = false; h->fw_bf16 = 0;
+#ifndef WN_EMU
+    h->d_tws = nullptr; h->tws_floats = 0; h->train_valid = false;
+#endif
     WnPlan& pl = h->plan;
     pl.layers = cfg->layers; pl.blocks = cfg->blocks; pl.NL = cfg->layers * cfg->blocks;
     pl.R = cfg->residual_channels; pl.D = cfg->dilation_channels; pl.S = cfg->skip_channels; pl.E = cfg->end_channels;
@@ -462,6 +482,8 @@ extern "C" int wn_load_weights(wn_handle* h, const wn_weight_ptrs* w) {
             h->fw_off_b1 = o; o += (size_t)E;
             h->fw_off_w2 = o; o += (size_t)E * C;
             h->fw_off_b2 = o; o += (size_t)C;
+            h->fw_off_start_t = o; o += (size_t)C * R;
+            h->fw_off_start_b = o; o += (size_t)R;
             std::vector<float> fw(o, 0.f);
             for (int l = 0; l < NL; ++l) {
                 float* fg = fw.data() + h->fw_off_fg + (size_t)l * 2 * R * 2 * D;
@@ -495,6 +517,8 @@ extern "C" int wn_load_weights(wn_handle* h, const wn_weight_ptrs* w) {
             for (int e = 0; e < E; ++e)
                 for (int c = 0; c < C; ++c) fw[h->fw_off_w2 + (size_t)e * C + c] = w->end2_w[(size_t)c * E + e];
             for (int c = 0; c < C; ++c) fw[h->fw_off_b2 + c] = w->end2_b[c];
+            memcpy(fw.data() + h->fw_off_start_t, st.data(), st.size() * 4);
+            if (pl.has_bias) memcpy(fw.data() + h->fw_off_start_b, w->start_b, (size_t)R * 4);
             if (h->fw_floats != o) { rt_free(h->d_fw); h->d_fw = (float*)rt_malloc(o * 4); h->fw_floats = o; }
             if (!h->d_fw) return wn_fail(WN_E_NOMEM, "wn_load_weights: forward weight banks (%.1f MB)", o * 4e-6);
             rc = rt_h2d(h->d_fw, fw.data(), o * 4);
@@ -943,3 +967,13 @@ extern "C" int wn_set_forward_precision(wn_handle* h, int32_t bf16) {
     return WN_OK;
 #endif
 }
+
+#ifndef WN_EMU
+#include "wn_train.inl"
+#else
+// the training step exists on the GPU only
+extern "C" int wn_train_get_layout(wn_handle*, wn_train_layout*) { g_err[0] = 0; return wn_fail(WN_E_UNSUPPORTED, "wn_train: GPU only"); }
+extern "C" int wn_train_export_params(wn_handle*, float*, void*) { g_err[0] = 0; return wn_fail(WN_E_UNSUPPORTED, "wn_train: GPU only"); }
+extern "C" int wn_train_forward(wn_handle*, const float*, const int32_t*, int64_t, int64_t, int64_t, float*, void*) { g_err[0] = 0; return wn_fail(WN_E_UNSUPPORTED, "wn_train: GPU only"); }
+extern "C" int wn_train_backward(wn_handle*, const float*, const float*, float*, void*) { g_err[0] = 0; return wn_fail(WN_E_UNSUPPORTED, "wn_train: GPU only"); }
+#endif

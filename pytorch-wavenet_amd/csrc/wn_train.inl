@@ -1,0 +1,335 @@
+// wn_train.inl -- host side of the native training step (included by wn_runtime.hip; GPU build only).
+//
+// Reference: WavenetTrainer.train (wavenet_training.py:58-107) runs output = model(x); loss = F.cross_entropy(...);
+// loss.backward(); optimizer.step().  wn_train_forward / wn_train_backward replace model(x) and the autograd walk through
+// WaveNetModel.wavenet (wavenet_model.py:125-171) with fp32 matrix-core GEMMs over all time steps at once:
+//
+//   forward  (per layer l, rows = the time steps the loss still depends on):
+//       [F|G] = [x_l(t-d) | x_l(t)] . Wfg^T + b        T = tanh(F), G = sigmoid(G), z = T*G            (saved: x_l, z, T, G)
+//       x_{l+1}(t) = z . Wres^T + bres + x_l(t)          skip += z[last output_length rows] . Wskip^T + bskip
+//       logits = relu(relu(skip) . W1^T + b1) . W2^T + b2                                               (saved: skip, e)
+//   backward (given dlogits):
+//       de = (dlogits . W2) * [e > 0]      dskip = (de . W1) * [skip > 0]       dW2^T = e^T . dlogits   dW1^T = relu(skip)^T . de
+//       per layer, last to first, with dx' = dLoss/dx_{l+1}:
+//           dz   = dx' . Wres  (+ dskip . Wskip on the skip rows)          dWres^T = z^T . dx'      dWskip^T = z_skiprows^T . dskip
+//           dF   = dz * G * (1 - T^2),  dG = dz * T * G * (1 - G)           dWfg^T  = [x_l(t-d) | x_l(t)]^T . [dF|dG]
+//           dx_l(t) = dx'(t) + [dF|dG](t) . Wfg(tap 1) + [dF|dG](t+d) . Wfg(tap 0)
+//       dstart^T = onehot(indices)^T . dx_0
+//   "NN" products reuse wn_fwd_gemm with re-laid-out banks (rebuilt from `params` by wn_transpose_batched on every forward);
+//   "TN" products (weight gradients) use wn_bwd_gemm_tn; bias gradients are column sums.
+
+
+static void wn_train_layout_ws(const wn_handle* h, long long N, long long L, long long out_len, WnTrainLay& t) {
+    const WnPlan& pl = h->plan;
+    const int R = pl.R, D = pl.D, S = pl.S, E = pl.E, C = pl.C, NL = pl.NL;
+    t.N = N; t.L = L; t.out_len = out_len;
+    t.need.assign(NL + 1, 0);
+    t.need[NL] = out_len;
+    for (int l = NL - 1; l >= 0; --l) t.need[l] = t.need[l + 1] + h->dil[l];
+    t.G = pl.layers < NL ? pl.layers : NL;
+    size_t o = 0;
+    auto take = [&](size_t n) { size_t r = o; o += (n + 63) & ~(size_t)63; return r; };
+    t.x.resize(NL); t.z.resize(NL); t.th.resize(NL); t.sg.resize(NL);
+    size_t zmax = 0;
+    for (int l = 0; l < NL; ++l) {
+        const size_t zl = (size_t)N * t.need[l + 1] * D;
+        zmax = zl > zmax ? zl : zmax;
+        t.x[l] = take((size_t)N * L * R);
+        t.z[l] = take(zl); t.th[l] = take(zl); t.sg[l] = take(zl);
+    }
+    const size_t Mo = (size_t)N * out_len;
+    t.skip = take(Mo * S); t.ev = take(Mo * E); t.zg = take(Mo * t.G * D); t.bskip_total = take(S);
+    t.res_o = take((size_t)NL * R * D); t.skip_o = take((size_t)NL * S * D); t.w1_o = take((size_t)E * S); t.w2_o = take((size_t)C * E);
+    t.fgb0 = take((size_t)NL * 2 * D * R); t.fgb1 = take((size_t)NL * 2 * D * R);
+    t.dskip = take(Mo * S); t.de = take(Mo * E); t.dz = take(zmax); t.dfg = take(2 * zmax);
+    t.dxa = take((size_t)N * L * R); t.dxb = take((size_t)N * L * R);
+    t.colsum_tmp = take(S);
+    t.idx = take((size_t)N * L);
+    t.total = o;
+}
+
+extern "C" int wn_train_get_layout(wn_handle* h, wn_train_layout* out) {
+    g_err[0] = 0;
+    if (!h || !out) return wn_fail(WN_E_BADARG, "wn_train_get_layout: NULL argument");
+    if (!h->have_weights) return wn_fail(WN_E_STATE, "wn_train_get_layout: wn_load_weights has not been called");
+    if (!h->fw_ok) return wn_fail(WN_E_UNSUPPORTED, "wn_train: needs kernel_size 2 and channel counts that are multiples of 32");
+    out->total = (int64_t)h->fw_floats;
+    out->fg = h->fw_off_fg; out->bfg = h->fw_off_bfg; out->res = h->fw_off_res; out->bres = h->fw_off_bres;
+    out->skip = h->fw_off_skip; out->bskip = h->fw_off_bskip; out->bskip_total = h->fw_off_bskip_total;
+    out->w1 = h->fw_off_w1; out->b1 = h->fw_off_b1; out->w2 = h->fw_off_w2; out->b2 = h->fw_off_b2;
+    out->start_t = h->fw_off_start_t; out->start_b = h->fw_off_start_b;
+    return WN_OK;
+}
+
+extern "C" int wn_train_export_params(wn_handle* h, float* params, void* hip_stream) {
+    g_err[0] = 0;
+    if (!h || !params) return wn_fail(WN_E_BADARG, "wn_train_export_params: NULL argument");
+    if (!h->have_weights) return wn_fail(WN_E_STATE, "wn_train_export_params: wn_load_weights has not been called");
+    if (!h->fw_ok) return wn_fail(WN_E_UNSUPPORTED, "wn_train: needs kernel_size 2 and channel counts that are multiples of 32");
+    { int rc = rt_hip(hipSetDevice(h->cfg.device_id), "hipSetDevice"); if (rc) return rc; }
+    return rt_hip(hipMemcpyAsync(params, h->d_fw, h->fw_floats * 4, hipMemcpyDeviceToDevice, (hipStream_t)hip_stream), "hipMemcpyAsync(params)");
+}
+
+static void wn_launch_nn(hipStream_t st, int epi, const WnGemmArgs& a) {
+    dim3 grid((unsigned)((a.M + 127) / 128), (unsigned)((a.N + 127) / 128));
+    if (epi == WN_EPI_GATE) hipLaunchKernelGGL(wn_fwd_gemm<WN_EPI_GATE>, grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(wn_fwd_gemm<WN_EPI_PLAIN>, grid, dim3(256), 0, st, a);
+}
+
+static void wn_launch_tn(hipStream_t st, WnGemmTnArgs a) {
+    const int tiles = ((a.Ka + 127) / 128) * ((a.Nb + 127) / 128);
+    long long splits = (a.M + 2047) / 2048;
+    const long long cap = 2048 / tiles > 1 ? 2048 / tiles : 1;
+    if (splits > cap) splits = cap;
+    if (splits < 1) splits = 1;
+    long long rps = (a.M + splits - 1) / splits;
+    rps = (rps + 31) / 32 * 32;
+    splits = (a.M + rps - 1) / rps;
+    a.rows_per_split = rps;
+    hipLaunchKernelGGL(wn_bwd_gemm_tn, dim3((unsigned)((a.Ka + 127) / 128), (unsigned)((a.Nb + 127) / 128), (unsigned)splits), dim3(256), 0, st, a);
+}
+
+static void wn_launch_colsum(hipStream_t st, const WnRowMap& x, long long M, int rows_per_batch, int N, float* out) {
+    hipLaunchKernelGGL(wn_bwd_colsum, dim3((unsigned)((M + 511) / 512), (unsigned)((N + 63) / 64)), dim3(64), 0, st, x, M, rows_per_batch, N, out);
+}
+
+static void wn_launch_transpose(hipStream_t st, const float* in, long long in_batch_stride, float* out, int rows, int cols, int batches) {
+    hipLaunchKernelGGL(wn_transpose_batched, dim3((unsigned)((cols + 31) / 32), (unsigned)((rows + 31) / 32), (unsigned)batches), dim3(256), 0, st,
+                       in, in_batch_stride, out, rows, cols);
+}
+
+extern "C" int wn_train_forward(wn_handle* h, const float* params, const int32_t* indices, int64_t N, int64_t L, int64_t out_len,
+                                float* logits, void* hip_stream) {
+    g_err[0] = 0;
+    if (!h || !params || !indices || !logits) return wn_fail(WN_E_BADARG, "wn_train_forward: NULL argument");
+    if (!h->have_weights) return wn_fail(WN_E_STATE, "wn_train_forward: wn_load_weights has not been called");
+    if (N < 1 || out_len < 1) return wn_fail(WN_E_BADARG, "wn_train_forward: N and output_length must be >= 1");
+    const WnPlan& pl = h->plan;
+    const int R = pl.R, D = pl.D, S = pl.S, E = pl.E, C = pl.C, NL = pl.NL;
+    if (!h->fw_ok) return wn_fail(WN_E_UNSUPPORTED, "wn_train_forward: needs kernel_size 2 and channel counts that are multiples of 32");
+    const long long rf = 1 + (long long)pl.blocks * ((1 << pl.layers) - 1);
+    if (L < rf + out_len - 1)
+        return wn_fail(WN_E_UNSUPPORTED, "wn_train_forward: L=%lld < receptive_field + output_length - 1 = %lld (the reference zero-pads "
+                       "activations there; use the torch path)", (long long)L, (long long)(rf + out_len - 1));
+    if ((long long)N * L >= 0x7fffffffll) return wn_fail(WN_E_UNSUPPORTED, "wn_train_forward: N*L must stay below 2^31 rows");
+    { int rc = rt_hip(hipSetDevice(h->cfg.device_id), "hipSetDevice"); if (rc) return rc; }
+    WnTrainLay& t = h->train;
+    h->train_valid = false;
+    wn_train_layout_ws(h, N, L, out_len, t);
+    if (h->tws_floats < t.total) {
+        (void)hipDeviceSynchronize();
+        rt_free(h->d_tws);
+        h->d_tws = nullptr;
+        float* p = nullptr;
+        if (hipMalloc((void**)&p, t.total * 4) != hipSuccess) { h->tws_floats = 0; return wn_fail(WN_E_NOMEM, "wn_train_forward: workspace of %.1f MB", t.total * 4e-6); }
+        h->d_tws = p; h->tws_floats = t.total;
+    }
+    float* ws = h->d_tws;
+    hipStream_t st = (hipStream_t)hip_stream;
+    const float* fw = params;
+    int rc = rt_hip(hipMemcpyAsync(ws + t.idx, indices, (size_t)N * L * 4, hipMemcpyDeviceToDevice, st), "hipMemcpyAsync(indices)");
+    if (rc) return rc;
+    // operand layouts of the backward products, rebuilt from the (just updated) parameters
+    wn_launch_transpose(st, fw + h->fw_off_res, (long long)D * R, ws + t.res_o, D, R, NL);      // [D][R] -> [R][D]
+    wn_launch_transpose(st, fw + h->fw_off_skip, (long long)D * S, ws + t.skip_o, D, S, NL);    // [D][S] -> [S][D]
+    wn_launch_transpose(st, fw + h->fw_off_w1, 0, ws + t.w1_o, S, E, 1);                         // [S][E] -> [E][S]
+    wn_launch_transpose(st, fw + h->fw_off_w2, 0, ws + t.w2_o, E, C, 1);                         // [E][C] -> [C][E]
+    wn_launch_transpose(st, fw + h->fw_off_fg, (long long)2 * R * 2 * D, ws + t.fgb0, R, 2 * D, NL);               // tap 0 rows -> [2D][R]
+    wn_launch_transpose(st, fw + h->fw_off_fg + (size_t)R * 2 * D, (long long)2 * R * 2 * D, ws + t.fgb1, R, 2 * D, NL);
+    if (pl.has_bias) {  // the grouped skip GEMM adds the sum of all layers' skip biases once
+        rc = rt_hip(hipMemsetAsync(ws + t.bskip_total, 0, (size_t)S * 4, st), "hipMemsetAsync");
+        if (rc) return rc;
+        wn_launch_colsum(st, WnRowMap{fw + h->fw_off_bskip, 0, S, 0}, NL, NL, S, ws + t.bskip_total);
+    }
+    {
+        const long long rows = N * L, work = rows * (R / 4);
+        hipLaunchKernelGGL(wn_fwd_start, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, indices, fw + h->fw_off_start_t,
+                           pl.has_bias ? fw + h->fw_off_start_b : nullptr, ws + t.x[0], rows, R);
+    }
+    const int G = t.G;
+    float* skip = ws + t.skip; float* ev = ws + t.ev; float* zg = ws + t.zg;
+    for (int l = 0; l < NL; ++l) {
+        const long long d = h->dil[l], rows = t.need[l + 1], t0 = L - rows;
+        const int gi = l % G;
+        float* xin = ws + t.x[l];
+        float* z = ws + t.z[l];
+        WnGemmArgs a;
+        memset(&a, 0, sizeof(a));
+        a.a0 = WnRowMap{xin, (long long)L * R, R, t0 - d};
+        a.a1 = WnRowMap{xin, (long long)L * R, R, t0};
+        a.k_split = R; a.K = 2 * R; a.bt = fw + h->fw_off_fg + (size_t)l * 2 * R * 2 * D; a.N = 2 * D;
+        a.bias = pl.has_bias ? fw + h->fw_off_bfg + (size_t)l * 2 * D : nullptr;
+        a.c = WnRowMap{z, rows * D, D, 0};
+        a.c2 = WnRowMap{zg + (size_t)gi * D, out_len * (long long)G * D, (long long)G * D, 0};
+        a.c2_first_row = (int)(rows - out_len);
+        a.gate_t = ws + t.th[l]; a.gate_g = ws + t.sg[l];
+        a.M = N * rows; a.rows_per_batch = (int)rows;
+        wn_launch_nn(st, WN_EPI_GATE, a);
+        if (l < NL - 1) {
+            memset(&a, 0, sizeof(a));
+            a.a0 = a.a1 = WnRowMap{z, rows * D, D, 0};
+            a.k_split = D; a.K = D; a.bt = fw + h->fw_off_res + (size_t)l * D * R; a.N = R;
+            a.bias = pl.has_bias ? fw + h->fw_off_bres + (size_t)l * R : nullptr;
+            a.cin = WnRowMap{xin, (long long)L * R, R, t0};
+            a.c = WnRowMap{ws + t.x[l + 1], (long long)L * R, R, t0};
+            a.M = N * rows; a.rows_per_batch = (int)rows;
+            wn_launch_nn(st, WN_EPI_PLAIN, a);
+        }
+        if (gi == G - 1 || l == NL - 1) {
+            const int first = l - gi, cnt = gi + 1;
+            memset(&a, 0, sizeof(a));
+            a.a0 = a.a1 = WnRowMap{zg, out_len * (long long)G * D, (long long)G * D, 0};
+            a.k_split = cnt * D; a.K = cnt * D; a.bt = fw + h->fw_off_skip + (size_t)first * D * S; a.N = S;
+            a.bias = (pl.has_bias && first == 0) ? ws + t.bskip_total : nullptr;
+            if (first > 0) a.cin = WnRowMap{skip, out_len * S, S, 0};
+            a.c = WnRowMap{skip, out_len * S, S, 0};
+            a.M = N * out_len; a.rows_per_batch = (int)out_len;
+            wn_launch_nn(st, WN_EPI_PLAIN, a);
+        }
+    }
+    {
+        WnGemmArgs a;
+        memset(&a, 0, sizeof(a));
+        a.a0 = a.a1 = WnRowMap{skip, out_len * S, S, 0};
+        a.k_split = S; a.K = S; a.bt = fw + h->fw_off_w1; a.N = E; a.bias = fw + h->fw_off_b1;
+        a.c = WnRowMap{ev, out_len * E, E, 0};
+        a.M = N * out_len; a.rows_per_batch = (int)out_len; a.relu_a = 1; a.relu_c = 1;
+        wn_launch_nn(st, WN_EPI_PLAIN, a);
+        memset(&a, 0, sizeof(a));
+        a.a0 = a.a1 = WnRowMap{ev, out_len * E, E, 0};
+        a.k_split = E; a.K = E; a.bt = fw + h->fw_off_w2; a.N = C; a.bias = fw + h->fw_off_b2;
+        a.c = WnRowMap{logits, out_len * C, C, 0};
+        a.M = N * out_len; a.rows_per_batch = (int)out_len;
+        wn_launch_nn(st, WN_EPI_PLAIN, a);
+    }
+    rc = rt_hip(hipGetLastError(), "wn_train_forward launches");
+    if (rc) return rc;
+    h->train_valid = true;
+    return WN_OK;
+}
+
+extern "C" int wn_train_backward(wn_handle* h, const float* params, const float* dlogits, float* grads, void* hip_stream) {
+    g_err[0] = 0;
+    if (!h || !params || !dlogits || !grads) return wn_fail(WN_E_BADARG, "wn_train_backward: NULL argument");
+    if (!h->train_valid) return wn_fail(WN_E_STATE, "wn_train_backward: no wn_train_forward to differentiate");
+    { int rc = rt_hip(hipSetDevice(h->cfg.device_id), "hipSetDevice"); if (rc) return rc; }
+    const WnPlan& pl = h->plan;
+    const int R = pl.R, D = pl.D, S = pl.S, E = pl.E, C = pl.C, NL = pl.NL;
+    const WnTrainLay& t = h->train;
+    const long long N = t.N, L = t.L, out_len = t.out_len, Mo = N * out_len;
+    float* ws = h->d_tws;
+    hipStream_t st = (hipStream_t)hip_stream;
+    (void)params;  // the operand layouts of this step's parameters were rebuilt by wn_train_forward
+    int rc = rt_hip(hipMemsetAsync(grads, 0, h->fw_floats * 4, st), "hipMemsetAsync(grads)");
+    if (rc) return rc;
+    float* dskip = ws + t.dskip; float* de = ws + t.de; float* dz = ws + t.dz; float* dfg = ws + t.dfg;
+    const float* skip = ws + t.skip; const float* ev = ws + t.ev;
+    WnGemmArgs a;
+    WnGemmTnArgs g;
+    // ---- head
+    memset(&g, 0, sizeof(g));   // dW2^T [E][C] = e^T . dlogits
+    g.a = WnRowMap{ev, out_len * E, E, 0}; g.b = WnRowMap{dlogits, out_len * C, C, 0};
+    g.Ka = E; g.Nb = C; g.c = grads + h->fw_off_w2; g.ldc = C; g.M = Mo; g.rows_per_batch = (int)out_len;
+    wn_launch_tn(st, g);
+    wn_launch_colsum(st, WnRowMap{dlogits, out_len * C, C, 0}, Mo, (int)out_len, C, grads + h->fw_off_b2);
+    memset(&a, 0, sizeof(a));   // de = (dlogits . W2) * [e > 0]
+    a.a0 = a.a1 = WnRowMap{dlogits, out_len * C, C, 0};
+    a.k_split = C; a.K = C; a.bt = ws + t.w2_o; a.N = E;
+    a.c = WnRowMap{de, out_len * E, E, 0}; a.mask = ev;
+    a.M = Mo; a.rows_per_batch = (int)out_len;
+    wn_launch_nn(st, WN_EPI_PLAIN, a);
+    memset(&g, 0, sizeof(g));   // dW1^T [S][E] = relu(skip)^T . de
+    g.a = WnRowMap{skip, out_len * S, S, 0}; g.b = WnRowMap{de, out_len * E, E, 0}; g.relu_a = 1;
+    g.Ka = S; g.Nb = E; g.c = grads + h->fw_off_w1; g.ldc = E; g.M = Mo; g.rows_per_batch = (int)out_len;
+    wn_launch_tn(st, g);
+    wn_launch_colsum(st, WnRowMap{de, out_len * E, E, 0}, Mo, (int)out_len, E, grads + h->fw_off_b1);
+    memset(&a, 0, sizeof(a));   // dskip = (de . W1) * [skip > 0]
+    a.a0 = a.a1 = WnRowMap{de, out_len * E, E, 0};
+    a.k_split = E; a.K = E; a.bt = ws + t.w1_o; a.N = S;
+    a.c = WnRowMap{dskip, out_len * S, S, 0}; a.mask = skip;
+    a.M = Mo; a.rows_per_batch = (int)out_len;
+    wn_launch_nn(st, WN_EPI_PLAIN, a);
+    if (pl.has_bias) {          // every layer's skip bias sees the same gradient
+        rc = rt_hip(hipMemsetAsync(ws + t.colsum_tmp, 0, (size_t)S * 4, st), "hipMemsetAsync");
+        if (rc) return rc;
+        wn_launch_colsum(st, WnRowMap{dskip, out_len * S, S, 0}, Mo, (int)out_len, S, ws + t.colsum_tmp);
+        for (int l = 0; l < NL; ++l) {
+            rc = rt_hip(hipMemcpyAsync(grads + h->fw_off_bskip + (size_t)l * S, ws + t.colsum_tmp, (size_t)S * 4, hipMemcpyDeviceToDevice, st), "hipMemcpyAsync(dbskip)");
+            if (rc) return rc;
+        }
+    }
+    // ---- layers, last to first
+    float* dxn = ws + t.dxa;  // dLoss/dx_{l+1}
+    float* dxc = ws + t.dxb;  // dLoss/dx_l
+    for (int l = NL - 1; l >= 0; --l) {
+        const long long d = h->dil[l], rows = t.need[l + 1], t0 = L - rows, M = N * rows;
+        const float* xin = ws + t.x[l];
+        const float* z = ws + t.z[l];
+        const bool has_res = l < NL - 1;
+        if (has_res) {          // dz = dx' . Wres ;  dWres^T [D][R] = z^T . dx'
+            memset(&a, 0, sizeof(a));
+            a.a0 = a.a1 = WnRowMap{dxn, L * (long long)R, R, t0};
+            a.k_split = R; a.K = R; a.bt = ws + t.res_o + (size_t)l * R * D; a.N = D;
+            a.c = WnRowMap{dz, rows * D, D, 0};
+            a.M = M; a.rows_per_batch = (int)rows;
+            wn_launch_nn(st, WN_EPI_PLAIN, a);
+            memset(&g, 0, sizeof(g));
+            g.a = WnRowMap{z, rows * D, D, 0}; g.b = WnRowMap{dxn, L * (long long)R, R, t0};
+            g.Ka = D; g.Nb = R; g.c = grads + h->fw_off_res + (size_t)l * D * R; g.ldc = R; g.M = M; g.rows_per_batch = (int)rows;
+            wn_launch_tn(st, g);
+            if (pl.has_bias) wn_launch_colsum(st, WnRowMap{dxn, L * (long long)R, R, t0}, M, (int)rows, R, grads + h->fw_off_bres + (size_t)l * R);
+        } else {
+            rc = rt_hip(hipMemsetAsync(dz, 0, (size_t)M * D * 4, st), "hipMemsetAsync(dz)");
+            if (rc) return rc;
+        }
+        memset(&a, 0, sizeof(a));   // dz[skip rows] += dskip . Wskip ;  dWskip^T [D][S] = z[skip rows]^T . dskip
+        a.a0 = a.a1 = WnRowMap{dskip, out_len * S, S, 0};
+        a.k_split = S; a.K = S; a.bt = ws + t.skip_o + (size_t)l * S * D; a.N = D;
+        a.cin = WnRowMap{dz, rows * D, D, rows - out_len};
+        a.c = WnRowMap{dz, rows * D, D, rows - out_len};
+        a.M = Mo; a.rows_per_batch = (int)out_len;
+        wn_launch_nn(st, WN_EPI_PLAIN, a);
+        memset(&g, 0, sizeof(g));
+        g.a = WnRowMap{z, rows * D, D, rows - out_len}; g.b = WnRowMap{dskip, out_len * S, S, 0};
+        g.Ka = D; g.Nb = S; g.c = grads + h->fw_off_skip + (size_t)l * D * S; g.ldc = S; g.M = Mo; g.rows_per_batch = (int)out_len;
+        wn_launch_tn(st, g);
+        {   // [dF | dG]
+            const long long work = M * D;
+            hipLaunchKernelGGL(wn_bwd_gate, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, dz, ws + t.th[l], ws + t.sg[l], dfg, M, D);
+        }
+        for (int tap = 0; tap < 2; ++tap) {  // dWfg^T rows tap*R.. = x_l(t - (1-tap) d)^T . dfg
+            memset(&g, 0, sizeof(g));
+            g.a = WnRowMap{xin, L * (long long)R, R, tap ? t0 : t0 - d}; g.b = WnRowMap{dfg, rows * 2 * D, 2 * D, 0};
+            g.Ka = R; g.Nb = 2 * D; g.c = grads + h->fw_off_fg + (size_t)l * 2 * R * 2 * D + (size_t)tap * R * 2 * D; g.ldc = 2 * D;
+            g.M = M; g.rows_per_batch = (int)rows;
+            wn_launch_tn(st, g);
+        }
+        if (pl.has_bias) wn_launch_colsum(st, WnRowMap{dfg, rows * 2 * D, 2 * D, 0}, M, (int)rows, 2 * D, grads + h->fw_off_bfg + (size_t)l * 2 * D);
+        // dx_l: rows [L - need[l], L); everything the two products below do not write must read as zero
+        rc = rt_hip(hipMemsetAsync(dxc, 0, (size_t)N * L * R * 4, st), "hipMemsetAsync(dx)");
+        if (rc) return rc;
+        memset(&a, 0, sizeof(a));   // dx_l(t) = dfg(t) . Wfg(tap 1) + dx'(t)
+        a.a0 = a.a1 = WnRowMap{dfg, rows * 2 * D, 2 * D, 0};
+        a.k_split = 2 * D; a.K = 2 * D; a.bt = ws + t.fgb1 + (size_t)l * 2 * D * R; a.N = R;
+        if (has_res) a.cin = WnRowMap{dxn, L * (long long)R, R, t0};
+        a.c = WnRowMap{dxc, L * (long long)R, R, t0};
+        a.M = M; a.rows_per_batch = (int)rows;
+        wn_launch_nn(st, WN_EPI_PLAIN, a);
+        memset(&a, 0, sizeof(a));   // dx_l(t - d) += dfg(t) . Wfg(tap 0)
+        a.a0 = a.a1 = WnRowMap{dfg, rows * 2 * D, 2 * D, 0};
+        a.k_split = 2 * D; a.K = 2 * D; a.bt = ws + t.fgb0 + (size_t)l * 2 * D * R; a.N = R;
+        a.cin = WnRowMap{dxc, L * (long long)R, R, t0 - d};
+        a.c = WnRowMap{dxc, L * (long long)R, R, t0 - d};
+        a.M = M; a.rows_per_batch = (int)rows;
+        wn_launch_nn(st, WN_EPI_PLAIN, a);
+        float* tmp = dxn; dxn = dxc; dxc = tmp;
+    }
+    // ---- start_conv: dstart^T [C][R] = onehot(indices)^T . dx_0
+    memset(&g, 0, sizeof(g));
+    g.a = WnRowMap{nullptr, L, 1, 0}; g.a_idx = reinterpret_cast<const int32_t*>(ws + t.idx);
+    g.b = WnRowMap{dxn, L * (long long)R, R, 0};
+    g.Ka = C; g.Nb = R; g.c = grads + h->fw_off_start_t; g.ldc = R; g.M = N * L; g.rows_per_batch = (int)L;
+    wn_launch_tn(st, g);
+    if (pl.has_bias) wn_launch_colsum(st, WnRowMap{dxn, L * (long long)R, R, 0}, N * L, (int)L, R, grads + h->fw_off_start_b);
+    return rt_hip(hipGetLastError(), "wn_train_backward launches");
+}

@@ -91,6 +91,8 @@ class WaveNetModel(nn.Module):
         self._wn_engine = None
         self._wn_engine_key = None
         self._wn_forward_calls = 0
+        self._wn_train_runner = None
+        self._wn_train_calls = 0
 
     # ------------------------------------------------------------------ training path (torch ops)
     def wavenet(self, input, dilation_func):
@@ -122,12 +124,10 @@ class WaveNetModel(nn.Module):
         return queue.dequeue(num_deq=self.kernel_size, dilation=dilation).unsqueeze(0)
 
     def _native_forward(self, input):
-        """Matrix-core forward (C ABI wn_forward) when it applies: CUDA input that is exactly one-hot, no autograd
-        (backward is not native yet), every returned position with a full receptive field, shapes the GEMM kernel
-        supports.  Returns None otherwise -- the caller then runs the torch path, which also reproduces the
-        reference's zero-padding quirk for short inputs."""
-        if torch.is_grad_enabled() and (input.requires_grad or any(p.requires_grad for p in self.parameters())):
-            return None
+        """Matrix-core forward (C ABI wn_forward, or wn_train_forward + wn_train_backward behind a torch.autograd.Function
+        when gradients are wanted) when it applies: CUDA input that is exactly one-hot, every returned position with a full
+        receptive field, shapes the GEMM kernels support.  Returns None otherwise -- the caller then runs the torch path,
+        which also reproduces the reference's zero-padding quirk for short inputs."""
         if not input.is_cuda or input.dim() != 3 or input.size(1) != self.classes or self.kernel_size != 2:
             return None
         n, _, l = input.shape
@@ -135,13 +135,51 @@ class WaveNetModel(nn.Module):
             return None
         if any(c % 32 for c in (self.residual_channels, self.dilation_channels, self.skip_channels, self.end_channels, self.classes)):
             return None
+        want_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        if torch.is_grad_enabled() and input.requires_grad:
+            return None  # a gradient w.r.t. the one-hot input itself: torch path
+        if want_grad and (input.dtype != torch.float32 or os.environ.get("WN_TORCH_BACKWARD") == "1"):
+            return None
         vals, idx = input.max(dim=1)
         if not bool(((vals == 1) & (input.sum(dim=1) == 1)).all()):
             return None  # not a one-hot batch: start_conv is a real contraction
+        if want_grad:
+            return self._native_train_forward(idx)
         eng = self._engine(1)
         out = eng.forward_indices(idx, self.output_length)
         self._wn_forward_calls = getattr(self, "_wn_forward_calls", 0) + 1
         return out.to(input.dtype)
+
+    def _native_train_forward(self, idx):
+        """model(x) with a native backward: see mi355_wavenet/training.py."""
+        from mi355_wavenet import engine, training
+        runner = getattr(self, "_wn_train_runner", None)
+        dev = next(self.parameters()).device
+        if runner is None or runner.device != dev:
+            eng = engine.Engine(self._config(), dict(self.state_dict()), n_streams=1, device_index=dev.index or 0)
+            runner = training.StackRunner(eng)  # the handle only provides plan, layout and workspace: parameters are passed per call
+            self._wn_train_runner = runner
+        names, tensors = [], []
+
+        def add(key, ts):
+            names.append((key, len(ts)))
+            tensors.extend(ts)
+
+        add("start_w", [self.start_conv.weight])
+        add("filter_w", [m.weight for m in self.filter_convs])
+        add("gate_w", [m.weight for m in self.gate_convs])
+        add("res_w", [m.weight for m in self.residual_convs])
+        add("skip_w", [m.weight for m in self.skip_convs])
+        add("end1_w", [self.end_conv_1.weight]); add("end1_b", [self.end_conv_1.bias])
+        add("end2_w", [self.end_conv_2.weight]); add("end2_b", [self.end_conv_2.bias])
+        if self.start_conv.bias is not None:
+            add("start_b", [self.start_conv.bias])
+            add("filter_b", [m.bias for m in self.filter_convs])
+            add("gate_b", [m.bias for m in self.gate_convs])
+            add("res_b", [m.bias for m in self.residual_convs])
+            add("skip_b", [m.bias for m in self.skip_convs])
+        self._wn_train_calls = getattr(self, "_wn_train_calls", 0) + 1
+        return training.StackFunction.apply(runner, idx, self.output_length, tuple(names), *tensors)
 
     def forward_indices(self, indices):
         """Extension: forward() on class indices (N, L) instead of a one-hot (N, classes, L) tensor -- what the
@@ -267,6 +305,7 @@ class WaveNetModel(nn.Module):
         state = self.__dict__.copy()
         state["_wn_engine"] = None
         state["_wn_engine_key"] = None
+        state["_wn_train_runner"] = None
         return state
 
 

@@ -49,6 +49,7 @@ def test_struct_sizes_match_header():
     assert ctypes.sizeof(_abi.wn_weight_ptrs) == 14 * 8
     assert ctypes.sizeof(_abi.wn_generate_args) == 8 + 8 + 8 + 4 + 4 + 8 * 5 + 4 + 4
     assert ctypes.sizeof(_abi.wn_info) == 8 * 4 + 4 * 8 + 8
+    assert ctypes.sizeof(_abi.wn_train_layout) == 14 * 8
 
 
 def _cfg(**kw):

@@ -1,0 +1,159 @@
+"""Native training step (wn_train_forward / wn_train_backward behind the facade's forward) against torch autograd.
+
+The checker is the facade's torch path -- the same conv1d/dilate graph as the reference's WaveNetModel.forward, pinned to
+the real reference in tests/test_oracle_pinning.py / test_facade.py -- differentiated by torch autograd on the same GPU.
+Tolerances: logits 1e-4 absolute (fp32 matrix-core GEMMs vs MIOpen), gradients 2e-5 of the largest |gradient| of the
+tensor (sums over up to N*L rows accumulated with fp32 atomics in a different order).
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "pytorch-wavenet_amd"))
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(bias, layers=3, blocks=2, ch=32, skip=64, end=64, out_len=16, seed=0):
+    import wavenet_model
+    torch.manual_seed(seed)
+    m = wavenet_model.WaveNetModel(layers=layers, blocks=blocks, dilation_channels=ch, residual_channels=ch, skip_channels=skip,
+                                   end_channels=end, classes=256, output_length=out_len, kernel_size=2, bias=bias)
+    with torch.no_grad():
+        for p in m.parameters():  # PyTorch's default init leaves the logits tiny: spread them so every ReLU / gate regime is hit
+            p.mul_(3.0)
+    return m.cuda()
+
+
+def _batch(m, n, extra, seed=1):
+    g = torch.Generator().manual_seed(seed)
+    L = m.receptive_field + m.output_length - 1 + extra
+    idx = torch.randint(0, 256, (n, L), generator=g)
+    x = torch.zeros(n, 256, L).scatter_(1, idx.unsqueeze(1), 1.0).cuda()
+    target = torch.randint(0, 256, (n * m.output_length,), generator=g).cuda()
+    return x, target
+
+
+def _step(m, x, target, torch_path):
+    if torch_path:
+        os.environ["WN_TORCH_BACKWARD"] = "1"
+    else:
+        os.environ.pop("WN_TORCH_BACKWARD", None)
+    try:
+        m.zero_grad(set_to_none=True)
+        before = m._wn_train_calls
+        out = m(x)
+        loss = torch.nn.functional.cross_entropy(out, target)
+        loss.backward()
+        assert (m._wn_train_calls > before) == (not torch_path)
+        return out.detach().clone(), float(loss), {k: (None if p.grad is None else p.grad.detach().clone()) for k, p in m.named_parameters()}
+    finally:
+        os.environ.pop("WN_TORCH_BACKWARD", None)
+
+
+@pytest.mark.parametrize("bias,extra,n", [(False, 0, 3), (True, 5, 2), (True, 0, 1)])
+def test_gradients_match_torch_autograd(bias, extra, n):
+    m = _model(bias)
+    x, target = _batch(m, n, extra)
+    out_t, loss_t, g_t = _step(m, x, target, torch_path=True)
+    out_n, loss_n, g_n = _step(m, x, target, torch_path=False)
+    assert torch.allclose(out_n, out_t, atol=1e-4, rtol=1e-4), float((out_n - out_t).abs().max())
+    assert abs(loss_n - loss_t) < 1e-5 * max(1.0, abs(loss_t))
+    assert set(g_t) == set(g_n)
+    for k in g_t:
+        if g_t[k] is None:
+            assert g_n[k] is None, k  # the last residual conv is unused (also upstream)
+            continue
+        assert g_n[k] is not None, k
+        scale = float(g_t[k].abs().max())
+        err = float((g_n[k] - g_t[k]).abs().max())
+        assert err <= 2e-5 * scale + 1e-9, (k, err, scale)
+
+
+def test_packed_layout_matches_the_c_side():
+    """pack(parameters) in Python == what wn_load_weights built in C (wn_train_export_params), element for element."""
+    from mi355_wavenet import engine, training
+    for bias in (False, True):
+        m = _model(bias)
+        eng = engine.Engine(m._config(), dict(m.state_dict()), n_streams=1, device_index=0)
+        r = training.StackRunner(eng)
+        sd = m.state_dict()
+        NL = m.layers * m.blocks
+        p = {"start_w": sd["start_conv.weight"], "end1_w": sd["end_conv_1.weight"], "end1_b": sd["end_conv_1.bias"],
+             "end2_w": sd["end_conv_2.weight"], "end2_b": sd["end_conv_2.bias"]}
+        for key, name in (("filter", "filter_convs"), ("gate", "gate_convs"), ("res", "residual_convs"), ("skip", "skip_convs")):
+            p[key + "_w"] = torch.stack([sd["%s.%d.weight" % (name, l)] for l in range(NL)])
+            if bias:
+                p[key + "_b"] = torch.stack([sd["%s.%d.bias" % (name, l)] for l in range(NL)])
+        if bias:
+            p["start_b"] = sd["start_conv.bias"]
+        flat = r.pack(p)
+        ref = r.export_params()
+        torch.cuda.synchronize()
+        o, s = r.off, r.sizes()
+        ref[o["bskip_total"]:o["bskip_total"] + s["bskip_total"]] = 0  # derived scratch section
+        assert torch.equal(flat, ref)
+        back = r.unpack(flat)
+        for k, v in p.items():
+            assert torch.equal(back[k].reshape(v.shape), v), k
+        eng.close()
+
+
+def test_a_few_adam_steps_follow_the_torch_trajectory():
+    losses = {}
+    for torch_path in (True, False):
+        m = _model(True, seed=3)
+        opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+        x, target = _batch(m, 2, 0, seed=5)
+        ls = []
+        for _ in range(5):
+            if torch_path:
+                os.environ["WN_TORCH_BACKWARD"] = "1"
+            try:
+                opt.zero_grad()
+                loss = torch.nn.functional.cross_entropy(m(x), target)
+                loss.backward()
+                torch.nn.utils.clip_grad_norm_(m.parameters(), 10.0)
+                opt.step()
+            finally:
+                os.environ.pop("WN_TORCH_BACKWARD", None)
+            ls.append(float(loss))
+        losses[torch_path] = ls
+    assert losses[False][-1] < losses[False][0]
+    assert np.allclose(losses[True], losses[False], rtol=2e-3), losses
+
+
+def test_backward_of_a_stale_forward_is_refused():
+    m = _model(False)
+    x, target = _batch(m, 1, 0)
+    out1 = m(x)
+    out2 = m(x)
+    with pytest.raises(RuntimeError, match="another forward"):
+        out1.sum().backward()
+    out2.sum().backward()
+
+
+def test_generate_after_training_uses_the_updated_weights():
+    """generate_fast picks up parameters changed by optimiser steps (the engine is rebuilt from the live state_dict)."""
+    m = _model(False, seed=7)
+    opt = torch.optim.SGD(m.parameters(), lr=0.05)
+    x, target = _batch(m, 2, 0)
+    a = m.generate_fast(40, temperature=0.)
+    for _ in range(3):
+        opt.zero_grad()
+        torch.nn.functional.cross_entropy(m(x), target).backward()
+        opt.step()
+    m.train()
+    b = m.generate_fast(40, temperature=0.)
+    import wavenet_model
+    torch.manual_seed(0)
+    m2 = wavenet_model.WaveNetModel(layers=m.layers, blocks=m.blocks, dilation_channels=32, residual_channels=32, skip_channels=64,
+                                    end_channels=64, classes=256, output_length=16, kernel_size=2, bias=False).cuda()
+    m2.load_state_dict(m.state_dict())
+    c = m2.generate_fast(40, temperature=0.)
+    assert np.array_equal(b, c)
+    assert a.shape == b.shape

@@ -1,0 +1,72 @@
+"""Times one training step (model(x); cross_entropy; backward; Adam step) at BASELINE config 5's shape: layers=10 blocks=5
+dil/res=128 skip=512, N one-second 16 kHz mu-law clips, through the facade -- native matrix-core forward + backward
+(wn_train_forward / wn_train_backward) next to the facade's torch path (MIOpen conv1d + autograd) on the same GPU.
+
+    python tools/bench_train.py [N] [L] [--no-torch]
+"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "pytorch-wavenet_amd"))
+import torch  # noqa: E402
+
+import wavenet_model  # noqa: E402
+
+
+def main():
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    N = int(args[0]) if len(args) > 0 else 32
+    L = int(args[1]) if len(args) > 1 else 16000
+    torch.manual_seed(0)
+    m = wavenet_model.WaveNetModel(layers=10, blocks=5, dilation_channels=128, residual_channels=128, skip_channels=512,
+                                   end_channels=256, classes=256, output_length=1, kernel_size=2, bias=False).cuda()
+    m.output_length = L - m.receptive_field + 1
+    out_len = m.output_length
+    g = torch.Generator().manual_seed(1)
+    idx = torch.randint(0, 256, (N, L), generator=g).cuda()
+    x = torch.zeros(N, 256, L, device="cuda").scatter_(1, idx.unsqueeze(1), 1.0)
+    target = torch.randint(0, 256, (N * out_len,), generator=g).cuda()
+    opt = torch.optim.Adam(m.parameters(), lr=1e-4)
+    R = D = 128; S = 512; E = 256; C = 256
+    need, fwd = out_len, 0
+    for d in reversed([2 ** (i % 10) for i in range(50)]):
+        fwd += 2 * N * need * (2 * R * 2 * D + D * R) + 2 * N * out_len * D * S
+        need += d
+    fwd += 2 * N * out_len * (S * E + E * C)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss = torch.nn.functional.cross_entropy(m(x), target)
+        loss.backward()
+        opt.step()
+        return loss
+
+    def timed(label, reps):
+        for _ in range(2):
+            loss = step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            loss = step()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / reps * 1e3
+        print("%s: %.1f ms / step (loss %.4f); forward GEMM work %.2f TFLOP, step ~3x -> %.1f TFLOP/s; %.0f clip-seconds/s" % (
+            label, ms, float(loss), fwd / 1e12, 3 * fwd / ms / 1e9, N * L / 16000 / (ms * 1e-3)))
+        return ms
+
+    a = timed("native fp32 matrix-core step", 3)
+    peak = torch.cuda.max_memory_allocated() / 2**30
+    print("torch-allocated peak %.1f GiB (the native workspace is allocated by the library, not by torch)" % peak)
+    if "--no-torch" not in sys.argv:
+        os.environ["WN_TORCH_BACKWARD"] = "1"
+        try:
+            b = timed("torch path (MIOpen conv1d + autograd)", 2)
+            print("speed-up %.2fx" % (b / a))
+        except Exception as e:  # noqa: BLE001
+            print("torch path failed:", type(e).__name__, str(e)[:200])
+
+
+if __name__ == "__main__":
+    main()
