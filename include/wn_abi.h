@@ -91,6 +91,9 @@ typedef struct wn_generate_args {
     void* hip_stream;             /* hipStream_t to enqueue on (NULL = default stream)                     */
     int32_t timeout_ms;           /* per-hand-off spin bound inside the kernel; 0 = default (10 s)         */
     int32_t reserved;
+    const float* stream_temperatures; /* [n_streams] fp32 | NULL: per-stream temperature overriding `temperature`
+                                     (<= 0: that stream takes the argmax) -- generate_audio's list of
+                                     temperatures (wavenet_training.py:115-124) as parallel streams          */
 } wn_generate_args;
 
 /* What the planner decided (for logs, benches and tests). */

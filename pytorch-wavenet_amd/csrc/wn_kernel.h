@@ -232,7 +232,7 @@ WN_DEV WnSmp wn_smp_carve(const WnPlan& p, float* lds) {
 //   x -= reg;  T>0: x /= T; p = exp(x-max) * (1/sum) in fp32; cdf = cumsum(double(p)); cdf /= cdf[-1];
 //   idx = #{cdf <= u} (searchsorted side='right');   greedy: first index of the maximum.
 // Result lands in smp.iscal[0].  lgt[] must hold the summed logits.
-WN_DEV void wn_sample(WnCtx& cx, const WnSmp& sm, double u, bool greedy) {
+WN_DEV void wn_sample(WnCtx& cx, const WnSmp& sm, double u, bool greedy, float temperature) {
     const WnPlan& p = *cx.p;
     const WnRun& r = *cx.r;
     const int C = p.C, G = WN_SAMPLER_GROUPS, chunk = (C + G - 1) / G;
@@ -240,7 +240,7 @@ WN_DEV void wn_sample(WnCtx& cx, const WnSmp& sm, double u, bool greedy) {
         for (int i = tid; i < C; i += WN_THREADS) {
             float v = sm.lgt[i];
             if (r.reg) v -= r.reg[i];
-            if (!greedy) v = v / r.temperature;
+            if (!greedy) v = v / temperature;
             sm.xsm[i] = v;
         }
     }
@@ -371,9 +371,10 @@ WN_DEV bool wn_l0_input(WnCtx& cx, int c, long long e, int s) {
                         r.dbg_logits[((size_t)s * r.num_samples + g) * p.C + i] = sm.lgt[i];
                 }
             }
-            const bool greedy = r.greedy != 0;
+            const float temp = r.stream_temps ? r.stream_temps[s] : r.temperature;
+            const bool greedy = r.greedy != 0 || !(temp > 0.f);
             const double u = greedy ? 0. : r.uniforms[(size_t)s * r.num_samples + g];
-            wn_sample(cx, sm, u, greedy);
+            wn_sample(cx, sm, u, greedy, temp);
             if (c == 0) {
                 WN_PHASE { if (tid == 0) r.out_idx[(size_t)s * r.num_samples + g] = sm.iscal[0]; }
             }

@@ -276,7 +276,7 @@ static __device__ __forceinline__ double wn_lane_d(double v, int lane) {
 
 // ---- sampler: C = 256 classes, one per lane.  Same arithmetic as wn_sample (wn_kernel.h) /
 // wavenet_model.py:280-294.  Returns the class index (uniform over the block).
-static __device__ __forceinline__ int wn_sample_v2(WnCtx& cx, float* scratch, float logit, double u, bool greedy) {
+static __device__ __forceinline__ int wn_sample_v2(WnCtx& cx, float* scratch, float logit, double u, bool greedy, float temperature) {
     const WnRun& r = *cx.r;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     float* fsc = scratch;                                    // [0..3] wave max, [4..7] wave sum
@@ -284,7 +284,7 @@ static __device__ __forceinline__ int wn_sample_v2(WnCtx& cx, float* scratch, fl
     double* dsc = reinterpret_cast<double*>(scratch + 24);   // [0..3] wave totals
     float x = logit;
     if (r.reg) x -= r.reg[tid];
-    if (!greedy) x = x / r.temperature;
+    if (!greedy) x = x / temperature;
     const float wm = wn_wave_max(x);
     if (lane == 0) fsc[wv] = wm;
     wn_lds_barrier();
@@ -432,9 +432,10 @@ static __device__ void wn_v2_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
                     } else {
                         const long long g = e - r.n_given;
                         if (r.dbg_logits && c == 0) r.dbg_logits[((size_t)s * r.num_samples + g) * 256 + tid] = logit;
-                        const bool greedy = r.greedy != 0;
+                        const float temp = r.stream_temps ? r.stream_temps[s] : r.temperature;
+                        const bool greedy = r.greedy != 0 || !(temp > 0.f);
                         const double u = greedy ? 0. : r.uniforms[(size_t)s * r.num_samples + g];
-                        idx = wn_sample_v2(cx, smp, logit, u, greedy);
+                        idx = wn_sample_v2(cx, smp, logit, u, greedy, temp);
                         if (c == 0 && tid == 0) r.out_idx[(size_t)s * r.num_samples + g] = idx;
                     }
                 }
@@ -1019,9 +1020,10 @@ static __device__ void wn_v2_sampler(const WnPlan& p, const WnRun& r, WnCtx& cx,
             } else {
                 const long long g = e - r.n_given;
                 if (r.dbg_logits) r.dbg_logits[((size_t)s * r.num_samples + g) * 256 + tid] = logit;
-                const bool greedy = r.greedy != 0;
+                const float temp = r.stream_temps ? r.stream_temps[s] : r.temperature;
+                const bool greedy = r.greedy != 0 || !(temp > 0.f);
                 const double u = greedy ? 0. : r.uniforms[(size_t)s * r.num_samples + g];
-                idx = wn_sample_v2(cx, lds_smp, logit, u, greedy);
+                idx = wn_sample_v2(cx, lds_smp, logit, u, greedy, temp);
                 if (tid == 0) r.out_idx[(size_t)s * r.num_samples + g] = idx;
             }
             if (e < r.n_eval && tid == 0) {

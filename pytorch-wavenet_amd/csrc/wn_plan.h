@@ -92,6 +92,7 @@ struct WnRun {
     long long* prof;        // optional [n_wg][prof_items][4] wall-clock stamps (diagnostics), or NULL
     int32_t prof_items;
     int32_t pad;
+    const float* stream_temps;  // optional [n_streams]: per-stream temperature (<= 0: that stream is greedy); NULL = `temperature` for all
 };
 
 // ---- host-side planner / packer (plain C++; also parsed, unused, in the device pass) ----

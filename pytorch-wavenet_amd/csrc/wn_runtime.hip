@@ -612,7 +612,7 @@ extern "C" int wn_generate(wn_handle* h, const wn_generate_args* a) {
     if (!a->first_samples) return wn_fail(WN_E_BADARG, "wn_generate: first_samples is NULL");
     if (a->num_samples > 0 && !a->out_idx) return wn_fail(WN_E_BADARG, "wn_generate: out_idx is NULL");
     if (a->flags != 0 || a->reserved != 0) return wn_fail(WN_E_BADARG, "wn_generate: flags/reserved must be 0");
-    const bool greedy = !(a->temperature > 0.f) || a->uniforms == nullptr;
+    const bool greedy = (!(a->temperature > 0.f) && !a->stream_temperatures) || a->uniforms == nullptr;
     const long long n_eval = a->n_given - 1 + a->num_samples;
     if (n_eval + 1 >= 0xFFFFFFFFll) return wn_fail(WN_E_BADARG, "wn_generate: job too long for 32-bit hand-off tags");
 #ifndef WN_EMU
@@ -624,7 +624,7 @@ extern "C" int wn_generate(wn_handle* h, const wn_generate_args* a) {
     memset(&r, 0, sizeof(r));
     r.first = a->first_samples; r.n_given = a->n_given; r.num_samples = a->num_samples; r.n_eval = n_eval;
     r.t_base = h->t_base; r.temperature = a->temperature; r.greedy = greedy ? 1 : 0; r.reg = a->regularizer;
-    r.uniforms = a->uniforms; r.out_idx = a->out_idx; r.dbg_logits = a->dbg_logits;
+    r.uniforms = a->uniforms; r.out_idx = a->out_idx; r.dbg_logits = a->dbg_logits; r.stream_temps = a->stream_temperatures;
     const long long ms = a->timeout_ms > 0 ? a->timeout_ms : 10000;
     r.timeout_ticks = ms * (long long)h->wall_khz;
     if (h->prof_items > 0) {

@@ -39,7 +39,8 @@ class wn_generate_args(ctypes.Structure):
     _fields_ = [("first_samples", ctypes.c_void_p), ("n_given", ctypes.c_int64), ("num_samples", ctypes.c_int64),
                 ("temperature", ctypes.c_float), ("flags", ctypes.c_int32), ("regularizer", ctypes.c_void_p),
                 ("uniforms", ctypes.c_void_p), ("out_idx", ctypes.c_void_p), ("dbg_logits", ctypes.c_void_p),
-                ("hip_stream", ctypes.c_void_p), ("timeout_ms", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+                ("hip_stream", ctypes.c_void_p), ("timeout_ms", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("stream_temperatures", ctypes.c_void_p)]
 
 
 class wn_info(ctypes.Structure):

@@ -167,11 +167,12 @@ class Engine:
         self.lib.check(self.lib.dll.wn_profile_read(self._h, out.ctypes.data, out.size))
         return out
 
-    def launch(self, first_dev, n_given, num_samples, temperature, reg_dev, uni_dev, out_dev, logits_dev, timeout_ms=0):
-        """Enqueue one job on the current stream (asynchronous)."""
+    def launch(self, first_dev, n_given, num_samples, temperature, reg_dev, uni_dev, out_dev, logits_dev, timeout_ms=0,
+               temps_dev=None):
+        """Enqueue one job on the current stream (asynchronous).  temps_dev: optional fp32 (n_streams,) per-stream temperatures."""
         a = _abi.wn_generate_args(self.mem.ptr(first_dev), n_given, num_samples, float(temperature), 0,
                                   self.mem.ptr(reg_dev), self.mem.ptr(uni_dev), self.mem.ptr(out_dev),
-                                  self.mem.ptr(logits_dev), self.mem.stream(), int(timeout_ms), 0)
+                                  self.mem.ptr(logits_dev), self.mem.stream(), int(timeout_ms), 0, self.mem.ptr(temps_dev))
         self.lib.check(self.lib.dll.wn_generate(self._h, ctypes.byref(a)))
 
     def wait(self):
@@ -193,6 +194,7 @@ class Engine:
                  want_logits=False, reset=True, timeout_ms=0, batched_prime=True):
         """first_samples: (n_streams, n_given) or (n_given,) ints (broadcast to every stream) or None -> classes//2.
         uniforms: float64 (n_streams, num_samples) (np.random.random_sample draws) or None -> greedy.
+        temperature: a number, or one per stream (a stream with temperature <= 0 is greedy and ignores its uniforms row).
         Returns indices int32 (n_streams, num_samples) [, logits float32 (n_streams, num_samples, classes)]."""
         ns, C = self.n_streams, self.classes
         if first_samples is None:
@@ -205,6 +207,11 @@ class Engine:
         if fs.min() < 0 or fs.max() >= C:
             raise ValueError("first_samples outside [0, classes)")
         fs = np.ascontiguousarray(fs, dtype=np.int32)
+        temps_dev = None
+        if np.ndim(temperature) > 0:
+            temps = np.ascontiguousarray(np.asarray(temperature, dtype=np.float32).reshape(ns))
+            temps_dev = self.mem.upload(temps)
+            temperature = float(temps.max())
         greedy = not (temperature > 0) or uniforms is None
         uni_dev = None
         if not greedy:
@@ -220,7 +227,7 @@ class Engine:
             if batched_prime and n_given - 1 >= self.PRIME_BATCH_MIN and self.prime(first_dev, n_given - 1, n_given):
                 first_dev = self.mem.upload(np.ascontiguousarray(fs[:, -1:]))  # the last given sample is the next input
                 n_given = 1
-        self.launch(first_dev, n_given, num_samples, temperature, reg_dev, uni_dev, out_dev, logits_dev, timeout_ms)
+        self.launch(first_dev, n_given, num_samples, temperature, reg_dev, uni_dev, out_dev, logits_dev, timeout_ms, temps_dev)
         self.wait()
         idx = self.mem.download(out_dev)[:, :num_samples]
         if want_logits:

@@ -188,6 +188,16 @@ class WaveNetModel(nn.Module):
         self._wn_forward_calls = getattr(self, "_wn_forward_calls", 0) + 1
         return out
 
+    def train_forward_indices(self, indices):
+        """Extension: the differentiable forward() on class indices (N, L) -- the training-time sibling of forward_indices:
+        logits (N*output_length, classes) whose backward runs natively (see _native_train_forward).  MI355X only."""
+        idx = torch.as_tensor(indices)
+        n, l = idx.shape
+        if l < self.receptive_field + self.output_length - 1:
+            raise ValueError("train_forward_indices: items of %d samples are shorter than receptive_field + output_length - 1 = %d"
+                             % (l, self.receptive_field + self.output_length - 1))
+        return self._native_train_forward(idx)
+
     def forward(self, input):
         """(N, classes, L) one-hot -> (N*output_length, classes) logits (wavenet_model.py:186-196)."""
         native = self._native_forward(input)
@@ -290,6 +300,31 @@ class WaveNetModel(nn.Module):
         self.train()
         mu_gen = mu_law_expansion(generated, self.classes)  # :314
         return mu_gen if batched else mu_gen[0]
+
+    def generate_fast_streams(self, num_samples, temperatures, first_samples=None, regularize=0.):
+        """Extension: one generate_fast() per entry of ``temperatures`` -- the reference's generate_audio loop
+        (wavenet_training.py:115-124) -- as parallel streams of ONE persistent-kernel job.  Returns float64
+        (len(temperatures), num_samples), row k equal to ``generate_fast(num_samples, first_samples, temperatures[k])``
+        of sequential calls: sampled rows consume the global numpy RNG in the order of ``temperatures`` (one draw per
+        sample), greedy rows (temperature <= 0, wavenet_model.py:290-294) consume none."""
+        self.eval()
+        temps = [float(t) for t in temperatures]
+        if first_samples is None:
+            first_samples = torch.LongTensor(1).zero_() + (self.classes // 2)
+        first = torch.as_tensor(first_samples).detach().cpu().numpy().astype(np.int64).reshape(1, -1)
+        first = np.repeat(first, len(temps), axis=0)
+        for queue in self.dilated_queues:
+            queue.reset()
+        eng = self._engine(len(temps))
+        uniforms = np.zeros((len(temps), num_samples), dtype=np.float64)
+        for k, t in enumerate(temps):
+            if t > 0:
+                uniforms[k] = np.random.random_sample(num_samples)
+        idx = eng.generate(num_samples, first, temperature=np.asarray(temps, dtype=np.float32), regularize=regularize,
+                           uniforms=uniforms if any(t > 0 for t in temps) else None)
+        generated = (idx.astype(np.int64) / self.classes) * 2. - 1
+        self.train()
+        return mu_law_expansion(generated, self.classes)
 
     # ------------------------------------------------------------------ bookkeeping
     def parameter_count(self):

@@ -1,0 +1,169 @@
+"""Drop-in for the reference's ``wavenet_training`` (/root/reference/wavenet_training.py): ``WavenetTrainer`` and
+``generate_audio``.
+
+The loop is the reference's (:50-88): batch -> ``model(x)`` -> ``F.cross_entropy`` -> backward -> optional clip -> step ->
+snapshot -> logger.  On an MI355X ``model(x)`` and ``loss.backward()`` run through the native matrix-core stack
+(wavenet_model.WaveNetModel._native_forward, mi355_wavenet/training.py).  Extensions, all off by default:
+  * ``device_batches=True``: batches are cut on the GPU from the resident class-index stream (audio_data.DeviceBatches)
+    and enter the model as indices -- no host one-hot, no 256x inflated H2D copy;
+  * ``process_group``: data-parallel training, one process per GPU: every rank steps on the average of all ranks'
+    gradients (ONE flat all-reduce per step over RCCL; SURVEY.md section 8e "Training (cfg5): plain data parallel").
+"""
+import time
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+import torch.optim as optim
+import torch.utils.data
+
+from model_logging import Logger
+
+
+def print_last_loss(opt):
+    print("loss: ", opt.losses[-1])
+
+
+def print_last_validation_result(opt):
+    print("validation loss: ", opt.validation_results[-1])
+
+
+def average_gradients(parameters, process_group=None):
+    """Data-parallel gradient exchange: ONE all-reduce over the flattened gradients of ``parameters`` (30 MB at BASELINE
+    config 5: latency-bound on xGMI, so a single bucket), then every .grad <- mean over ranks.  No-op without a group."""
+    import torch.distributed as dist
+    if process_group is None and not (dist.is_available() and dist.is_initialized()):
+        return
+    world = dist.get_world_size(process_group)
+    if world == 1:
+        return
+    grads = [p.grad for p in parameters if p.grad is not None]
+    if not grads:
+        return
+    flat = torch.cat([g.reshape(-1) for g in grads])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=process_group)
+    flat.div_(world)
+    pos = 0
+    for g in grads:
+        n = g.numel()
+        g.copy_(flat[pos:pos + n].view_as(g))
+        pos += n
+
+
+class WavenetTrainer:
+    def __init__(self, model, dataset, optimizer=optim.Adam, lr=0.001, weight_decay=0, gradient_clipping=None,
+                 logger=None, snapshot_path=None, snapshot_name='snapshot', snapshot_interval=1000,
+                 dtype=torch.FloatTensor, ltype=torch.LongTensor, device_batches=False, process_group=None, num_workers=8):
+        self.model = model
+        self.dataset = dataset
+        self.dataloader = None
+        self.lr = lr
+        self.weight_decay = weight_decay
+        self.clip = gradient_clipping
+        self.optimizer_type = optimizer
+        self.optimizer = self.optimizer_type(params=self.model.parameters(), lr=self.lr, weight_decay=self.weight_decay)
+        self.logger = logger if logger is not None else Logger()  # upstream shares ONE default Logger between trainers (:27)
+        self.logger.trainer = self
+        self.snapshot_path = snapshot_path
+        self.snapshot_name = snapshot_name
+        self.snapshot_interval = snapshot_interval
+        self.dtype = dtype
+        self.ltype = ltype
+        self.device_batches = device_batches
+        self.process_group = process_group
+        self.num_workers = num_workers
+        self._batches = None
+
+    def _device(self):
+        return next(self.model.parameters()).device
+
+    def _to_model(self, x, target):
+        dev = self._device()
+        if isinstance(self.dtype, torch.dtype):
+            x = x.to(dev, self.dtype)
+        else:
+            x = x.type(self.dtype).to(dev)
+        target = target.view(-1).type(self.ltype).to(dev)
+        return x, target
+
+    def _epoch(self, batch_size, shuffle):
+        """Yields (kind, x, target): kind "indices" (device batches) or "onehot" (the reference's DataLoader items)."""
+        if self.device_batches:
+            if self._batches is None or self._batches.device != self._device():
+                from audio_data import DeviceBatches
+                self._batches = DeviceBatches(self.dataset, self._device())
+            for idx, target in self._batches.epoch(batch_size, shuffle=shuffle):
+                yield "indices", idx, target
+        else:
+            for x, target in iter(self.dataloader):
+                x, target = self._to_model(x, target)
+                yield "onehot", x, target
+
+    def _forward(self, kind, x):
+        if kind == "indices":
+            return self.model.train_forward_indices(x) if torch.is_grad_enabled() else self.model.forward_indices(x)
+        return self.model(x)
+
+    def train_step(self, kind, x, target):
+        """One optimiser step (wavenet_training.py:68-77); returns the loss as a float."""
+        output = self._forward(kind, x)
+        loss = F.cross_entropy(output.squeeze(), target.squeeze())
+        self.optimizer.zero_grad()
+        loss.backward()
+        average_gradients(self.model.parameters(), self.process_group)
+        if self.clip is not None:
+            torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.clip)
+        self.optimizer.step()
+        return loss.item()
+
+    def train(self, batch_size=32, epochs=10, continue_training_at_step=0):
+        self.model.train()
+        self.dataloader = torch.utils.data.DataLoader(self.dataset, batch_size=batch_size, shuffle=True,
+                                                      num_workers=self.num_workers, pin_memory=False)
+        step = continue_training_at_step
+        for current_epoch in range(epochs):
+            print("epoch", current_epoch)
+            tic = time.time()
+            for kind, x, target in self._epoch(batch_size, shuffle=True):
+                loss = self.train_step(kind, x, target)
+                step += 1
+                if step == 100:
+                    toc = time.time()
+                    print("one training step does take approximately " + str((toc - tic) * 0.01) + " seconds)")
+                if step % self.snapshot_interval == 0:
+                    if self.snapshot_path is None:
+                        continue
+                    time_string = time.strftime("%Y-%m-%d_%H-%M-%S", time.gmtime())
+                    torch.save(self.model, self.snapshot_path + '/' + self.snapshot_name + '_' + time_string)
+                self.logger.log(step, loss)
+
+    def validate(self):  # :89-112
+        self.model.eval()
+        self.dataset.train = False
+        if self.dataloader is None:
+            self.dataloader = torch.utils.data.DataLoader(self.dataset, batch_size=32, shuffle=False, num_workers=0)
+        total_loss = 0
+        accurate_classifications = 0
+        n_batches = 0
+        with torch.no_grad():
+            for kind, x, target in self._epoch(self.dataloader.batch_size, shuffle=False):
+                output = self._forward(kind, x)
+                loss = F.cross_entropy(output.squeeze(), target.squeeze())
+                total_loss += loss.item()
+                predictions = torch.max(output, 1)[1].view(-1)
+                accurate_classifications += torch.sum(torch.eq(target, predictions)).item()
+                n_batches += 1
+        avg_loss = total_loss / max(n_batches, 1)
+        avg_accuracy = accurate_classifications / (len(self.dataset) * self.dataset.target_length)
+        self.dataset.train = True
+        self.model.train()
+        return avg_loss, avg_accuracy
+
+
+def generate_audio(model, length=8000, temperatures=[0., 1.]):
+    """:115-124.  The reference generates once per temperature, one after the other; the temperatures are independent
+    streams, and on the MI355X engine all of them run in ONE persistent-kernel job (model.generate_fast_streams)."""
+    if hasattr(model, "generate_fast_streams"):
+        return model.generate_fast_streams(length, temperatures=list(temperatures))
+    samples = [model.generate_fast(length, temperature=temp) for temp in temperatures]
+    return np.stack(samples, axis=0)

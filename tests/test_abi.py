@@ -47,7 +47,7 @@ def test_hip_library_builds_and_exports_every_symbol():
 def test_struct_sizes_match_header():
     assert ctypes.sizeof(_abi.wn_config) == 16 * 4
     assert ctypes.sizeof(_abi.wn_weight_ptrs) == 14 * 8
-    assert ctypes.sizeof(_abi.wn_generate_args) == 8 + 8 + 8 + 4 + 4 + 8 * 5 + 4 + 4
+    assert ctypes.sizeof(_abi.wn_generate_args) == 8 + 8 + 8 + 4 + 4 + 8 * 5 + 4 + 4 + 8
     assert ctypes.sizeof(_abi.wn_info) == 8 * 4 + 4 * 8 + 8
     assert ctypes.sizeof(_abi.wn_train_layout) == 14 * 8
 

@@ -219,3 +219,22 @@ def test_two_streams_per_pipeline_item(monkeypatch):
     check_engine(eng, cfg, W, 80, first, 1.0, 0.0, uniforms, "cfg3 G=2 sampled")
     check_engine(eng, cfg, W, 80, first, 0.0, 0.0, None, "cfg3 G=2 greedy")
     eng.close()
+
+
+def test_per_stream_temperatures():
+    """wn_generate_args.stream_temperatures: every stream samples at its own temperature (<= 0: argmax), all kernels."""
+    from mi355_wavenet import engine, synth
+    for cfgname, ns in (("tiny_bias", 3), ("cfg2", 3), ("cfg2", 1)):
+        cfg = synth.CONFIGS[cfgname]
+        W = synth.init_weights(cfg, seed=31)
+        rs = np.random.RandomState(17)
+        temps = [0.8, 0.0, 1.3][:ns]
+        first = rs.randint(0, 256, (ns, 4))
+        u = rs.random_sample((ns, 50))
+        eng = engine.Engine(cfg, W, n_streams=ns)
+        out = eng.generate(50, first, temperature=np.asarray(temps, dtype=np.float32), uniforms=u)
+        eng.close()
+        for s, t in enumerate(temps):
+            idx, _ = c_oracle.generate(cfg, W, 50, first[s], t if t > 0 else 0.0, 0.0, u[s] if t > 0 else None)
+            agree = int((out[s] == idx).sum())
+            assert agree == 50, (cfgname, ns, s, t, agree)

@@ -50,7 +50,7 @@ def _step(m, x, target, torch_path):
         loss = torch.nn.functional.cross_entropy(out, target)
         loss.backward()
         assert (m._wn_train_calls > before) == (not torch_path)
-        return out.detach().clone(), float(loss), {k: (None if p.grad is None else p.grad.detach().clone()) for k, p in m.named_parameters()}
+        return out.detach().clone(), float(loss.detach()), {k: (None if p.grad is None else p.grad.detach().clone()) for k, p in m.named_parameters()}
     finally:
         os.environ.pop("WN_TORCH_BACKWARD", None)
 
@@ -157,3 +157,78 @@ def test_generate_after_training_uses_the_updated_weights():
     c = m2.generate_fast(40, temperature=0.)
     assert np.array_equal(b, c)
     assert a.shape == b.shape
+
+
+def test_train_forward_indices_equals_one_hot_forward():
+    m = _model(True)
+    x, target = _batch(m, 2, 3)
+    idx = x.argmax(dim=1)
+    _, loss_a, g_a = _step(m, x, target, torch_path=False)
+    m.zero_grad(set_to_none=True)
+    out = m.train_forward_indices(idx)
+    loss = torch.nn.functional.cross_entropy(out, target)
+    loss.backward()
+    assert abs(float(loss) - loss_a) < 1e-6
+    for k, p in m.named_parameters():
+        if g_a[k] is None:
+            assert p.grad is None
+        else:  # same kernels, same inputs; the fp32 atomics may reorder sums
+            assert torch.allclose(p.grad, g_a[k], rtol=1e-4, atol=1e-7 * float(g_a[k].abs().max()) + 1e-12), k
+    with pytest.raises(ValueError):
+        m.train_forward_indices(idx[:, :10])
+
+
+def test_trainer_with_device_batches(tmp_path):
+    import audio_data
+    import model_logging
+    import wavenet_training
+    rs = np.random.RandomState(0)
+    t = np.arange(6000)
+    wave = 0.6 * np.sin(t * 0.05) + 0.05 * rs.randn(6000)  # learnable signal
+    np.savez(str(tmp_path / "ds.npz"), audio_data.quantize_data(wave[:3500], 256).astype(np.uint8),
+             audio_data.quantize_data(wave[3500:], 256).astype(np.uint8))
+    m = _model(False, seed=2)
+    il = m.receptive_field + m.output_length - 1
+    ds = audio_data.WavenetDataset(str(tmp_path / "ds.npz"), item_length=il, target_length=m.output_length, test_stride=20)
+    losses = []
+
+    class L(model_logging.Logger):
+        def log(self, step, loss):
+            losses.append(loss)
+
+    tr = wavenet_training.WavenetTrainer(m, ds, lr=2e-3, gradient_clipping=5.0, logger=L(), device_batches=True)
+    before = m._wn_train_calls
+    tr.train(batch_size=8, epochs=2)
+    assert m._wn_train_calls - before == len(losses) > 10
+    assert np.mean(losses[-5:]) < np.mean(losses[:5])
+    avg_loss, acc = tr.validate()
+    assert np.isfinite(avg_loss) and 0.0 <= acc <= 1.0
+    # the same trainer through the reference's DataLoader / one-hot path gives the same first loss
+    m2 = _model(False, seed=2)
+    tr2 = wavenet_training.WavenetTrainer(m2, ds, lr=2e-3, num_workers=0)
+    db = audio_data.DeviceBatches(ds, "cuda")
+    idx, target = db.batch([0, 1, 2, 3])
+    x = torch.stack([ds[i][0] for i in range(4)]).cuda()
+    l_idx = tr2.train_step("indices", idx, target)
+    m3 = _model(False, seed=2)
+    tr3 = wavenet_training.WavenetTrainer(m3, ds, lr=2e-3, num_workers=0)
+    l_hot = tr3.train_step("onehot", x, target)
+    assert abs(l_idx - l_hot) < 1e-6
+
+
+def test_generate_audio_runs_its_temperatures_as_parallel_streams():
+    import wavenet_training
+    m = _model(False, seed=9)
+    m.eval()
+    np.random.seed(123)
+    seq = np.stack([m.generate_fast(60, temperature=t) for t in (0., 1., 0.7)])
+    np.random.seed(123)
+    par = wavenet_training.generate_audio(m, length=60, temperatures=[0., 1., 0.7])
+    assert par.shape == (3, 60) and par.dtype == np.float64
+    assert np.array_equal(seq, par)
+    first = torch.tensor([3, 200, 77, 128])
+    np.random.seed(5)
+    a = np.stack([m.generate_fast(30, first_samples=first, temperature=t, regularize=0.1) for t in (0.9, 0.)])
+    np.random.seed(5)
+    b = m.generate_fast_streams(30, [0.9, 0.], first_samples=first, regularize=0.1)
+    assert np.array_equal(a, b)

@@ -53,7 +53,7 @@ def main():
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / reps * 1e3
         print("%s: %.1f ms / step (loss %.4f); forward GEMM work %.2f TFLOP, step ~3x -> %.1f TFLOP/s; %.0f clip-seconds/s" % (
-            label, ms, float(loss), fwd / 1e12, 3 * fwd / ms / 1e9, N * L / 16000 / (ms * 1e-3)))
+            label, ms, float(loss.detach()), fwd / 1e12, 3 * fwd / ms / 1e9, N * L / 16000 / (ms * 1e-3)))
         return ms
 
     a = timed("native fp32 matrix-core step", 3)
