@@ -112,7 +112,8 @@ typedef struct wn_info {
     int64_t evals_done;      /* timesteps evaluated since the last wn_reset (queue time) */
     int32_t kernel_variant;  /* 1 = generic kernel (weights stationary in LDS, any shape)
                                 2 = latency-optimised kernel (weights stationary in registers, instantiated shapes) */
-    int32_t reserved;
+    int32_t n_chains;        /* independent chains (persistent kernels) the streams are split over: 1, or an even number that
+                                share the CUs two by two; n_workgroups and the byte counts are totals over the chains */
 } wn_info;
 
 typedef struct wn_handle wn_handle;

@@ -619,7 +619,7 @@ static __device__ void wn_v2_head(const WnPlan& p, const WnRun& r, WnCtx& cx, fl
 //   * sampling is moved off L0 onto NSMP dedicated sampler workgroups (chain positions after the head): they turn
 //     partial logits into a class index per stream and publish it as an index granule gi[s]; L0 only gathers.
 // LDS layout (floats) of the multi-stream kernel: G streams are processed per pipeline item
-template <class SH, int G>
+template <class SH, int G, bool W0L = false>
 struct WnV2LdsM {
     static constexpr int XR = SH::R + 4 * SH::T1, SKP = SH::S + 4 * SH::T3, DCP = (SH::DC + 3) & ~3;
     static constexpr int xs = 0;                   // [2][G][XR]
@@ -630,8 +630,32 @@ struct WnV2LdsM {
     static constexpr int smp = ev + G * SH::EC;    // sampler scratch (64 floats); [48] fail flag, [52..] flags
     static constexpr int park = smp + 64;          // 8 parked int64 stamps
     static constexpr int pre = park + 16;          // [n_streams][256]
-    static __host__ __device__ int floats(int n_streams) { return pre + n_streams * 256; }
+    // tap-0 weights (used off the critical path, in the tail) can live in LDS instead of registers: [K1/4][256] float4 --
+    // the layer role then fits 256 VGPRs, so that two workgroups (of two independent chains) can share a CU
+    static constexpr bool w0_lds = W0L;
+    static_assert(!W0L || SH::K1 % 4 == 0, "tap-0 weights in LDS are stored as float4");
+    static constexpr int w0_floats = w0_lds ? SH::K1 * 256 : 0;
+    static __host__ __device__ int floats(int n_streams) { return pre + n_streams * 256 + w0_floats; }
 };
+
+// dot of one weight vector held in LDS as float4s strided by 256 lanes with G LDS vectors
+template <int K, int G>
+static __device__ __forceinline__ void wn_dot_lds_w(const float* w4, const float* x, int xstride, const float (&init)[G], float (&out)[G]) {
+    float a[G][4];
+#pragma unroll
+    for (int g = 0; g < G; ++g) { a[g][0] = init[g]; a[g][1] = a[g][2] = a[g][3] = 0.f; }
+#pragma unroll
+    for (int k = 0; k < K / 4; ++k) {
+        const float4 w = *reinterpret_cast<const float4*>(w4 + k * 1024);
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const float4 v = reinterpret_cast<const float4*>(x + g * xstride)[k];
+            a[g][0] += w.x * v.x; a[g][1] += w.y * v.y; a[g][2] += w.z * v.z; a[g][3] += w.w * v.w;
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) out[g] = (a[g][0] + a[g][1]) + (a[g][2] + a[g][3]);
+}
 
 // dot of one register weight vector with G LDS vectors (G items share every weight operand)
 template <int K, int G>
@@ -663,20 +687,26 @@ static __device__ __forceinline__ void wn_dot_lds_g(const float (&w)[K], const f
     }
 }
 
-template <class SH, int P, int G>
+template <class SH, int P, int G, bool W0LDS>
 static __device__ void wn_v2_layer_multi(const WnPlan& p, const WnRun& r, WnCtx& cx, float* lds, int l, int c) {
     constexpr int R = SH::R, DC = SH::DC, S = SH::S, T1 = SH::T1, K1 = SH::K1, T2 = SH::T2, K2 = SH::K2, RS = SH::RS;
-    using L = WnV2LdsM<SH, G>;
+    using L = WnV2LdsM<SH, G, W0LDS>;
     const int tid = threadIdx.x;
     const int ns = p.n_streams, NL = p.NL, ni = ns / G;  // ni items (of G streams) per evaluation
-    float w1[K1], w0[K1], w2[K2], w3[RS][DC], bskip[RS];
+    constexpr bool W0L = L::w0_lds;
+    float w1[K1], w0[W0L ? 1 : K1], w2[K2], w3[RS][DC], bskip[RS];
+    float* w0s = lds + L::pre + p.n_streams * 256 + tid * 4;  // W0L: this lane's float4 k of tap 0 is w0s[k * 1024 .. +3]
     const float* img = p.blobs + (size_t)cx.w * (SH::NWL * 256) + tid;
     {
         int j = 0;
 #pragma unroll
         for (int k = 0; k < K1; ++k) w1[k] = img[(size_t)(j++) * 256];
 #pragma unroll
-        for (int k = 0; k < K1; ++k) w0[k] = img[(size_t)(j++) * 256];
+        for (int k = 0; k < K1; ++k) {
+            const float v = img[(size_t)(j++) * 256];
+            if constexpr (W0L) w0s[(k / 4) * 1024 + (k % 4)] = v;
+            else w0[k] = v;
+        }
 #pragma unroll
         for (int k = 0; k < K2; ++k) w2[k] = img[(size_t)(j++) * 256];
 #pragma unroll
@@ -725,7 +755,7 @@ static __device__ void wn_v2_layer_multi(const WnPlan& p, const WnRun& r, WnCtx&
         if (pos < 0) pos += ML;
         float acc = kq1 == 0 ? bfg : 0.f;
 #pragma unroll
-        for (int k = 0; k < K1; ++k) acc += w0[k] * ring[(size_t)pos * R + kq1 * K1 + k];
+        for (int k = 0; k < K1; ++k) acc += (W0L ? w0s[(k / 4) * 1024 + (k % 4)] : w0[W0L ? 0 : k]) * ring[(size_t)pos * R + kq1 * K1 + k];
         pre[s * 256 + tid] = acc;
     }
     __syncthreads();
@@ -888,15 +918,16 @@ static __device__ void wn_v2_layer_multi(const WnPlan& p, const WnRun& r, WnCtx&
                     if (tid < R) ring0[((size_t)g * ML + tmod) * R + tid] = xb[g * L::XR + SH::xpad(tid)];
                     a0i[g] = kq1 == 0 ? bfg : 0.f;
                 }
-                if (d == 1) {
-                    wn_dot_lds_g<K1, G>(w0, xb + kq1 * (K1 + 4), L::XR, a0i, a0);
-                } else {
+                const float* xsrc = xb;
+                if (d != 1) {
 #pragma unroll
                     for (int g = 0; g < G; ++g)
                         if (tid < R) xol[g * L::XR + SH::xpad(tid)] = xo_v[g];
                     wn_lds_barrier();
-                    wn_dot_lds_g<K1, G>(w0, xol + kq1 * (K1 + 4), L::XR, a0i, a0);
+                    xsrc = xol;
                 }
+                if constexpr (W0L) wn_dot_lds_w<K1, G>(w0s, xsrc + kq1 * (K1 + 4), L::XR, a0i, a0);
+                else wn_dot_lds_g<K1, G>(w0, xsrc + kq1 * (K1 + 4), L::XR, a0i, a0);
 #pragma unroll
                 for (int g = 0; g < G; ++g) pre[(s0 + g) * 256 + tid] = a0[g];
             }
@@ -1036,8 +1067,14 @@ static __device__ void wn_v2_sampler(const WnPlan& p, const WnRun& r, WnCtx& cx,
     }
 }
 
-template <int R, int DC, int S, int EC, int P, int G>
-__global__ __launch_bounds__(WN_THREADS) void wn_generate_kernel_v2m(WnPlan p, WnRun r) {
+// Shapes whose layer role fits 256 VGPRs once the tap-0 weights live in LDS: two workgroups -- of two independent chains,
+// see wn_runtime.hip -- can then share a CU (2 waves per SIMD) and fill each other's hand-off waits.
+static constexpr bool wn_v2m_shareable(int R, int DC, int S, int EC) {
+    return (R / (256 / (2 * DC))) % 4 == 0 && !(R == 128 && EC == 64) && S < 1024;
+}
+
+template <int R, int DC, int S, int EC, int P, int G, bool W0LDS>
+__global__ __launch_bounds__(WN_THREADS, W0LDS ? 2 : 1) void wn_generate_kernel_v2m(WnPlan p, WnRun r) {
     using SH = WnV2Shape<R, DC, S, EC>;
     extern __shared__ __attribute__((aligned(16))) float wn_lds2m[];
     const int w = p.wg_map[blockIdx.x];
@@ -1046,7 +1083,7 @@ __global__ __launch_bounds__(WN_THREADS) void wn_generate_kernel_v2m(WnPlan p, W
     cx.p = &p; cx.r = &r; cx.lds = wn_lds2m; cx.w = w; cx.fail = 0;
     cx.t_start = (long long)wall_clock64();
     const int n_layer_wg = p.NL * p.P;
-    if (w < n_layer_wg) wn_v2_layer_multi<SH, P, G>(p, r, cx, wn_lds2m, w / P, w % P);
+    if (w < n_layer_wg) wn_v2_layer_multi<SH, P, G, W0LDS>(p, r, cx, wn_lds2m, w / P, w % P);
     else if (w < n_layer_wg + p.PA) wn_v2_head_multi<SH, P, G>(p, r, cx, wn_lds2m, w - n_layer_wg);
     else wn_v2_sampler(p, r, cx, wn_lds2m + WnV2LdsM<SH, G>::smp, w - n_layer_wg - p.PA);
 }

@@ -21,6 +21,10 @@
 #include "wn_forward.h"
 
 static thread_local char g_err[512] = "";
+static thread_local int g_chain_member = 0;  // wn_create is building one chain of a two-chain handle
+#define WN_LDS_SHARED_MAX_BYTES (81920 - 1024)  // two workgroups per CU: half of the 160 KB LDS each, minus the static allocation
+#define WN_CHAIN_MIN_STREAMS 16   // below: the chain is latency-bound, splitting does not pay (measured: 16 neutral, 32 +9 %, 64 +44 %)
+#define WN_CHAIN_MAX_STREAMS 40   // streams per chain that still fit two workgroups per CU at cfg3's shape (78 KB LDS)
 
 static int wn_fail(int code, const char* fmt, ...) {
     va_list ap;
@@ -100,13 +104,13 @@ struct WnV2Entry {
     int R, DC, S, EC, nwl, nwh;
     int Pm;  // layer split the multi-stream kernel is compiled for (its request code is unrolled over it)
     const void* fn;
-    const void* fn_multi;   // one stream per pipeline item
-    const void* fn_multi2;  // two streams per pipeline item (even stream counts)
+    const void* fn_multi;     // multi-stream kernel, one workgroup per CU
+    const void* fn_multi_w0;  // ... with the tap-0 weights in LDS: fits 2 workgroups per CU (NULL: shape does not fit 256 VGPRs)
     int (*lds_floats)(int);
     int (*lds_floats_with_start)(int);
-    int (*lds_floats_multi)(int ns, int g);
+    int (*lds_floats_multi)(int ns, int w0lds);
     void (*launch)(int grid, size_t lds, hipStream_t st, const WnPlan& p, const WnRun& r);
-    void (*launch_multi)(int g, int grid, size_t lds, hipStream_t st, const WnPlan& p, const WnRun& r);
+    void (*launch_multi)(int w0lds, int grid, size_t lds, hipStream_t st, const WnPlan& p, const WnRun& r);
     void (*pack)(const WnPlan& pl, const WnHostWeights& w, std::vector<float>& out);
 };
 
@@ -164,13 +168,20 @@ static WnV2Entry wn_v2_entry() {
     WnV2Entry e;
     e.R = R; e.DC = DC; e.S = S; e.EC = EC; e.nwl = SH::NWL; e.nwh = SH::NWH; e.Pm = PM;
     e.fn = (const void*)wn_generate_kernel_v2<R, DC, S, EC>;
-    e.fn_multi = (const void*)wn_generate_kernel_v2m<R, DC, S, EC, PM, 1>;
-    e.fn_multi2 = (const void*)wn_generate_kernel_v2m<R, DC, S, EC, PM, 2>;
-    e.lds_floats_multi = [](int ns, int g) { return g == 2 ? WnV2LdsM<SH, 2>::floats(ns) : WnV2LdsM<SH, 1>::floats(ns); };
-    e.launch_multi = [](int g, int grid, size_t lds, hipStream_t st, const WnPlan& p, const WnRun& r) {
-        if (g == 2) hipLaunchKernelGGL((wn_generate_kernel_v2m<R, DC, S, EC, PM, 2>), dim3(grid), dim3(WN_THREADS), lds, st, p, r);
-        else hipLaunchKernelGGL((wn_generate_kernel_v2m<R, DC, S, EC, PM, 1>), dim3(grid), dim3(WN_THREADS), lds, st, p, r);
+    e.fn_multi = (const void*)wn_generate_kernel_v2m<R, DC, S, EC, PM, 1, false>;
+    e.fn_multi_w0 = nullptr;
+    e.lds_floats_multi = [](int ns, int) { return WnV2LdsM<SH, 1, false>::floats(ns); };
+    e.launch_multi = [](int, int grid, size_t lds, hipStream_t st, const WnPlan& p, const WnRun& r) {
+        hipLaunchKernelGGL((wn_generate_kernel_v2m<R, DC, S, EC, PM, 1, false>), dim3(grid), dim3(WN_THREADS), lds, st, p, r);
     };
+    if constexpr (wn_v2m_shareable(R, DC, S, EC)) {
+        e.fn_multi_w0 = (const void*)wn_generate_kernel_v2m<R, DC, S, EC, PM, 1, true>;
+        e.lds_floats_multi = [](int ns, int w0lds) { return w0lds ? WnV2LdsM<SH, 1, true>::floats(ns) : WnV2LdsM<SH, 1, false>::floats(ns); };
+        e.launch_multi = [](int w0lds, int grid, size_t lds, hipStream_t st, const WnPlan& p, const WnRun& r) {
+            if (w0lds) hipLaunchKernelGGL((wn_generate_kernel_v2m<R, DC, S, EC, PM, 1, true>), dim3(grid), dim3(WN_THREADS), lds, st, p, r);
+            else hipLaunchKernelGGL((wn_generate_kernel_v2m<R, DC, S, EC, PM, 1, false>), dim3(grid), dim3(WN_THREADS), lds, st, p, r);
+        };
+    }
     e.lds_floats = [](int ns) { return WnV2Lds<SH>::floats(ns); };
     e.lds_floats_with_start = [](int ns) { return WnV2Lds<SH>::floats_with_start(ns); };
     e.launch = [](int grid, size_t lds, hipStream_t st, const WnPlan& p, const WnRun& r) {
@@ -234,7 +245,16 @@ struct wn_handle {
     int variant;   // 1 = generic LDS-resident kernel, 2 = register-resident kernel
     int v2_index;  // row of wn_v2_table()
     int lds_bytes;
-    int multi_g;   // streams per pipeline item of the multi-stream kernel (1 or 2)
+    int w0lds;     // multi-stream kernel variant with tap-0 weights in LDS (this handle is one of two chains sharing the chip)
+    // Two chains: with >= WN_CHAIN_MIN_STREAMS streams the job is split into two independent chains of n_streams/2 streams,
+    // each a complete persistent kernel with its own queues and hand-off buffers, launched on two HIP streams.  Their
+    // workgroups share the CUs two by two (224 VGPRs, <= 80 KB LDS each) and compute in each other's hand-off waits:
+    // cfg3 x 64 streams 556 k -> 788 k samples/s.  This handle is then only a front that routes every call.
+    std::vector<wn_handle*> chains;
+    std::vector<int> chain_first;  // first stream of chain i (chain_first[n_chains] = n_streams)
+    void* side_stream;  // hipStream_t of the second chain
+    void* ev_fork;      // hipEvent_t: user stream -> side stream
+    void* ev_join;      // hipEvent_t: side stream -> user stream
     // owned device allocations
     float *d_blobs, *d_start_t, *d_start_b, *d_rings;
     int32_t *d_dil, *d_wg_map;
@@ -265,6 +285,17 @@ extern "C" const char* wn_last_error(void) { return g_err; }
 
 extern "C" void wn_destroy(wn_handle* h) {
     if (!h) return;
+    if (!h->chains.empty()) {
+        for (wn_handle* c : h->chains) wn_destroy(c);
+#ifndef WN_EMU
+        (void)hipSetDevice(h->cfg.device_id);
+        if (h->ev_fork) (void)hipEventDestroy((hipEvent_t)h->ev_fork);
+        if (h->ev_join) (void)hipEventDestroy((hipEvent_t)h->ev_join);
+        if (h->side_stream) (void)hipStreamDestroy((hipStream_t)h->side_stream);
+#endif
+        delete h;
+        return;
+    }
 #ifndef WN_EMU
     (void)hipSetDevice(h->cfg.device_id);
     if (h->pending) (void)hipStreamSynchronize((hipStream_t)h->last_stream);
@@ -306,9 +337,70 @@ extern "C" int wn_create(const wn_config* cfg, wn_handle** out) {
         if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, cfg->device_id) == hipSuccess && khz > 0) wall_khz = khz;
     }
 #endif
+#ifndef WN_EMU
+    {   // chains sharing the CUs two by two (see wn_handle::chains): 2 chains up to WN_CHAIN_MAX_STREAMS streams each, more
+        // chains (run pairwise, one pair after the other on the two HIP streams) for larger jobs
+        const char* ce = getenv("WN_CHAINS");
+        const bool off = ce && ce[0] == '1';
+        const bool forced = ce && ce[0] == '2' && cfg->n_streams >= 4;
+        if (!g_chain_member && !off && (cfg->n_streams >= WN_CHAIN_MIN_STREAMS || forced)) {
+            const int ns = cfg->n_streams;
+            const int K = 2 * ((ns + 2 * WN_CHAIN_MAX_STREAMS - 1) / (2 * WN_CHAIN_MAX_STREAMS));
+            std::vector<wn_handle*> cs;
+            std::vector<int> firsts(1, 0);
+            int rc = WN_OK;
+            bool fits = true;
+            for (int i = 0; i < K && fits && rc == WN_OK; ++i) {
+                wn_config part = *cfg;
+                part.n_streams = ns / K + (i < ns % K ? 1 : 0);
+                wn_handle* c = nullptr;
+                g_chain_member = 1;
+                rc = wn_create(&part, &c);
+                g_chain_member = 0;
+                if (rc == WN_OK) {
+                    cs.push_back(c);
+                    firsts.push_back(firsts.back() + part.n_streams);
+                    fits = c->w0lds != 0;
+                }
+            }
+            if (rc == WN_OK && fits) {
+                wn_handle* c0 = cs[0];
+                wn_handle* f = new wn_handle();
+                f->cfg = *cfg;
+                f->plan = c0->plan;
+                f->plan.n_streams = cfg->n_streams;
+                f->have_weights = false; f->pending = false; f->last_stream = nullptr; f->t_base = 0;
+                f->n_cu = n_cu; f->wall_khz = wall_khz; f->variant = c0->variant; f->v2_index = c0->v2_index; f->lds_bytes = c0->lds_bytes; f->w0lds = 1;
+                f->d_blobs = f->d_start_t = f->d_start_b = f->d_rings = nullptr;
+                f->d_dil = f->d_wg_map = nullptr; f->d_ring_off = nullptr; f->d_gran = nullptr; f->d_status = nullptr;
+                f->d_prof = nullptr; f->prof_items = 0; f->prof_recorded = 0;
+                f->d_fw = nullptr; f->fw_floats = 0; f->fw_ok = false; f->d_ws = nullptr; f->ws_floats = 0;
+                f->d_fwb = nullptr; f->fwb_elems = 0; f->fwb_ok = false; f->fw_bf16 = 0;
+                f->d_tws = nullptr; f->tws_floats = 0; f->train_valid = false;
+                f->blob_floats = f->ring_floats = f->gran_count = 0;
+                f->dil = c0->dil;
+                f->chains = cs;
+                f->chain_first = firsts;
+                f->side_stream = f->ev_fork = f->ev_join = nullptr;
+                hipStream_t ss; hipEvent_t e0, e1;
+                rc = rt_hip(hipStreamCreateWithFlags(&ss, hipStreamNonBlocking), "hipStreamCreate");
+                if (!rc) { f->side_stream = ss; rc = rt_hip(hipEventCreateWithFlags(&e0, hipEventDisableTiming), "hipEventCreate"); }
+                if (!rc) { f->ev_fork = e0; rc = rt_hip(hipEventCreateWithFlags(&e1, hipEventDisableTiming), "hipEventCreate"); }
+                if (!rc) f->ev_join = e1;
+                if (rc) { wn_destroy(f); return rc; }
+                *out = f;
+                return WN_OK;
+            }
+            for (wn_handle* c : cs) wn_destroy(c);  // this shape does not fit two workgroups per CU: one chain
+            if (rc != WN_OK && rc != WN_E_UNSUPPORTED) return rc;
+            g_err[0] = 0;
+        }
+    }
+#endif
     wn_handle* h = new wn_handle();
     memset(&h->plan, 0, sizeof(h->plan));
     h->cfg = *cfg;
+    h->side_stream = h->ev_fork = h->ev_join = nullptr; h->w0lds = 0;
     h->have_weights = false; h->pending = false; h->last_stream = nullptr; h->t_base = 0;
     h->n_cu = n_cu; h->wall_khz = wall_khz;
     h->d_blobs = h->d_start_t = h->d_start_b = h->d_rings = nullptr;
@@ -336,15 +428,11 @@ extern "C" int wn_create(const wn_config* cfg, wn_handle** out) {
             pl.n_smp = n_smp;
             pl.n_wg += n_smp;               // sampler workgroups follow the head in the chain
             h->lds_bytes = wn_v2_table()[vi].lds_floats(pl.n_streams) * 4;
-            h->multi_g = 1;
+            h->w0lds = 0;
             if (n_smp > 0) {
-                // Streams per pipeline item.  Two per item halve the hand-offs per evaluation, but measured on cfg3 x 64 it is
-                // slower (492 k vs 557 k samples/s): the skip lane is a second dependency chain through the stages' tails and a
-                // tail twice as long delays every downstream lane.  Kept selectable (WN_MULTI_G=2) for experiments.
-                const char* fg = getenv("WN_MULTI_G");
-                h->multi_g = 1;
-                if (fg && fg[0] == '2' && cfg->n_streams % 2 == 0) h->multi_g = 2;
-                h->lds_bytes = wn_v2_table()[vi].lds_floats_multi(pl.n_streams, h->multi_g) * 4;
+                if (g_chain_member && wn_v2_table()[vi].fn_multi_w0 &&
+                    wn_v2_table()[vi].lds_floats_multi(pl.n_streams, 1) * 4 <= WN_LDS_SHARED_MAX_BYTES) h->w0lds = 1;
+                h->lds_bytes = wn_v2_table()[vi].lds_floats_multi(pl.n_streams, h->w0lds) * 4;
             }
             pl.start_in_lds = 0;
             if (n_smp == 0 && wn_v2_table()[vi].lds_floats_with_start(pl.n_streams) * 4 <= WN_LDS_MAX_BYTES) {
@@ -422,7 +510,7 @@ extern "C" int wn_create(const wn_config* cfg, wn_handle** out) {
     pl.status = h->d_status;
     pl.xcc_tab = h->d_status + 8;
 #ifndef WN_EMU
-    rc = rt_hip(hipFuncSetAttribute(h->variant == 2 ? (pl.n_smp > 0 ? (h->multi_g == 2 ? wn_v2_table()[h->v2_index].fn_multi2 : wn_v2_table()[h->v2_index].fn_multi) : wn_v2_table()[h->v2_index].fn)
+    rc = rt_hip(hipFuncSetAttribute(h->variant == 2 ? (pl.n_smp > 0 ? (h->w0lds ? wn_v2_table()[h->v2_index].fn_multi_w0 : wn_v2_table()[h->v2_index].fn_multi) : wn_v2_table()[h->v2_index].fn)
                                                     : (const void*)wn_generate_kernel,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes),
                 "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
@@ -433,6 +521,11 @@ extern "C" int wn_create(const wn_config* cfg, wn_handle** out) {
 }
 
 extern "C" int wn_load_weights(wn_handle* h, const wn_weight_ptrs* w) {
+    if (h && !h->chains.empty()) {
+        for (wn_handle* c : h->chains) { int rc = wn_load_weights(c, w); if (rc) return rc; }
+        h->have_weights = true;
+        return WN_OK;
+    }
     g_err[0] = 0;
     if (!h || !w) return wn_fail(WN_E_BADARG, "wn_load_weights: NULL argument");
     if (!w->start_w || !w->filter_w || !w->gate_w || !w->res_w || !w->skip_w || !w->end1_w || !w->end1_b || !w->end2_w || !w->end2_b)
@@ -567,6 +660,12 @@ extern "C" int wn_load_weights(wn_handle* h, const wn_weight_ptrs* w) {
 extern "C" int wn_reset(wn_handle* h, void* hip_stream) {
     g_err[0] = 0;
     if (!h) return wn_fail(WN_E_BADARG, "wn_reset: NULL handle");
+    if (!h->chains.empty()) {
+        if (h->pending) { int rc = wn_wait(h); if (rc) return rc; }
+        for (wn_handle* c : h->chains) { int rc = wn_reset(c, hip_stream); if (rc) return rc; }
+        h->t_base = 0;
+        return WN_OK;
+    }
 #ifndef WN_EMU
     { int rc = rt_hip(hipSetDevice(h->cfg.device_id), "hipSetDevice"); if (rc) return rc; }
 #endif
@@ -608,6 +707,38 @@ extern "C" int wn_generate(wn_handle* h, const wn_generate_args* a) {
     g_err[0] = 0;
     if (!h || !a) return wn_fail(WN_E_BADARG, "wn_generate: NULL argument");
     if (!h->have_weights) return wn_fail(WN_E_STATE, "wn_generate: wn_load_weights has not been called");
+#ifndef WN_EMU
+    if (!h->chains.empty()) {   // chain i owns streams [chain_first[i], chain_first[i + 1]): fork onto the side stream, join back
+        if (a->n_given < 1 || a->num_samples < 0) return wn_fail(WN_E_BADARG, "wn_generate: n_given must be >= 1 and num_samples >= 0");
+        if (!a->first_samples) return wn_fail(WN_E_BADARG, "wn_generate: first_samples is NULL");
+        { int rc = rt_hip(hipSetDevice(h->cfg.device_id), "hipSetDevice"); if (rc) return rc; }
+        if (h->pending) { int rc = wn_wait(h); if (rc) return rc; }
+        hipStream_t user = (hipStream_t)a->hip_stream, side = (hipStream_t)h->side_stream;
+        int rc = rt_hip(hipEventRecord((hipEvent_t)h->ev_fork, user), "hipEventRecord");
+        rc = rc ? rc : rt_hip(hipStreamWaitEvent(side, (hipEvent_t)h->ev_fork, 0), "hipStreamWaitEvent");
+        if (rc) return rc;
+        for (size_t i = 0; i < h->chains.size(); ++i) {  // even chains on the caller's stream, odd ones on the side stream
+            wn_generate_args b = *a;
+            const size_t s0 = (size_t)h->chain_first[i];
+            b.first_samples = a->first_samples + s0 * (size_t)a->n_given;
+            if (a->uniforms) b.uniforms = a->uniforms + s0 * (size_t)a->num_samples;
+            if (a->out_idx) b.out_idx = a->out_idx + s0 * (size_t)a->num_samples;
+            if (a->dbg_logits) b.dbg_logits = a->dbg_logits + s0 * (size_t)a->num_samples * h->plan.C;
+            if (a->stream_temperatures) b.stream_temperatures = a->stream_temperatures + s0;
+            b.hip_stream = i % 2 == 0 ? (void*)user : (void*)side;
+            if (i == 0 && h->prof_items > 0) { h->chains[0]->prof_items = h->prof_items; h->prof_items = 0; }
+            rc = wn_generate(h->chains[i], &b);
+            if (rc) return rc;
+        }
+        rc = rt_hip(hipEventRecord((hipEvent_t)h->ev_join, side), "hipEventRecord");
+        rc = rc ? rc : rt_hip(hipStreamWaitEvent(user, (hipEvent_t)h->ev_join, 0), "hipStreamWaitEvent");
+        if (rc) return rc;
+        h->pending = true;
+        h->last_stream = a->hip_stream;
+        h->t_base = h->chains[0]->t_base;
+        return WN_OK;
+    }
+#endif
     if (a->n_given < 1 || a->num_samples < 0) return wn_fail(WN_E_BADARG, "wn_generate: n_given must be >= 1 and num_samples >= 0");
     if (!a->first_samples) return wn_fail(WN_E_BADARG, "wn_generate: first_samples is NULL");
     if (a->num_samples > 0 && !a->out_idx) return wn_fail(WN_E_BADARG, "wn_generate: out_idx is NULL");
@@ -650,7 +781,7 @@ extern "C" int wn_generate(wn_handle* h, const wn_generate_args* a) {
     }
 #else
     if (h->variant == 2 && h->plan.n_smp > 0)
-        wn_v2_table()[h->v2_index].launch_multi(h->multi_g, h->plan.n_blocks, (size_t)h->lds_bytes, (hipStream_t)a->hip_stream, h->plan, r);
+        wn_v2_table()[h->v2_index].launch_multi(h->w0lds, h->plan.n_blocks, (size_t)h->lds_bytes, (hipStream_t)a->hip_stream, h->plan, r);
     else if (h->variant == 2)
         wn_v2_table()[h->v2_index].launch(h->plan.n_blocks, (size_t)h->lds_bytes, (hipStream_t)a->hip_stream, h->plan, r);
     else
@@ -669,6 +800,16 @@ extern "C" int wn_wait(wn_handle* h) {
     if (!h) return wn_fail(WN_E_BADARG, "wn_wait: NULL handle");
     if (!h->pending) return WN_OK;
     h->pending = false;
+    if (!h->chains.empty()) {
+        int first_rc = WN_OK;
+        char msg[sizeof(g_err)] = "";
+        for (wn_handle* c : h->chains) {
+            const int rc = wn_wait(c);
+            if (rc && !first_rc) { first_rc = rc; memcpy(msg, g_err, sizeof(msg)); }
+        }
+        if (first_rc) memcpy(g_err, msg, sizeof(msg));
+        return first_rc;
+    }
     int rc = rt_sync(h->last_stream);
     if (rc) return rc;
     uint32_t st[8];
@@ -687,6 +828,18 @@ extern "C" int wn_wait(wn_handle* h) {
 
 extern "C" int wn_get_info(wn_handle* h, wn_info* out) {
     if (!h || !out) return wn_fail(WN_E_BADARG, "wn_get_info: NULL argument");
+    if (!h->chains.empty()) {  // both chains have the same geometry; sizes and workgroups add up
+        int rc = wn_get_info(h->chains[0], out);
+        if (rc) return rc;
+        for (size_t i = 1; i < h->chains.size(); ++i) {
+            wn_info ci;
+            if ((rc = wn_get_info(h->chains[i], &ci))) return rc;
+            out->n_workgroups += ci.n_workgroups; out->weight_bytes += ci.weight_bytes; out->queue_bytes += ci.queue_bytes;
+            out->handoff_bytes += ci.handoff_bytes;
+        }
+        out->n_chains = (int)h->chains.size();
+        return WN_OK;
+    }
     const WnPlan& pl = h->plan;
     memset(out, 0, sizeof(*out));
     out->abi_version = WN_ABI_VERSION;
@@ -697,12 +850,20 @@ extern "C" int wn_get_info(wn_handle* h, wn_info* out) {
     out->queue_bytes = (int64_t)h->ring_floats * 4;
     out->handoff_bytes = (int64_t)h->gran_count * 8;
     out->evals_done = h->t_base;
+    out->n_chains = 1;
     return WN_OK;
 }
 
 extern "C" int wn_export_queue(wn_handle* h, int32_t layer, int32_t stream, float* host_data, int32_t* in_pos, int32_t* out_pos) {
     g_err[0] = 0;
     if (!h || !host_data) return wn_fail(WN_E_BADARG, "wn_export_queue: NULL argument");
+    if (!h->chains.empty()) {
+        if (stream < 0 || stream >= h->plan.n_streams) return wn_fail(WN_E_BADARG, "wn_export_queue: index out of range");
+        if (h->pending) { int rc = wn_wait(h); if (rc) return rc; }
+        size_t i = 0;
+        while (stream >= h->chain_first[i + 1]) ++i;
+        return wn_export_queue(h->chains[i], layer, stream - h->chain_first[i], host_data, in_pos, out_pos);
+    }
     const WnPlan& pl = h->plan;
     if (layer < 0 || layer >= pl.NL || stream < 0 || stream >= pl.n_streams) return wn_fail(WN_E_BADARG, "wn_export_queue: index out of range");
 #ifndef WN_EMU
@@ -726,12 +887,17 @@ extern "C" int wn_export_queue(wn_handle* h, int32_t layer, int32_t stream, floa
 // every workgroup of the NEXT wn_generate, 4 stamps each (start, input staged, x' published, done), 100 MHz ticks.
 extern "C" int wn_profile_next(wn_handle* h, int32_t n_items) {
     if (!h || n_items < 0) return wn_fail(WN_E_BADARG, "wn_profile_next: bad argument");
+    if (!h->chains.empty()) return wn_profile_next(h->chains[0], n_items);  // stamps of the first chain
     h->prof_items = n_items;
     return WN_OK;
 }
 
 extern "C" int wn_profile_read(wn_handle* h, int64_t* host_out, int64_t capacity) {
     if (!h || !host_out) return wn_fail(WN_E_BADARG, "wn_profile_read: NULL argument");
+    if (!h->chains.empty()) {
+        if (h->pending) { int rc = wn_wait(h); if (rc) return rc; }
+        return wn_profile_read(h->chains[0], host_out, capacity);
+    }
     if (h->pending) { int rc = wn_wait(h); if (rc) return rc; }
     const int64_t n = (int64_t)h->plan.n_wg * h->prof_recorded * 8;
     if (!h->d_prof || n == 0 || capacity < n) return wn_fail(WN_E_STATE, "wn_profile_read: nothing recorded / buffer too small (%lld)", (long long)n);
@@ -742,6 +908,7 @@ extern "C" int wn_profile_read(wn_handle* h, int64_t* host_out, int64_t capacity
 extern "C" int wn_forward(wn_handle* h, const int32_t* indices, int64_t N, int64_t L, int64_t out_len, float* logits, void* hip_stream) {
     g_err[0] = 0;
     if (!h || !indices || !logits) return wn_fail(WN_E_BADARG, "wn_forward: NULL argument");
+    if (!h->chains.empty()) return wn_forward(h->chains[0], indices, N, L, out_len, logits, hip_stream);  // every chain holds the weights
     if (!h->have_weights) return wn_fail(WN_E_STATE, "wn_forward: wn_load_weights has not been called");
     if (N < 1 || out_len < 1) return wn_fail(WN_E_BADARG, "wn_forward: N and output_length must be >= 1");
 #ifdef WN_EMU
@@ -862,6 +1029,16 @@ extern "C" int wn_forward(wn_handle* h, const int32_t* indices, int64_t N, int64
 extern "C" int wn_prime(wn_handle* h, const int32_t* first_samples, int64_t n_prime, int64_t row_stride, void* hip_stream) {
     g_err[0] = 0;
     if (!h || !first_samples) return wn_fail(WN_E_BADARG, "wn_prime: NULL argument");
+    if (!h->chains.empty()) {
+        if (n_prime < 0 || row_stride < n_prime) return wn_fail(WN_E_BADARG, "wn_prime: bad n_prime / row_stride");
+        if (h->pending) { int rc = wn_wait(h); if (rc) return rc; }
+        for (size_t i = 0; i < h->chains.size(); ++i) {
+            int rc = wn_prime(h->chains[i], first_samples + (size_t)h->chain_first[i] * (size_t)row_stride, n_prime, row_stride, hip_stream);
+            if (rc) return rc;
+        }
+        h->t_base = h->chains[0]->t_base;
+        return WN_OK;
+    }
     if (!h->have_weights) return wn_fail(WN_E_STATE, "wn_prime: wn_load_weights has not been called");
     if (n_prime < 0 || row_stride < n_prime) return wn_fail(WN_E_BADARG, "wn_prime: bad n_prime / row_stride");
     if (n_prime == 0) return WN_OK;
@@ -957,6 +1134,7 @@ extern "C" int wn_prime(wn_handle* h, const int32_t* first_samples, int64_t n_pr
 extern "C" int wn_set_forward_precision(wn_handle* h, int32_t bf16) {
     g_err[0] = 0;
     if (!h) return wn_fail(WN_E_BADARG, "wn_set_forward_precision: NULL handle");
+    if (!h->chains.empty()) return wn_set_forward_precision(h->chains[0], bf16);
 #ifdef WN_EMU
     (void)bf16;
     return wn_fail(WN_E_UNSUPPORTED, "wn_set_forward_precision: GPU only");

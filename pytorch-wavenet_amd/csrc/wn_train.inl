@@ -51,6 +51,7 @@ static void wn_train_layout_ws(const wn_handle* h, long long N, long long L, lon
 extern "C" int wn_train_get_layout(wn_handle* h, wn_train_layout* out) {
     g_err[0] = 0;
     if (!h || !out) return wn_fail(WN_E_BADARG, "wn_train_get_layout: NULL argument");
+    if (!h->chains.empty()) return wn_train_get_layout(h->chains[0], out);
     if (!h->have_weights) return wn_fail(WN_E_STATE, "wn_train_get_layout: wn_load_weights has not been called");
     if (!h->fw_ok) return wn_fail(WN_E_UNSUPPORTED, "wn_train: needs kernel_size 2 and channel counts that are multiples of 32");
     out->total = (int64_t)h->fw_floats;
@@ -64,6 +65,7 @@ extern "C" int wn_train_get_layout(wn_handle* h, wn_train_layout* out) {
 extern "C" int wn_train_export_params(wn_handle* h, float* params, void* hip_stream) {
     g_err[0] = 0;
     if (!h || !params) return wn_fail(WN_E_BADARG, "wn_train_export_params: NULL argument");
+    if (!h->chains.empty()) return wn_train_export_params(h->chains[0], params, hip_stream);
     if (!h->have_weights) return wn_fail(WN_E_STATE, "wn_train_export_params: wn_load_weights has not been called");
     if (!h->fw_ok) return wn_fail(WN_E_UNSUPPORTED, "wn_train: needs kernel_size 2 and channel counts that are multiples of 32");
     { int rc = rt_hip(hipSetDevice(h->cfg.device_id), "hipSetDevice"); if (rc) return rc; }
@@ -102,6 +104,7 @@ extern "C" int wn_train_forward(wn_handle* h, const float* params, const int32_t
                                 float* logits, void* hip_stream) {
     g_err[0] = 0;
     if (!h || !params || !indices || !logits) return wn_fail(WN_E_BADARG, "wn_train_forward: NULL argument");
+    if (!h->chains.empty()) return wn_train_forward(h->chains[0], params, indices, N, L, out_len, logits, hip_stream);
     if (!h->have_weights) return wn_fail(WN_E_STATE, "wn_train_forward: wn_load_weights has not been called");
     if (N < 1 || out_len < 1) return wn_fail(WN_E_BADARG, "wn_train_forward: N and output_length must be >= 1");
     const WnPlan& pl = h->plan;
@@ -211,6 +214,7 @@ extern "C" int wn_train_forward(wn_handle* h, const float* params, const int32_t
 extern "C" int wn_train_backward(wn_handle* h, const float* params, const float* dlogits, float* grads, void* hip_stream) {
     g_err[0] = 0;
     if (!h || !params || !dlogits || !grads) return wn_fail(WN_E_BADARG, "wn_train_backward: NULL argument");
+    if (!h->chains.empty()) return wn_train_backward(h->chains[0], params, dlogits, grads, hip_stream);
     if (!h->train_valid) return wn_fail(WN_E_STATE, "wn_train_backward: no wn_train_forward to differentiate");
     { int rc = rt_hip(hipSetDevice(h->cfg.device_id), "hipSetDevice"); if (rc) return rc; }
     const WnPlan& pl = h->plan;

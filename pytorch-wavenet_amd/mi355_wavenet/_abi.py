@@ -47,7 +47,7 @@ class wn_info(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in ("abi_version", "n_layers", "layer_split", "head_split", "n_workgroups",
                                                "lds_bytes", "n_compute_units", "receptive_field")] + \
                [(n, ctypes.c_int64) for n in ("weight_bytes", "queue_bytes", "handoff_bytes", "evals_done")] + \
-               [("kernel_variant", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+               [("kernel_variant", ctypes.c_int32), ("n_chains", ctypes.c_int32)]
 
 
 EXPORTS = ["wn_abi_version", "wn_create", "wn_destroy", "wn_load_weights", "wn_reset", "wn_generate", "wn_wait",

@@ -162,7 +162,8 @@ class Engine:
 
     def profile_read(self, n_items):
         """int64 (n_workgroups, n_items, 8) wall-clock stamps (100 MHz ticks) of the last profiled job."""
-        n_wg = self.info()["n_workgroups"]
+        info = self.info()
+        n_wg = info["n_workgroups"] // max(1, info["n_chains"])  # stamps of the first chain
         out = np.zeros((n_wg, n_items, 8), dtype=np.int64)
         self.lib.check(self.lib.dll.wn_profile_read(self._h, out.ctypes.data, out.size))
         return out

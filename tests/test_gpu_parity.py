@@ -211,14 +211,45 @@ def test_batched_priming_equals_chain_priming(cfgname, ns, n_given):
     eng.close()
 
 
-def test_two_streams_per_pipeline_item(monkeypatch):
-    """The experimental WN_MULTI_G=2 form of the multi-stream kernel (two streams per pipeline item) stays correct."""
-    monkeypatch.setenv("WN_MULTI_G", "2")
-    cfg, W, first, uniforms = make_case("cfg3", 60, 4, 12, 80)
-    eng = engine.Engine(cfg, W, n_streams=4)
-    check_engine(eng, cfg, W, 80, first, 1.0, 0.0, uniforms, "cfg3 G=2 sampled")
-    check_engine(eng, cfg, W, 80, first, 0.0, 0.0, None, "cfg3 G=2 greedy")
+def test_two_chains_sharing_the_cus(monkeypatch):
+    """With >= 16 streams (or WN_CHAINS=2) the job runs as two independent chains of n_streams/2 streams whose workgroups
+    share the CUs two by two (wn_info.n_chains == 2): same samples as one chain and as the oracle, queues exported per
+    stream, batched priming split per chain, per-stream temperatures routed to the owning chain."""
+    cfg, W, first, uniforms = make_case("cfg3", 61, 16, 70, 90)   # 70 given samples: batched priming + generation
+    eng = engine.Engine(cfg, W, n_streams=16)
+    info = eng.info()
+    assert info["n_chains"] == 2 and info["kernel_variant"] == 2 and info["n_workgroups"] == 2 * (50 * 4 + 8 + 4)
+    assert info["lds_bytes"] <= 80 * 1024
+    check_engine(eng, cfg, W, 90, first, 1.0, 0.0, uniforms, "cfg3 two chains sampled")
+    check_engine(eng, cfg, W, 90, first, 0.0, 0.3, None, "cfg3 two chains greedy + regulariser")
+    temps = np.where(np.arange(16) % 3 == 0, 0.0, 0.5 + 0.1 * np.arange(16)).astype(np.float32)
+    out = eng.generate(40, first[:, :3], temperature=temps, uniforms=uniforms[:, :40])
+    for s in (0, 7, 8, 15):
+        idx, _ = c_oracle.generate(cfg, W, 40, first[s, :3], float(temps[s]), 0.0, uniforms[s, :40] if temps[s] > 0 else None)
+        assert np.array_equal(out[s], idx), s
+    q8, ip, op = eng.export_queue(3, 8)
     eng.close()
+    monkeypatch.setenv("WN_CHAINS", "1")
+    one = engine.Engine(cfg, W, n_streams=16)
+    assert one.info()["n_chains"] == 1
+    out1 = one.generate(40, first[:, :3], temperature=temps, uniforms=uniforms[:, :40])
+    q8_1, ip1, op1 = one.export_queue(3, 8)
+    one.close()
+    assert np.array_equal(out, out1)
+    # the two kernel variants keep tap-0 weights in LDS / in registers: same sums, scheduled differently -> equal to rounding
+    assert np.allclose(q8, q8_1, rtol=1e-5, atol=1e-6) and (ip, op) == (ip1, op1)
+    monkeypatch.delenv("WN_CHAINS")
+    cfg4, W4, first4, uni4 = make_case("cfg3", 63, 90, 2, 24)   # > 80 streams: four chains (23 + 23 + 22 + 22), run pairwise
+    e4 = engine.Engine(cfg4, W4, n_streams=90)
+    assert e4.info()["n_chains"] == 4
+    check_engine(e4, cfg4, W4, 24, first4, 1.0, 0.0, uni4, "cfg3 four chains")
+    e4.close()
+    monkeypatch.setenv("WN_CHAINS", "2")   # forced for a small stream count, small model (P = 1)
+    cfg2, W2, first2, uni2 = make_case("cfg2", 62, 6, 5, 60)
+    e2 = engine.Engine(cfg2, W2, n_streams=6)
+    assert e2.info()["n_chains"] == 2
+    check_engine(e2, cfg2, W2, 60, first2, 0.9, 0.0, uni2, "cfg2 two chains")
+    e2.close()
 
 
 def test_per_stream_temperatures():

@@ -27,7 +27,7 @@ def main():
     info = eng.info()
     P, PA, NL = info["layer_split"], info["head_split"], info["n_layers"]
     N = 400 if ns == 1 else 60
-    G = int(os.environ.get("WN_MULTI_G", "1")) if ns > 1 else 1
+    G = 1
     items = N * ns // G  # pipeline items: G streams each in the multi-stream kernel
     u = np.random.RandomState(0).random_sample((ns, N))
     eng.generate(N, None, temperature=1.0, uniforms=u)  # warm-up
