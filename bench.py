@@ -4,7 +4,8 @@
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg3x64] [--samples 2000]
 
 A "step" is one generate_fast()-shaped job: every stream of the workload generates ``--samples`` audio samples
-(queue reset + ONE persistent kernel launch; temperature 1.0, host-drawn uniforms, inputs resident in HBM).
+(queue reset + ONE wn_generate job = one persistent kernel per chain, the chains running concurrently; temperature 1.0,
+host-drawn uniforms, inputs resident in HBM).
 ``value`` = audio samples/s summed over all streams and all GPUs.  N > 1: one process per GPU (torchrun), streams
 sharded across ranks with no data-path collective; the finished index blocks are gathered to rank 0 over RCCL inside
 the timed region (that is the job's only exchange step).  Prints ONE JSON line on rank 0.
@@ -173,12 +174,14 @@ def main():
                                "temperature 1.0" % (a.workload, ", ".join("%s=%s" % kv for kv in cfg.items()), per_gpu, a.samples),
                    "streams_per_gpu": per_gpu, "samples_per_stream_per_step": a.samples,
                    "per_stream_samples_per_s": round(value / (n_gpus * per_gpu), 1),
-                   "chain": {k: info[k] for k in ("kernel_variant", "layer_split", "head_split", "n_workgroups", "lds_bytes")}},
+                   "chain": {k: info[k] for k in ("kernel_variant", "n_chains", "layer_split", "head_split", "n_workgroups", "lds_bytes")}},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                      "kernel": ("wn_generate_kernel_v2m" if per_gpu > 1 else "wn_generate_kernel_v2") if info["kernel_variant"] == 2 else "wn_generate_kernel", "kernel_ms_per_launch": round(kernel_ms, 3),
                      "algorithmic_bytes_per_launch": int(bytes_per_launch),
-                     "algorithmic_bytes_per_timestep": int(bytes_per_tstep), "launches_per_step": 1},
+                     "algorithmic_bytes_per_timestep": int(bytes_per_tstep), "launches_per_step": 1,
+                     "note": "one launch = one wn_generate job: n_chains persistent kernels running CONCURRENTLY (two per CU), timed "
+                             "together with HIP events on the launch stream; rocprofv3 lists them as n_chains overlapping dispatches"},
     }
     if n_gpus == 1 and not a.no_extra:
         extra = {}
