@@ -79,6 +79,46 @@ def time_workload(cfgname, n_streams, samples, steps, warmup, dist, device):
     return t1 - t0, kernel_ms, info, cfg
 
 
+def train_step_cfg5(device, N=32, L=16000, reps=3):
+    """BASELINE configs[4] (SURVEY.md 8d "cfg5"): one training step -- model(x), F.cross_entropy, backward, Adam -- at
+    layers=10 blocks=5 128/128/512, N one-second 16 kHz clips given as class indices, through the facade's native
+    matrix-core forward + backward.  Reports step time and executed TFLOP/s (forward GEMM work x 3)."""
+    import wavenet_model
+    torch.manual_seed(0)
+    m = wavenet_model.WaveNetModel(layers=10, blocks=5, dilation_channels=128, residual_channels=128, skip_channels=512,
+                                   end_channels=256, classes=256, output_length=1, kernel_size=2, bias=False).cuda(device)
+    m.output_length = out_len = L - m.receptive_field + 1
+    g = torch.Generator().manual_seed(1)
+    idx = torch.randint(0, 256, (N, L), generator=g).cuda(device)
+    target = torch.randint(0, 256, (N * out_len,), generator=g).cuda(device)
+    opt = torch.optim.Adam(m.parameters(), lr=1e-4)
+    R = D = 128; S = 512; E = 256; C = 256
+    need, fwd = out_len, 0
+    for d in reversed([2 ** (i % 10) for i in range(50)]):
+        fwd += 2 * N * need * (2 * R * 2 * D + D * R) + 2 * N * out_len * D * S
+        need += d
+    fwd += 2 * N * out_len * (S * E + E * C)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss = torch.nn.functional.cross_entropy(m.train_forward_indices(idx), target)
+        loss.backward()
+        opt.step()
+        return loss
+
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        loss = step()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / reps * 1e3
+    return {"ms_per_step": round(ms, 2), "clips": N, "clip_samples": L, "output_length": out_len, "dtype": "f32 (matrix cores)",
+            "tflop_per_step": round(3 * fwd / 1e12, 2), "tflops": round(3 * fwd / ms / 1e9, 1),
+            "mfma_f32_peak_frac": round(3 * fwd / ms / 1e9 / 157.3, 3), "loss": round(float(loss.detach()), 4)}
+
+
 def cpu_baseline(cfgname, budget_s=10.0):
     """The reference's CPU path (torch restatement of generate_fast, oracle/restated.py, proven bit-equal to the real
     reference in tests/test_oracle_pinning.py) timed on this box's host cores: a bounded single-stream sample.  The path
@@ -194,6 +234,11 @@ def main():
                          "hbm_frac": round(synth.algorithmic_bytes_per_step(cf2, s2) * 8000 / (k2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                          "n_workgroups": i2["n_workgroups"]}
         line["extra"] = extra
+    if n_gpus == 1 and not a.no_extra:
+        try:
+            line["extra"]["train_cfg5"] = train_step_cfg5(local)
+        except Exception as e:  # noqa: BLE001 -- the secondary measurement must never cost the headline line
+            line["extra"]["train_cfg5"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
     if n_gpus == 1 and not a.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(cfgname)
     print(json.dumps(line))

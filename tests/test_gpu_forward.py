@@ -116,3 +116,22 @@ def test_forward_indices_extension():
         ref = m(_onehot(ids)).numpy()
     y = m.forward_indices(torch.from_numpy(ids)).cpu().numpy()
     assert np.abs(y - ref).max() <= TOL
+
+
+@pytest.mark.parametrize("cfgname", ["cfg1", "cfg2", "cfg3"])
+def test_forward_equals_queue_path_logits_after_priming(cfgname):
+    """forward(window)[-1] == the logits the generation path computes for the sample that follows a
+    window it was primed on (1.5e-8 in the reference itself).  Ties the two native paths -- GEMM forward and the
+    persistent chain with its dilation queues -- to each other, with chain priming and with batched priming."""
+    cfg = synth.CONFIGS[cfgname]
+    W = synth.init_weights(cfg, seed=44)
+    rf = synth.receptive_field(cfg)
+    rs = np.random.RandomState(45)
+    window = rs.randint(0, 256, (2, rf + 9))  # a little more history than the receptive field
+    eng = engine.Engine(cfg, W, n_streams=2)
+    fwd = eng.forward_indices(window, 1).cpu().numpy()  # (2, 256): logits for the sample after each window
+    scale = max(1.0, float(np.abs(fwd).max()))
+    for batched in (False, True):
+        _, logits = eng.generate(1, window, temperature=0.0, want_logits=True, batched_prime=batched)
+        assert np.abs(logits[:, 0, :] - fwd).max() <= 1e-5 * scale, (cfgname, batched, float(np.abs(logits[:, 0, :] - fwd).max()))
+    eng.close()
