@@ -159,9 +159,11 @@ int wn_export_queue(wn_handle* h, int32_t layer, int32_t stream, float* host_dat
  * multiples of 32: callers use the torch path for those. */
 int wn_forward(wn_handle* h, const int32_t* indices, int64_t N, int64_t L, int64_t output_length, float* logits, void* hip_stream);
 
-/* Operand precision of wn_forward: 0 = fp32 matrix-core GEMMs (default: equals the reference's fp32 forward to rounding),
- * 1 = bf16 operands with fp32 accumulation (residual stream, skip sum and all accumulators stay fp32; logits differ from
- * the fp32 path at the 1e-2 level of their scale).  WN_E_UNSUPPORTED unless R, D, S and E are multiples of 64. */
+/* Operand precision of wn_forward, wn_train_forward and the activation-gradient products of wn_train_backward:
+ * 0 = fp32 matrix-core GEMMs (default: equals the reference's fp32 graph to rounding), 1 = bf16 operands with fp32
+ * accumulation (residual stream, skip sum, saved activations, weight-gradient products and all accumulators stay fp32;
+ * logits differ from the fp32 path at the 1e-2 level of their scale, gradients by a few per cent in norm -- mostly sign
+ * flips of ReLU masks).  WN_E_UNSUPPORTED unless R, D, S and E are multiples of 64. */
 int wn_set_forward_precision(wn_handle* h, int32_t bf16);
 
 /* The priming loop of generate_fast (wavenet_model.py:259-269) for ALL given samples at once: `first_samples` is a DEVICE

@@ -291,11 +291,17 @@ __global__ __launch_bounds__(256) void wn_fwd_gemm_bf16(WnGemmArgsBf16 ga) {
                 if (ng >= g.N) continue;
                 const float f = acc[2 * p][i] + (g.bias ? g.bias[nf] : 0.f);
                 const float gg = acc[2 * p + 1][i] + (g.bias ? g.bias[ng] : 0.f);
-                const float z = tanhf(f) * (1.0f / (1.0f + expf(-gg)));
+                const float th = tanhf(f), sg = 1.0f / (1.0f + expf(-gg));
+                const float z = th * sg;
                 crow[(n0 >> 1) + 32 * p + col] = z;
                 if (c2row) c2row[(n0 >> 1) + 32 * p + col] = z;
+                if (g.gate_t) {
+                    g.gate_t[m * (g.N >> 1) + (n0 >> 1) + 32 * p + col] = th;
+                    g.gate_g[m * (g.N >> 1) + (n0 >> 1) + 32 * p + col] = sg;
+                }
             }
         } else {
+            const float* mrow = g.mask ? g.mask + (crow - g.c.base) : nullptr;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int n = n0 + 32 * j + col;
@@ -303,10 +309,32 @@ __global__ __launch_bounds__(256) void wn_fwd_gemm_bf16(WnGemmArgsBf16 ga) {
                 float v = acc[j][i] + (g.bias ? g.bias[n] : 0.f);
                 if (addrow) v += addrow[n];
                 if (g.relu_c) v = fmaxf(v, 0.f);
+                if (mrow && !(mrow[n] > 0.f)) v = 0.f;
                 crow[n] = v;
             }
         }
     }
+}
+
+// out[i] = bf16(in[i]) (round to nearest even): the backward products' weight operands, [N][K] row-major, are the forward
+// banks as they are
+__global__ void wn_cvt_bf16(const float* in, unsigned short* out, long long n) {
+    const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 2;
+    if (i + 1 < n) *reinterpret_cast<unsigned*>(out + i) = wn_pack_bf16(in[i], in[i + 1]);
+    else if (i < n) out[i] = (unsigned short)(wn_pack_bf16(in[i], 0.f) & 0xffffu);
+}
+
+// out[b][c][r] = bf16(in[b][r][c]): the forward products' weight operands ([N][K]) from the fp32 banks ([K][N])
+__global__ void wn_cvt_bf16_transposed(const float* in, long long in_batch_stride, unsigned short* out, int rows, int cols) {
+    __shared__ float tile[32][33];
+    const float* ib = in + (long long)blockIdx.z * in_batch_stride;
+    unsigned short* ob = out + (long long)blockIdx.z * rows * cols;
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8)
+        if (r0 + i < rows && c0 + tx < cols) tile[i][tx] = ib[(long long)(r0 + i) * cols + c0 + tx];
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8)
+        if (c0 + i < cols && r0 + tx < rows) ob[(long long)(c0 + i) * rows + r0 + tx] = (unsigned short)(wn_pack_bf16(tile[tx][i], 0.f) & 0xffffu);
 }
 
 // x0[(n,t)][r] = start_conv.weight[r][idx[n][t]] (+ bias): the one-hot input makes start_conv a column gather (wavenet_model.py:127)

@@ -45,6 +45,11 @@ static void wn_train_layout_ws(const wn_handle* h, long long N, long long L, lon
     t.dxa = take((size_t)N * L * R); t.dxb = take((size_t)N * L * R);
     t.colsum_tmp = take(S);
     t.idx = take((size_t)N * L);
+    // bf16 operand banks (2 bytes each; sizes in floats): the whole parameter blob as it is (backward products) and the
+    // transposed forward banks
+    t.bw = take((h->fw_floats + 1) / 2);
+    t.bt_fg = take((size_t)NL * 2 * D * 2 * R / 2); t.bt_res = take((size_t)NL * R * D / 2); t.bt_skip = take((size_t)NL * S * D / 2);
+    t.bt_w1 = take((size_t)E * S / 2); t.bt_w2 = take((size_t)C * E / 2);
     t.total = o;
 }
 
@@ -72,10 +77,21 @@ extern "C" int wn_train_export_params(wn_handle* h, float* params, void* hip_str
     return rt_hip(hipMemcpyAsync(params, h->d_fw, h->fw_floats * 4, hipMemcpyDeviceToDevice, (hipStream_t)hip_stream), "hipMemcpyAsync(params)");
 }
 
-static void wn_launch_nn(hipStream_t st, int epi, const WnGemmArgs& a) {
+// bn != NULL: bf16 operands (B given as [N][K] bf16, A rounded while staged), fp32 accumulation; else fp32 operands
+static void wn_launch_nn(hipStream_t st, int epi, const WnGemmArgs& a, const unsigned short* bn = nullptr) {
     dim3 grid((unsigned)((a.M + 127) / 128), (unsigned)((a.N + 127) / 128));
-    if (epi == WN_EPI_GATE) hipLaunchKernelGGL(wn_fwd_gemm<WN_EPI_GATE>, grid, dim3(256), 0, st, a);
+    if (bn) {
+        WnGemmArgsBf16 b;
+        b.g = a; b.bn = bn;
+        if (epi == WN_EPI_GATE) hipLaunchKernelGGL(wn_fwd_gemm_bf16<WN_EPI_GATE>, grid, dim3(256), 0, st, b);
+        else hipLaunchKernelGGL(wn_fwd_gemm_bf16<WN_EPI_PLAIN>, grid, dim3(256), 0, st, b);
+    } else if (epi == WN_EPI_GATE) hipLaunchKernelGGL(wn_fwd_gemm<WN_EPI_GATE>, grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL(wn_fwd_gemm<WN_EPI_PLAIN>, grid, dim3(256), 0, st, a);
+}
+
+static void wn_launch_cvt_t(hipStream_t st, const float* in, long long in_batch_stride, unsigned short* out, int rows, int cols, int batches) {
+    hipLaunchKernelGGL(wn_cvt_bf16_transposed, dim3((unsigned)((cols + 31) / 32), (unsigned)((rows + 31) / 32), (unsigned)batches), dim3(256), 0, st,
+                       in, in_batch_stride, out, rows, cols);
 }
 
 static void wn_launch_tn(hipStream_t st, WnGemmTnArgs a) {
@@ -139,6 +155,24 @@ extern "C" int wn_train_forward(wn_handle* h, const float* params, const int32_t
     wn_launch_transpose(st, fw + h->fw_off_w2, 0, ws + t.w2_o, E, C, 1);                         // [E][C] -> [C][E]
     wn_launch_transpose(st, fw + h->fw_off_fg, (long long)2 * R * 2 * D, ws + t.fgb0, R, 2 * D, NL);               // tap 0 rows -> [2D][R]
     wn_launch_transpose(st, fw + h->fw_off_fg + (size_t)R * 2 * D, (long long)2 * R * 2 * D, ws + t.fgb1, R, 2 * D, NL);
+    const int G = t.G;
+    const bool bf16 = h->fw_bf16 && h->fwb_ok;
+    t.bf16 = bf16;
+    unsigned short* bw = reinterpret_cast<unsigned short*>(ws + t.bw);
+    unsigned short* bt_fg = reinterpret_cast<unsigned short*>(ws + t.bt_fg);
+    unsigned short* bt_res = reinterpret_cast<unsigned short*>(ws + t.bt_res);
+    unsigned short* bt_skip = reinterpret_cast<unsigned short*>(ws + t.bt_skip);
+    unsigned short* bt_w1 = reinterpret_cast<unsigned short*>(ws + t.bt_w1);
+    unsigned short* bt_w2 = reinterpret_cast<unsigned short*>(ws + t.bt_w2);
+    if (bf16) {
+        const long long n = (long long)h->fw_floats;
+        hipLaunchKernelGGL(wn_cvt_bf16, dim3((unsigned)((n / 2 + 256) / 256)), dim3(256), 0, st, fw, bw, n);
+        wn_launch_cvt_t(st, fw + h->fw_off_fg, (long long)2 * R * 2 * D, bt_fg, 2 * R, 2 * D, NL);        // [2R][2D] -> [2D][2R]
+        wn_launch_cvt_t(st, fw + h->fw_off_res, (long long)D * R, bt_res, D, R, NL);                          // [D][R] -> [R][D]
+        wn_launch_cvt_t(st, fw + h->fw_off_skip, (long long)G * D * S, bt_skip, G * D, S, NL / G);            // [G*D][S] -> [S][G*D] per block
+        wn_launch_cvt_t(st, fw + h->fw_off_w1, 0, bt_w1, S, E, 1);
+        wn_launch_cvt_t(st, fw + h->fw_off_w2, 0, bt_w2, E, C, 1);
+    }
     if (pl.has_bias) {  // the grouped skip GEMM adds the sum of all layers' skip biases once
         rc = rt_hip(hipMemsetAsync(ws + t.bskip_total, 0, (size_t)S * 4, st), "hipMemsetAsync");
         if (rc) return rc;
@@ -149,7 +183,6 @@ extern "C" int wn_train_forward(wn_handle* h, const float* params, const int32_t
         hipLaunchKernelGGL(wn_fwd_start, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, indices, fw + h->fw_off_start_t,
                            pl.has_bias ? fw + h->fw_off_start_b : nullptr, ws + t.x[0], rows, R);
     }
-    const int G = t.G;
     float* skip = ws + t.skip; float* ev = ws + t.ev; float* zg = ws + t.zg;
     for (int l = 0; l < NL; ++l) {
         const long long d = h->dil[l], rows = t.need[l + 1], t0 = L - rows;
@@ -167,7 +200,7 @@ extern "C" int wn_train_forward(wn_handle* h, const float* params, const int32_t
         a.c2_first_row = (int)(rows - out_len);
         a.gate_t = ws + t.th[l]; a.gate_g = ws + t.sg[l];
         a.M = N * rows; a.rows_per_batch = (int)rows;
-        wn_launch_nn(st, WN_EPI_GATE, a);
+        wn_launch_nn(st, WN_EPI_GATE, a, bf16 ? bt_fg + (size_t)l * 2 * D * 2 * R : nullptr);
         if (l < NL - 1) {
             memset(&a, 0, sizeof(a));
             a.a0 = a.a1 = WnRowMap{z, rows * D, D, 0};
@@ -176,7 +209,7 @@ extern "C" int wn_train_forward(wn_handle* h, const float* params, const int32_t
             a.cin = WnRowMap{xin, (long long)L * R, R, t0};
             a.c = WnRowMap{ws + t.x[l + 1], (long long)L * R, R, t0};
             a.M = N * rows; a.rows_per_batch = (int)rows;
-            wn_launch_nn(st, WN_EPI_PLAIN, a);
+            wn_launch_nn(st, WN_EPI_PLAIN, a, bf16 ? bt_res + (size_t)l * R * D : nullptr);
         }
         if (gi == G - 1 || l == NL - 1) {
             const int first = l - gi, cnt = gi + 1;
@@ -187,7 +220,7 @@ extern "C" int wn_train_forward(wn_handle* h, const float* params, const int32_t
             if (first > 0) a.cin = WnRowMap{skip, out_len * S, S, 0};
             a.c = WnRowMap{skip, out_len * S, S, 0};
             a.M = N * out_len; a.rows_per_batch = (int)out_len;
-            wn_launch_nn(st, WN_EPI_PLAIN, a);
+            wn_launch_nn(st, WN_EPI_PLAIN, a, bf16 ? bt_skip + (size_t)(first / G) * S * G * D : nullptr);
         }
     }
     {
@@ -197,13 +230,13 @@ extern "C" int wn_train_forward(wn_handle* h, const float* params, const int32_t
         a.k_split = S; a.K = S; a.bt = fw + h->fw_off_w1; a.N = E; a.bias = fw + h->fw_off_b1;
         a.c = WnRowMap{ev, out_len * E, E, 0};
         a.M = N * out_len; a.rows_per_batch = (int)out_len; a.relu_a = 1; a.relu_c = 1;
-        wn_launch_nn(st, WN_EPI_PLAIN, a);
+        wn_launch_nn(st, WN_EPI_PLAIN, a, bf16 ? bt_w1 : nullptr);
         memset(&a, 0, sizeof(a));
         a.a0 = a.a1 = WnRowMap{ev, out_len * E, E, 0};
         a.k_split = E; a.K = E; a.bt = fw + h->fw_off_w2; a.N = C; a.bias = fw + h->fw_off_b2;
         a.c = WnRowMap{logits, out_len * C, C, 0};
         a.M = N * out_len; a.rows_per_batch = (int)out_len;
-        wn_launch_nn(st, WN_EPI_PLAIN, a);
+        wn_launch_nn(st, WN_EPI_PLAIN, a, bf16 ? bt_w2 : nullptr);
     }
     rc = rt_hip(hipGetLastError(), "wn_train_forward launches");
     if (rc) return rc;
@@ -227,6 +260,8 @@ extern "C" int wn_train_backward(wn_handle* h, const float* params, const float*
     int rc = rt_hip(hipMemsetAsync(grads, 0, h->fw_floats * 4, st), "hipMemsetAsync(grads)");
     if (rc) return rc;
     float* dskip = ws + t.dskip; float* de = ws + t.de; float* dz = ws + t.dz; float* dfg = ws + t.dfg;
+    // bf16 mode: the "NN" products take their weight operand ([N][K] bf16) straight from the bf16 copy of the parameter blob
+    const unsigned short* bw = t.bf16 ? reinterpret_cast<const unsigned short*>(ws + t.bw) : nullptr;
     const float* skip = ws + t.skip; const float* ev = ws + t.ev;
     WnGemmArgs a;
     WnGemmTnArgs g;
@@ -241,7 +276,7 @@ extern "C" int wn_train_backward(wn_handle* h, const float* params, const float*
     a.k_split = C; a.K = C; a.bt = ws + t.w2_o; a.N = E;
     a.c = WnRowMap{de, out_len * E, E, 0}; a.mask = ev;
     a.M = Mo; a.rows_per_batch = (int)out_len;
-    wn_launch_nn(st, WN_EPI_PLAIN, a);
+    wn_launch_nn(st, WN_EPI_PLAIN, a, bw ? bw + h->fw_off_w2 : nullptr);
     memset(&g, 0, sizeof(g));   // dW1^T [S][E] = relu(skip)^T . de
     g.a = WnRowMap{skip, out_len * S, S, 0}; g.b = WnRowMap{de, out_len * E, E, 0}; g.relu_a = 1;
     g.Ka = S; g.Nb = E; g.c = grads + h->fw_off_w1; g.ldc = E; g.M = Mo; g.rows_per_batch = (int)out_len;
@@ -252,7 +287,7 @@ extern "C" int wn_train_backward(wn_handle* h, const float* params, const float*
     a.k_split = E; a.K = E; a.bt = ws + t.w1_o; a.N = S;
     a.c = WnRowMap{dskip, out_len * S, S, 0}; a.mask = skip;
     a.M = Mo; a.rows_per_batch = (int)out_len;
-    wn_launch_nn(st, WN_EPI_PLAIN, a);
+    wn_launch_nn(st, WN_EPI_PLAIN, a, bw ? bw + h->fw_off_w1 : nullptr);
     if (pl.has_bias) {          // every layer's skip bias sees the same gradient
         rc = rt_hip(hipMemsetAsync(ws + t.colsum_tmp, 0, (size_t)S * 4, st), "hipMemsetAsync");
         if (rc) return rc;
@@ -276,7 +311,7 @@ extern "C" int wn_train_backward(wn_handle* h, const float* params, const float*
             a.k_split = R; a.K = R; a.bt = ws + t.res_o + (size_t)l * R * D; a.N = D;
             a.c = WnRowMap{dz, rows * D, D, 0};
             a.M = M; a.rows_per_batch = (int)rows;
-            wn_launch_nn(st, WN_EPI_PLAIN, a);
+            wn_launch_nn(st, WN_EPI_PLAIN, a, bw ? bw + h->fw_off_res + (size_t)l * D * R : nullptr);
             memset(&g, 0, sizeof(g));
             g.a = WnRowMap{z, rows * D, D, 0}; g.b = WnRowMap{dxn, L * (long long)R, R, t0};
             g.Ka = D; g.Nb = R; g.c = grads + h->fw_off_res + (size_t)l * D * R; g.ldc = R; g.M = M; g.rows_per_batch = (int)rows;
@@ -292,7 +327,7 @@ extern "C" int wn_train_backward(wn_handle* h, const float* params, const float*
         a.cin = WnRowMap{dz, rows * D, D, rows - out_len};
         a.c = WnRowMap{dz, rows * D, D, rows - out_len};
         a.M = Mo; a.rows_per_batch = (int)out_len;
-        wn_launch_nn(st, WN_EPI_PLAIN, a);
+        wn_launch_nn(st, WN_EPI_PLAIN, a, bw ? bw + h->fw_off_skip + (size_t)l * D * S : nullptr);
         memset(&g, 0, sizeof(g));
         g.a = WnRowMap{z, rows * D, D, rows - out_len}; g.b = WnRowMap{dskip, out_len * S, S, 0};
         g.Ka = D; g.Nb = S; g.c = grads + h->fw_off_skip + (size_t)l * D * S; g.ldc = S; g.M = Mo; g.rows_per_batch = (int)out_len;
@@ -318,14 +353,14 @@ extern "C" int wn_train_backward(wn_handle* h, const float* params, const float*
         if (has_res) a.cin = WnRowMap{dxn, L * (long long)R, R, t0};
         a.c = WnRowMap{dxc, L * (long long)R, R, t0};
         a.M = M; a.rows_per_batch = (int)rows;
-        wn_launch_nn(st, WN_EPI_PLAIN, a);
+        wn_launch_nn(st, WN_EPI_PLAIN, a, bw ? bw + h->fw_off_fg + (size_t)l * 2 * R * 2 * D + (size_t)R * 2 * D : nullptr);
         memset(&a, 0, sizeof(a));   // dx_l(t - d) += dfg(t) . Wfg(tap 0)
         a.a0 = a.a1 = WnRowMap{dfg, rows * 2 * D, 2 * D, 0};
         a.k_split = 2 * D; a.K = 2 * D; a.bt = ws + t.fgb0 + (size_t)l * 2 * D * R; a.N = R;
         a.cin = WnRowMap{dxc, L * (long long)R, R, t0 - d};
         a.c = WnRowMap{dxc, L * (long long)R, R, t0 - d};
         a.M = M; a.rows_per_batch = (int)rows;
-        wn_launch_nn(st, WN_EPI_PLAIN, a);
+        wn_launch_nn(st, WN_EPI_PLAIN, a, bw ? bw + h->fw_off_fg + (size_t)l * 2 * R * 2 * D : nullptr);
         float* tmp = dxn; dxn = dxc; dxc = tmp;
     }
     // ---- start_conv: dstart^T [C][R] = onehot(indices)^T . dx_0

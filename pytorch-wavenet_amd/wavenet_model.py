@@ -93,6 +93,10 @@ class WaveNetModel(nn.Module):
         self._wn_forward_calls = 0
         self._wn_train_runner = None
         self._wn_train_calls = 0
+        # Extension: operand precision of the native matrix-core forward / backward GEMMs: "fp32" (default: equals the
+        # reference's fp32 graph to rounding) or "bf16" (bf16 operands, fp32 accumulation and fp32 residual stream;
+        # needs channel counts that are multiples of 64, otherwise fp32 is used)
+        self.matrix_precision = "fp32"
 
     # ------------------------------------------------------------------ training path (torch ops)
     def wavenet(self, input, dilation_func):
@@ -146,9 +150,16 @@ class WaveNetModel(nn.Module):
         if want_grad:
             return self._native_train_forward(idx)
         eng = self._engine(1)
+        self._apply_precision(eng)
         out = eng.forward_indices(idx, self.output_length)
         self._wn_forward_calls = getattr(self, "_wn_forward_calls", 0) + 1
         return out.to(input.dtype)
+
+    def _apply_precision(self, eng):
+        want = getattr(self, "matrix_precision", "fp32") == "bf16"
+        if want and any(c % 64 for c in (self.residual_channels, self.dilation_channels, self.skip_channels, self.end_channels)):
+            want = False
+        eng.set_forward_precision(want)
 
     def _native_train_forward(self, idx):
         """model(x) with a native backward: see mi355_wavenet/training.py."""
@@ -179,12 +190,15 @@ class WaveNetModel(nn.Module):
             add("res_b", [m.bias for m in self.residual_convs])
             add("skip_b", [m.bias for m in self.skip_convs])
         self._wn_train_calls = getattr(self, "_wn_train_calls", 0) + 1
+        self._apply_precision(runner.eng)
         return training.StackFunction.apply(runner, idx, self.output_length, tuple(names), *tensors)
 
     def forward_indices(self, indices):
         """Extension: forward() on class indices (N, L) instead of a one-hot (N, classes, L) tensor -- what the
         dataset holds before audio_data.py:119-121 inflates it 256x.  Inference only (matrix-core path, no autograd)."""
-        out = self._engine(1).forward_indices(indices, self.output_length)
+        eng = self._engine(1)
+        self._apply_precision(eng)
+        out = eng.forward_indices(indices, self.output_length)
         self._wn_forward_calls = getattr(self, "_wn_forward_calls", 0) + 1
         return out
 

@@ -18,14 +18,14 @@ sys.path.insert(0, os.path.join(ROOT, "pytorch-wavenet_amd"))
 pytestmark = pytest.mark.gpu
 
 
-def _model(bias, layers=3, blocks=2, ch=32, skip=64, end=64, out_len=16, seed=0):
+def _model(bias, layers=3, blocks=2, ch=32, skip=64, end=64, out_len=16, seed=0, gain=3.0):
     import wavenet_model
     torch.manual_seed(seed)
     m = wavenet_model.WaveNetModel(layers=layers, blocks=blocks, dilation_channels=ch, residual_channels=ch, skip_channels=skip,
                                    end_channels=end, classes=256, output_length=out_len, kernel_size=2, bias=bias)
     with torch.no_grad():
         for p in m.parameters():  # PyTorch's default init leaves the logits tiny: spread them so every ReLU / gate regime is hit
-            p.mul_(3.0)
+            p.mul_(gain)
     return m.cuda()
 
 
@@ -232,3 +232,39 @@ def test_generate_audio_runs_its_temperatures_as_parallel_streams():
     np.random.seed(5)
     b = m.generate_fast_streams(30, [0.9, 0.], first_samples=first, regularize=0.1)
     assert np.array_equal(a, b)
+
+
+def test_bf16_operands_for_the_training_step():
+    """model.matrix_precision = "bf16": forward and the backward's activation-gradient products run with bf16 operands (fp32
+    accumulation; weight gradients stay fp32 products of the saved activations): logits and gradients stay within bf16
+    distance of the fp32 step -- the opt-in trade of BASELINE config 5 ("MFMA bf16"), never the parity default."""
+    # What to expect: operand roundings of 2^-9 give ~0.2 % per product (end_conv_2's gradient, downstream of every ReLU:
+    # 0.3 %).  Upstream of the head's two ReLUs the error is dominated by *mask flips*: pre-activations within the forward's
+    # rounding error of zero change sign, the affected elements' gradient changes by 100 %, and a fraction eps of flipped
+    # elements is a relative L2 error of sqrt(eps) -- measured 6-9 % on every stack parameter, the same at every depth.
+    # That is the discontinuity of ReLU, not an accumulating error; direction and size of the gradients are preserved.
+    m = _model(True, ch=64, skip=128, end=64, gain=1.5)
+    x, target = _batch(m, 2, 0)
+    out32, loss32, g32 = _step(m, x, target, torch_path=False)
+    m.matrix_precision = "bf16"
+    out16, loss16, g16 = _step(m, x, target, torch_path=False)
+    scale = float(out32.abs().max())
+    assert 0 < float((out16 - out32).abs().max()) <= 1e-2 * scale   # really a different arithmetic, and close
+    assert abs(loss16 - loss32) <= 1e-3 * abs(loss32)
+    for k in g32:
+        if g32[k] is None:
+            assert g16[k] is None
+            continue
+        rel = float((g16[k] - g32[k]).norm() / (g32[k].norm() + 1e-30))
+        cos = float((g16[k] * g32[k]).sum() / (g16[k].norm() * g32[k].norm() + 1e-30))
+        assert rel <= (5e-3 if k.startswith("end_conv_2") else 0.15) and cos >= 0.99, (k, rel, cos)
+    m.matrix_precision = "fp32"
+    out_again, _, _ = _step(m, x, target, torch_path=False)
+    assert torch.allclose(out_again, out32, atol=1e-6)
+    small = _model(False)  # 32-channel model: bf16 is not available, the fp32 kernels run
+    small.matrix_precision = "bf16"
+    xs, ts = _batch(small, 1, 0)
+    o1, _, _ = _step(small, xs, ts, torch_path=False)
+    small.matrix_precision = "fp32"
+    o2, _, _ = _step(small, xs, ts, torch_path=False)
+    assert torch.allclose(o1, o2, atol=1e-6)
