@@ -28,8 +28,14 @@ def main():
     P, PA, NL = info["layer_split"], info["head_split"], info["n_layers"]
     N = 400 if ns == 1 else 60
     G = 1
+    n_total = ns
+    nc = max(1, info.get("n_chains", 1))
+    ns = ns // nc          # the stamps are those of the first chain: its streams
+    info["n_workgroups"] //= nc
+    if nc > 1:
+        print("%d chains of %d streams share the CUs; stamps of chain 0" % (nc, ns))
     items = N * ns // G  # pipeline items: G streams each in the multi-stream kernel
-    u = np.random.RandomState(0).random_sample((ns, N))
+    u = np.random.RandomState(0).random_sample((n_total, N))
     eng.generate(N, None, temperature=1.0, uniforms=u)  # warm-up
     eng.profile_next(items)
     eng.generate(N, None, temperature=1.0, uniforms=u)
