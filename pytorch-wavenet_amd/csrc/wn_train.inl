@@ -95,10 +95,12 @@ static void wn_launch_cvt_t(hipStream_t st, const float* in, long long in_batch_
 }
 
 static void wn_launch_tn(hipStream_t st, WnGemmTnArgs a) {
+    // Split the rows so that ~512 workgroups exist (two are resident per CU: 64 KB LDS each), but never below 256 rows per
+    // split: every split ends with a 128x128 tile of atomics.
     const int tiles = ((a.Ka + 127) / 128) * ((a.Nb + 127) / 128);
-    long long splits = (a.M + 2047) / 2048;
-    const long long cap = 2048 / tiles > 1 ? 2048 / tiles : 1;
-    if (splits > cap) splits = cap;
+    long long splits = 512 / tiles > 1 ? 512 / tiles : 1;
+    const long long most = (a.M + 255) / 256;
+    if (splits > most) splits = most;
     if (splits < 1) splits = 1;
     long long rps = (a.M + splits - 1) / splits;
     rps = (rps + 31) / 32 * 32;
