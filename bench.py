@@ -119,6 +119,72 @@ def train_step_cfg5(device, N=32, L=16000, reps=3):
             "mfma_f32_peak_frac": round(3 * fwd / ms / 1e9 / 157.3, 3), "loss": round(float(loss.detach()), 4)}
 
 
+def train5_main(a, dist, rank, local, n_gpus, global_batch=32, L=16000):
+    """--workload train5: BASELINE configs[4] -- the training step of layers=10 blocks=5 128/128/512 on one-second 16 kHz
+    clips, GLOBAL batch 32 split over the ranks (plain data parallel): native forward + backward per rank, ONE
+    flat gradient all-reduce over RCCL (wavenet_training.average_gradients), Adam on every rank.  A "step" is one
+    optimiser step; value = clips (= seconds of audio) per second over all GPUs; scaling is strong (fixed global batch)."""
+    import wavenet_model
+    import wavenet_training
+    torch.manual_seed(0)
+    m = wavenet_model.WaveNetModel(layers=10, blocks=5, dilation_channels=128, residual_channels=128, skip_channels=512,
+                                   end_channels=256, classes=256, output_length=1, kernel_size=2, bias=False).cuda(local)
+    m.output_length = out_len = L - m.receptive_field + 1
+    n_local = global_batch // n_gpus
+    g = torch.Generator().manual_seed(1 + rank)
+    idx = torch.randint(0, 256, (n_local, L), generator=g).cuda(local)
+    target = torch.randint(0, 256, (n_local * out_len,), generator=g).cuda(local)
+    opt = torch.optim.Adam(m.parameters(), lr=1e-4)
+    group = dist.group.WORLD if dist else None
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss = torch.nn.functional.cross_entropy(m.train_forward_indices(idx), target)
+        loss.backward()
+        if dist:
+            wavenet_training.average_gradients(m.parameters(), group)
+        opt.step()
+
+    for _ in range(max(a.warmup, 1)):
+        step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    wall = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([wall], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+    if rank == 0:
+        R = D = 128; S = 512; E = 256; C = 256
+        need, fwd = out_len, 0
+        for d in reversed([2 ** (i % 10) for i in range(50)]):
+            fwd += 2 * global_batch * need * (2 * R * 2 * D + D * R) + 2 * global_batch * out_len * D * S
+            need += d
+        fwd += 2 * global_batch * out_len * (S * E + E * C)
+        ms = wall / a.steps * 1e3
+        tflops = 3 * fwd / ms / 1e9
+        print(json.dumps({
+            "metric": "training step throughput, one-second 16 kHz clips per second (forward + backward + Adam), whole job",
+            "value": round(global_batch / (ms * 1e-3), 2), "unit": "clips/s", "n_gpus": n_gpus, "steps": a.steps, "warmup": max(a.warmup, 1),
+            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic (seeded random weights, uniform random class indices and targets)",
+            "config": {"workload": "train5: WaveNetModel(layers=10, blocks=5, 128/128/512/256), global batch %d clips x %d samples, "
+                                   "output_length %d, data parallel over %d GPU(s), one flat gradient all-reduce per step"
+                                   % (global_batch, L, out_len, n_gpus), "global_batch": global_batch, "clips_per_gpu": n_local},
+            "roofline": {"bound": "mfma", "achieved": round(tflops, 2), "peak": 157.3 * n_gpus, "unit": "TFLOP/s",
+                         "frac": round(tflops / (157.3 * n_gpus), 4), "traffic": None,
+                         "kernel": "wn_fwd_gemm / wn_bwd_gemm_tn (fp32 MFMA)", "flop_per_step": int(3 * fwd)}}))
+    if dist:
+        dist.destroy_process_group()
+
+
 def cpu_baseline(cfgname, budget_s=10.0):
     """The reference's CPU path (torch restatement of generate_fast, oracle/restated.py, proven bit-equal to the real
     reference in tests/test_oracle_pinning.py) timed on this box's host cores: a bounded single-stream sample.  The path
@@ -160,7 +226,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="cfg3x64", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="cfg3x64", choices=sorted(WORKLOADS) + ["train5"],
+                    help="train5: BASELINE configs[4], the data-parallel training step (global batch 32, strong scaling)")
     ap.add_argument("--samples", type=int, default=2000, help="audio samples per stream per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
@@ -182,6 +249,9 @@ def main():
     if a.gpus != n_gpus and rank == 0 and world > 1:
         print("warning: --gpus %d but WORLD_SIZE %d" % (a.gpus, world), file=sys.stderr)
 
+    if a.workload == "train5":
+        train5_main(a, dist, rank, local, n_gpus)
+        return
     cfgname, per_gpu = WORKLOADS[a.workload]
     wall, kernel_ms, info, cfg = time_workload(cfgname, per_gpu, a.samples, a.steps, a.warmup, dist, local)
     if dist:

@@ -14,6 +14,12 @@
  *   - a handle is single-threaded (like a reference model object whose DilatedQueues are mutable
  *     state); distinct handles may be used concurrently from different threads (the reference calls
  *     generate_fast from a daemon thread during training: model_logging.py:48-58).
+ *   - wn_generate jobs are persistent kernels: every workgroup of a job must be resident before the job
+ *     makes progress.  A job that finds the device's CUs taken (another handle's job, a long torch
+ *     kernel) starts when they free up; its hand-off timeout (timeout_ms) runs from the moment its
+ *     workgroups start, so size it for the longest job that may run next to it.  Jobs of >= 16 streams
+ *     run as several independent chains, two workgroups per CU, on the caller's stream plus one
+ *     library-owned stream (forked and joined with events: to the caller it is one asynchronous job).
  */
 #ifndef WN_ABI_H
 #define WN_ABI_H
