@@ -62,9 +62,18 @@ struct WnGemmArgs {
 // C[M][N] (+)= A[M][K] . B^T[K][N]; 128 x 128 tile per workgroup, 4 waves, wave w owns rows 32w..32w+31 and all 128
 // columns (4 accumulator tiles of 32x32).  WN_EPI_GATE: the 128 columns are [F(32) | G(32) | F(32) | G(32)] and the tile
 // emits 64 columns of tanh(F+bf) * sigmoid(G+bg).
+#ifndef WN_GEMM_KC
+#define WN_GEMM_KC 16   // K chunk of the fp32 GEMMs.  Measured on the config-5 forward: 32 (65.8 KB LDS, 2 workgroups per CU)
+                        // 89.4 ms; 16 (32.9 KB) with 3 per CU 78.4 ms, with 4 per CU (119 VGPRs) 71.2 ms; 8: 70.9 ms
+#endif
 template <int EPI>
-__global__ __launch_bounds__(256) void wn_fwd_gemm(WnGemmArgs g) {
-    constexpr int TM = 128, TN = 128, KC = 32, AP = TM + 1;  // AP: padded row length of the transposed A chunk
+#ifndef WN_GEMM_MINB
+#define WN_GEMM_MINB 4
+#endif
+__global__ __launch_bounds__(256, WN_GEMM_MINB) void wn_fwd_gemm(WnGemmArgs g) {
+    constexpr int TM = 128, TN = 128, KC = WN_GEMM_KC, AP = TM + 1;  // AP: padded row length of the transposed A chunk
+    constexpr int NQ = KC / 8;          // float4 per thread per operand and chunk
+    constexpr int BT = 256 / KC;        // threads per B row
     __shared__ float a_t[2][KC * AP];                         // [k][row]
     __shared__ float b_s[2][KC * TN];                         // [k][col]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -82,31 +91,31 @@ __global__ __launch_bounds__(256) void wn_fwd_gemm(WnGemmArgs g) {
     const bool arow_ok = am < g.M;
     const float* a0p = arow_ok ? wn_row(g.a0, am, g.rows_per_batch) : nullptr;
     const float* a1p = arow_ok ? wn_row(g.a1, am, g.rows_per_batch) : nullptr;
-    const int brow = tid >> 3, bcol = (tid & 7) * 16;
+    const int brow = tid / BT, bcol = (tid % BT) * (KC / 2);
 
-    float4 va[4], vb[4];  // staging registers of the chunk in flight
+    float4 va[NQ], vb[NQ];  // staging registers of the chunk in flight
     auto fetch = [&](int kc) {  // global -> registers (issued before the multiply of the current chunk)
         const int k0 = kc * KC;
         const float* src = k0 < g.k_split ? a0p + k0 : a1p + (k0 - g.k_split);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) va[q] = arow_ok ? *reinterpret_cast<const float4*>(src + ahalf * 16 + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int q = 0; q < NQ; ++q) va[q] = arow_ok ? *reinterpret_cast<const float4*>(src + ahalf * (KC / 2) + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
         const float* bsrc = g.bt + (size_t)(k0 + brow) * g.N + n0 + bcol;
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+        for (int q = 0; q < NQ; ++q)
             vb[q] = (n0 + bcol + q * 4 < g.N) ? *reinterpret_cast<const float4*>(bsrc + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
     };
     auto stash = [&](int buf) {  // registers -> LDS (A transposed to [k][row])
         float* at = a_t[buf];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < NQ; ++q) {
             float4 x = va[q];
             if (g.relu_a) { x.x = fmaxf(x.x, 0.f); x.y = fmaxf(x.y, 0.f); x.z = fmaxf(x.z, 0.f); x.w = fmaxf(x.w, 0.f); }
-            const int k = ahalf * 16 + q * 4;
+            const int k = ahalf * (KC / 2) + q * 4;
             at[(k + 0) * AP + arow] = x.x; at[(k + 1) * AP + arow] = x.y; at[(k + 2) * AP + arow] = x.z; at[(k + 3) * AP + arow] = x.w;
         }
         float* bs = b_s[buf] + brow * TN + bcol;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(bs + q * 4) = vb[q];
+        for (int q = 0; q < NQ; ++q) *reinterpret_cast<float4*>(bs + q * 4) = vb[q];
     };
 
     const int nchunks = g.K / KC;
@@ -199,10 +208,17 @@ struct WnGemmArgsBf16 {
     const unsigned short* bn;  // B as bf16 [N][K] row-major (K contiguous: the weights' natural (out, in) layout)
 };
 
+#ifndef WN_GEMM_BF16_KC
+#define WN_GEMM_BF16_KC 32    // config-5 forward: 64 (73.7 KB LDS, 2 workgroups per CU) 52.7 ms; 32 (41 KB, 3 per CU, 152 VGPRs) 40.8 ms
+#endif
+#ifndef WN_GEMM_BF16_MINB
+#define WN_GEMM_BF16_MINB 3
+#endif
 template <int EPI>
-__global__ __launch_bounds__(256) void wn_fwd_gemm_bf16(WnGemmArgsBf16 ga) {
+__global__ __launch_bounds__(256, WN_GEMM_BF16_MINB) void wn_fwd_gemm_bf16(WnGemmArgsBf16 ga) {
     const WnGemmArgs& g = ga.g;
-    constexpr int TM = 128, TN = 128, KC = 64, LD = KC + 8;  // LD: padded row length (bf16) -> 144-byte rows, conflict-free b128 reads
+    constexpr int TM = 128, TN = 128, KC = WN_GEMM_BF16_KC, LD = KC + 8;  // LD: padded row length (bf16): 144- / 80-byte rows, conflict-free b128 reads
+    constexpr int HK = KC / 2;   // k values per loader thread (two threads per row)
     __shared__ __attribute__((aligned(16))) unsigned short a_s[2][TM * LD];
     __shared__ __attribute__((aligned(16))) unsigned short b_s[2][TN * LD];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -221,21 +237,21 @@ __global__ __launch_bounds__(256) void wn_fwd_gemm_bf16(WnGemmArgsBf16 ga) {
     const bool bcol_ok = n0 + lrow < g.N;
     const unsigned short* bp = ga.bn + (size_t)(n0 + lrow) * g.K;
 
-    float4 va[8];
-    uint4 vb[4];
+    float4 va[HK / 4];
+    uint4 vb[HK / 8];
     auto fetch = [&](int kc) {
         const int k0 = kc * KC;
-        const float* src = (k0 < g.k_split ? a0p + k0 : a1p + (k0 - g.k_split)) + lhalf * 32;
+        const float* src = (k0 < g.k_split ? a0p + k0 : a1p + (k0 - g.k_split)) + lhalf * HK;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) va[q] = arow_ok ? *reinterpret_cast<const float4*>(src + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-        const uint4* bsrc = reinterpret_cast<const uint4*>(bp + k0 + lhalf * 32);
+        for (int q = 0; q < HK / 4; ++q) va[q] = arow_ok ? *reinterpret_cast<const float4*>(src + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const uint4* bsrc = reinterpret_cast<const uint4*>(bp + k0 + lhalf * HK);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) vb[q] = bcol_ok ? bsrc[q] : make_uint4(0u, 0u, 0u, 0u);
+        for (int q = 0; q < HK / 8; ++q) vb[q] = bcol_ok ? bsrc[q] : make_uint4(0u, 0u, 0u, 0u);
     };
     auto stash = [&](int buf) {
-        uint4* ad = reinterpret_cast<uint4*>(a_s[buf] + lrow * LD + lhalf * 32);
+        uint4* ad = reinterpret_cast<uint4*>(a_s[buf] + lrow * LD + lhalf * HK);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < HK / 8; ++q) {
             float4 x = va[2 * q], y = va[2 * q + 1];
             if (g.relu_a) {
                 x.x = fmaxf(x.x, 0.f); x.y = fmaxf(x.y, 0.f); x.z = fmaxf(x.z, 0.f); x.w = fmaxf(x.w, 0.f);
@@ -243,9 +259,9 @@ __global__ __launch_bounds__(256) void wn_fwd_gemm_bf16(WnGemmArgsBf16 ga) {
             }
             ad[q] = make_uint4(wn_pack_bf16(x.x, x.y), wn_pack_bf16(x.z, x.w), wn_pack_bf16(y.x, y.y), wn_pack_bf16(y.z, y.w));
         }
-        uint4* bd = reinterpret_cast<uint4*>(b_s[buf] + lrow * LD + lhalf * 32);
+        uint4* bd = reinterpret_cast<uint4*>(b_s[buf] + lrow * LD + lhalf * HK);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) bd[q] = vb[q];
+        for (int q = 0; q < HK / 8; ++q) bd[q] = vb[q];
     };
 
     const int nchunks = g.K / KC;
@@ -367,8 +383,8 @@ struct WnGemmTnArgs {
     long long rows_per_split;
 };
 
-__global__ __launch_bounds__(256) void wn_bwd_gemm_tn(WnGemmTnArgs g) {
-    constexpr int T = 128, KC = 32;
+__global__ __launch_bounds__(256, WN_GEMM_MINB) void wn_bwd_gemm_tn(WnGemmTnArgs g) {
+    constexpr int T = 128, KC = WN_GEMM_KC, NQ = KC / 8, LT = 256 / KC;  // NQ float4 per thread per operand, LT threads per row
     __shared__ float a_s[2][KC * T];  // [m][ka]
     __shared__ float b_s[2][KC * T];  // [m][nb]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -382,8 +398,8 @@ __global__ __launch_bounds__(256) void wn_bwd_gemm_tn(WnGemmTnArgs g) {
     for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
-    const int lrow = tid >> 3, lcol = (tid & 7) * 16;  // loader: row of the chunk, 16 floats of its 128
-    float4 va[4], vb[4];
+    const int lrow = tid / LT, lcol = (tid % LT) * (KC / 2);  // loader: row of the chunk, KC/2 floats of its 128
+    float4 va[NQ], vb[NQ];
     auto fetch = [&](long long mc) {
         const long long m = mc + lrow;
         const bool ok = m < m_end;
@@ -394,24 +410,24 @@ __global__ __launch_bounds__(256) void wn_bwd_gemm_tn(WnGemmTnArgs g) {
                 cls = g.a_idx[(long long)q * g.a.batch_stride + (g.a.t0 + (long long)rem) * g.a.row_stride];
             }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < NQ; ++q) {
                 const int k = ka0 + lcol + q * 4;
                 va[q] = make_float4(cls == k ? 1.f : 0.f, cls == k + 1 ? 1.f : 0.f, cls == k + 2 ? 1.f : 0.f, cls == k + 3 ? 1.f : 0.f);
             }
         } else {
             const float* ap = ok ? wn_row(g.a, m, g.rows_per_batch) + ka0 + lcol : nullptr;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) va[q] = (ok && ka0 + lcol + q * 4 < g.Ka) ? *reinterpret_cast<const float4*>(ap + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int q = 0; q < NQ; ++q) va[q] = (ok && ka0 + lcol + q * 4 < g.Ka) ? *reinterpret_cast<const float4*>(ap + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
         const float* bp = ok ? wn_row(g.b, m, g.rows_per_batch) + nb0 + lcol : nullptr;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) vb[q] = (ok && nb0 + lcol + q * 4 < g.Nb) ? *reinterpret_cast<const float4*>(bp + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int q = 0; q < NQ; ++q) vb[q] = (ok && nb0 + lcol + q * 4 < g.Nb) ? *reinterpret_cast<const float4*>(bp + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
     };
     auto stash = [&](int buf) {
         float* ad = a_s[buf] + lrow * T + lcol;
         float* bd = b_s[buf] + lrow * T + lcol;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < NQ; ++q) {
             float4 x = va[q];
             if (g.relu_a) { x.x = fmaxf(x.x, 0.f); x.y = fmaxf(x.y, 0.f); x.z = fmaxf(x.z, 0.f); x.w = fmaxf(x.w, 0.f); }
             *reinterpret_cast<float4*>(ad + q * 4) = x;

@@ -95,10 +95,10 @@ static void wn_launch_cvt_t(hipStream_t st, const float* in, long long in_batch_
 }
 
 static void wn_launch_tn(hipStream_t st, WnGemmTnArgs a) {
-    // Split the rows so that ~512 workgroups exist (two are resident per CU: 64 KB LDS each), but never below 256 rows per
+    // Split the rows so that ~1024 workgroups exist (four are resident per CU), but never below 256 rows per
     // split: every split ends with a 128x128 tile of atomics.
     const int tiles = ((a.Ka + 127) / 128) * ((a.Nb + 127) / 128);
-    long long splits = 512 / tiles > 1 ? 512 / tiles : 1;
+    long long splits = 1024 / tiles > 1 ? 1024 / tiles : 1;
     const long long most = (a.M + 255) / 256;
     if (splits > most) splits = most;
     if (splits < 1) splits = 1;

@@ -13,17 +13,19 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 import wavenet_model  # noqa: E402
-from mi355_wavenet import engine, synth  # noqa: E402
+from mi355_wavenet import _abi, engine, synth  # noqa: E402
 
 
 def main():
-    N = int(sys.argv[1]) if len(sys.argv) > 1 else 32
-    L = int(sys.argv[2]) if len(sys.argv) > 2 else 16000
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    N = int(args[0]) if len(args) > 0 else 32
+    L = int(args[1]) if len(args) > 1 else 16000
     cfg = synth.CONFIGS["cfg3"]
     rf = synth.receptive_field(cfg)
     out_len = L - rf + 1
     W = synth.init_weights(cfg, seed=0)
-    eng = engine.Engine(cfg, W)
+    lib = _abi.Library(os.environ["WN_DEV_LIB"]) if os.environ.get("WN_DEV_LIB") else None  # dev build of the library
+    eng = engine.Engine(cfg, W, lib=lib)
     ids = torch.from_numpy(np.random.RandomState(0).randint(0, 256, (N, L))).cuda().int()
     R, D, S, E, C = 128, 128, 512, 256, 256
     dil = synth.dilation_list(cfg)
@@ -46,6 +48,8 @@ def main():
     ms = ev0.elapsed_time(ev1) / reps
     print("wn_forward N=%d L=%d out_len=%d: %.2f ms, %.2f TFLOP executed -> %.1f TFLOP/s fp32 MFMA (peak 157.3; frac %.3f)" % (
         N, L, out_len, ms, flops / 1e12, flops / ms / 1e9, flops / ms / 1e9 / 157.3))
+    if "--fp32-only" in sys.argv:
+        return
     try:
         eng.set_forward_precision(True)
         for _ in range(2):
@@ -62,6 +66,8 @@ def main():
         eng.set_forward_precision(False)
     except Exception as e:  # noqa: BLE001
         print("bf16 path unavailable:", e)
+    if "--no-torch" in sys.argv:
+        return
     # torch path of the facade on the same GPU (the reference's algorithm with ATen/MIOpen ops)
     m = wavenet_model.WaveNetModel(output_length=out_len, **cfg)
     m.load_state_dict({k: torch.from_numpy(v) for k, v in W.items()})
