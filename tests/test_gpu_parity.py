@@ -269,3 +269,24 @@ def test_per_stream_temperatures():
             idx, _ = c_oracle.generate(cfg, W, 50, first[s], t if t > 0 else 0.0, 0.0, u[s] if t > 0 else None)
             agree = int((out[s] == idx).sum())
             assert agree == 50, (cfgname, ns, s, t, agree)
+
+
+def test_two_chain_front_edge_cases():
+    """The multi-chain front handle on the calls the facade makes around a job: prime-only (zero samples), continuation
+    without reset (progress callbacks), an odd stream count (chains of 9 + 8), a single generated sample."""
+    cfg, W, first, uniforms = make_case("cfg2", 71, 17, 6, 64)
+    eng = engine.Engine(cfg, W, n_streams=17)
+    assert eng.info()["n_chains"] == 2
+    idx = eng.generate(0, first, temperature=0.0)
+    assert idx.shape == (17, 0) and eng.info()["evals_done"] == 5
+    full = eng.generate(64, first, temperature=1.0, uniforms=uniforms)
+    a = eng.generate(23, first, temperature=1.0, uniforms=uniforms[:, :23])
+    b = eng.generate(41, a[:, -1:], temperature=1.0, uniforms=uniforms[:, 23:], reset=False)
+    assert np.array_equal(np.concatenate([a, b], axis=1), full)
+    assert eng.info()["evals_done"] == 6 - 1 + 64
+    one = eng.generate(1, first, temperature=1.0, uniforms=uniforms[:, :1])
+    assert np.array_equal(one, full[:, :1])
+    for s in (0, 8, 9, 16):  # both sides of the chain boundary
+        o_idx, _ = c_oracle.generate(cfg, W, 64, first[s], 1.0, 0.0, uniforms[s])
+        assert np.array_equal(full[s], o_idx), s
+    eng.close()
