@@ -268,3 +268,74 @@ def test_bf16_operands_for_the_training_step():
     small.matrix_precision = "fp32"
     o2, _, _ = _step(small, xs, ts, torch_path=False)
     assert torch.allclose(o1, o2, atol=1e-6)
+
+
+def test_training_abi_error_codes():
+    """wn_train_* through the C ABI: call-order and shape errors come back as codes with a message, nothing throws."""
+    import ctypes
+    from mi355_wavenet import _abi, engine, training
+    m = _model(False)
+    eng = engine.Engine(m._config(), dict(m.state_dict()), n_streams=1, device_index=0)
+    r = training.StackRunner(eng)
+    d = eng.lib.dll
+    flat = r.export_params()
+    grads = torch.empty_like(flat)
+    dl = torch.zeros(16, 256, device="cuda")
+    assert d.wn_train_backward(eng._h, flat.data_ptr(), dl.data_ptr(), grads.data_ptr(), None) == _abi.WN_E_STATE
+    assert b"wn_train_forward" in d.wn_last_error()
+    idx = torch.zeros(1, 10, dtype=torch.int32, device="cuda")  # shorter than the receptive field
+    out = torch.empty(16, 256, device="cuda")
+    assert d.wn_train_forward(eng._h, flat.data_ptr(), idx.data_ptr(), 1, 10, 16, out.data_ptr(), None) == _abi.WN_E_UNSUPPORTED
+    assert d.wn_train_forward(eng._h, None, idx.data_ptr(), 1, 10, 16, out.data_ptr(), None) == _abi.WN_E_BADARG
+    lay = _abi.wn_train_layout()
+    assert d.wn_train_get_layout(eng._h, ctypes.byref(lay)) == 0 and lay.total == flat.numel() and lay.fg == 0
+    eng.close()
+    import wavenet_model
+    odd = wavenet_model.WaveNetModel(layers=2, blocks=1, dilation_channels=8, residual_channels=8, skip_channels=16, end_channels=16,
+                                     classes=256, output_length=4, kernel_size=2).cuda()
+    L = odd.receptive_field + 3
+    x = torch.zeros(1, 256, L, device="cuda")
+    x[0, 5, :] = 1.0
+    before = odd._wn_train_calls
+    odd(x).sum().backward()   # channel counts that are not multiples of 32: the torch graph runs, silently and correctly
+    assert odd._wn_train_calls == before and odd.start_conv.weight.grad is not None
+
+
+def test_train_script_shape_end_to_end(tmp_path):
+    """The reference's train_script.py configuration (layers=10, blocks=3, 32/32/1024/512, bias, output_length=16,
+    legacy CUDA tensor types for dtype/ltype, one-hot DataLoader items, snapshots) for a few optimiser steps on the native path."""
+    import audio_data
+    import model_logging
+    import wavenet_model
+    import wavenet_training
+    dtype, ltype = torch.cuda.FloatTensor, torch.cuda.LongTensor
+    torch.manual_seed(0)
+    model = wavenet_model.WaveNetModel(layers=10, blocks=3, dilation_channels=32, residual_channels=32, skip_channels=1024,
+                                       end_channels=512, output_length=16, dtype=dtype, bias=True)
+    model.cuda()
+    assert model.receptive_field == 3070 and model.parameter_count() == 1834592
+    rs = np.random.RandomState(0)
+    np.savez(str(tmp_path / "dataset.npz"), rs.randint(0, 256, 9000).astype(np.uint8), rs.randint(0, 256, 4000).astype(np.uint8))
+    data = audio_data.WavenetDataset(dataset_file=str(tmp_path / "dataset.npz"), item_length=model.receptive_field + model.output_length - 1,
+                                     target_length=model.output_length, test_stride=500)
+    losses = []
+
+    class StopAfter(model_logging.Logger):
+        def log(self, step, loss):
+            losses.append(loss)
+            if step >= 4:
+                raise StopIteration
+
+    os.makedirs(str(tmp_path / "snapshots"))
+    trainer = wavenet_training.WavenetTrainer(model=model, dataset=data, lr=0.0001, weight_decay=0.0, snapshot_path=str(tmp_path / "snapshots"),
+                                              snapshot_name="chaconne_model", snapshot_interval=2, logger=StopAfter(), dtype=dtype, ltype=ltype,
+                                              num_workers=0)
+    before = model._wn_train_calls
+    with pytest.raises(StopIteration):
+        trainer.train(batch_size=4, epochs=1, continue_training_at_step=0)
+    assert model._wn_train_calls - before == 4 and len(losses) == 4 and all(np.isfinite(losses))
+    snaps = os.listdir(str(tmp_path / "snapshots"))
+    assert snaps and snaps[0].startswith("chaconne_model_")
+    gen_model = wavenet_model.load_latest_model_from(str(tmp_path / "snapshots"), use_cuda=False)   # what train_script's sampler thread does
+    audio = wavenet_training.generate_audio(gen_model, length=50, temperatures=[0.5])
+    assert audio.shape == (1, 50) and np.all(np.abs(audio) <= 1.0)
