@@ -99,3 +99,19 @@ def test_product_library_is_the_only_default(monkeypatch):
     monkeypatch.setattr(_abi, "_product", None)
     with pytest.raises(RuntimeError, match="no CPU/torch fallback"):
         _abi.load_product_library()
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/wn_abi.h is the boundary for non-Python callers: it must compile as plain C (no C++, no HIP, no torch types)."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    src = tmp_path / "use_abi.c"
+    src.write_text('#include "wn_abi.h"\n'
+                   'int probe(void) { wn_config c; wn_generate_args a; wn_info i; wn_train_layout t; (void)c; (void)a; (void)i; (void)t;\n'
+                   '                  return (int)sizeof(wn_weight_ptrs) + WN_ABI_VERSION + WN_E_STATE; }\n')
+    inc = os.path.join(ROOT, "include")
+    for std in ("c99", "c11"):
+        subprocess.check_call([gcc, "-std=" + std, "-Wall", "-Wextra", "-Werror", "-pedantic", "-fsyntax-only", "-I", inc, str(src)])
