@@ -467,13 +467,21 @@ __global__ __launch_bounds__(256, WN_GEMM_MINB) void wn_bwd_gemm_tn(WnGemmTnArgs
     }
 }
 
-// dF = dz * G * (1 - T^2), dG = dz * T * G * (1 - G), written in the packed [F(32) | G(32)] column order of Wfg^T
-__global__ void wn_bwd_gate(const float* dz, const float* th, const float* sg, float* dfg, long long M, int D) {
+// dF = dz * G * (1 - T^2), dG = dz * T * G * (1 - G), written in the packed [F(32) | G(32)] column order of Wfg^T.
+// dzg != NULL: the skip path's share of dz -- column block of the per-block product dskip . Wskip^T, [N*out_len][ldg] -- is
+// added on the last out_len rows of every batch entry (the rows the skip conv saw).
+__global__ void wn_bwd_gate(const float* dz, const float* th, const float* sg, float* dfg, long long M, int D,
+                            const float* dzg, int ldg, int rows, int out_len) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= M * D) return;
     const long long m = i / D;
     const int ch = (int)(i % D);
-    const float d = dz[i], t = th[i], s = sg[i];
+    float d = dz[i];
+    if (dzg) {
+        const unsigned n = (unsigned)m / (unsigned)rows, tt = (unsigned)m - n * (unsigned)rows;
+        if ((int)tt >= rows - out_len) d += dzg[((long long)n * out_len + ((int)tt - (rows - out_len))) * ldg + ch];
+    }
+    const float t = th[i], s = sg[i];
     const int nf = 64 * (ch >> 5) + (ch & 31);
     dfg[m * 2 * D + nf] = d * s * (1.f - t * t);
     dfg[m * 2 * D + nf + 32] = d * t * s * (1.f - s);

@@ -230,9 +230,9 @@ struct WnTrainLay {
     long long N, L, out_len;
     std::vector<long long> need;          // need[l] = trailing time steps of layer l's input the loss depends on
     std::vector<size_t> x, z, th, sg;     // per layer offsets (floats) into the training workspace
-    size_t skip, ev, zg, bskip_total, res_o, skip_o, w1_o, w2_o, fgb0, fgb1, dskip, de, dz, dfg, dxa, dxb, colsum_tmp, idx, total;
+    size_t skip, ev, zg, dzg, bskip_total, res_o, skip_o, w1_o, w2_o, fgb0, fgb1, dskip, de, dz, dfg, dxa, dxb, colsum_tmp, idx, total;
     size_t bw, bt_fg, bt_res, bt_skip, bt_w1, bt_w2;  // bf16 operand banks (offsets in floats)
-    int G;
+    int G, nblk;  // layers per skip block, blocks
     bool bf16;  // the saved forward ran with bf16 operands: so does its backward
 };
 #endif

@@ -38,7 +38,7 @@ static void wn_train_layout_ws(const wn_handle* h, long long N, long long L, lon
         t.z[l] = take(zl); t.th[l] = take(zl); t.sg[l] = take(zl);
     }
     const size_t Mo = (size_t)N * out_len;
-    t.skip = take(Mo * S); t.ev = take(Mo * E); t.zg = take(Mo * t.G * D); t.bskip_total = take(S);
+    t.skip = take(Mo * S); t.ev = take(Mo * E); t.nblk = (NL + t.G - 1) / t.G; t.zg = take((size_t)t.nblk * Mo * t.G * D); t.dzg = take(Mo * t.G * D); t.bskip_total = take(S);
     t.res_o = take((size_t)NL * R * D); t.skip_o = take((size_t)NL * S * D); t.w1_o = take((size_t)E * S); t.w2_o = take((size_t)C * E);
     t.fgb0 = take((size_t)NL * 2 * D * R); t.fgb1 = take((size_t)NL * 2 * D * R);
     t.dskip = take(Mo * S); t.de = take(Mo * E); t.dz = take(zmax); t.dfg = take(2 * zmax);
@@ -152,7 +152,10 @@ extern "C" int wn_train_forward(wn_handle* h, const float* params, const int32_t
     if (rc) return rc;
     // operand layouts of the backward products, rebuilt from the (just updated) parameters
     wn_launch_transpose(st, fw + h->fw_off_res, (long long)D * R, ws + t.res_o, D, R, NL);      // [D][R] -> [R][D]
-    wn_launch_transpose(st, fw + h->fw_off_skip, (long long)D * S, ws + t.skip_o, D, S, NL);    // [D][S] -> [S][D]
+    for (int b = 0; b < t.nblk; ++b) {  // per block of G layers: [cnt*D][S] -> [S][cnt*D], the operand of the backward's grouped skip product
+        const int first = b * t.G, cnt = NL - first < t.G ? NL - first : t.G;
+        wn_launch_transpose(st, fw + h->fw_off_skip + (size_t)first * D * S, 0, ws + t.skip_o + (size_t)first * S * D, cnt * D, S, 1);
+    }
     wn_launch_transpose(st, fw + h->fw_off_w1, 0, ws + t.w1_o, S, E, 1);                         // [S][E] -> [E][S]
     wn_launch_transpose(st, fw + h->fw_off_w2, 0, ws + t.w2_o, E, C, 1);                         // [E][C] -> [C][E]
     wn_launch_transpose(st, fw + h->fw_off_fg, (long long)2 * R * 2 * D, ws + t.fgb0, R, 2 * D, NL);               // tap 0 rows -> [2D][R]
@@ -185,10 +188,11 @@ extern "C" int wn_train_forward(wn_handle* h, const float* params, const int32_t
         hipLaunchKernelGGL(wn_fwd_start, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, indices, fw + h->fw_off_start_t,
                            pl.has_bias ? fw + h->fw_off_start_b : nullptr, ws + t.x[0], rows, R);
     }
-    float* skip = ws + t.skip; float* ev = ws + t.ev; float* zg = ws + t.zg;
+    float* skip = ws + t.skip; float* ev = ws + t.ev;
     for (int l = 0; l < NL; ++l) {
         const long long d = h->dil[l], rows = t.need[l + 1], t0 = L - rows;
         const int gi = l % G;
+        float* zg = ws + t.zg + (size_t)(l / G) * ((size_t)N * out_len * G * D);  // this block's z on the skip rows (kept for the backward)
         float* xin = ws + t.x[l];
         float* z = ws + t.z[l];
         WnGemmArgs a;
@@ -323,20 +327,29 @@ extern "C" int wn_train_backward(wn_handle* h, const float* params, const float*
             rc = rt_hip(hipMemsetAsync(dz, 0, (size_t)M * D * 4, st), "hipMemsetAsync(dz)");
             if (rc) return rc;
         }
-        memset(&a, 0, sizeof(a));   // dz[skip rows] += dskip . Wskip ;  dWskip^T [D][S] = z[skip rows]^T . dskip
-        a.a0 = a.a1 = WnRowMap{dskip, out_len * S, S, 0};
-        a.k_split = S; a.K = S; a.bt = ws + t.skip_o + (size_t)l * S * D; a.N = D;
-        a.cin = WnRowMap{dz, rows * D, D, rows - out_len};
-        a.c = WnRowMap{dz, rows * D, D, rows - out_len};
-        a.M = Mo; a.rows_per_batch = (int)out_len;
-        wn_launch_nn(st, WN_EPI_PLAIN, a, bw ? bw + h->fw_off_skip + (size_t)l * D * S : nullptr);
-        memset(&g, 0, sizeof(g));
-        g.a = WnRowMap{z, rows * D, D, rows - out_len}; g.b = WnRowMap{dskip, out_len * S, S, 0};
-        g.Ka = D; g.Nb = S; g.c = grads + h->fw_off_skip + (size_t)l * D * S; g.ldc = S; g.M = Mo; g.rows_per_batch = (int)out_len;
-        wn_launch_tn(st, g);
-        {   // [dF | dG]
+        // The skip path, one block of G layers at a time (as in the forward): entering a block from above,
+        //   dzg [Mo][cnt*D] = dskip . [Wskip of the block's layers]      dWskip^T of the block [cnt*D][S] = zg^T . dskip
+        // so dskip (0.7 GB at config 5) is read twice per block instead of twice per layer; the gate kernel below adds
+        // this layer's column block of dzg to dz on the skip rows.
+        const int gi = l % t.G, first = l - gi, cnt = NL - first < t.G ? NL - first : t.G;
+        float* dzg = ws + t.dzg;
+        if (gi == cnt - 1) {
+            const float* zg = ws + t.zg + (size_t)(l / t.G) * ((size_t)Mo * t.G * D);
+            memset(&a, 0, sizeof(a));
+            a.a0 = a.a1 = WnRowMap{dskip, out_len * S, S, 0};
+            a.k_split = S; a.K = S; a.bt = ws + t.skip_o + (size_t)first * S * D; a.N = cnt * D;
+            a.c = WnRowMap{dzg, out_len * (long long)cnt * D, (long long)cnt * D, 0};
+            a.M = Mo; a.rows_per_batch = (int)out_len;
+            wn_launch_nn(st, WN_EPI_PLAIN, a, bw ? bw + h->fw_off_skip + (size_t)first * D * S : nullptr);
+            memset(&g, 0, sizeof(g));
+            g.a = WnRowMap{zg, out_len * (long long)t.G * D, (long long)t.G * D, 0}; g.b = WnRowMap{dskip, out_len * S, S, 0};
+            g.Ka = cnt * D; g.Nb = S; g.c = grads + h->fw_off_skip + (size_t)first * D * S; g.ldc = S; g.M = Mo; g.rows_per_batch = (int)out_len;
+            wn_launch_tn(st, g);
+        }
+        {   // [dF | dG] of dz + this layer's share of dzg
             const long long work = M * D;
-            hipLaunchKernelGGL(wn_bwd_gate, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, dz, ws + t.th[l], ws + t.sg[l], dfg, M, D);
+            hipLaunchKernelGGL(wn_bwd_gate, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, dz, ws + t.th[l], ws + t.sg[l], dfg, M, D,
+                               dzg + (size_t)gi * D, cnt * D, (int)rows, (int)out_len);
         }
         for (int tap = 0; tap < 2; ++tap) {  // dWfg^T rows tap*R.. = x_l(t - (1-tap) d)^T . dfg
             memset(&g, 0, sizeof(g));
