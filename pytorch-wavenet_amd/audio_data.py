@@ -172,8 +172,12 @@ class DeviceBatches:
         target = window[:, -ds.target_length:].to(torch.int64).reshape(-1)
         return indices, target
 
-    def epoch(self, batch_size, shuffle=True, generator=None):
+    def epoch(self, batch_size, shuffle=True, generator=None, rank=0, world=1):
+        """Batches of one pass over the items.  Data parallel: every rank draws the SAME permutation (same ``generator``
+        seed on all ranks) and keeps items rank, rank + world, ... of it -- disjoint shards of equal size."""
         n = len(self.dataset)
         order = torch.randperm(n, generator=generator) if shuffle else torch.arange(n)
-        for i in range(0, n, batch_size):
+        if world > 1:
+            order = order[:n - n % world][rank::world]
+        for i in range(0, len(order), batch_size):
             yield self.batch(order[i:i + batch_size].tolist())

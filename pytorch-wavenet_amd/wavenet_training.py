@@ -86,13 +86,25 @@ class WavenetTrainer:
         target = target.view(-1).type(self.ltype).to(dev)
         return x, target
 
+    def _rank_world(self):
+        import torch.distributed as dist
+        if self.process_group is None and not (dist.is_available() and dist.is_initialized()):
+            return 0, 1
+        return dist.get_rank(self.process_group), dist.get_world_size(self.process_group)
+
     def _epoch(self, batch_size, shuffle):
-        """Yields (kind, x, target): kind "indices" (device batches) or "onehot" (the reference's DataLoader items)."""
+        """Yields (kind, x, target): kind "indices" (device batches) or "onehot" (the reference's DataLoader items).
+        Data parallel: every rank sees a disjoint shard of the epoch (same permutation seed on all ranks)."""
+        rank, world = self._rank_world()
         if self.device_batches:
             if self._batches is None or self._batches.device != self._device():
                 from audio_data import DeviceBatches
                 self._batches = DeviceBatches(self.dataset, self._device())
-            for idx, target in self._batches.epoch(batch_size, shuffle=shuffle):
+            gen = None
+            if world > 1:
+                self._epoch_count = getattr(self, "_epoch_count", 0) + 1
+                gen = torch.Generator().manual_seed(1234 + self._epoch_count)
+            for idx, target in self._batches.epoch(batch_size, shuffle=shuffle, generator=gen, rank=rank, world=world):
                 yield "indices", idx, target
         else:
             for x, target in iter(self.dataloader):
@@ -118,7 +130,9 @@ class WavenetTrainer:
 
     def train(self, batch_size=32, epochs=10, continue_training_at_step=0):
         self.model.train()
-        self.dataloader = torch.utils.data.DataLoader(self.dataset, batch_size=batch_size, shuffle=True,
+        rank, world = self._rank_world()
+        sampler = torch.utils.data.distributed.DistributedSampler(self.dataset, num_replicas=world, rank=rank, shuffle=True) if world > 1 else None
+        self.dataloader = torch.utils.data.DataLoader(self.dataset, batch_size=batch_size, shuffle=sampler is None, sampler=sampler,
                                                       num_workers=self.num_workers, pin_memory=False)
         step = continue_training_at_step
         for current_epoch in range(epochs):

@@ -77,6 +77,18 @@ def test_device_batches_equal_dataset_items(dataset_file):
     assert seen == len(ds)
     with pytest.raises(IndexError):
         ds.item_indices(len(ds) + 10_000)
+    # data parallel: the ranks' shards of one epoch are disjoint, equally long and together one permutation (minus the remainder)
+    shards = []
+    for rank in range(3):
+        g = torch.Generator().manual_seed(7)
+        shards.append(torch.cat([b[0][:, 0] * 0 + 1 for b in db.epoch(5, shuffle=True, generator=g, rank=rank, world=3)]).numel())
+    assert len(set(shards)) == 1 and sum(shards) == len(ds) - len(ds) % 3
+    picks = []
+    for rank in range(3):
+        g = torch.Generator().manual_seed(7)
+        order = torch.randperm(len(ds), generator=g)
+        picks.append(set(order[:len(ds) - len(ds) % 3][rank::3].tolist()))
+    assert not (picks[0] & picks[1]) and not (picks[1] & picks[2]) and len(picks[0] | picks[1] | picks[2]) == len(ds) - len(ds) % 3
 
 
 def test_dataset_from_wav_files(tmp_path):
