@@ -188,6 +188,17 @@ class Engine:
         self.lib.check(rc)
         return True
 
+    def prime_host(self, first_samples):
+        """prime() on a host array (n_streams, n_prime) of class indices: all of them are teacher-forced inputs."""
+        fs = np.ascontiguousarray(np.asarray(first_samples), dtype=np.int32)
+        if fs.ndim != 2 or fs.shape[0] != self.n_streams:
+            raise ValueError("first_samples must be (n_streams, n_prime)")
+        if fs.size and (fs.min() < 0 or fs.max() >= self.classes):
+            raise ValueError("first_samples outside [0, classes)")
+        if fs.shape[1] == 0:
+            return True
+        return self.prime(self.mem.upload(fs), fs.shape[1], fs.shape[1])
+
     # -- convenience: one synchronous generate_fast-shaped job
     PRIME_BATCH_MIN = 64  # given samples from which the GEMM priming path beats the per-sample chain passes
 

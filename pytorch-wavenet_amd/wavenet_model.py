@@ -12,7 +12,11 @@ What is different underneath:
     sample when ``temperature > 0``: ``np.random.choice``, wavenet_model.py:288) -- the draws are made on the
     host and shipped to the kernel, which performs the same float64 inverse-CDF lookup.
   * extension: ``first_samples`` may be 2-D ``(streams, n_given)``; the result is then ``(streams, num_samples)``.
-``forward()`` (training) runs the reference's algorithm with torch ops on whatever device the module lives on.
+  * the priming window (``first_samples`` of length n > 64) is evaluated as one batched matrix-core pass (wn_prime).
+  * ``forward()`` on a CUDA one-hot batch runs natively on the matrix cores (wn_forward; wn_train_forward / wn_train_backward
+    behind a torch.autograd.Function when gradients are wanted); CPU tensors, inputs shorter than
+    receptive_field + output_length - 1 (the reference's zero-padding regime), non-one-hot inputs and channel counts that
+    are not multiples of 32 run the reference's algorithm with torch ops on whatever device the module lives on.
 """
 import os
 import os.path
@@ -246,6 +250,7 @@ class WaveNetModel(nn.Module):
                 self._wn_engine.load_weights(dict(params))
             else:
                 if self._wn_engine is not None:
+                    self._flush_queues()  # their loaders read the engine that is about to go
                     self._wn_engine.close()
                 self._wn_engine = engine.Engine(self._config(), dict(params), n_streams=n_streams, device_index=index)
             self._wn_engine_key = key
@@ -268,25 +273,37 @@ class WaveNetModel(nn.Module):
         eng.reset()
         sampled = temperature > 0
 
-        # The job is evaluations ev = 0 .. n_eval-1 (num_given-1 priming + num_samples generating).  It is cut
-        # where the reference would have called back / printed, one persistent launch per piece:
-        #   priming step i fires the callback when i % interval == 0            (:266-269)
-        #   generating step i fires it when (i + num_given) % interval == 0      (:308-311)
-        #   the timing line is printed after generating step 99                 (:304-306)
+        # The job is evaluations ev = 0 .. n_eval-1 (num_given-1 priming + num_samples generating).
+        #   priming (:259-269): all n_prime teacher-forced evaluations run as ONE batched pass over the given window
+        #     (C ABI wn_prime: the stack as matrix-core GEMMs over all positions, queues filled from the result), then the
+        #     callbacks the reference would have fired at i % interval == 0 are delivered in order; shapes the batched
+        #     pass does not cover take the per-sample chain (WN_E_UNSUPPORTED), cut at the callbacks like below.
+        #   generating (:276-311): one persistent launch per piece, cut where the reference would have called back
+        #     ((i + num_given) % interval == 0, :308-311) or printed its timing line (after generating step 99, :304-306).
         n_prime = num_given - 1
         n_eval = n_prime + num_samples
+        a = 0
+        if n_prime >= eng.PRIME_BATCH_MIN and eng.prime_host(first[:, :n_prime]):
+            a = n_prime
+            if progress_callback is not None:
+                for i in range(0, n_prime, progress_interval):
+                    progress_callback(i, total_samples)
+        self._wn_last_prime_batched = a > 0
         cuts = {n_eval}
+        if n_prime > a:
+            cuts.add(n_prime)  # the generating loop (and the reference's stopwatch, :275) starts here
         if num_samples >= 100:
             cuts.add(n_prime + 100)
         if progress_callback is not None:
-            cuts.update(i + 1 for i in range(n_prime) if i % progress_interval == 0)
+            cuts.update(i + 1 for i in range(a, n_prime) if i % progress_interval == 0)
             cuts.update(n_prime + i + 1 for i in range(num_samples) if (i + num_given) % progress_interval == 0)
         pieces = []
         last = None
         tic = time.time()
-        a = 0
         for b in sorted(cuts):
             if b > a:
+                if a == n_prime:
+                    tic = time.time()  # :275
                 seg_prime = max(0, min(b, n_prime) - a)
                 n_new = (b - a) - seg_prime
                 head = first[:, a:a + seg_prime + 1] if a < num_given else last
@@ -311,9 +328,22 @@ class WaveNetModel(nn.Module):
                     progress_callback(ev - n_prime + num_given, total_samples)
         idx = np.concatenate(pieces, axis=1) if pieces else np.zeros((n_streams, 0), dtype=np.int32)
         generated = (idx.astype(np.int64) / self.classes) * 2. - 1  # :296
+        self._defer_queues(eng)
         self.train()
         mu_gen = mu_law_expansion(generated, self.classes)  # :314
         return mu_gen if batched else mu_gen[0]
+
+    def _defer_queues(self, eng, stream=0):
+        """The reference leaves model.dilated_queues in their final state (wavenet_model.py:177-184).  Here that state is on
+        the GPU: every queue gets a loader that downloads its ring on first access (wn_export_queue); nothing is copied
+        for callers that never look."""
+        for layer, queue in enumerate(self.dilated_queues):
+            queue._defer(lambda layer=layer: eng.export_queue(layer, stream))
+
+    def _flush_queues(self):
+        for queue in self.dilated_queues:
+            if getattr(queue, "_lazy", None) is not None:
+                queue._sync()
 
     def generate_fast_streams(self, num_samples, temperatures, first_samples=None, regularize=0.):
         """Extension: one generate_fast() per entry of ``temperatures`` -- the reference's generate_audio loop
@@ -337,6 +367,7 @@ class WaveNetModel(nn.Module):
         idx = eng.generate(num_samples, first, temperature=np.asarray(temps, dtype=np.float32), regularize=regularize,
                            uniforms=uniforms if any(t > 0 for t in temps) else None)
         generated = (idx.astype(np.int64) / self.classes) * 2. - 1
+        self._defer_queues(eng, stream=len(temps) - 1)  # sequential calls would leave the LAST temperature's queues
         self.train()
         return mu_law_expansion(generated, self.classes)
 
@@ -351,11 +382,28 @@ class WaveNetModel(nn.Module):
         return super().cpu()
 
     def __getstate__(self):  # the engine handle is not picklable and is rebuilt on demand
+        self._flush_queues()
         state = self.__dict__.copy()
         state["_wn_engine"] = None
         state["_wn_engine_key"] = None
         state["_wn_train_runner"] = None
         return state
+
+    def __setstate__(self, state):
+        """Also accepts snapshots pickled by the REFERENCE's class (torch.save(model), wavenet_training.py:84-88 -- its only
+        checkpoint format): their __dict__ has no end_channels / bias / engine fields (wavenet_model.py:42-56)."""
+        self.__dict__.update(state)
+        d = self.__dict__
+        d.setdefault("_wn_engine", None)
+        d.setdefault("_wn_engine_key", None)
+        d.setdefault("_wn_forward_calls", 0)
+        d.setdefault("_wn_train_runner", None)
+        d.setdefault("_wn_train_calls", 0)
+        d.setdefault("matrix_precision", "fp32")
+        if "end_channels" not in d:
+            d["end_channels"] = self.end_conv_1.out_channels
+        if "bias" not in d:
+            d["bias"] = self.start_conv.bias is not None
 
 
 def load_latest_model_from(location, use_cuda=True):

@@ -72,19 +72,71 @@ def _zeros(dtype, *shape):
 
 class DilatedQueue:
     """Ring buffer (num_channels, max_length): ``enqueue`` writes one column at ``in_pos``; ``dequeue`` returns
-    ``num_deq`` columns spaced ``dilation`` ending at ``out_pos``, oldest first (wavenet_modules.py:42-77)."""
+    ``num_deq`` columns spaced ``dilation`` ending at ``out_pos``, oldest first (wavenet_modules.py:42-77).
+
+    ``data`` / ``in_pos`` / ``out_pos`` are the reference's attributes.  After ``WaveNetModel.generate_fast`` the queues
+    of the run live on the GPU; the facade then only leaves a loader here (``_defer``) and the first access to one of the
+    three attributes downloads that layer's ring (C ABI wn_export_queue) -- the reference leaves its queues in their final
+    state (wavenet_model.py:177-184), and callers that never look pay nothing."""
 
     def __init__(self, max_length, data=None, dilation=1, num_deq=1, num_channels=1, dtype=torch.FloatTensor):
-        self.in_pos = 0
-        self.out_pos = 0
+        self._lazy = None
+        self._in_pos = 0
+        self._out_pos = 0
         self.num_deq = num_deq
         self.num_channels = num_channels
         self.dilation = dilation
         self.max_length = max_length
-        self.data = data
+        self._data = data
         self.dtype = dtype
         if data is None:
-            self.data = _zeros(dtype, num_channels, max_length)
+            self._data = _zeros(dtype, num_channels, max_length)
+
+    # -- lazily materialised state
+    def _defer(self, loader):
+        """loader() -> (float32 ndarray (num_channels, max_length), in_pos, out_pos), called at most once."""
+        self._lazy = loader
+
+    def _sync(self):
+        loader, self._lazy = self._lazy, None
+        if loader is not None:
+            data, ip, op = loader()
+            t = torch.from_numpy(np.ascontiguousarray(data, dtype=np.float32))
+            self._data = t.type(self.dtype) if not isinstance(self.dtype, torch.dtype) else t.to(self.dtype)
+            self._in_pos, self._out_pos = int(ip), int(op)
+
+    def _get(name):  # noqa: N805
+        def getter(self):
+            if self._lazy is not None:
+                self._sync()
+            return getattr(self, name)
+
+        def setter(self, value):
+            if self._lazy is not None:
+                self._sync()
+            setattr(self, name, value)
+        return property(getter, setter)
+
+    data = _get("_data")
+    in_pos = _get("_in_pos")
+    out_pos = _get("_out_pos")
+    del _get
+
+    def __getstate__(self):  # pickles carry the reference's attribute names (and no loader)
+        if self._lazy is not None:
+            self._sync()
+        st = {k: v for k, v in self.__dict__.items() if k not in ("_lazy", "_data", "_in_pos", "_out_pos")}
+        st.update(data=self._data, in_pos=self._in_pos, out_pos=self._out_pos)
+        return st
+
+    def __setstate__(self, st):  # also accepts a queue pickled by the reference's own class
+        st = dict(st)
+        self._lazy = None
+        self._data = st.pop("data", st.pop("_data", None))
+        self._in_pos = st.pop("in_pos", st.pop("_in_pos", 0))
+        self._out_pos = st.pop("out_pos", st.pop("_out_pos", 0))
+        st.pop("_lazy", None)
+        self.__dict__.update(st)
 
     def enqueue(self, input):
         self.data[:, self.in_pos] = input.reshape(-1)
@@ -103,6 +155,7 @@ class DilatedQueue:
         return t
 
     def reset(self):
-        self.data = _zeros(self.dtype, self.num_channels, self.max_length)  # rebinds, like the reference (:75)
-        self.in_pos = 0
-        self.out_pos = 0
+        self._lazy = None
+        self._data = _zeros(self.dtype, self.num_channels, self.max_length)  # rebinds, like the reference (:75)
+        self._in_pos = 0
+        self._out_pos = 0

@@ -1,7 +1,8 @@
 """Generates tests/golden/golden_v1.npz by running the REAL reference (/root/reference, through
 oracle/ref_shim.py -- the 3 documented import-time patches, nothing else) in the authoring container.
 
-    python tests/golden/make_golden.py
+    python tests/golden/make_golden.py          # golden_v1.npz
+    python tests/golden/make_golden.py --v2     # golden_v2.npz (cfg2 / cfg3, a few minutes of reference CPU time)
 
 The fixtures pin the oracle (oracle/restated.py, oracle/wn_oracle.c) and, through it, the HIP path.
 Weights are NOT stored: they are regenerated from mi355_wavenet.synth.init_weights(cfg, seed) which is
@@ -35,6 +36,12 @@ GEN_CASES = {
     "cfg1": ("cfg1", 13, 70, 400, 1.0, 0.0, 103),
     "cfg1_seed128": ("cfg1", 14, 1, 200, 1.0, 0.0, 104),  # default first_samples=None -> [128]
 }
+# golden_v2.npz: the 10-layer multi-block BASELINE shapes, n_given > 513 so that the d=512 queues wrap while priming and
+# again while generating.  Same recipe, same stored arrays, a second file so that v1 stays byte-stable.
+GEN_CASES_V2 = {
+    "cfg2": ("cfg2", 15, 640, 320, 1.0, 0.0, 105),
+    "cfg3": ("cfg3", 16, 700, 320, 0.9, 0.0, 106),
+}
 FWD_CASES = {"tiny": ("tiny", 11, 2, 5), "tiny_bias": ("tiny_bias", 12, 3, 4), "cfg1": ("cfg1", 13, 1, 3)}
 
 
@@ -53,6 +60,39 @@ def indices_from_audio(audio, classes=256):
     idx = np.array([int(np.argmin(np.abs(table - a))) for a in audio])
     assert np.array_equal(table[idx], audio)
     return idx
+
+
+def gen_cases(mdl, cases, out):
+    """generate_fast on the sampled branch (the only branch the unmodified reference can run)"""
+    for case, (cname, wseed, n_given, n, temp, regz, npseed) in cases.items():
+        cfg = synth.CONFIGS[cname]
+        m = build_ref_model(mdl, cfg, wseed)
+        fs = None if n_given == 1 else torch.from_numpy(np.random.RandomState(wseed).randint(0, 256, n_given))
+        np.random.seed(npseed)
+        audio = m.generate_fast(n, first_samples=fs, temperature=temp, regularize=regz)
+        idx = indices_from_audio(audio)
+        # per-step logits from the reference's own wavenet(): replay the same index sequence
+        for qq in m.dilated_queues:
+            qq.reset()
+        given = [128] if fs is None else fs.tolist()
+        seq = given + idx.tolist()
+        logits = []
+        for t in range(len(seq) - 1):
+            inp = torch.zeros(1, 256, 1)
+            inp[0, seq[t], 0] = 1.
+            y = m.wavenet(inp, dilation_func=m.queue_dilate).squeeze()
+            if t >= len(given) - 1:
+                logits.append(y.detach().numpy().copy())
+        logits = np.stack(logits)
+        assert logits.shape == (n, 256)
+        out["gen_%s_audio" % case] = audio
+        out["gen_%s_idx" % case] = idx.astype(np.int16)
+        out["gen_%s_first" % case] = np.asarray(given, dtype=np.int16)
+        out["gen_%s_logits" % case] = logits[:: max(1, n // 16)].astype(np.float32)  # 16-ish rows is enough
+        out["gen_%s_logit_rows" % case] = np.arange(n)[:: max(1, n // 16)].astype(np.int32)
+        out["gen_%s_meta" % case] = np.array([wseed, n_given, n, npseed], dtype=np.int64)
+        out["gen_%s_tr" % case] = np.array([temp, regz], dtype=np.float64)
+
 
 
 def main():
@@ -101,35 +141,7 @@ def main():
     xm = torch.linspace(0, 35, steps=36).view(2, 3, 6)
     out["dilate_mc_in"], out["dilate_mc_d4"] = xm.numpy(), wm.dilate(xm, 4).numpy()
 
-    # ---- generate_fast on the sampled branch (the only branch the unmodified reference can run) ----
-    for case, (cname, wseed, n_given, n, temp, regz, npseed) in GEN_CASES.items():
-        cfg = synth.CONFIGS[cname]
-        m = build_ref_model(mdl, cfg, wseed)
-        fs = None if n_given == 1 else torch.from_numpy(np.random.RandomState(wseed).randint(0, 256, n_given))
-        np.random.seed(npseed)
-        audio = m.generate_fast(n, first_samples=fs, temperature=temp, regularize=regz)
-        idx = indices_from_audio(audio)
-        # per-step logits from the reference's own wavenet(): replay the same index sequence
-        for qq in m.dilated_queues:
-            qq.reset()
-        given = [128] if fs is None else fs.tolist()
-        seq = given + idx.tolist()
-        logits = []
-        for t in range(len(seq) - 1):
-            inp = torch.zeros(1, 256, 1)
-            inp[0, seq[t], 0] = 1.
-            y = m.wavenet(inp, dilation_func=m.queue_dilate).squeeze()
-            if t >= len(given) - 1:
-                logits.append(y.detach().numpy().copy())
-        logits = np.stack(logits)
-        assert logits.shape == (n, 256)
-        out["gen_%s_audio" % case] = audio
-        out["gen_%s_idx" % case] = idx.astype(np.int16)
-        out["gen_%s_first" % case] = np.asarray(given, dtype=np.int16)
-        out["gen_%s_logits" % case] = logits[:: max(1, n // 16)].astype(np.float32)  # 16-ish rows is enough
-        out["gen_%s_logit_rows" % case] = np.arange(n)[:: max(1, n // 16)].astype(np.int32)
-        out["gen_%s_meta" % case] = np.array([wseed, n_given, n, npseed], dtype=np.int64)
-        out["gen_%s_tr" % case] = np.array([temp, regz], dtype=np.float64)
+    gen_cases(mdl, GEN_CASES, out)
 
     # ---- forward() ----
     for case, (cname, wseed, N, out_len) in FWD_CASES.items():
@@ -149,5 +161,20 @@ def main():
     print("wrote", path, os.path.getsize(path), "bytes;", len(out), "arrays")
 
 
+def main_v2():
+    mdl, wm, ad = ref_shim.load()
+    out = {}
+    gen_cases(mdl, GEN_CASES_V2, out)
+    path = os.path.join(HERE, "golden_v2.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes;", len(out), "arrays")
+
+
 if __name__ == "__main__":
-    main()
+    if "--v2" in sys.argv:
+        main_v2()
+    elif "--all" in sys.argv:
+        main()
+        main_v2()
+    else:
+        main()

@@ -218,6 +218,53 @@ def test_pickle_snapshot_roundtrip(tmp_path, monkeypatch):
     assert pickle.loads(pickle.dumps(m))._wn_engine is None
 
 
+def test_snapshot_pickled_by_the_reference_class_loads_and_generates(monkeypatch):
+    """torch.save(model) by the REFERENCE's WaveNetModel (its only checkpoint format, wavenet_training.py:84-88) has no
+    end_channels / bias / engine attributes in its __dict__ (wavenet_model.py:42-56) and its DilatedQueue objects carry
+    plain data / in_pos / out_pos: unpickling into this class must still generate."""
+    m, cfg, W = _model("tiny", 66)
+    state = m.__getstate__()
+    for k in ("end_channels", "bias", "_wn_engine", "_wn_engine_key", "_wn_forward_calls", "_wn_train_runner",
+              "_wn_train_calls", "matrix_precision"):
+        state.pop(k)
+    ref_queues = []
+    for q in state["dilated_queues"]:
+        rq = wavenet_modules.DilatedQueue.__new__(wavenet_modules.DilatedQueue)
+        rq.__setstate__(dict(in_pos=0, out_pos=0, num_deq=1, num_channels=q.num_channels, dilation=q.dilation,
+                             max_length=q.max_length, data=torch.zeros(q.num_channels, q.max_length), dtype=torch.FloatTensor))
+        ref_queues.append(rq)
+    state["dilated_queues"] = ref_queues
+    m2 = wavenet_model.WaveNetModel.__new__(wavenet_model.WaveNetModel)
+    m2.__setstate__(state)
+    assert m2.end_channels == cfg["end_channels"] and m2.bias is False and m2._wn_engine is None
+    _inject_emulator(m2, monkeypatch)
+    a = m2.generate_fast(20, temperature=0)
+    idx, _ = c_oracle.generate(cfg, W, 20, None, 0.0, 0.0)
+    assert np.array_equal(a, c_oracle.expand(idx))
+    m3 = pickle.loads(pickle.dumps(m2))   # and our own pickles still round-trip, queues included
+    assert m3.dilated_queues[1].data.shape == (cfg["residual_channels"], 3)
+
+
+def test_dilated_queues_hold_the_final_state_after_generate_fast(monkeypatch):
+    """wavenet_model.py:177-184: generation leaves model.dilated_queues in their final state.  Here the state is read back
+    from the engine lazily (first attribute access)."""
+    import restated
+    m, cfg, W = _model("tiny", 67)
+    _inject_emulator(m, monkeypatch)
+    first = torch.from_numpy(np.random.RandomState(67).randint(0, 256, 12))
+    m.generate_fast(30, first_samples=first, temperature=0)
+    assert all(q._lazy is not None for q in m.dilated_queues)  # nothing downloaded yet
+    r = restated.RestatedWaveNet(cfg, W)
+    r.generate_fast(30, first_samples=first.numpy(), temperature=0.0, return_details=True)
+    for q, rq in zip(m.dilated_queues, r.queues):
+        assert (q.in_pos, q.out_pos) == (rq.in_pos, rq.out_pos)
+        assert np.allclose(q.data.numpy(), rq.data.numpy(), rtol=0, atol=2e-6)
+    m.dilated_queues[0].enqueue(torch.ones(cfg["residual_channels"]))  # still a working DilatedQueue
+    assert float(m.dilated_queues[0].data[0, r.queues[0].in_pos]) == 1.0
+    m.generate_fast(3, temperature=0)  # the next call resets (wavenet_model.py:250-251): 3 evaluations into a 2-slot ring
+    assert [q.in_pos for q in m.dilated_queues] == [3 % q.max_length for q in m.dilated_queues]
+
+
 def test_generate_raises_like_dead_code():
     with pytest.raises(NotImplementedError):
         wavenet_model.WaveNetModel(layers=2, blocks=1).generate(3)

@@ -23,7 +23,8 @@ def _model(cname, seed, **kw):
 
 
 def test_generate_fast_reproduces_reference_golden(golden):
-    for case, cname in (("tiny", "tiny"), ("tiny_bias", "tiny_bias"), ("cfg1", "cfg1"), ("cfg1_seed128", "cfg1")):
+    for case, cname in (("tiny", "tiny"), ("tiny_bias", "tiny_bias"), ("cfg1", "cfg1"), ("cfg1_seed128", "cfg1"),
+                        ("cfg2", "cfg2"), ("cfg3", "cfg3")):
         wseed, n_given, n, npseed = [int(v) for v in golden["gen_%s_meta" % case]]
         temp, regz = [float(v) for v in golden["gen_%s_tr" % case]]
         m, cfg, W = _model(cname, wseed)
@@ -48,6 +49,62 @@ def test_generate_fast_callbacks_and_cuda_module():
     np.random.seed(4)
     idx, _ = c_oracle.generate(cfg, W, 350, first.numpy(), 1.0, 0.0, np.random.random_sample(350))
     assert np.array_equal(a, c_oracle.expand(idx))
+
+
+def test_generate_script_shape_batched_priming_behind_the_drop_in():
+    """/root/reference/generate_script.py:19-33: first_samples = one dataset item (receptive_field + output_length - 1 =
+    5116 samples at cfg3), a progress callback every 1000 steps.  The 5115 priming evaluations run as ONE batched pass
+    (wn_prime) behind generate_fast(); audio equals the oracle's, the callback list equals the reference's, the final
+    queue state is readable from model.dilated_queues like upstream."""
+    import time
+    m, cfg, W = _model("cfg3", 72)
+    rs = np.random.RandomState(72)
+    first = torch.from_numpy(rs.randint(0, 256, 5116))
+    N = 900
+    calls = []
+    np.random.seed(5)
+    with redirect_stdout(io.StringIO()):
+        m.generate_fast(1, first_samples=first[:100], temperature=1.0)  # builds the engine (weight upload) outside the stopwatch
+    np.random.seed(5)
+    t0 = time.perf_counter()
+    with redirect_stdout(io.StringIO()):
+        a = m.generate_fast(N, first_samples=first, temperature=1.0, progress_callback=lambda s, t: calls.append((s, t)),
+                            progress_interval=1000)
+    wall = time.perf_counter() - t0
+    assert m._wn_last_prime_batched
+    total = 5116 + N
+    assert calls == [(i, total) for i in range(5115) if i % 1000 == 0] + [(i + 5116, total) for i in range(N) if (i + 5116) % 1000 == 0]
+    np.random.seed(5)
+    idx, _ = c_oracle.generate(cfg, W, N, first.numpy(), 1.0, 0.0, np.random.random_sample(N))
+    assert np.array_equal(a, c_oracle.expand(idx))
+    # priming cost: the engine alone, stopwatch around wn_prime
+    eng = m._engine(1)
+    eng.reset()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    assert eng.prime_host(first.numpy()[None, :5115])
+    torch.cuda.synchronize()
+    prime_ms = (time.perf_counter() - t0) * 1e3
+    print("generate_script shape: %d given + %d generated in %.1f ms wall; batched priming of 5115 samples %.2f ms" % (5116, N, wall * 1e3, prime_ms))
+    assert prime_ms <= 10.0
+    # queues after generation (wavenet_model.py:177-184): layer 9 (d = 512) holds the last 513 inputs of that layer
+    np.random.seed(5)
+    m.generate_fast(N, first_samples=first, temperature=1.0)
+    q = m.dilated_queues[9]
+    assert q.data.shape == (128, 513) and q.in_pos == q.out_pos == (5115 + N) % 513
+    assert float(q.data.abs().max()) > 0
+
+
+def test_queue_state_after_generation_matches_the_reference_queues():
+    import restated
+    m, cfg, W = _model("tiny", 73)
+    first = torch.from_numpy(np.random.RandomState(73).randint(0, 256, 12))
+    m.generate_fast(40, first_samples=first, temperature=0)
+    r = restated.RestatedWaveNet(cfg, W)
+    r.generate_fast(40, first_samples=first.numpy(), temperature=0.0, return_details=True)
+    for q, rq in zip(m.dilated_queues, r.queues):
+        assert (q.in_pos, q.out_pos) == (rq.in_pos, rq.out_pos)
+        assert np.allclose(q.data.numpy(), rq.data.numpy(), rtol=0, atol=2e-6)
 
 
 def test_forward_on_gpu_matches_golden(golden):

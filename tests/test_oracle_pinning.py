@@ -14,7 +14,8 @@ import ref_shim
 import restated
 from mi355_wavenet import synth
 
-GEN_CASES = {"tiny": "tiny", "tiny_bias": "tiny_bias", "cfg1": "cfg1", "cfg1_seed128": "cfg1"}
+GEN_CASES = {"tiny": "tiny", "tiny_bias": "tiny_bias", "cfg1": "cfg1", "cfg1_seed128": "cfg1",
+             "cfg2": "cfg2", "cfg3": "cfg3"}  # cfg2 / cfg3: golden_v2.npz, 640 / 700 given samples (the d=512 queues wrap)
 LOGIT_TOL = 1e-5  # max|dlogit| <= 1e-5 * max(1, |logits|_inf)   
 
 
