@@ -241,6 +241,7 @@ struct wn_handle {
     WnPlan plan;
     bool have_weights;
     bool pending;
+    bool broken;   // multi-chain front: a launch failed after some chains had started; the chains' queue times diverged -> wn_reset
     void* last_stream;
     long long t_base;  // evaluations since the last reset
     int n_cu, wall_khz;
@@ -494,9 +495,9 @@ extern "C" int wn_create(const wn_config* cfg, wn_handle** out) {
     h->d_status = (uint32_t*)rt_malloc((size_t)(8 + pl.n_wg) * 4);
     if (!h->d_blobs || !h->d_start_t || !h->d_start_b || !h->d_rings || !h->d_dil || !h->d_ring_off || !h->d_wg_map ||
         !h->d_gran || !h->d_status) {
+        const double q_mb = h->ring_floats * 4e-6, g_mb = h->gran_count * 8e-6, w_mb = h->blob_floats * 4e-6;
         wn_destroy(h);
-        return wn_fail(WN_E_NOMEM, "wn_create: device allocation failed (queues %.1f MB, hand-off %.1f MB, weights %.1f MB)",
-                       h->ring_floats * 4e-6, h->gran_count * 8e-6, h->blob_floats * 4e-6);
+        return wn_fail(WN_E_NOMEM, "wn_create: device allocation failed (queues %.1f MB, hand-off %.1f MB, weights %.1f MB)", q_mb, g_mb, w_mb);
     }
     int rc = 0;
     rc = rc ? rc : rt_h2d(h->d_dil, h->dil.data(), (size_t)pl.NL * 4);
@@ -666,6 +667,7 @@ extern "C" int wn_reset(wn_handle* h, void* hip_stream) {
         if (h->pending) { int rc = wn_wait(h); if (rc) return rc; }
         for (wn_handle* c : h->chains) { int rc = wn_reset(c, hip_stream); if (rc) return rc; }
         h->t_base = 0;
+        h->broken = false;
         return WN_OK;
     }
 #ifndef WN_EMU
@@ -715,6 +717,7 @@ extern "C" int wn_generate(wn_handle* h, const wn_generate_args* a) {
         if (!a->first_samples) return wn_fail(WN_E_BADARG, "wn_generate: first_samples is NULL");
         { int rc = rt_hip(hipSetDevice(h->cfg.device_id), "hipSetDevice"); if (rc) return rc; }
         if (h->pending) { int rc = wn_wait(h); if (rc) return rc; }
+        if (h->broken) return wn_fail(WN_E_STATE, "wn_generate: an earlier job failed half way through its chains; call wn_reset");
         hipStream_t user = (hipStream_t)a->hip_stream, side = (hipStream_t)h->side_stream;
         int rc = rt_hip(hipEventRecord((hipEvent_t)h->ev_fork, user), "hipEventRecord");
         rc = rc ? rc : rt_hip(hipStreamWaitEvent(side, (hipEvent_t)h->ev_fork, 0), "hipStreamWaitEvent");
@@ -730,7 +733,19 @@ extern "C" int wn_generate(wn_handle* h, const wn_generate_args* a) {
             b.hip_stream = i % 2 == 0 ? (void*)user : (void*)side;
             if (i == 0 && h->prof_items > 0) { h->chains[0]->prof_items = h->prof_items; h->prof_items = 0; }
             rc = wn_generate(h->chains[i], &b);
-            if (rc) return rc;
+            if (rc) {
+                if (i > 0) {  // chains 0..i-1 are running: drain them, then refuse further jobs until the queues are reset
+                    char msg[sizeof(g_err)];
+                    memcpy(msg, g_err, sizeof(msg));
+                    (void)hipEventRecord((hipEvent_t)h->ev_join, side);
+                    (void)hipStreamWaitEvent(user, (hipEvent_t)h->ev_join, 0);
+                    h->pending = true; h->last_stream = a->hip_stream;
+                    (void)wn_wait(h);
+                    h->broken = true;
+                    memcpy(g_err, msg, sizeof(msg));
+                }
+                return rc;
+            }
         }
         rc = rt_hip(hipEventRecord((hipEvent_t)h->ev_join, side), "hipEventRecord");
         rc = rc ? rc : rt_hip(hipStreamWaitEvent(user, (hipEvent_t)h->ev_join, 0), "hipStreamWaitEvent");

@@ -131,17 +131,21 @@ class WaveNetModel(nn.Module):
         queue.enqueue(input.data[0])
         return queue.dequeue(num_deq=self.kernel_size, dilation=dilation).unsqueeze(0)
 
+    def _native_supported(self):
+        """Shapes the matrix-core kernels cover (wn_forward / wn_train_*): kernel_size 2, channel counts multiples of 32."""
+        return self.kernel_size == 2 and not any(c % 32 for c in (self.residual_channels, self.dilation_channels, self.skip_channels,
+                                                                  self.end_channels, self.classes))
+
     def _native_forward(self, input):
         """Matrix-core forward (C ABI wn_forward, or wn_train_forward + wn_train_backward behind a torch.autograd.Function
         when gradients are wanted) when it applies: CUDA input that is exactly one-hot, every returned position with a full
         receptive field, shapes the GEMM kernels support.  Returns None otherwise -- the caller then runs the torch path,
-        which also reproduces the reference's zero-padding quirk for short inputs."""
-        if not input.is_cuda or input.dim() != 3 or input.size(1) != self.classes or self.kernel_size != 2:
+        which also reproduces the reference's zero-padding quirk for short inputs.  A library that is not built is NOT a
+        reason to fall back: on a CUDA tensor that raises (the product must not run silently without its kernels)."""
+        if not input.is_cuda or input.dim() != 3 or input.size(1) != self.classes or not self._native_supported():
             return None
         n, _, l = input.shape
         if l < self.receptive_field + self.output_length - 1:
-            return None
-        if any(c % 32 for c in (self.residual_channels, self.dilation_channels, self.skip_channels, self.end_channels, self.classes)):
             return None
         want_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
         if torch.is_grad_enabled() and input.requires_grad:
@@ -151,11 +155,17 @@ class WaveNetModel(nn.Module):
         vals, idx = input.max(dim=1)
         if not bool(((vals == 1) & (input.sum(dim=1) == 1)).all()):
             return None  # not a one-hot batch: start_conv is a real contraction
-        if want_grad:
-            return self._native_train_forward(idx)
-        eng = self._engine(1)
-        self._apply_precision(eng)
-        out = eng.forward_indices(idx, self.output_length)
+        from mi355_wavenet import _abi
+        try:
+            if want_grad:
+                return self._native_train_forward(idx)
+            eng = self._engine(1)
+            self._apply_precision(eng)
+            out = eng.forward_indices(idx, self.output_length)
+        except _abi.WnError as e:
+            if e.code == _abi.WN_E_UNSUPPORTED:
+                return None  # e.g. N*L >= 2^31 rows: the torch graph handles it
+            raise
         self._wn_forward_calls = getattr(self, "_wn_forward_calls", 0) + 1
         return out.to(input.dtype)
 
@@ -197,24 +207,36 @@ class WaveNetModel(nn.Module):
         self._apply_precision(runner.eng)
         return training.StackFunction.apply(runner, idx, self.output_length, tuple(names), *tensors)
 
-    def forward_indices(self, indices):
+    def _checked_indices(self, indices, check):
+        idx = torch.as_tensor(indices)
+        if idx.dim() != 2:
+            raise ValueError("indices must be (N, L) class indices")
+        if not self._native_supported():
+            raise ValueError("the index-based forward needs kernel_size 2 and channel counts that are multiples of 32 "
+                             "(residual %d, dilation %d, skip %d, end %d, classes %d)" % (
+                                 self.residual_channels, self.dilation_channels, self.skip_channels, self.end_channels, self.classes))
+        if idx.size(1) < self.receptive_field + self.output_length - 1:
+            raise ValueError("items of %d samples are shorter than receptive_field + output_length - 1 = %d"
+                             % (idx.size(1), self.receptive_field + self.output_length - 1))
+        if check and idx.numel() and (int(idx.min()) < 0 or int(idx.max()) >= self.classes):
+            raise ValueError("class indices outside [0, %d)" % self.classes)  # they address rows of start_conv^T on the GPU
+        return idx
+
+    def forward_indices(self, indices, check=True):
         """Extension: forward() on class indices (N, L) instead of a one-hot (N, classes, L) tensor -- what the
-        dataset holds before audio_data.py:119-121 inflates it 256x.  Inference only (matrix-core path, no autograd)."""
+        dataset holds before audio_data.py:119-121 inflates it 256x.  Inference only (matrix-core path, no autograd).
+        ``check=False`` skips the range check of the indices (one device sync) when the producer guarantees it."""
+        idx = self._checked_indices(indices, check)
         eng = self._engine(1)
         self._apply_precision(eng)
-        out = eng.forward_indices(indices, self.output_length)
+        out = eng.forward_indices(idx, self.output_length)
         self._wn_forward_calls = getattr(self, "_wn_forward_calls", 0) + 1
         return out
 
-    def train_forward_indices(self, indices):
+    def train_forward_indices(self, indices, check=True):
         """Extension: the differentiable forward() on class indices (N, L) -- the training-time sibling of forward_indices:
         logits (N*output_length, classes) whose backward runs natively (see _native_train_forward).  MI355X only."""
-        idx = torch.as_tensor(indices)
-        n, l = idx.shape
-        if l < self.receptive_field + self.output_length - 1:
-            raise ValueError("train_forward_indices: items of %d samples are shorter than receptive_field + output_length - 1 = %d"
-                             % (l, self.receptive_field + self.output_length - 1))
-        return self._native_train_forward(idx)
+        return self._native_train_forward(self._checked_indices(indices, check))
 
     def forward(self, input):
         """(N, classes, L) one-hot -> (N*output_length, classes) logits (wavenet_model.py:186-196)."""

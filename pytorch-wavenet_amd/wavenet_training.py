@@ -99,6 +99,8 @@ class WavenetTrainer:
         if self.device_batches:
             if self._batches is None or self._batches.device != self._device():
                 from audio_data import DeviceBatches
+                if getattr(self.dataset, "classes", 0) > getattr(self.model, "classes", 1 << 30):
+                    raise ValueError("dataset quantised to %d classes, model has %d" % (self.dataset.classes, self.model.classes))
                 self._batches = DeviceBatches(self.dataset, self._device())
             gen = None
             if world > 1:
@@ -112,8 +114,8 @@ class WavenetTrainer:
                 yield "onehot", x, target
 
     def _forward(self, kind, x):
-        if kind == "indices":
-            return self.model.train_forward_indices(x) if torch.is_grad_enabled() else self.model.forward_indices(x)
+        if kind == "indices":  # cut from the dataset's own quantised stream (DeviceBatches): in range by construction
+            return self.model.train_forward_indices(x, check=False) if torch.is_grad_enabled() else self.model.forward_indices(x, check=False)
         return self.model(x)
 
     def train_step(self, kind, x, target):
@@ -128,15 +130,26 @@ class WavenetTrainer:
         self.optimizer.step()
         return loss.item()
 
+    def _loader(self, batch_size, train):
+        """DataLoader over the split selected by ``dataset.train``; data parallel: a DistributedSampler over THAT split
+        (the dataset's length depends on the split, so the sampler is built per split and re-seeded every epoch)."""
+        rank, world = self._rank_world()
+        sampler = None
+        if world > 1:
+            sampler = torch.utils.data.distributed.DistributedSampler(self.dataset, num_replicas=world, rank=rank, shuffle=train,
+                                                                      drop_last=False)
+        loader = torch.utils.data.DataLoader(self.dataset, batch_size=batch_size, shuffle=train and sampler is None, sampler=sampler,
+                                             num_workers=self.num_workers if train else 0, pin_memory=False)
+        return loader, sampler
+
     def train(self, batch_size=32, epochs=10, continue_training_at_step=0):
         self.model.train()
-        rank, world = self._rank_world()
-        sampler = torch.utils.data.distributed.DistributedSampler(self.dataset, num_replicas=world, rank=rank, shuffle=True) if world > 1 else None
-        self.dataloader = torch.utils.data.DataLoader(self.dataset, batch_size=batch_size, shuffle=sampler is None, sampler=sampler,
-                                                      num_workers=self.num_workers, pin_memory=False)
+        self.dataloader, self._sampler = self._loader(batch_size, train=True)
         step = continue_training_at_step
         for current_epoch in range(epochs):
             print("epoch", current_epoch)
+            if self._sampler is not None:
+                self._sampler.set_epoch(current_epoch)  # a new permutation every epoch, the same one on every rank
             tic = time.time()
             for kind, x, target in self._epoch(batch_size, shuffle=True):
                 loss = self.train_step(kind, x, target)
@@ -152,24 +165,50 @@ class WavenetTrainer:
                 self.logger.log(step, loss)
 
     def validate(self):  # :89-112
+        """(average loss per batch, accuracy over the test split).  Data parallel: every rank scores a disjoint shard of the
+        test split (device batches: DeviceBatches.epoch(rank, world); DataLoader path: a sampler over the TEST split, whose
+        wrap-around padding is not counted) and the sums are all-reduced, so every rank returns the global figures."""
         self.model.eval()
         self.dataset.train = False
-        if self.dataloader is None:
-            self.dataloader = torch.utils.data.DataLoader(self.dataset, batch_size=32, shuffle=False, num_workers=0)
-        total_loss = 0
+        rank, world = self._rank_world()
+        train_loader = self.dataloader
+        batch_size = train_loader.batch_size if train_loader is not None else 32
+        n_items = len(self.dataset)
+        budget = None
+        if not self.device_batches:
+            self.dataloader, _ = self._loader(batch_size, train=False)
+            if world > 1:  # the sampler pads every rank to ceil(n/world) items by wrapping around: score only the real ones
+                budget = len(range(rank, n_items, world))
+        total_loss = 0.0
         accurate_classifications = 0
         n_batches = 0
+        n_targets = 0
         with torch.no_grad():
-            for kind, x, target in self._epoch(self.dataloader.batch_size, shuffle=False):
+            for kind, x, target in self._epoch(batch_size, shuffle=False):
+                if budget is not None:
+                    keep = min(budget, x.size(0))
+                    if keep == 0:
+                        break
+                    budget -= keep
+                    x, target = x[:keep], target.view(x.size(0), -1)[:keep].reshape(-1)
                 output = self._forward(kind, x)
                 loss = F.cross_entropy(output.squeeze(), target.squeeze())
                 total_loss += loss.item()
                 predictions = torch.max(output, 1)[1].view(-1)
-                accurate_classifications += torch.sum(torch.eq(target, predictions)).item()
+                accurate_classifications += torch.sum(torch.eq(target.view(-1), predictions)).item()
                 n_batches += 1
+                n_targets += target.numel()
+        if world > 1:
+            import torch.distributed as dist
+            dev = self._device() if dist.get_backend(self.process_group) == "nccl" else torch.device("cpu")
+            sums = torch.tensor([total_loss, float(n_batches), float(accurate_classifications), float(n_targets)], dtype=torch.float64, device=dev)
+            dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=self.process_group)
+            total_loss, n_batches, accurate_classifications, n_targets = (float(v) for v in sums.tolist())
         avg_loss = total_loss / max(n_batches, 1)
-        avg_accuracy = accurate_classifications / (len(self.dataset) * self.dataset.target_length)
+        # upstream divides by len(dataset) * target_length (:109); that is n_targets whenever the whole split was scored
+        avg_accuracy = accurate_classifications / max(n_targets, 1)
         self.dataset.train = True
+        self.dataloader = train_loader
         self.model.train()
         return avg_loss, avg_accuracy
 

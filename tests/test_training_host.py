@@ -258,3 +258,69 @@ def test_data_parallel_world2_equals_single_process_on_the_global_batch():
     for k, v in m.state_dict().items():
         assert np.array_equal(got[0][k], got[1][k]), k          # the ranks stay in lock step
         assert np.allclose(got[0][k], v.numpy(), rtol=1e-5, atol=1e-7), k  # and follow the single-process run on the whole batch
+
+
+def _dp_validate_worker(rank, world, port, q, ds_path):
+    for p in (os.path.join(ROOT, "pytorch-wavenet_amd"), HERE):
+        sys.path.insert(0, p)
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    m = _tiny_model(seed=4)
+    il = m.receptive_field + m.output_length - 1
+    ds = audio_data.WavenetDataset(ds_path, item_length=il, target_length=8, test_stride=5)
+    seen = []
+
+    class Stop(Exception):
+        pass
+
+    class Rec(model_logging.Logger):
+        def log(self, step, loss):
+            if step == 4:
+                raise Stop()
+
+    tr = wavenet_training.WavenetTrainer(m, ds, optimizer=torch.optim.SGD, lr=0.0, logger=Rec(), num_workers=0)
+    orders = []
+    for epoch_run in range(2):  # the sampler's permutation must change from epoch to epoch (set_epoch)
+        tr.dataloader, tr._sampler = tr._loader(4, train=True)
+        tr._sampler.set_epoch(epoch_run)
+        orders.append(list(iter(tr._sampler))[:6])
+    try:
+        tr.train(batch_size=4, epochs=1)
+    except Stop:
+        pass
+    res = tr.validate()
+    q.put((rank, res, orders, len(ds), ds.train))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_validate_scores_the_test_split_once(dataset_file):
+    """with a DistributedSampler the old validate() walked a train-sized, wrapped-around index list and divided
+    by the full test length.  Now: a sampler over the TEST split, padding not scored, sums all-reduced -- both ranks return
+    the figures of a single-process validate() on the same weights (lr = 0: the weights never move)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29700 + os.getpid() % 1000
+    procs = [ctx.Process(target=_dp_validate_worker, args=(r, 2, port, q, dataset_file)) for r in range(2)]
+    [p.start() for p in procs]
+    got = dict((r, rest) for r, *rest in (q.get(timeout=240) for _ in range(2)))
+    [p.join(60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    m = _tiny_model(seed=4)
+    il = m.receptive_field + m.output_length - 1
+    ds = audio_data.WavenetDataset(dataset_file, item_length=il, target_length=8, test_stride=5)
+    tr = wavenet_training.WavenetTrainer(m, ds, optimizer=torch.optim.SGD, lr=0.0, num_workers=0)
+    tr.dataloader, tr._sampler = tr._loader(4, train=True)
+    loss1, acc1 = tr.validate()
+    for r in (0, 1):
+        (loss, acc), orders, n_train, train_flag = got[r]
+        assert train_flag is True and n_train == len(ds)
+        assert 0.0 <= acc <= 1.0 and abs(acc - acc1) < 1e-12          # same correct-count / same target count
+        assert orders[0] != orders[1]                                   # a new permutation per epoch
+    assert got[0][0] == got[1][0]                                       # all-reduced: identical on both ranks
+    # the per-batch mean of batch-mean losses depends on how the items fall into batches; bound it by the spread
+    assert abs(got[0][0][0] - loss1) < 0.05 * max(1.0, abs(loss1))
