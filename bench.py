@@ -3,12 +3,17 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg3x64] [--samples 2000]
 
-A "step" is one generate_fast()-shaped job: every stream of the workload generates ``--samples`` audio samples
-(queue reset + ONE wn_generate job = one persistent kernel per chain, the chains running concurrently; temperature 1.0,
-host-drawn uniforms, inputs resident in HBM).
+A "step" is one ``WaveNetModel.generate_fast(--samples, first_samples=(streams, 1), temperature=1.0)`` call per GPU: every
+stream of the workload generates ``--samples`` audio samples.  Two legs are timed with the same K / W:
+  * facade (the headline ``value``): wall clock around the Python call -- uniform draw, H2D, queue reset, the persistent
+    kernels, D2H, mu-law expansion;
+  * engine_level: the same job through the C ABI with inputs and outputs resident in HBM (one wn_generate per step), with
+    HIP events around the launch for the roofline figure.
 ``value`` = audio samples/s summed over all streams and all GPUs.  N > 1: one process per GPU (torchrun), streams
-sharded across ranks with no data-path collective; the finished index blocks are gathered to rank 0 over RCCL inside
-the timed region (that is the job's only exchange step).  Prints ONE JSON line on rank 0.
+sharded across ranks with no data-path collective; the finished blocks are gathered to rank 0 over RCCL inside
+the timed region (that is the job's only exchange step); per-rank kernel and gather times are reported.
+``verified``: the last timed buffer of both legs re-checked against the C oracle (300 samples of two streams).
+Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -31,31 +36,50 @@ WORKLOADS = {  # name -> (BASELINE.json config, streams per GPU)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 
 
-def time_workload(cfgname, n_streams, samples, steps, warmup, dist, device):
+def _rank_stats(dist, kernel_ms, gather_ms, facade_ms=None):
+    """Per-rank timings collected on rank 0 (so that a scaling run explains itself): [{rank, kernel_ms, gather_ms, ...}]."""
+    mine = {"rank": dist.get_rank() if dist else 0, "kernel_ms": round(kernel_ms, 3), "gather_ms": round(gather_ms, 3)}
+    if facade_ms is not None:
+        mine["facade_ms"] = round(facade_ms, 3)
+    if not dist:
+        return [mine]
+    everyone = [None] * dist.get_world_size()
+    dist.all_gather_object(everyone, mine)
+    return everyone
+
+
+def time_engine(cfgname, n_streams, samples, steps, warmup, dist, device):
+    """Engine-level leg: one wn_generate job per step through the C ABI with every input already resident in HBM (first
+    samples, host-drawn uniforms) and the indices left in HBM; N > 1: the finished index blocks are gathered to rank 0 over
+    RCCL inside the timed region.  HIP events on the launch stream bracket the job (kernel_ms) and the gather (gather_ms)."""
     from mi355_wavenet import engine, synth
     cfg = synth.CONFIGS[cfgname]
     W = synth.init_weights(cfg, seed=0)
     eng = engine.Engine(cfg, W, n_streams=n_streams, device_index=device)
-    rs = np.random.RandomState(1234 + (dist.get_rank() if dist else 0))
-    first = eng.mem.upload(np.full((n_streams, 1), 128, dtype=np.int32))
-    uni = eng.mem.upload(rs.random_sample((n_streams, samples)))
+    rank = dist.get_rank() if dist else 0
+    rs = np.random.RandomState(1234 + rank)
+    first_h = np.full((n_streams, 1), 128, dtype=np.int32)
+    uni_h = rs.random_sample((n_streams, samples))
+    first = eng.mem.upload(first_h)
+    uni = eng.mem.upload(uni_h)
     out = eng.mem.empty((n_streams, samples), np.int32)
     gathered = None
-    if dist and dist.get_rank() == 0:
+    if dist and rank == 0:
         gathered = [torch.empty_like(out) for _ in range(dist.get_world_size())]
 
-    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
-    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(steps)] for _ in range(3)]
 
     def one_step(i=None):
         eng.reset()
         if i is not None:
-            ev0[i].record()
+            ev[0][i].record()
         eng.launch(first, 1, samples, 1.0, None, uni, out, None, timeout_ms=20000)
         if i is not None:
-            ev1[i].record()
+            ev[1][i].record()
         if dist:
             dist.gather(out, gathered, dst=0)
+        if i is not None:
+            ev[2][i].record()
 
     for _ in range(warmup):
         one_step()
@@ -71,12 +95,85 @@ def time_workload(cfgname, n_streams, samples, steps, warmup, dist, device):
     if dist:
         dist.barrier()
     t1 = time.perf_counter()
-    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev[0], ev[1])]))
+    gather_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev[1], ev[2])]))
     info = eng.info()
     idx = out.cpu().numpy()
-    assert idx.min() >= 0 and idx.max() < 256
     eng.close()
-    return t1 - t0, kernel_ms, info, cfg
+    return {"wall": t1 - t0, "kernel_ms": kernel_ms, "gather_ms": gather_ms, "info": info, "cfg": cfg, "W": W,
+            "last_idx": idx, "first": first_h, "uniforms": uni_h}
+
+
+def time_facade(cfgname, n_streams, samples, steps, warmup, dist, device):
+    """Facade leg -- what the metric names: WaveNetModel.generate_fast(samples, first_samples=(streams, 1), temperature=1.0)
+    per step, wall clock around the Python call: the uniform draw from the global numpy RNG, the H2D of first samples and
+    uniforms, queue reset, the persistent-kernel jobs (the reference's contract cuts the job after generating step 100 for its
+    timing print: two launches per call), the D2H of the indices and the mu-law expansion to float64 audio.
+    N > 1: the finished audio of every rank is gathered to rank 0 over RCCL inside the timed region."""
+    import contextlib
+    import io
+    import wavenet_model
+    from mi355_wavenet import synth
+    cfg = synth.CONFIGS[cfgname]
+    W = synth.init_weights(cfg, seed=0)
+    m = wavenet_model.WaveNetModel(output_length=1, **cfg)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in W.items()})
+    m = m.cuda(device)
+    rank = dist.get_rank() if dist else 0
+    first = torch.full((n_streams, 1), 128, dtype=torch.int64)
+    sink = io.StringIO()
+    gathered = None
+    dev = torch.device("cuda", device)
+    if dist and rank == 0:
+        gathered = [torch.empty((n_streams, samples), dtype=torch.float64, device=dev) for _ in range(dist.get_world_size())]
+    audio = None
+
+    def one_step(seed=None):
+        nonlocal audio
+        if seed is not None:
+            np.random.seed(seed)
+        with contextlib.redirect_stdout(sink):
+            audio = m.generate_fast(samples, first_samples=first, temperature=1.0)
+        if dist:
+            dist.gather(torch.from_numpy(audio).to(dev), gathered, dst=0)
+
+    for _ in range(max(warmup, 1)):
+        one_step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        one_step(seed=4321 + 100 * rank + i)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    t1 = time.perf_counter()
+    # the uniforms generate_fast drew in the LAST step: same seed, same draw shapes ((streams, 100) then (streams, rest))
+    np.random.seed(4321 + 100 * rank + steps - 1)
+    cut = 100 if samples >= 100 else samples
+    u = np.random.random_sample((n_streams, cut))
+    if samples > cut:
+        u = np.concatenate([u, np.random.random_sample((n_streams, samples - cut))], axis=1)
+    return {"wall": t1 - t0, "cfg": cfg, "W": W, "last_audio": audio, "first": first.numpy(), "uniforms": u}
+
+
+def verify_against_oracle(cfg, W, first, uniforms, idx=None, audio=None, streams=(0, -1), n=300):
+    """Re-runs the C oracle (oracle/wn_oracle.c -- the checker, never the thing measured) for the first n samples of two
+    streams of the buffer that was just timed: True iff the indices (or the expanded audio) are identical."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import c_oracle
+    ok = True
+    ns = first.shape[0]
+    for s in streams:
+        s = s % ns
+        n_s = min(n, uniforms.shape[1])
+        o_idx, _ = c_oracle.generate(cfg, W, n_s, first[s], 1.0, 0.0, uniforms[s, :n_s], want_logits=False)
+        if idx is not None:
+            ok = ok and bool(np.array_equal(idx[s, :n_s], o_idx))
+        if audio is not None:
+            ok = ok and bool(np.array_equal(audio[s, :n_s], c_oracle.expand(o_idx)))
+    return ok
 
 
 def train_step_cfg5(device, N=32, L=16000, reps=3):
@@ -216,6 +313,9 @@ def cpu_baseline(cfgname, budget_s=10.0):
             break
     torch.set_num_threads(default_threads)
     return {"value": round(best[0], 2), "unit": "samples/s", "cores": int(best[1]), "kind": "port",
+            "kind_rationale": "the reference tree (/root/reference, pure Python) does not exist on the GPU box; oracle/restated.py "
+                              "replays its ATen op sequence and is pinned bit-equal to the real reference's generate_fast() "
+                              "(tests/test_oracle_pinning.py, fixtures from tests/golden/make_golden.py)",
             "sample": "%s single stream, %d samples of generate_fast(temperature=1.0) through oracle/restated.py "
                       "(op-for-op torch restatement of the reference's CPU path; best of 1 and %d torch threads, "
                       "host has %d logical cores)" % (cfgname, best[2], default_threads, os.cpu_count())}
@@ -229,6 +329,9 @@ def main():
     ap.add_argument("--workload", default="cfg3x64", choices=sorted(WORKLOADS) + ["train5"],
                     help="train5: BASELINE configs[4], the data-parallel training step (global batch 32, strong scaling)")
     ap.add_argument("--samples", type=int, default=2000, help="audio samples per stream per step")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: the workload's streams PER GPU (64 for cfg3x64); strong: BASELINE configs[3], 512 streams in total "
+                         "sharded over the GPUs (512 / N per GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
     a = ap.parse_args()
@@ -243,6 +346,8 @@ def main():
         torch.cuda.set_device(local)
         dist_mod.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
         dist = dist_mod
+        from mi355_wavenet import streams
+        streams.pick_device(dist, local, torch.cuda.device_count())  # refuses two ranks on one GPU
     else:
         torch.cuda.set_device(local)
     n_gpus = world if world > 1 else 1
@@ -253,45 +358,70 @@ def main():
         train5_main(a, dist, rank, local, n_gpus)
         return
     cfgname, per_gpu = WORKLOADS[a.workload]
-    wall, kernel_ms, info, cfg = time_workload(cfgname, per_gpu, a.samples, a.steps, a.warmup, dist, local)
+    if a.scaling == "strong":
+        from mi355_wavenet import streams
+        lo, hi = streams.shard_bounds(512, rank, n_gpus)
+        per_gpu = hi - lo
+    eng_leg = time_engine(cfgname, per_gpu, a.samples, a.steps, a.warmup, dist, local)
+    fac_leg = time_facade(cfgname, per_gpu, a.samples, a.steps, a.warmup, dist, local)
+    verified = verify_against_oracle(eng_leg["cfg"], eng_leg["W"], eng_leg["first"], eng_leg["uniforms"], idx=eng_leg["last_idx"]) and \
+        verify_against_oracle(fac_leg["cfg"], fac_leg["W"], fac_leg["first"], fac_leg["uniforms"], audio=fac_leg["last_audio"])
+    walls = [eng_leg["wall"], fac_leg["wall"], 0.0 if verified else 1.0]
     if dist:
-        t = torch.tensor([wall], device="cuda", dtype=torch.float64)
+        t = torch.tensor(walls, device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall = float(t.item())
+        walls = [float(v) for v in t.tolist()]
+    per_rank = _rank_stats(dist, eng_leg["kernel_ms"], eng_leg["gather_ms"], fac_leg["wall"] / a.steps * 1e3)
     if rank != 0:
         if dist:
             dist.destroy_process_group()
         return
+    eng_wall, fac_wall, any_bad = walls
+    kernel_ms, info, cfg = eng_leg["kernel_ms"], eng_leg["info"], eng_leg["cfg"]
 
     from mi355_wavenet import synth
-    total_samples = n_gpus * per_gpu * a.samples * a.steps
-    value = total_samples / wall
+    total_streams = 512 if a.scaling == "strong" else n_gpus * per_gpu
+    total_samples = total_streams * a.samples * a.steps
+    engine_value = total_samples / eng_wall
+    facade_value = total_samples / fac_wall
+    value, wall = facade_value, fac_wall  # the metric names generate_fast(): the facade's figure is the headline
     bytes_per_tstep = synth.algorithmic_bytes_per_step(cfg, per_gpu)   # W_touched + streams*(Q+8)
     bytes_per_launch = bytes_per_tstep * a.samples
     achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
     traffic = None
     pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, committed
-    if os.path.exists(pmc_path):
+    if os.path.exists(pmc_path) and a.scaling == "weak":
         pmc = json.load(open(pmc_path)).get(a.workload)
         if pmc:  # hand-off traffic is linear in the number of timesteps: scale to this launch
             traffic = int((pmc["fetch_kib"] + pmc["write_kib"]) * 1024 * a.samples / pmc["samples_per_launch"])
+    kname = {1: "wn_generate_kernel", 2: "wn_generate_kernel_v2m" if per_gpu > 1 else "wn_generate_kernel_v2",
+             3: "wn_generate_kernel_v3"}.get(info["kernel_variant"], "?")
     line = {
         "metric": "generate_fast() audio samples/sec (256-class mu-law), whole job over all GPUs",
         "value": round(value, 1), "unit": "samples/s", "n_gpus": n_gpus, "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": round(wall / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic (seeded random weights, host-drawn uniforms)",
-        "config": {"workload": "%s: WaveNetModel(%s), %d independent streams per GPU x %d samples per step, "
-                               "temperature 1.0" % (a.workload, ", ".join("%s=%s" % kv for kv in cfg.items()), per_gpu, a.samples),
+        "ms_per_step": round(wall / a.steps * 1e3, 3), "higher_is_better": True, "scaling": a.scaling,
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic (seeded random weights, uniforms from the global numpy RNG)",
+        "verified": bool(verified and any_bad == 0.0),
+        "config": {"workload": "%s: WaveNetModel(%s).generate_fast(%d, first_samples=(%d, 1), temperature=1.0) per GPU per step"
+                               % (a.workload, ", ".join("%s=%s" % kv for kv in cfg.items()), a.samples, per_gpu),
                    "streams_per_gpu": per_gpu, "samples_per_stream_per_step": a.samples,
-                   "per_stream_samples_per_s": round(value / (n_gpus * per_gpu), 1),
+                   "per_stream_samples_per_s": round(value / total_streams, 1),
+                   "timed": "wall clock around the facade call: RNG draw, H2D, queue reset, kernels, D2H, mu-law expansion"
+                            + ("; + RCCL gather of the audio to rank 0" if n_gpus > 1 else ""),
                    "chain": {k: info[k] for k in ("kernel_variant", "n_chains", "layer_split", "head_split", "n_workgroups", "lds_bytes")}},
+        "engine_level": {"value": round(engine_value, 1), "ms_per_step": round(eng_wall / a.steps * 1e3, 3),
+                         "note": "the same job through the C ABI with inputs and outputs resident in HBM (one wn_generate per step"
+                                 + ("; + RCCL gather of the index blocks" if n_gpus > 1 else "") + ")",
+                         "facade_over_engine": round(fac_wall / eng_wall, 4)},
+        "per_rank": per_rank,
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                     "kernel": ("wn_generate_kernel_v2m" if per_gpu > 1 else "wn_generate_kernel_v2") if info["kernel_variant"] == 2 else "wn_generate_kernel", "kernel_ms_per_launch": round(kernel_ms, 3),
+                     "kernel": kname, "kernel_ms_per_launch": round(kernel_ms, 3),
                      "algorithmic_bytes_per_launch": int(bytes_per_launch),
                      "algorithmic_bytes_per_timestep": int(bytes_per_tstep), "launches_per_step": 1,
-                     "note": "one launch = one wn_generate job: n_chains persistent kernels running CONCURRENTLY (two per CU), timed "
-                             "together with HIP events on the launch stream; rocprofv3 lists them as n_chains overlapping dispatches"},
+                     "note": "engine-level leg: one launch = one wn_generate job of %d timesteps: n_chains persistent kernels running "
+                             "CONCURRENTLY, timed together with HIP events on the launch stream; rocprofv3 lists them as n_chains "
+                             "overlapping dispatches" % a.samples},
     }
     if n_gpus == 1 and not a.no_extra:
         extra = {}
@@ -299,12 +429,16 @@ def main():
             if wl == a.workload:
                 continue
             c2, s2 = WORKLOADS[wl]
-            w2, k2, i2, cf2 = time_workload(c2, s2, 8000, 2, 1, None, local)
-            extra[wl] = {"samples_per_s": round(2 * 8000 * s2 / w2, 1), "kernel_ms_per_launch": round(k2, 3),
-                         "hbm_frac": round(synth.algorithmic_bytes_per_step(cf2, s2) * 8000 / (k2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                         "n_workgroups": i2["n_workgroups"]}
+            leg = time_engine(c2, s2, 8000, 2, 1, None, local)
+            extra[wl] = {"samples_per_s": round(2 * 8000 * s2 / leg["wall"], 1), "kernel_ms_per_launch": round(leg["kernel_ms"], 3),
+                         "hbm_frac": round(synth.algorithmic_bytes_per_step(leg["cfg"], s2) * 8000 / (leg["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                         "n_workgroups": leg["info"]["n_workgroups"],
+                         "verified": verify_against_oracle(leg["cfg"], leg["W"], leg["first"], leg["uniforms"], idx=leg["last_idx"], streams=(0,))}
         line["extra"] = extra
-    if n_gpus == 1 and not a.no_extra:
+        try:
+            line["extra"]["prime_generate_script_shape"] = prime_timing(local)
+        except Exception as e:  # noqa: BLE001
+            line["extra"]["prime_generate_script_shape"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
         try:
             line["extra"]["train_cfg5"] = train_step_cfg5(local)
         except Exception as e:  # noqa: BLE001 -- the secondary measurement must never cost the headline line
@@ -314,6 +448,27 @@ def main():
     print(json.dumps(line))
     if dist:
         dist.destroy_process_group()
+
+
+def prime_timing(device):
+    """generate_script.py's call shape (/root/reference/generate_script.py:19-33): 5116 given samples at cfg3.  Time of the
+    batched priming pass (wn_prime) next to the same priming through the per-sample chain."""
+    from mi355_wavenet import engine, synth
+    cfg = synth.CONFIGS["cfg3"]
+    W = synth.init_weights(cfg, seed=0)
+    eng = engine.Engine(cfg, W, n_streams=1, device_index=device)
+    first = np.random.RandomState(7).randint(0, 256, (1, 5116))
+    out = {}
+    for name, batched in (("batched_ms", True), ("chain_ms", False)):
+        eng.generate(1, first, temperature=0.0, batched_prime=batched)  # warm (workspace allocation)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        eng.generate(1, first, temperature=0.0, batched_prime=batched)
+        torch.cuda.synchronize()
+        out[name] = round((time.perf_counter() - t0) * 1e3, 3)
+    eng.close()
+    out["given_samples"] = 5116
+    return out
 
 
 if __name__ == "__main__":

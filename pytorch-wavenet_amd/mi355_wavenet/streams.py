@@ -5,6 +5,9 @@ NO collective on the data path: one process per GPU (torch.distributed, backend 
 runs its block of streams on its own engine, and the only exchange is the gather of the finished class-index blocks to
 rank 0.  A single stream cannot be sharded (52 dependent hops per sample): replicas only.
 """
+import os
+import socket
+
 import numpy as np
 
 
@@ -15,10 +18,35 @@ def shard_bounds(n_total, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def pick_device(dist=None, device_index=None, n_devices=None):
+    """The HIP device of this rank: ``device_index`` when given, else LOCAL_RANK (torchrun), else rank modulo the visible
+    devices.  With a process group the choice is checked across ranks: two ranks of one host on the same device would
+    silently serialise on it (and share its 256 CUs between two persistent chains that each assume the whole chip)."""
+    if device_index is None:
+        if "LOCAL_RANK" in os.environ:
+            device_index = int(os.environ["LOCAL_RANK"])
+        elif dist is not None:
+            device_index = dist.get_rank() % max(1, n_devices or 1)
+        else:
+            device_index = 0
+    if n_devices is not None and not (0 <= device_index < n_devices):
+        raise RuntimeError("rank wants HIP device %d but only %d are visible" % (device_index, n_devices))
+    if dist is not None and dist.get_world_size() > 1:
+        mine = (socket.gethostname(), int(device_index))
+        everyone = [None] * dist.get_world_size()
+        dist.all_gather_object(everyone, mine)
+        clash = sorted(r for r, v in enumerate(everyone) if everyone.count(v) > 1)
+        if clash:
+            raise RuntimeError("ranks %s share HIP device %d on %s: launch one process per GPU (torchrun sets LOCAL_RANK) or pass "
+                               "device_index" % (clash, everyone[clash[0]][1], everyone[clash[0]][0]))
+    return device_index
+
+
 def generate_streams(cfg, weights, first_samples, num_samples, temperature=1.0, regularize=0.0, uniforms=None,
                      dist=None, device_index=None, lib=None):
     """first_samples (S, n_given) ints, uniforms (S, num_samples) float64 or None (greedy).
-    Returns int32 (S, num_samples) on rank 0 (and on every rank when dist is None), else None."""
+    Returns int32 (S, num_samples) on rank 0 (and on every rank when dist is None), else None.
+    device_index: this rank's HIP device (default: LOCAL_RANK; checked for collisions across ranks, see pick_device)."""
     from . import engine
     first_samples = np.asarray(first_samples)
     S = first_samples.shape[0]
@@ -26,9 +54,12 @@ def generate_streams(cfg, weights, first_samples, num_samples, temperature=1.0, 
     world = dist.get_world_size() if dist is not None else 1
     lo, hi = shard_bounds(S, rank, world)
     mine = None
+    if lib is None or not lib.host_memory:
+        import torch
+        device_index = pick_device(dist, device_index, torch.cuda.device_count())
+    elif device_index is None:
+        device_index = 0  # host-memory test double: no device
     if hi > lo:
-        if device_index is None:
-            device_index = 0
         eng = engine.Engine(cfg, weights, n_streams=hi - lo, device_index=device_index, lib=lib)
         u = None if uniforms is None else np.asarray(uniforms)[lo:hi]
         mine = eng.generate(num_samples, first_samples[lo:hi], temperature=temperature, regularize=regularize, uniforms=u)

@@ -349,11 +349,28 @@ class WaveNetModel(nn.Module):
                 elif (ev - n_prime + num_given) % progress_interval == 0:
                     progress_callback(ev - n_prime + num_given, total_samples)
         idx = np.concatenate(pieces, axis=1) if pieces else np.zeros((n_streams, 0), dtype=np.int32)
-        generated = (idx.astype(np.int64) / self.classes) * 2. - 1  # :296
         self._defer_queues(eng)
         self.train()
-        mu_gen = mu_law_expansion(generated, self.classes)  # :314
+        mu_gen = self._expand_indices(idx)  # :296, :314
         return mu_gen if batched else mu_gen[0]
+
+    def _expand_indices(self, idx):
+        """Class indices -> float64 audio: ``o = idx / classes * 2 - 1`` (wavenet_model.py:296) then ``mu_law_expansion(o)``
+        (:314, audio_data.py:156-158).  Both are elementwise, so the 256 possible results are computed once with the very
+        same numpy expressions and looked up (10 ms -> 0.3 ms per 128 k samples); the table is checked once against the
+        elementwise evaluation on a probe that puts every class at shifted array positions."""
+        classes = self.classes
+        tab = getattr(self, "_wn_expansion", None)
+        if tab is None or tab[0] != classes:
+            every = np.arange(classes, dtype=np.int64)
+            table = mu_law_expansion((every / classes) * 2. - 1, classes)
+            probe = np.concatenate([every[3:], every[::-1], every[:5]])
+            ok = bool(np.array_equal(table[probe], mu_law_expansion((probe / classes) * 2. - 1, classes)))
+            tab = self._wn_expansion = (classes, table if ok else None)
+        idx = np.asarray(idx).astype(np.int64)
+        if tab[1] is None:
+            return mu_law_expansion((idx / classes) * 2. - 1, classes)
+        return tab[1][idx]
 
     def _defer_queues(self, eng, stream=0):
         """The reference leaves model.dilated_queues in their final state (wavenet_model.py:177-184).  Here that state is on
@@ -388,10 +405,9 @@ class WaveNetModel(nn.Module):
                 uniforms[k] = np.random.random_sample(num_samples)
         idx = eng.generate(num_samples, first, temperature=np.asarray(temps, dtype=np.float32), regularize=regularize,
                            uniforms=uniforms if any(t > 0 for t in temps) else None)
-        generated = (idx.astype(np.int64) / self.classes) * 2. - 1
         self._defer_queues(eng, stream=len(temps) - 1)  # sequential calls would leave the LAST temperature's queues
         self.train()
-        return mu_law_expansion(generated, self.classes)
+        return self._expand_indices(idx)
 
     # ------------------------------------------------------------------ bookkeeping
     def parameter_count(self):
@@ -409,6 +425,7 @@ class WaveNetModel(nn.Module):
         state["_wn_engine"] = None
         state["_wn_engine_key"] = None
         state["_wn_train_runner"] = None
+        state.pop("_wn_expansion", None)
         return state
 
     def __setstate__(self, state):

@@ -1,0 +1,108 @@
+"""-m gpu, needs >= 2 GPUs (skipped otherwise): the N > 1 path on the real backend -- two ranks, backend "nccl" (= RCCL over
+xGMI), streams sharded by mi355_wavenet.streams, the finished index blocks gathered to rank 0 -- against the oracle; and
+bench.py launched the way the driver launches it (python -m torch.distributed.run --nproc-per-node 2).  On a 1-GPU box only
+the device-collision guard is exercised (two ranks on one device must be refused, not silently serialised)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+pytestmark = pytest.mark.gpu
+
+two_gpus = pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs 2 GPUs")
+
+
+def _env():
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["PYTHONPATH"] = os.pathsep.join([os.path.join(ROOT, "pytorch-wavenet_amd"), os.path.join(ROOT, "oracle"), HERE, env.get("PYTHONPATH", "")])
+    return env
+
+
+WORKER = r"""
+import os, sys, json
+import numpy as np, torch
+import torch.distributed as dist
+local = int(os.environ["LOCAL_RANK"])
+forced = os.environ.get("WN_TEST_FORCE_DEVICE")
+torch.cuda.set_device(local if forced is None else int(forced))
+backend = os.environ.get("WN_TEST_BACKEND", "nccl")
+if backend == "nccl":
+    dist.init_process_group(backend="nccl", device_id=torch.device("cuda", torch.cuda.current_device()))
+else:
+    dist.init_process_group(backend="gloo")
+from mi355_wavenet import streams, synth
+cfg = synth.CONFIGS["cfg2"]
+W = synth.init_weights(cfg, seed=91)
+rs = np.random.RandomState(91)
+S, N = 7, 120   # odd: ranks get 4 and 3 streams
+first = rs.randint(0, 256, (S, 9))
+u = rs.random_sample((S, N))
+try:
+    out = streams.generate_streams(cfg, W, first, N, temperature=1.0, uniforms=u, dist=dist,
+                                   device_index=None if forced is None else int(forced))
+except RuntimeError as e:
+    print("REFUSED:", e)
+    dist.destroy_process_group()
+    sys.exit(0)
+if dist.get_rank() == 0:
+    np.save(os.environ["WN_TEST_OUT"], out)
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def _run(tmp_path, extra_env, nproc=2):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = _env()
+    env.update(extra_env)
+    env["WN_TEST_OUT"] = str(tmp_path / "out.npy")
+    port = 29800 + os.getpid() % 1000
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(script)]
+    return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600), env["WN_TEST_OUT"]
+
+
+@two_gpus
+def test_two_ranks_over_rccl_match_the_oracle(tmp_path):
+    import c_oracle
+    from mi355_wavenet import synth
+    res, out_path = _run(tmp_path, {})
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    out = np.load(out_path)
+    cfg = synth.CONFIGS["cfg2"]
+    W = synth.init_weights(cfg, seed=91)
+    rs = np.random.RandomState(91)
+    first = rs.randint(0, 256, (7, 9))
+    u = rs.random_sample((7, 120))
+    for s in range(7):
+        idx, _ = c_oracle.generate(cfg, W, 120, first[s], 1.0, 0.0, u[s])
+        assert np.array_equal(out[s], idx), s
+
+
+def test_two_ranks_on_one_device_are_refused(tmp_path):
+    """streams.pick_device: both ranks forced onto device 0 (gloo rendezvous so that it also runs on a 1-GPU box)."""
+    res, _ = _run(tmp_path, {"WN_TEST_FORCE_DEVICE": "0", "WN_TEST_BACKEND": "gloo"})
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    assert res.stdout.count("REFUSED:") == 2 and "share HIP device 0" in res.stdout
+
+
+@two_gpus
+def test_bench_two_gpus_as_the_driver_launches_it():
+    port = 29900 + os.getpid() % 1000
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--samples", "400"]
+    res = subprocess.run(cmd, env=_env(), capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    line = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0
+    assert len(line["per_rank"]) == 2 and all(r["kernel_ms"] > 0 for r in line["per_rank"])
+    assert line["verified"] is True
