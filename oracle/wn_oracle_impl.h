@@ -40,19 +40,62 @@ static void FN(conv)(const float *w, const float *b, int O, int I, int k, const 
     }
 }
 
-int FN(wno_generate)(const wno_config *c, const wno_weights *w, const int32_t *first_samples, int64_t n_given,
-                     int64_t num_samples, double temperature, const float *regularizer, const double *uniforms,
-                     const int32_t *forced, int32_t *out_idx, REAL *out_logits) {
-    const int R = c->residual_channels, D = c->dilation_channels, S = c->skip_channels, E = c->end_channels;
-    const int C = c->classes, k = c->kernel_size, NL = c->layers * c->blocks;
-    if (k < 1 || n_given < 1 || NL < 1) return -1;
-    FN(queue) *qs = (FN(queue) *)calloc((size_t)NL, sizeof(*qs));
+/* ---- stateful form: the queues outlive a call, like model.dilated_queues between two generate_fast-shaped jobs that do
+ * not reset (the facade continues a stream after a progress callback with n_given = 1).  wno_generate below is
+ * new + run + free.  Also used by the host-memory ABI test double (tests/double), never by the product. */
+typedef struct {
+    wno_config c;
+    int NL;
+    FN(queue) *qs;
+} FN(wno_state);
+
+FN(wno_state) *FN(wno_state_new)(const wno_config *c) {
+    const int R = c->residual_channels, k = c->kernel_size, NL = c->layers * c->blocks;
+    if (k < 1 || NL < 1) return 0;
+    FN(wno_state) *st = (FN(wno_state) *)calloc(1, sizeof(*st));
+    st->c = *c;
+    st->NL = NL;
+    st->qs = (FN(queue) *)calloc((size_t)NL, sizeof(*st->qs));
     /* wavenet_model.py:70-110: d_i = 2^(i mod layers); queue max_length (k-1)*d+1; reset() zeroes (:250-251) */
     for (int i = 0; i < NL; ++i) {
         int d = 1 << (i % c->layers);
-        qs[i].max_length = (k - 1) * d + 1;
-        qs[i].data = (REAL *)calloc((size_t)R * qs[i].max_length, sizeof(REAL));
+        st->qs[i].max_length = (k - 1) * d + 1;
+        st->qs[i].data = (REAL *)calloc((size_t)R * st->qs[i].max_length, sizeof(REAL));
     }
+    return st;
+}
+
+void FN(wno_state_free)(FN(wno_state) *st) {
+    if (!st) return;
+    for (int i = 0; i < st->NL; ++i) free(st->qs[i].data);
+    free(st->qs);
+    free(st);
+}
+
+void FN(wno_state_reset)(FN(wno_state) *st) { /* wavenet_modules.py:74-77 for every layer */
+    for (int i = 0; i < st->NL; ++i) {
+        memset(st->qs[i].data, 0, sizeof(REAL) * (size_t)st->c.residual_channels * st->qs[i].max_length);
+        st->qs[i].in_pos = st->qs[i].out_pos = 0;
+    }
+}
+
+/* DilatedQueue.data / in_pos / out_pos of one layer (wavenet_modules.py:43-57); data_out is [R][max_length] */
+void FN(wno_state_queue)(const FN(wno_state) *st, int layer, float *data_out, int32_t *in_pos, int32_t *out_pos) {
+    const FN(queue) *q = &st->qs[layer];
+    const size_t n = (size_t)st->c.residual_channels * q->max_length;
+    for (size_t i = 0; i < n; ++i) data_out[i] = (float)q->data[i];
+    if (in_pos) *in_pos = q->in_pos;
+    if (out_pos) *out_pos = q->out_pos;
+}
+
+int FN(wno_state_run)(FN(wno_state) *st, const wno_weights *w, const int32_t *first_samples, int64_t n_given,
+                      int64_t num_samples, double temperature, const float *regularizer, const double *uniforms,
+                      const int32_t *forced, int32_t *out_idx, REAL *out_logits) {
+    const wno_config *c = &st->c;
+    const int R = c->residual_channels, D = c->dilation_channels, S = c->skip_channels, E = c->end_channels;
+    const int C = c->classes, k = c->kernel_size, NL = c->layers * c->blocks;
+    if (k < 1 || n_given < 1 || NL < 1) return -1;
+    FN(queue) *qs = st->qs;
     REAL *x = (REAL *)malloc(sizeof(REAL) * (size_t)(R > D ? R : D));
     REAL *xn = (REAL *)malloc(sizeof(REAL) * (size_t)R);
     REAL *taps = (REAL *)malloc(sizeof(REAL) * (size_t)R * k);
@@ -113,7 +156,17 @@ int FN(wno_generate)(const wno_config *c, const wno_weights *w, const int32_t *f
         out_idx[gi] = idx;
         in_idx = forced ? forced[gi] : idx; /* :300-302 feedback */
     }
-    for (int i = 0; i < NL; ++i) free(qs[i].data);
-    free(qs); free(x); free(xn); free(taps); free(f); free(g); free(z); free(skip); free(s); free(e); free(lg); free(p);
+    free(x); free(xn); free(taps); free(f); free(g); free(z); free(skip); free(s); free(e); free(lg); free(p);
     return 0;
+}
+
+int FN(wno_generate)(const wno_config *c, const wno_weights *w, const int32_t *first_samples, int64_t n_given,
+                     int64_t num_samples, double temperature, const float *regularizer, const double *uniforms,
+                     const int32_t *forced, int32_t *out_idx, REAL *out_logits) {
+    FN(wno_state) *st = FN(wno_state_new)(c);
+    if (!st) return -1;
+    const int rc = FN(wno_state_run)(st, w, first_samples, n_given, num_samples, temperature, regularizer, uniforms, forced,
+                                     out_idx, out_logits);
+    FN(wno_state_free)(st);
+    return rc;
 }

@@ -20,7 +20,6 @@
 //  and are served by the torch path of the facade.
 #ifndef WN_FORWARD_H
 #define WN_FORWARD_H
-#ifndef WN_EMU
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -530,5 +529,4 @@ __global__ void wn_fill_ring(const float* x, long long x_batch_stride, float* ri
         *reinterpret_cast<float4*>(ring + (((long long)c * n_streams + s) * ML + (t % ML)) * R + q * 4) = v;
 }
 
-#endif  // !WN_EMU
 #endif  // WN_FORWARD_H

@@ -1,11 +1,8 @@
 // wn_kernel.h -- the per-timestep work of one persistent workgroup of the generation chain.
 //
-// Written in "phase style": a workgroup's step is a sequence of phases, each executed by all 256
-// threads and separated by a workgroup barrier; no per-thread value lives across a barrier (it goes
-// through LDS).  That makes the SAME source compile
-//   * with hipcc for gfx950 (WN_PHASE runs the body for threadIdx.x, WN_SYNC is __syncthreads), and
-//   * with g++ -DWN_EMU for the CPU test emulator (WN_PHASE loops tid = 0..255, WN_SYNC is a no-op,
-//     workgroups are run in dependency order) -- test infrastructure only, never a product path.
+// The generic kernel (any shape, kernel_size and class count; weights stationary in LDS).  Written in "phase style": a
+// workgroup's step is a sequence of phases, each executed by all 256 threads and separated by an LDS-only workgroup barrier;
+// no per-thread value lives across a barrier (it goes through LDS).  gfx950 only: one backend, no host build of this file.
 //
 // Reference lines restated here (paths relative to the reference root):
 //   wavenet_model.py:127      start_conv on a one-hot          -> wn_l0_input (column gather)
@@ -21,15 +18,6 @@
 
 #include "wn_plan.h"
 
-#ifdef WN_EMU
-#include <math.h>
-#include <string.h>
-#define WN_DEV static inline
-#define WN_TID_BEGIN 0
-#define WN_TID_STEP 1
-#define WN_SYNC() ((void)0)
-struct wn_f4 { float x, y, z, w; };
-#else
 #include <hip/hip_runtime.h>
 #define WN_DEV static __device__ __forceinline__
 #define WN_TID_BEGIN ((int)threadIdx.x)
@@ -38,14 +26,9 @@ struct wn_f4 { float x, y, z, w; };
 // (__syncthreads() would also drain in-flight polls and write-through stores)
 #define WN_SYNC() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 typedef float4 wn_f4;
-#endif
 
 #define WN_PHASE for (int tid = WN_TID_BEGIN; tid < WN_THREADS; tid += WN_TID_STEP)
-#ifdef WN_EMU
-#define WN_UNROLL
-#else
 #define WN_UNROLL _Pragma("unroll")
-#endif
 
 // where-codes reported in status[4] when a hand-off wait gives up
 enum { WN_W_LOGITS = 1, WN_W_X = 2, WN_W_SKIN = 3, WN_W_HEAD = 4 };
@@ -55,8 +38,8 @@ struct WnCtx {
     const WnRun* r;
     float* lds;
     int w;             // chain position of this workgroup
-    int fail;          // this thread gave up (device) / any thread gave up (emu)
-    long long t_start; // wall clock at kernel entry (device)
+    int fail;          // this thread gave up a hand-off wait
+    long long t_start; // wall clock at the start of the current hand-off wait
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -69,14 +52,9 @@ WN_DEV wn_u64 wn_pack_granule(uint32_t tag, float v) {
 }
 
 WN_DEV void wn_publish(wn_u64* g, uint32_t tag, float v) {
-#ifdef WN_EMU
-    *g = wn_pack_granule(tag, v);
-#else
     __hip_atomic_store(g, wn_pack_granule(tag, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#endif
 }
 
-#ifndef WN_EMU
 // `local` = every consumer of this granule sits on the producer's XCD (checked at run time from the XCC ids): the
 // store may then stay in that XCD's L2 -- the coherence point of all its CUs -- instead of writing through to the
 // fabric; consumers read it with the same L1-bypassing loads.  Decided per producer, never assumed.
@@ -84,33 +62,20 @@ WN_DEV void wn_publish_at(wn_u64* g, uint32_t tag, float v, bool local) {
     if (local) __hip_atomic_store(g, wn_pack_granule(tag, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     else __hip_atomic_store(g, wn_pack_granule(tag, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-#endif
 
 WN_DEV void wn_give_up(WnCtx& cx, int where, long long e, int s) {
     cx.fail = 1;
-#ifdef WN_EMU
-    uint32_t* st = cx.p->status;
-    if (st[0] == 0) { st[0] = 1; st[1] = (uint32_t)cx.w; st[2] = (uint32_t)e; st[3] = (uint32_t)s; st[4] = (uint32_t)where; }
-#else
     uint32_t* st = cx.p->status;
     if (atomicCAS(st, 0u, 1u) == 0u) {
         st[1] = (uint32_t)cx.w; st[2] = (uint32_t)e; st[3] = (uint32_t)s; st[4] = (uint32_t)where;
         __threadfence();
     }
-#endif
 }
 
 // Spin until the granule carries `tag`.  Bounded: gives up after r->timeout_ticks of wall clock or as
 // soon as any workgroup has raised the abort word, so the kernel always terminates.
 WN_DEV float wn_wait_granule(WnCtx& cx, const wn_u64* g, uint32_t tag, int where, long long e, int s) {
     if (cx.fail) return 0.f;
-#ifdef WN_EMU
-    const wn_u64 v = *g;
-    if ((uint32_t)(v >> 32) != tag) { wn_give_up(cx, where, e, s); return 0.f; }
-    union { float f; uint32_t u; } c;
-    c.u = (uint32_t)v;
-    return c.f;
-#else
     unsigned spins = 0;
     for (;;) {
         const wn_u64 v = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -122,16 +87,11 @@ WN_DEV float wn_wait_granule(WnCtx& cx, const wn_u64* g, uint32_t tag, int where
         }
         __builtin_amdgcn_s_sleep(1);
     }
-#endif
 }
 
 // unchecked read of a granule (the caller looks at the tag)
 WN_DEV wn_u64 wn_peek(const wn_u64* g) {
-#ifdef WN_EMU
-    return *g;
-#else
     return __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#endif
 }
 WN_DEV float wn_granule_value(wn_u64 v) {
     union { float f; uint32_t u; } c;
@@ -156,14 +116,10 @@ WN_UNROLL
 
 // true if any thread of the workgroup failed; doubles as a barrier
 WN_DEV bool wn_any_failed(WnCtx& cx) {
-#ifdef WN_EMU
-    return cx.fail != 0;
-#else
     int* flag = reinterpret_cast<int*>(cx.lds + cx.p->lds_floats);  // one LDS word behind the layout, zeroed by wn_load_lds
     if (cx.fail) *flag = 1;
     WN_SYNC();
     return *flag != 0;
-#endif
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -1,7 +1,7 @@
 // wn_kernel_v2.h -- latency-optimised generation chain for gfx950 (device only).
 //
 // Same chain, same hand-off protocol and same HBM buffers as the generic kernel (wn_kernel.h, which stays
-// the fallback for arbitrary shapes and the source the CPU emulator tests), re-organised around what the
+// the fallback for arbitrary shapes), re-organised around what the
 // MI355X hand-off probe measured (profiles/r01_handoff_probe.txt): a granule hop costs 0.45-0.75 us no
 // matter what, so everything else must get off the critical path x[t] -> filter/gate -> z -> residual -> x'.
 //
@@ -23,7 +23,6 @@
 
 #include "wn_kernel.h"
 
-#ifndef WN_EMU
 
 #ifndef WN_MULTI_SLEEP
 #define WN_MULTI_SLEEP 0
@@ -1102,5 +1101,4 @@ __global__ __launch_bounds__(WN_THREADS) void wn_generate_kernel_v2(WnPlan p, Wn
     else wn_v2_head<SH>(p, r, cx, wn_lds2, w - n_layer_wg);
 }
 
-#endif  // !WN_EMU
 #endif  // WN_KERNEL_V2_H

@@ -1,12 +1,8 @@
 // wn_runtime.hip -- C ABI of libwn_mi355.so (include/wn_abi.h): handle, planner glue, HIP launch.
 //
-// Built two ways from this one file:
-//   hipcc --offload-arch=gfx950 ... wn_runtime.hip            -> libwn_mi355.so   (the product)
-//   g++ -x c++ -DWN_EMU ... wn_runtime.hip                    -> tests/emu/libwn_emu.so
-// The -DWN_EMU build replaces the device with host memory and runs the workgroups of wn_kernel.h
-// sequentially in dependency order.  It exists so that planner, packer, ABI and the kernel's index
-// arithmetic are testable in the GPU-less authoring container; the Python package never loads it
-// (mi355_wavenet/_abi.py only looks for libwn_mi355.so and raises if it is missing).
+//   hipcc --offload-arch=gfx950 -shared ... wn_runtime.hip    -> libwn_mi355.so
+// One backend: gfx950.  (Host logic above this ABI is tested without a GPU against tests/double, a host-memory test double
+// of include/wn_abi.h built on the C oracle -- it shares no code with this file.)
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -35,15 +31,6 @@ static int wn_fail(int code, const char* fmt, ...) {
 }
 
 // ------------------------------------------------------------------------------------------------ runtime shim
-#ifdef WN_EMU
-#define RT_CHECK(x) (x)
-static void* rt_malloc(size_t n) { return calloc(1, n ? n : 1); }
-static void rt_free(void* p) { free(p); }
-static int rt_h2d(void* d, const void* h, size_t n) { memcpy(d, h, n); return 0; }
-static int rt_d2h(void* h, const void* d, size_t n) { memcpy(h, d, n); return 0; }
-static int rt_memset_async(void* d, int v, size_t n, void*) { memset(d, v, n); return 0; }
-static int rt_sync(void*) { return 0; }
-#else
 static const char* g_hip_what = "";
 static int rt_hip(hipError_t e, const char* what) {
     if (e == hipSuccess) return 0;
@@ -93,10 +80,8 @@ __global__ __launch_bounds__(WN_THREADS) void wn_generate_kernel(WnPlan p, WnRun
             }
     }
 }
-#endif
 
 
-#ifndef WN_EMU
 // ------------------------------------------------------------------------------------------------ v2 (register-resident) variants
 // Shapes the latency-optimised kernel is instantiated for: (R, D/P, S, E/PA).  Anything else runs on the generic
 // LDS-resident kernel above.
@@ -222,10 +207,8 @@ static int wn_v2_choose(const WnPlan& pl, int n_cu, int n_smp, int forced_P, int
     }
     return -1;
 }
-#endif
 
 // ------------------------------------------------------------------------------------------------ handle
-#ifndef WN_EMU
 struct WnTrainLay {
     long long N, L, out_len;
     std::vector<long long> need;          // need[l] = trailing time steps of layer l's input the loss depends on
@@ -235,7 +218,6 @@ struct WnTrainLay {
     int G, nblk;  // layers per skip block, blocks
     bool bf16;  // the saved forward ran with bf16 operands: so does its backward
 };
-#endif
 struct wn_handle {
     wn_config cfg;
     WnPlan plan;
@@ -277,10 +259,8 @@ struct wn_handle {
     int prof_recorded;   // stamps held in d_prof
     std::vector<int64_t> ring_off;
     std::vector<int32_t> dil;
-#ifndef WN_EMU
     float* d_tws; size_t tws_floats;  // training workspace (saved activations + backward temporaries)
     WnTrainLay train; bool train_valid;
-#endif
 };
 
 extern "C" int wn_abi_version(void) { return WN_ABI_VERSION; }
@@ -290,24 +270,18 @@ extern "C" void wn_destroy(wn_handle* h) {
     if (!h) return;
     if (!h->chains.empty()) {
         for (wn_handle* c : h->chains) wn_destroy(c);
-#ifndef WN_EMU
         (void)hipSetDevice(h->cfg.device_id);
         if (h->ev_fork) (void)hipEventDestroy((hipEvent_t)h->ev_fork);
         if (h->ev_join) (void)hipEventDestroy((hipEvent_t)h->ev_join);
         if (h->side_stream) (void)hipStreamDestroy((hipStream_t)h->side_stream);
-#endif
         delete h;
         return;
     }
-#ifndef WN_EMU
     (void)hipSetDevice(h->cfg.device_id);
     if (h->pending) (void)hipStreamSynchronize((hipStream_t)h->last_stream);
-#endif
     rt_free(h->d_blobs); rt_free(h->d_start_t); rt_free(h->d_start_b); rt_free(h->d_rings); rt_free(h->d_dil);
     rt_free(h->d_wg_map); rt_free(h->d_ring_off); rt_free(h->d_gran); rt_free(h->d_status); rt_free(h->d_prof); rt_free(h->d_fw); rt_free(h->d_ws); rt_free(h->d_fwb);
-#ifndef WN_EMU
     rt_free(h->d_tws);
-#endif
     delete h;
 }
 
@@ -323,7 +297,6 @@ extern "C" int wn_create(const wn_config* cfg, wn_handle** out) {
     if (cfg->layer_split < 0 || cfg->head_split < 0 || cfg->reserved[0] || cfg->reserved[1] || cfg->reserved[2])
         return wn_fail(WN_E_BADARG, "wn_create: negative split / non-zero reserved field");
     int n_cu = 256, wall_khz = 100000;
-#ifndef WN_EMU
     {
         int ndev = 0;
         int rc = rt_hip(hipGetDeviceCount(&ndev), "hipGetDeviceCount");
@@ -339,8 +312,6 @@ extern "C" int wn_create(const wn_config* cfg, wn_handle** out) {
         int khz = 0;
         if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, cfg->device_id) == hipSuccess && khz > 0) wall_khz = khz;
     }
-#endif
-#ifndef WN_EMU
     {   // chains sharing the CUs two by two (see wn_handle::chains): 2 chains up to WN_CHAIN_MAX_STREAMS streams each, more
         // chains (run pairwise, one pair after the other on the two HIP streams) for larger jobs
         const char* ce = getenv("WN_CHAINS");
@@ -399,7 +370,6 @@ extern "C" int wn_create(const wn_config* cfg, wn_handle** out) {
             g_err[0] = 0;
         }
     }
-#endif
     wn_handle* h = new wn_handle();
     memset(&h->plan, 0, sizeof(h->plan));
     h->cfg = *cfg;
@@ -411,15 +381,12 @@ extern "C" int wn_create(const wn_config* cfg, wn_handle** out) {
     h->d_prof = nullptr; h->prof_items = 0; h->prof_recorded = 0;
     h->d_fw = nullptr; h->fw_floats = 0; h->fw_ok = false; h->d_ws = nullptr; h->ws_floats = 0;
     h->d_fwb = nullptr; h->fwb_elems = 0; h->fwb_ok = false; h->fw_bf16 = 0;
-#ifndef WN_EMU
     h->d_tws = nullptr; h->tws_floats = 0; h->train_valid = false;
-#endif
     WnPlan& pl = h->plan;
     pl.layers = cfg->layers; pl.blocks = cfg->blocks; pl.NL = cfg->layers * cfg->blocks;
     pl.R = cfg->residual_channels; pl.D = cfg->dilation_channels; pl.S = cfg->skip_channels; pl.E = cfg->end_channels;
     pl.C = cfg->classes; pl.k = cfg->kernel_size; pl.has_bias = cfg->bias ? 1 : 0; pl.n_streams = cfg->n_streams;
     h->variant = 1; h->v2_index = -1;
-#ifndef WN_EMU
     {
         const char* force = getenv("WN_KERNEL");  // "generic" pins the LDS-resident kernel (A/B runs, tests)
         int P2 = 0, PA2 = 0;
@@ -445,7 +412,6 @@ extern "C" int wn_create(const wn_config* cfg, wn_handle** out) {
             if (h->lds_bytes > WN_LDS_MAX_BYTES) { h->variant = 1; h->v2_index = -1; pl.n_smp = 0; }
         }
     }
-#endif
     if (h->variant == 1) {
         const std::string why = wn_plan_choose(pl, n_cu, cfg->layer_split, cfg->head_split);
         if (!why.empty()) {
@@ -478,12 +444,10 @@ extern "C" int wn_create(const wn_config* cfg, wn_handle** out) {
     const size_t gx_n = n_lw * pl.n_streams * pl.R, gs_n = n_lw * pl.n_streams * pl.S, gl_n = (size_t)pl.PA * pl.n_streams * pl.C;
     h->gran_count = gx_n + gs_n + gl_n + (size_t)pl.n_streams;
     h->blob_floats = n_lw * pl.blob_layer_floats + (size_t)pl.PA * pl.blob_head_floats;
-#ifndef WN_EMU
     if (h->variant == 2) {
         const WnV2Entry& ve = wn_v2_table()[h->v2_index];
         h->blob_floats = n_lw * (size_t)ve.nwl * 256 + (size_t)pl.PA * ve.nwh * 256;
     }
-#endif
     h->d_blobs = (float*)rt_malloc(h->blob_floats * 4);
     h->d_start_t = (float*)rt_malloc((size_t)pl.C * pl.R * 4);
     h->d_start_b = (float*)rt_malloc((size_t)pl.R * 4);
@@ -512,13 +476,11 @@ extern "C" int wn_create(const wn_config* cfg, wn_handle** out) {
     pl.gx = h->d_gran; pl.gs = h->d_gran + gx_n; pl.gl = h->d_gran + gx_n + gs_n; pl.gi = h->d_gran + gx_n + gs_n + gl_n;
     pl.status = h->d_status;
     pl.xcc_tab = h->d_status + 8;
-#ifndef WN_EMU
     rc = rt_hip(hipFuncSetAttribute(h->variant == 2 ? (pl.n_smp > 0 ? (h->w0lds ? wn_v2_table()[h->v2_index].fn_multi_w0 : wn_v2_table()[h->v2_index].fn_multi) : wn_v2_table()[h->v2_index].fn)
                                                     : (const void*)wn_generate_kernel,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes),
                 "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
     if (rc) { wn_destroy(h); return rc; }
-#endif
     *out = h;
     return WN_OK;
 }
@@ -536,17 +498,13 @@ extern "C" int wn_load_weights(wn_handle* h, const wn_weight_ptrs* w) {
     const WnPlan& pl = h->plan;
     if (pl.has_bias && (!w->start_b || !w->filter_b || !w->gate_b || !w->res_b || !w->skip_b))
         return wn_fail(WN_E_BADARG, "wn_load_weights: cfg.bias=1 but a stack bias pointer is NULL");
-#ifndef WN_EMU
     { int rc = rt_hip(hipSetDevice(h->cfg.device_id), "hipSetDevice"); if (rc) return rc; }
-#endif
     if (h->pending) { int rc = wn_wait(h); if (rc) return rc; }
     WnHostWeights hw = {w->start_w, w->start_b, w->filter_w, w->filter_b, w->gate_w, w->gate_b, w->res_w,
                         w->res_b, w->skip_w, w->skip_b, w->end1_w, w->end1_b, w->end2_w, w->end2_b};
     std::vector<float> blobs;
-#ifndef WN_EMU
     if (h->variant == 2) wn_v2_table()[h->v2_index].pack(pl, hw, blobs);
     else
-#endif
         wn_pack_blobs(pl, hw, blobs);
     if (blobs.size() != h->blob_floats) return wn_fail(WN_E_STATE, "wn_load_weights: internal blob size mismatch");
     std::vector<float> st((size_t)pl.C * pl.R);
@@ -561,7 +519,6 @@ extern "C" int wn_load_weights(wn_handle* h, const wn_weight_ptrs* w) {
         h->plan.start_b = nullptr;
     }
     if (rc) return rc;
-#ifndef WN_EMU
     {   // GEMM-ready banks for wn_forward: B^T [K][N] row-major per layer (see wn_forward.h)
         const int R = pl.R, D = pl.D, S = pl.S, E = pl.E, C = pl.C, NL = pl.NL;
         h->fw_ok = pl.k == 2 && R % 32 == 0 && D % 32 == 0 && S % 32 == 0 && E % 32 == 0 && C % 32 == 0;
@@ -655,7 +612,6 @@ extern "C" int wn_load_weights(wn_handle* h, const wn_weight_ptrs* w) {
             }
         }
     }
-#endif
     h->have_weights = true;
     return WN_OK;
 }
@@ -670,48 +626,17 @@ extern "C" int wn_reset(wn_handle* h, void* hip_stream) {
         h->broken = false;
         return WN_OK;
     }
-#ifndef WN_EMU
     { int rc = rt_hip(hipSetDevice(h->cfg.device_id), "hipSetDevice"); if (rc) return rc; }
-#endif
     if (h->pending) { int rc = wn_wait(h); if (rc) return rc; }
     h->t_base = 0;
     return rt_memset_async(h->d_rings, 0, h->ring_floats * 4, hip_stream);
 }
 
-#ifdef WN_EMU
-// Sequential schedule honouring the chain's dependencies: for every evaluation and stream run L0..L(NL-1)
-// (all slices), then the head slices; finally L0's sample-only iteration.
-static void wn_emu_run(const WnPlan& p, const WnRun& r, std::vector<std::vector<float>>& lds) {
-    const int32_t* dil_host = p.dil;  // host memory in the emulator build
-    const int n_lw = p.NL * p.P;
-    auto ctx = [&](int w) {
-        WnCtx cx;
-        cx.p = &p; cx.r = &r; cx.lds = lds[w].data(); cx.w = w; cx.fail = 0; cx.t_start = 0;
-        return cx;
-    };
-    for (long long e = 0; e <= r.n_eval; ++e)
-        for (int s = 0; s < p.n_streams; ++s) {
-            for (int w = 0; w < n_lw; ++w) {
-                const int l = w / p.P, c = w % p.P;
-                if (e == r.n_eval && l != 0) continue;
-                WnCtx cx = ctx(w);
-                const int ML = (p.k - 1) * dil_host[l] + 1;
-                if (!wn_layer_item(cx, l, c, e, s, (int)((r.t_base + e) % ML))) return;
-            }
-            if (e == r.n_eval) continue;
-            for (int hh = 0; hh < p.PA; ++hh) {
-                WnCtx cx = ctx(n_lw + hh);
-                if (!wn_head_item(cx, hh, e, s)) return;
-            }
-        }
-}
-#endif
 
 extern "C" int wn_generate(wn_handle* h, const wn_generate_args* a) {
     g_err[0] = 0;
     if (!h || !a) return wn_fail(WN_E_BADARG, "wn_generate: NULL argument");
     if (!h->have_weights) return wn_fail(WN_E_STATE, "wn_generate: wn_load_weights has not been called");
-#ifndef WN_EMU
     if (!h->chains.empty()) {   // chain i owns streams [chain_first[i], chain_first[i + 1]): fork onto the side stream, join back
         if (a->n_given < 1 || a->num_samples < 0) return wn_fail(WN_E_BADARG, "wn_generate: n_given must be >= 1 and num_samples >= 0");
         if (!a->first_samples) return wn_fail(WN_E_BADARG, "wn_generate: first_samples is NULL");
@@ -755,7 +680,6 @@ extern "C" int wn_generate(wn_handle* h, const wn_generate_args* a) {
         h->t_base = h->chains[0]->t_base;
         return WN_OK;
     }
-#endif
     if (a->n_given < 1 || a->num_samples < 0) return wn_fail(WN_E_BADARG, "wn_generate: n_given must be >= 1 and num_samples >= 0");
     if (!a->first_samples) return wn_fail(WN_E_BADARG, "wn_generate: first_samples is NULL");
     if (a->num_samples > 0 && !a->out_idx) return wn_fail(WN_E_BADARG, "wn_generate: out_idx is NULL");
@@ -763,9 +687,7 @@ extern "C" int wn_generate(wn_handle* h, const wn_generate_args* a) {
     const bool greedy = (!(a->temperature > 0.f) && !a->stream_temperatures) || a->uniforms == nullptr;
     const long long n_eval = a->n_given - 1 + a->num_samples;
     if (n_eval + 1 >= 0xFFFFFFFFll) return wn_fail(WN_E_BADARG, "wn_generate: job too long for 32-bit hand-off tags");
-#ifndef WN_EMU
     { int rc = rt_hip(hipSetDevice(h->cfg.device_id), "hipSetDevice"); if (rc) return rc; }
-#endif
     if (h->pending) { int rc = wn_wait(h); if (rc) return rc; }
     if (n_eval == 0) return WN_OK;
     WnRun r;
@@ -790,13 +712,6 @@ extern "C" int wn_generate(wn_handle* h, const wn_generate_args* a) {
     int rc = rt_memset_async(h->d_gran, 0, h->gran_count * 8, a->hip_stream);
     rc = rc ? rc : rt_memset_async(h->d_status, 0, (size_t)(8 + h->plan.n_wg) * 4, a->hip_stream);
     if (rc) return rc;
-#ifdef WN_EMU
-    {
-        std::vector<std::vector<float>> lds(h->plan.n_wg, std::vector<float>((size_t)h->plan.lds_floats + 8, 0.f));
-        for (int w = 0; w < h->plan.n_wg; ++w) wn_load_lds(h->plan, w, lds[w].data());
-        wn_emu_run(h->plan, r, lds);
-    }
-#else
     if (h->variant == 2 && h->plan.n_smp > 0)
         wn_v2_table()[h->v2_index].launch_multi(h->w0lds, h->plan.n_blocks, (size_t)h->lds_bytes, (hipStream_t)a->hip_stream, h->plan, r);
     else if (h->variant == 2)
@@ -806,7 +721,6 @@ extern "C" int wn_generate(wn_handle* h, const wn_generate_args* a) {
                            (hipStream_t)a->hip_stream, h->plan, r);
     rc = rt_hip(hipGetLastError(), "launch wn_generate_kernel");
     if (rc) return rc;
-#endif
     h->pending = true;
     h->last_stream = a->hip_stream;
     h->t_base += n_eval;
@@ -883,9 +797,7 @@ extern "C" int wn_export_queue(wn_handle* h, int32_t layer, int32_t stream, floa
     }
     const WnPlan& pl = h->plan;
     if (layer < 0 || layer >= pl.NL || stream < 0 || stream >= pl.n_streams) return wn_fail(WN_E_BADARG, "wn_export_queue: index out of range");
-#ifndef WN_EMU
     { int rc = rt_hip(hipSetDevice(h->cfg.device_id), "hipSetDevice"); if (rc) return rc; }
-#endif
     if (h->pending) { int rc = wn_wait(h); if (rc) return rc; }
     const int d = h->dil[layer];
     const int ML = (pl.k - 1) * d + 1;
@@ -928,10 +840,6 @@ extern "C" int wn_forward(wn_handle* h, const int32_t* indices, int64_t N, int64
     if (!h->chains.empty()) return wn_forward(h->chains[0], indices, N, L, out_len, logits, hip_stream);  // every chain holds the weights
     if (!h->have_weights) return wn_fail(WN_E_STATE, "wn_forward: wn_load_weights has not been called");
     if (N < 1 || out_len < 1) return wn_fail(WN_E_BADARG, "wn_forward: N and output_length must be >= 1");
-#ifdef WN_EMU
-    (void)L; (void)hip_stream;
-    return wn_fail(WN_E_UNSUPPORTED, "wn_forward: the matrix-core forward exists on the GPU only");
-#else
     const WnPlan& pl = h->plan;
     const int R = pl.R, D = pl.D, S = pl.S, E = pl.E, C = pl.C, NL = pl.NL;
     if (!h->fw_ok) return wn_fail(WN_E_UNSUPPORTED, "wn_forward: needs kernel_size 2 and channel counts that are multiples of 32");
@@ -1035,7 +943,6 @@ extern "C" int wn_forward(wn_handle* h, const int32_t* indices, int64_t N, int64
         launch(WN_EPI_PLAIN, a, bf16 ? fwb + h->fwb_off_w2 : nullptr);
     }
     return rt_hip(hipGetLastError(), "wn_forward launches");
-#endif
 }
 
 // Batched (teacher-forced) priming: the n_prime = n_given - 1 priming evaluations of generate_fast (wavenet_model.py:259-269)
@@ -1059,10 +966,6 @@ extern "C" int wn_prime(wn_handle* h, const int32_t* first_samples, int64_t n_pr
     if (!h->have_weights) return wn_fail(WN_E_STATE, "wn_prime: wn_load_weights has not been called");
     if (n_prime < 0 || row_stride < n_prime) return wn_fail(WN_E_BADARG, "wn_prime: bad n_prime / row_stride");
     if (n_prime == 0) return WN_OK;
-#ifdef WN_EMU
-    (void)hip_stream;
-    return wn_fail(WN_E_UNSUPPORTED, "wn_prime: the batched priming path exists on the GPU only");
-#else
     const WnPlan& pl = h->plan;
     const int R = pl.R, D = pl.D, NL = pl.NL, ns = pl.n_streams;
     if (!h->fw_ok) return wn_fail(WN_E_UNSUPPORTED, "wn_prime: needs kernel_size 2 and channel counts that are multiples of 32");
@@ -1143,7 +1046,6 @@ extern "C" int wn_prime(wn_handle* h, const int32_t* first_samples, int64_t n_pr
     if (rc) return rc;
     h->t_base = n;
     return WN_OK;
-#endif
 }
 
 // Operand precision of wn_forward's GEMMs: 0 = fp32 (default; matches the reference's fp32 forward to rounding),
@@ -1152,23 +1054,10 @@ extern "C" int wn_set_forward_precision(wn_handle* h, int32_t bf16) {
     g_err[0] = 0;
     if (!h) return wn_fail(WN_E_BADARG, "wn_set_forward_precision: NULL handle");
     if (!h->chains.empty()) return wn_set_forward_precision(h->chains[0], bf16);
-#ifdef WN_EMU
-    (void)bf16;
-    return wn_fail(WN_E_UNSUPPORTED, "wn_set_forward_precision: GPU only");
-#else
     if (bf16 && !h->have_weights) return wn_fail(WN_E_STATE, "wn_set_forward_precision: load the weights first");
     if (bf16 && !h->fwb_ok) return wn_fail(WN_E_UNSUPPORTED, "wn_set_forward_precision: bf16 needs R, D, S, E to be multiples of 64");
     h->fw_bf16 = bf16 ? 1 : 0;
     return WN_OK;
-#endif
 }
 
-#ifndef WN_EMU
 #include "wn_train.inl"
-#else
-// the training step exists on the GPU only
-extern "C" int wn_train_get_layout(wn_handle*, wn_train_layout*) { g_err[0] = 0; return wn_fail(WN_E_UNSUPPORTED, "wn_train: GPU only"); }
-extern "C" int wn_train_export_params(wn_handle*, float*, void*) { g_err[0] = 0; return wn_fail(WN_E_UNSUPPORTED, "wn_train: GPU only"); }
-extern "C" int wn_train_forward(wn_handle*, const float*, const int32_t*, int64_t, int64_t, int64_t, float*, void*) { g_err[0] = 0; return wn_fail(WN_E_UNSUPPORTED, "wn_train: GPU only"); }
-extern "C" int wn_train_backward(wn_handle*, const float*, const float*, float*, void*) { g_err[0] = 0; return wn_fail(WN_E_UNSUPPORTED, "wn_train: GPU only"); }
-#endif

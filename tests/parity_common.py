@@ -1,5 +1,5 @@
-"""Shared differential checks: an engine (HIP library on the GPU box, or the CPU emulator build of the
-same sources in the authoring container) against the C oracle (oracle/wn_oracle.c).
+"""Shared differential checks: an engine (the HIP library on the GPU box; in host-logic tests the test double of the C
+ABI) against the C oracle (oracle/wn_oracle.c).
 
 Tolerances:
   * logits, teacher-forced on the oracle's index sequence:  max|d| <= 1e-5 * max(1, |logits|_inf)

@@ -1,6 +1,6 @@
 """The drop-in Python surface (pytorch-wavenet_amd/wavenet_model.py, wavenet_modules.py, audio_data.py)
 against the reference's own known answers and golden outputs.  generate_fast() is exercised here on the
-emulator build (explicitly injected); on the GPU it is covered by tests/test_gpu_facade.py."""
+host-memory test double of the C ABI (tests/double, explicitly injected); on the GPU it is covered by tests/test_gpu_facade.py."""
 import io
 import pickle
 from contextlib import redirect_stdout
@@ -12,7 +12,7 @@ import torch
 import c_oracle
 import wavenet_model
 import wavenet_modules
-from emu_lib import emu_library
+from double_lib import double_library
 from mi355_wavenet import engine, synth
 
 
@@ -133,23 +133,23 @@ def test_forward_equals_queue_path():
 _REAL_ENGINE = engine.Engine
 
 
-def _inject_emulator(m, monkeypatch):
+def _inject_double(m, monkeypatch):
     real = _REAL_ENGINE
 
     def make(cfg, weights, n_streams=1, device_index=0, **kw):
-        return real(cfg, weights, n_streams=n_streams, device_index=device_index, lib=emu_library(), **kw)
+        return real(cfg, weights, n_streams=n_streams, device_index=device_index, lib=double_library(), **kw)
 
     monkeypatch.setattr(engine, "Engine", make)
 
 
-def test_generate_fast_contract_on_emulator(golden, monkeypatch):
+def test_generate_fast_contract_on_the_double(golden, monkeypatch):
     """Audio equals what the REAL reference returned for the same seed (tests/golden): same RNG consumption,
     same de-quantisation + mu-law expansion, float64 (num_samples,)."""
     for case, cname in (("tiny", "tiny"), ("tiny_bias", "tiny_bias"), ("cfg1_seed128", "cfg1")):
         wseed, n_given, n, npseed = [int(v) for v in golden["gen_%s_meta" % case]]
         temp, regz = [float(v) for v in golden["gen_%s_tr" % case]]
         m, cfg, W = _model(cname, wseed)
-        _inject_emulator(m, monkeypatch)
+        _inject_double(m, monkeypatch)
         first = None if n_given == 1 else torch.from_numpy(golden["gen_%s_first" % case].astype(np.int64))
         np.random.seed(npseed)
         buf = io.StringIO()
@@ -167,7 +167,7 @@ def test_generate_fast_contract_on_emulator(golden, monkeypatch):
 
 def test_generate_fast_progress_callbacks_match_reference_cadence(monkeypatch):
     m, cfg, W = _model("tiny", 62)
-    _inject_emulator(m, monkeypatch)
+    _inject_double(m, monkeypatch)
     first = torch.from_numpy(np.random.RandomState(62).randint(0, 256, 23))
     calls = []
     np.random.seed(9)
@@ -185,7 +185,7 @@ def test_generate_fast_progress_callbacks_match_reference_cadence(monkeypatch):
 
 def test_generate_fast_multi_stream_extension(monkeypatch):
     m, cfg, W = _model("tiny_bias", 63)
-    _inject_emulator(m, monkeypatch)
+    _inject_double(m, monkeypatch)
     first = torch.from_numpy(np.random.RandomState(63).randint(0, 256, (3, 9)))
     out = m.generate_fast(20, first_samples=first, temperature=0)
     assert out.shape == (3, 20)
@@ -196,7 +196,7 @@ def test_generate_fast_multi_stream_extension(monkeypatch):
 
 def test_weights_update_reaches_engine(monkeypatch):
     m, cfg, W = _model("tiny", 64)
-    _inject_emulator(m, monkeypatch)
+    _inject_double(m, monkeypatch)
     a = m.generate_fast(20, temperature=0)
     with torch.no_grad():
         m.end_conv_2.bias.add_(torch.linspace(-1, 1, 256))
@@ -209,7 +209,7 @@ def test_weights_update_reaches_engine(monkeypatch):
 def test_pickle_snapshot_roundtrip(tmp_path, monkeypatch):
     """torch.save(model) / load_latest_model_from, the reference's checkpoint flow (wavenet_training.py:84-88)."""
     m, cfg, W = _model("tiny", 65)
-    _inject_emulator(m, monkeypatch)
+    _inject_double(m, monkeypatch)
     m.generate_fast(5, temperature=0)  # engine exists now; must not break pickling
     torch.save(m, str(tmp_path / "snap_2026"))
     m2 = wavenet_model.load_latest_model_from(str(tmp_path), use_cuda=False)
@@ -237,7 +237,7 @@ def test_snapshot_pickled_by_the_reference_class_loads_and_generates(monkeypatch
     m2 = wavenet_model.WaveNetModel.__new__(wavenet_model.WaveNetModel)
     m2.__setstate__(state)
     assert m2.end_channels == cfg["end_channels"] and m2.bias is False and m2._wn_engine is None
-    _inject_emulator(m2, monkeypatch)
+    _inject_double(m2, monkeypatch)
     a = m2.generate_fast(20, temperature=0)
     idx, _ = c_oracle.generate(cfg, W, 20, None, 0.0, 0.0)
     assert np.array_equal(a, c_oracle.expand(idx))
@@ -250,7 +250,7 @@ def test_dilated_queues_hold_the_final_state_after_generate_fast(monkeypatch):
     from the engine lazily (first attribute access)."""
     import restated
     m, cfg, W = _model("tiny", 67)
-    _inject_emulator(m, monkeypatch)
+    _inject_double(m, monkeypatch)
     first = torch.from_numpy(np.random.RandomState(67).randint(0, 256, 12))
     m.generate_fast(30, first_samples=first, temperature=0)
     assert all(q._lazy is not None for q in m.dilated_queues)  # nothing downloaded yet

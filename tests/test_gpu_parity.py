@@ -145,9 +145,10 @@ def test_headline_workload_cfg3_x64_against_the_oracle():
         assert np.array_equal(idx[s], o_idx), "stream %d: sampled indices differ at step %d" % (s, int(np.argmax(idx[s] != o_idx)))
         assert float(np.abs(logits[s] - o_log).max()) <= tol, s
         g_idx, g_log = c_oracle.generate(cfg, W, 300, first[s], 0.0, 0.0)
-        top2 = np.sort(g_log, axis=1)
-        assert float((top2[:, -1] - top2[:, -2]).min()) > 10 * tol  # otherwise an argmax flip would be legitimate rounding
-        assert np.array_equal(gidx[s], g_idx), "stream %d: greedy indices differ" % s
+        if not np.array_equal(gidx[s], g_idx):  # an argmax flip is legitimate rounding only where the top-2 gap is degenerate
+            t = int(np.argmax(gidx[s] != g_idx))
+            row = np.sort(g_log[t])
+            assert row[-1] - row[-2] <= 10 * tol, "stream %d: greedy indices differ at step %d (gap %.3g)" % (s, t, row[-1] - row[-2])
     for s in range(ns):
         assert np.array_equal(idx[s], idx[probes[s % 4]]) and np.array_equal(gidx[s], gidx[probes[s % 4]]), s
     print("cfg3 x64 headline parity ok", info)
@@ -322,3 +323,24 @@ def test_two_chain_front_edge_cases():
         o_idx, _ = c_oracle.generate(cfg, W, 64, first[s], 1.0, 0.0, uniforms[s])
         assert np.array_equal(full[s], o_idx), s
     eng.close()
+
+
+def test_abi_error_codes_on_a_live_handle():
+    """Call-order and range errors of the product library on a real handle: codes, never exceptions or crashes."""
+    import ctypes
+    d = _abi.load_product_library().dll
+    h = ctypes.c_void_p()
+    ok = _abi.wn_config(3, 2, 16, 16, 32, 32, 256, 2, 0, 1, 0, 0, 0)
+    assert d.wn_create(ctypes.byref(ok), ctypes.byref(h)) == 0
+    args = _abi.wn_generate_args()
+    assert d.wn_generate(h, ctypes.byref(args)) == _abi.WN_E_STATE  # no weights yet
+    assert d.wn_load_weights(h, None) == _abi.WN_E_BADARG
+    w = _abi.wn_weight_ptrs()
+    assert d.wn_load_weights(h, ctypes.byref(w)) == _abi.WN_E_BADARG
+    assert d.wn_export_queue(h, 99, 0, None, None, None) == _abi.WN_E_BADARG
+    assert d.wn_prime(h, None, 4, 4, None) == _abi.WN_E_BADARG
+    d.wn_destroy(h)
+    huge = _abi.wn_config(10, 20, 128, 128, 512, 256, 256, 2, 0, 1, 0, 4, 8)  # 808 workgroups > 256 CUs
+    assert d.wn_create(ctypes.byref(huge), ctypes.byref(h)) == _abi.WN_E_UNSUPPORTED
+    assert b"co-resident" in d.wn_last_error()
+    assert d.wn_create(ctypes.byref(_abi.wn_config(3, 2, 16, 16, 32, 32, 256, 2, 0, 1, 99, 0, 0)), ctypes.byref(h)) == _abi.WN_E_BADARG  # device 99

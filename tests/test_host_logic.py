@@ -1,0 +1,76 @@
+"""CPU-side (-m "not gpu") tests of the HOST logic between the Python facade and the C ABI -- mi355_wavenet/engine.py:
+argument shaping, default first sample, continuation without reset, zero-sample jobs, batched priming hand-over, queue
+export -- against the C oracle, with the host-memory test double of include/wn_abi.h (tests/double) standing in for the
+device.  The double IS the oracle behind the ABI, so nothing here says anything about the HIP kernels: those are checked on
+the GPU (tests/test_gpu_parity.py)."""
+import numpy as np
+
+import c_oracle
+import restated
+from double_lib import double_library
+from mi355_wavenet import engine
+from parity_common import check_engine, make_case
+
+
+def test_engine_wrapper_round_trip_multi_stream():
+    cfg, W, first, uniforms = make_case("tiny_bias", 41, 3, 25, 60)
+    eng = engine.Engine(cfg, W, n_streams=3, lib=double_library())
+    check_engine(eng, cfg, W, 60, first, 0.0, 0.0, None, "double greedy")
+    check_engine(eng, cfg, W, 60, first, 0.85, 0.0015, uniforms, "double sampled")
+    eng.close()
+
+
+def test_default_first_sample_and_no_priming():
+    cfg, W, _, uniforms = make_case("tiny", 42, 1, 1, 80)
+    eng = engine.Engine(cfg, W, lib=double_library())
+    idx = eng.generate(80, None, temperature=1.0, uniforms=uniforms)
+    o_idx, _ = c_oracle.generate(cfg, W, 80, None, 1.0, 0.0, uniforms[0])  # first_samples=None -> [classes//2]
+    assert np.array_equal(idx[0], o_idx)
+
+
+def test_continuation_equals_one_shot():
+    """generate(N) == generate(a) then generate(N-a, first=[last], reset=False): how the facade implements
+    progress callbacks (wavenet_model.py:308-311) with one launch per interval."""
+    cfg, W, first, uniforms = make_case("tiny_bias", 43, 2, 9, 90)
+    eng = engine.Engine(cfg, W, n_streams=2, lib=double_library())
+    full = eng.generate(90, first, temperature=1.0, uniforms=uniforms)
+    a = eng.generate(37, first, temperature=1.0, uniforms=uniforms[:, :37])
+    b = eng.generate(53, a[:, -1:], temperature=1.0, uniforms=uniforms[:, 37:], reset=False)
+    assert np.array_equal(np.concatenate([a, b], axis=1), full)
+    assert eng.info()["evals_done"] == 9 - 1 + 90
+
+
+def test_batched_priming_hand_over():
+    """Engine.generate primes long given windows through wn_prime and continues with n_given = 1 from the last given
+    sample: same indices as per-sample priming."""
+    cfg, W, first, uniforms = make_case("tiny", 46, 2, engine.Engine.PRIME_BATCH_MIN + 10, 30)
+    eng = engine.Engine(cfg, W, n_streams=2, lib=double_library())
+    a = eng.generate(30, first, temperature=1.0, uniforms=uniforms, batched_prime=True)
+    b = eng.generate(30, first, temperature=1.0, uniforms=uniforms, batched_prime=False)
+    assert np.array_equal(a, b)
+    o_idx, _ = c_oracle.generate(cfg, W, 30, first[1], 1.0, 0.0, uniforms[1])
+    assert np.array_equal(a[1], o_idx)
+
+
+def test_export_queue_matches_reference_queue_layout():
+    """wn_export_queue hands out DilatedQueue.data / in_pos / out_pos (wavenet_modules.py:43-57) after the same pushes,
+    checked against the torch restatement of the reference queue."""
+    cfg, W, first, _ = make_case("tiny", 44, 1, 12, 30)
+    eng = engine.Engine(cfg, W, lib=double_library())
+    idx = eng.generate(30, first, temperature=0.0)
+    r = restated.RestatedWaveNet(cfg, W)
+    _, ridx, _ = r.generate_fast(30, first_samples=first[0], temperature=0.0, return_details=True)
+    assert np.array_equal(idx[0], ridx)
+    for layer in range(cfg["layers"] * cfg["blocks"]):
+        data, ip, op = eng.export_queue(layer)
+        q = r.queues[layer]
+        assert (ip, op) == (q.in_pos, q.out_pos)
+        assert np.allclose(data, q.data.numpy(), rtol=0, atol=2e-6)
+
+
+def test_zero_samples_and_prime_only():
+    cfg, W, first, _ = make_case("tiny", 45, 1, 6, 1)
+    eng = engine.Engine(cfg, W, lib=double_library())
+    idx = eng.generate(0, first, temperature=0.0)
+    assert idx.shape == (1, 0)
+    assert eng.info()["evals_done"] == 5

@@ -1,5 +1,5 @@
-"""N > 1 path on CPU: world_size 2 over gloo.  Stream sharding + gather of mi355_wavenet.streams, with the emulator
-build standing in for the two GPUs (explicitly injected; test infrastructure only)."""
+"""N > 1 path on CPU: world_size 2 over gloo.  Stream sharding + gather of mi355_wavenet.streams, with the host-memory
+test double of the C ABI standing in for the two GPUs (explicitly injected; test infrastructure only)."""
 import os
 import sys
 
@@ -17,7 +17,7 @@ def _worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from emu_lib import emu_library
+    from double_lib import double_library
     from mi355_wavenet import streams, synth
     cfg = synth.CONFIGS["tiny_bias"]
     W = synth.init_weights(cfg, seed=81)
@@ -25,7 +25,7 @@ def _worker(rank, world, port, q):
     S, N = 5, 40  # odd stream count: ranks get 3 and 2
     first = rs.randint(0, 256, (S, 7))
     u = rs.random_sample((S, N))
-    out = streams.generate_streams(cfg, W, first, N, temperature=1.0, uniforms=u, dist=dist, lib=emu_library())
+    out = streams.generate_streams(cfg, W, first, N, temperature=1.0, uniforms=u, dist=dist, lib=double_library())
     if rank == 0:
         q.put(out)
     else:

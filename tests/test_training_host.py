@@ -1,6 +1,6 @@
 """Host side of the training rows on CPU: the dataset item path against golden items
 produced by the real reference, device batches, the trainer loop against a hand-rolled copy of the reference's loop
-on the reference's own model, the logger cadence, per-stream temperatures (emulator vs the C oracle), and the
+on the reference's own model, the logger cadence, per-stream temperatures through engine.py (test double), and the
 data-parallel gradient exchange over gloo with world_size 2."""
 import os
 import sys
@@ -194,10 +194,10 @@ def test_trainer_steps_equal_the_reference_loop(dataset_file):
     assert np.isfinite(avg_loss) and 0.0 <= acc <= 1.0 and ds.train is True
 
 
-def test_per_stream_temperatures_emulator_vs_oracle():
+def test_per_stream_temperatures_through_the_engine_wrapper():
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import c_oracle
-    from emu_lib import emu_library
+    from double_lib import double_library
     from mi355_wavenet import engine, synth
     cfg = synth.CONFIGS["tiny_bias"]
     W = synth.init_weights(cfg, seed=5)
@@ -205,7 +205,7 @@ def test_per_stream_temperatures_emulator_vs_oracle():
     rs = np.random.RandomState(9)
     first = rs.randint(0, 256, (4, 3))
     u = rs.random_sample((4, 30))
-    eng = engine.Engine(cfg, W, n_streams=4, lib=emu_library())
+    eng = engine.Engine(cfg, W, n_streams=4, lib=double_library())
     out = eng.generate(30, first, temperature=np.asarray(temps, dtype=np.float32), uniforms=u)
     eng.close()
     for s, t in enumerate(temps):
