@@ -14,6 +14,7 @@
 #include "../../include/wn_abi.h"
 #include "wn_kernel.h"
 #include "wn_kernel_v2.h"
+#include "wn_kernel_v3.h"
 #include "wn_forward.h"
 
 static thread_local char g_err[512] = "";
@@ -97,6 +98,10 @@ struct WnV2Entry {
     void (*launch)(int grid, size_t lds, hipStream_t st, const WnPlan& p, const WnRun& r);
     void (*launch_multi)(int w0lds, int grid, size_t lds, hipStream_t st, const WnPlan& p, const WnRun& r);
     void (*pack)(const WnPlan& pl, const WnHostWeights& w, std::vector<float>& out);
+    // wave-specialised multi-stream kernel (wn_kernel_v3.h): 512-thread layer workgroups, one chain for all streams
+    const void* fn_v3;
+    int (*lds_floats_v3)(int ns);
+    void (*launch_v3)(int grid, size_t lds, hipStream_t st, const WnPlan& p, const WnRun& r);
 };
 
 template <class SH>
@@ -173,6 +178,17 @@ static WnV2Entry wn_v2_entry() {
         hipLaunchKernelGGL((wn_generate_kernel_v2<R, DC, S, EC>), dim3(grid), dim3(WN_THREADS), lds, st, p, r);
     };
     e.pack = wn_pack_v2<SH>;
+    e.fn_v3 = nullptr; e.lds_floats_v3 = nullptr; e.launch_v3 = nullptr;
+    if constexpr (wn_v3_fits<SH>()) {
+        e.fn_v3 = (const void*)wn_generate_kernel_v3m<R, DC, S, EC, PM>;
+        e.lds_floats_v3 = [](int ns) {
+            const int lay = WnV3Lds<SH>::floats(ns), head = WnV2LdsM<SH, 1, false>::pre;
+            return lay > head ? lay : head;
+        };
+        e.launch_v3 = [](int grid, size_t lds, hipStream_t st, const WnPlan& p, const WnRun& r) {
+            hipLaunchKernelGGL((wn_generate_kernel_v3m<R, DC, S, EC, PM>), dim3(grid), dim3(WN_THREADS_V3), lds, st, p, r);
+        };
+    }
     return e;
 }
 
@@ -206,6 +222,28 @@ static int wn_v2_choose(const WnPlan& pl, int n_cu, int n_smp, int forced_P, int
         return (int)i;
     }
     return -1;
+}
+
+// true iff the wave-specialised kernel (variant 3) serves this configuration with ONE chain: an instantiated shape, at least
+// two streams, the parked tap-0 sums of all streams fit the LDS next to the activations, one CU per workgroup
+static bool wn_v3_applicable(const wn_config* cfg, int n_cu, int* out_vi, int* outP, int* outPA) {
+    const char* force = getenv("WN_KERNEL");  // "generic" / "v2" pin the older kernels (A/B runs, tests)
+    if (force && (!strcmp(force, "generic") || !strcmp(force, "v2"))) return false;
+    if (cfg->n_streams < 2) return false;
+    WnPlan pl;
+    memset(&pl, 0, sizeof(pl));
+    pl.layers = cfg->layers; pl.blocks = cfg->blocks; pl.NL = cfg->layers * cfg->blocks;
+    pl.R = cfg->residual_channels; pl.D = cfg->dilation_channels; pl.S = cfg->skip_channels; pl.E = cfg->end_channels;
+    pl.C = cfg->classes; pl.k = cfg->kernel_size; pl.n_streams = cfg->n_streams;
+    const int n_smp = cfg->n_streams < 4 ? cfg->n_streams : 4;
+    int P = 0, PA = 0;
+    const int vi = wn_v2_choose(pl, n_cu, n_smp, cfg->layer_split, cfg->head_split, &P, &PA);
+    if (vi < 0 || !wn_v2_table()[vi].fn_v3) return false;
+    if (wn_v2_table()[vi].lds_floats_v3(cfg->n_streams) * 4 > WN_LDS_MAX_BYTES) return false;
+    if (out_vi) *out_vi = vi;
+    if (outP) *outP = P;
+    if (outPA) *outPA = PA;
+    return true;
 }
 
 // ------------------------------------------------------------------------------------------------ handle
@@ -317,7 +355,7 @@ extern "C" int wn_create(const wn_config* cfg, wn_handle** out) {
         const char* ce = getenv("WN_CHAINS");
         const bool off = ce && ce[0] == '1';
         const bool forced = ce && ce[0] == '2' && cfg->n_streams >= 4;
-        if (!g_chain_member && !off && (cfg->n_streams >= WN_CHAIN_MIN_STREAMS || forced)) {
+        if (!g_chain_member && !off && !wn_v3_applicable(cfg, n_cu, nullptr, nullptr, nullptr) && (cfg->n_streams >= WN_CHAIN_MIN_STREAMS || forced)) {
             const int ns = cfg->n_streams;
             const int K = 2 * ((ns + 2 * WN_CHAIN_MAX_STREAMS - 1) / (2 * WN_CHAIN_MAX_STREAMS));
             std::vector<wn_handle*> cs;
@@ -388,10 +426,20 @@ extern "C" int wn_create(const wn_config* cfg, wn_handle** out) {
     pl.C = cfg->classes; pl.k = cfg->kernel_size; pl.has_bias = cfg->bias ? 1 : 0; pl.n_streams = cfg->n_streams;
     h->variant = 1; h->v2_index = -1;
     {
-        const char* force = getenv("WN_KERNEL");  // "generic" pins the LDS-resident kernel (A/B runs, tests)
+        const char* force = getenv("WN_KERNEL");  // "generic" pins the LDS-resident kernel, "v2" the 256-thread register kernels (A/B runs, tests)
         int P2 = 0, PA2 = 0;
         const int n_smp = cfg->n_streams > 1 ? (cfg->n_streams < 4 ? cfg->n_streams : 4) : 0;
-        const int vi = (force && !strcmp(force, "generic")) ? -1 : wn_v2_choose(pl, n_cu, n_smp, cfg->layer_split, cfg->head_split, &P2, &PA2);
+        int vi3 = -1;
+        if (!g_chain_member && wn_v3_applicable(cfg, n_cu, &vi3, &P2, &PA2)) {
+            h->variant = 3; h->v2_index = vi3;
+            wn_plan_geometry(pl, P2, PA2);
+            pl.n_smp = n_smp;
+            pl.n_wg += n_smp;
+            pl.start_in_lds = 0;
+            h->w0lds = 0;
+            h->lds_bytes = wn_v2_table()[vi3].lds_floats_v3(pl.n_streams) * 4;
+        }
+        const int vi = (h->variant == 3 || (force && !strcmp(force, "generic"))) ? -1 : wn_v2_choose(pl, n_cu, n_smp, cfg->layer_split, cfg->head_split, &P2, &PA2);
         if (vi >= 0) {
             h->variant = 2; h->v2_index = vi;
             wn_plan_geometry(pl, P2, PA2);  // fills P, PA, Dc, Ec, n_wg (the LDS-image fields are unused by v2)
@@ -434,7 +482,7 @@ extern "C" int wn_create(const wn_config* cfg, wn_handle** out) {
     std::vector<int32_t> wg_map;
     pl.n_blocks = pl.n_wg;
     pl.allow_plain = 0;
-    if (h->variant == 2 && n_cu % 8 == 0 && wn_make_wg_map_layers(pl.NL, pl.P, pl.PA, pl.n_smp, 8, n_cu / 8, wg_map, &pl.n_blocks)) {
+    if (h->variant >= 2 && n_cu % 8 == 0 && wn_make_wg_map_layers(pl.NL, pl.P, pl.PA, pl.n_smp, 8, n_cu / 8, wg_map, &pl.n_blocks)) {
         const char* np = getenv("WN_NO_LOCAL_STORES");
         pl.allow_plain = (np && np[0] == '1') ? 0 : 1;
     } else {
@@ -444,7 +492,7 @@ extern "C" int wn_create(const wn_config* cfg, wn_handle** out) {
     const size_t gx_n = n_lw * pl.n_streams * pl.R, gs_n = n_lw * pl.n_streams * pl.S, gl_n = (size_t)pl.PA * pl.n_streams * pl.C;
     h->gran_count = gx_n + gs_n + gl_n + (size_t)pl.n_streams;
     h->blob_floats = n_lw * pl.blob_layer_floats + (size_t)pl.PA * pl.blob_head_floats;
-    if (h->variant == 2) {
+    if (h->variant >= 2) {
         const WnV2Entry& ve = wn_v2_table()[h->v2_index];
         h->blob_floats = n_lw * (size_t)ve.nwl * 256 + (size_t)pl.PA * ve.nwh * 256;
     }
@@ -476,7 +524,7 @@ extern "C" int wn_create(const wn_config* cfg, wn_handle** out) {
     pl.gx = h->d_gran; pl.gs = h->d_gran + gx_n; pl.gl = h->d_gran + gx_n + gs_n; pl.gi = h->d_gran + gx_n + gs_n + gl_n;
     pl.status = h->d_status;
     pl.xcc_tab = h->d_status + 8;
-    rc = rt_hip(hipFuncSetAttribute(h->variant == 2 ? (pl.n_smp > 0 ? (h->w0lds ? wn_v2_table()[h->v2_index].fn_multi_w0 : wn_v2_table()[h->v2_index].fn_multi) : wn_v2_table()[h->v2_index].fn)
+    rc = rt_hip(hipFuncSetAttribute(h->variant == 3 ? wn_v2_table()[h->v2_index].fn_v3 : h->variant == 2 ? (pl.n_smp > 0 ? (h->w0lds ? wn_v2_table()[h->v2_index].fn_multi_w0 : wn_v2_table()[h->v2_index].fn_multi) : wn_v2_table()[h->v2_index].fn)
                                                     : (const void*)wn_generate_kernel,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes),
                 "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
@@ -503,7 +551,7 @@ extern "C" int wn_load_weights(wn_handle* h, const wn_weight_ptrs* w) {
     WnHostWeights hw = {w->start_w, w->start_b, w->filter_w, w->filter_b, w->gate_w, w->gate_b, w->res_w,
                         w->res_b, w->skip_w, w->skip_b, w->end1_w, w->end1_b, w->end2_w, w->end2_b};
     std::vector<float> blobs;
-    if (h->variant == 2) wn_v2_table()[h->v2_index].pack(pl, hw, blobs);
+    if (h->variant >= 2) wn_v2_table()[h->v2_index].pack(pl, hw, blobs);
     else
         wn_pack_blobs(pl, hw, blobs);
     if (blobs.size() != h->blob_floats) return wn_fail(WN_E_STATE, "wn_load_weights: internal blob size mismatch");
@@ -712,7 +760,9 @@ extern "C" int wn_generate(wn_handle* h, const wn_generate_args* a) {
     int rc = rt_memset_async(h->d_gran, 0, h->gran_count * 8, a->hip_stream);
     rc = rc ? rc : rt_memset_async(h->d_status, 0, (size_t)(8 + h->plan.n_wg) * 4, a->hip_stream);
     if (rc) return rc;
-    if (h->variant == 2 && h->plan.n_smp > 0)
+    if (h->variant == 3)
+        wn_v2_table()[h->v2_index].launch_v3(h->plan.n_blocks, (size_t)h->lds_bytes, (hipStream_t)a->hip_stream, h->plan, r);
+    else if (h->variant == 2 && h->plan.n_smp > 0)
         wn_v2_table()[h->v2_index].launch_multi(h->w0lds, h->plan.n_blocks, (size_t)h->lds_bytes, (hipStream_t)a->hip_stream, h->plan, r);
     else if (h->variant == 2)
         wn_v2_table()[h->v2_index].launch(h->plan.n_blocks, (size_t)h->lds_bytes, (hipStream_t)a->hip_stream, h->plan, r);

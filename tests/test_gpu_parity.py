@@ -48,7 +48,7 @@ V2 = [("v2a", V2A, 1, 200, 20), ("v2a_ns3", V2A, 3, 120, 9), ("v2b_ns2", V2B, 2,
 def test_register_resident_kernel_shapes(label, cfg, ns, N, n_given):
     cfg, W, first, uniforms = make_case(cfg, 57, ns, n_given, N)
     eng = engine.Engine(cfg, W, n_streams=ns)
-    assert eng.info()["kernel_variant"] == 2
+    assert eng.info()["kernel_variant"] == (2 if ns == 1 else 3)
     g = check_engine(eng, cfg, W, N, first, 0.0, 0.0, None, label + " greedy")
     s = check_engine(eng, cfg, W, N, first, 0.8, 0.002, uniforms, label + " sampled")
     print(label, g, s, eng.info())
@@ -85,7 +85,7 @@ BIG = [("cfg2", "cfg2", 1, 150, 64), ("cfg2_ns4", "cfg2", 4, 60, 8), ("cfg3", "c
 def test_baseline_configs(label, cfgname, ns, N, n_given):
     cfg, W, first, uniforms = make_case(cfgname, 52, ns, n_given, N)
     eng = engine.Engine(cfg, W, n_streams=ns)
-    assert eng.info()["kernel_variant"] == 2
+    assert eng.info()["kernel_variant"] == (2 if ns == 1 or cfgname == "chaconne" else 3)
     g = check_engine(eng, cfg, W, N, first, 0.0, 0.0, None, label + " greedy")
     s = check_engine(eng, cfg, W, N, first, 1.0, 0.0, uniforms, label + " sampled")
     print(label, "greedy", g, "sampled", s, eng.info())
@@ -248,6 +248,7 @@ def test_two_chains_sharing_the_cus(monkeypatch):
     """With >= 16 streams (or WN_CHAINS=2) the job runs as two independent chains of n_streams/2 streams whose workgroups
     share the CUs two by two (wn_info.n_chains == 2): same samples as one chain and as the oracle, queues exported per
     stream, batched priming split per chain, per-stream temperatures routed to the owning chain."""
+    monkeypatch.setenv("WN_KERNEL", "v2")   # the 256-thread kernels; by default these jobs run on the wave-specialised kernel
     cfg, W, first, uniforms = make_case("cfg3", 61, 16, 70, 90)   # 70 given samples: batched priming + generation
     eng = engine.Engine(cfg, W, n_streams=16)
     info = eng.info()
@@ -285,9 +286,12 @@ def test_two_chains_sharing_the_cus(monkeypatch):
     e2.close()
 
 
-def test_per_stream_temperatures():
+@pytest.mark.parametrize("kernel", ["default", "v2"])
+def test_per_stream_temperatures(kernel, monkeypatch):
     """wn_generate_args.stream_temperatures: every stream samples at its own temperature (<= 0: argmax), all kernels."""
     from mi355_wavenet import engine, synth
+    if kernel != "default":
+        monkeypatch.setenv("WN_KERNEL", kernel)
     for cfgname, ns in (("tiny_bias", 3), ("cfg2", 3), ("cfg2", 1)):
         cfg = synth.CONFIGS[cfgname]
         W = synth.init_weights(cfg, seed=31)
@@ -304,9 +308,10 @@ def test_per_stream_temperatures():
             assert agree == 50, (cfgname, ns, s, t, agree)
 
 
-def test_two_chain_front_edge_cases():
+def test_two_chain_front_edge_cases(monkeypatch):
     """The multi-chain front handle on the calls the facade makes around a job: prime-only (zero samples), continuation
     without reset (progress callbacks), an odd stream count (chains of 9 + 8), a single generated sample."""
+    monkeypatch.setenv("WN_KERNEL", "v2")
     cfg, W, first, uniforms = make_case("cfg2", 71, 17, 6, 64)
     eng = engine.Engine(cfg, W, n_streams=17)
     assert eng.info()["n_chains"] == 2
@@ -344,3 +349,77 @@ def test_abi_error_codes_on_a_live_handle():
     assert d.wn_create(ctypes.byref(huge), ctypes.byref(h)) == _abi.WN_E_UNSUPPORTED
     assert b"co-resident" in d.wn_last_error()
     assert d.wn_create(ctypes.byref(_abi.wn_config(3, 2, 16, 16, 32, 32, 256, 2, 0, 1, 99, 0, 0)), ctypes.byref(h)) == _abi.WN_E_BADARG  # device 99
+
+
+# ---------------------------------------------------------------- wave-specialised multi-stream kernel (csrc/wn_kernel_v3.h)
+V3 = [("cfg1_ns2", "cfg1", 2, 150, 40), ("cfg1_bias_ns5", V2C, 5, 120, 9), ("cfg2_ns3", "cfg2", 3, 100, 700), ("cfg3_ns2", "cfg3", 2, 80, 5),
+      ("cfg3_ns7", "cfg3", 7, 60, 30), ("cfg3_ns40", "cfg3", 40, 40, 3), ("v2b_ns4", V2B, 4, 100, 20)]
+
+
+@pytest.mark.parametrize("label,cfg,ns,N,n_given", V3, ids=[c[0] for c in V3])
+def test_wave_specialised_kernel(label, cfg, ns, N, n_given):
+    """Variant 3 (512-thread layer workgroups: critical waves + tail waves) against the oracle: greedy, sampled with a
+    regulariser, priming through the chain (n_given - 1 teacher-forced evaluations, batched priming off), every stream."""
+    cfg, W, first, uniforms = make_case(cfg, 81, ns, n_given, N)
+    eng = engine.Engine(cfg, W, n_streams=ns)
+    info = eng.info()
+    assert info["kernel_variant"] == 3 and info["n_chains"] == 1
+    ids, logits = eng.generate(N, first, temperature=0.0, want_logits=True, batched_prime=False, timeout_ms=8000)
+    for s in sorted(set((0, ns // 2, ns - 1))):
+        o_idx, o_log = c_oracle.generate(cfg, W, N, first[s], 0.0, 0.0)
+        tol = 1e-5 * max(1.0, float(np.abs(o_log).max()))
+        if not np.array_equal(ids[s], o_idx):
+            t = int(np.argmax(ids[s] != o_idx))
+            row = np.sort(o_log[t])
+            assert row[-1] - row[-2] <= 10 * tol, (label, s, t)
+        else:
+            assert float(np.abs(logits[s] - o_log).max()) <= tol, (label, s)
+    sres = check_engine(eng, cfg, W, N, first, 0.9, 0.002, uniforms, label + " sampled") if ns <= 8 else None
+    if sres is None:
+        out = eng.generate(N, first, temperature=0.9, regularize=0.002, uniforms=uniforms, timeout_ms=8000)
+        for s in (0, ns // 2, ns - 1):
+            o_idx, _ = c_oracle.generate(cfg, W, N, first[s], 0.9, 0.002, uniforms[s])
+            assert np.array_equal(out[s], o_idx), (label, s)
+    print(label, sres, info)
+    eng.close()
+
+
+def test_wave_specialised_kernel_host_calls():
+    """The calls the facade makes around a job on variant 3: prime-only, continuation without reset, one generated sample,
+    per-stream temperatures, queue export, and equality with the 256-thread kernels on the same job."""
+    cfg, W, first, uniforms = make_case("cfg2", 82, 9, 6, 64)
+    eng = engine.Engine(cfg, W, n_streams=9)
+    assert eng.info()["kernel_variant"] == 3
+    idx = eng.generate(0, first, temperature=0.0)
+    assert idx.shape == (9, 0) and eng.info()["evals_done"] == 5
+    full = eng.generate(64, first, temperature=1.0, uniforms=uniforms)
+    a = eng.generate(23, first, temperature=1.0, uniforms=uniforms[:, :23])
+    b = eng.generate(41, a[:, -1:], temperature=1.0, uniforms=uniforms[:, 23:], reset=False)
+    assert np.array_equal(np.concatenate([a, b], axis=1), full)
+    assert eng.info()["evals_done"] == 6 - 1 + 64
+    q3 = [eng.export_queue(l, 4) for l in (0, 9, 29)]
+    one = eng.generate(1, first, temperature=1.0, uniforms=uniforms[:, :1])
+    assert np.array_equal(one, full[:, :1])
+    for s in (0, 4, 8):
+        o_idx, _ = c_oracle.generate(cfg, W, 64, first[s], 1.0, 0.0, uniforms[s])
+        assert np.array_equal(full[s], o_idx), s
+    temps = np.where(np.arange(9) % 3 == 0, 0.0, 0.5 + 0.1 * np.arange(9)).astype(np.float32)
+    out = eng.generate(40, first[:, :3], temperature=temps, uniforms=uniforms[:, :40])
+    for s in (0, 1, 8):
+        o_idx, _ = c_oracle.generate(cfg, W, 40, first[s, :3], float(temps[s]), 0.0, uniforms[s, :40] if temps[s] > 0 else None)
+        assert np.array_equal(out[s], o_idx), s
+    eng.close()
+    import os
+    os.environ["WN_KERNEL"] = "v2"
+    try:
+        old = engine.Engine(cfg, W, n_streams=9)
+        assert old.info()["kernel_variant"] == 2
+        a2 = old.generate(23, first, temperature=1.0, uniforms=uniforms[:, :23])
+        old.generate(41, a2[:, -1:], temperature=1.0, uniforms=uniforms[:, 23:], reset=False)
+        q2 = [old.export_queue(l, 4) for l in (0, 9, 29)]
+        old.close()
+    finally:
+        del os.environ["WN_KERNEL"]
+    assert np.array_equal(a2, a)
+    for (d3, i3, o3), (d2, i2, o2) in zip(q3, q2):
+        assert (i3, o3) == (i2, o2) and np.allclose(d3, d2, rtol=1e-5, atol=1e-6)

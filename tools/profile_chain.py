@@ -42,9 +42,12 @@ def main():
     raw = eng.profile_read(items)
     if ns > 1:
         tt = raw[P:NL * P, items // 4:items - ns // G].astype(np.float64) * 0.01
-        print("multi: wave0 input ready %.3f us after start, wave1 input ready %.3f us, barrier passed %.3f us; wave0 published %.3f, wave3 published %.3f" % (
-            (tt[:, :, 4] - tt[:, :, 0]).mean(), (tt[:, :, 7] - tt[:, :, 0]).mean(), (tt[:, :, 1] - tt[:, :, 0]).mean(),
-            (tt[:, :, 2] - tt[:, :, 0]).mean(), (tt[:, :, 6] - tt[:, :, 0]).mean()))
+        print("multi (critical waves): input in registers %.3f us after start, barrier A passed %.3f us, z staged (barrier B) %.3f us, x' published %.3f us" % (
+            (tt[:, :, 4] - tt[:, :, 0]).mean(), (tt[:, :, 1] - tt[:, :, 0]).mean(), (tt[:, :, 5] - tt[:, :, 0]).mean(),
+            (tt[:, :, 2] - tt[:, :, 0]).mean()))
+        if info["kernel_variant"] == 3:
+            print("tail waves: leave barrier B %.3f us after the critical waves' start of the item, finish the item (skip lane, queue, tap 0) %.3f us later; "
+                  "tail period %.3f us" % ((tt[:, :, 6] - tt[:, :, 0]).mean(), (tt[:, :, 7] - tt[:, :, 6]).mean(), np.diff(tt[:, :, 6], axis=1).mean()))
     st = raw.astype(np.float64) * 0.01  # us
     lo, hi = items // 4, items - ns // G  # steady state
     T = st[:, lo:hi, :]
