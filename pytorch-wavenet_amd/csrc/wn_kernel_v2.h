@@ -141,9 +141,12 @@ static __device__ __forceinline__ float wn_poll_fixed(WnCtx& cx, const wn_u64* b
             for (int j = 0; j < N; ++j) sum += __uint_as_float((uint32_t)v[j]);
             return sum;
         }
-        if ((++spins & 127u) == 0u) {
+        if ((++spins & 127u) == 0u) {  // the wall clock (s_memrealtime, hundreds of cycles) is only read on this slow path: the
+            // spin bound of a wait runs from its first check, not from a time stamp taken on every item
             if (__hip_atomic_load(cx.p->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { cx.fail = 1; return 0.f; }
-            if ((long long)wall_clock64() - cx.t_start > cx.r->timeout_ticks) { wn_give_up(cx, where, e, s); return 0.f; }
+            const long long now = (long long)wall_clock64();
+            if (spins == 128u) cx.t_start = now;
+            else if (now - cx.t_start > cx.r->timeout_ticks) { wn_give_up(cx, where, e, s); return 0.f; }
         }
         if constexpr (SLEEP > 0) __builtin_amdgcn_s_sleep(SLEEP);
     }
@@ -1039,11 +1042,14 @@ static __device__ void wn_v2_sampler(const WnPlan& p, const WnRun& r, WnCtx& cx,
     }
     __syncthreads();
     const bool local_i = locflags[0] != 0;
+    long long* park = reinterpret_cast<long long*>(lds_smp + 64);  // the 8 stamp slots behind the sampler scratch (both LDS layouts)
     for (long long e = 1; e <= r.n_eval; ++e) {
         for (int s = j; s < ns; s += p.n_smp) {
-            cx.t_start = (long long)wall_clock64();
+            const long long item = (e - 1) * ns + s;  // stamps (diagnostics): 0 start of the wait, 1 logits complete, 2 index published
+            wn_stamp(r, park, item, 0);
             const float logit = wn_poll_sum<16>(cx, p.gl + (size_t)s * 256 + tid, (size_t)ns * 256, p.PA, (uint32_t)e, WN_W_LOGITS, e, s);
             if (wn_barrier_failed(cx, failflag)) return;
+            wn_stamp(r, park, item, 1);
             int idx;
             if (e < r.n_given) {
                 idx = r.first[(size_t)s * r.n_given + e];
@@ -1061,6 +1067,8 @@ static __device__ void wn_v2_sampler(const WnPlan& p, const WnRun& r, WnCtx& cx,
                 if (local_i) __hip_atomic_store(p.gi + s, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 else __hip_atomic_store(p.gi + s, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
+            wn_stamp(r, park, item, 2);
+            wn_stamp_flush(r, park, cx.w, item);
             wn_lds_barrier();
         }
     }

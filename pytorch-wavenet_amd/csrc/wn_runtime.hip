@@ -224,18 +224,26 @@ static int wn_v2_choose(const WnPlan& pl, int n_cu, int n_smp, int forced_P, int
     return -1;
 }
 
+// dedicated sampler workgroups of a multi-stream chain (each serves the streams s = j mod n): 4 by default
+static int wn_sampler_count(int n_streams) {
+    int n = 4;
+    const char* e = getenv("WN_SAMPLERS");
+    if (e && atoi(e) >= 1 && atoi(e) <= 16) n = atoi(e);
+    return n_streams < n ? n_streams : n;
+}
+
 // true iff the wave-specialised kernel (variant 3) serves this configuration with ONE chain: an instantiated shape, at least
 // two streams, the parked tap-0 sums of all streams fit the LDS next to the activations, one CU per workgroup
 static bool wn_v3_applicable(const wn_config* cfg, int n_cu, int* out_vi, int* outP, int* outPA) {
     const char* force = getenv("WN_KERNEL");  // "generic" / "v2" pin the older kernels (A/B runs, tests)
     if (force && (!strcmp(force, "generic") || !strcmp(force, "v2"))) return false;
-    if (cfg->n_streams < 2) return false;
+    if (cfg->n_streams < WN_V3_MIN_STREAMS) return false;
     WnPlan pl;
     memset(&pl, 0, sizeof(pl));
     pl.layers = cfg->layers; pl.blocks = cfg->blocks; pl.NL = cfg->layers * cfg->blocks;
     pl.R = cfg->residual_channels; pl.D = cfg->dilation_channels; pl.S = cfg->skip_channels; pl.E = cfg->end_channels;
     pl.C = cfg->classes; pl.k = cfg->kernel_size; pl.n_streams = cfg->n_streams;
-    const int n_smp = cfg->n_streams < 4 ? cfg->n_streams : 4;
+    const int n_smp = wn_sampler_count(cfg->n_streams);
     int P = 0, PA = 0;
     const int vi = wn_v2_choose(pl, n_cu, n_smp, cfg->layer_split, cfg->head_split, &P, &PA);
     if (vi < 0 || !wn_v2_table()[vi].fn_v3) return false;
@@ -428,7 +436,7 @@ extern "C" int wn_create(const wn_config* cfg, wn_handle** out) {
     {
         const char* force = getenv("WN_KERNEL");  // "generic" pins the LDS-resident kernel, "v2" the 256-thread register kernels (A/B runs, tests)
         int P2 = 0, PA2 = 0;
-        const int n_smp = cfg->n_streams > 1 ? (cfg->n_streams < 4 ? cfg->n_streams : 4) : 0;
+        const int n_smp = cfg->n_streams > 1 ? wn_sampler_count(cfg->n_streams) : 0;
         int vi3 = -1;
         if (!g_chain_member && wn_v3_applicable(cfg, n_cu, &vi3, &P2, &PA2)) {
             h->variant = 3; h->v2_index = vi3;

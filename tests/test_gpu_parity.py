@@ -29,6 +29,16 @@ SMALL = [
 ]
 
 
+def _expected_variant(cfg, ns):
+    """3 = wave-specialised kernel (csrc/wn_kernel_v3.h): >= 4 streams and the cfg3 channel shape (skip rows in 16-byte pairs)."""
+    cfg = synth.CONFIGS[cfg] if isinstance(cfg, str) else cfg
+    shape3 = (cfg["residual_channels"], cfg["dilation_channels"], cfg["skip_channels"], cfg["end_channels"]) == (128, 128, 512, 256)
+    return 3 if ns >= 4 and shape3 else 2
+
+
+MINI3 = dict(synth.CONFIGS["cfg3"], layers=3, blocks=2)   # cfg3's channel shape, 6 layers: the wave-specialised kernel on 36 workgroups
+
+
 def test_library_is_the_hip_build():
     lib = _abi.load_product_library()
     assert lib.path.endswith("libwn_mi355.so") and not lib.host_memory
@@ -48,7 +58,7 @@ V2 = [("v2a", V2A, 1, 200, 20), ("v2a_ns3", V2A, 3, 120, 9), ("v2b_ns2", V2B, 2,
 def test_register_resident_kernel_shapes(label, cfg, ns, N, n_given):
     cfg, W, first, uniforms = make_case(cfg, 57, ns, n_given, N)
     eng = engine.Engine(cfg, W, n_streams=ns)
-    assert eng.info()["kernel_variant"] == (2 if ns == 1 else 3)
+    assert eng.info()["kernel_variant"] == _expected_variant(cfg, ns)
     g = check_engine(eng, cfg, W, N, first, 0.0, 0.0, None, label + " greedy")
     s = check_engine(eng, cfg, W, N, first, 0.8, 0.002, uniforms, label + " sampled")
     print(label, g, s, eng.info())
@@ -85,7 +95,7 @@ BIG = [("cfg2", "cfg2", 1, 150, 64), ("cfg2_ns4", "cfg2", 4, 60, 8), ("cfg3", "c
 def test_baseline_configs(label, cfgname, ns, N, n_given):
     cfg, W, first, uniforms = make_case(cfgname, 52, ns, n_given, N)
     eng = engine.Engine(cfg, W, n_streams=ns)
-    assert eng.info()["kernel_variant"] == (2 if ns == 1 or cfgname == "chaconne" else 3)
+    assert eng.info()["kernel_variant"] == _expected_variant(cfgname, ns)
     g = check_engine(eng, cfg, W, N, first, 0.0, 0.0, None, label + " greedy")
     s = check_engine(eng, cfg, W, N, first, 1.0, 0.0, uniforms, label + " sampled")
     print(label, "greedy", g, "sampled", s, eng.info())
@@ -150,7 +160,8 @@ def test_headline_workload_cfg3_x64_against_the_oracle():
             row = np.sort(g_log[t])
             assert row[-1] - row[-2] <= 10 * tol, "stream %d: greedy indices differ at step %d (gap %.3g)" % (s, t, row[-1] - row[-2])
     for s in range(ns):
-        assert np.array_equal(idx[s], idx[probes[s % 4]]) and np.array_equal(gidx[s], gidx[probes[s % 4]]), s
+        if s not in probes:
+            assert np.array_equal(idx[s], idx[probes[s % 4]]) and np.array_equal(gidx[s], gidx[probes[s % 4]]), s
     print("cfg3 x64 headline parity ok", info)
 
 
@@ -352,13 +363,13 @@ def test_abi_error_codes_on_a_live_handle():
 
 
 # ---------------------------------------------------------------- wave-specialised multi-stream kernel (csrc/wn_kernel_v3.h)
-V3 = [("cfg1_ns2", "cfg1", 2, 150, 40), ("cfg1_bias_ns5", V2C, 5, 120, 9), ("cfg2_ns3", "cfg2", 3, 100, 700), ("cfg3_ns2", "cfg3", 2, 80, 5),
-      ("cfg3_ns7", "cfg3", 7, 60, 30), ("cfg3_ns40", "cfg3", 40, 40, 3), ("v2b_ns4", V2B, 4, 100, 20)]
+V3 = [("mini3_ns4", MINI3, 4, 200, 40), ("mini3_bias_ns5", dict(MINI3, bias=True), 5, 150, 9), ("mini3_ns33", MINI3, 33, 100, 20),
+      ("cfg3_ns4", "cfg3", 4, 80, 700), ("cfg3_ns7", "cfg3", 7, 60, 30), ("cfg3_ns40", "cfg3", 40, 40, 3)]
 
 
 @pytest.mark.parametrize("label,cfg,ns,N,n_given", V3, ids=[c[0] for c in V3])
 def test_wave_specialised_kernel(label, cfg, ns, N, n_given):
-    """Variant 3 (512-thread layer workgroups: critical waves + tail waves) against the oracle: greedy, sampled with a
+    """Variant 3 (768-thread layer workgroups: critical, skip and queue wave groups; n_streams >= 4) against the oracle: greedy, sampled with a
     regulariser, priming through the chain (n_given - 1 teacher-forced evaluations, batched priming off), every stream."""
     cfg, W, first, uniforms = make_case(cfg, 81, ns, n_given, N)
     eng = engine.Engine(cfg, W, n_streams=ns)
@@ -387,7 +398,7 @@ def test_wave_specialised_kernel(label, cfg, ns, N, n_given):
 def test_wave_specialised_kernel_host_calls():
     """The calls the facade makes around a job on variant 3: prime-only, continuation without reset, one generated sample,
     per-stream temperatures, queue export, and equality with the 256-thread kernels on the same job."""
-    cfg, W, first, uniforms = make_case("cfg2", 82, 9, 6, 64)
+    cfg, W, first, uniforms = make_case(MINI3, 82, 9, 6, 64)
     eng = engine.Engine(cfg, W, n_streams=9)
     assert eng.info()["kernel_variant"] == 3
     idx = eng.generate(0, first, temperature=0.0)
@@ -397,7 +408,7 @@ def test_wave_specialised_kernel_host_calls():
     b = eng.generate(41, a[:, -1:], temperature=1.0, uniforms=uniforms[:, 23:], reset=False)
     assert np.array_equal(np.concatenate([a, b], axis=1), full)
     assert eng.info()["evals_done"] == 6 - 1 + 64
-    q3 = [eng.export_queue(l, 4) for l in (0, 9, 29)]
+    q3 = [eng.export_queue(l, 4) for l in (0, 2, 5)]
     one = eng.generate(1, first, temperature=1.0, uniforms=uniforms[:, :1])
     assert np.array_equal(one, full[:, :1])
     for s in (0, 4, 8):
@@ -416,7 +427,7 @@ def test_wave_specialised_kernel_host_calls():
         assert old.info()["kernel_variant"] == 2
         a2 = old.generate(23, first, temperature=1.0, uniforms=uniforms[:, :23])
         old.generate(41, a2[:, -1:], temperature=1.0, uniforms=uniforms[:, 23:], reset=False)
-        q2 = [old.export_queue(l, 4) for l in (0, 9, 29)]
+        q2 = [old.export_queue(l, 4) for l in (0, 2, 5)]
         old.close()
     finally:
         del os.environ["WN_KERNEL"]

@@ -46,8 +46,18 @@ def main():
             (tt[:, :, 4] - tt[:, :, 0]).mean(), (tt[:, :, 1] - tt[:, :, 0]).mean(), (tt[:, :, 5] - tt[:, :, 0]).mean(),
             (tt[:, :, 2] - tt[:, :, 0]).mean()))
         if info["kernel_variant"] == 3:
-            print("tail waves: leave barrier B %.3f us after the critical waves' start of the item, finish the item (skip lane, queue, tap 0) %.3f us later; "
-                  "tail period %.3f us" % ((tt[:, :, 6] - tt[:, :, 0]).mean(), (tt[:, :, 7] - tt[:, :, 6]).mean(), np.diff(tt[:, :, 6], axis=1).mean()))
+            rw = raw[P:NL * P, items // 4:items - ns // G]
+            m40 = (1 << 40) - 1
+            c0 = rw[:, :, 0] & m40
+            s6, q7 = rw[:, :, 6], rw[:, :, 7]
+            s_t0 = ((s6 & m40) - c0) * 0.01
+            s_len = (s6 >> 40) * 0.01
+            q_t0 = ((q7 & m40) - c0) * 0.01
+            q_push = ((q7 >> 40) & 0xfff) * 0.01
+            q_dot = ((q7 >> 52) & 0xfff) * 0.01
+            print("skip group: passes barrier B %.3f us after the critical group's start of the item (critical: %.3f), its chunk (request, 64-FMA dot, add, publish) "
+                  "takes %.3f us; queue group: passes barrier A at %.3f us, push + tap staging %.3f us, tap-0 dot + prefetch %.3f us" % (
+                      s_t0.mean(), (tt[:, :, 5] - tt[:, :, 0]).mean(), s_len.mean(), q_t0.mean(), q_push.mean(), q_dot.mean()))
     st = raw.astype(np.float64) * 0.01  # us
     lo, hi = items // 4, items - ns // G  # steady state
     T = st[:, lo:hi, :]
@@ -65,11 +75,23 @@ def main():
         for l in list(range(0, NL, max(1, NL // 10))) + [NL - 1]:
             print("  layer %2d: busy %s  wait %s" % (l, np.array2string(busy[l * P:(l + 1) * P], precision=2), np.array2string(wait[l * P:(l + 1) * P], precision=2)))
         print("  head    : busy %s  wait %s" % (np.array2string(busy[nlw:nlw + PA], precision=2), np.array2string(wait[nlw:nlw + PA], precision=2)))
+        n_smp = info["n_workgroups"] - nlw - PA
+        for j in range(n_smp):
+            rows = st[nlw + PA + j, lo:hi]
+            rows = rows[rows[:, 0] > 0]
+            if len(rows) > 2:
+                print("  sampler %d: waits %.2f us for the logits, samples + publishes in %.2f us; one token every %.2f us" % (
+                    j, (rows[:, 1] - rows[:, 0]).mean(), (rows[:, 2] - rows[:, 1]).mean(), np.diff(rows[:, 0]).mean()))
         crit = (T[:nlw, :, 2] - T[:nlw, :, 1]).mean()
         print("  layer staged->published %.3f us, published->done %.3f us" % (crit, (T[:nlw, :, 3] - T[:nlw, :, 2]).mean()))
         inp = (T[P:nlw, :, 4] - T[P:nlw, :, 0]).mean()
-        print("  layers>0: start->input in registers %.3f us, ->barrier passed %.3f us; request misses %.0f%% of items" % (
-            inp, (T[P:nlw, :, 1] - T[P:nlw, :, 4]).mean(), 100.0 * (st[P:nlw, hi - 1, 5] - st[P:nlw, lo, 5]).mean() / 0.01 / (hi - 1 - lo)))
+        if info["kernel_variant"] == 3:
+            print("  layers>0: start->input in registers %.3f us, ->barrier A passed %.3f us, ->barrier B passed %.3f us, ->x' published %.3f us, ->requests issued %.3f us" % (
+                inp, (T[P:nlw, :, 1] - T[P:nlw, :, 4]).mean(), (T[P:nlw, :, 5] - T[P:nlw, :, 1]).mean(), (T[P:nlw, :, 2] - T[P:nlw, :, 5]).mean(),
+                (T[P:nlw, :, 3] - T[P:nlw, :, 2]).mean()))
+        else:
+            print("  layers>0: start->input in registers %.3f us, ->barrier passed %.3f us; request misses %.0f%% of items" % (
+                inp, (T[P:nlw, :, 1] - T[P:nlw, :, 4]).mean(), 100.0 * (st[P:nlw, hi - 1, 5] - st[P:nlw, lo, 5]).mean() / 0.01 / (hi - 1 - lo)))
         eng.close()
         return
     # layer hops
