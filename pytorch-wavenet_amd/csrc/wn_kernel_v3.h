@@ -34,6 +34,16 @@
 #define WN_THREADS_V3 768
 #define WN_V3_MIN_STREAMS 4
 #define WN_V3_TAP_AHEAD 3
+#ifndef WN_V3_EARLY_REQ
+#define WN_V3_EARLY_REQ 0  // 1: inputs of the next item are also requested right after barrier A (measured: never fresh in steady state -- the
+                           // upstream stage publishes item i+1 about when this one publishes item i -- and the extra loads cost 2 %)
+#endif
+#ifndef WN_V3_SKIP_SLEEP
+#define WN_V3_SKIP_SLEEP 0  // s_sleep between the skip group's poll retries (the skip lane is not latency critical; fewer polls on the fabric)
+#endif
+#ifndef WN_V3_ABL
+#define WN_V3_ABL 0  // timing ablations (results are WRONG when != 0): 1 the skip group only passes its barriers, 2 the queue group, 3 both
+#endif
 #ifndef WN_V3_PRIO
 #define WN_V3_PRIO 0  // 1: critical waves at a higher static wave priority (measured: no effect, profiles/r02_v3_variants.txt)
 #endif
@@ -57,13 +67,14 @@ static __device__ __forceinline__ void wn_st_pair(__amdgpu_buffer_rsrc_t rs, uns
     else __builtin_amdgcn_raw_buffer_store_b128(d, rs, byte_off, 0, 16);        // write-through
 }
 // spins until both halves of the pair carry `tag` (bounded like wn_poll_fixed)
-static __device__ __forceinline__ wn_v4i wn_poll_pair(WnCtx& cx, __amdgpu_buffer_rsrc_t rs, unsigned byte_off, uint32_t tag, int where, long long e, int s) {
+static __device__ __forceinline__ wn_v4i wn_poll_pair(WnCtx& cx, __amdgpu_buffer_rsrc_t rs, unsigned byte_off, uint32_t tag, int where, long long e, int s, int sleep = 0) {
     wn_v4i v = {0, 0, 0, 0};
     if (cx.fail) return v;
     unsigned spins = 0;
     for (;;) {
         v = wn_ld_pair(rs, byte_off);
         if ((uint32_t)v.y == tag && (uint32_t)v.w == tag) return v;
+        if (sleep > 0) __builtin_amdgcn_s_sleep(WN_V3_SKIP_SLEEP > 0 ? WN_V3_SKIP_SLEEP : 1);
         if ((++spins & 127u) == 0u) {
             if (__hip_atomic_load(cx.p->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { cx.fail = 1; return v; }
             const long long now = (long long)wall_clock64();
@@ -137,20 +148,25 @@ static __device__ void wn_v3_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
         for (int k = 0; k < K2; ++k) w2[k] = img[(size_t)(2 * K1 + k) * 256];
         const float bres = img[(size_t)(2 * K1 + K2 + RS * DC + 1) * 256];
         long long* park = reinterpret_cast<long long*>(lds + L::park);
+        const __amdgpu_buffer_rsrc_t rs_gx = wn_rsrc(p.gx);
         // one-item-ahead request registers (branch-free, compile-time load count: see wn_v2_layer_multi)
         wn_u64 nx[P];
-        const wn_u64* xbase = l == 0 ? p.gi : p.gx + ((size_t)(l - 1) * P) * ns * R + (t < R ? t : 0);
-        const size_t xstep_s = l == 0 ? 1 : R, xstep_j = l == 0 ? 0 : (size_t)ns * R;
+        const wn_u64* xbase = (l == 0 ? p.g0 : p.gx + ((size_t)(l - 1) * P) * ns * R) + (t < R ? t : 0);
+        const size_t xstep_s = R, xstep_j = l == 0 ? 0 : (size_t)ns * R;  // layer 0 reads its single granule P times (branch-free loads)
         auto request = [&](int s2) {
 #pragma unroll
             for (int j = 0; j < P; ++j) nx[j] = wn_ld_granule(xbase + (size_t)s2 * xstep_s + (size_t)j * xstep_j);
         };
-        if (l == 0) nx[0] = wn_ld_granule(p.gi + (1 < ns ? 1 : 0));  // layer 0 looks one item further ahead (item 1's index granule)
-        else request(0);
+        request(0);
+        // A second, EARLY set of request registers: the next item's inputs are also requested right after barrier A of the
+        // current item.  With tokens queued in front of this stage that request already returns the data, and the next item
+        // starts without waiting for a memory round trip (a request issued only at the end of an item puts its ~0.4 us round
+        // trip on the stage's cycle: 1.09 us per item however many streams are in flight).  With nothing queued both requests
+        // come back stale and the stage polls, as before.
+        wn_u64 nxe[P];
+#pragma unroll
+        for (int j = 0; j < P; ++j) nxe[j] = 0;
         int buf = 0;
-        float xg = 0.f;          // layer 0: the start_conv row of the next item, fetched ahead when its index is already known
-        bool xg_valid = false;   // wave-uniform (the index is)
-        const float bias0 = (l == 0 && p.start_b && t < R) ? p.start_b[t] : 0.f;
         for (long long e = 0; e < r.n_eval; ++e) {
             const uint32_t tag = (uint32_t)(e + 1);
             for (int s = 0; s < ns; ++s, buf ^= 1) {
@@ -158,61 +174,40 @@ static __device__ void wn_v3_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
                 const long long item = e * ns + s;
                 wn_stamp(r, park, item, 0);
                 // ---- 1. layer input x[t]
-                if (l == 0) {
-                    // start_conv on a one-hot = a gather of one 512-byte row of start_conv^T (wavenet_model.py:127).  Index
-                    // granule -> dependent row load is ~0.9 us of serial latency; with tokens queued in front of layer 0 that
-                    // made layer 0 the slowest stage of the whole chain (1.7 us per item, profiles/r02_v3_samplers.txt).  The
-                    // row of the NEXT item is therefore fetched while this item computes (below, after barrier A) whenever its
-                    // index has already arrived; only a token that arrives just in time takes the serial path here.
-                    float xv = xg;
-                    if (!xg_valid) {
-                        int idx;
-                        if (e == 0) {
-                            idx = r.first[(size_t)s * r.n_given];
-                        } else {  // (nx[0] holds the granule of item i+1 here, see below: poll this item's afresh)
-                            wn_u64 gv;
-                            unsigned spins = 0;
-                            while ((uint32_t)((gv = wn_ld_granule(p.gi + s)) >> 32) != (uint32_t)e) {
-                                if ((++spins & 127u) == 0u) {
-                                    if (__hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { cx.fail = 1; break; }
-                                    const long long now = (long long)wall_clock64();
-                                    if (spins == 128u) cx.t_start = now;
-                                    else if (now - cx.t_start > r.timeout_ticks) { wn_give_up(cx, WN_W_LOGITS, e, s); break; }
-                                }
-                            }
-                            idx = (int)(uint32_t)gv & 255;
-                        }
-                        xv = t < R ? p.start_t[(size_t)idx * R + t] + bias0 : 0.f;
-                    }
-                    if (t < R) xb[SH::xpad(t)] = xv;
+                if (l == 0 && e == 0) {  // the first evaluation's input is a given sample: start_conv row gather (wavenet_model.py:127, 256-257)
+                    const int idx = r.first[(size_t)s * r.n_given];
+                    if (t < R) xb[SH::xpad(t)] = p.start_t[(size_t)idx * R + t] + (p.start_b ? p.start_b[t] : 0.f);
                 } else if (t < R) {
+                    // layer 0 (e > 0): ONE complete row per stream, published by the sampler that drew the class (the row gather
+                    // sits there, off this workgroup: with it layer 0 was the slowest stage of the chain); layers > 0: P partials
                     bool ok = true;
                     float sum = 0.f;
 #pragma unroll
-                    for (int j = 0; j < P; ++j) { ok = ok && ((uint32_t)(nx[j] >> 32) == tag); sum += __uint_as_float((uint32_t)nx[j]); }
+                    for (int j = 0; j < P; ++j)
+                        if (j == 0 || l > 0) { ok = ok && ((uint32_t)(nxe[j] >> 32) == tag); sum += __uint_as_float((uint32_t)nxe[j]); }
+                    if (!ok) {  // the early request was stale: the late one
+                        ok = true;
+                        sum = 0.f;
+#pragma unroll
+                        for (int j = 0; j < P; ++j)
+                            if (j == 0 || l > 0) { ok = ok && ((uint32_t)(nx[j] >> 32) == tag); sum += __uint_as_float((uint32_t)nx[j]); }
+                    }
                     if (!ok) {
-                        sum = wn_poll_fixed<P, WN_MULTI_SLEEP>(cx, p.gx + (((size_t)(l - 1) * P) * ns + s) * R + t, (size_t)ns * R, tag, WN_W_X, e, s);
+                        if (l == 0) sum = wn_poll_fixed<1, WN_MULTI_SLEEP>(cx, p.g0 + (size_t)s * R + t, 0, tag, WN_W_LOGITS, e, s);
+                        else sum = wn_poll_fixed<P, WN_MULTI_SLEEP>(cx, p.gx + (((size_t)(l - 1) * P) * ns + s) * R + t, (size_t)ns * R, tag, WN_W_X, e, s);
                     }
                     xb[SH::xpad(t)] = sum;
                 }
                 wn_stamp(r, park, item, 4);
                 if (wn_barrier_failed(cx, failflag)) return;  // ---- A(i): x staged
                 wn_stamp(r, park, item, 1);
-                if (l == 0) {  // the next item's start_conv row, if its index is known by now (requested one item ago)
-                    const bool wrap = s + 1 == ns;
-                    const int s1 = wrap ? 0 : s + 1;
-                    const long long e1 = wrap ? e + 1 : e;
-                    xg_valid = false;
-                    if (e1 < r.n_eval) {
-                        int idx1 = -1;
-                        if (e1 == 0) idx1 = r.first[(size_t)s1 * r.n_given];
-                        else if ((uint32_t)(nx[0] >> 32) == (uint32_t)e1) idx1 = (int)(uint32_t)nx[0] & 255;
-                        if (idx1 >= 0) {
-                            xg = t < R ? p.start_t[(size_t)idx1 * R + t] + bias0 : 0.f;
-                            xg_valid = true;
-                        }
-                    }
+#if WN_V3_EARLY_REQ
+                {   // early request of the next item's inputs (see above)
+                    const int s2 = s + 1 < ns ? s + 1 : 0;
+#pragma unroll
+                    for (int j = 0; j < P; ++j) nxe[j] = wn_ld_granule(xbase + (size_t)s2 * xstep_s + (size_t)j * xstep_j);
                 }
+#endif
                 // ---- 2. filter/gate: tap 1 on x[t] + parked tap 0, tanh * sigmoid   (wavenet_model.py:147-151)
                 const float xres = (c == 0 && kq2 == 0) ? xb[SH::xpad(row2)] : 0.f;
                 float acc = wn_dot_lds<K1>(w1, xb + kq1 * (K1 + 4), pre[s * 256 + t]);
@@ -227,16 +222,18 @@ static __device__ void wn_v3_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
                 if (l < NL - 1) {
                     float a2 = wn_dot_lds<K2>(w2, zs + kq2 * K2, 0.f);
                     a2 = wn_reduce<T2>(a2);
-                    if (kq2 == 0) wn_publish_at(p.gx + ((size_t)cx.w * ns + s) * R + row2, tag, (a2 + bres) + xres, local_x);
+                    const float xn = (a2 + bres) + xres;  // valid on the kq2 == 0 lane of every row
+                    if constexpr (T2 == 2) {
+                        // rows 2j and 2j+1 sit on lanes 4j and 4j+2: one 16-byte store {x'(2j), tag, x'(2j+1), tag} by lane 4j instead of
+                        // two 8-byte stores (write-through stores are retired per lane; consumers keep reading their own 8-byte half)
+                        const float xn1 = wn_dpp<0x4E>(xn);  // quad_perm [2,3,0,1]
+                        if ((t & 3) == 0) wn_st_pair(rs_gx, (unsigned)((((size_t)cx.w * ns + s) * R + row2) * 8), tag, xn, xn1, local_x);
+                    } else {
+                        if (kq2 == 0) wn_publish_at(p.gx + ((size_t)cx.w * ns + s) * R + row2, tag, xn, local_x);
+                    }
                 }
                 wn_stamp(r, park, item, 2);
-                if (l == 0) {  // the index granule of item i+2 (item i+1's is examined after the next barrier A)
-                    int s2 = s + 2;
-                    if (s2 >= ns) s2 -= ns;
-                    nx[0] = wn_ld_granule(p.gi + s2);
-                } else {
-                    request(s + 1 < ns ? s + 1 : 0);
-                }
+                request(s + 1 < ns ? s + 1 : 0);
                 wn_stamp(r, park, item, 3);
                 if (r.prof && item < r.prof_items && tid == 0) {  // slots 0-5 (6 and 7 belong to the skip and queue groups)
                     long long* dst = r.prof + ((size_t)cx.w * r.prof_items + item) * WN_STAMPS;
@@ -263,6 +260,9 @@ static __device__ void wn_v3_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
         const __amdgpu_buffer_rsrc_t rs_gs = wn_rsrc(p.gs);
         const size_t up_wg = (size_t)(l > 0 ? l - 1 : 0) * P + c;  // the upstream slice (l > 0)
         if (wn_barrier_failed(cx, failflag)) return;  // A(0)
+        wn_v4i sk_early[RS / 2];  // the upstream lane of the coming item, requested already at barrier A (may come back stale)
+#pragma unroll
+        for (int h2 = 0; h2 < RS / 2; ++h2) sk_early[h2] = wn_ld_pair(rs_gs, (unsigned)(((up_wg * ns + 0) * (size_t)S) * 8) + (unsigned)t * 16 + h2 * 4096);
         long long item = 0;
         for (long long e = 0; e < r.n_eval; ++e) {
             const bool prime = e < n_prime;
@@ -278,9 +278,14 @@ static __device__ void wn_v3_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
                 const unsigned off_me = (unsigned)((((size_t)cx.w * ns + s) * (size_t)S) * 8) + (unsigned)t * 16;
                 wn_v4i sk_now[RS / 2];
 #pragma unroll
-                for (int h2 = 0; h2 < RS / 2; ++h2) sk_now[h2] = wn_ld_pair(rs_gs, off_up + h2 * 4096);
+                for (int h2 = 0; h2 < RS / 2; ++h2) sk_now[h2] = (WN_V3_ABL & 1) ? wn_v4i{0, 0, 0, 0} : wn_ld_pair(rs_gs, off_up + h2 * 4096);
                 // ---- skip 1x1 partial on this lane of the running skip sum          (wavenet_model.py:154-162)
-                if (!prime) {
+                if ((WN_V3_ABL & 1) != 0) {
+                    if (l == NL - 1) {
+#pragma unroll
+                        for (int h2 = 0; h2 < RS / 2; ++h2) wn_st_pair(rs_gs, off_me + h2 * 4096, tag, 0.f, 0.f, local_s);
+                    }
+                } else if (!prime) {
                     float a3[RS];
 #pragma unroll
                     for (int q = 0; q < RS; ++q) a3[q] = bskip[q];
@@ -293,8 +298,9 @@ static __device__ void wn_v3_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
 #pragma unroll
                     for (int h2 = 0; h2 < RS / 2; ++h2) {
                         if (l > 0) {
-                            wn_v4i v = sk_now[h2];
-                            if ((uint32_t)v.y != tag || (uint32_t)v.w != tag) v = wn_poll_pair(cx, rs_gs, off_up + h2 * 4096, tag, WN_W_SKIN, e, s);
+                            wn_v4i v = sk_early[h2];
+                            if ((uint32_t)v.y != tag || (uint32_t)v.w != tag) v = sk_now[h2];
+                            if ((uint32_t)v.y != tag || (uint32_t)v.w != tag) v = wn_poll_pair(cx, rs_gs, off_up + h2 * 4096, tag, WN_W_SKIN, e, s, WN_V3_SKIP_SLEEP);
                             a3[2 * h2] += __int_as_float(v.x);
                             a3[2 * h2 + 1] += __int_as_float(v.z);
                         }
@@ -307,6 +313,13 @@ static __device__ void wn_v3_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
                 if (stamp)  // slot 6: the skip group's B(i) | its chunk length << 40 (10 ns ticks)
                     r.prof[((size_t)cx.w * r.prof_items + item) * WN_STAMPS + 6] = (t0 & 0xffffffffffll) | (((long long)wall_clock64() - t0) << 40);
                 if (wn_barrier_failed(cx, failflag)) return;  // ---- A(i+1)
+#if WN_V3_EARLY_REQ
+                {   // early request for the coming item
+                    const int s2 = s + 1 < ns ? s + 1 : 0;
+#pragma unroll
+                    for (int h2 = 0; h2 < RS / 2; ++h2) sk_early[h2] = wn_ld_pair(rs_gs, (unsigned)(((up_wg * ns + s2) * (size_t)S) * 8) + (unsigned)t * 16 + h2 * 4096);
+                }
+#endif
             }
         }
         (void)wn_barrier_failed(cx, failflag);  // B(N)
@@ -349,7 +362,7 @@ static __device__ void wn_v3_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
             const bool stamp = r.prof && item < r.prof_items && tid == 512;
             const long long t0 = stamp ? (long long)wall_clock64() : 0;
             // ---- queue push (wavenet_modules.py:55-57); stage the tap x[t+1-d] (d = 1: it is x[t] itself)
-            if (t < R) {
+            if (t < R && !(WN_V3_ABL & 2)) {
                 const float xv = xs[buf * L::XR + SH::xpad(t)];
                 rings_l[((size_t)s * ML + tmod) * R + t] = xv;
                 xol[SH::xpad(t)] = d != 1 ? xo_f[0] : xv;
@@ -359,8 +372,10 @@ static __device__ void wn_v3_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
             if (wn_barrier_failed(cx, failflag)) return;  // ---- B(i): the tap is staged
             const long long t1 = stamp ? (long long)wall_clock64() : 0;
             // ---- tap-0 half of the dilated conv for the NEXT timestep of this stream, parked for the critical group
-            pre[s * 256 + t] = wn_dot_lds<K1>(w0, xol + kq1 * (K1 + 4), bfg0);
-            xo_f[WN_V3_TAP_AHEAD - 1] = request_tap();
+            if (!(WN_V3_ABL & 2)) {
+                pre[s * 256 + t] = wn_dot_lds<K1>(w0, xol + kq1 * (K1 + 4), bfg0);
+                xo_f[WN_V3_TAP_AHEAD - 1] = request_tap();
+            }
             if (stamp)  // slot 7: the queue group's A(i) | push+stage length << 40 | dot length << 52
                 r.prof[((size_t)cx.w * r.prof_items + item) * WN_STAMPS + 7] =
                     (t0 & 0xffffffffffll) | (((t1 - t0) & 0xfff) << 40) | ((((long long)wall_clock64() - t1) & 0xfff) << 52);
@@ -466,6 +481,59 @@ static __device__ void wn_v3_head(const WnPlan& p, const WnRun& r, WnCtx& cx, fl
     }
 }
 
+// Sampler role (threads 0-255; workgroup j of n_smp serves the streams s = j mod n_smp): like wn_v2_sampler it turns the head's
+// partial logits of evaluation e-1 into the class index that enters evaluation e (teacher forced while priming) -- and then does
+// layer 0's start_conv itself: the row of start_conv^T for that class (+ bias) goes out as layer 0's input granules g0[s][R]
+// (tag e+1, 16-byte pairs), so that layer 0 consumes a ready vector like every other layer (wavenet_model.py:127, 300-302).
+template <class SH>
+static __device__ void wn_v3_sampler(const WnPlan& p, const WnRun& r, WnCtx& cx, float* lds_smp, int j) {
+    constexpr int R = SH::R;
+    static_assert(R <= 256 && R % 2 == 0, "one start_conv row per sampler workgroup");
+    const int tid = threadIdx.x, ns = p.n_streams;
+    int* failflag = reinterpret_cast<int*>(lds_smp + 48);
+    int* locflags = reinterpret_cast<int*>(lds_smp + 52);
+    if (tid == 0) {
+        *failflag = 0;
+        const int mine = wn_xcc_id();
+        __hip_atomic_store(p.xcc_tab + cx.w, (unsigned)(mine + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        locflags[0] = p.allow_plain ? (int)wn_same_xcd(cx, mine, 0, p.P) : 0;  // the row feeds every slice of layer 0
+    }
+    wn_lds_barrier();
+    const bool local_i = locflags[0] != 0;
+    const __amdgpu_buffer_rsrc_t rs_g0 = wn_rsrc(p.g0);
+    const float bias0 = (p.start_b && tid < R) ? p.start_b[tid] : 0.f;
+    long long* park = reinterpret_cast<long long*>(lds_smp + 64);
+    for (long long e = 1; e <= r.n_eval; ++e) {
+        for (int s = j; s < ns; s += p.n_smp) {
+            const long long item = (e - 1) * ns + s;  // stamps (diagnostics): 0 start of the wait, 1 logits complete, 2 row published
+            wn_stamp(r, park, item, 0);
+            const float logit = wn_poll_sum<16>(cx, p.gl + (size_t)s * 256 + tid, (size_t)ns * 256, p.PA, (uint32_t)e, WN_W_LOGITS, e, s);
+            if (wn_barrier_failed(cx, failflag)) return;
+            wn_stamp(r, park, item, 1);
+            int idx;
+            if (e < r.n_given) {
+                idx = r.first[(size_t)s * r.n_given + e];
+            } else {
+                const long long g = e - r.n_given;
+                if (r.dbg_logits) r.dbg_logits[((size_t)s * r.num_samples + g) * 256 + tid] = logit;
+                const float temp = r.stream_temps ? r.stream_temps[s] : r.temperature;
+                const bool greedy = r.greedy != 0 || !(temp > 0.f);
+                const double u = greedy ? 0. : r.uniforms[(size_t)s * r.num_samples + g];
+                idx = wn_sample_v2(cx, lds_smp, logit, u, greedy, temp);
+                if (tid == 0) r.out_idx[(size_t)s * r.num_samples + g] = idx;
+            }
+            if (e < r.n_eval) {
+                const float v = tid < R ? p.start_t[(size_t)idx * R + tid] + bias0 : 0.f;
+                const float v1 = wn_dpp<0xB1>(v);  // quad_perm [1,0,3,2]: the odd neighbour's element
+                if (tid < R && (tid & 1) == 0) wn_st_pair(rs_g0, (unsigned)(((size_t)s * R + tid) * 8), (uint32_t)(e + 1), v, v1, local_i);
+            }
+            wn_stamp(r, park, item, 2);
+            wn_stamp_flush(r, park, cx.w, item);
+            wn_lds_barrier();
+        }
+    }
+}
+
 template <int R, int DC, int S, int EC, int P>
 __global__ __launch_bounds__(WN_THREADS_V3) void wn_generate_kernel_v3m(WnPlan p, WnRun r) {
     using SH = WnV2Shape<R, DC, S, EC>;
@@ -482,7 +550,7 @@ __global__ __launch_bounds__(WN_THREADS_V3) void wn_generate_kernel_v3m(WnPlan p
     }
     if (threadIdx.x >= WN_THREADS) return;  // head and sampler roles are 256-thread roles (wn_kernel_v2.h)
     if (w < n_layer_wg + p.PA) wn_v3_head<SH, P>(p, r, cx, wn_lds3m, w - n_layer_wg);
-    else wn_v2_sampler(p, r, cx, wn_lds3m + WnV3Lds<SH>::smp, w - n_layer_wg - p.PA);
+    else wn_v3_sampler<SH>(p, r, cx, wn_lds3m + WnV3Lds<SH>::smp, w - n_layer_wg - p.PA);
 }
 
 #endif  // WN_KERNEL_V3_H

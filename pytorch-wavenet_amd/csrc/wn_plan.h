@@ -71,6 +71,7 @@ struct WnPlan {
     wn_u64* gs;               // skip lanes    [(NL*P)][n_streams][S]
     wn_u64* gl;               // partial logits[PA][n_streams][C]
     wn_u64* gi;               // sampled class index per stream [n_streams] (multi-stream kernel: samplers -> L0)
+    wn_u64* g0;               // variant 3: layer 0's input, the start_conv row of the sampled class [n_streams][R] (samplers -> L0)
     int32_t n_smp;            // dedicated sampler workgroups (0 in the single-stream kernels)
     int32_t start_in_lds;     // v2 single-stream: layer 0 holds start_conv^T in LDS
     uint32_t* status;         // [8] 0: abort code, 1: chain position, 2: eval, 3: stream, 4: where

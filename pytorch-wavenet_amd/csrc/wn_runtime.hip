@@ -498,7 +498,8 @@ extern "C" int wn_create(const wn_config* cfg, wn_handle** out) {
     }
     const size_t n_lw = (size_t)pl.NL * pl.P;
     const size_t gx_n = n_lw * pl.n_streams * pl.R, gs_n = n_lw * pl.n_streams * pl.S, gl_n = (size_t)pl.PA * pl.n_streams * pl.C;
-    h->gran_count = gx_n + gs_n + gl_n + (size_t)pl.n_streams;
+    const size_t g0_n = h->variant == 3 ? (size_t)pl.n_streams * pl.R : 0;
+    h->gran_count = gx_n + gs_n + gl_n + (size_t)pl.n_streams + g0_n;
     h->blob_floats = n_lw * pl.blob_layer_floats + (size_t)pl.PA * pl.blob_head_floats;
     if (h->variant >= 2) {
         const WnV2Entry& ve = wn_v2_table()[h->v2_index];
@@ -530,6 +531,7 @@ extern "C" int wn_create(const wn_config* cfg, wn_handle** out) {
     pl.blobs = h->d_blobs; pl.start_t = h->d_start_t; pl.start_b = nullptr;
     pl.dil = h->d_dil; pl.ring_off = h->d_ring_off; pl.wg_map = h->d_wg_map; pl.rings = h->d_rings;
     pl.gx = h->d_gran; pl.gs = h->d_gran + gx_n; pl.gl = h->d_gran + gx_n + gs_n; pl.gi = h->d_gran + gx_n + gs_n + gl_n;
+    pl.g0 = pl.gi + pl.n_streams;
     pl.status = h->d_status;
     pl.xcc_tab = h->d_status + 8;
     rc = rt_hip(hipFuncSetAttribute(h->variant == 3 ? wn_v2_table()[h->v2_index].fn_v3 : h->variant == 2 ? (pl.n_smp > 0 ? (h->w0lds ? wn_v2_table()[h->v2_index].fn_multi_w0 : wn_v2_table()[h->v2_index].fn_multi) : wn_v2_table()[h->v2_index].fn)

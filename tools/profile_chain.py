@@ -82,6 +82,21 @@ def main():
             if len(rows) > 2:
                 print("  sampler %d: waits %.2f us for the logits, samples + publishes in %.2f us; one token every %.2f us" % (
                     j, (rows[:, 1] - rows[:, 0]).mean(), (rows[:, 2] - rows[:, 1]).mean(), np.diff(rows[:, 0]).mean()))
+        # cross-workgroup hand-off: x' published by layer l-1 (latest of its P slices) -> layer l has its input in registers
+        m40 = (1 << 40) - 1
+        rawT = raw[:nlw, lo:hi, :] & m40
+        layT = rawT.reshape(NL, P, hi - lo, 8).astype(np.float64) * 0.01
+        pub_prev = layT[:-1, :, :, 2].max(axis=1)                      # (NL-1, items)
+        got = layT[1:, :, :, 4]                                        # (NL-1, P, items)
+        hop = got - pub_prev[:, None, :]
+        start_next = layT[1:, :, :, 0]
+        early = (start_next <= pub_prev[:, None, :])                   # the consumer was already looking when the data was published
+        print("  hand-off x' published -> consumer has it in registers: mean %.3f us (p10 %.3f, p50 %.3f, p90 %.3f); the consumer was already waiting in %.0f%% of the hand-offs; "
+              "when it was: %.3f us, when it came later: %.3f us after ITS start" % (
+                  hop.mean(), np.percentile(hop, 10), np.percentile(hop, 50), np.percentile(hop, 90), 100.0 * early.mean(),
+                  hop[early].mean() if early.any() else float("nan"), (got - start_next)[~early].mean() if (~early).any() else float("nan")))
+        by_layer = hop.mean(axis=(1, 2))
+        print("  hand-off by consumer layer: %s" % np.array2string(by_layer, precision=2, max_line_width=200))
         crit = (T[:nlw, :, 2] - T[:nlw, :, 1]).mean()
         print("  layer staged->published %.3f us, published->done %.3f us" % (crit, (T[:nlw, :, 3] - T[:nlw, :, 2]).mean()))
         inp = (T[P:nlw, :, 4] - T[P:nlw, :, 0]).mean()
