@@ -260,9 +260,11 @@ static __device__ void wn_v3_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
         const __amdgpu_buffer_rsrc_t rs_gs = wn_rsrc(p.gs);
         const size_t up_wg = (size_t)(l > 0 ? l - 1 : 0) * P + c;  // the upstream slice (l > 0)
         if (wn_barrier_failed(cx, failflag)) return;  // A(0)
+#if WN_V3_EARLY_REQ
         wn_v4i sk_early[RS / 2];  // the upstream lane of the coming item, requested already at barrier A (may come back stale)
 #pragma unroll
         for (int h2 = 0; h2 < RS / 2; ++h2) sk_early[h2] = wn_ld_pair(rs_gs, (unsigned)(((up_wg * ns + 0) * (size_t)S) * 8) + (unsigned)t * 16 + h2 * 4096);
+#endif
         long long item = 0;
         for (long long e = 0; e < r.n_eval; ++e) {
             const bool prime = e < n_prime;
@@ -298,8 +300,12 @@ static __device__ void wn_v3_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
 #pragma unroll
                     for (int h2 = 0; h2 < RS / 2; ++h2) {
                         if (l > 0) {
-                            wn_v4i v = sk_early[h2];
+#if WN_V3_EARLY_REQ
+                            wn_v4i v = sk_early[h2];   // (only ever this item's stream: re-requested after every barrier A)
                             if ((uint32_t)v.y != tag || (uint32_t)v.w != tag) v = sk_now[h2];
+#else
+                            wn_v4i v = sk_now[h2];
+#endif
                             if ((uint32_t)v.y != tag || (uint32_t)v.w != tag) v = wn_poll_pair(cx, rs_gs, off_up + h2 * 4096, tag, WN_W_SKIN, e, s, WN_V3_SKIP_SLEEP);
                             a3[2 * h2] += __int_as_float(v.x);
                             a3[2 * h2 + 1] += __int_as_float(v.z);

@@ -8,7 +8,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-CMD="python $ROOT/bench.py --steps 3 --warmup 1 --no-extra --no-cpu-baseline"
+CMD="python $ROOT/tools/rate.py cfg3 64 2000 2"   # one wn_generate job of 2000 timesteps x 64 streams per repetition (the engine-level leg of bench.py)
 rm -rf /tmp/prof_kt /tmp/prof_f /tmp/prof_w
 timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_kt -o kt -- $CMD > /tmp/kt.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/prof_f -o f -- $CMD > /tmp/f.log 2>&1
@@ -17,7 +17,7 @@ cd "$ROOT"
 {
   echo "# rocprofv3 (ROCm 7.2) summaries of: $CMD"
   echo "# pass 1: --kernel-trace --stats; pass 2: --pmc FETCH_SIZE; pass 3: --pmc WRITE_SIZE (counters in separate passes)"
-  grep -h '^{"metric"' /tmp/kt.log | head -1 | cut -c1-400
+  grep -h 'samples/s' /tmp/kt.log | head -1
   python tools/rocprof_summary.py $(find /tmp/prof_kt /tmp/prof_f /tmp/prof_w -name "*.db" | sort)
 } > "$OUT/rocprofv3_$TAG.txt" 2>&1
 head -c 3000 "$OUT/rocprofv3_$TAG.txt"
