@@ -23,16 +23,16 @@
 //   xs[buf(i)]   W: C before A(i).  R: C in A(i)..A(i+1), Q in A(i)..B(i).  Next W (item i+2) after B(i+1).
 //   zs           W: C in A(i)..B(i).  R: C and S in B(i)..A(i+1).
 //   xo           W: Q in A(i)..B(i).  R: Q in B(i)..A(i+1).
-//   pre[s]       W: Q in B(i)..A(i+1) for item (e, s).  R: C in A(j)..B(j) of item j = (e+1, s) = i + n_streams >= i + 4.
-// Queue (HBM) hazard: the tap of item j is read 3 items ahead, during item j-3; it was pushed (d >= 2) at item j - n_streams*(d-1)
-// at the latest j - n_streams, so the kernel needs n_streams >= 4 (smaller jobs run on the kernels of wn_kernel_v2.h).
+//   pre[s]       W: Q in B(i)..A(i+1) for item (e, s).  R: C in A(j)..B(j) of item j = (e+1, s) = i + n_streams >= i + 1.
+// Queue (HBM) hazard: the tap of item j is read 3 items ahead, during item j-3; it was pushed (d >= 2) at item j - n_streams*(d-1).
+// Where that is fewer than 4 items back (1-3 streams, d <= 4) the queue group takes the row from its own registers instead.
 #ifndef WN_KERNEL_V3_H
 #define WN_KERNEL_V3_H
 
 #include "wn_kernel_v2.h"
 
 #define WN_THREADS_V3 768
-#define WN_V3_MIN_STREAMS 4
+#define WN_V3_MIN_STREAMS 1
 #define WN_V3_TAP_AHEAD 3
 #ifndef WN_V3_EARLY_REQ
 #define WN_V3_EARLY_REQ 0  // 1: inputs of the next item are also requested right after barrier A (measured: never fresh in steady state -- the
@@ -360,6 +360,12 @@ static __device__ void wn_v3_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
     };
 #pragma unroll
     for (int j = 0; j < WN_V3_TAP_AHEAD; ++j) xo_f[j] = request_tap();
+    // With few streams and a small dilation the tap row of an item was pushed fewer than WN_V3_TAP_AHEAD items before it (it is
+    // x of item i - n_streams*(d-1)): the lane keeps its own last three x values instead of reading the queue ahead of the push.
+    static_assert(WN_V3_TAP_AHEAD == 3, "the register history below holds three items");
+    const long long back = (long long)ns * (d - 1);
+    const bool near = d != 1 && back <= WN_V3_TAP_AHEAD;
+    float hx[3] = {0.f, 0.f, 0.f};
     int buf = 0;
     long long item = 0;
     for (long long e = 0; e < r.n_eval; ++e, tmod = (tmod + 1 == ML) ? 0 : tmod + 1) {
@@ -371,7 +377,13 @@ static __device__ void wn_v3_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
             if (t < R && !(WN_V3_ABL & 2)) {
                 const float xv = xs[buf * L::XR + SH::xpad(t)];
                 rings_l[((size_t)s * ML + tmod) * R + t] = xv;
-                xol[SH::xpad(t)] = d != 1 ? xo_f[0] : xv;
+                // the tap: d = 1: x[t] itself; a row pushed fewer items ago than the prefetch distance (few streams, small d):
+                // this lane's own copy of it (the queue read ahead of the push would be stale); else the prefetched queue row
+                float tap = xo_f[0];
+                if (d == 1) tap = xv;
+                else if (near && item >= back) tap = back == 1 ? hx[0] : back == 2 ? hx[1] : hx[2];
+                xol[SH::xpad(t)] = tap;
+                hx[2] = hx[1]; hx[1] = hx[0]; hx[0] = xv;
             }
 #pragma unroll
             for (int j = 0; j + 1 < WN_V3_TAP_AHEAD; ++j) xo_f[j] = xo_f[j + 1];

@@ -441,8 +441,8 @@ extern "C" int wn_create(const wn_config* cfg, wn_handle** out) {
         if (!g_chain_member && wn_v3_applicable(cfg, n_cu, &vi3, &P2, &PA2)) {
             h->variant = 3; h->v2_index = vi3;
             wn_plan_geometry(pl, P2, PA2);
-            pl.n_smp = n_smp;
-            pl.n_wg += n_smp;
+            pl.n_smp = wn_sampler_count(cfg->n_streams);  // variant 3 always samples on dedicated workgroups (they also feed layer 0)
+            pl.n_wg += pl.n_smp;
             pl.start_in_lds = 0;
             h->w0lds = 0;
             h->lds_bytes = wn_v2_table()[vi3].lds_floats_v3(pl.n_streams) * 4;

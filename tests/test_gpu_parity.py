@@ -30,10 +30,11 @@ SMALL = [
 
 
 def _expected_variant(cfg, ns):
-    """3 = wave-specialised kernel (csrc/wn_kernel_v3.h): >= 4 streams and the cfg3 channel shape (skip rows in 16-byte pairs)."""
+    """3 = wave-specialised kernel (csrc/wn_kernel_v3.h): the cfg3 channel shape (skip rows in 16-byte pairs), any stream count."""
     cfg = synth.CONFIGS[cfg] if isinstance(cfg, str) else cfg
     shape3 = (cfg["residual_channels"], cfg["dilation_channels"], cfg["skip_channels"], cfg["end_channels"]) == (128, 128, 512, 256)
-    return 3 if ns >= 4 and shape3 else 2
+    import os
+    return 3 if shape3 and os.environ.get("WN_KERNEL") not in ("v2", "generic") else 2
 
 
 MINI3 = dict(synth.CONFIGS["cfg3"], layers=3, blocks=2)   # cfg3's channel shape, 6 layers: the wave-specialised kernel on 36 workgroups
@@ -363,7 +364,8 @@ def test_abi_error_codes_on_a_live_handle():
 
 
 # ---------------------------------------------------------------- wave-specialised multi-stream kernel (csrc/wn_kernel_v3.h)
-V3 = [("mini3_ns4", MINI3, 4, 200, 40), ("mini3_bias_ns5", dict(MINI3, bias=True), 5, 150, 9), ("mini3_ns33", MINI3, 33, 100, 20),
+V3 = [("mini3_ns1", MINI3, 1, 300, 40), ("mini3_ns2", MINI3, 2, 200, 7), ("mini3_ns3_bias", dict(MINI3, bias=True), 3, 200, 25), ("cfg3_ns1", "cfg3", 1, 100, 600),
+      ("mini3_ns4", MINI3, 4, 200, 40), ("mini3_bias_ns5", dict(MINI3, bias=True), 5, 150, 9), ("mini3_ns33", MINI3, 33, 100, 20),
       ("cfg3_ns4", "cfg3", 4, 80, 700), ("cfg3_ns7", "cfg3", 7, 60, 30), ("cfg3_ns40", "cfg3", 40, 40, 3)]
 
 
