@@ -176,7 +176,7 @@ def verify_against_oracle(cfg, W, first, uniforms, idx=None, audio=None, streams
     return ok
 
 
-def train_step_cfg5(device, N=32, L=16000, reps=3):
+def train_step_cfg5(device, N=32, L=16000, reps=3, precision="fp32"):
     """BASELINE configs[4] (SURVEY.md 8d "cfg5"): one training step -- model(x), F.cross_entropy, backward, Adam -- at
     layers=10 blocks=5 128/128/512, N one-second 16 kHz clips given as class indices, through the facade's native
     matrix-core forward + backward.  Reports step time and executed TFLOP/s (forward GEMM work x 3)."""
@@ -185,6 +185,7 @@ def train_step_cfg5(device, N=32, L=16000, reps=3):
     m = wavenet_model.WaveNetModel(layers=10, blocks=5, dilation_channels=128, residual_channels=128, skip_channels=512,
                                    end_channels=256, classes=256, output_length=1, kernel_size=2, bias=False).cuda(device)
     m.output_length = out_len = L - m.receptive_field + 1
+    m.matrix_precision = precision
     g = torch.Generator().manual_seed(1)
     idx = torch.randint(0, 256, (N, L), generator=g).cuda(device)
     target = torch.randint(0, 256, (N * out_len,), generator=g).cuda(device)
@@ -211,9 +212,11 @@ def train_step_cfg5(device, N=32, L=16000, reps=3):
         loss = step()
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / reps * 1e3
-    return {"ms_per_step": round(ms, 2), "clips": N, "clip_samples": L, "output_length": out_len, "dtype": "f32 (matrix cores)",
+    peak = 157.3 if precision == "fp32" else 2500.0  # dense MFMA peaks, TFLOP/s (MI355X_MICROARCH.md)
+    return {"ms_per_step": round(ms, 2), "clips": N, "clip_samples": L, "output_length": out_len,
+            "dtype": "f32 (matrix cores)" if precision == "fp32" else "bf16 matrix operands (forward, activation- and weight-gradient products), f32 accumulation and storage",
             "tflop_per_step": round(3 * fwd / 1e12, 2), "tflops": round(3 * fwd / ms / 1e9, 1),
-            "mfma_f32_peak_frac": round(3 * fwd / ms / 1e9 / 157.3, 3), "loss": round(float(loss.detach()), 4)}
+            "mfma_peak_tflops": peak, "mfma_peak_frac": round(3 * fwd / ms / 1e9 / peak, 4), "loss": round(float(loss.detach()), 4)}
 
 
 def train5_main(a, dist, rank, local, n_gpus, global_batch=32, L=16000):
@@ -439,10 +442,11 @@ def main():
             line["extra"]["prime_generate_script_shape"] = prime_timing(local)
         except Exception as e:  # noqa: BLE001
             line["extra"]["prime_generate_script_shape"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
-        try:
-            line["extra"]["train_cfg5"] = train_step_cfg5(local)
-        except Exception as e:  # noqa: BLE001 -- the secondary measurement must never cost the headline line
-            line["extra"]["train_cfg5"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+        for key, prec in (("train_cfg5", "fp32"), ("train_cfg5_bf16", "bf16")):
+            try:
+                line["extra"][key] = train_step_cfg5(local, precision=prec)
+            except Exception as e:  # noqa: BLE001 -- the secondary measurement must never cost the headline line
+                line["extra"][key] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
     if n_gpus == 1 and not a.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(cfgname)
     print(json.dumps(line))

@@ -466,6 +466,98 @@ __global__ __launch_bounds__(256, WN_GEMM_MINB) void wn_bwd_gemm_tn(WnGemmTnArgs
     }
 }
 
+// The same weight-gradient product with bf16 MATRIX OPERANDS (fp32 accumulation, fp32 atomics into the gradient): the rows of
+// A and B are rounded to bf16 (RNE) on their way into LDS and multiplied with v_mfma_f32_32x32x16_bf16 (16x the fp32 matrix
+// rate), which turns the product from matrix-pipe bound (104 TFLOP/s of fp32 MFMA) into a stream over the two operands.
+// The contraction runs over the ROWS, so both operands are needed "transposed" ([column][8 consecutive rows] per lane): a loader
+// thread reads a 4-column x 8-row patch (eight coalesced float4 loads), transposes it in registers and writes four 16-byte
+// [column][row 0..7] vectors.  Used by wn_train_backward when the step runs with bf16 operands (wn_set_forward_precision);
+// the one-hot product of start_conv stays on the fp32 kernel.
+#ifndef WN_TN_BF16_MINB
+#define WN_TN_BF16_MINB 3
+#endif
+__global__ __launch_bounds__(256, WN_TN_BF16_MINB) void wn_bwd_gemm_tn_bf16(WnGemmTnArgs g) {
+    constexpr int T = 128, KC = 32, LD = KC + 8;  // LDS rows: [column][KC rows of the chunk] bf16, padded to 80 bytes
+    __shared__ __attribute__((aligned(16))) unsigned short a_s[2][T * LD];
+    __shared__ __attribute__((aligned(16))) unsigned short b_s[2][T * LD];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int ka0 = blockIdx.x * T, nb0 = blockIdx.y * T;
+    const long long m_begin = (long long)blockIdx.z * g.rows_per_split;
+    long long m_end = m_begin + g.rows_per_split;
+    if (m_end > g.M) m_end = g.M;
+    if (m_begin >= m_end) return;
+    wn_f16v acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
+    // loader: threads 0-127 feed A, 128-255 feed B; unit = 8 rows (group mg) x 4 columns (group cg)
+    const bool is_b = tid >= 128;
+    const int u = tid & 127, mg = u >> 5, cg = u & 31;
+    const WnRowMap& rm = is_b ? g.b : g.a;
+    const int col0 = (is_b ? nb0 : ka0) + 4 * cg, ncols = is_b ? g.Nb : g.Ka;
+    const bool col_ok = col0 < ncols;
+    const bool relu = !is_b && g.relu_a;
+    float4 v[8];
+    auto fetch = [&](long long mc) {
+        long long m = mc + mg * 8;
+        unsigned q = (unsigned)m / (unsigned)g.rows_per_batch, rem = (unsigned)m - q * (unsigned)g.rows_per_batch;
+        const float* ptr = rm.base + (long long)q * rm.batch_stride + (rm.t0 + (long long)rem) * rm.row_stride + col0;
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) {
+            v[rr] = (col_ok && m + rr < m_end) ? *reinterpret_cast<const float4*>(ptr) : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (++rem == (unsigned)g.rows_per_batch) {  // next row is in the next batch entry
+                rem = 0; ++q;
+                ptr = rm.base + (long long)q * rm.batch_stride + rm.t0 * rm.row_stride + col0;
+            } else {
+                ptr += rm.row_stride;
+            }
+        }
+    };
+    auto stash = [&](int buf) {
+        unsigned short* dst = (is_b ? b_s[buf] : a_s[buf]) + (4 * cg) * LD + mg * 8;
+        if (relu) {
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr) { v[rr].x = fmaxf(v[rr].x, 0.f); v[rr].y = fmaxf(v[rr].y, 0.f); v[rr].z = fmaxf(v[rr].z, 0.f); v[rr].w = fmaxf(v[rr].w, 0.f); }
+        }
+        *reinterpret_cast<uint4*>(dst) = make_uint4(wn_pack_bf16(v[0].x, v[1].x), wn_pack_bf16(v[2].x, v[3].x), wn_pack_bf16(v[4].x, v[5].x), wn_pack_bf16(v[6].x, v[7].x));
+        *reinterpret_cast<uint4*>(dst + LD) = make_uint4(wn_pack_bf16(v[0].y, v[1].y), wn_pack_bf16(v[2].y, v[3].y), wn_pack_bf16(v[4].y, v[5].y), wn_pack_bf16(v[6].y, v[7].y));
+        *reinterpret_cast<uint4*>(dst + 2 * LD) = make_uint4(wn_pack_bf16(v[0].z, v[1].z), wn_pack_bf16(v[2].z, v[3].z), wn_pack_bf16(v[4].z, v[5].z), wn_pack_bf16(v[6].z, v[7].z));
+        *reinterpret_cast<uint4*>(dst + 3 * LD) = make_uint4(wn_pack_bf16(v[0].w, v[1].w), wn_pack_bf16(v[2].w, v[3].w), wn_pack_bf16(v[4].w, v[5].w), wn_pack_bf16(v[6].w, v[7].w));
+    };
+    fetch(m_begin);
+    stash(0);
+    __syncthreads();
+    int buf = 0;
+    for (long long mc = m_begin; mc < m_end; mc += KC, buf ^= 1) {
+        if (mc + KC < m_end) fetch(mc + KC);
+        const unsigned short* ar = a_s[buf] + (32 * wv + (lane & 31)) * LD + 8 * (lane >> 5);
+        const unsigned short* br = b_s[buf] + (lane & 31) * LD + 8 * (lane >> 5);
+#pragma unroll
+        for (int ks = 0; ks < KC / 16; ++ks) {
+            const wn_bf16x8 a = *reinterpret_cast<const wn_bf16x8*>(ar + 16 * ks);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const wn_bf16x8 b = *reinterpret_cast<const wn_bf16x8*>(br + 32 * j * LD + 16 * ks);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[j], 0, 0, 0);
+            }
+        }
+        if (mc + KC < m_end) stash(buf ^ 1);
+        __syncthreads();
+    }
+    const int col = lane & 31;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int ka = ka0 + 32 * wv + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+        if (ka >= g.Ka) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int nb = nb0 + 32 * j + col;
+            if (nb < g.Nb) unsafeAtomicAdd(g.c + (size_t)ka * g.ldc + nb, acc[j][i]);
+        }
+    }
+}
+
 // dF = dz * G * (1 - T^2), dG = dz * T * G * (1 - G), written in the packed [F(32) | G(32)] column order of Wfg^T.
 // dzg != NULL: the skip path's share of dz -- column block of the per-block product dskip . Wskip^T, [N*out_len][ldg] -- is
 // added on the last out_len rows of every batch entry (the rows the skip conv saw).

@@ -94,7 +94,7 @@ static void wn_launch_cvt_t(hipStream_t st, const float* in, long long in_batch_
                        in, in_batch_stride, out, rows, cols);
 }
 
-static void wn_launch_tn(hipStream_t st, WnGemmTnArgs a) {
+static void wn_launch_tn(hipStream_t st, WnGemmTnArgs a, bool bf16 = false) {
     // Split the rows so that ~1024 workgroups exist (four are resident per CU), but never below 256 rows per
     // split: every split ends with a 128x128 tile of atomics.
     const int tiles = ((a.Ka + 127) / 128) * ((a.Nb + 127) / 128);
@@ -106,7 +106,9 @@ static void wn_launch_tn(hipStream_t st, WnGemmTnArgs a) {
     rps = (rps + 31) / 32 * 32;
     splits = (a.M + rps - 1) / rps;
     a.rows_per_split = rps;
-    hipLaunchKernelGGL(wn_bwd_gemm_tn, dim3((unsigned)((a.Ka + 127) / 128), (unsigned)((a.Nb + 127) / 128), (unsigned)splits), dim3(256), 0, st, a);
+    const dim3 grid((unsigned)((a.Ka + 127) / 128), (unsigned)((a.Nb + 127) / 128), (unsigned)splits);
+    if (bf16 && !a.a_idx) hipLaunchKernelGGL(wn_bwd_gemm_tn_bf16, grid, dim3(256), 0, st, a);  // bf16 matrix operands, fp32 accumulation
+    else hipLaunchKernelGGL(wn_bwd_gemm_tn, grid, dim3(256), 0, st, a);
 }
 
 static void wn_launch_colsum(hipStream_t st, const WnRowMap& x, long long M, int rows_per_batch, int N, float* out) {
@@ -275,7 +277,7 @@ extern "C" int wn_train_backward(wn_handle* h, const float* params, const float*
     memset(&g, 0, sizeof(g));   // dW2^T [E][C] = e^T . dlogits
     g.a = WnRowMap{ev, out_len * E, E, 0}; g.b = WnRowMap{dlogits, out_len * C, C, 0};
     g.Ka = E; g.Nb = C; g.c = grads + h->fw_off_w2; g.ldc = C; g.M = Mo; g.rows_per_batch = (int)out_len;
-    wn_launch_tn(st, g);
+    wn_launch_tn(st, g, t.bf16);
     wn_launch_colsum(st, WnRowMap{dlogits, out_len * C, C, 0}, Mo, (int)out_len, C, grads + h->fw_off_b2);
     memset(&a, 0, sizeof(a));   // de = (dlogits . W2) * [e > 0]
     a.a0 = a.a1 = WnRowMap{dlogits, out_len * C, C, 0};
@@ -286,7 +288,7 @@ extern "C" int wn_train_backward(wn_handle* h, const float* params, const float*
     memset(&g, 0, sizeof(g));   // dW1^T [S][E] = relu(skip)^T . de
     g.a = WnRowMap{skip, out_len * S, S, 0}; g.b = WnRowMap{de, out_len * E, E, 0}; g.relu_a = 1;
     g.Ka = S; g.Nb = E; g.c = grads + h->fw_off_w1; g.ldc = E; g.M = Mo; g.rows_per_batch = (int)out_len;
-    wn_launch_tn(st, g);
+    wn_launch_tn(st, g, t.bf16);
     wn_launch_colsum(st, WnRowMap{de, out_len * E, E, 0}, Mo, (int)out_len, E, grads + h->fw_off_b1);
     memset(&a, 0, sizeof(a));   // dskip = (de . W1) * [skip > 0]
     a.a0 = a.a1 = WnRowMap{de, out_len * E, E, 0};
@@ -321,7 +323,7 @@ extern "C" int wn_train_backward(wn_handle* h, const float* params, const float*
             memset(&g, 0, sizeof(g));
             g.a = WnRowMap{z, rows * D, D, 0}; g.b = WnRowMap{dxn, L * (long long)R, R, t0};
             g.Ka = D; g.Nb = R; g.c = grads + h->fw_off_res + (size_t)l * D * R; g.ldc = R; g.M = M; g.rows_per_batch = (int)rows;
-            wn_launch_tn(st, g);
+            wn_launch_tn(st, g, t.bf16);
             if (pl.has_bias) wn_launch_colsum(st, WnRowMap{dxn, L * (long long)R, R, t0}, M, (int)rows, R, grads + h->fw_off_bres + (size_t)l * R);
         } else {
             rc = rt_hip(hipMemsetAsync(dz, 0, (size_t)M * D * 4, st), "hipMemsetAsync(dz)");
@@ -344,7 +346,7 @@ extern "C" int wn_train_backward(wn_handle* h, const float* params, const float*
             memset(&g, 0, sizeof(g));
             g.a = WnRowMap{zg, out_len * (long long)t.G * D, (long long)t.G * D, 0}; g.b = WnRowMap{dskip, out_len * S, S, 0};
             g.Ka = cnt * D; g.Nb = S; g.c = grads + h->fw_off_skip + (size_t)first * D * S; g.ldc = S; g.M = Mo; g.rows_per_batch = (int)out_len;
-            wn_launch_tn(st, g);
+            wn_launch_tn(st, g, t.bf16);
         }
         {   // [dF | dG] of dz + this layer's share of dzg
             const long long work = M * D;
@@ -356,7 +358,7 @@ extern "C" int wn_train_backward(wn_handle* h, const float* params, const float*
             g.a = WnRowMap{xin, L * (long long)R, R, tap ? t0 : t0 - d}; g.b = WnRowMap{dfg, rows * 2 * D, 2 * D, 0};
             g.Ka = R; g.Nb = 2 * D; g.c = grads + h->fw_off_fg + (size_t)l * 2 * R * 2 * D + (size_t)tap * R * 2 * D; g.ldc = 2 * D;
             g.M = M; g.rows_per_batch = (int)rows;
-            wn_launch_tn(st, g);
+            wn_launch_tn(st, g, t.bf16);
         }
         if (pl.has_bias) wn_launch_colsum(st, WnRowMap{dfg, rows * 2 * D, 2 * D, 0}, M, (int)rows, 2 * D, grads + h->fw_off_bfg + (size_t)l * 2 * D);
         // dx_l: rows [L - need[l], L); everything the two products below do not write must read as zero
@@ -383,7 +385,7 @@ extern "C" int wn_train_backward(wn_handle* h, const float* params, const float*
     g.a = WnRowMap{nullptr, L, 1, 0}; g.a_idx = reinterpret_cast<const int32_t*>(ws + t.idx);
     g.b = WnRowMap{dxn, L * (long long)R, R, 0};
     g.Ka = C; g.Nb = R; g.c = grads + h->fw_off_start_t; g.ldc = R; g.M = N * L; g.rows_per_batch = (int)L;
-    wn_launch_tn(st, g);
+    wn_launch_tn(st, g, t.bf16);
     if (pl.has_bias) wn_launch_colsum(st, WnRowMap{dxn, L * (long long)R, R, 0}, N * L, (int)L, R, grads + h->fw_off_start_b);
     return rt_hip(hipGetLastError(), "wn_train_backward launches");
 }

@@ -74,6 +74,35 @@ def test_gradients_match_torch_autograd(bias, extra, n):
         assert err <= 2e-5 * scale + 1e-9, (k, err, scale)
 
 
+def test_gradients_at_the_headline_widths():
+    """BASELINE config 5's stack -- 10 layers x 5 blocks, 128 / 128 / 512 / 256 channels: 50 layers, d up to 512, the grouped
+    skip product with 10 layers per group, different row splits of the weight-gradient products -- at N = 1, output_length = 32:
+    every parameter's gradient within 2e-5 of its largest element of torch autograd through the reference's conv1d graph.
+    The checker runs on the CPU (the facade's torch path, bit-equal to the reference there): no MIOpen shape searches."""
+    import copy
+    m = _model(True, layers=10, blocks=5, ch=128, skip=512, end=256, out_len=32, seed=5, gain=1.5)
+    x, target = _batch(m, 1, 0, seed=6)
+    ref = copy.deepcopy(m).cpu()
+    ref.zero_grad(set_to_none=True)
+    out_t = ref(x.cpu())
+    loss_t = torch.nn.functional.cross_entropy(out_t, target.cpu())
+    loss_t.backward()
+    g_t = {k: (None if p.grad is None else p.grad.detach().clone()) for k, p in ref.named_parameters()}
+    out_n, loss_n, g_n = _step(m, x, target, torch_path=False)
+    assert torch.allclose(out_n.cpu(), out_t.detach(), atol=1e-4, rtol=1e-4), float((out_n.cpu() - out_t.detach()).abs().max())
+    assert abs(loss_n - float(loss_t.detach())) < 1e-5 * max(1.0, abs(float(loss_t.detach())))
+    worst = 0.0
+    for k in g_t:
+        if g_t[k] is None:
+            assert g_n[k] is None, k
+            continue
+        scale = float(g_t[k].abs().max())
+        err = float((g_n[k].cpu() - g_t[k]).abs().max())
+        worst = max(worst, err / max(scale, 1e-30))
+        assert err <= 2e-5 * scale + 1e-9, (k, err, scale)
+    print("cfg5-width gradients: worst relative deviation %.2e over %d tensors" % (worst, len(g_t)))
+
+
 def test_packed_layout_matches_the_c_side():
     """pack(parameters) in Python == what wn_load_weights built in C (wn_train_export_params), element for element."""
     from mi355_wavenet import engine, training
