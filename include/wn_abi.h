@@ -16,10 +16,12 @@
  *     generate_fast from a daemon thread during training: model_logging.py:48-58).
  *   - wn_generate jobs are persistent kernels: every workgroup of a job must be resident before the job
  *     makes progress.  A job that finds the device's CUs taken (another handle's job, a long torch
- *     kernel) starts when they free up; its hand-off timeout (timeout_ms) runs from the moment its
- *     workgroups start, so size it for the longest job that may run next to it.  Jobs of >= 16 streams
- *     run as several independent chains, two workgroups per CU, on the caller's stream plus one
- *     library-owned stream (forked and joined with events: to the caller it is one asynchronous job).
+ *     kernel) starts when they free up; its hand-off timeout (timeout_ms) bounds every single hand-off
+ *     wait of its workgroups, so size it for the longest job that may run next to it.  Depending on the
+ *     shape a job is ONE persistent kernel (kernel_variant 3, any stream count up to ~150) or, on the
+ *     256-thread kernels from 16 streams up, several independent chains, two workgroups per CU, on the
+ *     caller's stream plus one library-owned stream (forked and joined with events: to the caller it is
+ *     one asynchronous job).
  */
 #ifndef WN_ABI_H
 #define WN_ABI_H
@@ -117,7 +119,9 @@ typedef struct wn_info {
     int64_t handoff_bytes;   /* inter-workgroup granule buffers */
     int64_t evals_done;      /* timesteps evaluated since the last wn_reset (queue time) */
     int32_t kernel_variant;  /* 1 = generic kernel (weights stationary in LDS, any shape)
-                                2 = latency-optimised kernel (weights stationary in registers, instantiated shapes) */
+                                2 = latency-optimised 256-thread kernels (weights stationary in registers, instantiated shapes)
+                                3 = wave-specialised kernel (768-thread layer workgroups: critical / skip / queue wave groups,
+                                    one chain for any stream count; shapes with an even number of skip rows per lane) */
     int32_t n_chains;        /* independent chains (persistent kernels) the streams are split over: 1, or an even number that
                                 share the CUs two by two; n_workgroups and the byte counts are totals over the chains */
 } wn_info;
@@ -165,9 +169,10 @@ int wn_export_queue(wn_handle* h, int32_t layer, int32_t stream, float* host_dat
  * multiples of 32: callers use the torch path for those. */
 int wn_forward(wn_handle* h, const int32_t* indices, int64_t N, int64_t L, int64_t output_length, float* logits, void* hip_stream);
 
-/* Operand precision of wn_forward, wn_train_forward and the activation-gradient products of wn_train_backward:
+/* Operand precision of wn_forward, wn_train_forward and the products of wn_train_backward (activation gradients AND weight
+ * gradients; the one-hot product of start_conv stays fp32):
  * 0 = fp32 matrix-core GEMMs (default: equals the reference's fp32 graph to rounding), 1 = bf16 operands with fp32
- * accumulation (residual stream, skip sum, saved activations, weight-gradient products and all accumulators stay fp32;
+ * accumulation (residual stream, skip sum, saved activations and all accumulators stay fp32;
  * logits differ from the fp32 path at the 1e-2 level of their scale, gradients by a few per cent in norm -- mostly sign
  * flips of ReLU masks).  WN_E_UNSUPPORTED unless R, D, S and E are multiples of 64. */
 int wn_set_forward_precision(wn_handle* h, int32_t bf16);
