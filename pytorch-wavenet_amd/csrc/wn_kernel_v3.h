@@ -9,8 +9,9 @@
 // around in 58 us (16 tokens: 58.2 us per timestep).  Each of these instruction streams is latency bound (~6 cycles per
 // instruction with one wave per SIMD), so the cure is more waves, each with its own part of the item.  A layer workgroup has
 // 768 threads = three wave groups, one wave of each per SIMD:
-//     waves 0-3  C "critical": poll x' partials -> stage x -> [A] -> filter/gate dot (tap 1) + parked tap 0 -> tanh*sigmoid -> z
-//                              -> [B] -> residual partial -> publish x' -> request the next item's inputs
+//     waves 0-3  C "critical": poll x' partials (two request sets in flight, hand-scheduled: wn_ap_poll4) -> stage x -> [A]
+//                              -> filter/gate dot (tap 1) + parked tap 0 -> tanh*sigmoid -> z -> [B] -> residual partial
+//                              -> publish x' -> request the next item's inputs
 //     waves 4-7  S "skip":     [B] -> request the upstream skip lane -> skip 1x1 partial -> add -> publish          -> [A]
 //     waves 8-11 Q "queue":    [A] -> queue push of x[t], stage the queue tap x[t+1-d] (prefetched 3 items ahead) -> [B]
 //                              -> tap-0 half of the dilated conv for the NEXT timestep of this stream -> park it  -> [A]
@@ -34,9 +35,8 @@
 #define WN_THREADS_V3 768
 #define WN_V3_MIN_STREAMS 1
 #define WN_V3_TAP_AHEAD 3
-#ifndef WN_V3_EARLY_REQ
-#define WN_V3_EARLY_REQ 0  // 1: inputs of the next item are also requested right after barrier A (measured: never fresh in steady state -- the
-                           // upstream stage publishes item i+1 about when this one publishes item i -- and the extra loads cost 2 %)
+#ifndef WN_V3_REQ_AT
+#define WN_V3_REQ_AT 0  // where set A of the next item's input is requested: 0 at the end of the item, 1 after barrier B, 2 after barrier A
 #endif
 #ifndef WN_V3_SKIP_SLEEP
 #define WN_V3_SKIP_SLEEP 0  // s_sleep between the skip group's poll retries (the skip lane is not latency critical; fewer polls on the fabric)
@@ -82,6 +82,125 @@ static __device__ __forceinline__ wn_v4i wn_poll_pair(WnCtx& cx, __amdgpu_buffer
             else if (now - cx.t_start > cx.r->timeout_ticks) { wn_give_up(cx, where, e, s); return v; }
         }
     }
+}
+
+// ---- Input polling of the critical group with TWO request sets in flight, hand-scheduled.
+// What the stamps of a 64-stream run show (profiles/r02_v3_first_check.txt, r02_load_flavour_probe.txt): a load takes ~0.1 us
+// on an idle chip and 0.25-0.3 us in the running chain, a store becomes visible ~0.25 us after its issue idle and ~0.45 us in the
+// running chain.  The request issued at the end of an item therefore comes back STALE in every item, and the token is caught by
+// the next poll a whole round trip later: the stage's cycle is quantised, service + 2 round trips (1.19 us).  With two sets in
+// flight half a round trip apart the token is caught within half a round trip of becoming visible.
+// The compiler cannot be made to schedule this: it derives every s_waitcnt vmcnt(N) from the order of the memory operations it
+// sees and falls back to waiting for (nearly) everything wherever paths with different sequences meet (loop entry vs back edge,
+// early exits, a store under a lane predicate) -- every variant written in C++ ended up waiting for the YOUNGEST set at every
+// check, and registers of a set that is still in flight when the wave moves on are handed to the next temporary behind a
+// full wait (profiles/r02_v3_request_experiments.txt).  So the sets live in the sixteen HIGHEST registers of the
+// 168 a 768-thread workgroup leaves each lane (A = v[152:159], B = v[160:167]; the compiler's own allocation stays below them --
+// tests/test_abi.py disassembles the library and checks that no instruction outside these blocks touches them; accumulation
+// registers would make the allocator split the register file in halves), and the loop is written out: issue, s_waitcnt vmcnt(4) = "the older set
+// is complete", check, reissue.  The wave leaves as soon as all its lanes have their input, with one set still in flight; it
+// lands in registers nobody else uses and is overwritten (in order) by the next request.
+#define WN_AP_CLOBBERS "v152", "v153", "v154", "v155", "v156", "v157", "v158", "v159", "v160", "v161", "v162", "v163", "v164", "v165", "v166", "v167", "vcc", "scc", "memory"
+static __device__ __forceinline__ void wn_ap_issue_a4(const wn_u64* p0, const wn_u64* p1, const wn_u64* p2, const wn_u64* p3) {
+    asm volatile(
+        "global_load_dwordx2 v[152:153], %0, off sc1\n\t"
+        "global_load_dwordx2 v[154:155], %1, off sc1\n\t"
+        "global_load_dwordx2 v[156:157], %2, off sc1\n\t"
+        "global_load_dwordx2 v[158:159], %3, off sc1"
+        ::"v"(p0), "v"(p1), "v"(p2), "v"(p3) : WN_AP_CLOBBERS);
+}
+static __device__ __forceinline__ void wn_ap_issue_a1(const wn_u64* p0) {
+    asm volatile("global_load_dwordx2 v[152:153], %0, off sc1" ::"v"(p0) : WN_AP_CLOBBERS);
+}
+// one check of a set: lanes that are not ok yet and see fresh tags take their sum (fixed order ((0+x0)+x1)+x2)+x3, as wn_poll_fixed)
+#define WN_AP_MERGE                                      \
+    "v_cmp_eq_u32_e64 %[m], 0, %[ok]\n\t"                \
+    "s_and_b64 %[m], %[m], vcc\n\t"                      \
+    "v_cndmask_b32_e64 %[sum], %[sum], %[t0], %[m]\n\t"  \
+    "v_cndmask_b32_e64 %[ok], %[ok], 1, %[m]\n\t"        \
+    "v_cmp_eq_u32_e32 vcc, 0, %[ok]\n\t"                 \
+    "s_nop 4\n\t"
+#define WN_AP_CHECK4(B0, B1, B2, B3, B4, B5, B6, B7)    \
+    "v_cmp_eq_u32_e32 vcc, %[tag], v" #B1 "\n\t"         \
+    "v_cmp_eq_u32_e64 %[m], %[tag], v" #B3 "\n\t"        \
+    "s_and_b64 vcc, vcc, %[m]\n\t"                       \
+    "v_cmp_eq_u32_e64 %[m], %[tag], v" #B5 "\n\t"        \
+    "s_and_b64 vcc, vcc, %[m]\n\t"                       \
+    "v_cmp_eq_u32_e64 %[m], %[tag], v" #B7 "\n\t"        \
+    "s_and_b64 vcc, vcc, %[m]\n\t"                       \
+    "v_add_f32_e32 %[t0], 0, v" #B0 "\n\t"               \
+    "v_add_f32_e32 %[t0], %[t0], v" #B2 "\n\t"           \
+    "v_add_f32_e32 %[t0], %[t0], v" #B4 "\n\t"           \
+    "v_add_f32_e32 %[t0], %[t0], v" #B6 "\n\t"           \
+    WN_AP_MERGE
+#define WN_AP_CHECK1(B0, B1)                             \
+    "v_cmp_eq_u32_e32 vcc, %[tag], v" #B1 "\n\t"         \
+    "v_add_f32_e32 %[t0], 0, v" #B0 "\n\t"               \
+    WN_AP_MERGE
+// Polls the granules p0..p3 until every active lane has seen four tags == tag, at most `rounds` double rounds (set A was issued by
+// wn_ap_issue_a4 at the end of the previous item; set B is issued here).  ok == 0: the lane ran out of rounds (caller: bounded wait).
+static __device__ __forceinline__ void wn_ap_poll4(const wn_u64* p0, const wn_u64* p1, const wn_u64* p2, const wn_u64* p3, uint32_t tag, int rounds,
+                                                    float& sum, int& ok) {
+    float t0;
+    long long m;
+    int cnt;
+    asm volatile(
+        "global_load_dwordx2 v[160:161], %[p0], off sc1\n\t"
+        "global_load_dwordx2 v[162:163], %[p1], off sc1\n\t"
+        "global_load_dwordx2 v[164:165], %[p2], off sc1\n\t"
+        "global_load_dwordx2 v[166:167], %[p3], off sc1\n\t"
+        "v_mov_b32_e32 %[ok], 0\n\t"
+        "v_mov_b32_e32 %[sum], 0\n\t"
+        "s_mov_b32 %[cnt], %[rounds]\n"
+        "1:\n\t"
+        "s_waitcnt vmcnt(4)\n\t"
+        WN_AP_CHECK4(152, 153, 154, 155, 156, 157, 158, 159)
+        "s_cbranch_vccz 2f\n\t"
+        "global_load_dwordx2 v[152:153], %[p0], off sc1\n\t"
+        "global_load_dwordx2 v[154:155], %[p1], off sc1\n\t"
+        "global_load_dwordx2 v[156:157], %[p2], off sc1\n\t"
+        "global_load_dwordx2 v[158:159], %[p3], off sc1\n\t"
+        "s_waitcnt vmcnt(4)\n\t"
+        WN_AP_CHECK4(160, 161, 162, 163, 164, 165, 166, 167)
+        "s_cbranch_vccz 2f\n\t"
+        "global_load_dwordx2 v[160:161], %[p0], off sc1\n\t"
+        "global_load_dwordx2 v[162:163], %[p1], off sc1\n\t"
+        "global_load_dwordx2 v[164:165], %[p2], off sc1\n\t"
+        "global_load_dwordx2 v[166:167], %[p3], off sc1\n\t"
+        "s_sub_u32 %[cnt], %[cnt], 1\n\t"
+        "s_cmp_lg_u32 %[cnt], 0\n\t"
+        "s_cbranch_scc1 1b\n"
+        "2:"
+        : [sum] "=&v"(sum), [ok] "=&v"(ok), [t0] "=&v"(t0), [m] "=&s"(m), [cnt] "=&s"(cnt)
+        : [p0] "v"(p0), [p1] "v"(p1), [p2] "v"(p2), [p3] "v"(p3), [tag] "s"(tag), [rounds] "s"(rounds)
+        : WN_AP_CLOBBERS);
+}
+// the single-granule form (layer 0: one complete row per stream from the sampler): A = v[152:153], B = v[160:161]
+static __device__ __forceinline__ void wn_ap_poll1(const wn_u64* p0, uint32_t tag, int rounds, float& sum, int& ok) {
+    float t0;
+    long long m;
+    int cnt;
+    asm volatile(
+        "global_load_dwordx2 v[160:161], %[p0], off sc1\n\t"
+        "v_mov_b32_e32 %[ok], 0\n\t"
+        "v_mov_b32_e32 %[sum], 0\n\t"
+        "s_mov_b32 %[cnt], %[rounds]\n"
+        "1:\n\t"
+        "s_waitcnt vmcnt(1)\n\t"
+        WN_AP_CHECK1(152, 153)
+        "s_cbranch_vccz 2f\n\t"
+        "global_load_dwordx2 v[152:153], %[p0], off sc1\n\t"
+        "s_waitcnt vmcnt(1)\n\t"
+        WN_AP_CHECK1(160, 161)
+        "s_cbranch_vccz 2f\n\t"
+        "global_load_dwordx2 v[160:161], %[p0], off sc1\n\t"
+        "s_sub_u32 %[cnt], %[cnt], 1\n\t"
+        "s_cmp_lg_u32 %[cnt], 0\n\t"
+        "s_cbranch_scc1 1b\n"
+        "2:"
+        : [sum] "=&v"(sum), [ok] "=&v"(ok), [t0] "=&v"(t0), [m] "=&s"(m), [cnt] "=&s"(cnt)
+        : [p0] "v"(p0), [tag] "s"(tag), [rounds] "s"(rounds)
+        : WN_AP_CLOBBERS);
 }
 
 template <class SH>
@@ -149,23 +268,16 @@ static __device__ void wn_v3_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
         const float bres = img[(size_t)(2 * K1 + K2 + RS * DC + 1) * 256];
         long long* park = reinterpret_cast<long long*>(lds + L::park);
         const __amdgpu_buffer_rsrc_t rs_gx = wn_rsrc(p.gx);
-        // one-item-ahead request registers (branch-free, compile-time load count: see wn_v2_layer_multi)
-        wn_u64 nx[P];
+        // the layer's input granules of stream s2: layer 0 ONE complete row per stream (g0), layers > 0 the P partials of the upstream slices
+        static_assert(P == 4, "the hand-scheduled input poll (wn_ap_poll4) is written for four partials");
         const wn_u64* xbase = (l == 0 ? p.g0 : p.gx + ((size_t)(l - 1) * P) * ns * R) + (t < R ? t : 0);
-        const size_t xstep_s = R, xstep_j = l == 0 ? 0 : (size_t)ns * R;  // layer 0 reads its single granule P times (branch-free loads)
-        auto request = [&](int s2) {
-#pragma unroll
-            for (int j = 0; j < P; ++j) nx[j] = wn_ld_granule(xbase + (size_t)s2 * xstep_s + (size_t)j * xstep_j);
+        const size_t xstep_j = (size_t)ns * R;
+        auto request = [&](int s2) {  // set A for the coming item (see wn_ap_poll4)
+            const wn_u64* q = xbase + (size_t)s2 * R;
+            if (l == 0) wn_ap_issue_a1(q);
+            else wn_ap_issue_a4(q, q + xstep_j, q + 2 * xstep_j, q + 3 * xstep_j);
         };
-        request(0);
-        // A second, EARLY set of request registers: the next item's inputs are also requested right after barrier A of the
-        // current item.  With tokens queued in front of this stage that request already returns the data, and the next item
-        // starts without waiting for a memory round trip (a request issued only at the end of an item puts its ~0.4 us round
-        // trip on the stage's cycle: 1.09 us per item however many streams are in flight).  With nothing queued both requests
-        // come back stale and the stage polls, as before.
-        wn_u64 nxe[P];
-#pragma unroll
-        for (int j = 0; j < P; ++j) nxe[j] = 0;
+        if (t < R) request(0);
         int buf = 0;
         for (long long e = 0; e < r.n_eval; ++e) {
             const uint32_t tag = (uint32_t)(e + 1);
@@ -180,33 +292,27 @@ static __device__ void wn_v3_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
                 } else if (t < R) {
                     // layer 0 (e > 0): ONE complete row per stream, published by the sampler that drew the class (the row gather
                     // sits there, off this workgroup: with it layer 0 was the slowest stage of the chain); layers > 0: P partials
-                    bool ok = true;
+                    const wn_u64* q = xbase + (size_t)s * R;
                     float sum = 0.f;
-#pragma unroll
-                    for (int j = 0; j < P; ++j)
-                        if (j == 0 || l > 0) { ok = ok && ((uint32_t)(nxe[j] >> 32) == tag); sum += __uint_as_float((uint32_t)nxe[j]); }
-                    if (!ok) {  // the early request was stale: the late one
-                        ok = true;
-                        sum = 0.f;
-#pragma unroll
-                        for (int j = 0; j < P; ++j)
-                            if (j == 0 || l > 0) { ok = ok && ((uint32_t)(nx[j] >> 32) == tag); sum += __uint_as_float((uint32_t)nx[j]); }
-                    }
-                    if (!ok) {
-                        if (l == 0) sum = wn_poll_fixed<1, WN_MULTI_SLEEP>(cx, p.g0 + (size_t)s * R + t, 0, tag, WN_W_LOGITS, e, s);
-                        else sum = wn_poll_fixed<P, WN_MULTI_SLEEP>(cx, p.gx + (((size_t)(l - 1) * P) * ns + s) * R + t, (size_t)ns * R, tag, WN_W_X, e, s);
+                    int ok = 0;
+                    unsigned spins = 0;
+                    while (!cx.fail) {
+                        if (l == 0) wn_ap_poll1(q, tag, 64, sum, ok);
+                        else wn_ap_poll4(q, q + xstep_j, q + 2 * xstep_j, q + 3 * xstep_j, tag, 64, sum, ok);
+                        if (__builtin_amdgcn_ballot_w64(ok == 0) == 0) break;  // the wave leaves together (its lanes share the barrier that follows)
+                        // bounded wait, slow path (like wn_poll_fixed): ~64 double rounds between looks at the abort word and the wall clock
+                        if (__hip_atomic_load(cx.p->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { cx.fail = 1; break; }
+                        const long long now = (long long)wall_clock64();
+                        if (spins++ == 0u) cx.t_start = now;
+                        else if (now - cx.t_start > cx.r->timeout_ticks) { wn_give_up(cx, l == 0 ? WN_W_LOGITS : WN_W_X, e, s); break; }
                     }
                     xb[SH::xpad(t)] = sum;
                 }
                 wn_stamp(r, park, item, 4);
                 if (wn_barrier_failed(cx, failflag)) return;  // ---- A(i): x staged
                 wn_stamp(r, park, item, 1);
-#if WN_V3_EARLY_REQ
-                {   // early request of the next item's inputs (see above)
-                    const int s2 = s + 1 < ns ? s + 1 : 0;
-#pragma unroll
-                    for (int j = 0; j < P; ++j) nxe[j] = wn_ld_granule(xbase + (size_t)s2 * xstep_s + (size_t)j * xstep_j);
-                }
+#if WN_V3_REQ_AT == 2
+                if (t < R) request(s + 1 < ns ? s + 1 : 0);
 #endif
                 // ---- 2. filter/gate: tap 1 on x[t] + parked tap 0, tanh * sigmoid   (wavenet_model.py:147-151)
                 const float xres = (c == 0 && kq2 == 0) ? xb[SH::xpad(row2)] : 0.f;
@@ -218,6 +324,9 @@ static __device__ void wn_v3_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
                 if (!is_gate && kq1 == 0) zs[ch] = z;
                 if (wn_barrier_failed(cx, failflag)) return;  // ---- B(i): z staged
                 wn_stamp(r, park, item, 5);
+#if WN_V3_REQ_AT == 1
+                if (t < R) request(s + 1 < ns ? s + 1 : 0);
+#endif
                 // ---- 3. residual 1x1 partial, published at once                      (wavenet_model.py:164-165)
                 if (l < NL - 1) {
                     float a2 = wn_dot_lds<K2>(w2, zs + kq2 * K2, 0.f);
@@ -233,13 +342,15 @@ static __device__ void wn_v3_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
                     }
                 }
                 wn_stamp(r, park, item, 2);
-                request(s + 1 < ns ? s + 1 : 0);
                 wn_stamp(r, park, item, 3);
-                if (r.prof && item < r.prof_items && tid == 0) {  // slots 0-5 (6 and 7 belong to the skip and queue groups)
-                    long long* dst = r.prof + ((size_t)cx.w * r.prof_items + item) * WN_STAMPS;
+                if (r.prof && item < r.prof_items && tid == 0) {  // slots 0-5 (6 and 7 belong to the skip and queue groups); BEFORE the request:
+                    long long* dst = r.prof + ((size_t)cx.w * r.prof_items + item) * WN_STAMPS;  // nothing may sit between set A and set B
 #pragma unroll
                     for (int k = 0; k < 6; ++k) dst[k] = park[k];
                 }
+#if WN_V3_REQ_AT == 0
+                if (t < R) request(s + 1 < ns ? s + 1 : 0);
+#endif
             }
         }
         if (wn_barrier_failed(cx, failflag)) return;  // A(N), B(N): the tail group's last chunk 2 runs between them
@@ -338,6 +449,7 @@ static __device__ void wn_v3_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
     for (int k = 0; k < K1; ++k) w0[k] = img[(size_t)(K1 + k) * 256];
     const float bfg = img[(size_t)(2 * K1 + K2 + RS * DC) * 256];
     const float bfg0 = kq1 == 0 ? bfg : 0.f;
+#pragma clang loop vectorize(disable) interleave(disable)
     for (int s = 0; s < ns; ++s) {  // tap 0 of the first evaluation of every stream: x[t_base - d] from the queue (zeros after reset)
         const float* ring = p.rings + p.ring_off[l] + ((size_t)c * ns + s) * (size_t)ML * R;
         long long pos = (r.t_base - d) % ML;

@@ -137,3 +137,49 @@ def test_header_is_plain_c(tmp_path):
     inc = os.path.join(ROOT, "include")
     for std in ("c99", "c11"):
         subprocess.check_call([gcc, "-std=" + std, "-Wall", "-Wextra", "-Werror", "-pedantic", "-fsyntax-only", "-I", inc, str(src)])
+
+
+def test_reserved_poll_registers_belong_to_the_hand_scheduled_blocks_only(tmp_path):
+    """csrc/wn_kernel_v3.h keeps two sets of request registers in v[152:167] across its inline-assembly blocks (loads into them
+    may still be in flight when a block ends).  That is only sound while the compiler's own allocation stays below them: every
+    instruction of the variant-3 kernels that names one of them must be one the blocks contain (a load INTO them, a tag compare
+    or the sum of their values)."""
+    import shutil
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "pytorch-wavenet_amd"))
+    import build
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("llvm-objdump not found")
+    so = shutil.copy(build.build_hip(), tmp_path / "lib.so")
+    subprocess.check_call([objdump, "--offloading", str(so)], cwd=tmp_path, stdout=subprocess.DEVNULL)
+    co = [f for f in os.listdir(tmp_path) if "gfx950" in f]
+    assert len(co) == 1, os.listdir(tmp_path)
+    dis = subprocess.check_output([objdump, "-d", str(tmp_path / co[0])]).decode()
+    reserved = set(range(152, 168))
+    allowed = {"global_load_dwordx2", "v_cmp_eq_u32_e32", "v_cmp_eq_u32_e64", "v_add_f32_e32"}
+    seen_kernel = False
+    current = None
+    for line in dis.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+        if m:
+            current = m.group(1)
+            continue
+        if not current or "wn_generate_kernel_v3m" not in current:
+            continue
+        seen_kernel = True
+        text = line.split("//")[0].strip()
+        if not text:
+            continue
+        regs = set(int(x) for x in re.findall(r"\bv(\d+)\b", text))
+        for a, b in re.findall(r"\bv\[(\d+):(\d+)\]", text):
+            regs.update(range(int(a), int(b) + 1))
+        if regs & reserved:
+            op = text.split()[0]
+            assert op in allowed, "compiler-allocated use of a reserved poll register in %s: %s" % (current, text)
+            if op == "global_load_dwordx2":  # only ever as the destination
+                dst = text.split()[1].rstrip(",")
+                assert re.match(r"v\[1(5[2-9]|6[0-7]):1(5[2-9]|6[0-7])\]", dst), text
+                rest = text.split(",", 1)[1]
+                assert not (set(int(x) for x in re.findall(r"\bv(\d+)\b", rest)) & reserved), text
+    assert seen_kernel

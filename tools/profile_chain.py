@@ -97,6 +97,19 @@ def main():
                   hop[early].mean() if early.any() else float("nan"), (got - start_next)[~early].mean() if (~early).any() else float("nan")))
         by_layer = hop.mean(axis=(1, 2))
         print("  hand-off by consumer layer: %s" % np.array2string(by_layer, precision=2, max_line_width=200))
+        if os.environ.get("WN_PROFILE_LAYERS"):  # per-layer table: where the cycle of each stage goes
+            L4 = T[:nlw].reshape(NL, P, hi - lo, 8)
+            perl = np.diff(L4[:, :, :, 0], axis=2).mean(axis=(1, 2))
+            print("  per layer: period | start->input | ->A | ->B | ->published | ->end | skip chunk | queue push, dot   (us)")
+            rwl = raw[:nlw, lo:hi].reshape(NL, P, hi - lo, 8)
+            for l in range(NL):
+                a = L4[l]
+                sk = ((rwl[l, :, :, 6] >> 40) * 0.01).mean()
+                qp = (((rwl[l, :, :, 7] >> 40) & 0xfff) * 0.01).mean()
+                qd = (((rwl[l, :, :, 7] >> 52) & 0xfff) * 0.01).mean()
+                print("   L%02d d=%3d: %.3f | %.3f | %.3f | %.3f | %.3f | %.3f | %.3f | %.3f %.3f" % (
+                    l, 1 << (l % 10), perl[l], (a[:, :, 4] - a[:, :, 0]).mean(), (a[:, :, 1] - a[:, :, 4]).mean(), (a[:, :, 5] - a[:, :, 1]).mean(),
+                    (a[:, :, 2] - a[:, :, 5]).mean(), (a[:, :, 3] - a[:, :, 2]).mean(), sk, qp, qd))
         crit = (T[:nlw, :, 2] - T[:nlw, :, 1]).mean()
         print("  layer staged->published %.3f us, published->done %.3f us" % (crit, (T[:nlw, :, 3] - T[:nlw, :, 2]).mean()))
         inp = (T[P:nlw, :, 4] - T[P:nlw, :, 0]).mean()
