@@ -138,69 +138,101 @@ static __device__ __forceinline__ void wn_ap_issue_a1(const wn_u64* p0) {
     "v_add_f32_e32 %[t0], 0, v" #B0 "\n\t"               \
     WN_AP_MERGE
 // Polls the granules p0..p3 until every active lane has seen four tags == tag, at most `rounds` double rounds (set A was issued by
-// wn_ap_issue_a4 at the end of the previous item; set B is issued here).  ok == 0: the lane ran out of rounds (caller: bounded wait).
+// wn_ap_issue_a4 during the previous item; set B is issued here).  ok == 0: the lane ran out of rounds (caller: bounded wait).
+// BETWEEN = vector-memory operations this wave issued between set A and this call (the publication store of the previous item,
+// when set A is requested in front of it): the first wait lets them stay in flight next to set B.
+#define WN_AP_ISSUE4(R0, R1, R2, R3, R4, R5, R6, R7)                             \
+    "global_load_dwordx2 v[" #R0 ":" #R1 "], %[p0], off sc1\n\t"                  \
+    "global_load_dwordx2 v[" #R2 ":" #R3 "], %[p1], off sc1\n\t"                  \
+    "global_load_dwordx2 v[" #R4 ":" #R5 "], %[p2], off sc1\n\t"                  \
+    "global_load_dwordx2 v[" #R6 ":" #R7 "], %[p3], off sc1\n\t"
+#define WN_AP_POLL4_BODY(FIRST_WAIT)                                              \
+        WN_AP_ISSUE4(160, 161, 162, 163, 164, 165, 166, 167)                      \
+        "v_mov_b32_e32 %[ok], 0\n\t"                                              \
+        "v_mov_b32_e32 %[sum], 0\n\t"                                             \
+        "s_mov_b32 %[cnt], %[rounds]\n\t"                                         \
+        "s_waitcnt vmcnt(" FIRST_WAIT ")\n\t"                                     \
+        WN_AP_CHECK4(152, 153, 154, 155, 156, 157, 158, 159)                      \
+        "s_cbranch_vccz 2f\n\t"                                                   \
+        WN_AP_ISSUE4(152, 153, 154, 155, 156, 157, 158, 159)                      \
+        "1:\n\t"                                                                  \
+        "s_waitcnt vmcnt(4)\n\t"                                                  \
+        WN_AP_CHECK4(160, 161, 162, 163, 164, 165, 166, 167)                      \
+        "s_cbranch_vccz 2f\n\t"                                                   \
+        WN_AP_ISSUE4(160, 161, 162, 163, 164, 165, 166, 167)                      \
+        "s_waitcnt vmcnt(4)\n\t"                                                  \
+        WN_AP_CHECK4(152, 153, 154, 155, 156, 157, 158, 159)                      \
+        "s_cbranch_vccz 2f\n\t"                                                   \
+        WN_AP_ISSUE4(152, 153, 154, 155, 156, 157, 158, 159)                      \
+        "s_sub_u32 %[cnt], %[cnt], 1\n\t"                                         \
+        "s_cmp_lg_u32 %[cnt], 0\n\t"                                              \
+        "s_cbranch_scc1 1b\n"                                                     \
+        "2:"
+template <int BETWEEN>
 static __device__ __forceinline__ void wn_ap_poll4(const wn_u64* p0, const wn_u64* p1, const wn_u64* p2, const wn_u64* p3, uint32_t tag, int rounds,
                                                     float& sum, int& ok) {
+    static_assert(BETWEEN == 0 || BETWEEN == 1, "operations between set A and set B");
     float t0;
     long long m;
     int cnt;
-    asm volatile(
-        "global_load_dwordx2 v[160:161], %[p0], off sc1\n\t"
-        "global_load_dwordx2 v[162:163], %[p1], off sc1\n\t"
-        "global_load_dwordx2 v[164:165], %[p2], off sc1\n\t"
-        "global_load_dwordx2 v[166:167], %[p3], off sc1\n\t"
-        "v_mov_b32_e32 %[ok], 0\n\t"
-        "v_mov_b32_e32 %[sum], 0\n\t"
-        "s_mov_b32 %[cnt], %[rounds]\n"
-        "1:\n\t"
-        "s_waitcnt vmcnt(4)\n\t"
-        WN_AP_CHECK4(152, 153, 154, 155, 156, 157, 158, 159)
-        "s_cbranch_vccz 2f\n\t"
-        "global_load_dwordx2 v[152:153], %[p0], off sc1\n\t"
-        "global_load_dwordx2 v[154:155], %[p1], off sc1\n\t"
-        "global_load_dwordx2 v[156:157], %[p2], off sc1\n\t"
-        "global_load_dwordx2 v[158:159], %[p3], off sc1\n\t"
-        "s_waitcnt vmcnt(4)\n\t"
-        WN_AP_CHECK4(160, 161, 162, 163, 164, 165, 166, 167)
-        "s_cbranch_vccz 2f\n\t"
-        "global_load_dwordx2 v[160:161], %[p0], off sc1\n\t"
-        "global_load_dwordx2 v[162:163], %[p1], off sc1\n\t"
-        "global_load_dwordx2 v[164:165], %[p2], off sc1\n\t"
-        "global_load_dwordx2 v[166:167], %[p3], off sc1\n\t"
-        "s_sub_u32 %[cnt], %[cnt], 1\n\t"
-        "s_cmp_lg_u32 %[cnt], 0\n\t"
-        "s_cbranch_scc1 1b\n"
-        "2:"
-        : [sum] "=&v"(sum), [ok] "=&v"(ok), [t0] "=&v"(t0), [m] "=&s"(m), [cnt] "=&s"(cnt)
-        : [p0] "v"(p0), [p1] "v"(p1), [p2] "v"(p2), [p3] "v"(p3), [tag] "s"(tag), [rounds] "s"(rounds)
-        : WN_AP_CLOBBERS);
+    if constexpr (BETWEEN == 0)
+        asm volatile(WN_AP_POLL4_BODY("4")
+                     : [sum] "=&v"(sum), [ok] "=&v"(ok), [t0] "=&v"(t0), [m] "=&s"(m), [cnt] "=&s"(cnt)
+                     : [p0] "v"(p0), [p1] "v"(p1), [p2] "v"(p2), [p3] "v"(p3), [tag] "s"(tag), [rounds] "s"(rounds)
+                     : WN_AP_CLOBBERS);
+    else
+        asm volatile(WN_AP_POLL4_BODY("5")
+                     : [sum] "=&v"(sum), [ok] "=&v"(ok), [t0] "=&v"(t0), [m] "=&s"(m), [cnt] "=&s"(cnt)
+                     : [p0] "v"(p0), [p1] "v"(p1), [p2] "v"(p2), [p3] "v"(p3), [tag] "s"(tag), [rounds] "s"(rounds)
+                     : WN_AP_CLOBBERS);
 }
 // the single-granule form (layer 0: one complete row per stream from the sampler): A = v[152:153], B = v[160:161]
+#define WN_AP_POLL1_BODY(FIRST_WAIT)                                              \
+        "global_load_dwordx2 v[160:161], %[p0], off sc1\n\t"                      \
+        "v_mov_b32_e32 %[ok], 0\n\t"                                              \
+        "v_mov_b32_e32 %[sum], 0\n\t"                                             \
+        "s_mov_b32 %[cnt], %[rounds]\n\t"                                         \
+        "s_waitcnt vmcnt(" FIRST_WAIT ")\n\t"                                     \
+        WN_AP_CHECK1(152, 153)                                                    \
+        "s_cbranch_vccz 2f\n\t"                                                   \
+        "global_load_dwordx2 v[152:153], %[p0], off sc1\n\t"                      \
+        "1:\n\t"                                                                  \
+        "s_waitcnt vmcnt(1)\n\t"                                                  \
+        WN_AP_CHECK1(160, 161)                                                    \
+        "s_cbranch_vccz 2f\n\t"                                                   \
+        "global_load_dwordx2 v[160:161], %[p0], off sc1\n\t"                      \
+        "s_waitcnt vmcnt(1)\n\t"                                                  \
+        WN_AP_CHECK1(152, 153)                                                    \
+        "s_cbranch_vccz 2f\n\t"                                                   \
+        "global_load_dwordx2 v[152:153], %[p0], off sc1\n\t"                      \
+        "s_sub_u32 %[cnt], %[cnt], 1\n\t"                                         \
+        "s_cmp_lg_u32 %[cnt], 0\n\t"                                              \
+        "s_cbranch_scc1 1b\n"                                                     \
+        "2:"
+template <int BETWEEN>
 static __device__ __forceinline__ void wn_ap_poll1(const wn_u64* p0, uint32_t tag, int rounds, float& sum, int& ok) {
     float t0;
     long long m;
     int cnt;
-    asm volatile(
-        "global_load_dwordx2 v[160:161], %[p0], off sc1\n\t"
-        "v_mov_b32_e32 %[ok], 0\n\t"
-        "v_mov_b32_e32 %[sum], 0\n\t"
-        "s_mov_b32 %[cnt], %[rounds]\n"
-        "1:\n\t"
-        "s_waitcnt vmcnt(1)\n\t"
-        WN_AP_CHECK1(152, 153)
-        "s_cbranch_vccz 2f\n\t"
-        "global_load_dwordx2 v[152:153], %[p0], off sc1\n\t"
-        "s_waitcnt vmcnt(1)\n\t"
-        WN_AP_CHECK1(160, 161)
-        "s_cbranch_vccz 2f\n\t"
-        "global_load_dwordx2 v[160:161], %[p0], off sc1\n\t"
-        "s_sub_u32 %[cnt], %[cnt], 1\n\t"
-        "s_cmp_lg_u32 %[cnt], 0\n\t"
-        "s_cbranch_scc1 1b\n"
-        "2:"
-        : [sum] "=&v"(sum), [ok] "=&v"(ok), [t0] "=&v"(t0), [m] "=&s"(m), [cnt] "=&s"(cnt)
-        : [p0] "v"(p0), [tag] "s"(tag), [rounds] "s"(rounds)
-        : WN_AP_CLOBBERS);
+    if constexpr (BETWEEN == 0)
+        asm volatile(WN_AP_POLL1_BODY("1")
+                     : [sum] "=&v"(sum), [ok] "=&v"(ok), [t0] "=&v"(t0), [m] "=&s"(m), [cnt] "=&s"(cnt)
+                     : [p0] "v"(p0), [tag] "s"(tag), [rounds] "s"(rounds)
+                     : WN_AP_CLOBBERS);
+    else
+        asm volatile(WN_AP_POLL1_BODY("2")
+                     : [sum] "=&v"(sum), [ok] "=&v"(ok), [t0] "=&v"(t0), [m] "=&s"(m), [cnt] "=&s"(cnt)
+                     : [p0] "v"(p0), [tag] "s"(tag), [rounds] "s"(rounds)
+                     : WN_AP_CLOBBERS);
+}
+
+// Barrier whose "did any wave give up?" word is read but not yet looked at: the LDS read is issued with the reads that follow the
+// barrier and the caller branches on it at the END of the window -- wn_barrier_failed branches at once, and that puts an LDS round
+// trip (~0.03 us) between every barrier and the first instruction of the critical path, twice per item and hop.
+static __device__ __forceinline__ int wn_barrier_flag(WnCtx& cx, int* flag) {
+    if (cx.fail) *flag = 1;
+    wn_lds_barrier();
+    return *flag;
 }
 
 template <class SH>
@@ -297,8 +329,16 @@ static __device__ void wn_v3_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
                     int ok = 0;
                     unsigned spins = 0;
                     while (!cx.fail) {
-                        if (l == 0) wn_ap_poll1(q, tag, 64, sum, ok);
-                        else wn_ap_poll4(q, q + xstep_j, q + 2 * xstep_j, q + 3 * xstep_j, tag, 64, sum, ok);
+#if WN_V3_REQ_AT == 3
+                        // (set A was requested in front of the previous item's publication store: one operation between the sets -- on
+                        //  the first pass only; a second pass after the slow path finds both long complete, and the plain wait is the safe one)
+                        if (l == 0) { if (spins == 0u) wn_ap_poll1<1>(q, tag, 64, sum, ok); else wn_ap_poll1<0>(q, tag, 64, sum, ok); }
+                        else if (l < NL - 1 && spins == 0u) wn_ap_poll4<1>(q, q + xstep_j, q + 2 * xstep_j, q + 3 * xstep_j, tag, 64, sum, ok);
+                        else wn_ap_poll4<0>(q, q + xstep_j, q + 2 * xstep_j, q + 3 * xstep_j, tag, 64, sum, ok);
+#else
+                        if (l == 0) wn_ap_poll1<0>(q, tag, 64, sum, ok);
+                        else wn_ap_poll4<0>(q, q + xstep_j, q + 2 * xstep_j, q + 3 * xstep_j, tag, 64, sum, ok);
+#endif
                         if (__builtin_amdgcn_ballot_w64(ok == 0) == 0) break;  // the wave leaves together (its lanes share the barrier that follows)
                         // bounded wait, slow path (like wn_poll_fixed): ~64 double rounds between looks at the abort word and the wall clock
                         if (__hip_atomic_load(cx.p->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { cx.fail = 1; break; }
@@ -309,7 +349,7 @@ static __device__ void wn_v3_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
                     xb[SH::xpad(t)] = sum;
                 }
                 wn_stamp(r, park, item, 4);
-                if (wn_barrier_failed(cx, failflag)) return;  // ---- A(i): x staged
+                const int fail_a = wn_barrier_flag(cx, failflag);  // ---- A(i): x staged
                 wn_stamp(r, park, item, 1);
 #if WN_V3_REQ_AT == 2
                 if (t < R) request(s + 1 < ns ? s + 1 : 0);
@@ -322,7 +362,8 @@ static __device__ void wn_v3_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
                 const float fv = is_gate ? other : acc, gv = is_gate ? acc : other;
                 const float z = wn_gate(fv, gv);
                 if (!is_gate && kq1 == 0) zs[ch] = z;
-                if (wn_barrier_failed(cx, failflag)) return;  // ---- B(i): z staged
+                if (fail_a) return;
+                const int fail_b = wn_barrier_flag(cx, failflag);  // ---- B(i): z staged
                 wn_stamp(r, park, item, 5);
 #if WN_V3_REQ_AT == 1
                 if (t < R) request(s + 1 < ns ? s + 1 : 0);
@@ -336,11 +377,17 @@ static __device__ void wn_v3_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
                         // rows 2j and 2j+1 sit on lanes 4j and 4j+2: one 16-byte store {x'(2j), tag, x'(2j+1), tag} by lane 4j instead of
                         // two 8-byte stores (write-through stores are retired per lane; consumers keep reading their own 8-byte half)
                         const float xn1 = wn_dpp<0x4E>(xn);  // quad_perm [2,3,0,1]
+#if WN_V3_REQ_AT == 3
+                        if (t < R) request(s + 1 < ns ? s + 1 : 0);  // in FRONT of the store: the wait for set A does not include its acknowledgement
+#endif
                         if ((t & 3) == 0) wn_st_pair(rs_gx, (unsigned)((((size_t)cx.w * ns + s) * R + row2) * 8), tag, xn, xn1, local_x);
                     } else {
                         if (kq2 == 0) wn_publish_at(p.gx + ((size_t)cx.w * ns + s) * R + row2, tag, xn, local_x);
                     }
                 }
+#if WN_V3_REQ_AT == 3
+                else if (t < R) request(s + 1 < ns ? s + 1 : 0);  // the last layer publishes no x'
+#endif
                 wn_stamp(r, park, item, 2);
                 wn_stamp(r, park, item, 3);
                 if (r.prof && item < r.prof_items && tid == 0) {  // slots 0-5 (6 and 7 belong to the skip and queue groups); BEFORE the request:
@@ -351,6 +398,7 @@ static __device__ void wn_v3_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
 #if WN_V3_REQ_AT == 0
                 if (t < R) request(s + 1 < ns ? s + 1 : 0);
 #endif
+                if (fail_b) return;
             }
         }
         if (wn_barrier_failed(cx, failflag)) return;  // A(N), B(N): the tail group's last chunk 2 runs between them

@@ -1,0 +1,9 @@
+#!/bin/bash
+mkdir -p gpurun_out
+cd /root/repo
+O=gpurun_out/r02_v3_deferred_flag.txt
+: > $O
+for ns in 1 7 48; do timeout 120 python tools/quick_check.py cfg3 $ns 2>&1 | grep -v amdgpu >> $O; done
+for ns in 1 16 32 48 64 96; do timeout 120 python tools/rate.py cfg3 $ns 2>&1 | grep -v amdgpu >> $O; done
+for ns in 16 64; do echo "=== anatomy x$ns" >> $O; timeout 120 python tools/profile_chain.py cfg3 $ns 2>&1 | grep -v amdgpu | grep "layers>0\|loop period" >> $O; done
+cat $O
