@@ -219,6 +219,13 @@ int wn_train_forward(wn_handle* h, const float* params, const int32_t* indices, 
  * Sums over rows are accumulated with fp32 atomics: results are reproducible to rounding, not bit for bit. */
 int wn_train_backward(wn_handle* h, const float* params, const float* dlogits, float* grads, void* hip_stream);
 
+/* loss = F.cross_entropy(logits, targets) (mean over the M rows) and dLoss/dlogits in ONE pass over the logits -- the loss of the
+ * training step (wavenet_training.py:69-70; torch runs log_softmax, nll_loss and their two backward kernels).  logits [M][classes]
+ * fp32, targets [M] int64 class indices (torch's dtype), loss ONE float, dlogits [M][classes] or NULL: all DEVICE pointers.  Per
+ * row: log-sum-exp in fp32; the mean is accumulated in fp64 in a fixed order (bit-reproducible).  A target outside [0, classes)
+ * makes the row's loss NaN (torch raises a device assert).  WN_E_UNSUPPORTED unless classes == 256. */
+int wn_train_loss(wn_handle* h, const float* logits, const int64_t* targets, int64_t M, float* loss, float* dlogits, void* hip_stream);
+
 /* Diagnostics: record wall-clock stamps (100 MHz ticks) for the first n_items (evaluation, stream) steps of every
  * workgroup during the NEXT wn_generate: 8 slots per step -- 0 start, 1 input staged, 2 x' published, 3 done,
  * 4 filter/gate sums ready, 5 z staged, 6-7 unused -- then read them back as int64 [n_workgroups][n_items][8].  Used by tools/profile_chain.py. */

@@ -578,6 +578,50 @@ __global__ void wn_bwd_gate(const float* dz, const float* th, const float* sg, f
     dfg[m * 2 * D + nf + 32] = d * t * s * (1.f - s);
 }
 
+// ---- fused softmax cross-entropy (wavenet_training.py:69-70): one wave per row of 256 logits, four classes per lane.
+// row_loss[m] = logsumexp(x) - x[target];  dlogits[m][c] = (softmax(x)[c] - [c == target]) * scale   (scale = 1/M: mean reduction)
+__global__ __launch_bounds__(256) void wn_xent_rows(const float* logits, const long long* targets, long long M, float scale, float* row_loss, float* dlogits) {
+    const int lane = threadIdx.x & 63;
+    const long long m = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const float4 x = reinterpret_cast<const float4*>(logits + m * 256)[lane];
+    float mx = fmaxf(fmaxf(x.x, x.y), fmaxf(x.z, x.w));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    const float4 e = make_float4(expf(x.x - mx), expf(x.y - mx), expf(x.z - mx), expf(x.w - mx));
+    float sum = (e.x + e.y) + (e.z + e.w);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    const long long t = targets[m];
+    const bool valid = t >= 0 && t < 256;
+    const int tl = (int)(t >> 2), tc = (int)(t & 3);
+    float xt = (valid && lane == tl) ? (tc == 0 ? x.x : tc == 1 ? x.y : tc == 2 ? x.z : x.w) : 0.f;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) xt += __shfl_xor(xt, o);
+    if (lane == 0) row_loss[m] = valid ? (mx + logf(sum)) - xt : __uint_as_float(0x7fc00000u);
+    if (dlogits) {
+        const float inv = scale / sum;
+        float4 d = make_float4(e.x * inv, e.y * inv, e.z * inv, e.w * inv);
+        if (valid && lane == tl) {
+            if (tc == 0) d.x -= scale; else if (tc == 1) d.y -= scale; else if (tc == 2) d.z -= scale; else d.w -= scale;
+        }
+        reinterpret_cast<float4*>(dlogits + m * 256)[lane] = d;
+    }
+}
+// loss = scale * sum(row_loss), fp64, fixed order (one workgroup: thread-strided partial sums, then a tree)
+__global__ __launch_bounds__(1024) void wn_xent_reduce(const float* row_loss, long long M, double scale, float* loss) {
+    __shared__ double part[1024];
+    double s = 0.;
+    for (long long i = threadIdx.x; i < M; i += 1024) s += (double)row_loss[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) part[threadIdx.x] += part[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *loss = (float)(part[0] * scale);
+}
+
 // out[n] += sum over rows of x[row][n]   (bias gradients); x rows addressed through a row map
 __global__ void wn_bwd_colsum(WnRowMap x, long long M, int rows_per_batch, int N, float* out) {
     const int n = blockIdx.y * blockDim.x + threadIdx.x;

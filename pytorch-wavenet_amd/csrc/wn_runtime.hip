@@ -306,6 +306,7 @@ struct wn_handle {
     std::vector<int64_t> ring_off;
     std::vector<int32_t> dil;
     float* d_tws; size_t tws_floats;  // training workspace (saved activations + backward temporaries)
+    float* d_xent = nullptr; size_t xent_rows = 0;  // wn_train_loss: per-row losses
     WnTrainLay train; bool train_valid;
 };
 
@@ -328,6 +329,7 @@ extern "C" void wn_destroy(wn_handle* h) {
     rt_free(h->d_blobs); rt_free(h->d_start_t); rt_free(h->d_start_b); rt_free(h->d_rings); rt_free(h->d_dil);
     rt_free(h->d_wg_map); rt_free(h->d_ring_off); rt_free(h->d_gran); rt_free(h->d_status); rt_free(h->d_prof); rt_free(h->d_fw); rt_free(h->d_ws); rt_free(h->d_fwb);
     rt_free(h->d_tws);
+    rt_free(h->d_xent);
     delete h;
 }
 

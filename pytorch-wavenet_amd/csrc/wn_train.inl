@@ -389,3 +389,24 @@ extern "C" int wn_train_backward(wn_handle* h, const float* params, const float*
     if (pl.has_bias) wn_launch_colsum(st, WnRowMap{dxn, L * (long long)R, R, 0}, N * L, (int)L, R, grads + h->fw_off_start_b);
     return rt_hip(hipGetLastError(), "wn_train_backward launches");
 }
+
+extern "C" int wn_train_loss(wn_handle* h, const float* logits, const int64_t* targets, int64_t M, float* loss, float* dlogits, void* hip_stream) {
+    g_err[0] = 0;
+    if (!h || !logits || !targets || !loss) return wn_fail(WN_E_BADARG, "wn_train_loss: NULL argument");
+    if (!h->chains.empty()) return wn_train_loss(h->chains[0], logits, targets, M, loss, dlogits, hip_stream);
+    if (M < 1) return wn_fail(WN_E_BADARG, "wn_train_loss: M must be >= 1");
+    if (h->plan.C != 256) return wn_fail(WN_E_UNSUPPORTED, "wn_train_loss: classes = %d (the fused loss is written for 256)", h->plan.C);
+    { int rc = rt_hip(hipSetDevice(h->cfg.device_id), "hipSetDevice"); if (rc) return rc; }
+    if (h->xent_rows < (size_t)M) {
+        (void)hipDeviceSynchronize();
+        rt_free(h->d_xent);
+        h->d_xent = (float*)rt_malloc((size_t)M * 4);
+        h->xent_rows = h->d_xent ? (size_t)M : 0;
+        if (!h->d_xent) return wn_fail(WN_E_NOMEM, "wn_train_loss: %lld row losses", (long long)M);
+    }
+    hipStream_t st = (hipStream_t)hip_stream;
+    hipLaunchKernelGGL(wn_xent_rows, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, logits, reinterpret_cast<const long long*>(targets), (long long)M,
+                       (float)(1.0 / (double)M), h->d_xent, dlogits);
+    hipLaunchKernelGGL(wn_xent_reduce, dim3(1), dim3(1024), 0, st, h->d_xent, (long long)M, 1.0 / (double)M, loss);
+    return rt_hip(hipGetLastError(), "wn_train_loss launches");
+}

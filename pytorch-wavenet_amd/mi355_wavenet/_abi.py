@@ -51,7 +51,7 @@ class wn_info(ctypes.Structure):
 
 
 EXPORTS = ["wn_abi_version", "wn_create", "wn_destroy", "wn_load_weights", "wn_reset", "wn_generate", "wn_wait",
-           "wn_get_info", "wn_export_queue", "wn_forward", "wn_set_forward_precision", "wn_prime", "wn_train_get_layout", "wn_train_export_params", "wn_train_forward", "wn_train_backward", "wn_profile_next", "wn_profile_read", "wn_last_error"]
+           "wn_get_info", "wn_export_queue", "wn_forward", "wn_set_forward_precision", "wn_prime", "wn_train_get_layout", "wn_train_export_params", "wn_train_forward", "wn_train_backward", "wn_train_loss", "wn_profile_next", "wn_profile_read", "wn_last_error"]
 
 
 TRAIN_SECTIONS = ("fg", "bfg", "res", "bres", "skip", "bskip", "bskip_total", "w1", "b1", "w2", "b2", "start_t", "start_b")
@@ -97,6 +97,7 @@ class Library:
         d.wn_train_forward.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
                                        ctypes.c_void_p, ctypes.c_void_p]
         d.wn_train_backward.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        d.wn_train_loss.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         d.wn_profile_next.argtypes = [ctypes.c_void_p, ctypes.c_int32]
         d.wn_profile_read.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64]
         for name in EXPORTS:

@@ -5,7 +5,8 @@ Replaces, for one-hot inputs on an MI355X, the autograd graph the reference buil
 ``loss.backward()``.  The parameters stay ordinary ``nn.Parameter``s in the reference's Conv1d layouts (so optimisers,
 ``clip_grad_norm`` and ``torch.save(model)`` keep working): every step they are packed into the flat GEMM layout of
 ``wn_train_layout`` (include/wn_abi.h) with a handful of torch view ops, and the flat gradient that wn_train_backward
-returns is unpacked the same way.  The loss stays in torch (F.cross_entropy on the returned logits).
+returns is unpacked the same way.  The loss (F.cross_entropy on the returned logits, wavenet_training.py:69-70) is one fused pass
+over the logits as well (wn_train_loss: value and gradient together), behind ``cross_entropy`` below.
 """
 import ctypes
 
@@ -148,3 +149,31 @@ class StackFunction(torch.autograd.Function):
                     rows[-1] = None  # the last layer's residual conv never reaches the loss (also upstream: its .grad stays None)
                 out.extend(rows)
         return (None, None, None, None, *out)
+
+
+class XentFunction(torch.autograd.Function):
+    """loss = F.cross_entropy(logits, target) on the engine: one pass over the logits yields the mean loss and dLoss/dlogits
+    (torch: log_softmax, nll_loss and their two backward kernels)."""
+
+    @staticmethod
+    def forward(ctx, runner, logits, target):
+        logits = logits.contiguous()
+        target = target.to(device=logits.device, dtype=torch.int64).contiguous()
+        m = logits.size(0)
+        loss = torch.empty((), dtype=torch.float32, device=logits.device)
+        dl = torch.empty_like(logits) if ctx.needs_input_grad[1] else None
+        e = runner.eng
+        e.lib.check(e.lib.dll.wn_train_loss(e._h, logits.data_ptr(), target.data_ptr(), m, loss.data_ptr(),
+                                            dl.data_ptr() if dl is not None else None, e.mem.stream()))
+        ctx.dl = dl
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        dl, ctx.dl = ctx.dl, None
+        return None, (dl.mul_(g) if dl is not None else None), None
+
+
+def cross_entropy(runner, logits, target):
+    """Drop-in for ``F.cross_entropy(logits, target)`` (mean reduction, class-index targets) on fp32 CUDA logits of 256 classes."""
+    return XentFunction.apply(runner, logits, target.reshape(-1))

@@ -9,6 +9,7 @@ snapshot -> logger.  On an MI355X ``model(x)`` and ``loss.backward()`` run throu
   * ``process_group``: data-parallel training, one process per GPU: every rank steps on the average of all ranks'
     gradients (ONE flat all-reduce per step over RCCL; SURVEY.md section 8e "Training (cfg5): plain data parallel").
 """
+import os
 import time
 
 import numpy as np
@@ -118,10 +119,21 @@ class WavenetTrainer:
             return self.model.train_forward_indices(x, check=False) if torch.is_grad_enabled() else self.model.forward_indices(x, check=False)
         return self.model(x)
 
+    def _loss(self, output, target):
+        """F.cross_entropy(output.squeeze(), target.squeeze()) (wavenet_training.py:69) -- on the engine when the logits came from it
+        (fp32, 256 classes, on the GPU): loss and dLoss/dlogits in one pass (wn_train_loss).  WN_TORCH_LOSS=1 pins torch's."""
+        out2, tgt = output.squeeze(), target.squeeze()
+        runner = getattr(self.model, "_wn_train_runner", None)
+        if (runner is not None and out2.is_cuda and out2.dim() == 2 and out2.size(1) == 256 and out2.dtype == torch.float32
+                and tgt.dim() == 1 and os.environ.get("WN_TORCH_LOSS") != "1"):
+            from mi355_wavenet import training
+            return training.cross_entropy(runner, out2, tgt)
+        return F.cross_entropy(out2, tgt)
+
     def train_step(self, kind, x, target):
         """One optimiser step (wavenet_training.py:68-77); returns the loss as a float."""
         output = self._forward(kind, x)
-        loss = F.cross_entropy(output.squeeze(), target.squeeze())
+        loss = self._loss(output, target)
         self.optimizer.zero_grad()
         loss.backward()
         average_gradients(self.model.parameters(), self.process_group)

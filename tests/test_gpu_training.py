@@ -368,3 +368,55 @@ def test_train_script_shape_end_to_end(tmp_path):
     gen_model = wavenet_model.load_latest_model_from(str(tmp_path / "snapshots"), use_cuda=False)   # what train_script's sampler thread does
     audio = wavenet_training.generate_audio(gen_model, length=50, temperatures=[0.5])
     assert audio.shape == (1, 50) and np.all(np.abs(audio) <= 1.0 + 1e-12)  # class 0 expands to -(257 - 1) / 256 = -1 up to rounding
+
+
+def test_fused_cross_entropy_matches_torch():
+    """wn_train_loss == F.cross_entropy (value 1e-6 relative, gradient 1e-6 of its largest entry), as a value-only call, through
+    autograd into the native backward, bit-reproducible, and NaN (not garbage) for a target outside [0, 256)."""
+    from mi355_wavenet import training
+    m = _model(True, seed=7)
+    x, target = _batch(m, 3, 4, seed=8)
+    out = m(x)                       # native forward: creates the runner whose engine handle the loss runs on
+    runner = m._wn_train_runner
+    assert runner is not None
+    logits = (out.detach() * 4.0).clone().requires_grad_(True)   # spread the logits: rows with a dominant class and near-uniform rows
+    ref_in = logits.detach().clone().requires_grad_(True)
+    ref = torch.nn.functional.cross_entropy(ref_in, target)
+    ref.backward()
+    loss = training.cross_entropy(runner, logits, target)
+    loss.backward()
+    assert abs(float(loss) - float(ref)) <= 1e-6 * abs(float(ref))
+    assert float((logits.grad - ref_in.grad).abs().max()) <= 1e-6 * float(ref_in.grad.abs().max())
+    again = training.cross_entropy(runner, logits.detach(), target)            # value only (no gradient buffer), same bits
+    assert float(again) == float(loss)
+    scaled = logits.detach().clone().requires_grad_(True)                        # an upstream factor reaches the gradient
+    (training.cross_entropy(runner, scaled, target) * 0.5).backward()
+    assert torch.allclose(scaled.grad, 0.5 * logits.grad, rtol=0, atol=1e-12)
+    bad = target.clone()
+    bad[1] = 256
+    assert torch.isnan(training.cross_entropy(runner, logits.detach(), bad))
+
+
+def test_trainer_step_uses_the_fused_loss_and_follows_torch(tmp_path):
+    """WavenetTrainer.train_step with the engine's loss vs the same step with WN_TORCH_LOSS=1: same loss, same gradients."""
+    import wavenet_training
+    m = _model(True, seed=9)
+    x, target = _batch(m, 2, 0, seed=10)
+
+    class _DS:  # the trainer only needs these attributes when it is stepped by hand
+        train = True
+        classes = 256
+        def __len__(self):
+            return 1
+
+    tr = wavenet_training.WavenetTrainer(m, _DS(), lr=0.0, snapshot_path=None)
+    res = {}
+    for pin in ("1", "0"):
+        os.environ["WN_TORCH_LOSS"] = pin
+        try:
+            res[pin] = (tr.train_step("onehot", x, target), {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None})
+        finally:
+            os.environ.pop("WN_TORCH_LOSS", None)
+    assert abs(res["0"][0] - res["1"][0]) <= 1e-6 * abs(res["1"][0])
+    for k, g in res["1"][1].items():
+        assert float((res["0"][1][k] - g).abs().max()) <= 2e-5 * max(float(g.abs().max()), 1e-12), k
