@@ -197,9 +197,12 @@ def train_step_cfg5(device, N=32, L=16000, reps=3, precision="fp32"):
         need += d
     fwd += 2 * N * out_len * (S * E + E * C)
 
-    def step():
+    from mi355_wavenet import training
+
+    def step():  # WavenetTrainer.train_step: forward, the engine's fused loss (WavenetTrainer._loss), backward, optimizer
         opt.zero_grad(set_to_none=True)
-        loss = torch.nn.functional.cross_entropy(m.train_forward_indices(idx), target)
+        logits = m.train_forward_indices(idx)
+        loss = training.cross_entropy(m._wn_train_runner, logits, target)
         loss.backward()
         opt.step()
         return loss
@@ -237,9 +240,12 @@ def train5_main(a, dist, rank, local, n_gpus, global_batch=32, L=16000):
     opt = torch.optim.Adam(m.parameters(), lr=1e-4)
     group = dist.group.WORLD if dist else None
 
+    from mi355_wavenet import training
+
     def step():
         opt.zero_grad(set_to_none=True)
-        loss = torch.nn.functional.cross_entropy(m.train_forward_indices(idx), target)
+        logits = m.train_forward_indices(idx)
+        loss = training.cross_entropy(m._wn_train_runner, logits, target)  # WavenetTrainer._loss
         loss.backward()
         if dist:
             wavenet_training.average_gradients(m.parameters(), group)

@@ -77,6 +77,7 @@ static __device__ __forceinline__ float wn_reduce(float v) {
 
 // dot(w[0..K), x[0..K)) with x in LDS: all float4 reads issued up front (one LDS latency, not K/16 of them), then
 // four independent FMA chains (K % 4 == 0); else a plain chain
+typedef float wn_f2 __attribute__((ext_vector_type(2)));
 template <int K>
 static __device__ __forceinline__ float wn_dot_lds(const float (&w)[K], const float* x, float init) {
     if constexpr (K % 4 == 0) {
@@ -84,12 +85,15 @@ static __device__ __forceinline__ float wn_dot_lds(const float (&w)[K], const fl
         const float4* x4 = reinterpret_cast<const float4*>(x);
 #pragma unroll
         for (int k = 0; k < K / 4; ++k) v[k] = x4[k];
-        float a0 = init, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        // the four chains as two PACKED chains (v_pk_fma_f32: two fp32 FMAs per lane and instruction; each element's arithmetic and
+        // the final summation order are those of four scalar chains: bit-identical)
+        wn_f2 a01 = {init, 0.f}, a23 = {0.f, 0.f};
 #pragma unroll
         for (int k = 0; k < K / 4; ++k) {
-            a0 += w[4 * k] * v[k].x; a1 += w[4 * k + 1] * v[k].y; a2 += w[4 * k + 2] * v[k].z; a3 += w[4 * k + 3] * v[k].w;
+            a01 = __builtin_elementwise_fma(wn_f2{w[4 * k], w[4 * k + 1]}, wn_f2{v[k].x, v[k].y}, a01);
+            a23 = __builtin_elementwise_fma(wn_f2{w[4 * k + 2], w[4 * k + 3]}, wn_f2{v[k].z, v[k].w}, a23);
         }
-        return (a0 + a1) + (a2 + a3);
+        return (a01.x + a01.y) + (a23.x + a23.y);
     } else {
         float a = init;
 #pragma unroll

@@ -25,8 +25,8 @@
 //   zs           W: C in A(i)..B(i).  R: C and S in B(i)..A(i+1).
 //   xo           W: Q in A(i)..B(i).  R: Q in B(i)..A(i+1).
 //   pre[s]       W: Q in B(i)..A(i+1) for item (e, s).  R: C in A(j)..B(j) of item j = (e+1, s) = i + n_streams >= i + 1.
-// Queue (HBM) hazard: the tap of item j is read 3 items ahead, during item j-3; it was pushed (d >= 2) at item j - n_streams*(d-1).
-// Where that is fewer than 4 items back (1-3 streams, d <= 4) the queue group takes the row from its own registers instead.
+// Queue (HBM) hazard: the tap of item j is read WN_V3_TAP_AHEAD items ahead, during item j-WN_V3_TAP_AHEAD; it was pushed (d >= 2) at item j - n_streams*(d-1).
+// Where that is no more than WN_V3_TAP_AHEAD items back (few streams, small d) the queue group takes the row from its own registers instead.
 #ifndef WN_KERNEL_V3_H
 #define WN_KERNEL_V3_H
 
@@ -34,7 +34,7 @@
 
 #define WN_THREADS_V3 768
 #define WN_V3_MIN_STREAMS 1
-#define WN_V3_TAP_AHEAD 3
+#define WN_V3_TAP_AHEAD 6
 #ifndef WN_V3_REQ_AT
 #define WN_V3_REQ_AT 0  // where set A of the next item's input is requested: 0 at the end of the item, 1 after barrier B, 2 after barrier A
 #endif
@@ -45,7 +45,7 @@
 #define WN_V3_ABL 0  // timing ablations (results are WRONG when != 0): 1 the skip group only passes its barriers, 2 the queue group, 3 both
 #endif
 #ifndef WN_V3_PRIO
-#define WN_V3_PRIO 0  // 1: critical waves at a higher static wave priority (measured: no effect, profiles/r02_v3_variants.txt)
+#define WN_V3_PRIO 1  // 1: critical waves at a higher static wave priority (the queue and skip waves share their SIMDs: x64 911 -> 919 k, profiles/r02_v3_tap_fifo.txt)
 #endif
 
 // ---- 16-byte skip-lane hand-offs.  A lane of the skip group owns rows t and t + 256 of the running skip sum.  Written as two
@@ -224,6 +224,49 @@ static __device__ __forceinline__ void wn_ap_poll1(const wn_u64* p0, uint32_t ta
                      : [sum] "=&v"(sum), [ok] "=&v"(ok), [t0] "=&v"(t0), [m] "=&s"(m), [cnt] "=&s"(cnt)
                      : [p0] "v"(p0), [tag] "s"(tag), [rounds] "s"(rounds)
                      : WN_AP_CLOBBERS);
+}
+
+// ---- The queue group's tap FIFO, hand-scheduled for the same reason.  Queue taps x[t+1-d] are requested WN_V3_TAP_AHEAD items ahead
+// (rows of large-d layers miss the L2).  Held in a C++ array the FIFO is loop carried, and the compiler's wait in front of the
+// OLDEST entry is a wait for the YOUNGEST one, requested one item ago: layers with d >= 128 ran 0.06-0.12 us per item slower than
+// the others and set the pace of the 64-stream chain (tools/dilation_probe.py: all dilations <= 64: 930 k samples/s, cfg3: 837 k;
+// three entries hand-scheduled: cfg3 881 k, d <= 128 as fast as d = 1; profiles/r02_v3_tap_fifo.txt).  The entries live in
+// v152-v157 of the queue waves (the critical waves' request sets are other waves' registers of the same numbers).
+// A wave's vector-memory operations per item, in program order: push store (window A), [take], tap load (window B); so the entry
+// taken at item i has AHEAD-1 younger loads and AHEAD younger stores: s_waitcnt vmcnt(2 AHEAD - 1); in the first AHEAD-1 items
+// fewer were issued (AHEAD + i of them), and vmcnt(AHEAD) is the safe count.
+#define WN_Q_STR2(x) #x
+#define WN_Q_STR(x) WN_Q_STR2(x)
+#define WN_Q_ISSUE_CASE(SL, REG) \
+    if constexpr (SLOT == SL) asm volatile("global_load_dword v" #REG ", %0, off" ::"v"(ptr) : "v" #REG, "memory")
+#define WN_Q_TAKE_CASE(SL, REG, CNT) \
+    if constexpr (SLOT == SL) asm volatile("s_waitcnt vmcnt(%1)\n\tv_mov_b32_e32 %0, v" #REG : "=v"(v) : "n"(CNT) : "memory")
+template <int SLOT>
+static __device__ __forceinline__ void wn_q_issue(const float* ptr) {
+    static_assert(WN_V3_TAP_AHEAD == 6 && SLOT >= 0 && SLOT < 6, "tap FIFO registers v152-v157");
+    WN_Q_ISSUE_CASE(0, 152); WN_Q_ISSUE_CASE(1, 153); WN_Q_ISSUE_CASE(2, 154); WN_Q_ISSUE_CASE(3, 155); WN_Q_ISSUE_CASE(4, 156); WN_Q_ISSUE_CASE(5, 157);
+}
+// CNT = vector-memory operations of this wave that may stay in flight while the entry is read (everything younger than its load)
+template <int SLOT, int CNT>
+static __device__ __forceinline__ float wn_q_take() {
+    float v;
+    WN_Q_TAKE_CASE(0, 152, CNT); WN_Q_TAKE_CASE(1, 153, CNT); WN_Q_TAKE_CASE(2, 154, CNT);
+    WN_Q_TAKE_CASE(3, 155, CNT); WN_Q_TAKE_CASE(4, 156, CNT); WN_Q_TAKE_CASE(5, 157, CNT);
+    return v;
+}
+// the entry is a run-time (wave-uniform) value at the call sites
+static __device__ __forceinline__ void wn_q_issue_slot(int slot, const float* q) {
+    switch (slot) {
+        case 0: wn_q_issue<0>(q); break; case 1: wn_q_issue<1>(q); break; case 2: wn_q_issue<2>(q); break;
+        case 3: wn_q_issue<3>(q); break; case 4: wn_q_issue<4>(q); break; default: wn_q_issue<5>(q); break;
+    }
+}
+template <int CNT>
+static __device__ __forceinline__ float wn_q_take_slot(int slot) {
+    switch (slot) {
+        case 0: return wn_q_take<0, CNT>(); case 1: return wn_q_take<1, CNT>(); case 2: return wn_q_take<2, CNT>();
+        case 3: return wn_q_take<3, CNT>(); case 4: return wn_q_take<4, CNT>(); default: return wn_q_take<5, CNT>();
+    }
 }
 
 // Barrier whose "did any wave give up?" word is read but not yet looked at: the LDS read is issued with the reads that follow the
@@ -509,51 +552,87 @@ static __device__ void wn_v3_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
     }
     float* rings_l = p.rings + p.ring_off[l] + (size_t)c * ns * (size_t)ML * R;  // stream s: + s * ML * R
     int tmod = (int)(r.t_base % ML);  // queue slot of x[t] of the current item, kept incrementally
-    // Queue taps x[t+1-d] are read WN_V3_TAP_AHEAD items ahead (rows of large-d layers are an HBM miss): a register FIFO.
-    float xo_f[WN_V3_TAP_AHEAD];
+    // Queue taps x[t+1-d] are read WN_V3_TAP_AHEAD items ahead (rows of large-d layers are an HBM miss): a register FIFO of three
+    // entries, hand-scheduled (wn_q_issue / wn_q_take); entry = item mod 3.
+    const bool fifo = d != 1 && t < R && !(WN_V3_ABL & 2);  // (wave-uniform: R is a multiple of 64 in every instantiated shape)
+    static_assert(R % 64 == 0, "the tap FIFO is issued by whole waves");
     int s_a = 0, tmod_a = tmod;  // coordinates of the item whose tap is requested next
-    auto request_tap = [&]() -> float {
+    auto next_tap_ptr = [&]() -> const float* {
         const int tap = tmod_a + 2 >= ML ? tmod_a + 2 - ML : tmod_a + 2;  // slot of x[t+1-d]: (t+1-d) mod (d+1) = (t+2) mod (d+1)
-        const float v = (d != 1 && t < R) ? rings_l[((size_t)s_a * ML + tap) * R + t] : 0.f;
+        const float* q = rings_l + ((size_t)s_a * ML + tap) * R + (t < R ? t : 0);
         if (++s_a == ns) { s_a = 0; tmod_a = (tmod_a + 1 == ML) ? 0 : tmod_a + 1; }
-        return v;
+        return q;
     };
+    if (fifo) {
 #pragma unroll
-    for (int j = 0; j < WN_V3_TAP_AHEAD; ++j) xo_f[j] = request_tap();
+        for (int j = 0; j < WN_V3_TAP_AHEAD; ++j) wn_q_issue_slot(j, next_tap_ptr());
+    }
+    int slot = 0;  // item mod WN_V3_TAP_AHEAD
     // With few streams and a small dilation the tap row of an item was pushed fewer than WN_V3_TAP_AHEAD items before it (it is
-    // x of item i - n_streams*(d-1)): the lane keeps its own last three x values instead of reading the queue ahead of the push.
-    static_assert(WN_V3_TAP_AHEAD == 3, "the register history below holds three items");
+    // x of item i - n_streams*(d-1)): the lane keeps its own last x values instead of reading the queue ahead of the push.
     const long long back = (long long)ns * (d - 1);
     const bool near = d != 1 && back <= WN_V3_TAP_AHEAD;
-    float hx[3] = {0.f, 0.f, 0.f};
+    float hx[WN_V3_TAP_AHEAD];  // x of the last WN_V3_TAP_AHEAD items, newest first
+#pragma unroll
+    for (int j = 0; j < WN_V3_TAP_AHEAD; ++j) hx[j] = 0.f;
+    // Layers whose tap does not depend on recent x (d != 1, not `near`) do NOTHING between barriers A and B: the tap of item i is
+    // staged (double buffered) at the end of item i-1's window after barrier B, and x[t] is pushed after barrier B as well (x stays
+    // in LDS until item i+1's B).  With the packed filter/gate dot of the critical group the queue group's push + staging (0.29 us)
+    // had become as long as the critical group's own A -> B.
+    const bool late_wg = d != 1 && !near && !(WN_V3_ABL & 2);  // workgroup-uniform
+    const bool late = late_wg && fifo;                          // ... and this wave loads taps
+    float* xol1 = lds + L::sk;  // second tap buffer (the head's staging area is free in a layer workgroup)
+    const long long n_items = r.n_eval * ns;
+    constexpr int D = WN_V3_TAP_AHEAD;
+    if (late && n_items > 0) xol[SH::xpad(t)] = wn_q_take_slot<D - 1>(0);  // item 0's tap (D - 1 younger loads of the initial fill)
+    // ... and the push of a late layer is done by the waves that load no taps (lanes R..2R-1, when there are that many): the tap
+    // waves then issue nothing but tap loads, and an entry always has exactly D - 1 younger operations
+    constexpr bool PUSH_HI = 2 * R <= 256;
+    const bool pusher = late_wg && (PUSH_HI ? (t >= R && t < 2 * R) : t < R);
+    const int prow = PUSH_HI ? t - R : t;
     int buf = 0;
     long long item = 0;
     for (long long e = 0; e < r.n_eval; ++e, tmod = (tmod + 1 == ML) ? 0 : tmod + 1) {
         for (int s = 0; s < ns; ++s, buf ^= 1, ++item) {
+            float* xo_cur = (late_wg && (item & 1)) ? xol1 : xol;
+            float* xo_nxt = (item & 1) ? xol : xol1;
             if (wn_barrier_failed(cx, failflag)) return;  // ---- A(i): x of this item staged
             const bool stamp = r.prof && item < r.prof_items && tid == 512;
             const long long t0 = stamp ? (long long)wall_clock64() : 0;
             // ---- queue push (wavenet_modules.py:55-57); stage the tap x[t+1-d] (d = 1: it is x[t] itself)
-            if (t < R && !(WN_V3_ABL & 2)) {
+            if (!late_wg && t < R && !(WN_V3_ABL & 2)) {
                 const float xv = xs[buf * L::XR + SH::xpad(t)];
                 rings_l[((size_t)s * ML + tmod) * R + t] = xv;
                 // the tap: d = 1: x[t] itself; a row pushed fewer items ago than the prefetch distance (few streams, small d):
                 // this lane's own copy of it (the queue read ahead of the push would be stale); else the prefetched queue row
-                float tap = xo_f[0];
+                // (program order here: push, take, [B], load: an entry has D - 1 younger loads and D younger stores)
+                float tap = 0.f;
+                if (fifo) tap = item < D - 1 ? wn_q_take_slot<D>(slot) : wn_q_take_slot<2 * D - 1>(slot);
                 if (d == 1) tap = xv;
-                else if (near && item >= back) tap = back == 1 ? hx[0] : back == 2 ? hx[1] : hx[2];
-                xol[SH::xpad(t)] = tap;
-                hx[2] = hx[1]; hx[1] = hx[0]; hx[0] = xv;
-            }
+                else if (near && item >= back) {
 #pragma unroll
-            for (int j = 0; j + 1 < WN_V3_TAP_AHEAD; ++j) xo_f[j] = xo_f[j + 1];
+                    for (int j = 0; j < D; ++j) tap = back == j + 1 ? hx[j] : tap;  // (back is workgroup-uniform)
+                }
+                xo_cur[SH::xpad(t)] = tap;
+#pragma unroll
+                for (int j = D - 1; j > 0; --j) hx[j] = hx[j - 1];
+                hx[0] = xv;
+            }
             if (wn_barrier_failed(cx, failflag)) return;  // ---- B(i): the tap is staged
             const long long t1 = stamp ? (long long)wall_clock64() : 0;
             // ---- tap-0 half of the dilated conv for the NEXT timestep of this stream, parked for the critical group
             if (!(WN_V3_ABL & 2)) {
-                pre[s * 256 + t] = wn_dot_lds<K1>(w0, xol + kq1 * (K1 + 4), bfg0);
-                xo_f[WN_V3_TAP_AHEAD - 1] = request_tap();
+                if (pusher) rings_l[((size_t)s * ML + tmod) * R + prow] = xs[buf * L::XR + SH::xpad(prow)];  // the push, off the A -> B window
+                pre[s * 256 + t] = wn_dot_lds<K1>(w0, xo_cur + kq1 * (K1 + 4), bfg0);
+                if (fifo) wn_q_issue_slot(slot, next_tap_ptr());  // the tap of item i + D goes into the entry item i has just given up
+                if (late && item + 1 < n_items) {
+                    // the NEXT item's tap into the other buffer: D - 1 younger loads; the stores of a wave that also pushes (R > 128:
+                    // program order push, load, take) only add to what may stay in flight from item D - 2 on
+                    const int ns1 = slot == D - 1 ? 0 : slot + 1;
+                    xo_nxt[SH::xpad(t)] = (PUSH_HI || item < D - 2) ? wn_q_take_slot<D - 1>(ns1) : wn_q_take_slot<2 * D - 2>(ns1);
+                }
             }
+            slot = slot == D - 1 ? 0 : slot + 1;
             if (stamp)  // slot 7: the queue group's A(i) | push+stage length << 40 | dot length << 52
                 r.prof[((size_t)cx.w * r.prof_items + item) * WN_STAMPS + 7] =
                     (t0 & 0xffffffffffll) | (((t1 - t0) & 0xfff) << 40) | ((((long long)wall_clock64() - t1) & 0xfff) << 52);
@@ -569,7 +648,7 @@ template <int K, int CH>
 static __device__ __forceinline__ float wn_dot_lds_chunked(const float (&w)[K], const float* x, float init) {
     static_assert(K % (4 * CH) == 0, "chunking");
     const float4* x4 = reinterpret_cast<const float4*>(x);
-    float a0 = init, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    wn_f2 a01 = {init, 0.f}, a23 = {0.f, 0.f};  // two packed chains (v_pk_fma_f32), as wn_dot_lds
 #pragma unroll
     for (int c0 = 0; c0 < K / 4; c0 += CH) {
         float4 v[CH];
@@ -577,10 +656,11 @@ static __device__ __forceinline__ float wn_dot_lds_chunked(const float (&w)[K], 
         for (int k = 0; k < CH; ++k) v[k] = x4[c0 + k];
 #pragma unroll
         for (int k = 0; k < CH; ++k) {
-            a0 += w[4 * (c0 + k)] * v[k].x; a1 += w[4 * (c0 + k) + 1] * v[k].y; a2 += w[4 * (c0 + k) + 2] * v[k].z; a3 += w[4 * (c0 + k) + 3] * v[k].w;
+            a01 = __builtin_elementwise_fma(wn_f2{w[4 * (c0 + k)], w[4 * (c0 + k) + 1]}, wn_f2{v[k].x, v[k].y}, a01);
+            a23 = __builtin_elementwise_fma(wn_f2{w[4 * (c0 + k) + 2], w[4 * (c0 + k) + 3]}, wn_f2{v[k].z, v[k].w}, a23);
         }
     }
-    return (a0 + a1) + (a2 + a3);
+    return (a01.x + a01.y) + (a23.x + a23.y);
 }
 
 // Head role (threads 0-255 of the workgroup; same arithmetic, granules and LDS offsets as wn_v2_head_multi with G = 1): relu(skip)
@@ -588,7 +668,7 @@ static __device__ __forceinline__ float wn_dot_lds_chunked(const float (&w)[K], 
 template <class SH, int P>
 static __device__ void wn_v3_head(const WnPlan& p, const WnRun& r, WnCtx& cx, float* lds, int h) {
     constexpr int S = SH::S, EC = SH::EC, T3 = SH::T3, K3 = SH::K3, QS = S / 256;
-    constexpr int CH3 = (K3 / 4) % 4 == 0 ? 4 : 1, CHE = (EC / 4) % 4 == 0 ? 4 : 1;
+    constexpr int CH3 = (K3 / 4) % 2 == 0 ? 2 : 1, CHE = (EC / 4) % 2 == 0 ? 2 : 1;  // (chunks of two float4: the early request set below needs the registers)
     static_assert(K3 % 4 == 0 && EC % 4 == 0, "head slices are read as float4");
     using L = WnV3Lds<SH>;
     const int tid = threadIdx.x, ns = p.n_streams, NL = p.NL;
@@ -615,30 +695,40 @@ static __device__ void wn_v3_head(const WnPlan& p, const WnRun& r, WnCtx& cx, fl
     const bool local_l = locflags[0] != 0;
     static_assert(QS % 2 == 0, "the skip lanes arrive in 16-byte pairs (rows t, t + 256)");
     const __amdgpu_buffer_rsrc_t rs_gs = wn_rsrc(p.gs);
+    // The P lanes of the running skip sum (published by the last layer's skip groups) of the NEXT item are requested as soon as
+    // this item's lanes are staged: the head sits in another XCD than the last layers, a request round trip is ~0.6 us, and with
+    // tokens queued in front of it the head's cycle was compute (0.58 us) PLUS that round trip = 1.19 us per item -- the slowest
+    // stage of the 64-stream chain, whatever the layer stages did (profiles/r02_v3_head_request.txt).  Nothing queued (latency-
+    // bound runs): the early request comes back stale and the lanes are polled when due, as before.
+    wn_v4i nv[QS / 2][P];
+    auto lane_off = [&](int j, int s2, int h2) { return (unsigned)(((((size_t)(NL - 1) * P + j) * ns + s2) * (size_t)S) * 8) + (unsigned)tid * 16 + h2 * 4096; };
+    auto request = [&](int s2) {
+#pragma unroll
+        for (int h2 = 0; h2 < QS / 2; ++h2)
+#pragma unroll
+            for (int j = 0; j < P; ++j) nv[h2][j] = wn_ld_pair(rs_gs, lane_off(j, s2, h2));
+    };
+    request(0);
     for (long long e = 0; e < r.n_eval; ++e) {
         const bool prime = e < r.n_given - 1;
         const uint32_t tag = (uint32_t)(e + 1);
         for (int s = 0; s < ns; ++s) {
             const long long item = e * ns + s;
             wn_stamp(r, park, item, 0);
-            // the P lanes of the running skip sum (published by the last layer's skip groups): polled when due -- in the
-            // latency-bound regime a request issued one item ahead is always stale
 #pragma unroll
             for (int h2 = 0; h2 < QS / 2; ++h2) {
                 float sum0 = 0.f, sum1 = 0.f;
-                wn_v4i v[P];
-#pragma unroll
-                for (int j = 0; j < P; ++j) v[j] = wn_ld_pair(rs_gs, (unsigned)(((((size_t)(NL - 1) * P + j) * ns + s) * (size_t)S) * 8) + (unsigned)tid * 16 + h2 * 4096);
 #pragma unroll
                 for (int j = 0; j < P; ++j) {  // fixed order j = 0..P-1, late lanes re-polled one by one
-                    if ((uint32_t)v[j].y != tag || (uint32_t)v[j].w != tag)
-                        v[j] = wn_poll_pair(cx, rs_gs, (unsigned)(((((size_t)(NL - 1) * P + j) * ns + s) * (size_t)S) * 8) + (unsigned)tid * 16 + h2 * 4096, tag, WN_W_HEAD, e, s);
-                    sum0 += __int_as_float(v[j].x);
-                    sum1 += __int_as_float(v[j].z);
+                    wn_v4i v = nv[h2][j];      // (this item's stream: requested for it one item ago)
+                    if ((uint32_t)v.y != tag || (uint32_t)v.w != tag) v = wn_poll_pair(cx, rs_gs, lane_off(j, s, h2), tag, WN_W_HEAD, e, s);
+                    sum0 += __int_as_float(v.x);
+                    sum1 += __int_as_float(v.z);
                 }
                 sk[SH::skpad(tid + 512 * h2)] = sum0 > 0.f ? sum0 : 0.f;        // relu(skip), rows tid + 512 h2 and tid + 512 h2 + 256
                 sk[SH::skpad(tid + 512 * h2 + 256)] = sum1 > 0.f ? sum1 : 0.f;
             }
+            request(s + 1 < ns ? s + 1 : 0);
             if (wn_barrier_failed(cx, failflag)) return;
             wn_stamp(r, park, item, 1);
             wn_u64* gl = p.gl + ((size_t)h * ns + s) * 256;

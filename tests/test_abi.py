@@ -157,7 +157,8 @@ def test_reserved_poll_registers_belong_to_the_hand_scheduled_blocks_only(tmp_pa
     assert len(co) == 1, os.listdir(tmp_path)
     dis = subprocess.check_output([objdump, "-d", str(tmp_path / co[0])]).decode()
     reserved = set(range(152, 168))
-    allowed = {"global_load_dwordx2", "v_cmp_eq_u32_e32", "v_cmp_eq_u32_e64", "v_add_f32_e32"}
+    allowed = {"global_load_dwordx2", "v_cmp_eq_u32_e32", "v_cmp_eq_u32_e64", "v_add_f32_e32",   # the critical group's request sets
+               "global_load_dword", "v_mov_b32_e32"}                                               # the queue group's tap FIFO
     seen_kernel = False
     current = None
     for line in dis.splitlines():
@@ -182,4 +183,9 @@ def test_reserved_poll_registers_belong_to_the_hand_scheduled_blocks_only(tmp_pa
                 assert re.match(r"v\[1(5[2-9]|6[0-7]):1(5[2-9]|6[0-7])\]", dst), text
                 rest = text.split(",", 1)[1]
                 assert not (set(int(x) for x in re.findall(r"\bv(\d+)\b", rest)) & reserved), text
+            if op == "global_load_dword":    # destination v152-v157 only
+                assert text.split()[1].rstrip(",") in ("v152", "v153", "v154", "v155", "v156", "v157"), text
+                assert not (set(int(x) for x in re.findall(r"\bv(\d+)\b", text.split(",", 1)[1])) & reserved), text
+            if op == "v_mov_b32_e32":        # source only
+                assert int(text.split()[1].rstrip(",").lstrip("v")) not in reserved, text
     assert seen_kernel

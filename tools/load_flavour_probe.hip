@@ -16,6 +16,7 @@ typedef int v2i __attribute__((ext_vector_type(2)));
 static __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc(const void* base) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);
 }
+static __device__ char* rs_base;  // the granule buffer, for the flavours that need a pointer
 template <int LF>
 static __device__ __forceinline__ v2i ld(__amdgpu_buffer_rsrc_t rs, unsigned off) {
     if constexpr (LF == 0) return __builtin_amdgcn_raw_buffer_load_b64(rs, off, 0, 16);       // sc1
@@ -25,16 +26,25 @@ static __device__ __forceinline__ v2i ld(__amdgpu_buffer_rsrc_t rs, unsigned off
     else if constexpr (LF == 4) return __builtin_amdgcn_raw_buffer_load_b64(rs, off, 0, 3);   // sc0 nt
     else if constexpr (LF == 5) { asm volatile("buffer_inv sc1" ::: "memory"); return __builtin_amdgcn_raw_buffer_load_b64(rs, off, 0, 0); }
     else if constexpr (LF == 6) { asm volatile("buffer_inv sc1" ::: "memory"); return __builtin_amdgcn_raw_buffer_load_b64(rs, off, 0, 1); }
+    else if constexpr (LF == 8) {  // an atomic executed AT the L2: fetch_add(0)
+        unsigned long long* p = reinterpret_cast<unsigned long long*>(rs_base + off);
+        const unsigned long long v = __hip_atomic_fetch_add(p, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return v2i{(int)(unsigned)v, (int)(unsigned)(v >> 32)};
+    }
     else return __builtin_amdgcn_raw_buffer_load_b64(rs, off, 0, 0);                          // plain
 }
 template <int SF>
 static __device__ __forceinline__ void st(__amdgpu_buffer_rsrc_t rs, unsigned off, v2i v) {
     if constexpr (SF == 0) __builtin_amdgcn_raw_buffer_store_b64(v, rs, off, 0, 0);
     else if constexpr (SF == 1) __builtin_amdgcn_raw_buffer_store_b64(v, rs, off, 0, 16);
-    else __builtin_amdgcn_raw_buffer_store_b64(v, rs, off, 0, 1);
+    else if constexpr (SF == 2) __builtin_amdgcn_raw_buffer_store_b64(v, rs, off, 0, 1);
+    else {  // an atomic exchange executed AT the L2, result unused
+        unsigned long long* p = reinterpret_cast<unsigned long long*>(rs_base + off);
+        (void)__hip_atomic_exchange(p, ((unsigned long long)(unsigned)v.y << 32) | (unsigned)v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
-static const char* SFN[] = {"plain", "sc1", "sc0"};
-static const char* LFN[] = {"sc1", "sc0", "sc0+sc1", "nt", "sc0+nt", "inv+plain", "inv+sc0", "plain"};
+static const char* SFN[] = {"plain", "sc1", "sc0", "xchg"};
+static const char* LFN[] = {"sc1", "sc0", "sc0+sc1", "nt", "sc0+nt", "inv+plain", "inv+sc0", "plain", "fetch_add0"};
 
 // (a) raw dependent-load round trip: one wave, the same line over and over (lane 0's result feeds the next address)
 template <int LF>
@@ -161,6 +171,7 @@ int main() {
     CHECK(hipMemset(gran, 0, (size_t)256 * 128 * 8));
     run_rtt<0>(gran, dout, khz); run_rtt<1>(gran, dout, khz); run_rtt<2>(gran, dout, khz); run_rtt<3>(gran, dout, khz);
     run_rtt<4>(gran, dout, khz); run_rtt<5>(gran, dout, khz); run_rtt<6>(gran, dout, khz); run_rtt<7>(gran, dout, khz);
+    { char* b = reinterpret_cast<char*>(gran); CHECK(hipMemcpyToSymbol(HIP_SYMBOL(rs_base), &b, sizeof(b))); }
     run_store_ack<0>(gran, dout, khz); run_store_ack<1>(gran, dout, khz); run_store_ack<2>(gran, dout, khz);
     for (int n : {16}) {
         run_ring<0, 0>(gran, dpos, dfail, n, true, khz);
@@ -173,6 +184,11 @@ int main() {
         run_ring<5, 0>(gran, dpos, dfail, n, true, khz);
         run_ring<6, 0>(gran, dpos, dfail, n, true, khz);
         run_ring<7, 0>(gran, dpos, dfail, n, true, khz);
+        run_ring<0, 3>(gran, dpos, dfail, n, true, khz);
+        run_ring<8, 0>(gran, dpos, dfail, n, true, khz);
+        run_ring<8, 3>(gran, dpos, dfail, n, true, khz);
+        run_ring<0, 3>(gran, dpos, dfail, n, false, khz);
+        run_ring<8, 3>(gran, dpos, dfail, n, false, khz);
         run_ring<0, 1>(gran, dpos, dfail, n, false, khz);
         run_ring<2, 1>(gran, dpos, dfail, n, false, khz);
         run_ring<1, 1>(gran, dpos, dfail, n, false, khz);
