@@ -38,6 +38,19 @@
 #ifndef WN_V3_REQ_AT
 #define WN_V3_REQ_AT 0  // where set A of the next item's input is requested: 0 at the end of the item, 1 after barrier B, 2 after barrier A
 #endif
+#ifndef WN_V3_LAZY_B
+#define WN_V3_LAZY_B 1  // 1: the second request set of the critical group's input poll is only issued when the first came back stale
+#endif
+#if WN_V3_LAZY_B
+#define WN_AP_FIRST0 "0"
+#define WN_AP_FIRST1 "1"
+#else
+#define WN_AP_FIRST0 "4"
+#define WN_AP_FIRST1 "5"
+#endif
+#ifndef WN_V3_QDOT_EARLY
+#define WN_V3_QDOT_EARLY 0  // 1: a late layer's tap-0 dot runs between barriers A and B (next to the critical group's dot) instead of after B
+#endif
 #ifndef WN_V3_SKIP_SLEEP
 #define WN_V3_SKIP_SLEEP 0  // s_sleep between the skip group's poll retries (the skip lane is not latency critical; fewer polls on the fabric)
 #endif
@@ -146,6 +159,35 @@ static __device__ __forceinline__ void wn_ap_issue_a1(const wn_u64* p0) {
     "global_load_dwordx2 v[" #R2 ":" #R3 "], %[p1], off sc1\n\t"                  \
     "global_load_dwordx2 v[" #R4 ":" #R5 "], %[p2], off sc1\n\t"                  \
     "global_load_dwordx2 v[" #R6 ":" #R7 "], %[p3], off sc1\n\t"
+#if WN_V3_LAZY_B
+// Set B is only issued when set A came back stale: with tokens queued in front of the stage (64 streams: 88 % of the items) the
+// first check then waits for set A alone -- not for "set A and (the publication store or the first load of set B)", which the
+// shared in-order counter makes of a wait issued after set B -- and the polls of set B are not spent.  FIRST_WAIT counts the
+// operations issued AFTER set A that may stay in flight (0: set A was the last; 1: the publication store follows it).
+#define WN_AP_POLL4_BODY(FIRST_WAIT)                                              \
+        "v_mov_b32_e32 %[ok], 0\n\t"                                              \
+        "v_mov_b32_e32 %[sum], 0\n\t"                                             \
+        "s_mov_b32 %[cnt], %[rounds]\n\t"                                         \
+        "s_waitcnt vmcnt(" FIRST_WAIT ")\n\t"                                     \
+        WN_AP_CHECK4(152, 153, 154, 155, 156, 157, 158, 159)                      \
+        "s_cbranch_vccz 2f\n\t"                                                   \
+        WN_AP_ISSUE4(160, 161, 162, 163, 164, 165, 166, 167)                      \
+        "s_sleep 2\n\t"                                                           \
+        WN_AP_ISSUE4(152, 153, 154, 155, 156, 157, 158, 159)                      \
+        "1:\n\t"                                                                  \
+        "s_waitcnt vmcnt(4)\n\t"                                                  \
+        WN_AP_CHECK4(160, 161, 162, 163, 164, 165, 166, 167)                      \
+        "s_cbranch_vccz 2f\n\t"                                                   \
+        WN_AP_ISSUE4(160, 161, 162, 163, 164, 165, 166, 167)                      \
+        "s_waitcnt vmcnt(4)\n\t"                                                  \
+        WN_AP_CHECK4(152, 153, 154, 155, 156, 157, 158, 159)                      \
+        "s_cbranch_vccz 2f\n\t"                                                   \
+        WN_AP_ISSUE4(152, 153, 154, 155, 156, 157, 158, 159)                      \
+        "s_sub_u32 %[cnt], %[cnt], 1\n\t"                                         \
+        "s_cmp_lg_u32 %[cnt], 0\n\t"                                              \
+        "s_cbranch_scc1 1b\n"                                                     \
+        "2:"
+#else
 #define WN_AP_POLL4_BODY(FIRST_WAIT)                                              \
         WN_AP_ISSUE4(160, 161, 162, 163, 164, 165, 166, 167)                      \
         "v_mov_b32_e32 %[ok], 0\n\t"                                              \
@@ -168,6 +210,7 @@ static __device__ __forceinline__ void wn_ap_issue_a1(const wn_u64* p0) {
         "s_cmp_lg_u32 %[cnt], 0\n\t"                                              \
         "s_cbranch_scc1 1b\n"                                                     \
         "2:"
+#endif
 template <int BETWEEN>
 static __device__ __forceinline__ void wn_ap_poll4(const wn_u64* p0, const wn_u64* p1, const wn_u64* p2, const wn_u64* p3, uint32_t tag, int rounds,
                                                     float& sum, int& ok) {
@@ -176,12 +219,12 @@ static __device__ __forceinline__ void wn_ap_poll4(const wn_u64* p0, const wn_u6
     long long m;
     int cnt;
     if constexpr (BETWEEN == 0)
-        asm volatile(WN_AP_POLL4_BODY("4")
+        asm volatile(WN_AP_POLL4_BODY(WN_AP_FIRST0)
                      : [sum] "=&v"(sum), [ok] "=&v"(ok), [t0] "=&v"(t0), [m] "=&s"(m), [cnt] "=&s"(cnt)
                      : [p0] "v"(p0), [p1] "v"(p1), [p2] "v"(p2), [p3] "v"(p3), [tag] "s"(tag), [rounds] "s"(rounds)
                      : WN_AP_CLOBBERS);
     else
-        asm volatile(WN_AP_POLL4_BODY("5")
+        asm volatile(WN_AP_POLL4_BODY(WN_AP_FIRST1)
                      : [sum] "=&v"(sum), [ok] "=&v"(ok), [t0] "=&v"(t0), [m] "=&s"(m), [cnt] "=&s"(cnt)
                      : [p0] "v"(p0), [p1] "v"(p1), [p2] "v"(p2), [p3] "v"(p3), [tag] "s"(tag), [rounds] "s"(rounds)
                      : WN_AP_CLOBBERS);
@@ -462,11 +505,14 @@ static __device__ void wn_v3_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
         const __amdgpu_buffer_rsrc_t rs_gs = wn_rsrc(p.gs);
         const size_t up_wg = (size_t)(l > 0 ? l - 1 : 0) * P + c;  // the upstream slice (l > 0)
         if (wn_barrier_failed(cx, failflag)) return;  // A(0)
-#if WN_V3_EARLY_REQ
-        wn_v4i sk_early[RS / 2];  // the upstream lane of the coming item, requested already at barrier A (may come back stale)
+        // The upstream skip lane of the coming item is requested right after barrier A: its producer published it a little after
+        // the x' this workgroup has just consumed, so the load returns it, and its round trip runs next to the critical group's
+        // filter/gate dot instead of inside this group's chunk after barrier B (requested at B the chunk took 0.57 us at 64 streams,
+        // nearly as long as the critical group needs from B to the next A).  One item ahead it would come back stale in the
+        // latency-bound regime.
+        wn_v4i sk_req[RS / 2];
 #pragma unroll
-        for (int h2 = 0; h2 < RS / 2; ++h2) sk_early[h2] = wn_ld_pair(rs_gs, (unsigned)(((up_wg * ns + 0) * (size_t)S) * 8) + (unsigned)t * 16 + h2 * 4096);
-#endif
+        for (int h2 = 0; h2 < RS / 2; ++h2) sk_req[h2] = wn_ld_pair(rs_gs, (unsigned)(((up_wg * ns + 0) * (size_t)S) * 8) + (unsigned)t * 16 + h2 * 4096);
         long long item = 0;
         for (long long e = 0; e < r.n_eval; ++e) {
             const bool prime = e < n_prime;
@@ -475,14 +521,8 @@ static __device__ void wn_v3_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
                 if (wn_barrier_failed(cx, failflag)) return;  // ---- B(i): z of this item staged
                 const bool stamp = r.prof && item < r.prof_items && tid == 256;
                 const long long t0 = stamp ? (long long)wall_clock64() : 0;
-                // The upstream skip lane of THIS item: its producer published it a little after the x' this workgroup has just
-                // consumed, so a load issued now returns it; it is consumed after the dot (a request issued one item ahead
-                // comes back stale in the latency-bound regime and costs a full poll round trip).
                 const unsigned off_up = (unsigned)(((up_wg * ns + s) * (size_t)S) * 8) + (unsigned)t * 16;    // upstream slice's lane, this stream
                 const unsigned off_me = (unsigned)((((size_t)cx.w * ns + s) * (size_t)S) * 8) + (unsigned)t * 16;
-                wn_v4i sk_now[RS / 2];
-#pragma unroll
-                for (int h2 = 0; h2 < RS / 2; ++h2) sk_now[h2] = (WN_V3_ABL & 1) ? wn_v4i{0, 0, 0, 0} : wn_ld_pair(rs_gs, off_up + h2 * 4096);
                 // ---- skip 1x1 partial on this lane of the running skip sum          (wavenet_model.py:154-162)
                 if ((WN_V3_ABL & 1) != 0) {
                     if (l == NL - 1) {
@@ -502,12 +542,7 @@ static __device__ void wn_v3_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
 #pragma unroll
                     for (int h2 = 0; h2 < RS / 2; ++h2) {
                         if (l > 0) {
-#if WN_V3_EARLY_REQ
-                            wn_v4i v = sk_early[h2];   // (only ever this item's stream: re-requested after every barrier A)
-                            if ((uint32_t)v.y != tag || (uint32_t)v.w != tag) v = sk_now[h2];
-#else
-                            wn_v4i v = sk_now[h2];
-#endif
+                            wn_v4i v = sk_req[h2];   // (only ever this item's stream: re-requested after every barrier A)
                             if ((uint32_t)v.y != tag || (uint32_t)v.w != tag) v = wn_poll_pair(cx, rs_gs, off_up + h2 * 4096, tag, WN_W_SKIN, e, s, WN_V3_SKIP_SLEEP);
                             a3[2 * h2] += __int_as_float(v.x);
                             a3[2 * h2 + 1] += __int_as_float(v.z);
@@ -521,13 +556,11 @@ static __device__ void wn_v3_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
                 if (stamp)  // slot 6: the skip group's B(i) | its chunk length << 40 (10 ns ticks)
                     r.prof[((size_t)cx.w * r.prof_items + item) * WN_STAMPS + 6] = (t0 & 0xffffffffffll) | (((long long)wall_clock64() - t0) << 40);
                 if (wn_barrier_failed(cx, failflag)) return;  // ---- A(i+1)
-#if WN_V3_EARLY_REQ
-                {   // early request for the coming item
+                {   // the upstream lane of the coming item
                     const int s2 = s + 1 < ns ? s + 1 : 0;
 #pragma unroll
-                    for (int h2 = 0; h2 < RS / 2; ++h2) sk_early[h2] = wn_ld_pair(rs_gs, (unsigned)(((up_wg * ns + s2) * (size_t)S) * 8) + (unsigned)t * 16 + h2 * 4096);
+                    for (int h2 = 0; h2 < RS / 2; ++h2) sk_req[h2] = wn_ld_pair(rs_gs, (unsigned)(((up_wg * ns + s2) * (size_t)S) * 8) + (unsigned)t * 16 + h2 * 4096);
                 }
-#endif
             }
         }
         (void)wn_barrier_failed(cx, failflag);  // B(N)
@@ -618,12 +651,16 @@ static __device__ void wn_v3_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
                 for (int j = D - 1; j > 0; --j) hx[j] = hx[j - 1];
                 hx[0] = xv;
             }
+            // a late layer's tap was staged an item ago: its tap-0 dot runs HERE, next to the critical group's dot (this group has
+            // nothing else to do between A and B), and is parked in a register until the critical group has read pre[s] (barrier B)
+            float acc_late = 0.f;
+            if (WN_V3_QDOT_EARLY && late_wg) acc_late = wn_dot_lds<K1>(w0, xo_cur + kq1 * (K1 + 4), bfg0);
             if (wn_barrier_failed(cx, failflag)) return;  // ---- B(i): the tap is staged
             const long long t1 = stamp ? (long long)wall_clock64() : 0;
             // ---- tap-0 half of the dilated conv for the NEXT timestep of this stream, parked for the critical group
             if (!(WN_V3_ABL & 2)) {
                 if (pusher) rings_l[((size_t)s * ML + tmod) * R + prow] = xs[buf * L::XR + SH::xpad(prow)];  // the push, off the A -> B window
-                pre[s * 256 + t] = wn_dot_lds<K1>(w0, xo_cur + kq1 * (K1 + 4), bfg0);
+                pre[s * 256 + t] = (WN_V3_QDOT_EARLY && late_wg) ? acc_late : wn_dot_lds<K1>(w0, xo_cur + kq1 * (K1 + 4), bfg0);
                 if (fifo) wn_q_issue_slot(slot, next_tap_ptr());  // the tap of item i + D goes into the entry item i has just given up
                 if (late && item + 1 < n_items) {
                     // the NEXT item's tap into the other buffer: D - 1 younger loads; the stores of a wave that also pushes (R > 128:
