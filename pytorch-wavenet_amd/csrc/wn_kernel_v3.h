@@ -415,7 +415,7 @@ static __device__ void wn_v3_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
                     int ok = 0;
                     unsigned spins = 0;
                     while (!cx.fail) {
-#if WN_V3_REQ_AT == 3
+#if WN_V3_REQ_AT >= 1
                         // (set A was requested in front of the previous item's publication store: one operation between the sets -- on
                         //  the first pass only; a second pass after the slow path finds both long complete, and the plain wait is the safe one)
                         if (l == 0) { if (spins == 0u) wn_ap_poll1<1>(q, tag, 64, sum, ok); else wn_ap_poll1<0>(q, tag, 64, sum, ok); }
