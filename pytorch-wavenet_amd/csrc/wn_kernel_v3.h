@@ -444,9 +444,12 @@ static __device__ void wn_v3_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
                 const float xres = (c == 0 && kq2 == 0) ? xb[SH::xpad(row2)] : 0.f;
                 float acc = wn_dot_lds<K1>(w1, xb + kq1 * (K1 + 4), pre[s * 256 + t]);
                 acc = wn_reduce<T1>(acc);
-                const float other = wn_partner<T1>(acc);
-                const float fv = is_gate ? other : acc, gv = is_gate ? acc : other;
-                const float z = wn_gate(fv, gv);
+                // tanh(f) * sigmoid(g) as in wn_gate, but each lane evaluates only ITS factor (filter lanes 2 sigmoid(2f) - 1, gate
+                // lanes sigmoid(g): one exp and one reciprocal instead of two each) and takes the other from its partner row; the
+                // product is the same two numbers multiplied: bit-identical
+                const float rc = __builtin_amdgcn_rcpf(1.0f + wn_exp(is_gate ? -acc : -2.0f * acc));
+                const float fac = is_gate ? rc : fmaf(2.0f, rc, -1.0f);
+                const float z = fac * wn_partner<T1>(fac);  // (the DPP move outside any lane-dependent branch)
                 if (!is_gate && kq1 == 0) zs[ch] = z;
                 if (fail_a) return;
                 const int fail_b = wn_barrier_flag(cx, failflag);  // ---- B(i): z staged
