@@ -12,21 +12,27 @@
 //     waves 0-3  C "critical": poll x' partials (two request sets in flight, hand-scheduled: wn_ap_poll4) -> stage x -> [A]
 //                              -> filter/gate dot (tap 1) + parked tap 0 -> tanh*sigmoid -> z -> [B] -> residual partial
 //                              -> publish x' -> request the next item's inputs
-//     waves 4-7  S "skip":     [B] -> request the upstream skip lane -> skip 1x1 partial -> add -> publish          -> [A]
-//     waves 8-11 Q "queue":    [A] -> queue push of x[t], stage the queue tap x[t+1-d] (prefetched 3 items ahead) -> [B]
-//                              -> tap-0 half of the dilated conv for the NEXT timestep of this stream -> park it  -> [A]
+//     waves 4-7  S "skip":     [A] -> request the upstream skip lane (its round trip runs next to the critical dot) -> [B]
+//                              -> skip 1x1 partial -> add -> publish                                                -> [A]
+//     waves 8-11 Q "queue":    d = 1 / few streams and small d:  [A] -> queue push of x[t], stage the tap -> [B] -> tap-0 half of the
+//                              dilated conv for the NEXT timestep of this stream -> park it -> [A];
+//                              every other layer ("late"): nothing between [A] and [B]; after [B]: push x[t] (the waves that load
+//                              no taps), tap-0 dot on the tap staged an item ago, request the tap of item i+6, stage the tap of
+//                              item i+1 (hand-scheduled register FIFO: wn_q_issue / wn_q_take) -> [A]
 // [A] and [B] are the two LDS-only workgroup barriers of an item (all 12 waves).  Each group holds only the weights of its
 // part (C: tap 1 + residual slice, S: skip slice, Q: tap 0) and has a memory stream of its own (C polls x' partials, S the
 // skip lane, Q reads/writes the queue): a slow queue read can never sit in front of a poll.  ONE chain serves all streams
-// (no second copy of the weights, no second set of hand-off buffers).
+// (no second copy of the weights, no second set of hand-off buffers).  Head workgroups request the next item's skip lanes as soon
+// as they have staged the current ones; samplers perform layer 0's start_conv.
 //
-// LDS hazards (i = item index; x is double buffered, everything else single; W = written in, R = read in):
-//   xs[buf(i)]   W: C before A(i).  R: C in A(i)..A(i+1), Q in A(i)..B(i).  Next W (item i+2) after B(i+1).
+// LDS hazards (i = item index; x and the late layers' tap are double buffered, everything else single; W = written in, R = read in):
+//   xs[buf(i)]   W: C before A(i).  R: C in A(i)..A(i+1), Q in A(i)..A(i+1) (late layers push after B(i)).  Next W (item i+2) after B(i+1).
 //   zs           W: C in A(i)..B(i).  R: C and S in B(i)..A(i+1).
-//   xo           W: Q in A(i)..B(i).  R: Q in B(i)..A(i+1).
+//   xo           not late: W: Q in A(i)..B(i).  R: Q in B(i)..A(i+1).   late: xo[i & 1]: W: Q in B(i-1)..A(i).  R: Q in B(i)..A(i+1).
 //   pre[s]       W: Q in B(i)..A(i+1) for item (e, s).  R: C in A(j)..B(j) of item j = (e+1, s) = i + n_streams >= i + 1.
-// Queue (HBM) hazard: the tap of item j is read WN_V3_TAP_AHEAD items ahead, during item j-WN_V3_TAP_AHEAD; it was pushed (d >= 2) at item j - n_streams*(d-1).
-// Where that is no more than WN_V3_TAP_AHEAD items back (few streams, small d) the queue group takes the row from its own registers instead.
+// Queue (HBM) hazard: the tap of item j is requested WN_V3_TAP_AHEAD items ahead, after barrier B of item j-WN_V3_TAP_AHEAD; it was pushed
+// (d >= 2) at item j - n_streams*(d-1).  Where that is no more than WN_V3_TAP_AHEAD items back (few streams, small d) the queue group takes
+// the row from its own registers instead.
 #ifndef WN_KERNEL_V3_H
 #define WN_KERNEL_V3_H
 
