@@ -38,12 +38,15 @@ static __device__ __forceinline__ void st(__amdgpu_buffer_rsrc_t rs, unsigned of
     if constexpr (SF == 0) __builtin_amdgcn_raw_buffer_store_b64(v, rs, off, 0, 0);
     else if constexpr (SF == 1) __builtin_amdgcn_raw_buffer_store_b64(v, rs, off, 0, 16);
     else if constexpr (SF == 2) __builtin_amdgcn_raw_buffer_store_b64(v, rs, off, 0, 1);
+    else if constexpr (SF == 4) __builtin_amdgcn_raw_buffer_store_b64(v, rs, off, 0, 2);   // nt
+    else if constexpr (SF == 5) __builtin_amdgcn_raw_buffer_store_b64(v, rs, off, 0, 3);   // sc0 nt
+    else if constexpr (SF == 6) __builtin_amdgcn_raw_buffer_store_b64(v, rs, off, 0, 18);  // sc1 nt
     else {  // an atomic exchange executed AT the L2, result unused
         unsigned long long* p = reinterpret_cast<unsigned long long*>(rs_base + off);
         (void)__hip_atomic_exchange(p, ((unsigned long long)(unsigned)v.y << 32) | (unsigned)v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
-static const char* SFN[] = {"plain", "sc1", "sc0", "xchg"};
+static const char* SFN[] = {"plain", "sc1", "sc0", "xchg", "nt", "sc0+nt", "sc1+nt"};
 static const char* LFN[] = {"sc1", "sc0", "sc0+sc1", "nt", "sc0+nt", "inv+plain", "inv+sc0", "plain", "fetch_add0"};
 
 // (a) raw dependent-load round trip: one wave, the same line over and over (lane 0's result feeds the next address)
@@ -184,6 +187,11 @@ int main() {
         run_ring<5, 0>(gran, dpos, dfail, n, true, khz);
         run_ring<6, 0>(gran, dpos, dfail, n, true, khz);
         run_ring<7, 0>(gran, dpos, dfail, n, true, khz);
+        run_ring<0, 4>(gran, dpos, dfail, n, true, khz);
+        run_ring<0, 5>(gran, dpos, dfail, n, true, khz);
+        run_ring<0, 6>(gran, dpos, dfail, n, true, khz);
+        run_ring<3, 4>(gran, dpos, dfail, n, true, khz);
+        run_ring<0, 6>(gran, dpos, dfail, n, false, khz);
         run_ring<0, 3>(gran, dpos, dfail, n, true, khz);
         run_ring<8, 0>(gran, dpos, dfail, n, true, khz);
         run_ring<8, 3>(gran, dpos, dfail, n, true, khz);
