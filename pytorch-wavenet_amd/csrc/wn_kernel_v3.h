@@ -44,6 +44,10 @@
 #ifndef WN_V3_REQ_AT
 #define WN_V3_REQ_AT 0  // where set A of the next item's input is requested: 0 at the end of the item, 1 after barrier B, 2 after barrier A
 #endif
+#ifndef WN_V3_REQ_FIRST_ON_CROSSING
+#define WN_V3_REQ_FIRST_ON_CROSSING 0  // 1: stages that publish across an XCD boundary request in front of their (write-through) store: measured
+                                       // x64 924 k against 935 k without (profiles/r02_v3_crossing_request.txt)
+#endif
 #ifndef WN_V3_LAZY_B
 #define WN_V3_LAZY_B 1  // 1: the second request set of the critical group's input poll is only issued when the first came back stale
 #endif
@@ -402,6 +406,9 @@ static __device__ void wn_v3_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
             else wn_ap_issue_a4(q, q + xstep_j, q + 2 * xstep_j, q + 3 * xstep_j);
         };
         if (t < R) request(0);
+        // (experiment switch: a stage whose consumers sit in another XCD publishes write-through; requesting set A in FRONT of that
+        // store keeps its acknowledgement out of the first wait -- no gain measured, see WN_V3_REQ_FIRST_ON_CROSSING)
+        const bool req_first = WN_V3_REQ_FIRST_ON_CROSSING && !local_x && l > 0 && l < NL - 1;
         int buf = 0;
         for (long long e = 0; e < r.n_eval; ++e) {
             const uint32_t tag = (uint32_t)(e + 1);
@@ -429,6 +436,7 @@ static __device__ void wn_v3_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
                         else wn_ap_poll4<0>(q, q + xstep_j, q + 2 * xstep_j, q + 3 * xstep_j, tag, 64, sum, ok);
 #else
                         if (l == 0) wn_ap_poll1<0>(q, tag, 64, sum, ok);
+                        else if (req_first && spins == 0u) wn_ap_poll4<1>(q, q + xstep_j, q + 2 * xstep_j, q + 3 * xstep_j, tag, 64, sum, ok);
                         else wn_ap_poll4<0>(q, q + xstep_j, q + 2 * xstep_j, q + 3 * xstep_j, tag, 64, sum, ok);
 #endif
                         if (__builtin_amdgcn_ballot_w64(ok == 0) == 0) break;  // the wave leaves together (its lanes share the barrier that follows)
@@ -474,6 +482,8 @@ static __device__ void wn_v3_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
                         const float xn1 = wn_dpp<0x4E>(xn);  // quad_perm [2,3,0,1]
 #if WN_V3_REQ_AT == 3
                         if (t < R) request(s + 1 < ns ? s + 1 : 0);  // in FRONT of the store: the wait for set A does not include its acknowledgement
+#elif WN_V3_REQ_AT == 0
+                        if (req_first && t < R) request(s + 1 < ns ? s + 1 : 0);
 #endif
                         if ((t & 3) == 0) wn_st_pair(rs_gx, (unsigned)((((size_t)cx.w * ns + s) * R + row2) * 8), tag, xn, xn1, local_x);
                     } else {
@@ -491,7 +501,7 @@ static __device__ void wn_v3_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
                     for (int k = 0; k < 6; ++k) dst[k] = park[k];
                 }
 #if WN_V3_REQ_AT == 0
-                if (t < R) request(s + 1 < ns ? s + 1 : 0);
+                if (!req_first && t < R) request(s + 1 < ns ? s + 1 : 0);
 #endif
                 if (fail_b) return;
             }
