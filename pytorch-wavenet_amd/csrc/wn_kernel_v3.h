@@ -59,7 +59,8 @@
 #define WN_AP_FIRST1 "5"
 #endif
 #ifndef WN_V3_QDOT_EARLY
-#define WN_V3_QDOT_EARLY 0  // 1: a late layer's tap-0 dot runs between barriers A and B (next to the critical group's dot) instead of after B
+#define WN_V3_QDOT_EARLY 0  // 1: a late layer's tap-0 dot runs between barriers A and B (next to the critical group's dot) instead of after B;
+                            // 2: only in the two-streams-per-item form
 #endif
 #ifndef WN_V3_SKIP_SLEEP
 #define WN_V3_SKIP_SLEEP 0  // s_sleep between the skip group's poll retries (the skip lane is not latency critical; fewer polls on the fabric)
@@ -331,9 +332,9 @@ static __device__ __forceinline__ int wn_barrier_flag(WnCtx& cx, int* flag) {
     return *flag;
 }
 
-template <class SH>
+template <class SH, int G = 1>
 struct WnV3Lds {
-    using M = WnV2LdsM<SH, 1, false>;  // the head / sampler roles are those of wn_kernel_v2.h: keep their offsets
+    using M = WnV2LdsM<SH, G, false>;  // G streams per pipeline item: x, z, taps, the head's staging areas are [G][...]
     static constexpr int XR = M::XR, SKP = M::SKP, DCP = M::DCP;
     static constexpr int xs = M::xs, zs = M::zs, xo = M::xo, sk = M::sk, ev = M::ev, smp = M::smp, park = M::park;
     static constexpr int pre = M::pre;        // [n_streams][256]
@@ -345,13 +346,44 @@ struct WnV3Lds {
 template <class SH>
 static constexpr bool wn_v3_fits() { return SH::RS % 2 == 0 && SH::RS * SH::DC <= 100 && SH::K1 + SH::K2 <= 80 && SH::K3 + SH::EC <= 130; }
 
-template <class SH, int P>
+// dot of one register weight vector with the G vectors x + g * xstride in LDS (the G streams of an item share every weight operand;
+// per stream the arithmetic is wn_dot_lds's: two packed chains, same summation order -- bit-identical whatever G)
+template <int K, int G>
+static __device__ __forceinline__ void wn_dot_lds_gp(const float (&w)[K], const float* x, int xstride, const float (&init)[G], float (&out)[G]) {
+    if constexpr (K % 4 == 0) {
+        float4 v[G][K / 4];
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int k = 0; k < K / 4; ++k) v[g][k] = reinterpret_cast<const float4*>(x + g * xstride)[k];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            wn_f2 a01 = {init[g], 0.f}, a23 = {0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < K / 4; ++k) {
+                a01 = __builtin_elementwise_fma(wn_f2{w[4 * k], w[4 * k + 1]}, wn_f2{v[g][k].x, v[g][k].y}, a01);
+                a23 = __builtin_elementwise_fma(wn_f2{w[4 * k + 2], w[4 * k + 3]}, wn_f2{v[g][k].z, v[g][k].w}, a23);
+            }
+            out[g] = (a01.x + a01.y) + (a23.x + a23.y);
+        }
+    } else {
+#pragma unroll
+        for (int g = 0; g < G; ++g) out[g] = wn_dot_lds<K>(w, x + g * xstride, init[g]);
+    }
+}
+
+template <class SH, int P, int G>
 static __device__ void wn_v3_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, float* lds, int l, int c) {
     constexpr int R = SH::R, DC = SH::DC, S = SH::S, T1 = SH::T1, K1 = SH::K1, T2 = SH::T2, K2 = SH::K2, RS = SH::RS;
-    using L = WnV3Lds<SH>;
+    using L = WnV3Lds<SH, G>;
+    static_assert(G >= 1 && G * R <= 256 && R % 64 == 0, "the G streams of an item are polled / pushed by G*R lanes, whole waves each");
     const int tid = threadIdx.x, t = tid & 255;
     const int group = tid >> 8;  // wave-uniform: 0 critical, 1 skip, 2 queue
     const int ns = p.n_streams, NL = p.NL;
+    const int nI = ns / G;  // pipeline items per evaluation: item (e, s) carries the streams s .. s+G-1 (s a multiple of G)
+    // lanes t < G*R handle element tr of stream s + tg of the item (hand-off granules and queue rows of consecutive streams are
+    // R apart: their index is simply + t)
+    const int tg = t < G * R ? t / R : 0, tr = t < G * R ? t - tg * R : 0;
     const float* img = p.blobs + (size_t)cx.w * (SH::NWL * 256) + t;  // image rows: w1[K1] w0[K1] w2[K2] w3[RS][DC] bfg bres bskip[RS]
     const int kq1 = t % T1, grp = t / T1, ch = grp >> 1, is_gate = grp & 1;
     const int kq2 = t % T2, row2 = t / T2;
@@ -374,7 +406,7 @@ static __device__ void wn_v3_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
                 lx = wn_same_xcd(cx, mine, (l + 1) * P, P);
                 lsk = wn_same_xcd(cx, mine, (l + 1) * P + c, 1);
             } else {
-                lsk = wn_same_xcd(cx, mine, NL * P, p.PA);
+                lsk = wn_same_xcd(cx, mine, NL * P, p.PA * p.HR);
             }
         }
         locflags[0] = lx; locflags[1] = lsk;
@@ -398,29 +430,30 @@ static __device__ void wn_v3_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
         const __amdgpu_buffer_rsrc_t rs_gx = wn_rsrc(p.gx);
         // the layer's input granules of stream s2: layer 0 ONE complete row per stream (g0), layers > 0 the P partials of the upstream slices
         static_assert(P == 4, "the hand-scheduled input poll (wn_ap_poll4) is written for four partials");
-        const wn_u64* xbase = (l == 0 ? p.g0 : p.gx + ((size_t)(l - 1) * P) * ns * R) + (t < R ? t : 0);
+        const bool poller = t < G * R;  // (whole waves)
+        const wn_u64* xbase = (l == 0 ? p.g0 : p.gx + ((size_t)(l - 1) * P) * ns * R) + (poller ? t : 0);
         const size_t xstep_j = (size_t)ns * R;
-        auto request = [&](int s2) {  // set A for the coming item (see wn_ap_poll4)
+        auto request = [&](int s2) {  // set A for the coming item, first stream s2 (see wn_ap_poll4)
             const wn_u64* q = xbase + (size_t)s2 * R;
             if (l == 0) wn_ap_issue_a1(q);
             else wn_ap_issue_a4(q, q + xstep_j, q + 2 * xstep_j, q + 3 * xstep_j);
         };
-        if (t < R) request(0);
+        if (poller) request(0);
         // (experiment switch: a stage whose consumers sit in another XCD publishes write-through; requesting set A in FRONT of that
         // store keeps its acknowledgement out of the first wait -- no gain measured, see WN_V3_REQ_FIRST_ON_CROSSING)
         const bool req_first = WN_V3_REQ_FIRST_ON_CROSSING && !local_x && l > 0 && l < NL - 1;
         int buf = 0;
         for (long long e = 0; e < r.n_eval; ++e) {
             const uint32_t tag = (uint32_t)(e + 1);
-            for (int s = 0; s < ns; ++s, buf ^= 1) {
-                float* xb = xs + buf * L::XR;
-                const long long item = e * ns + s;
+            for (int s = 0; s < ns; s += G, buf ^= 1) {
+                float* xb = xs + buf * (G * L::XR);  // [G][XR]
+                const long long item = e * nI + s / G;
                 wn_stamp(r, park, item, 0);
-                // ---- 1. layer input x[t]
+                // ---- 1. layer input x[t] of the item's G streams
                 if (l == 0 && e == 0) {  // the first evaluation's input is a given sample: start_conv row gather (wavenet_model.py:127, 256-257)
-                    const int idx = r.first[(size_t)s * r.n_given];
-                    if (t < R) xb[SH::xpad(t)] = p.start_t[(size_t)idx * R + t] + (p.start_b ? p.start_b[t] : 0.f);
-                } else if (t < R) {
+                    const int idx = r.first[(size_t)(s + tg) * r.n_given];
+                    if (poller) xb[tg * L::XR + SH::xpad(tr)] = p.start_t[(size_t)idx * R + tr] + (p.start_b ? p.start_b[tr] : 0.f);
+                } else if (poller) {
                     // layer 0 (e > 0): ONE complete row per stream, published by the sampler that drew the class (the row gather
                     // sits there, off this workgroup: with it layer 0 was the slowest stage of the chain); layers > 0: P partials
                     const wn_u64* q = xbase + (size_t)s * R;
@@ -446,52 +479,72 @@ static __device__ void wn_v3_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
                         if (spins++ == 0u) cx.t_start = now;
                         else if (now - cx.t_start > cx.r->timeout_ticks) { wn_give_up(cx, l == 0 ? WN_W_LOGITS : WN_W_X, e, s); break; }
                     }
-                    xb[SH::xpad(t)] = sum;
+                    xb[tg * L::XR + SH::xpad(tr)] = sum;
                 }
                 wn_stamp(r, park, item, 4);
                 const int fail_a = wn_barrier_flag(cx, failflag);  // ---- A(i): x staged
                 wn_stamp(r, park, item, 1);
 #if WN_V3_REQ_AT == 2
-                if (t < R) request(s + 1 < ns ? s + 1 : 0);
+                if (poller) request(s + G < ns ? s + G : 0);
 #endif
                 // ---- 2. filter/gate: tap 1 on x[t] + parked tap 0, tanh * sigmoid   (wavenet_model.py:147-151)
-                const float xres = (c == 0 && kq2 == 0) ? xb[SH::xpad(row2)] : 0.f;
-                float acc = wn_dot_lds<K1>(w1, xb + kq1 * (K1 + 4), pre[s * 256 + t]);
-                acc = wn_reduce<T1>(acc);
+                float xres[G], pin[G], acc[G];
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    xres[g] = (c == 0 && kq2 == 0) ? xb[g * L::XR + SH::xpad(row2)] : 0.f;
+                    pin[g] = pre[(s + g) * 256 + t];
+                }
+                wn_dot_lds_gp<K1, G>(w1, xb + kq1 * (K1 + 4), L::XR, pin, acc);
+#pragma unroll
+                for (int g = 0; g < G; ++g) acc[g] = wn_reduce<T1>(acc[g]);
                 // tanh(f) * sigmoid(g) as in wn_gate, but each lane evaluates only ITS factor (filter lanes 2 sigmoid(2f) - 1, gate
                 // lanes sigmoid(g): one exp and one reciprocal instead of two each) and takes the other from its partner row; the
                 // product is the same two numbers multiplied: bit-identical
-                const float rc = __builtin_amdgcn_rcpf(1.0f + wn_exp(is_gate ? -acc : -2.0f * acc));
-                const float fac = is_gate ? rc : fmaf(2.0f, rc, -1.0f);
-                const float z = fac * wn_partner<T1>(fac);  // (the DPP move outside any lane-dependent branch)
-                if (!is_gate && kq1 == 0) zs[ch] = z;
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    const float rc = __builtin_amdgcn_rcpf(1.0f + wn_exp(is_gate ? -acc[g] : -2.0f * acc[g]));
+                    const float fac = is_gate ? rc : fmaf(2.0f, rc, -1.0f);
+                    const float z = fac * wn_partner<T1>(fac);  // (the DPP move outside any lane-dependent branch)
+                    if (!is_gate && kq1 == 0) zs[g * L::DCP + ch] = z;
+                }
                 if (fail_a) return;
                 const int fail_b = wn_barrier_flag(cx, failflag);  // ---- B(i): z staged
                 wn_stamp(r, park, item, 5);
 #if WN_V3_REQ_AT == 1
-                if (t < R) request(s + 1 < ns ? s + 1 : 0);
+                if (poller) request(s + G < ns ? s + G : 0);
 #endif
                 // ---- 3. residual 1x1 partial, published at once                      (wavenet_model.py:164-165)
                 if (l < NL - 1) {
-                    float a2 = wn_dot_lds<K2>(w2, zs + kq2 * K2, 0.f);
-                    a2 = wn_reduce<T2>(a2);
-                    const float xn = (a2 + bres) + xres;  // valid on the kq2 == 0 lane of every row
+                    float a2[G], zero[G], xn[G];
+#pragma unroll
+                    for (int g = 0; g < G; ++g) zero[g] = 0.f;
+                    wn_dot_lds_gp<K2, G>(w2, zs + kq2 * K2, L::DCP, zero, a2);
+#pragma unroll
+                    for (int g = 0; g < G; ++g) xn[g] = (wn_reduce<T2>(a2[g]) + bres) + xres[g];  // valid on the kq2 == 0 lane of every row
                     if constexpr (T2 == 2) {
                         // rows 2j and 2j+1 sit on lanes 4j and 4j+2: one 16-byte store {x'(2j), tag, x'(2j+1), tag} by lane 4j instead of
                         // two 8-byte stores (write-through stores are retired per lane; consumers keep reading their own 8-byte half)
-                        const float xn1 = wn_dpp<0x4E>(xn);  // quad_perm [2,3,0,1]
+                        float xn1[G];
+#pragma unroll
+                        for (int g = 0; g < G; ++g) xn1[g] = wn_dpp<0x4E>(xn[g]);  // quad_perm [2,3,0,1]
 #if WN_V3_REQ_AT == 3
-                        if (t < R) request(s + 1 < ns ? s + 1 : 0);  // in FRONT of the store: the wait for set A does not include its acknowledgement
+                        if (poller) request(s + G < ns ? s + G : 0);  // in FRONT of the store: the wait for set A does not include its acknowledgement
 #elif WN_V3_REQ_AT == 0
-                        if (req_first && t < R) request(s + 1 < ns ? s + 1 : 0);
+                        if (req_first && poller) request(s + G < ns ? s + G : 0);
 #endif
-                        if ((t & 3) == 0) wn_st_pair(rs_gx, (unsigned)((((size_t)cx.w * ns + s) * R + row2) * 8), tag, xn, xn1, local_x);
+                        if ((t & 3) == 0) {
+#pragma unroll
+                            for (int g = 0; g < G; ++g) wn_st_pair(rs_gx, (unsigned)((((size_t)cx.w * ns + s + g) * R + row2) * 8), tag, xn[g], xn1[g], local_x);
+                        }
                     } else {
-                        if (kq2 == 0) wn_publish_at(p.gx + ((size_t)cx.w * ns + s) * R + row2, tag, xn, local_x);
+                        if (kq2 == 0) {
+#pragma unroll
+                            for (int g = 0; g < G; ++g) wn_publish_at(p.gx + ((size_t)cx.w * ns + s + g) * R + row2, tag, xn[g], local_x);
+                        }
                     }
                 }
 #if WN_V3_REQ_AT == 3
-                else if (t < R) request(s + 1 < ns ? s + 1 : 0);  // the last layer publishes no x'
+                else if (poller) request(s + G < ns ? s + G : 0);  // the last layer publishes no x'
 #endif
                 wn_stamp(r, park, item, 2);
                 wn_stamp(r, park, item, 3);
@@ -501,7 +554,7 @@ static __device__ void wn_v3_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
                     for (int k = 0; k < 6; ++k) dst[k] = park[k];
                 }
 #if WN_V3_REQ_AT == 0
-                if (!req_first && t < R) request(s + 1 < ns ? s + 1 : 0);
+                if (!req_first && poller) request(s + G < ns ? s + G : 0);
 #endif
                 if (fail_b) return;
             }
@@ -513,11 +566,14 @@ static __device__ void wn_v3_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
 
     if (group == 1) {
         // ================================================================== skip group
-        float w3[RS][DC], bskip[RS];
+        // rows 2h and 2h+1 of this lane's skip slice side by side: one packed FMA (v_pk_fma_f32) per z element and row pair
+        wn_f2 w3p[RS / 2][DC];
+        float bskip[RS];
 #pragma unroll
-        for (int q = 0; q < RS; ++q)
+        for (int h2 = 0; h2 < RS / 2; ++h2)
 #pragma unroll
-            for (int k = 0; k < DC; ++k) w3[q][k] = img[(size_t)(2 * K1 + K2 + q * DC + k) * 256];
+            for (int k = 0; k < DC; ++k)
+                w3p[h2][k] = wn_f2{img[(size_t)(2 * K1 + K2 + (2 * h2) * DC + k) * 256], img[(size_t)(2 * K1 + K2 + (2 * h2 + 1) * DC + k) * 256]};
 #pragma unroll
         for (int q = 0; q < RS; ++q) bskip[q] = img[(size_t)(2 * K1 + K2 + RS * DC + 2 + q) * 256];
         static_assert(RS % 2 == 0, "the skip lane is handed over in 16-byte pairs (rows t, t + 256)");
@@ -529,56 +585,86 @@ static __device__ void wn_v3_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
         // filter/gate dot instead of inside this group's chunk after barrier B (requested at B the chunk took 0.57 us at 64 streams,
         // nearly as long as the critical group needs from B to the next A).  One item ahead it would come back stale in the
         // latency-bound regime.
-        wn_v4i sk_req[RS / 2];
+        wn_v4i sk_req[G][RS / 2];
 #pragma unroll
-        for (int h2 = 0; h2 < RS / 2; ++h2) sk_req[h2] = wn_ld_pair(rs_gs, (unsigned)(((up_wg * ns + 0) * (size_t)S) * 8) + (unsigned)t * 16 + h2 * 4096);
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int h2 = 0; h2 < RS / 2; ++h2) sk_req[g][h2] = wn_ld_pair(rs_gs, (unsigned)(((up_wg * ns + g) * (size_t)S) * 8) + (unsigned)t * 16 + h2 * 4096);
         long long item = 0;
         for (long long e = 0; e < r.n_eval; ++e) {
             const bool prime = e < n_prime;
             const uint32_t tag = (uint32_t)(e + 1);
-            for (int s = 0; s < ns; ++s, ++item) {
+            for (int s = 0; s < ns; s += G, ++item) {
                 if (wn_barrier_failed(cx, failflag)) return;  // ---- B(i): z of this item staged
                 const bool stamp = r.prof && item < r.prof_items && tid == 256;
                 const long long t0 = stamp ? (long long)wall_clock64() : 0;
-                const unsigned off_up = (unsigned)(((up_wg * ns + s) * (size_t)S) * 8) + (unsigned)t * 16;    // upstream slice's lane, this stream
+                constexpr unsigned SB = (unsigned)S * 8;  // bytes between the lanes of consecutive streams
+                const unsigned off_up = (unsigned)(((up_wg * ns + s) * (size_t)S) * 8) + (unsigned)t * 16;    // upstream slice's lane, first stream of the item
                 const unsigned off_me = (unsigned)((((size_t)cx.w * ns + s) * (size_t)S) * 8) + (unsigned)t * 16;
                 // ---- skip 1x1 partial on this lane of the running skip sum          (wavenet_model.py:154-162)
                 if ((WN_V3_ABL & 1) != 0) {
                     if (l == NL - 1) {
 #pragma unroll
-                        for (int h2 = 0; h2 < RS / 2; ++h2) wn_st_pair(rs_gs, off_me + h2 * 4096, tag, 0.f, 0.f, local_s);
+                        for (int g = 0; g < G; ++g)
+#pragma unroll
+                            for (int h2 = 0; h2 < RS / 2; ++h2) wn_st_pair(rs_gs, off_me + g * SB + h2 * 4096, tag, 0.f, 0.f, local_s);
                     }
                 } else if (!prime) {
-                    float a3[RS];
+                    // per row: bias, then + w[k] z[k] for k = 0..DC-1 in order (one fused multiply-add each), as before the packing
+                    wn_f2 a3p[G][RS / 2];
 #pragma unroll
-                    for (int q = 0; q < RS; ++q) a3[q] = bskip[q];
+                    for (int g = 0; g < G; ++g)
 #pragma unroll
-                    for (int k = 0; k < DC; ++k) {
-                        const float zk = zs[k];
+                        for (int h2 = 0; h2 < RS / 2; ++h2) a3p[g][h2] = wn_f2{bskip[2 * h2], bskip[2 * h2 + 1]};
+                    static_assert(DC % 4 == 0 && L::DCP % 4 == 0, "z is read as float4");
 #pragma unroll
-                        for (int q = 0; q < RS; ++q) a3[q] += w3[q][k] * zk;
-                    }
+                    for (int g = 0; g < G; ++g) {
+                        float4 z4[DC / 4];
 #pragma unroll
-                    for (int h2 = 0; h2 < RS / 2; ++h2) {
-                        if (l > 0) {
-                            wn_v4i v = sk_req[h2];   // (only ever this item's stream: re-requested after every barrier A)
-                            if ((uint32_t)v.y != tag || (uint32_t)v.w != tag) v = wn_poll_pair(cx, rs_gs, off_up + h2 * 4096, tag, WN_W_SKIN, e, s, WN_V3_SKIP_SLEEP);
-                            a3[2 * h2] += __int_as_float(v.x);
-                            a3[2 * h2 + 1] += __int_as_float(v.z);
+                        for (int k = 0; k < DC / 4; ++k) z4[k] = reinterpret_cast<const float4*>(zs + g * L::DCP)[k];
+#pragma unroll
+                        for (int k = 0; k < DC / 4; ++k) {
+#pragma unroll
+                            for (int h2 = 0; h2 < RS / 2; ++h2) {
+                                a3p[g][h2] = __builtin_elementwise_fma(w3p[h2][4 * k], wn_f2{z4[k].x, z4[k].x}, a3p[g][h2]);
+                                a3p[g][h2] = __builtin_elementwise_fma(w3p[h2][4 * k + 1], wn_f2{z4[k].y, z4[k].y}, a3p[g][h2]);
+                                a3p[g][h2] = __builtin_elementwise_fma(w3p[h2][4 * k + 2], wn_f2{z4[k].z, z4[k].z}, a3p[g][h2]);
+                                a3p[g][h2] = __builtin_elementwise_fma(w3p[h2][4 * k + 3], wn_f2{z4[k].w, z4[k].w}, a3p[g][h2]);
+                            }
                         }
-                        wn_st_pair(rs_gs, off_me + h2 * 4096, tag, a3[2 * h2], a3[2 * h2 + 1], local_s);
                     }
+                    float a3[G][RS];
+#pragma unroll
+                    for (int g = 0; g < G; ++g)
+#pragma unroll
+                        for (int h2 = 0; h2 < RS / 2; ++h2) { a3[g][2 * h2] = a3p[g][h2].x; a3[g][2 * h2 + 1] = a3p[g][h2].y; }
+#pragma unroll
+                    for (int g = 0; g < G; ++g)
+#pragma unroll
+                        for (int h2 = 0; h2 < RS / 2; ++h2) {
+                            if (l > 0) {
+                                wn_v4i v = sk_req[g][h2];   // (only ever this item's streams: re-requested after every barrier A)
+                                if ((uint32_t)v.y != tag || (uint32_t)v.w != tag) v = wn_poll_pair(cx, rs_gs, off_up + g * SB + h2 * 4096, tag, WN_W_SKIN, e, s + g, WN_V3_SKIP_SLEEP);
+                                a3[g][2 * h2] += __int_as_float(v.x);
+                                a3[g][2 * h2 + 1] += __int_as_float(v.z);
+                            }
+                            wn_st_pair(rs_gs, off_me + g * SB + h2 * 4096, tag, a3[g][2 * h2], a3[g][2 * h2 + 1], local_s);
+                        }
                 } else if (l == NL - 1) {
 #pragma unroll
-                    for (int h2 = 0; h2 < RS / 2; ++h2) wn_st_pair(rs_gs, off_me + h2 * 4096, tag, 0.f, 0.f, local_s);
+                    for (int g = 0; g < G; ++g)
+#pragma unroll
+                        for (int h2 = 0; h2 < RS / 2; ++h2) wn_st_pair(rs_gs, off_me + g * SB + h2 * 4096, tag, 0.f, 0.f, local_s);
                 }
                 if (stamp)  // slot 6: the skip group's B(i) | its chunk length << 40 (10 ns ticks)
                     r.prof[((size_t)cx.w * r.prof_items + item) * WN_STAMPS + 6] = (t0 & 0xffffffffffll) | (((long long)wall_clock64() - t0) << 40);
                 if (wn_barrier_failed(cx, failflag)) return;  // ---- A(i+1)
                 {   // the upstream lane of the coming item
-                    const int s2 = s + 1 < ns ? s + 1 : 0;
+                    const int s2 = s + G < ns ? s + G : 0;
 #pragma unroll
-                    for (int h2 = 0; h2 < RS / 2; ++h2) sk_req[h2] = wn_ld_pair(rs_gs, (unsigned)(((up_wg * ns + s2) * (size_t)S) * 8) + (unsigned)t * 16 + h2 * 4096);
+                    for (int g = 0; g < G; ++g)
+#pragma unroll
+                        for (int h2 = 0; h2 < RS / 2; ++h2) sk_req[g][h2] = wn_ld_pair(rs_gs, (unsigned)(((up_wg * ns + s2 + g) * (size_t)S) * 8) + (unsigned)t * 16 + h2 * 4096);
                 }
             }
         }
@@ -606,13 +692,15 @@ static __device__ void wn_v3_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
     int tmod = (int)(r.t_base % ML);  // queue slot of x[t] of the current item, kept incrementally
     // Queue taps x[t+1-d] are read WN_V3_TAP_AHEAD items ahead (rows of large-d layers are an HBM miss): a register FIFO of three
     // entries, hand-scheduled (wn_q_issue / wn_q_take); entry = item mod 3.
-    const bool fifo = d != 1 && t < R && !(WN_V3_ABL & 2);  // (wave-uniform: R is a multiple of 64 in every instantiated shape)
-    static_assert(R % 64 == 0, "the tap FIFO is issued by whole waves");
+    // lanes t < G*R: element tr of stream s + tg of the item -- every wave issues ONE tap load per item, whatever G
+    const bool qlane = t < G * R;
+    const bool fifo = d != 1 && qlane && !(WN_V3_ABL & 2);  // (wave-uniform: R is a multiple of 64 in every instantiated shape)
     int s_a = 0, tmod_a = tmod;  // coordinates of the item whose tap is requested next
     auto next_tap_ptr = [&]() -> const float* {
         const int tap = tmod_a + 2 >= ML ? tmod_a + 2 - ML : tmod_a + 2;  // slot of x[t+1-d]: (t+1-d) mod (d+1) = (t+2) mod (d+1)
-        const float* q = rings_l + ((size_t)s_a * ML + tap) * R + (t < R ? t : 0);
-        if (++s_a == ns) { s_a = 0; tmod_a = (tmod_a + 1 == ML) ? 0 : tmod_a + 1; }
+        const float* q = rings_l + ((size_t)(s_a + tg) * ML + tap) * R + tr;
+        s_a += G;
+        if (s_a == ns) { s_a = 0; tmod_a = (tmod_a + 1 == ML) ? 0 : tmod_a + 1; }
         return q;
     };
     if (fifo) {
@@ -622,7 +710,7 @@ static __device__ void wn_v3_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
     int slot = 0;  // item mod WN_V3_TAP_AHEAD
     // With few streams and a small dilation the tap row of an item was pushed fewer than WN_V3_TAP_AHEAD items before it (it is
     // x of item i - n_streams*(d-1)): the lane keeps its own last x values instead of reading the queue ahead of the push.
-    const long long back = (long long)ns * (d - 1);
+    const long long back = (long long)nI * (d - 1);  // in items
     const bool near = d != 1 && back <= WN_V3_TAP_AHEAD;
     float hx[WN_V3_TAP_AHEAD];  // x of the last WN_V3_TAP_AHEAD items, newest first
 #pragma unroll
@@ -634,27 +722,28 @@ static __device__ void wn_v3_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
     const bool late_wg = d != 1 && !near && !(WN_V3_ABL & 2);  // workgroup-uniform
     const bool late = late_wg && fifo;                          // ... and this wave loads taps
     float* xol1 = lds + L::sk;  // second tap buffer (the head's staging area is free in a layer workgroup)
-    const long long n_items = r.n_eval * ns;
+    const long long n_items = r.n_eval * nI;
     constexpr int D = WN_V3_TAP_AHEAD;
-    if (late && n_items > 0) xol[SH::xpad(t)] = wn_q_take_slot<D - 1>(0);  // item 0's tap (D - 1 younger loads of the initial fill)
+    const int xq = tg * L::XR + SH::xpad(tr);  // this lane's element in a [G][XR] staging area
+    if (late && n_items > 0) xol[xq] = wn_q_take_slot<D - 1>(0);  // item 0's tap (D - 1 younger loads of the initial fill)
     // ... and the push of a late layer is done by the waves that load no taps (lanes R..2R-1, when there are that many): the tap
     // waves then issue nothing but tap loads, and an entry always has exactly D - 1 younger operations
-    constexpr bool PUSH_HI = 2 * R <= 256;
-    const bool pusher = late_wg && (PUSH_HI ? (t >= R && t < 2 * R) : t < R);
-    const int prow = PUSH_HI ? t - R : t;
+    constexpr bool PUSH_HI = 2 * G * R <= 256;
+    const bool pusher = late_wg && (PUSH_HI ? (t >= G * R && t < 2 * G * R) : qlane);
+    const int pg = PUSH_HI ? (t - G * R) / R : tg, prow = PUSH_HI ? (t - G * R) % R : tr;  // (stream of the item, element) this lane pushes
     int buf = 0;
     long long item = 0;
     for (long long e = 0; e < r.n_eval; ++e, tmod = (tmod + 1 == ML) ? 0 : tmod + 1) {
-        for (int s = 0; s < ns; ++s, buf ^= 1, ++item) {
+        for (int s = 0; s < ns; s += G, buf ^= 1, ++item) {
             float* xo_cur = (late_wg && (item & 1)) ? xol1 : xol;
             float* xo_nxt = (item & 1) ? xol : xol1;
             if (wn_barrier_failed(cx, failflag)) return;  // ---- A(i): x of this item staged
             const bool stamp = r.prof && item < r.prof_items && tid == 512;
             const long long t0 = stamp ? (long long)wall_clock64() : 0;
             // ---- queue push (wavenet_modules.py:55-57); stage the tap x[t+1-d] (d = 1: it is x[t] itself)
-            if (!late_wg && t < R && !(WN_V3_ABL & 2)) {
-                const float xv = xs[buf * L::XR + SH::xpad(t)];
-                rings_l[((size_t)s * ML + tmod) * R + t] = xv;
+            if (!late_wg && qlane && !(WN_V3_ABL & 2)) {
+                const float xv = xs[buf * (G * L::XR) + xq];
+                rings_l[((size_t)(s + tg) * ML + tmod) * R + tr] = xv;
                 // the tap: d = 1: x[t] itself; a row pushed fewer items ago than the prefetch distance (few streams, small d):
                 // this lane's own copy of it (the queue read ahead of the push would be stale); else the prefetched queue row
                 // (program order here: push, take, [B], load: an entry has D - 1 younger loads and D younger stores)
@@ -665,27 +754,32 @@ static __device__ void wn_v3_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
 #pragma unroll
                     for (int j = 0; j < D; ++j) tap = back == j + 1 ? hx[j] : tap;  // (back is workgroup-uniform)
                 }
-                xo_cur[SH::xpad(t)] = tap;
+                xo_cur[xq] = tap;
 #pragma unroll
                 for (int j = D - 1; j > 0; --j) hx[j] = hx[j - 1];
                 hx[0] = xv;
             }
             // a late layer's tap was staged an item ago: its tap-0 dot runs HERE, next to the critical group's dot (this group has
             // nothing else to do between A and B), and is parked in a register until the critical group has read pre[s] (barrier B)
-            float acc_late = 0.f;
-            if (WN_V3_QDOT_EARLY && late_wg) acc_late = wn_dot_lds<K1>(w0, xo_cur + kq1 * (K1 + 4), bfg0);
+            float acc_late[G], bin[G];
+#pragma unroll
+            for (int g = 0; g < G; ++g) { acc_late[g] = 0.f; bin[g] = bfg0; }
+            constexpr bool QDE = WN_V3_QDOT_EARLY == 1 || (WN_V3_QDOT_EARLY == 2 && G >= 2);
+            if (QDE && late_wg) wn_dot_lds_gp<K1, G>(w0, xo_cur + kq1 * (K1 + 4), L::XR, bin, acc_late);
             if (wn_barrier_failed(cx, failflag)) return;  // ---- B(i): the tap is staged
             const long long t1 = stamp ? (long long)wall_clock64() : 0;
             // ---- tap-0 half of the dilated conv for the NEXT timestep of this stream, parked for the critical group
             if (!(WN_V3_ABL & 2)) {
-                if (pusher) rings_l[((size_t)s * ML + tmod) * R + prow] = xs[buf * L::XR + SH::xpad(prow)];  // the push, off the A -> B window
-                pre[s * 256 + t] = (WN_V3_QDOT_EARLY && late_wg) ? acc_late : wn_dot_lds<K1>(w0, xo_cur + kq1 * (K1 + 4), bfg0);
+                if (pusher) rings_l[((size_t)(s + pg) * ML + tmod) * R + prow] = xs[buf * (G * L::XR) + pg * L::XR + SH::xpad(prow)];  // the push, off the A -> B window
+                if (!(QDE && late_wg)) wn_dot_lds_gp<K1, G>(w0, xo_cur + kq1 * (K1 + 4), L::XR, bin, acc_late);
+#pragma unroll
+                for (int g = 0; g < G; ++g) pre[(s + g) * 256 + t] = acc_late[g];
                 if (fifo) wn_q_issue_slot(slot, next_tap_ptr());  // the tap of item i + D goes into the entry item i has just given up
                 if (late && item + 1 < n_items) {
                     // the NEXT item's tap into the other buffer: D - 1 younger loads; the stores of a wave that also pushes (R > 128:
                     // program order push, load, take) only add to what may stay in flight from item D - 2 on
                     const int ns1 = slot == D - 1 ? 0 : slot + 1;
-                    xo_nxt[SH::xpad(t)] = (PUSH_HI || item < D - 2) ? wn_q_take_slot<D - 1>(ns1) : wn_q_take_slot<2 * D - 2>(ns1);
+                    xo_nxt[xq] = (PUSH_HI || item < D - 2) ? wn_q_take_slot<D - 1>(ns1) : wn_q_take_slot<2 * D - 2>(ns1);
                 }
             }
             slot = slot == D - 1 ? 0 : slot + 1;
@@ -721,13 +815,18 @@ static __device__ __forceinline__ float wn_dot_lds_chunked(const float (&w)[K], 
 
 // Head role (threads 0-255 of the workgroup; same arithmetic, granules and LDS offsets as wn_v2_head_multi with G = 1): relu(skip)
 // -> end_conv_1 slice (+b, relu) -> its K-slice of end_conv_2 -> partial logits   (wavenet_model.py:167-169)
+// p.HR replicas of the PA head workgroups share the streams (replica j serves the streams s = j mod HR): a head workgroup's cycle
+// per stream (compute 0.53 us + the round trip of its publication) is the slowest stage once the layer workgroups process two
+// streams per item -- and the chain leaves 44 of the 256 CUs unused.
 template <class SH, int P>
-static __device__ void wn_v3_head(const WnPlan& p, const WnRun& r, WnCtx& cx, float* lds, int h) {
+static __device__ void wn_v3_head(const WnPlan& p, const WnRun& r, WnCtx& cx, float* lds, int hw) {
     constexpr int S = SH::S, EC = SH::EC, T3 = SH::T3, K3 = SH::K3, QS = S / 256;
     constexpr int CH3 = (K3 / 4) % 2 == 0 ? 2 : 1, CHE = (EC / 4) % 2 == 0 ? 2 : 1;  // (chunks of two float4: the early request set below needs the registers)
     static_assert(K3 % 4 == 0 && EC % 4 == 0, "head slices are read as float4");
     using L = WnV3Lds<SH>;
     const int tid = threadIdx.x, ns = p.n_streams, NL = p.NL;
+    const int HR = p.HR, h = hw % p.PA, rep = hw / p.PA;  // slice of end_conv_1 / end_conv_2, replica
+    const int n_mine = rep < ns ? (ns - rep + HR - 1) / HR : 0;  // streams this replica serves
     float w4[K3], w5[EC];
     const float* img = p.blobs + (size_t)NL * P * (SH::NWL * 256) + (size_t)h * (SH::NWH * 256) + tid;
 #pragma unroll
@@ -745,7 +844,7 @@ static __device__ void wn_v3_head(const WnPlan& p, const WnRun& r, WnCtx& cx, fl
         *failflag = 0;
         const int mine = wn_xcc_id();
         __hip_atomic_store(p.xcc_tab + cx.w, (unsigned)(mine + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        locflags[0] = p.allow_plain ? (int)wn_same_xcd(cx, mine, NL * P + p.PA, p.n_smp) : 0;  // logits feed the samplers
+        locflags[0] = p.allow_plain ? (int)wn_same_xcd(cx, mine, NL * P + p.PA * p.HR, p.n_smp) : 0;  // logits feed the samplers
     }
     wn_lds_barrier();
     const bool local_l = locflags[0] != 0;
@@ -764,12 +863,12 @@ static __device__ void wn_v3_head(const WnPlan& p, const WnRun& r, WnCtx& cx, fl
 #pragma unroll
             for (int j = 0; j < P; ++j) nv[h2][j] = wn_ld_pair(rs_gs, lane_off(j, s2, h2));
     };
-    request(0);
+    if (n_mine > 0) request(rep);
     for (long long e = 0; e < r.n_eval; ++e) {
         const bool prime = e < r.n_given - 1;
         const uint32_t tag = (uint32_t)(e + 1);
-        for (int s = 0; s < ns; ++s) {
-            const long long item = e * ns + s;
+        for (int s = rep; s < ns; s += HR) {
+            const long long item = e * n_mine + (s - rep) / HR;
             wn_stamp(r, park, item, 0);
 #pragma unroll
             for (int h2 = 0; h2 < QS / 2; ++h2) {
@@ -784,7 +883,7 @@ static __device__ void wn_v3_head(const WnPlan& p, const WnRun& r, WnCtx& cx, fl
                 sk[SH::skpad(tid + 512 * h2)] = sum0 > 0.f ? sum0 : 0.f;        // relu(skip), rows tid + 512 h2 and tid + 512 h2 + 256
                 sk[SH::skpad(tid + 512 * h2 + 256)] = sum1 > 0.f ? sum1 : 0.f;
             }
-            request(s + 1 < ns ? s + 1 : 0);
+            request(s + HR < ns ? s + HR : rep);
             if (wn_barrier_failed(cx, failflag)) return;
             wn_stamp(r, park, item, 1);
             wn_u64* gl = p.gl + ((size_t)h * ns + s) * 256;
@@ -858,7 +957,9 @@ static __device__ void wn_v3_sampler(const WnPlan& p, const WnRun& r, WnCtx& cx,
     }
 }
 
-template <int R, int DC, int S, int EC, int P>
+// G = streams per pipeline item of the layer workgroups (hand-offs are per stream: head and sampler workgroups see the same granules
+// different G talk to each other unchanged; the stream count must be a multiple of both)
+template <int R, int DC, int S, int EC, int P, int G = 1>
 __global__ __launch_bounds__(WN_THREADS_V3) void wn_generate_kernel_v3m(WnPlan p, WnRun r) {
     using SH = WnV2Shape<R, DC, S, EC>;
     extern __shared__ __attribute__((aligned(16))) float wn_lds3m[];
@@ -869,12 +970,12 @@ __global__ __launch_bounds__(WN_THREADS_V3) void wn_generate_kernel_v3m(WnPlan p
     cx.t_start = (long long)wall_clock64();
     const int n_layer_wg = p.NL * p.P;
     if (w < n_layer_wg) {
-        wn_v3_layer<SH, P>(p, r, cx, wn_lds3m, w / P, w % P);
+        wn_v3_layer<SH, P, G>(p, r, cx, wn_lds3m, w / P, w % P);
         return;
     }
     if (threadIdx.x >= WN_THREADS) return;  // head and sampler roles are 256-thread roles (wn_kernel_v2.h)
-    if (w < n_layer_wg + p.PA) wn_v3_head<SH, P>(p, r, cx, wn_lds3m, w - n_layer_wg);
-    else wn_v3_sampler<SH>(p, r, cx, wn_lds3m + WnV3Lds<SH>::smp, w - n_layer_wg - p.PA);
+    if (w < n_layer_wg + p.PA * p.HR) wn_v3_head<SH, P>(p, r, cx, wn_lds3m, w - n_layer_wg);
+    else wn_v3_sampler<SH>(p, r, cx, wn_lds3m + WnV3Lds<SH, 1>::smp, w - n_layer_wg - p.PA * p.HR);
 }
 
 #endif  // WN_KERNEL_V3_H

@@ -50,6 +50,7 @@ struct WnPlan {
     int32_t n_streams;
     // chain geometry
     int32_t P, PA, Dc, Ec, n_wg;
+    int32_t HR;  // replicas of the PA head workgroups (wave-specialised kernel: replica j serves the streams s = j mod HR); 1 elsewhere
     WnMatvec fg, res, skip, end1, end2;
     // LDS layout of a layer workgroup (float offsets; blob first)
     int32_t l_bias_fg, l_bias_res, l_bias_skip;  // inside the blob, valid iff has_bias
@@ -139,7 +140,7 @@ static inline void wn_pack_matvec(float* dst, const WnMatvec& m, const std::func
 
 // Fills the geometry part of the plan for a given split; returns LDS bytes needed.
 static inline int64_t wn_plan_geometry(WnPlan& pl, int P, int PA) {
-    pl.P = P; pl.PA = PA;
+    pl.P = P; pl.PA = PA; pl.HR = 1;
     pl.Dc = wn_cdiv(pl.D, P);
     pl.Ec = wn_cdiv(pl.E, PA);
     pl.n_wg = pl.NL * P + PA;

@@ -21,6 +21,7 @@ static thread_local char g_err[512] = "";
 static thread_local int g_chain_member = 0;  // wn_create is building one chain of a two-chain handle
 #define WN_LDS_SHARED_MAX_BYTES (81920 - 1024)  // two workgroups per CU: half of the 160 KB LDS each, minus the static allocation
 #define WN_CHAIN_MIN_STREAMS 16   // below: the chain is latency-bound, splitting does not pay (measured: 16 neutral, 32 +9 %, 64 +44 %)
+#define WN_V3_ROUND_STREAMS 128  // streams per round of the wave-specialised chain when a job exceeds what one chain holds (wn_handle::rounds)
 #define WN_CHAIN_MAX_STREAMS 40   // streams per chain that still fit two workgroups per CU at cfg3's shape (78 KB LDS)
 
 static int wn_fail(int code, const char* fmt, ...) {
@@ -99,9 +100,10 @@ struct WnV2Entry {
     void (*launch_multi)(int w0lds, int grid, size_t lds, hipStream_t st, const WnPlan& p, const WnRun& r);
     void (*pack)(const WnPlan& pl, const WnHostWeights& w, std::vector<float>& out);
     // wave-specialised multi-stream kernel (wn_kernel_v3.h): 512-thread layer workgroups, one chain for all streams
-    const void* fn_v3;
-    int (*lds_floats_v3)(int ns);
-    void (*launch_v3)(int grid, size_t lds, hipStream_t st, const WnPlan& p, const WnRun& r);
+    // [g2]: 0 = one stream per pipeline item of a layer workgroup, 1 = two (wn_v3_mode)
+    const void* fn_v3[2];
+    int (*lds_floats_v3)(int ns, int g2);
+    void (*launch_v3)(int g2, int grid, size_t lds, hipStream_t st, const WnPlan& p, const WnRun& r);
 };
 
 template <class SH>
@@ -178,15 +180,18 @@ static WnV2Entry wn_v2_entry() {
         hipLaunchKernelGGL((wn_generate_kernel_v2<R, DC, S, EC>), dim3(grid), dim3(WN_THREADS), lds, st, p, r);
     };
     e.pack = wn_pack_v2<SH>;
-    e.fn_v3 = nullptr; e.lds_floats_v3 = nullptr; e.launch_v3 = nullptr;
+    e.fn_v3[0] = e.fn_v3[1] = nullptr; e.lds_floats_v3 = nullptr; e.launch_v3 = nullptr;
     if constexpr (wn_v3_fits<SH>()) {
-        e.fn_v3 = (const void*)wn_generate_kernel_v3m<R, DC, S, EC, PM>;
-        e.lds_floats_v3 = [](int ns) {
-            const int lay = WnV3Lds<SH>::floats(ns), head = WnV2LdsM<SH, 1, false>::pre;
+        e.fn_v3[0] = (const void*)wn_generate_kernel_v3m<R, DC, S, EC, PM, 1>;
+        e.fn_v3[1] = (const void*)wn_generate_kernel_v3m<R, DC, S, EC, PM, 2>;
+        e.lds_floats_v3 = [](int ns, int g2) {
+            const int lay = g2 ? WnV3Lds<SH, 2>::floats(ns) : WnV3Lds<SH, 1>::floats(ns);
+            const int head = WnV3Lds<SH, 1>::pre;
             return lay > head ? lay : head;
         };
-        e.launch_v3 = [](int grid, size_t lds, hipStream_t st, const WnPlan& p, const WnRun& r) {
-            hipLaunchKernelGGL((wn_generate_kernel_v3m<R, DC, S, EC, PM>), dim3(grid), dim3(WN_THREADS_V3), lds, st, p, r);
+        e.launch_v3 = [](int g2, int grid, size_t lds, hipStream_t st, const WnPlan& p, const WnRun& r) {
+            if (g2) hipLaunchKernelGGL((wn_generate_kernel_v3m<R, DC, S, EC, PM, 2>), dim3(grid), dim3(WN_THREADS_V3), lds, st, p, r);
+            else hipLaunchKernelGGL((wn_generate_kernel_v3m<R, DC, S, EC, PM, 1>), dim3(grid), dim3(WN_THREADS_V3), lds, st, p, r);
         };
     }
     return e;
@@ -232,6 +237,23 @@ static int wn_sampler_count(int n_streams) {
     return n_streams < n ? n_streams : n;
 }
 
+// Throughput form of the wave-specialised kernel (bit 0: two streams per pipeline item of a layer workgroup; bit 1: two replicas
+// of the head workgroups, each serving every other stream).  One stream per item is the latency-optimal form; with more streams
+// than the chain can turn around in one trip the stages' fixed costs per item -- the request round trip, two workgroup barriers,
+// the LDS and DPP latencies of the dot products -- bound the throughput, and two streams per item share them (every weight
+// operand is used twice) at the price of a longer trip through each stage.  WN_V3_MODE = 0..3 pins a form (A/B runs, tests).
+#ifndef WN_V3_G2_MIN_STREAMS
+#define WN_V3_G2_MIN_STREAMS 64
+#endif
+static int wn_v3_mode(int n_streams) {
+    const char* e = getenv("WN_V3_MODE");
+    int mode = (n_streams >= WN_V3_G2_MIN_STREAMS) ? 3 : 0;
+    if (e && e[0] >= '0' && e[0] <= '3' && !e[1]) mode = e[0] - '0';
+    if (n_streams % 2) mode &= ~1;
+    if (n_streams < 2) mode = 0;
+    return mode;
+}
+
 // true iff the wave-specialised kernel (variant 3) serves this configuration with ONE chain: an instantiated shape, at least
 // two streams, the parked tap-0 sums of all streams fit the LDS next to the activations, one CU per workgroup
 static bool wn_v3_applicable(const wn_config* cfg, int n_cu, int* out_vi, int* outP, int* outPA) {
@@ -246,8 +268,8 @@ static bool wn_v3_applicable(const wn_config* cfg, int n_cu, int* out_vi, int* o
     const int n_smp = wn_sampler_count(cfg->n_streams);
     int P = 0, PA = 0;
     const int vi = wn_v2_choose(pl, n_cu, n_smp, cfg->layer_split, cfg->head_split, &P, &PA);
-    if (vi < 0 || !wn_v2_table()[vi].fn_v3) return false;
-    if (wn_v2_table()[vi].lds_floats_v3(cfg->n_streams) * 4 > WN_LDS_MAX_BYTES) return false;
+    if (vi < 0 || !wn_v2_table()[vi].fn_v3[0]) return false;
+    if (wn_v2_table()[vi].lds_floats_v3(cfg->n_streams, wn_v3_mode(cfg->n_streams) & 1) * 4 > WN_LDS_MAX_BYTES) return false;
     if (out_vi) *out_vi = vi;
     if (outP) *outP = P;
     if (outPA) *outPA = PA;
@@ -276,6 +298,7 @@ struct wn_handle {
     int variant;   // 1 = generic LDS-resident kernel, 2 = register-resident kernel
     int v2_index;  // row of wn_v2_table()
     int lds_bytes;
+    int v3_mode;   // variant 3: streams per pipeline item (wn_v3_mode)
     int w0lds;     // multi-stream kernel variant with tap-0 weights in LDS (this handle is one of two chains sharing the chip)
     // Two chains: with >= WN_CHAIN_MIN_STREAMS streams the job is split into two independent chains of n_streams/2 streams,
     // each a complete persistent kernel with its own queues and hand-off buffers, launched on two HIP streams.  Their
@@ -283,6 +306,10 @@ struct wn_handle {
     // cfg3 x 64 streams 556 k -> 788 k samples/s.  This handle is then only a front that routes every call.
     std::vector<wn_handle*> chains;
     std::vector<int> chain_first;  // first stream of chain i (chain_first[n_chains] = n_streams)
+    // Rounds: more streams than ONE wave-specialised chain holds (its LDS parks a tap-0 sum per stream: cfg3 ~150 streams) are
+    // served in rounds of up to WN_V3_ROUND_STREAMS streams, one round after the other on the caller's stream -- the member handles
+    // are those of `chains`, only they do not run concurrently.
+    bool rounds;
     void* side_stream;  // hipStream_t of the second chain
     void* ev_fork;      // hipEvent_t: user stream -> side stream
     void* ev_join;      // hipEvent_t: side stream -> user stream
@@ -360,6 +387,62 @@ extern "C" int wn_create(const wn_config* cfg, wn_handle** out) {
         int khz = 0;
         if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, cfg->device_id) == hipSuccess && khz > 0) wall_khz = khz;
     }
+    {   // rounds of the wave-specialised chain (see wn_handle::rounds)
+        const char* ce = getenv("WN_CHAINS");
+        const bool off = ce && ce[0] == '1';
+        wn_config probe = *cfg;
+        probe.n_streams = WN_V3_ROUND_STREAMS;
+        if (!g_chain_member && !off && cfg->n_streams > WN_V3_ROUND_STREAMS && !wn_v3_applicable(cfg, n_cu, nullptr, nullptr, nullptr) &&
+            wn_v3_applicable(&probe, n_cu, nullptr, nullptr, nullptr)) {
+            const int ns = cfg->n_streams;
+            const int K = (ns + WN_V3_ROUND_STREAMS - 1) / WN_V3_ROUND_STREAMS;
+            std::vector<wn_handle*> cs;
+            std::vector<int> firsts(1, 0);
+            int rc = WN_OK;
+            int left = ns;
+            for (int i = 0; i < K && rc == WN_OK; ++i) {
+                wn_config part = *cfg;
+                int n = (left + (K - i) - 1) / (K - i);  // even rounds (two streams per pipeline item) as long as streams are left
+                if (n % 2 && n < left) ++n;
+                part.n_streams = n;
+                left -= n;
+                wn_handle* c = nullptr;
+                rc = wn_create(&part, &c);
+                if (rc == WN_OK) {
+                    cs.push_back(c);
+                    firsts.push_back(firsts.back() + n);
+                    if (c->variant != 3) rc = WN_E_UNSUPPORTED;
+                }
+            }
+            if (rc == WN_OK) {
+                wn_handle* c0 = cs[0];
+                wn_handle* f = new wn_handle();
+                f->cfg = *cfg;
+                f->plan = c0->plan;
+                f->plan.n_streams = cfg->n_streams;
+                f->have_weights = false; f->pending = false; f->last_stream = nullptr; f->t_base = 0;
+                f->n_cu = n_cu; f->wall_khz = wall_khz; f->variant = c0->variant; f->v2_index = c0->v2_index; f->lds_bytes = c0->lds_bytes; f->w0lds = 0;
+                f->v3_mode = c0->v3_mode;
+                f->d_blobs = f->d_start_t = f->d_start_b = f->d_rings = nullptr;
+                f->d_dil = f->d_wg_map = nullptr; f->d_ring_off = nullptr; f->d_gran = nullptr; f->d_status = nullptr;
+                f->d_prof = nullptr; f->prof_items = 0; f->prof_recorded = 0;
+                f->d_fw = nullptr; f->fw_floats = 0; f->fw_ok = false; f->d_ws = nullptr; f->ws_floats = 0;
+                f->d_fwb = nullptr; f->fwb_elems = 0; f->fwb_ok = false; f->fw_bf16 = 0;
+                f->d_tws = nullptr; f->tws_floats = 0; f->train_valid = false;
+                f->blob_floats = f->ring_floats = f->gran_count = 0;
+                f->dil = c0->dil;
+                f->chains = cs;
+                f->chain_first = firsts;
+                f->rounds = true;
+                f->side_stream = f->ev_fork = f->ev_join = nullptr;
+                *out = f;
+                return WN_OK;
+            }
+            for (wn_handle* c : cs) wn_destroy(c);
+            if (rc != WN_E_UNSUPPORTED) return rc;
+            g_err[0] = 0;
+        }
+    }
     {   // chains sharing the CUs two by two (see wn_handle::chains): 2 chains up to WN_CHAIN_MAX_STREAMS streams each, more
         // chains (run pairwise, one pair after the other on the two HIP streams) for larger jobs
         const char* ce = getenv("WN_CHAINS");
@@ -403,6 +486,7 @@ extern "C" int wn_create(const wn_config* cfg, wn_handle** out) {
                 f->dil = c0->dil;
                 f->chains = cs;
                 f->chain_first = firsts;
+                f->rounds = false;
                 f->side_stream = f->ev_fork = f->ev_join = nullptr;
                 hipStream_t ss; hipEvent_t e0, e1;
                 rc = rt_hip(hipStreamCreateWithFlags(&ss, hipStreamNonBlocking), "hipStreamCreate");
@@ -421,7 +505,7 @@ extern "C" int wn_create(const wn_config* cfg, wn_handle** out) {
     wn_handle* h = new wn_handle();
     memset(&h->plan, 0, sizeof(h->plan));
     h->cfg = *cfg;
-    h->side_stream = h->ev_fork = h->ev_join = nullptr; h->w0lds = 0;
+    h->side_stream = h->ev_fork = h->ev_join = nullptr; h->w0lds = 0; h->v3_mode = 0; h->rounds = false;
     h->have_weights = false; h->pending = false; h->last_stream = nullptr; h->t_base = 0;
     h->n_cu = n_cu; h->wall_khz = wall_khz;
     h->d_blobs = h->d_start_t = h->d_start_b = h->d_rings = nullptr;
@@ -434,6 +518,7 @@ extern "C" int wn_create(const wn_config* cfg, wn_handle** out) {
     pl.layers = cfg->layers; pl.blocks = cfg->blocks; pl.NL = cfg->layers * cfg->blocks;
     pl.R = cfg->residual_channels; pl.D = cfg->dilation_channels; pl.S = cfg->skip_channels; pl.E = cfg->end_channels;
     pl.C = cfg->classes; pl.k = cfg->kernel_size; pl.has_bias = cfg->bias ? 1 : 0; pl.n_streams = cfg->n_streams;
+    pl.HR = 1;
     h->variant = 1; h->v2_index = -1;
     {
         const char* force = getenv("WN_KERNEL");  // "generic" pins the LDS-resident kernel, "v2" the 256-thread register kernels (A/B runs, tests)
@@ -447,7 +532,14 @@ extern "C" int wn_create(const wn_config* cfg, wn_handle** out) {
             pl.n_wg += pl.n_smp;
             pl.start_in_lds = 0;
             h->w0lds = 0;
-            h->lds_bytes = wn_v2_table()[vi3].lds_floats_v3(pl.n_streams) * 4;
+            h->v3_mode = wn_v3_mode(pl.n_streams);
+            if ((h->v3_mode & 2) && pl.NL * P2 + 2 * PA2 + pl.n_smp <= n_cu) {  // a second set of head workgroups
+                pl.HR = 2;
+                pl.n_wg += PA2;
+            } else {
+                h->v3_mode &= 1;
+            }
+            h->lds_bytes = wn_v2_table()[vi3].lds_floats_v3(pl.n_streams, h->v3_mode & 1) * 4;
         }
         const int vi = (h->variant == 3 || (force && !strcmp(force, "generic"))) ? -1 : wn_v2_choose(pl, n_cu, n_smp, cfg->layer_split, cfg->head_split, &P2, &PA2);
         if (vi >= 0) {
@@ -492,7 +584,7 @@ extern "C" int wn_create(const wn_config* cfg, wn_handle** out) {
     std::vector<int32_t> wg_map;
     pl.n_blocks = pl.n_wg;
     pl.allow_plain = 0;
-    if (h->variant >= 2 && n_cu % 8 == 0 && wn_make_wg_map_layers(pl.NL, pl.P, pl.PA, pl.n_smp, 8, n_cu / 8, wg_map, &pl.n_blocks)) {
+    if (h->variant >= 2 && n_cu % 8 == 0 && wn_make_wg_map_layers(pl.NL, pl.P, pl.PA * pl.HR, pl.n_smp, 8, n_cu / 8, wg_map, &pl.n_blocks)) {
         const char* np = getenv("WN_NO_LOCAL_STORES");
         pl.allow_plain = (np && np[0] == '1') ? 0 : 1;
     } else {
@@ -536,7 +628,7 @@ extern "C" int wn_create(const wn_config* cfg, wn_handle** out) {
     pl.g0 = pl.gi + pl.n_streams;
     pl.status = h->d_status;
     pl.xcc_tab = h->d_status + 8;
-    rc = rt_hip(hipFuncSetAttribute(h->variant == 3 ? wn_v2_table()[h->v2_index].fn_v3 : h->variant == 2 ? (pl.n_smp > 0 ? (h->w0lds ? wn_v2_table()[h->v2_index].fn_multi_w0 : wn_v2_table()[h->v2_index].fn_multi) : wn_v2_table()[h->v2_index].fn)
+    rc = rt_hip(hipFuncSetAttribute(h->variant == 3 ? wn_v2_table()[h->v2_index].fn_v3[h->v3_mode & 1] : h->variant == 2 ? (pl.n_smp > 0 ? (h->w0lds ? wn_v2_table()[h->v2_index].fn_multi_w0 : wn_v2_table()[h->v2_index].fn_multi) : wn_v2_table()[h->v2_index].fn)
                                                     : (const void*)wn_generate_kernel,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes),
                 "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
@@ -703,9 +795,12 @@ extern "C" int wn_generate(wn_handle* h, const wn_generate_args* a) {
         { int rc = rt_hip(hipSetDevice(h->cfg.device_id), "hipSetDevice"); if (rc) return rc; }
         if (h->pending) { int rc = wn_wait(h); if (rc) return rc; }
         if (h->broken) return wn_fail(WN_E_STATE, "wn_generate: an earlier job failed half way through its chains; call wn_reset");
-        hipStream_t user = (hipStream_t)a->hip_stream, side = (hipStream_t)h->side_stream;
-        int rc = rt_hip(hipEventRecord((hipEvent_t)h->ev_fork, user), "hipEventRecord");
-        rc = rc ? rc : rt_hip(hipStreamWaitEvent(side, (hipEvent_t)h->ev_fork, 0), "hipStreamWaitEvent");
+        hipStream_t user = (hipStream_t)a->hip_stream, side = h->rounds ? user : (hipStream_t)h->side_stream;
+        int rc = WN_OK;
+        if (!h->rounds) {
+            rc = rt_hip(hipEventRecord((hipEvent_t)h->ev_fork, user), "hipEventRecord");
+            rc = rc ? rc : rt_hip(hipStreamWaitEvent(side, (hipEvent_t)h->ev_fork, 0), "hipStreamWaitEvent");
+        }
         if (rc) return rc;
         for (size_t i = 0; i < h->chains.size(); ++i) {  // even chains on the caller's stream, odd ones on the side stream
             wn_generate_args b = *a;
@@ -722,8 +817,10 @@ extern "C" int wn_generate(wn_handle* h, const wn_generate_args* a) {
                 if (i > 0) {  // chains 0..i-1 are running: drain them, then refuse further jobs until the queues are reset
                     char msg[sizeof(g_err)];
                     memcpy(msg, g_err, sizeof(msg));
-                    (void)hipEventRecord((hipEvent_t)h->ev_join, side);
-                    (void)hipStreamWaitEvent(user, (hipEvent_t)h->ev_join, 0);
+                    if (!h->rounds) {
+                        (void)hipEventRecord((hipEvent_t)h->ev_join, side);
+                        (void)hipStreamWaitEvent(user, (hipEvent_t)h->ev_join, 0);
+                    }
                     h->pending = true; h->last_stream = a->hip_stream;
                     (void)wn_wait(h);
                     h->broken = true;
@@ -732,8 +829,10 @@ extern "C" int wn_generate(wn_handle* h, const wn_generate_args* a) {
                 return rc;
             }
         }
-        rc = rt_hip(hipEventRecord((hipEvent_t)h->ev_join, side), "hipEventRecord");
-        rc = rc ? rc : rt_hip(hipStreamWaitEvent(user, (hipEvent_t)h->ev_join, 0), "hipStreamWaitEvent");
+        if (!h->rounds) {
+            rc = rt_hip(hipEventRecord((hipEvent_t)h->ev_join, side), "hipEventRecord");
+            rc = rc ? rc : rt_hip(hipStreamWaitEvent(user, (hipEvent_t)h->ev_join, 0), "hipStreamWaitEvent");
+        }
         if (rc) return rc;
         h->pending = true;
         h->last_stream = a->hip_stream;
@@ -773,7 +872,7 @@ extern "C" int wn_generate(wn_handle* h, const wn_generate_args* a) {
     rc = rc ? rc : rt_memset_async(h->d_status, 0, (size_t)(8 + h->plan.n_wg) * 4, a->hip_stream);
     if (rc) return rc;
     if (h->variant == 3)
-        wn_v2_table()[h->v2_index].launch_v3(h->plan.n_blocks, (size_t)h->lds_bytes, (hipStream_t)a->hip_stream, h->plan, r);
+        wn_v2_table()[h->v2_index].launch_v3(h->v3_mode & 1, h->plan.n_blocks, (size_t)h->lds_bytes, (hipStream_t)a->hip_stream, h->plan, r);
     else if (h->variant == 2 && h->plan.n_smp > 0)
         wn_v2_table()[h->v2_index].launch_multi(h->w0lds, h->plan.n_blocks, (size_t)h->lds_bytes, (hipStream_t)a->hip_stream, h->plan, r);
     else if (h->variant == 2)

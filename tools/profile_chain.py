@@ -27,19 +27,22 @@ def main():
     info = eng.info()
     P, PA, NL = info["layer_split"], info["head_split"], info["n_layers"]
     N = 400 if ns == 1 else 60
-    G = 1
+    mode = int(os.environ.get("WN_V3_MODE", "3" if ns >= 64 else "0")) if (info["kernel_variant"] == 3 and ns >= 2) else 0
+    G = 2 if (mode & 1 and ns % 2 == 0) else 1   # streams per pipeline item of the layer workgroups
+    HG = 2 if mode & 2 else 1                     # replicas of the head workgroups (each serves every HG-th stream)
     n_total = ns
     nc = max(1, info.get("n_chains", 1))
     ns = ns // nc          # the stamps are those of the first chain: its streams
     info["n_workgroups"] //= nc
     if nc > 1:
         print("%d chains of %d streams share the CUs; stamps of chain 0" % (nc, ns))
-    items = N * ns // G  # pipeline items: G streams each in the multi-stream kernel
+    items = N * ns // G  # pipeline items of a layer workgroup: G streams each
+    items_h = N * ns // HG
     u = np.random.RandomState(0).random_sample((n_total, N))
     eng.generate(N, None, temperature=1.0, uniforms=u)  # warm-up
-    eng.profile_next(items)
+    eng.profile_next(N * ns)
     eng.generate(N, None, temperature=1.0, uniforms=u)
-    raw = eng.profile_read(items)
+    raw = eng.profile_read(N * ns)
     if ns > 1:
         tt = raw[P:NL * P, items // 4:items - ns // G].astype(np.float64) * 0.01
         print("multi (critical waves): input in registers %.3f us after start, barrier A passed %.3f us, z staged (barrier B) %.3f us, x' published %.3f us" % (
@@ -63,6 +66,7 @@ def main():
     T = st[:, lo:hi, :]
     lay = T[:NL * P].reshape(NL, P, hi - lo, 8)
     head = T[NL * P:]
+    Th = st[NL * P:NL * P + PA * HG, items_h // 4:items_h - ns // HG, :]  # the head workgroups' items
     period = np.diff(st[0, lo:hi:ns, 1]).mean() if ns == 1 else np.diff(st[0, lo:hi, 1][::ns // G]).mean()
     print("%s x%d: variant %d P=%d PA=%d workgroups %d; loop period %.2f us/eval (%.0f evals/s per stream, %.0f samples/s total)" % (
         cfgname, ns, info["kernel_variant"], P, PA, info["n_workgroups"], period, 1e6 / period, ns * 1e6 / period))
@@ -74,10 +78,12 @@ def main():
         print("G=%d streams per item; per-item period %.3f us (%.3f us per stream-step).  stage: busy (staged->done) / wait (start->staged), us" % (G, per[:nlw].mean(), per[:nlw].mean() / G))
         for l in list(range(0, NL, max(1, NL // 10))) + [NL - 1]:
             print("  layer %2d: busy %s  wait %s" % (l, np.array2string(busy[l * P:(l + 1) * P], precision=2), np.array2string(wait[l * P:(l + 1) * P], precision=2)))
-        print("  head    : busy %s  wait %s" % (np.array2string(busy[nlw:nlw + PA], precision=2), np.array2string(wait[nlw:nlw + PA], precision=2)))
-        n_smp = info["n_workgroups"] - nlw - PA
+        print("  head (%d replica(s)): busy %s  wait %s; staged->published %.3f" % (
+            HG, np.array2string((Th[:, :, 3] - Th[:, :, 1]).mean(axis=1), precision=2), np.array2string((Th[:, :, 1] - Th[:, :, 0]).mean(axis=1), precision=2),
+            (Th[:, :, 2] - Th[:, :, 1]).mean()))
+        n_smp = info["n_workgroups"] - nlw - PA * HG
         for j in range(n_smp):
-            rows = st[nlw + PA + j, lo:hi]
+            rows = st[nlw + PA * HG + j, N * ns // 4:N * ns - ns]
             rows = rows[rows[:, 0] > 0]
             if len(rows) > 2:
                 print("  sampler %d: waits %.2f us for the logits, samples + publishes in %.2f us; one token every %.2f us" % (
