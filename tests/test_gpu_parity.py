@@ -397,6 +397,58 @@ def test_wave_specialised_kernel(label, cfg, ns, N, n_given):
     eng.close()
 
 
+FORMS = [("mini3_ns4", MINI3, 4, 160, 9), ("mini3_ns12", MINI3, 12, 120, 30), ("mini3_bias_ns10", dict(MINI3, bias=True), 10, 120, 4),
+         ("mini3_ns7_odd", MINI3, 7, 100, 12), ("cfg3_ns6", "cfg3", 6, 60, 700), ("mini3_ns64", MINI3, 64, 100, 3)]
+
+
+@pytest.mark.parametrize("mode", [1, 2, 3])
+@pytest.mark.parametrize("label,cfg,ns,N,n_given", FORMS, ids=[c[0] for c in FORMS])
+def test_wave_specialised_kernel_throughput_forms(label, cfg, ns, N, n_given, mode, monkeypatch):
+    """The throughput forms of variant 3 (WN_V3_MODE bit 0: two streams per pipeline item of a layer workgroup, bit 1: two replicas
+    of the head workgroups; the default from 64 streams up) pinned at small stream counts: d = 1, `near` and `late` queue layers,
+    priming through the chain, an odd stream count (bit 0 must fall back to one stream per item), bias; against the oracle on
+    streams of both parities."""
+    monkeypatch.setenv("WN_V3_MODE", str(mode))
+    cfg, W, first, uniforms = make_case(cfg, 83 + mode, ns, n_given, N)
+    eng = engine.Engine(cfg, W, n_streams=ns)
+    info = eng.info()
+    assert info["kernel_variant"] == 3 and info["n_chains"] == 1
+    P, PA, NL = info["layer_split"], info["head_split"], info["n_layers"]
+    assert info["n_workgroups"] == NL * P + PA * (2 if mode & 2 else 1) + min(4, ns)
+    gidx = eng.generate(N, first, temperature=0.0, batched_prime=False, timeout_ms=8000)
+    out, logits = eng.generate(N, first, temperature=0.9, regularize=0.002, uniforms=uniforms, want_logits=True, timeout_ms=8000)
+    eng.close()
+    for s in sorted(set((0, 1, ns // 2, ns - 1))):
+        o_idx, o_log = c_oracle.generate(cfg, W, N, first[s], 0.9, 0.002, uniforms[s])
+        tol = 1e-5 * max(1.0, float(np.abs(o_log).max()))
+        assert np.array_equal(out[s], o_idx), (label, mode, s, int(np.argmax(out[s] != o_idx)))
+        assert float(np.abs(logits[s] - o_log).max()) <= tol, (label, mode, s)
+        g_idx, g_log = c_oracle.generate(cfg, W, N, first[s], 0.0, 0.0)
+        if not np.array_equal(gidx[s], g_idx):  # an argmax flip is legitimate rounding only where the top-2 gap is degenerate
+            t = int(np.argmax(gidx[s] != g_idx))
+            row = np.sort(g_log[t])
+            assert row[-1] - row[-2] <= 10 * tol, (label, mode, s, t)
+
+
+@pytest.mark.parametrize("ns", [170, 256])
+def test_wave_specialised_kernel_rounds(ns):
+    """More streams than one wave-specialised chain holds (its LDS parks one tap-0 sum per stream and lane: 151 streams at this
+    channel shape) run in rounds of up to 128 streams, one after the other on the caller's stream (170 -> 86 + 84, 256 -> 128 + 128)."""
+    N, n_given = 90, 5
+    cfg, W, first, uniforms = make_case(MINI3, 87, ns, n_given, N)
+    eng = engine.Engine(cfg, W, n_streams=ns)
+    info = eng.info()
+    assert info["kernel_variant"] == 3 and info["n_chains"] == 2
+    out = eng.generate(N, first, temperature=1.0, uniforms=uniforms, timeout_ms=8000)
+    a = eng.generate(40, first, temperature=1.0, uniforms=uniforms[:, :40], timeout_ms=8000)
+    b = eng.generate(N - 40, a[:, -1:], temperature=1.0, uniforms=uniforms[:, 40:], reset=False, timeout_ms=8000)
+    eng.close()
+    assert np.array_equal(np.concatenate([a, b], axis=1), out)
+    for s in (0, 83, 84, 85, 86, 127, 128, ns - 1):  # both sides of either round boundary
+        o_idx, _ = c_oracle.generate(cfg, W, N, first[s], 1.0, 0.0, uniforms[s])
+        assert np.array_equal(out[s], o_idx), s
+
+
 def test_wave_specialised_kernel_host_calls():
     """The calls the facade makes around a job on variant 3: prime-only, continuation without reset, one generated sample,
     per-stream temperatures, queue export, and equality with the 256-thread kernels on the same job."""
