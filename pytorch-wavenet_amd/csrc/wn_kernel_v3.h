@@ -68,6 +68,11 @@
 #ifndef WN_V3_ABL
 #define WN_V3_ABL 0  // timing ablations (results are WRONG when != 0): 1 the skip group only passes its barriers, 2 the queue group, 3 both
 #endif
+#ifndef WN_V3_PAIR_ROWS
+#define WN_V3_PAIR_ROWS 2  // a critical lane computes the filter AND the gate row of one channel on a half-width slice of x (see wn_v3_layer):
+                           // 0 never, 1 always, 2 in the two-streams-per-item form only (64 streams: 961 -> 974 k samples/s, 128: 1.464 -> 1.478 M;
+                           // one stream: 18.87 -> 18.74 k -- the longer lane reduction is on the single token's path; profiles/r02_v3_forms_final.txt)
+#endif
 #ifndef WN_V3_PRIO
 #define WN_V3_PRIO 1  // 1: critical waves at a higher static wave priority (the queue and skip waves share their SIMDs: x64 911 -> 919 k, profiles/r02_v3_tap_fifo.txt)
 #endif
@@ -356,16 +361,18 @@ static __device__ __forceinline__ void wn_dot_lds_gp(const float (&w)[K], const 
         for (int g = 0; g < G; ++g)
 #pragma unroll
             for (int k = 0; k < K / 4; ++k) v[g][k] = reinterpret_cast<const float4*>(x + g * xstride)[k];
+        wn_f2 a01[G], a23[G];
 #pragma unroll
-        for (int g = 0; g < G; ++g) {
-            wn_f2 a01 = {init[g], 0.f}, a23 = {0.f, 0.f};
+        for (int g = 0; g < G; ++g) { a01[g] = wn_f2{init[g], 0.f}; a23[g] = wn_f2{0.f, 0.f}; }
 #pragma unroll
-            for (int k = 0; k < K / 4; ++k) {
-                a01 = __builtin_elementwise_fma(wn_f2{w[4 * k], w[4 * k + 1]}, wn_f2{v[g][k].x, v[g][k].y}, a01);
-                a23 = __builtin_elementwise_fma(wn_f2{w[4 * k + 2], w[4 * k + 3]}, wn_f2{v[g][k].z, v[g][k].w}, a23);
+        for (int k = 0; k < K / 4; ++k)
+#pragma unroll
+            for (int g = 0; g < G; ++g) {  // (the streams' chains interleaved in program order)
+                a01[g] = __builtin_elementwise_fma(wn_f2{w[4 * k], w[4 * k + 1]}, wn_f2{v[g][k].x, v[g][k].y}, a01[g]);
+                a23[g] = __builtin_elementwise_fma(wn_f2{w[4 * k + 2], w[4 * k + 3]}, wn_f2{v[g][k].z, v[g][k].w}, a23[g]);
             }
-            out[g] = (a01.x + a01.y) + (a23.x + a23.y);
-        }
+#pragma unroll
+        for (int g = 0; g < G; ++g) out[g] = (a01[g].x + a01[g].y) + (a23[g].x + a23[g].y);
     } else {
 #pragma unroll
         for (int g = 0; g < G; ++g) out[g] = wn_dot_lds<K>(w, x + g * xstride, init[g]);
@@ -420,9 +427,27 @@ static __device__ void wn_v3_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
 #if WN_V3_PRIO
         __builtin_amdgcn_s_setprio(3);
 #endif
-        float w1[K1], w2[K2];
+        // Filter/gate lanes.  The register images give lane (row, kq1) the K1 tap-1 weights of ONE filter or gate row on x slice kq1;
+        // the 2 DC / T1-lane groups of a wave then read the same x slices from LDS, 8 x 16 bytes per lane and stream -- and the LDS
+        // pipe (128 bytes a clock for the whole CU), not the FMA issue, is what the filter/gate window waits for.  A critical lane
+        // therefore takes BOTH rows of a channel on HALF a slice: lane (ch8, kq8), 2 T1 lanes per channel, K1 / 2 x values per lane
+        // (half the LDS reads per row pair), each feeding one packed FMA {filter, gate}; its weights are those of the images' lanes
+        // (2 ch8, kq8 / 2) and (2 ch8 + 1, kq8 / 2), rows (kq8 & 1) K1/2 ..., gathered here once.
+        constexpr int T8 = 2 * T1, K8 = K1 / 2;
+        constexpr bool PAIR = WN_V3_PAIR_ROWS == 1 || (WN_V3_PAIR_ROWS == 2 && G >= 2);
+        static_assert(!PAIR || (K1 % 8 == 0 && T8 <= 16), "half slices are read as float4");
+        const int ch8 = t / T8, kq8 = t % T8, half8 = kq8 & 1;
+        const int t_f = (2 * ch8) * T1 + kq8 / 2;  // the image lane of the channel's filter row (gate row: + T1)
+        float w1[PAIR ? 1 : K1], w2[K2];
+        wn_f2 wfg[PAIR ? K8 : 1];
+        if constexpr (PAIR) {
+            const float* imw = p.blobs + (size_t)cx.w * (SH::NWL * 256);
 #pragma unroll
-        for (int k = 0; k < K1; ++k) w1[k] = img[(size_t)k * 256];
+            for (int k = 0; k < K8; ++k) wfg[k] = wn_f2{imw[(size_t)(half8 * K8 + k) * 256 + t_f], imw[(size_t)(half8 * K8 + k) * 256 + t_f + T1]};
+        } else {
+#pragma unroll
+            for (int k = 0; k < K1; ++k) w1[k] = img[(size_t)k * 256];
+        }
 #pragma unroll
         for (int k = 0; k < K2; ++k) w2[k] = img[(size_t)(2 * K1 + k) * 256];
         const float bres = img[(size_t)(2 * K1 + K2 + RS * DC + 1) * 256];
@@ -488,24 +513,70 @@ static __device__ void wn_v3_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
                 if (poller) request(s + G < ns ? s + G : 0);
 #endif
                 // ---- 2. filter/gate: tap 1 on x[t] + parked tap 0, tanh * sigmoid   (wavenet_model.py:147-151)
-                float xres[G], pin[G], acc[G];
+                // (the G streams' chains are kept in ONE basic block -- unconditional LDS reads, selects instead of lane-predicated
+                //  branches, the z stores after both chains -- so that the scheduler can interleave them: a predicated store between
+                //  them made the second stream's whole chain wait for the first one's)
+                float xres[G];
 #pragma unroll
                 for (int g = 0; g < G; ++g) {
-                    xres[g] = (c == 0 && kq2 == 0) ? xb[g * L::XR + SH::xpad(row2)] : 0.f;
-                    pin[g] = pre[(s + g) * 256 + t];
+                    const float xv = xb[g * L::XR + SH::xpad(row2)];
+                    xres[g] = (c == 0 && kq2 == 0) ? xv : 0.f;
                 }
-                wn_dot_lds_gp<K1, G>(w1, xb + kq1 * (K1 + 4), L::XR, pin, acc);
+                if constexpr (PAIR) {
+                    // the parked tap-0 sums are per image lane (row, kq1): the lane with the first half of slice kq1 takes both rows' sums
+                    wn_f2 a0[G], a1[G];
 #pragma unroll
-                for (int g = 0; g < G; ++g) acc[g] = wn_reduce<T1>(acc[g]);
-                // tanh(f) * sigmoid(g) as in wn_gate, but each lane evaluates only ITS factor (filter lanes 2 sigmoid(2f) - 1, gate
-                // lanes sigmoid(g): one exp and one reciprocal instead of two each) and takes the other from its partner row; the
-                // product is the same two numbers multiplied: bit-identical
+                    for (int g = 0; g < G; ++g) {
+                        const float pf = pre[(s + g) * 256 + t_f], pg = pre[(s + g) * 256 + t_f + T1];
+                        a0[g] = half8 ? wn_f2{0.f, 0.f} : wn_f2{pf, pg};
+                        a1[g] = wn_f2{0.f, 0.f};
+                    }
+                    float4 v[G][K8 / 4];
+                    const float* xsl = xb + (kq8 / 2) * (K1 + 4) + half8 * K8;
 #pragma unroll
-                for (int g = 0; g < G; ++g) {
-                    const float rc = __builtin_amdgcn_rcpf(1.0f + wn_exp(is_gate ? -acc[g] : -2.0f * acc[g]));
-                    const float fac = is_gate ? rc : fmaf(2.0f, rc, -1.0f);
-                    const float z = fac * wn_partner<T1>(fac);  // (the DPP move outside any lane-dependent branch)
-                    if (!is_gate && kq1 == 0) zs[g * L::DCP + ch] = z;
+                    for (int g = 0; g < G; ++g)
+#pragma unroll
+                        for (int k = 0; k < K8 / 4; ++k) v[g][k] = reinterpret_cast<const float4*>(xsl + g * L::XR)[k];
+#pragma unroll
+                    for (int k = 0; k < K8 / 4; ++k)
+#pragma unroll
+                        for (int g = 0; g < G; ++g) {  // two chains of packed {filter, gate} FMAs per stream, the streams interleaved
+                            a0[g] = __builtin_elementwise_fma(wfg[4 * k], wn_f2{v[g][k].x, v[g][k].x}, a0[g]);
+                            a1[g] = __builtin_elementwise_fma(wfg[4 * k + 1], wn_f2{v[g][k].y, v[g][k].y}, a1[g]);
+                            a0[g] = __builtin_elementwise_fma(wfg[4 * k + 2], wn_f2{v[g][k].z, v[g][k].z}, a0[g]);
+                            a1[g] = __builtin_elementwise_fma(wfg[4 * k + 3], wn_f2{v[g][k].w, v[g][k].w}, a1[g]);
+                        }
+                    // tanh(f) * sigmoid(g): even lanes of the channel's group evaluate the filter factor 2 sigmoid(2f) - 1, odd lanes the gate
+                    // factor sigmoid(g) (one exp and one reciprocal per lane), and each takes the other from its neighbour
+                    float z[G];
+#pragma unroll
+                    for (int g = 0; g < G; ++g) {
+                        const float f = wn_reduce<T8>(a0[g].x + a1[g].x), gt = wn_reduce<T8>(a0[g].y + a1[g].y);
+                        const float rc = __builtin_amdgcn_rcpf(1.0f + wn_exp(half8 ? -gt : -2.0f * f));
+                        const float fac = half8 ? rc : fmaf(2.0f, rc, -1.0f);
+                        z[g] = fac * wn_partner<1>(fac);  // (the DPP move outside any lane-dependent branch)
+                    }
+                    if (kq8 == 0) {
+#pragma unroll
+                        for (int g = 0; g < G; ++g) zs[g * L::DCP + ch8] = z[g];
+                    }
+                } else {
+                    float pin[G], acc[G];
+#pragma unroll
+                    for (int g = 0; g < G; ++g) pin[g] = pre[(s + g) * 256 + t];
+                    wn_dot_lds_gp<K1, G>(w1, xb + kq1 * (K1 + 4), L::XR, pin, acc);
+#pragma unroll
+                    for (int g = 0; g < G; ++g) acc[g] = wn_reduce<T1>(acc[g]);
+                    // tanh(f) * sigmoid(g) as in wn_gate, but each lane evaluates only ITS factor (filter lanes 2 sigmoid(2f) - 1, gate
+                    // lanes sigmoid(g): one exp and one reciprocal instead of two each) and takes the other from its partner row; the
+                    // product is the same two numbers multiplied: bit-identical
+#pragma unroll
+                    for (int g = 0; g < G; ++g) {
+                        const float rc = __builtin_amdgcn_rcpf(1.0f + wn_exp(is_gate ? -acc[g] : -2.0f * acc[g]));
+                        const float fac = is_gate ? rc : fmaf(2.0f, rc, -1.0f);
+                        const float z = fac * wn_partner<T1>(fac);  // (the DPP move outside any lane-dependent branch)
+                        if (!is_gate && kq1 == 0) zs[g * L::DCP + ch] = z;
+                    }
                 }
                 if (fail_a) return;
                 const int fail_b = wn_barrier_flag(cx, failflag);  // ---- B(i): z staged
@@ -617,19 +688,21 @@ static __device__ void wn_v3_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
 #pragma unroll
                         for (int h2 = 0; h2 < RS / 2; ++h2) a3p[g][h2] = wn_f2{bskip[2 * h2], bskip[2 * h2 + 1]};
                     static_assert(DC % 4 == 0 && L::DCP % 4 == 0, "z is read as float4");
+                    float4 z4[G][DC / 4];
 #pragma unroll
-                    for (int g = 0; g < G; ++g) {
-                        float4 z4[DC / 4];
+                    for (int g = 0; g < G; ++g)
 #pragma unroll
-                        for (int k = 0; k < DC / 4; ++k) z4[k] = reinterpret_cast<const float4*>(zs + g * L::DCP)[k];
+                        for (int k = 0; k < DC / 4; ++k) z4[g][k] = reinterpret_cast<const float4*>(zs + g * L::DCP)[k];
 #pragma unroll
-                        for (int k = 0; k < DC / 4; ++k) {
+                    for (int k = 0; k < DC / 4; ++k) {
+#pragma unroll
+                        for (int g = 0; g < G; ++g) {  // (the streams' chains interleaved in program order)
 #pragma unroll
                             for (int h2 = 0; h2 < RS / 2; ++h2) {
-                                a3p[g][h2] = __builtin_elementwise_fma(w3p[h2][4 * k], wn_f2{z4[k].x, z4[k].x}, a3p[g][h2]);
-                                a3p[g][h2] = __builtin_elementwise_fma(w3p[h2][4 * k + 1], wn_f2{z4[k].y, z4[k].y}, a3p[g][h2]);
-                                a3p[g][h2] = __builtin_elementwise_fma(w3p[h2][4 * k + 2], wn_f2{z4[k].z, z4[k].z}, a3p[g][h2]);
-                                a3p[g][h2] = __builtin_elementwise_fma(w3p[h2][4 * k + 3], wn_f2{z4[k].w, z4[k].w}, a3p[g][h2]);
+                                a3p[g][h2] = __builtin_elementwise_fma(w3p[h2][4 * k], wn_f2{z4[g][k].x, z4[g][k].x}, a3p[g][h2]);
+                                a3p[g][h2] = __builtin_elementwise_fma(w3p[h2][4 * k + 1], wn_f2{z4[g][k].y, z4[g][k].y}, a3p[g][h2]);
+                                a3p[g][h2] = __builtin_elementwise_fma(w3p[h2][4 * k + 2], wn_f2{z4[g][k].z, z4[g][k].z}, a3p[g][h2]);
+                                a3p[g][h2] = __builtin_elementwise_fma(w3p[h2][4 * k + 3], wn_f2{z4[g][k].w, z4[g][k].w}, a3p[g][h2]);
                             }
                         }
                     }
@@ -638,18 +711,21 @@ static __device__ void wn_v3_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
                     for (int g = 0; g < G; ++g)
 #pragma unroll
                         for (int h2 = 0; h2 < RS / 2; ++h2) { a3[g][2 * h2] = a3p[g][h2].x; a3[g][2 * h2 + 1] = a3p[g][h2].y; }
+                    if (l > 0) {
 #pragma unroll
-                    for (int g = 0; g < G; ++g)
+                        for (int g = 0; g < G; ++g)
 #pragma unroll
-                        for (int h2 = 0; h2 < RS / 2; ++h2) {
-                            if (l > 0) {
+                            for (int h2 = 0; h2 < RS / 2; ++h2) {
                                 wn_v4i v = sk_req[g][h2];   // (only ever this item's streams: re-requested after every barrier A)
                                 if ((uint32_t)v.y != tag || (uint32_t)v.w != tag) v = wn_poll_pair(cx, rs_gs, off_up + g * SB + h2 * 4096, tag, WN_W_SKIN, e, s + g, WN_V3_SKIP_SLEEP);
                                 a3[g][2 * h2] += __int_as_float(v.x);
                                 a3[g][2 * h2 + 1] += __int_as_float(v.z);
                             }
-                            wn_st_pair(rs_gs, off_me + g * SB + h2 * 4096, tag, a3[g][2 * h2], a3[g][2 * h2 + 1], local_s);
-                        }
+                    }
+#pragma unroll
+                    for (int g = 0; g < G; ++g)
+#pragma unroll
+                        for (int h2 = 0; h2 < RS / 2; ++h2) wn_st_pair(rs_gs, off_me + g * SB + h2 * 4096, tag, a3[g][2 * h2], a3[g][2 * h2 + 1], local_s);
                 } else if (l == NL - 1) {
 #pragma unroll
                     for (int g = 0; g < G; ++g)

@@ -243,7 +243,7 @@ static int wn_sampler_count(int n_streams) {
 // the LDS and DPP latencies of the dot products -- bound the throughput, and two streams per item share them (every weight
 // operand is used twice) at the price of a longer trip through each stage.  WN_V3_MODE = 0..3 pins a form (A/B runs, tests).
 #ifndef WN_V3_G2_MIN_STREAMS
-#define WN_V3_G2_MIN_STREAMS 64
+#define WN_V3_G2_MIN_STREAMS 56
 #endif
 static int wn_v3_mode(int n_streams) {
     const char* e = getenv("WN_V3_MODE");
