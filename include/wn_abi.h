@@ -121,9 +121,11 @@ typedef struct wn_info {
     int32_t kernel_variant;  /* 1 = generic kernel (weights stationary in LDS, any shape)
                                 2 = latency-optimised 256-thread kernels (weights stationary in registers, instantiated shapes)
                                 3 = wave-specialised kernel (768-thread layer workgroups: critical / skip / queue wave groups,
-                                    one chain for any stream count; shapes with an even number of skip rows per lane) */
-    int32_t n_chains;        /* independent chains (persistent kernels) the streams are split over: 1, or an even number that
-                                share the CUs two by two; n_workgroups and the byte counts are totals over the chains */
+                                    one chain for up to ~150 streams; from 56 streams up two streams per layer item and two
+                                    replicas of the head workgroups; shapes with an even number of skip rows per lane) */
+    int32_t n_chains;        /* independent chains (persistent kernels) the streams are split over: 1; an even number that share
+                                the CUs two by two (variant 2); or the rounds of up to 128 streams a variant-3 job beyond one
+                                chain's capacity runs one after the other; n_workgroups and the byte counts are totals over them */
 } wn_info;
 
 typedef struct wn_handle wn_handle;
