@@ -25,6 +25,17 @@
 // (no second copy of the weights, no second set of hand-off buffers).  Head workgroups request the next item's skip lanes as soon
 // as they have staged the current ones; samplers perform layer 0's start_conv.
 //
+// Throughput form (template parameter G = 2, chosen by the host from 56 streams up together with two replicas of the head
+// workgroups, wn_v3_mode in wn_runtime.hip): a pipeline item of a layer workgroup carries TWO streams, s and s+1.  Hand-offs stay per
+// stream (the granules of consecutive streams are R / S apart), so head and sampler workgroups and the protocol are unchanged; the
+// request round trip, both barriers and every LDS / DPP / transcendental latency of an item are paid once per two streams and
+// every weight operand is used twice.  All G*R lanes poll / stage / push (lane t: element t % R of stream s + t / R); x, z and the
+// taps are [G][...] in LDS; the tap FIFO is unchanged (every queue wave still issues one tap load per item).  The two streams'
+// dependency chains of a window are written as ONE basic block (unconditional LDS reads, selects, stores after both chains):
+// a lane-predicated store between them makes the compiler emit the second stream's whole chain after the first one's.  In this
+// form a critical lane computes the filter AND the gate row of a channel on half an x slice (WN_V3_PAIR_ROWS).  A trip through a
+// stage is longer (0.10 + 0.37 + 0.26 us against 0.08 + 0.26 + 0.17), which is why few streams keep G = 1.
+//
 // LDS hazards (i = item index; x and the late layers' tap are double buffered, everything else single; W = written in, R = read in):
 //   xs[buf(i)]   W: C before A(i).  R: C in A(i)..A(i+1), Q in A(i)..A(i+1) (late layers push after B(i)).  Next W (item i+2) after B(i+1).
 //   zs           W: C in A(i)..B(i).  R: C and S in B(i)..A(i+1).

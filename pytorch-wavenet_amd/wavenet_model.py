@@ -263,11 +263,12 @@ class WaveNetModel(nn.Module):
     def _engine(self, n_streams):
         """The MI355X engine holding this module's current parameters (rebuilt when they change)."""
         from mi355_wavenet import engine
-        params = list(self.state_dict().items())
-        dev = next(self.parameters()).device
+        plist = list(self.parameters())
+        dev = plist[0].device
         index = dev.index if dev.type == "cuda" and dev.index is not None else int(os.environ.get("WN_DEVICE", "0"))
-        key = (n_streams, index, tuple((k, v.data_ptr(), v._version) for k, v in params))
+        key = (n_streams, index, tuple((v.data_ptr(), v._version) for v in plist))  # (every state_dict entry of this module is a parameter)
         if self._wn_engine is None or self._wn_engine_key != key:
+            params = list(self.state_dict().items())
             if self._wn_engine is not None and self._wn_engine_key[:2] == key[:2]:
                 self._wn_engine.load_weights(dict(params))
             else:

@@ -155,7 +155,10 @@ class DilatedQueue:
         return t
 
     def reset(self):
-        self._lazy = None
-        self._data = _zeros(self.dtype, self.num_channels, self.max_length)  # rebinds, like the reference (:75)
+        # rebinds ``data`` to fresh zeros like the reference (:75) -- on first access: generate_fast() resets all queues per call
+        # (wavenet_model.py:250-251) and then leaves a loader for the GPU state here; zero-filling 50 rings was 3.6 ms per call
+        nc, ml = self.num_channels, self.max_length
+        self._lazy = lambda: (np.zeros((nc, ml), dtype=np.float32), 0, 0)
+        self._data = None
         self._in_pos = 0
         self._out_pos = 0
