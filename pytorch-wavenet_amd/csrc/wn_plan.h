@@ -290,6 +290,35 @@ static inline void wn_pack_blobs(const WnPlan& pl, const WnHostWeights& w, std::
     }
 }
 
+// ---- forms of the wave-specialised kernel (wn_kernel_v3.h), chosen per job by wn_create
+#ifndef WN_V3_G2_MIN_STREAMS
+#define WN_V3_G2_MIN_STREAMS 56   // from here up the throughput form pays (56 streams: 895 k against 887 k samples/s; 48: 783 k against 800 k)
+#endif
+#define WN_V3_ROUND_STREAMS 128   // streams per round when a job exceeds what one chain holds (wn_handle::rounds)
+// bit 0: two streams per pipeline item of a layer workgroup (needs an even stream count); bit 1: two replicas of the head
+// workgroups.  `pin`: the WN_V3_MODE environment override ("0".."3"), or NULL.
+static inline int wn_v3_mode_for(int n_streams, const char* pin) {
+    int mode = (n_streams >= WN_V3_G2_MIN_STREAMS) ? 3 : 0;
+    if (pin && pin[0] >= '0' && pin[0] <= '3' && !pin[1]) mode = pin[0] - '0';
+    if (n_streams % 2) mode &= ~1;
+    if (n_streams < 2) mode = 0;
+    return mode;
+}
+// sizes of the rounds a job of n_streams > round_max streams runs in: as few rounds as possible, equal within one or two streams,
+// even (two streams per pipeline item) wherever streams are left for it, none above round_max
+static inline std::vector<int> wn_v3_round_sizes(int n_streams, int round_max) {
+    std::vector<int> out;
+    const int K = (n_streams + round_max - 1) / round_max;
+    int left = n_streams;
+    for (int i = 0; i < K; ++i) {
+        int n = (left + (K - i) - 1) / (K - i);
+        if (n % 2 && n < left && n < round_max) ++n;
+        out.push_back(n);
+        left -= n;
+    }
+    return out;
+}
+
 // blockIdx -> chain position such that consecutive chain positions share an XCD (block b is observed
 // to land on XCD b % 8; a speed-only assumption -- correctness never depends on it).
 static inline void wn_make_wg_map(int n_wg, int n_xcd, std::vector<int32_t>& map) {

@@ -21,7 +21,6 @@ static thread_local char g_err[512] = "";
 static thread_local int g_chain_member = 0;  // wn_create is building one chain of a two-chain handle
 #define WN_LDS_SHARED_MAX_BYTES (81920 - 1024)  // two workgroups per CU: half of the 160 KB LDS each, minus the static allocation
 #define WN_CHAIN_MIN_STREAMS 16   // below: the chain is latency-bound, splitting does not pay (measured: 16 neutral, 32 +9 %, 64 +44 %)
-#define WN_V3_ROUND_STREAMS 128  // streams per round of the wave-specialised chain when a job exceeds what one chain holds (wn_handle::rounds)
 #define WN_CHAIN_MAX_STREAMS 40   // streams per chain that still fit two workgroups per CU at cfg3's shape (78 KB LDS)
 
 static int wn_fail(int code, const char* fmt, ...) {
@@ -242,17 +241,8 @@ static int wn_sampler_count(int n_streams) {
 // than the chain can turn around in one trip the stages' fixed costs per item -- the request round trip, two workgroup barriers,
 // the LDS and DPP latencies of the dot products -- bound the throughput, and two streams per item share them (every weight
 // operand is used twice) at the price of a longer trip through each stage.  WN_V3_MODE = 0..3 pins a form (A/B runs, tests).
-#ifndef WN_V3_G2_MIN_STREAMS
-#define WN_V3_G2_MIN_STREAMS 56
-#endif
-static int wn_v3_mode(int n_streams) {
-    const char* e = getenv("WN_V3_MODE");
-    int mode = (n_streams >= WN_V3_G2_MIN_STREAMS) ? 3 : 0;
-    if (e && e[0] >= '0' && e[0] <= '3' && !e[1]) mode = e[0] - '0';
-    if (n_streams % 2) mode &= ~1;
-    if (n_streams < 2) mode = 0;
-    return mode;
-}
+// (the rule itself is host-only arithmetic in wn_plan.h: wn_v3_mode_for, tests/test_plan_host.py)
+static int wn_v3_mode(int n_streams) { return wn_v3_mode_for(n_streams, getenv("WN_V3_MODE")); }
 
 // true iff the wave-specialised kernel (variant 3) serves this configuration with ONE chain: an instantiated shape, at least
 // two streams, the parked tap-0 sums of all streams fit the LDS next to the activations, one CU per workgroup
@@ -394,18 +384,14 @@ extern "C" int wn_create(const wn_config* cfg, wn_handle** out) {
         probe.n_streams = WN_V3_ROUND_STREAMS;
         if (!g_chain_member && !off && cfg->n_streams > WN_V3_ROUND_STREAMS && !wn_v3_applicable(cfg, n_cu, nullptr, nullptr, nullptr) &&
             wn_v3_applicable(&probe, n_cu, nullptr, nullptr, nullptr)) {
-            const int ns = cfg->n_streams;
-            const int K = (ns + WN_V3_ROUND_STREAMS - 1) / WN_V3_ROUND_STREAMS;
+            const std::vector<int> sizes = wn_v3_round_sizes(cfg->n_streams, WN_V3_ROUND_STREAMS);
             std::vector<wn_handle*> cs;
             std::vector<int> firsts(1, 0);
             int rc = WN_OK;
-            int left = ns;
-            for (int i = 0; i < K && rc == WN_OK; ++i) {
+            for (size_t i = 0; i < sizes.size() && rc == WN_OK; ++i) {
                 wn_config part = *cfg;
-                int n = (left + (K - i) - 1) / (K - i);  // even rounds (two streams per pipeline item) as long as streams are left
-                if (n % 2 && n < left) ++n;
+                const int n = sizes[i];
                 part.n_streams = n;
-                left -= n;
                 wn_handle* c = nullptr;
                 rc = wn_create(&part, &c);
                 if (rc == WN_OK) {

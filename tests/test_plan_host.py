@@ -15,6 +15,14 @@ HARNESS = r"""
 #include <cstdio>
 #include <cstdlib>
 int main(int argc, char** argv) {
+    if (argc >= 2 && argv[1][0] == 'm') {  // m <n_streams> [pin]: the form of the wave-specialised kernel
+        printf("%d\n", wn_v3_mode_for(atoi(argv[2]), argc > 3 ? argv[3] : nullptr));
+        return 0;
+    }
+    if (argc >= 2 && argv[1][0] == 'r') {  // r <n_streams>: round sizes
+        for (int n : wn_v3_round_sizes(atoi(argv[2]), WN_V3_ROUND_STREAMS)) printf("%d\n", n);
+        return 0;
+    }
     const int NL = atoi(argv[1]), P = atoi(argv[2]), heads = atoi(argv[3]), n_smp = atoi(argv[4]);
     std::vector<int32_t> m;
     int nb = 0;
@@ -65,3 +73,25 @@ def test_layer_aligned_placement(harness, NL, P, heads, n_smp):
 def test_placement_refuses_what_does_not_fit(harness):
     assert run(harness, 50, 4, 40, 4)[0] == 0   # head + samplers must fit one XCD
     assert run(harness, 80, 4, 8, 4)[0] == 0    # 332 workgroups > 256 CUs
+
+
+def test_form_of_the_wave_specialised_kernel(harness):
+    """bit 0 (two streams per layer item) needs an even stream count, the throughput form starts at 56 streams, WN_V3_MODE pins."""
+    def mode(n, pin=None):
+        return int(subprocess.check_output([harness, "m", str(n)] + ([pin] if pin is not None else [])).decode())
+    assert [mode(n) for n in (1, 2, 16, 48, 55)] == [0, 0, 0, 0, 0]
+    assert [mode(n) for n in (56, 64, 128)] == [3, 3, 3]
+    assert [mode(n) for n in (57, 63, 129)] == [2, 2, 2]          # odd: one stream per item, two head replicas
+    assert [mode(6, p) for p in ("0", "1", "2", "3")] == [0, 1, 2, 3]
+    assert [mode(7, p) for p in ("0", "1", "2", "3")] == [0, 0, 2, 2]
+    assert mode(1, "3") == 0 and mode(64, "0") == 0 and mode(64, "7") == 3 and mode(64, "12") == 3  # junk is ignored
+
+
+@pytest.mark.parametrize("ns", [129, 130, 170, 192, 255, 256, 257, 301, 381, 383, 384, 385, 512, 1000])
+def test_round_sizes(harness, ns):
+    sizes = [int(x) for x in subprocess.check_output([harness, "r", str(ns)]).decode().split()]
+    assert sum(sizes) == ns and len(sizes) == -(-ns // 128)
+    assert max(sizes) <= 128 and min(sizes) >= 1
+    assert max(sizes) - min(sizes) <= 3
+    assert sum(1 for n in sizes if n % 2) <= 1  # at most the last round is odd
+    assert all(n % 2 == 0 for n in sizes[:-1])
