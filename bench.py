@@ -331,6 +331,26 @@ def cpu_baseline(cfgname, budget_s=10.0):
                       "host has %d logical cores)" % (cfgname, best[2], default_threads, os.cpu_count())}
 
 
+def _launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher around it: re-executes this command line as N ranks, one per GPU, under
+    ``python -m torch.distributed.run`` (rendezvous on 127.0.0.1, a free port) and returns its exit code.  Refuses (exit 2)
+    when the node has fewer than N GPUs -- N ranks on fewer devices would be reported as an N-GPU number."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < n:
+        print("bench.py: --gpus %d but this node exposes %d GPU(s)" % (n, have), file=sys.stderr)
+        return 2
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -346,6 +366,8 @@ def main():
     ap.add_argument("--no-extra", action="store_true")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(_launch_ranks(a.gpus))  # plain `python bench.py --gpus N`: this process becomes the launcher of N ranks
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -361,8 +383,11 @@ def main():
     else:
         torch.cuda.set_device(local)
     n_gpus = world if world > 1 else 1
-    if a.gpus != n_gpus and rank == 0 and world > 1:
-        print("warning: --gpus %d but WORLD_SIZE %d" % (a.gpus, world), file=sys.stderr)
+    if a.gpus != n_gpus:  # a launcher that started another number of ranks than --gpus says: never print a line that lies about N
+        if rank == 0:
+            print("bench.py: --gpus %d but WORLD_SIZE %d: refusing to report a %d-GPU figure as %d GPUs" % (a.gpus, world, n_gpus, a.gpus),
+                  file=sys.stderr)
+        sys.exit(2)
 
     if a.workload == "train5":
         train5_main(a, dist, rank, local, n_gpus)

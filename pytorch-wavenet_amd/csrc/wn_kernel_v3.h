@@ -77,12 +77,20 @@
 #define WN_V3_SKIP_SLEEP 0  // s_sleep between the skip group's poll retries (the skip lane is not latency critical; fewer polls on the fabric)
 #endif
 #ifndef WN_V3_ABL
-#define WN_V3_ABL 0  // timing ablations (results are WRONG when != 0): 1 the skip group only passes its barriers, 2 the queue group, 3 both
+#define WN_V3_ABL 0  // timing ablations (results are WRONG when != 0): 1 the skip group only passes its barriers, 2 the queue group, 3 both;
+                     // 4 skip group without its dot, 8 skip group without its loads / stores, 16 queue group without its tap-0 dot, 32 without its push
 #endif
 #ifndef WN_V3_PAIR_ROWS
 #define WN_V3_PAIR_ROWS 2  // a critical lane computes the filter AND the gate row of one channel on a half-width slice of x (see wn_v3_layer):
                            // 0 never, 1 always, 2 in the two-streams-per-item form only (64 streams: 961 -> 974 k samples/s, 128: 1.464 -> 1.478 M;
                            // one stream: 18.87 -> 18.74 k -- the longer lane reduction is on the single token's path; profiles/r02_v3_forms_final.txt)
+#endif
+#ifndef WN_V3_S_SLEEP
+#define WN_V3_S_SLEEP 0  // two-streams-per-item form: the skip group sleeps this long (s_sleep units of 64 clocks) after barrier B, so that its
+                         // z reads / FMAs / stores do not sit in the critical group's residual window
+#endif
+#ifndef WN_V3_Q_SLEEP
+#define WN_V3_Q_SLEEP 0  // ... and the queue group
 #endif
 #ifndef WN_V3_PRIO
 #define WN_V3_PRIO 1  // 1: critical waves at a higher static wave priority (the queue and skip waves share their SIMDs: x64 911 -> 919 k, profiles/r02_v3_tap_fifo.txt)
@@ -678,6 +686,9 @@ static __device__ void wn_v3_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
             const uint32_t tag = (uint32_t)(e + 1);
             for (int s = 0; s < ns; s += G, ++item) {
                 if (wn_barrier_failed(cx, failflag)) return;  // ---- B(i): z of this item staged
+#if WN_V3_S_SLEEP
+                if (G >= 2 && l < NL - 1) __builtin_amdgcn_s_sleep(WN_V3_S_SLEEP);
+#endif
                 const bool stamp = r.prof && item < r.prof_items && tid == 256;
                 const long long t0 = stamp ? (long long)wall_clock64() : 0;
                 constexpr unsigned SB = (unsigned)S * 8;  // bytes between the lanes of consecutive streams
@@ -705,7 +716,7 @@ static __device__ void wn_v3_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
 #pragma unroll
                         for (int k = 0; k < DC / 4; ++k) z4[g][k] = reinterpret_cast<const float4*>(zs + g * L::DCP)[k];
 #pragma unroll
-                    for (int k = 0; k < DC / 4; ++k) {
+                    for (int k = 0; k < ((WN_V3_ABL & 4) ? 1 : DC / 4); ++k) {
 #pragma unroll
                         for (int g = 0; g < G; ++g) {  // (the streams' chains interleaved in program order)
 #pragma unroll
@@ -722,7 +733,7 @@ static __device__ void wn_v3_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
                     for (int g = 0; g < G; ++g)
 #pragma unroll
                         for (int h2 = 0; h2 < RS / 2; ++h2) { a3[g][2 * h2] = a3p[g][h2].x; a3[g][2 * h2 + 1] = a3p[g][h2].y; }
-                    if (l > 0) {
+                    if (l > 0 && !(WN_V3_ABL & 8)) {
 #pragma unroll
                         for (int g = 0; g < G; ++g)
 #pragma unroll
@@ -733,10 +744,14 @@ static __device__ void wn_v3_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
                                 a3[g][2 * h2 + 1] += __int_as_float(v.z);
                             }
                     }
+                    if (!(WN_V3_ABL & 8) || l == NL - 1) {
 #pragma unroll
                     for (int g = 0; g < G; ++g)
 #pragma unroll
                         for (int h2 = 0; h2 < RS / 2; ++h2) wn_st_pair(rs_gs, off_me + g * SB + h2 * 4096, tag, a3[g][2 * h2], a3[g][2 * h2 + 1], local_s);
+                    } else {  // keep the sums alive
+                        if (a3[0][0] == 1.2345e-30f) zs[t] = a3[0][1] + a3[G - 1][0];
+                    }
                 } else if (l == NL - 1) {
 #pragma unroll
                     for (int g = 0; g < G; ++g)
@@ -751,7 +766,8 @@ static __device__ void wn_v3_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
 #pragma unroll
                     for (int g = 0; g < G; ++g)
 #pragma unroll
-                        for (int h2 = 0; h2 < RS / 2; ++h2) sk_req[g][h2] = wn_ld_pair(rs_gs, (unsigned)(((up_wg * ns + s2 + g) * (size_t)S) * 8) + (unsigned)t * 16 + h2 * 4096);
+                        for (int h2 = 0; h2 < RS / 2; ++h2)
+                            if (!(WN_V3_ABL & 8)) sk_req[g][h2] = wn_ld_pair(rs_gs, (unsigned)(((up_wg * ns + s2 + g) * (size_t)S) * 8) + (unsigned)t * 16 + h2 * 4096);
                 }
             }
         }
@@ -854,11 +870,14 @@ static __device__ void wn_v3_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
             constexpr bool QDE = WN_V3_QDOT_EARLY == 1 || (WN_V3_QDOT_EARLY == 2 && G >= 2);
             if (QDE && late_wg) wn_dot_lds_gp<K1, G>(w0, xo_cur + kq1 * (K1 + 4), L::XR, bin, acc_late);
             if (wn_barrier_failed(cx, failflag)) return;  // ---- B(i): the tap is staged
+#if WN_V3_Q_SLEEP
+            if (G >= 2) __builtin_amdgcn_s_sleep(WN_V3_Q_SLEEP);
+#endif
             const long long t1 = stamp ? (long long)wall_clock64() : 0;
             // ---- tap-0 half of the dilated conv for the NEXT timestep of this stream, parked for the critical group
             if (!(WN_V3_ABL & 2)) {
-                if (pusher) rings_l[((size_t)(s + pg) * ML + tmod) * R + prow] = xs[buf * (G * L::XR) + pg * L::XR + SH::xpad(prow)];  // the push, off the A -> B window
-                if (!(QDE && late_wg)) wn_dot_lds_gp<K1, G>(w0, xo_cur + kq1 * (K1 + 4), L::XR, bin, acc_late);
+                if (pusher && !(WN_V3_ABL & 32)) rings_l[((size_t)(s + pg) * ML + tmod) * R + prow] = xs[buf * (G * L::XR) + pg * L::XR + SH::xpad(prow)];  // the push, off the A -> B window
+                if (!(QDE && late_wg) && !(WN_V3_ABL & 16)) wn_dot_lds_gp<K1, G>(w0, xo_cur + kq1 * (K1 + 4), L::XR, bin, acc_late);
 #pragma unroll
                 for (int g = 0; g < G; ++g) pre[(s + g) * 256 + t] = acc_late[g];
                 if (fifo) wn_q_issue_slot(slot, next_tap_ptr());  // the tap of item i + D goes into the entry item i has just given up
@@ -957,15 +976,34 @@ static __device__ void wn_v3_head(const WnPlan& p, const WnRun& r, WnCtx& cx, fl
         for (int s = rep; s < ns; s += HR) {
             const long long item = e * n_mine + (s - rep) / HR;
             wn_stamp(r, park, item, 0);
+            // (this item's stream: requested for it one item ago.)  Stale lanes are re-requested TOGETHER until all carry the tag: polled
+            // one by one, every late lane cost a round trip of its own -- with nothing queued in front of the head (latency-bound runs)
+            // that was 4 x ~0.5 us between the last layer's publication and the head's first instruction (profiles/r03_ring_tail.txt)
+            {
+                unsigned spins = 0;
+                while (!cx.fail) {
+                    bool fresh = true;
+#pragma unroll
+                    for (int h2 = 0; h2 < QS / 2; ++h2)
+#pragma unroll
+                        for (int j = 0; j < P; ++j) fresh = fresh && (uint32_t)nv[h2][j].y == tag && (uint32_t)nv[h2][j].w == tag;
+                    if (fresh) break;
+                    if ((++spins & 127u) == 0u) {  // bounded wait, as wn_poll_pair
+                        if (__hip_atomic_load(cx.p->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { cx.fail = 1; break; }
+                        const long long now = (long long)wall_clock64();
+                        if (spins == 128u) cx.t_start = now;
+                        else if (now - cx.t_start > cx.r->timeout_ticks) { wn_give_up(cx, WN_W_HEAD, e, s); break; }
+                    }
+                    request(s);
+                }
+            }
 #pragma unroll
             for (int h2 = 0; h2 < QS / 2; ++h2) {
                 float sum0 = 0.f, sum1 = 0.f;
 #pragma unroll
-                for (int j = 0; j < P; ++j) {  // fixed order j = 0..P-1, late lanes re-polled one by one
-                    wn_v4i v = nv[h2][j];      // (this item's stream: requested for it one item ago)
-                    if ((uint32_t)v.y != tag || (uint32_t)v.w != tag) v = wn_poll_pair(cx, rs_gs, lane_off(j, s, h2), tag, WN_W_HEAD, e, s);
-                    sum0 += __int_as_float(v.x);
-                    sum1 += __int_as_float(v.z);
+                for (int j = 0; j < P; ++j) {  // fixed order j = 0..P-1
+                    sum0 += __int_as_float(nv[h2][j].x);
+                    sum1 += __int_as_float(nv[h2][j].z);
                 }
                 sk[SH::skpad(tid + 512 * h2)] = sum0 > 0.f ? sum0 : 0.f;        // relu(skip), rows tid + 512 h2 and tid + 512 h2 + 256
                 sk[SH::skpad(tid + 512 * h2 + 256)] = sum1 > 0.f ? sum1 : 0.f;

@@ -116,6 +116,26 @@ def main():
                 print("   L%02d d=%3d: %.3f | %.3f | %.3f | %.3f | %.3f | %.3f | %.3f | %.3f %.3f" % (
                     l, 1 << (l % 10), perl[l], (a[:, :, 4] - a[:, :, 0]).mean(), (a[:, :, 1] - a[:, :, 4]).mean(), (a[:, :, 5] - a[:, :, 1]).mean(),
                     (a[:, :, 2] - a[:, :, 5]).mean(), (a[:, :, 3] - a[:, :, 2]).mean(), sk, qp, qd))
+        if info["kernel_variant"] == 3 and n_smp > 0:
+            # the tail of the ring, per (stream, evaluation): last layer's barrier B -> head staged -> logits published -> sampler has
+            # them -> layer 0's row published -> layer 0 has its input in registers (evaluation e+1)
+            nI, n_mine = ns // G, ns // HG
+            rf = (raw & m40).astype(np.float64) * 0.01
+            seg = []
+            for e in range(N // 4, N - 2):
+                for s in range(ns):
+                    b49 = rf[(NL - 1) * P:NL * P, e * nI + s // G, 5].max()
+                    rep = s % HG
+                    hrow = rf[nlw + rep * PA:nlw + (rep + 1) * PA, e * n_mine + (s - rep) // HG]
+                    smp = rf[nlw + PA * HG + s % n_smp, e * ns + s]
+                    l0 = rf[0:P, (e + 1) * nI + s // G, 4].max()
+                    l0a = rf[0:P, (e + 1) * nI + s // G, 1].max()
+                    seg.append([hrow[:, 1].max() - b49, hrow[:, 2].max() - hrow[:, 1].max(), smp[1] - hrow[:, 2].max(), smp[2] - smp[1], l0 - smp[2], l0a - l0,
+                                l0a - b49])
+            seg = np.array(seg)
+            print("  ring tail per token (us): L%d barrier B -> head staged %.3f | -> logits published %.3f | -> sampler has them %.3f | -> row published %.3f | "
+                  "-> L0 input in registers %.3f | -> L0 barrier A %.3f || total %.3f (p50 %.3f, p90 %.3f)" % (
+                      NL - 1, *seg.mean(axis=0), np.percentile(seg[:, 6], 50), np.percentile(seg[:, 6], 90)))
         crit = (T[:nlw, :, 2] - T[:nlw, :, 1]).mean()
         print("  layer staged->published %.3f us, published->done %.3f us" % (crit, (T[:nlw, :, 3] - T[:nlw, :, 2]).mean()))
         inp = (T[P:nlw, :, 4] - T[P:nlw, :, 0]).mean()
