@@ -30,14 +30,96 @@ def hipcc_path():
     raise RuntimeError("hipcc not found (need ROCm >= 7.0 to build the gfx950 engine)")
 
 
+OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+RESERVED_FIRST, RESERVED_LAST = 152, 167   # csrc/wn_kernel_v3.h: WN_V3_COMPILER_VGPRS .. the last register a 768-thread workgroup leaves a lane
+
+
+def check_hand_scheduled_registers(so, objdump=OBJDUMP):
+    """The variant-3 kernels keep loads in flight into v152-v167 across their inline-assembly blocks (input poll sets, the queue
+    group's tap FIFO).  The kernels carry amdgpu_num_vgpr so that the compiler's own allocation ends below them; this check
+    DISASSEMBLES the built library and raises unless (1) every instruction of those kernels that names a reserved register is one
+    the blocks emit, in the operand position they emit it, (2) nothing touches a register above v167, (3) the kernels use no
+    scratch (a spill in a persistent hot loop is a performance bug, and spill code is where an allocator would reach for "free"
+    registers).  Called by build_hip(): a library that breaks the invariant is never left in place."""
+    import re
+    import tempfile
+    if not os.path.exists(objdump):
+        raise RuntimeError("llvm-objdump not found at %s: cannot verify the hand-scheduled register reservation" % objdump)
+    with tempfile.TemporaryDirectory() as tmp:
+        local = shutil.copy(so, os.path.join(tmp, "lib.so"))
+        subprocess.check_call([objdump, "--offloading", local], cwd=tmp, stdout=subprocess.DEVNULL)
+        co = [f for f in os.listdir(tmp) if "gfx950" in f]
+        if len(co) != 1:
+            raise RuntimeError("expected one gfx950 code object in %s, found %r" % (so, co))
+        dis = subprocess.check_output([objdump, "-d", os.path.join(tmp, co[0])]).decode()
+    reserved = set(range(RESERVED_FIRST, RESERVED_LAST + 1))
+    is_res = lambda tok: bool(_regs(tok) & reserved)  # noqa: E731
+    seen, current = 0, None
+    for line in dis.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+        if m:
+            current = m.group(1)
+            seen += "wn_generate_kernel_v3m" in current
+            continue
+        if not current or "wn_generate_kernel_v3m" not in current:
+            continue
+        text = line.split("//")[0].strip()
+        if not text:
+            continue
+        op, _, rest = text.partition(" ")
+        ops = [o.strip() for o in rest.split(",")]
+        regs = _regs(text)
+        if regs and max(regs) > RESERVED_LAST:
+            raise RuntimeError("%s: register above v%d: %s" % (current, RESERVED_LAST, text))
+        if op.startswith("scratch_"):
+            raise RuntimeError("%s spills to scratch: %s" % (current, text))
+        if not (regs & reserved):
+            continue
+        where = "%s: %s" % (current, text)
+        if op == "global_load_dwordx2":      # a request set: destination pair inside the reserved range, address operands outside
+            ok = re.fullmatch(r"v\[(\d+):(\d+)\]", ops[0]) and _regs(ops[0]) <= reserved and not any(is_res(o) for o in ops[1:])
+        elif op == "global_load_dword":      # the tap FIFO: destination v152-v157, address outside
+            ok = ops[0] in ("v152", "v153", "v154", "v155", "v156", "v157") and not any(is_res(o) for o in ops[1:])
+        elif op == "v_cmp_eq_u32_e32":       # vcc = (tag == v<reserved>): reserved register as the LAST source only
+            ok = is_res(ops[-1]) and not any(is_res(o) for o in ops[:-1])
+        elif op == "v_cmp_eq_u32_e64":       # s[m] = (tag == v<reserved>)
+            ok = is_res(ops[-1]) and not any(is_res(o) for o in ops[:-1])
+        elif op == "v_add_f32_e32":          # t0 = t0 + v<reserved>: never the destination
+            ok = not is_res(ops[0]) and is_res(ops[-1])
+        elif op == "v_mov_b32_e32":          # FIFO take: source only
+            ok = not is_res(ops[0]) and is_res(ops[1])
+        else:
+            ok = False
+        if not ok:
+            raise RuntimeError("use of a reserved poll register outside the hand-scheduled blocks in " + where)
+    if not seen:
+        raise RuntimeError("no wn_generate_kernel_v3m kernel found in %s" % so)
+    return seen
+
+
+def _regs(text):
+    import re
+    regs = set(int(x) for x in re.findall(r"\bv(\d+)\b", text))
+    for a, b in re.findall(r"\bv\[(\d+):(\d+)\]", text):
+        regs.update(range(int(a), int(b) + 1))
+    return regs
+
+
 def build_hip(force=False, verbose=False, extra_flags=()):
     if not force and not _stale(OUT, DEPS):
         return OUT
+    tmp_out = OUT + ".tmp"
     cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
-           "-Wno-unused-function", *extra_flags, "-o", OUT] + SOURCES
+           "-Wno-unused-function", "-Wno-inline-asm", *extra_flags, "-o", tmp_out] + SOURCES
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    try:
+        check_hand_scheduled_registers(tmp_out)   # a library that breaks the reservation is never installed
+    except Exception:
+        os.remove(tmp_out)
+        raise
+    os.replace(tmp_out, OUT)
     return OUT
 
 

@@ -49,26 +49,12 @@
 
 #include "wn_kernel_v2.h"
 
+#ifndef WN_THREADS_V3
 #define WN_THREADS_V3 768
+#endif
 #define WN_V3_MIN_STREAMS 1
 #define WN_V3_TAP_AHEAD 6
-#ifndef WN_V3_REQ_AT
-#define WN_V3_REQ_AT 0  // where set A of the next item's input is requested: 0 at the end of the item, 1 after barrier B, 2 after barrier A
-#endif
-#ifndef WN_V3_REQ_FIRST_ON_CROSSING
-#define WN_V3_REQ_FIRST_ON_CROSSING 0  // 1: stages that publish across an XCD boundary request in front of their (write-through) store: measured
-                                       // x64 924 k against 935 k without (profiles/r02_v3_crossing_request.txt)
-#endif
-#ifndef WN_V3_LAZY_B
-#define WN_V3_LAZY_B 1  // 1: the second request set of the critical group's input poll is only issued when the first came back stale
-#endif
-#if WN_V3_LAZY_B
-#define WN_AP_FIRST0 "0"
-#define WN_AP_FIRST1 "1"
-#else
-#define WN_AP_FIRST0 "4"
-#define WN_AP_FIRST1 "5"
-#endif
+#define WN_V3_COMPILER_VGPRS 152  // v152-v167: request sets of the input poll / the queue group's tap FIFO (see wn_ap_*, wn_q_*)
 #ifndef WN_V3_QDOT_EARLY
 #define WN_V3_QDOT_EARLY 0  // 1: a late layer's tap-0 dot runs between barriers A and B (next to the critical group's dot) instead of after B;
                             // 2: only in the two-streams-per-item form
@@ -77,20 +63,12 @@
 #define WN_V3_SKIP_SLEEP 0  // s_sleep between the skip group's poll retries (the skip lane is not latency critical; fewer polls on the fabric)
 #endif
 #ifndef WN_V3_ABL
-#define WN_V3_ABL 0  // timing ablations (results are WRONG when != 0): 1 the skip group only passes its barriers, 2 the queue group, 3 both;
-                     // 4 skip group without its dot, 8 skip group without its loads / stores, 16 queue group without its tap-0 dot, 32 without its push
+#define WN_V3_ABL 0  // timing ablations (results are WRONG when != 0): 1 the skip group only polls the input and passes its barriers, 2 the queue group, 3 both
 #endif
 #ifndef WN_V3_PAIR_ROWS
 #define WN_V3_PAIR_ROWS 2  // a critical lane computes the filter AND the gate row of one channel on a half-width slice of x (see wn_v3_layer):
                            // 0 never, 1 always, 2 in the two-streams-per-item form only (64 streams: 961 -> 974 k samples/s, 128: 1.464 -> 1.478 M;
                            // one stream: 18.87 -> 18.74 k -- the longer lane reduction is on the single token's path; profiles/r02_v3_forms_final.txt)
-#endif
-#ifndef WN_V3_S_SLEEP
-#define WN_V3_S_SLEEP 0  // two-streams-per-item form: the skip group sleeps this long (s_sleep units of 64 clocks) after barrier B, so that its
-                         // z reads / FMAs / stores do not sit in the critical group's residual window
-#endif
-#ifndef WN_V3_Q_SLEEP
-#define WN_V3_Q_SLEEP 0  // ... and the queue group
 #endif
 #ifndef WN_V3_PRIO
 #define WN_V3_PRIO 1  // 1: critical waves at a higher static wave priority (the queue and skip waves share their SIMDs: x64 911 -> 919 k, profiles/r02_v3_tap_fifo.txt)
@@ -103,6 +81,7 @@
 // are therefore adjacent in memory, {value(t), tag, value(t+256), tag}, written by ONE 16-byte store and read by ONE 16-byte
 // load; each 8-byte half still carries its own tag, so nothing depends on the 16 bytes arriving together.
 typedef int wn_v4i __attribute__((ext_vector_type(4)));
+typedef int wn_v2i __attribute__((ext_vector_type(2)));
 static __device__ __forceinline__ __amdgpu_buffer_rsrc_t wn_rsrc(const void* base) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);  // raw buffer, 2 GB window
 }
@@ -148,17 +127,20 @@ static __device__ __forceinline__ wn_v4i wn_poll_pair(WnCtx& cx, __amdgpu_buffer
 // registers would make the allocator split the register file in halves), and the loop is written out: issue, s_waitcnt vmcnt(4) = "the older set
 // is complete", check, reissue.  The wave leaves as soon as all its lanes have their input, with one set still in flight; it
 // lands in registers nobody else uses and is overwritten (in order) by the next request.
+// (the clobbers make the kernel's register count cover v167; the compiler cannot allocate them anyway: amdgpu_num_vgpr)
 #define WN_AP_CLOBBERS "v152", "v153", "v154", "v155", "v156", "v157", "v158", "v159", "v160", "v161", "v162", "v163", "v164", "v165", "v166", "v167", "vcc", "scc", "memory"
-static __device__ __forceinline__ void wn_ap_issue_a4(const wn_u64* p0, const wn_u64* p1, const wn_u64* p2, const wn_u64* p3) {
+// (addresses: a wave-uniform base per partial in an SGPR pair + ONE 32-bit byte offset per lane -- four 64-bit lane pointers were
+//  eight registers of the polling waves' budget)
+static __device__ __forceinline__ void wn_ap_issue_a4(unsigned off, const wn_u64* b0, const wn_u64* b1, const wn_u64* b2, const wn_u64* b3) {
     asm volatile(
-        "global_load_dwordx2 v[152:153], %0, off sc1\n\t"
-        "global_load_dwordx2 v[154:155], %1, off sc1\n\t"
-        "global_load_dwordx2 v[156:157], %2, off sc1\n\t"
-        "global_load_dwordx2 v[158:159], %3, off sc1"
-        ::"v"(p0), "v"(p1), "v"(p2), "v"(p3) : WN_AP_CLOBBERS);
+        "global_load_dwordx2 v[152:153], %0, %1 sc1\n\t"
+        "global_load_dwordx2 v[154:155], %0, %2 sc1\n\t"
+        "global_load_dwordx2 v[156:157], %0, %3 sc1\n\t"
+        "global_load_dwordx2 v[158:159], %0, %4 sc1"
+        ::"v"(off), "s"(b0), "s"(b1), "s"(b2), "s"(b3) : WN_AP_CLOBBERS);
 }
-static __device__ __forceinline__ void wn_ap_issue_a1(const wn_u64* p0) {
-    asm volatile("global_load_dwordx2 v[152:153], %0, off sc1" ::"v"(p0) : WN_AP_CLOBBERS);
+static __device__ __forceinline__ void wn_ap_issue_a1(unsigned off, const wn_u64* b0) {
+    asm volatile("global_load_dwordx2 v[152:153], %0, %1 sc1" ::"v"(off), "s"(b0) : WN_AP_CLOBBERS);
 }
 // one check of a set: lanes that are not ok yet and see fresh tags take their sum (fixed order ((0+x0)+x1)+x2)+x3, as wn_poll_fixed)
 #define WN_AP_MERGE                                      \
@@ -190,22 +172,22 @@ static __device__ __forceinline__ void wn_ap_issue_a1(const wn_u64* p0) {
 // BETWEEN = vector-memory operations this wave issued between set A and this call (the publication store of the previous item,
 // when set A is requested in front of it): the first wait lets them stay in flight next to set B.
 #define WN_AP_ISSUE4(R0, R1, R2, R3, R4, R5, R6, R7)                             \
-    "global_load_dwordx2 v[" #R0 ":" #R1 "], %[p0], off sc1\n\t"                  \
-    "global_load_dwordx2 v[" #R2 ":" #R3 "], %[p1], off sc1\n\t"                  \
-    "global_load_dwordx2 v[" #R4 ":" #R5 "], %[p2], off sc1\n\t"                  \
-    "global_load_dwordx2 v[" #R6 ":" #R7 "], %[p3], off sc1\n\t"
-#if WN_V3_LAZY_B
-// Set B is only issued when set A came back stale: with tokens queued in front of the stage (64 streams: 88 % of the items) the
-// first check then waits for set A alone -- not for "set A and (the publication store or the first load of set B)", which the
-// shared in-order counter makes of a wait issued after set B -- and the polls of set B are not spent.  FIRST_WAIT counts the
-// operations issued AFTER set A that may stay in flight (0: set A was the last; 1: the publication store follows it).
-#define WN_AP_POLL4_BODY(FIRST_WAIT)                                              \
+    "global_load_dwordx2 v[" #R0 ":" #R1 "], %[off], %[p0] sc1\n\t"               \
+    "global_load_dwordx2 v[" #R2 ":" #R3 "], %[off], %[p1] sc1\n\t"               \
+    "global_load_dwordx2 v[" #R4 ":" #R5 "], %[off], %[p2] sc1\n\t"               \
+    "global_load_dwordx2 v[" #R6 ":" #R7 "], %[off], %[p3] sc1\n\t"
+// The poll comes in two pieces, so that the caller can put its own (compiler-scheduled) publication stores between the first look and
+// the spin: wn_ap_look4 waits for everything this wave has in flight (set A, requested a window ago, is the youngest load) and
+// merges set A; wn_ap_spin4 -- only entered when a lane is still without its input -- issues set B, then set A again, and keeps two
+// sets in flight half a round trip apart until every lane is served or `rounds` double rounds have passed.  Set B is only ever
+// issued after a stale first look: with tokens queued in front of the stage the first look succeeds and no further poll is spent.
+#define WN_AP_LOOK4_BODY                                                          \
         "v_mov_b32_e32 %[ok], 0\n\t"                                              \
         "v_mov_b32_e32 %[sum], 0\n\t"                                             \
+        "s_waitcnt vmcnt(0)\n\t"                                                  \
+        WN_AP_CHECK4(152, 153, 154, 155, 156, 157, 158, 159)
+#define WN_AP_SPIN4_BODY                                                          \
         "s_mov_b32 %[cnt], %[rounds]\n\t"                                         \
-        "s_waitcnt vmcnt(" FIRST_WAIT ")\n\t"                                     \
-        WN_AP_CHECK4(152, 153, 154, 155, 156, 157, 158, 159)                      \
-        "s_cbranch_vccz 2f\n\t"                                                   \
         WN_AP_ISSUE4(160, 161, 162, 163, 164, 165, 166, 167)                      \
         "s_sleep 2\n\t"                                                           \
         WN_AP_ISSUE4(152, 153, 154, 155, 156, 157, 158, 159)                      \
@@ -222,86 +204,64 @@ static __device__ __forceinline__ void wn_ap_issue_a1(const wn_u64* p0) {
         "s_cmp_lg_u32 %[cnt], 0\n\t"                                              \
         "s_cbranch_scc1 1b\n"                                                     \
         "2:"
-#else
-#define WN_AP_POLL4_BODY(FIRST_WAIT)                                              \
-        WN_AP_ISSUE4(160, 161, 162, 163, 164, 165, 166, 167)                      \
-        "v_mov_b32_e32 %[ok], 0\n\t"                                              \
-        "v_mov_b32_e32 %[sum], 0\n\t"                                             \
-        "s_mov_b32 %[cnt], %[rounds]\n\t"                                         \
-        "s_waitcnt vmcnt(" FIRST_WAIT ")\n\t"                                     \
-        WN_AP_CHECK4(152, 153, 154, 155, 156, 157, 158, 159)                      \
-        "s_cbranch_vccz 2f\n\t"                                                   \
-        WN_AP_ISSUE4(152, 153, 154, 155, 156, 157, 158, 159)                      \
-        "1:\n\t"                                                                  \
-        "s_waitcnt vmcnt(4)\n\t"                                                  \
-        WN_AP_CHECK4(160, 161, 162, 163, 164, 165, 166, 167)                      \
-        "s_cbranch_vccz 2f\n\t"                                                   \
-        WN_AP_ISSUE4(160, 161, 162, 163, 164, 165, 166, 167)                      \
-        "s_waitcnt vmcnt(4)\n\t"                                                  \
-        WN_AP_CHECK4(152, 153, 154, 155, 156, 157, 158, 159)                      \
-        "s_cbranch_vccz 2f\n\t"                                                   \
-        WN_AP_ISSUE4(152, 153, 154, 155, 156, 157, 158, 159)                      \
-        "s_sub_u32 %[cnt], %[cnt], 1\n\t"                                         \
-        "s_cmp_lg_u32 %[cnt], 0\n\t"                                              \
-        "s_cbranch_scc1 1b\n"                                                     \
-        "2:"
-#endif
-template <int BETWEEN>
-static __device__ __forceinline__ void wn_ap_poll4(const wn_u64* p0, const wn_u64* p1, const wn_u64* p2, const wn_u64* p3, uint32_t tag, int rounds,
+static __device__ __forceinline__ void wn_ap_look4(uint32_t tag, float& sum, int& ok) {
+    float t0;
+    long long m;
+    asm volatile(WN_AP_LOOK4_BODY
+                 : [sum] "=&v"(sum), [ok] "=&v"(ok), [t0] "=&v"(t0), [m] "=&s"(m)
+                 : [tag] "s"(tag)
+                 : WN_AP_CLOBBERS);
+}
+static __device__ __forceinline__ void wn_ap_spin4(unsigned off, const wn_u64* p0, const wn_u64* p1, const wn_u64* p2, const wn_u64* p3, uint32_t tag, int rounds,
                                                     float& sum, int& ok) {
-    static_assert(BETWEEN == 0 || BETWEEN == 1, "operations between set A and set B");
     float t0;
     long long m;
     int cnt;
-    if constexpr (BETWEEN == 0)
-        asm volatile(WN_AP_POLL4_BODY(WN_AP_FIRST0)
-                     : [sum] "=&v"(sum), [ok] "=&v"(ok), [t0] "=&v"(t0), [m] "=&s"(m), [cnt] "=&s"(cnt)
-                     : [p0] "v"(p0), [p1] "v"(p1), [p2] "v"(p2), [p3] "v"(p3), [tag] "s"(tag), [rounds] "s"(rounds)
-                     : WN_AP_CLOBBERS);
-    else
-        asm volatile(WN_AP_POLL4_BODY(WN_AP_FIRST1)
-                     : [sum] "=&v"(sum), [ok] "=&v"(ok), [t0] "=&v"(t0), [m] "=&s"(m), [cnt] "=&s"(cnt)
-                     : [p0] "v"(p0), [p1] "v"(p1), [p2] "v"(p2), [p3] "v"(p3), [tag] "s"(tag), [rounds] "s"(rounds)
-                     : WN_AP_CLOBBERS);
+    asm volatile(WN_AP_SPIN4_BODY
+                 : [sum] "+v"(sum), [ok] "+v"(ok), [t0] "=&v"(t0), [m] "=&s"(m), [cnt] "=&s"(cnt)
+                 : [off] "v"(off), [p0] "s"(p0), [p1] "s"(p1), [p2] "s"(p2), [p3] "s"(p3), [tag] "s"(tag), [rounds] "s"(rounds)
+                 : WN_AP_CLOBBERS);
 }
 // the single-granule form (layer 0: one complete row per stream from the sampler): A = v[152:153], B = v[160:161]
-#define WN_AP_POLL1_BODY(FIRST_WAIT)                                              \
-        "global_load_dwordx2 v[160:161], %[p0], off sc1\n\t"                      \
+#define WN_AP_LOOK1_BODY                                                          \
         "v_mov_b32_e32 %[ok], 0\n\t"                                              \
         "v_mov_b32_e32 %[sum], 0\n\t"                                             \
+        "s_waitcnt vmcnt(0)\n\t"                                                  \
+        WN_AP_CHECK1(152, 153)
+#define WN_AP_SPIN1_BODY                                                          \
         "s_mov_b32 %[cnt], %[rounds]\n\t"                                         \
-        "s_waitcnt vmcnt(" FIRST_WAIT ")\n\t"                                     \
-        WN_AP_CHECK1(152, 153)                                                    \
-        "s_cbranch_vccz 2f\n\t"                                                   \
-        "global_load_dwordx2 v[152:153], %[p0], off sc1\n\t"                      \
+        "global_load_dwordx2 v[160:161], %[off], %[p0] sc1\n\t"                      \
+        "s_sleep 2\n\t"                                                           \
+        "global_load_dwordx2 v[152:153], %[off], %[p0] sc1\n\t"                      \
         "1:\n\t"                                                                  \
         "s_waitcnt vmcnt(1)\n\t"                                                  \
         WN_AP_CHECK1(160, 161)                                                    \
         "s_cbranch_vccz 2f\n\t"                                                   \
-        "global_load_dwordx2 v[160:161], %[p0], off sc1\n\t"                      \
+        "global_load_dwordx2 v[160:161], %[off], %[p0] sc1\n\t"                      \
         "s_waitcnt vmcnt(1)\n\t"                                                  \
         WN_AP_CHECK1(152, 153)                                                    \
         "s_cbranch_vccz 2f\n\t"                                                   \
-        "global_load_dwordx2 v[152:153], %[p0], off sc1\n\t"                      \
+        "global_load_dwordx2 v[152:153], %[off], %[p0] sc1\n\t"                      \
         "s_sub_u32 %[cnt], %[cnt], 1\n\t"                                         \
         "s_cmp_lg_u32 %[cnt], 0\n\t"                                              \
         "s_cbranch_scc1 1b\n"                                                     \
         "2:"
-template <int BETWEEN>
-static __device__ __forceinline__ void wn_ap_poll1(const wn_u64* p0, uint32_t tag, int rounds, float& sum, int& ok) {
+static __device__ __forceinline__ void wn_ap_look1(uint32_t tag, float& sum, int& ok) {
+    float t0;
+    long long m;
+    asm volatile(WN_AP_LOOK1_BODY
+                 : [sum] "=&v"(sum), [ok] "=&v"(ok), [t0] "=&v"(t0), [m] "=&s"(m)
+                 : [tag] "s"(tag)
+                 : WN_AP_CLOBBERS);
+}
+static __device__ __forceinline__ void wn_ap_spin1(unsigned off, const wn_u64* p0, uint32_t tag, int rounds, float& sum, int& ok) {
     float t0;
     long long m;
     int cnt;
-    if constexpr (BETWEEN == 0)
-        asm volatile(WN_AP_POLL1_BODY("1")
-                     : [sum] "=&v"(sum), [ok] "=&v"(ok), [t0] "=&v"(t0), [m] "=&s"(m), [cnt] "=&s"(cnt)
-                     : [p0] "v"(p0), [tag] "s"(tag), [rounds] "s"(rounds)
-                     : WN_AP_CLOBBERS);
-    else
-        asm volatile(WN_AP_POLL1_BODY("2")
-                     : [sum] "=&v"(sum), [ok] "=&v"(ok), [t0] "=&v"(t0), [m] "=&s"(m), [cnt] "=&s"(cnt)
-                     : [p0] "v"(p0), [tag] "s"(tag), [rounds] "s"(rounds)
-                     : WN_AP_CLOBBERS);
+    asm volatile(WN_AP_SPIN1_BODY
+                 : [sum] "+v"(sum), [ok] "+v"(ok), [t0] "=&v"(t0), [m] "=&s"(m), [cnt] "=&s"(cnt)
+                 : [off] "v"(off), [p0] "s"(p0), [tag] "s"(tag), [rounds] "s"(rounds)
+                 : WN_AP_CLOBBERS);
 }
 
 // ---- The queue group's tap FIFO, hand-scheduled for the same reason.  Queue taps x[t+1-d] are requested WN_V3_TAP_AHEAD items ahead
@@ -441,6 +401,51 @@ static __device__ void wn_v3_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
     const bool local_x = locflags[0] != 0, local_s = locflags[1] != 0;
     const int n_prime = (int)(r.n_given - 1);
 
+    // ---- fetching the layer's input (lanes t < G*R of the critical group): request (set A), first look, spin with two sets in flight, stage.
+    // (Round 3 also tried the SKIP group as the fetcher -- request after barrier B, look after its chunk, the critical group pure compute --
+    //  and the skip group's chunk deferred into the next item's filter/gate window so that its polling waves are free between B and the
+    //  next A: profiles/r03_skip_group_polls.txt.  Slower wherever tokens queue: the request just misses the token, the next look comes a
+    //  chunk later; and ANY work next to the critical group's filter/gate window doubles that window -- the LDS pipe is what both wait for.)
+    // the layer's input granules of stream s2: layer 0 ONE complete row per stream (g0), layers > 0 the P partials of the upstream slices
+    static_assert(P == 4, "the hand-scheduled input poll (wn_ap_look4 / wn_ap_spin4) is written for four partials");
+    const bool poller = t < G * R;  // (whole waves)
+    const wn_u64* xb0 = l == 0 ? p.g0 : p.gx + ((size_t)(l - 1) * P) * ns * R;  // (wave-uniform) partial j: + j * xstep_j
+    const size_t xstep_j = (size_t)ns * R;
+    const unsigned xlane = (poller ? (unsigned)t : 0u) * 8u;  // this lane's byte offset inside the granules of the item's first stream
+    long long* park4 = reinterpret_cast<long long*>(smp + 56);
+    auto request = [&](int s2) {  // set A for the item whose first stream is s2
+        const unsigned off = xlane + (unsigned)s2 * (unsigned)(R * 8);
+        if (l == 0) wn_ap_issue_a1(off, xb0);
+        else wn_ap_issue_a4(off, xb0, xb0 + xstep_j, xb0 + 2 * xstep_j, xb0 + 3 * xstep_j);
+    };
+    auto look = [&](uint32_t tag2, float& sum, int& ok) {
+        if (l == 0) wn_ap_look1(tag2, sum, ok);
+        else wn_ap_look4(tag2, sum, ok);
+    };
+    // spins until every lane of this wave has its input (bounded like wn_poll_fixed), then stages it
+    auto finish_input = [&](long long e2, int s2, float* xb2, float sum, int ok, long long item2) {
+        const uint32_t tag2 = (uint32_t)(e2 + 1);
+        const unsigned off = xlane + (unsigned)s2 * (unsigned)(R * 8);
+        unsigned spins = 0;
+        while (!cx.fail && __builtin_amdgcn_ballot_w64(ok == 0) != 0) {  // the wave leaves together (its lanes share the barrier that follows)
+            if (l == 0) wn_ap_spin1(off, xb0, tag2, 64, sum, ok);
+            else wn_ap_spin4(off, xb0, xb0 + xstep_j, xb0 + 2 * xstep_j, xb0 + 3 * xstep_j, tag2, 64, sum, ok);
+            if (__builtin_amdgcn_ballot_w64(ok == 0) == 0) break;
+            // slow path: ~64 double rounds between looks at the abort word and the wall clock
+            if (__hip_atomic_load(cx.p->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { cx.fail = 1; break; }
+            const long long now = (long long)wall_clock64();
+            if (spins++ == 0u) cx.t_start = now;
+            else if (now - cx.t_start > cx.r->timeout_ticks) { wn_give_up(cx, l == 0 ? WN_W_LOGITS : WN_W_X, e2, s2); break; }
+            look(tag2, sum, ok);  // (set A was re-requested at the end of the spin)
+        }
+        xb2[tg * L::XR + SH::xpad(tr)] = sum;
+        if (r.prof && item2 < r.prof_items && (tid & 255) == 0) park4[item2 & 1] = (long long)wall_clock64();
+    };
+    // the first evaluation's input of layer 0 is a given sample: start_conv row gather (wavenet_model.py:127, 256-257)
+    auto given_input = [&](int s2, float* xb2) {
+        const int idx = r.first[(size_t)(s2 + tg) * r.n_given];
+        xb2[tg * L::XR + SH::xpad(tr)] = p.start_t[(size_t)idx * R + tr] + (p.start_b ? p.start_b[tr] : 0.f);
+    };
     if (group == 0) {
         // ================================================================== critical group
 #if WN_V3_PRIO
@@ -472,20 +477,7 @@ static __device__ void wn_v3_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
         const float bres = img[(size_t)(2 * K1 + K2 + RS * DC + 1) * 256];
         long long* park = reinterpret_cast<long long*>(lds + L::park);
         const __amdgpu_buffer_rsrc_t rs_gx = wn_rsrc(p.gx);
-        // the layer's input granules of stream s2: layer 0 ONE complete row per stream (g0), layers > 0 the P partials of the upstream slices
-        static_assert(P == 4, "the hand-scheduled input poll (wn_ap_poll4) is written for four partials");
-        const bool poller = t < G * R;  // (whole waves)
-        const wn_u64* xbase = (l == 0 ? p.g0 : p.gx + ((size_t)(l - 1) * P) * ns * R) + (poller ? t : 0);
-        const size_t xstep_j = (size_t)ns * R;
-        auto request = [&](int s2) {  // set A for the coming item, first stream s2 (see wn_ap_poll4)
-            const wn_u64* q = xbase + (size_t)s2 * R;
-            if (l == 0) wn_ap_issue_a1(q);
-            else wn_ap_issue_a4(q, q + xstep_j, q + 2 * xstep_j, q + 3 * xstep_j);
-        };
         if (poller) request(0);
-        // (experiment switch: a stage whose consumers sit in another XCD publishes write-through; requesting set A in FRONT of that
-        // store keeps its acknowledgement out of the first wait -- no gain measured, see WN_V3_REQ_FIRST_ON_CROSSING)
-        const bool req_first = WN_V3_REQ_FIRST_ON_CROSSING && !local_x && l > 0 && l < NL - 1;
         int buf = 0;
         for (long long e = 0; e < r.n_eval; ++e) {
             const uint32_t tag = (uint32_t)(e + 1);
@@ -494,43 +486,15 @@ static __device__ void wn_v3_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
                 const long long item = e * nI + s / G;
                 wn_stamp(r, park, item, 0);
                 // ---- 1. layer input x[t] of the item's G streams
-                if (l == 0 && e == 0) {  // the first evaluation's input is a given sample: start_conv row gather (wavenet_model.py:127, 256-257)
-                    const int idx = r.first[(size_t)(s + tg) * r.n_given];
-                    if (poller) xb[tg * L::XR + SH::xpad(tr)] = p.start_t[(size_t)idx * R + tr] + (p.start_b ? p.start_b[tr] : 0.f);
-                } else if (poller) {
-                    // layer 0 (e > 0): ONE complete row per stream, published by the sampler that drew the class (the row gather
-                    // sits there, off this workgroup: with it layer 0 was the slowest stage of the chain); layers > 0: P partials
-                    const wn_u64* q = xbase + (size_t)s * R;
-                    float sum = 0.f;
-                    int ok = 0;
-                    unsigned spins = 0;
-                    while (!cx.fail) {
-#if WN_V3_REQ_AT >= 1
-                        // (set A was requested in front of the previous item's publication store: one operation between the sets -- on
-                        //  the first pass only; a second pass after the slow path finds both long complete, and the plain wait is the safe one)
-                        if (l == 0) { if (spins == 0u) wn_ap_poll1<1>(q, tag, 64, sum, ok); else wn_ap_poll1<0>(q, tag, 64, sum, ok); }
-                        else if (l < NL - 1 && spins == 0u) wn_ap_poll4<1>(q, q + xstep_j, q + 2 * xstep_j, q + 3 * xstep_j, tag, 64, sum, ok);
-                        else wn_ap_poll4<0>(q, q + xstep_j, q + 2 * xstep_j, q + 3 * xstep_j, tag, 64, sum, ok);
-#else
-                        if (l == 0) wn_ap_poll1<0>(q, tag, 64, sum, ok);
-                        else if (req_first && spins == 0u) wn_ap_poll4<1>(q, q + xstep_j, q + 2 * xstep_j, q + 3 * xstep_j, tag, 64, sum, ok);
-                        else wn_ap_poll4<0>(q, q + xstep_j, q + 2 * xstep_j, q + 3 * xstep_j, tag, 64, sum, ok);
-#endif
-                        if (__builtin_amdgcn_ballot_w64(ok == 0) == 0) break;  // the wave leaves together (its lanes share the barrier that follows)
-                        // bounded wait, slow path (like wn_poll_fixed): ~64 double rounds between looks at the abort word and the wall clock
-                        if (__hip_atomic_load(cx.p->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { cx.fail = 1; break; }
-                        const long long now = (long long)wall_clock64();
-                        if (spins++ == 0u) cx.t_start = now;
-                        else if (now - cx.t_start > cx.r->timeout_ticks) { wn_give_up(cx, l == 0 ? WN_W_LOGITS : WN_W_X, e, s); break; }
-                    }
-                    xb[tg * L::XR + SH::xpad(tr)] = sum;
+                if (l == 0 && e == 0) { if (poller) given_input(s, xb); }
+                else if (poller) {  // (set A was requested at the end of the previous item)
+                    float sum;
+                    int ok;
+                    look(tag, sum, ok);
+                    finish_input(e, s, xb, sum, ok, item);
                 }
-                wn_stamp(r, park, item, 4);
                 const int fail_a = wn_barrier_flag(cx, failflag);  // ---- A(i): x staged
                 wn_stamp(r, park, item, 1);
-#if WN_V3_REQ_AT == 2
-                if (poller) request(s + G < ns ? s + G : 0);
-#endif
                 // ---- 2. filter/gate: tap 1 on x[t] + parked tap 0, tanh * sigmoid   (wavenet_model.py:147-151)
                 // (the G streams' chains are kept in ONE basic block -- unconditional LDS reads, selects instead of lane-predicated
                 //  branches, the z stores after both chains -- so that the scheduler can interleave them: a predicated store between
@@ -600,9 +564,6 @@ static __device__ void wn_v3_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
                 if (fail_a) return;
                 const int fail_b = wn_barrier_flag(cx, failflag);  // ---- B(i): z staged
                 wn_stamp(r, park, item, 5);
-#if WN_V3_REQ_AT == 1
-                if (poller) request(s + G < ns ? s + G : 0);
-#endif
                 // ---- 3. residual 1x1 partial, published at once                      (wavenet_model.py:164-165)
                 if (l < NL - 1) {
                     float a2[G], zero[G], xn[G];
@@ -617,11 +578,6 @@ static __device__ void wn_v3_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
                         float xn1[G];
 #pragma unroll
                         for (int g = 0; g < G; ++g) xn1[g] = wn_dpp<0x4E>(xn[g]);  // quad_perm [2,3,0,1]
-#if WN_V3_REQ_AT == 3
-                        if (poller) request(s + G < ns ? s + G : 0);  // in FRONT of the store: the wait for set A does not include its acknowledgement
-#elif WN_V3_REQ_AT == 0
-                        if (req_first && poller) request(s + G < ns ? s + G : 0);
-#endif
                         if ((t & 3) == 0) {
 #pragma unroll
                             for (int g = 0; g < G; ++g) wn_st_pair(rs_gx, (unsigned)((((size_t)cx.w * ns + s + g) * R + row2) * 8), tag, xn[g], xn1[g], local_x);
@@ -633,19 +589,14 @@ static __device__ void wn_v3_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
                         }
                     }
                 }
-#if WN_V3_REQ_AT == 3
-                else if (poller) request(s + G < ns ? s + G : 0);  // the last layer publishes no x'
-#endif
                 wn_stamp(r, park, item, 2);
                 wn_stamp(r, park, item, 3);
-                if (r.prof && item < r.prof_items && tid == 0) {  // slots 0-5 (6 and 7 belong to the skip and queue groups); BEFORE the request:
-                    long long* dst = r.prof + ((size_t)cx.w * r.prof_items + item) * WN_STAMPS;  // nothing may sit between set A and set B
+                if (r.prof && item < r.prof_items && tid == 0) {  // slots 0-5 (6 and 7 belong to the skip and queue groups)
+                    long long* dst = r.prof + ((size_t)cx.w * r.prof_items + item) * WN_STAMPS;
 #pragma unroll
-                    for (int k = 0; k < 6; ++k) dst[k] = park[k];
+                    for (int k = 0; k < 6; ++k) dst[k] = k == 4 ? park4[item & 1] : park[k];
                 }
-#if WN_V3_REQ_AT == 0
-                if (!req_first && poller) request(s + G < ns ? s + G : 0);
-#endif
+                if (poller) request(s + G < ns ? s + G : 0);  // set A of the coming item
                 if (fail_b) return;
             }
         }
@@ -686,23 +637,20 @@ static __device__ void wn_v3_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
             const uint32_t tag = (uint32_t)(e + 1);
             for (int s = 0; s < ns; s += G, ++item) {
                 if (wn_barrier_failed(cx, failflag)) return;  // ---- B(i): z of this item staged
-#if WN_V3_S_SLEEP
-                if (G >= 2 && l < NL - 1) __builtin_amdgcn_s_sleep(WN_V3_S_SLEEP);
-#endif
                 const bool stamp = r.prof && item < r.prof_items && tid == 256;
                 const long long t0 = stamp ? (long long)wall_clock64() : 0;
+                const int s2 = s + G < ns ? s + G : 0;  // the coming item's first stream
                 constexpr unsigned SB = (unsigned)S * 8;  // bytes between the lanes of consecutive streams
                 const unsigned off_up = (unsigned)(((up_wg * ns + s) * (size_t)S) * 8) + (unsigned)t * 16;    // upstream slice's lane, first stream of the item
                 const unsigned off_me = (unsigned)((((size_t)cx.w * ns + s) * (size_t)S) * 8) + (unsigned)t * 16;
                 // ---- skip 1x1 partial on this lane of the running skip sum          (wavenet_model.py:154-162)
-                if ((WN_V3_ABL & 1) != 0) {
-                    if (l == NL - 1) {
+                float a3[G][RS];
 #pragma unroll
-                        for (int g = 0; g < G; ++g)
+                for (int g = 0; g < G; ++g)
 #pragma unroll
-                            for (int h2 = 0; h2 < RS / 2; ++h2) wn_st_pair(rs_gs, off_me + g * SB + h2 * 4096, tag, 0.f, 0.f, local_s);
-                    }
-                } else if (!prime) {
+                    for (int q = 0; q < RS; ++q) a3[g][q] = 0.f;
+                const bool work = !prime && !(WN_V3_ABL & 1);
+                if (work) {
                     // per row: bias, then + w[k] z[k] for k = 0..DC-1 in order (one fused multiply-add each), as before the packing
                     wn_f2 a3p[G][RS / 2];
 #pragma unroll
@@ -716,7 +664,7 @@ static __device__ void wn_v3_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
 #pragma unroll
                         for (int k = 0; k < DC / 4; ++k) z4[g][k] = reinterpret_cast<const float4*>(zs + g * L::DCP)[k];
 #pragma unroll
-                    for (int k = 0; k < ((WN_V3_ABL & 4) ? 1 : DC / 4); ++k) {
+                    for (int k = 0; k < DC / 4; ++k) {
 #pragma unroll
                         for (int g = 0; g < G; ++g) {  // (the streams' chains interleaved in program order)
 #pragma unroll
@@ -728,12 +676,11 @@ static __device__ void wn_v3_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
                             }
                         }
                     }
-                    float a3[G][RS];
 #pragma unroll
                     for (int g = 0; g < G; ++g)
 #pragma unroll
                         for (int h2 = 0; h2 < RS / 2; ++h2) { a3[g][2 * h2] = a3p[g][h2].x; a3[g][2 * h2 + 1] = a3p[g][h2].y; }
-                    if (l > 0 && !(WN_V3_ABL & 8)) {
+                    if (l > 0) {
 #pragma unroll
                         for (int g = 0; g < G; ++g)
 #pragma unroll
@@ -744,30 +691,21 @@ static __device__ void wn_v3_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
                                 a3[g][2 * h2 + 1] += __int_as_float(v.z);
                             }
                     }
-                    if (!(WN_V3_ABL & 8) || l == NL - 1) {
+                }
+                if (work || l == NL - 1) {  // (priming: only the head's lanes are kept moving, with zeros)
 #pragma unroll
                     for (int g = 0; g < G; ++g)
 #pragma unroll
                         for (int h2 = 0; h2 < RS / 2; ++h2) wn_st_pair(rs_gs, off_me + g * SB + h2 * 4096, tag, a3[g][2 * h2], a3[g][2 * h2 + 1], local_s);
-                    } else {  // keep the sums alive
-                        if (a3[0][0] == 1.2345e-30f) zs[t] = a3[0][1] + a3[G - 1][0];
-                    }
-                } else if (l == NL - 1) {
-#pragma unroll
-                    for (int g = 0; g < G; ++g)
-#pragma unroll
-                        for (int h2 = 0; h2 < RS / 2; ++h2) wn_st_pair(rs_gs, off_me + g * SB + h2 * 4096, tag, 0.f, 0.f, local_s);
                 }
                 if (stamp)  // slot 6: the skip group's B(i) | its chunk length << 40 (10 ns ticks)
                     r.prof[((size_t)cx.w * r.prof_items + item) * WN_STAMPS + 6] = (t0 & 0xffffffffffll) | (((long long)wall_clock64() - t0) << 40);
                 if (wn_barrier_failed(cx, failflag)) return;  // ---- A(i+1)
                 {   // the upstream lane of the coming item
-                    const int s2 = s + G < ns ? s + G : 0;
 #pragma unroll
                     for (int g = 0; g < G; ++g)
 #pragma unroll
-                        for (int h2 = 0; h2 < RS / 2; ++h2)
-                            if (!(WN_V3_ABL & 8)) sk_req[g][h2] = wn_ld_pair(rs_gs, (unsigned)(((up_wg * ns + s2 + g) * (size_t)S) * 8) + (unsigned)t * 16 + h2 * 4096);
+                        for (int h2 = 0; h2 < RS / 2; ++h2) sk_req[g][h2] = wn_ld_pair(rs_gs, (unsigned)(((up_wg * ns + s2 + g) * (size_t)S) * 8) + (unsigned)t * 16 + h2 * 4096);
                 }
             }
         }
@@ -870,14 +808,11 @@ static __device__ void wn_v3_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
             constexpr bool QDE = WN_V3_QDOT_EARLY == 1 || (WN_V3_QDOT_EARLY == 2 && G >= 2);
             if (QDE && late_wg) wn_dot_lds_gp<K1, G>(w0, xo_cur + kq1 * (K1 + 4), L::XR, bin, acc_late);
             if (wn_barrier_failed(cx, failflag)) return;  // ---- B(i): the tap is staged
-#if WN_V3_Q_SLEEP
-            if (G >= 2) __builtin_amdgcn_s_sleep(WN_V3_Q_SLEEP);
-#endif
             const long long t1 = stamp ? (long long)wall_clock64() : 0;
             // ---- tap-0 half of the dilated conv for the NEXT timestep of this stream, parked for the critical group
             if (!(WN_V3_ABL & 2)) {
-                if (pusher && !(WN_V3_ABL & 32)) rings_l[((size_t)(s + pg) * ML + tmod) * R + prow] = xs[buf * (G * L::XR) + pg * L::XR + SH::xpad(prow)];  // the push, off the A -> B window
-                if (!(QDE && late_wg) && !(WN_V3_ABL & 16)) wn_dot_lds_gp<K1, G>(w0, xo_cur + kq1 * (K1 + 4), L::XR, bin, acc_late);
+                if (pusher) rings_l[((size_t)(s + pg) * ML + tmod) * R + prow] = xs[buf * (G * L::XR) + pg * L::XR + SH::xpad(prow)];  // the push, off the A -> B window
+                if (!(QDE && late_wg)) wn_dot_lds_gp<K1, G>(w0, xo_cur + kq1 * (K1 + 4), L::XR, bin, acc_late);
 #pragma unroll
                 for (int g = 0; g < G; ++g) pre[(s + g) * 256 + t] = acc_late[g];
                 if (fifo) wn_q_issue_slot(slot, next_tap_ptr());  // the tap of item i + D goes into the entry item i has just given up
@@ -927,18 +862,24 @@ static __device__ __forceinline__ float wn_dot_lds_chunked(const float (&w)[K], 
 template <class SH, int P>
 static __device__ void wn_v3_head(const WnPlan& p, const WnRun& r, WnCtx& cx, float* lds, int hw) {
     constexpr int S = SH::S, EC = SH::EC, T3 = SH::T3, K3 = SH::K3, QS = S / 256;
-    constexpr int CH3 = (K3 / 4) % 2 == 0 ? 2 : 1, CHE = (EC / 4) % 2 == 0 ? 2 : 1;  // (chunks of two float4: the early request set below needs the registers)
+    constexpr int CH3 = (K3 / 4) % 4 == 0 ? 4 : (K3 / 4) % 2 == 0 ? 2 : 1;  // (float4 reads of the long dot in flight together)
     static_assert(K3 % 4 == 0 && EC % 4 == 0, "head slices are read as float4");
     using L = WnV3Lds<SH>;
     const int tid = threadIdx.x, ns = p.n_streams, NL = p.NL;
     const int HR = p.HR, h = hw % p.PA, rep = hw / p.PA;  // slice of end_conv_1 / end_conv_2, replica
     const int n_mine = rep < ns ? (ns - rep + HR - 1) / HR : 0;  // streams this replica serves
-    float w4[K3], w5[EC];
+    // end_conv_1's slice stays in registers; the lane's end_conv_2 row (EC floats) lives in LDS as float4 [EC / 4][256 lanes] -- a head
+    // workgroup has the LDS to itself, and with the row in registers the role did not fit the 152 registers the compiler may use
+    // (it spilled operands of the long dot into scratch)
+    float w4[K3];
     const float* img = p.blobs + (size_t)NL * P * (SH::NWL * 256) + (size_t)h * (SH::NWH * 256) + tid;
 #pragma unroll
     for (int k = 0; k < K3; ++k) w4[k] = img[(size_t)k * 256];
+    static_assert(L::pre % 4 == 0, "the end_conv_2 rows are read as float4");
+    float4* w5l = reinterpret_cast<float4*>(lds + L::pre) + tid;  // [k4 * 256]
 #pragma unroll
-    for (int k = 0; k < EC; ++k) w5[k] = img[(size_t)(K3 + k) * 256];
+    for (int k4 = 0; k4 < EC / 4; ++k4)
+        w5l[k4 * 256] = float4{img[(size_t)(K3 + 4 * k4) * 256], img[(size_t)(K3 + 4 * k4 + 1) * 256], img[(size_t)(K3 + 4 * k4 + 2) * 256], img[(size_t)(K3 + 4 * k4 + 3) * 256]};
     const float b1 = img[(size_t)(K3 + EC) * 256], b2 = img[(size_t)(K3 + EC + 1) * 256];
     const int kq3 = tid % T3, row3 = tid / T3;
     float* sk = lds + L::sk;
@@ -962,12 +903,15 @@ static __device__ void wn_v3_head(const WnPlan& p, const WnRun& r, WnCtx& cx, fl
     // stage of the 64-stream chain, whatever the layer stages did (profiles/r02_v3_head_request.txt).  Nothing queued (latency-
     // bound runs): the early request comes back stale and the lanes are polled when due, as before.
     wn_v4i nv[QS / 2][P];
-    auto lane_off = [&](int j, int s2, int h2) { return (unsigned)(((((size_t)(NL - 1) * P + j) * ns + s2) * (size_t)S) * 8) + (unsigned)tid * 16 + h2 * 4096; };
+    // (offsets: the lane's part in ONE register, the wave-uniform part of every lane in the scalar offset of the buffer load)
+    const unsigned lane16 = (unsigned)tid * 16, lane8 = (unsigned)tid * 8;
+    const __amdgpu_buffer_rsrc_t rs_gl = wn_rsrc(p.gl);
     auto request = [&](int s2) {
 #pragma unroll
         for (int h2 = 0; h2 < QS / 2; ++h2)
 #pragma unroll
-            for (int j = 0; j < P; ++j) nv[h2][j] = wn_ld_pair(rs_gs, lane_off(j, s2, h2));
+            for (int j = 0; j < P; ++j)
+                nv[h2][j] = __builtin_amdgcn_raw_buffer_load_b128(rs_gs, lane16, (unsigned)(((((size_t)(NL - 1) * P + j) * ns + s2) * (size_t)S) * 8) + h2 * 4096, 16);
     };
     if (n_mine > 0) request(rep);
     for (long long e = 0; e < r.n_eval; ++e) {
@@ -1008,18 +952,36 @@ static __device__ void wn_v3_head(const WnPlan& p, const WnRun& r, WnCtx& cx, fl
                 sk[SH::skpad(tid + 512 * h2)] = sum0 > 0.f ? sum0 : 0.f;        // relu(skip), rows tid + 512 h2 and tid + 512 h2 + 256
                 sk[SH::skpad(tid + 512 * h2 + 256)] = sum1 > 0.f ? sum1 : 0.f;
             }
-            request(s + HR < ns ? s + HR : rep);
             if (wn_barrier_failed(cx, failflag)) return;
             wn_stamp(r, park, item, 1);
-            wn_u64* gl = p.gl + ((size_t)h * ns + s) * 256;
+            const unsigned gl_off = (unsigned)((((size_t)h * ns + s) * 256) * 8);  // (wave-uniform: the scalar offset of the store)
+            auto publish_logit = [&](float v) {
+                const wn_v2i d = {__float_as_int(v), (int)tag};
+                if (local_l) __builtin_amdgcn_raw_buffer_store_b64(d, rs_gl, lane8, gl_off, 0);
+                else __builtin_amdgcn_raw_buffer_store_b64(d, rs_gl, lane8, gl_off, 16);  // write-through
+            };
             if (!prime) {
                 float a = wn_dot_lds_chunked<K3, CH3>(w4, sk + kq3 * (K3 + 4), 0.f);
                 a = wn_reduce<T3>(a) + b1;
                 if (kq3 == 0) ev[row3] = a > 0.f ? a : 0.f;  // relu(end_conv_1)
+                request(s + HR < ns ? s + HR : rep);  // (after the long dot: its sixteen registers are not live next to that dot's operands)
+                float4 w5r[EC / 4];  // the lane's end_conv_2 row, fetched from LDS while the other waves finish end_conv_1
+#pragma unroll
+                for (int k4 = 0; k4 < EC / 4; ++k4) w5r[k4] = w5l[k4 * 256];
                 wn_lds_barrier();
-                wn_publish_at(gl + tid, tag, wn_dot_lds_chunked<EC, CHE>(w5, ev, b2), local_l);  // partial end_conv_2
+                {   // partial end_conv_2: the arithmetic of wn_dot_lds_chunked (two packed chains, same order)
+                    wn_f2 a01 = {b2, 0.f}, a23 = {0.f, 0.f};
+#pragma unroll
+                    for (int k4 = 0; k4 < EC / 4; ++k4) {
+                        const float4 w = w5r[k4], v = reinterpret_cast<const float4*>(ev)[k4];
+                        a01 = __builtin_elementwise_fma(wn_f2{w.x, w.y}, wn_f2{v.x, v.y}, a01);
+                        a23 = __builtin_elementwise_fma(wn_f2{w.z, w.w}, wn_f2{v.z, v.w}, a23);
+                    }
+                    publish_logit((a01.x + a01.y) + (a23.x + a23.y));
+                }
             } else {
-                wn_publish_at(gl + tid, tag, 0.f, local_l);
+                request(s + HR < ns ? s + HR : rep);
+                publish_logit(0.f);
             }
             wn_stamp(r, park, item, 2);
             wn_lds_barrier();
@@ -1084,8 +1046,14 @@ static __device__ void wn_v3_sampler(const WnPlan& p, const WnRun& r, WnCtx& cx,
 
 // G = streams per pipeline item of the layer workgroups (hand-offs are per stream: head and sampler workgroups see the same granules
 // different G talk to each other unchanged; the stream count must be a multiple of both)
+// amdgpu_num_vgpr(WN_V3_COMPILER_VGPRS): the compiler's own allocation ends below the registers the hand-scheduled blocks keep
+// loads in flight into (v152-v167 are RESERVED registers for it: it can neither allocate nor spill into them -- the reservation holds
+// by construction, not by the luck of the allocator; the launch bound still gives every lane the 168 the blocks address).  On gfx90a and
+// later the backend DOUBLES the attribute's value (unified VGPR + AGPR file) before it compares it with the occupancy limit -- a value above
+// 84 is silently dropped at 3 waves per SIMD -- hence WN_V3_COMPILER_VGPRS / 2; build.py disassembles the library and checks the result.
 template <int R, int DC, int S, int EC, int P, int G = 1>
-__global__ __launch_bounds__(WN_THREADS_V3) void wn_generate_kernel_v3m(WnPlan p, WnRun r) {
+__global__ __launch_bounds__(WN_THREADS_V3) __attribute__((amdgpu_num_vgpr(WN_V3_COMPILER_VGPRS / 2)))
+void wn_generate_kernel_v3m(WnPlan p, WnRun r) {
     using SH = WnV2Shape<R, DC, S, EC>;
     extern __shared__ __attribute__((aligned(16))) float wn_lds3m[];
     const int w = p.wg_map[blockIdx.x];

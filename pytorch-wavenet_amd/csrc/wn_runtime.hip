@@ -185,7 +185,7 @@ static WnV2Entry wn_v2_entry() {
         e.fn_v3[1] = (const void*)wn_generate_kernel_v3m<R, DC, S, EC, PM, 2>;
         e.lds_floats_v3 = [](int ns, int g2) {
             const int lay = g2 ? WnV3Lds<SH, 2>::floats(ns) : WnV3Lds<SH, 1>::floats(ns);
-            const int head = WnV3Lds<SH, 1>::pre;
+            const int head = WnV3Lds<SH, 1>::pre + EC * 256;  // + the head lanes' end_conv_2 rows (wn_v3_head)
             return lay > head ? lay : head;
         };
         e.launch_v3 = [](int g2, int grid, size_t lds, hipStream_t st, const WnPlan& p, const WnRun& r) {

@@ -140,52 +140,39 @@ def test_header_is_plain_c(tmp_path):
 
 
 def test_reserved_poll_registers_belong_to_the_hand_scheduled_blocks_only(tmp_path):
-    """csrc/wn_kernel_v3.h keeps two sets of request registers in v[152:167] across its inline-assembly blocks (loads into them
-    may still be in flight when a block ends).  That is only sound while the compiler's own allocation stays below them: every
-    instruction of the variant-3 kernels that names one of them must be one the blocks contain (a load INTO them, a tag compare
-    or the sum of their values)."""
-    import shutil
+    """csrc/wn_kernel_v3.h keeps request sets and the tap FIFO in v[152:167] across its inline-assembly blocks (loads into them may
+    still be in flight when a block ends).  The kernels carry amdgpu_num_vgpr, so the compiler cannot allocate those registers;
+    build.py verifies that on the disassembly of every library it builds and refuses to install one that breaks it.  Here: the
+    installed library passes the check, and the check does reject the patterns it is there for."""
     import sys
     sys.path.insert(0, os.path.join(ROOT, "pytorch-wavenet_amd"))
     import build
-    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
-    if not os.path.exists(objdump):
-        pytest.skip("llvm-objdump not found")
-    so = shutil.copy(build.build_hip(), tmp_path / "lib.so")
-    subprocess.check_call([objdump, "--offloading", str(so)], cwd=tmp_path, stdout=subprocess.DEVNULL)
-    co = [f for f in os.listdir(tmp_path) if "gfx950" in f]
-    assert len(co) == 1, os.listdir(tmp_path)
-    dis = subprocess.check_output([objdump, "-d", str(tmp_path / co[0])]).decode()
-    reserved = set(range(152, 168))
-    allowed = {"global_load_dwordx2", "v_cmp_eq_u32_e32", "v_cmp_eq_u32_e64", "v_add_f32_e32",   # the critical group's request sets
-               "global_load_dword", "v_mov_b32_e32"}                                               # the queue group's tap FIFO
-    seen_kernel = False
-    current = None
-    for line in dis.splitlines():
-        m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
-        if m:
-            current = m.group(1)
-            continue
-        if not current or "wn_generate_kernel_v3m" not in current:
-            continue
-        seen_kernel = True
-        text = line.split("//")[0].strip()
-        if not text:
-            continue
-        regs = set(int(x) for x in re.findall(r"\bv(\d+)\b", text))
-        for a, b in re.findall(r"\bv\[(\d+):(\d+)\]", text):
-            regs.update(range(int(a), int(b) + 1))
-        if regs & reserved:
-            op = text.split()[0]
-            assert op in allowed, "compiler-allocated use of a reserved poll register in %s: %s" % (current, text)
-            if op == "global_load_dwordx2":  # only ever as the destination
-                dst = text.split()[1].rstrip(",")
-                assert re.match(r"v\[1(5[2-9]|6[0-7]):1(5[2-9]|6[0-7])\]", dst), text
-                rest = text.split(",", 1)[1]
-                assert not (set(int(x) for x in re.findall(r"\bv(\d+)\b", rest)) & reserved), text
-            if op == "global_load_dword":    # destination v152-v157 only
-                assert text.split()[1].rstrip(",") in ("v152", "v153", "v154", "v155", "v156", "v157"), text
-                assert not (set(int(x) for x in re.findall(r"\bv(\d+)\b", text.split(",", 1)[1])) & reserved), text
-            if op == "v_mov_b32_e32":        # source only
-                assert int(text.split()[1].rstrip(",").lstrip("v")) not in reserved, text
-    assert seen_kernel
+    assert os.path.exists(build.OBJDUMP), "llvm-objdump is part of the ROCm image: the register check must not be skipped"
+    assert build.check_hand_scheduled_registers(build.build_hip()) >= 2   # one kernel per form (and shape)
+
+    fake = tmp_path / "objdump.py"   # a stand-in disassembler: feeds the checker hand-written listings
+
+    def run(body):
+        listing = "0000000000001000 <_Z22wn_generate_kernel_v3mILi128EEv6WnPlan5WnRun>:\n" + "".join("\t%s   // 0: 0\n" % ln for ln in body)
+        (tmp_path / "listing.txt").write_text(listing)
+        fake.write_text("#!/usr/bin/env python3\nimport sys, os\n"
+                        "if '--offloading' in sys.argv: open('x.gfx950', 'w').close()\n"
+                        "else: sys.stdout.write(open(%r).read())\n" % str(tmp_path / "listing.txt"))
+        fake.chmod(0o755)
+        lib = tmp_path / "dummy.so"
+        lib.write_bytes(b"")
+        return build.check_hand_scheduled_registers(str(lib), objdump=str(fake))
+
+    good = ["global_load_dwordx2 v[152:153], v1, s[2:3] sc1", "v_cmp_eq_u32_e32 vcc, s5, v153", "v_add_f32_e32 v3, v3, v152",
+            "global_load_dword v154, v[4:5], off", "v_mov_b32_e32 v7, v154", "v_cmp_eq_u32_e64 s[8:9], s5, v155"]
+    assert run(good) == 1
+    for bad in ("v_mov_b64_e32 v[156:157], s[18:19]",            # the compiler parking a value there
+                "v_add_f32_e32 v152, v3, v4",                     # a reserved register as a destination
+                "v_mov_b32_e32 v160, v3",
+                "v_cmp_eq_u32_e32 vcc, v153, v9",                 # ... in the wrong operand position
+                "global_load_dwordx2 v[10:11], v[152:153], off",  # ... as an address
+                "global_load_dword v158, v[4:5], off",            # FIFO entries are v152-v157
+                "v_mov_b32_e32 v3, v168",                         # beyond what a 768-thread workgroup leaves a lane
+                "scratch_load_dword v3, off, off"):               # a spill
+        with pytest.raises(RuntimeError):
+            run(good + [bad])
