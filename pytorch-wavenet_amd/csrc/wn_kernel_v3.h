@@ -991,55 +991,188 @@ static __device__ void wn_v3_head(const WnPlan& p, const WnRun& r, WnCtx& cx, fl
     }
 }
 
-// Sampler role (threads 0-255; workgroup j of n_smp serves the streams s = j mod n_smp): like wn_v2_sampler it turns the head's
+// ---- one-wave sampling: C = 256 classes, lane i holds the four CONSECUTIVE classes 4i .. 4i+3 (wavenet_model.py:280-294).
+// The four-wave sampler (wn_sample_v2: one class per lane) spends 1.65 us per token, most of it in six workgroup barriers and LDS
+// round trips between its waves (profiles/r03_ablations_two_streams_form_and_ring_tail.txt); a first one-wave version that kept its
+// arithmetic register by register (lane i: classes i, i+64, ...) was issue bound -- four of every wave-level reduction and scan in one
+// instruction stream: 2.0 us.  Here a lane reduces its own four classes first, so there is ONE wave-level max, sum and float64 scan
+// (DPP inside the 16-lane rows, row_bcast across them) and no LDS at all.  The probabilities are the same floats up to the order of
+// the float32 sum behind 1 / sum (1 ulp), the CDF the same float64 sums up to their order: an index can only differ from the
+// four-wave sampler's where the uniform sits within ~1e-7 of a CDF boundary -- an order of magnitude inside what the logits' own
+// rounding (2e-6 against the reference) moves those boundaries.
+template <int CTRL, int ROWS>  // value of the DPP source lane in the rows of ROWS (a row mask), 0.0 elsewhere
+static __device__ __forceinline__ double wn_dpp_rows_f64(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROWS, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROWS, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+static __device__ __forceinline__ int wn_sample_1w(const WnRun& r, const float (&logit)[4], int lane, double u, bool greedy, float temperature) {
+    float x[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        x[k] = logit[k];
+        if (r.reg) x[k] -= r.reg[4 * lane + k];
+        if (!greedy) x[k] = x[k] / temperature;
+    }
+    const float gm = wn_wave_max(fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3])));
+    if (greedy) {  // first index of the maximum (torch.max semantics)
+        const int mine = x[0] == gm ? 4 * lane : x[1] == gm ? 4 * lane + 1 : x[2] == gm ? 4 * lane + 2 : x[3] == gm ? 4 * lane + 3 : 0x7fffffff;
+        return wn_wave_min_i(mine);
+    }
+    float pk[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) pk[k] = expf(x[k] - gm);
+    const float tot = wn_wave_sum(((pk[0] + pk[1]) + pk[2]) + pk[3]);
+    const float inv = 1.0f / tot;
+    // inclusive float64 scan (np.cumsum): inside the lane, then over the lanes' totals
+    double c[4];
+    c[0] = (double)(pk[0] * inv);
+    c[1] = c[0] + (double)(pk[1] * inv);
+    c[2] = c[1] + (double)(pk[2] * inv);
+    c[3] = c[2] + (double)(pk[3] * inv);
+    double run = c[3];
+    run += wn_row_shr_f64<1>(run);
+    run += wn_row_shr_f64<2>(run);
+    run += wn_row_shr_f64<4>(run);
+    run += wn_row_shr_f64<8>(run);
+    run += wn_dpp_rows_f64<0x142, 0xA>(run);  // row_bcast:15 into rows 1 and 3
+    run += wn_dpp_rows_f64<0x143, 0xC>(run);  // row_bcast:31 into rows 2 and 3
+    const double total = wn_lane_d(run, 63);
+    const double before = __hiloint2double(wn_dpp_i<0x138>(__double2hiint(run)), wn_dpp_i<0x138>(__double2loint(run)));  // wave_shr:1 -- the classes before this lane's (lane 0: 0.0)
+    // searchsorted(cdf / cdf[-1], u, side='right') = the number of classes with cdf / total <= u.  The quotient only has to be formed
+    // where the comparison is within rounding of the boundary: cdf <= u total (1 - 2^-50) implies cdf / total < u, cdf > u total (1 + 2^-50)
+    // implies cdf / total > u + ulp -- the float64 division (four per lane, ~25 instructions each) is taken on the rare wave that holds a
+    // lane in between, and then by all its lanes: the count is the one the division gives, always.
+    const double ut = u * total;
+    const double lo = ut * (1. - 0x1p-50), hi = ut * (1. + 0x1p-50);
+    double cdf[4];
+    bool le[4], unsure = false;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        cdf[k] = k == 3 ? run : before + c[k];
+        le[k] = cdf[k] <= lo;
+        unsure = unsure || (cdf[k] > lo && cdf[k] <= hi);
+    }
+    if (__builtin_amdgcn_ballot_w64(unsure) != 0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) le[k] = cdf[k] / total <= u;
+    }
+    int idx = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) idx += __popcll(__builtin_amdgcn_ballot_w64(le[k]));
+    return idx > 255 ? 255 : idx;
+}
+
+// the partial logits of N head slices (h0 ..) for this lane's four consecutive classes (32 contiguous bytes per slice: two 16-byte
+// loads), re-requested together until all carry the tag; added to logit[] in the order h0, h0 + 1, ... (bounded like wn_poll_fixed)
+template <int N>
+static __device__ __forceinline__ void wn_poll_logits(WnCtx& cx, __amdgpu_buffer_rsrc_t rs_gl, unsigned lane32, int h0, int s, int ns, uint32_t tag, long long e,
+                                                      float (&logit)[4]) {
+    if (cx.fail) return;
+    unsigned spins = 0;
+    for (;;) {
+        wn_v4i v[N][2];
+#pragma unroll
+        for (int j = 0; j < N; ++j)
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                v[j][q] = __builtin_amdgcn_raw_buffer_load_b128(rs_gl, lane32, (unsigned)((((size_t)(h0 + j) * ns + s) * 256) * 8 + 16 * q), 16);  // sc1
+        unsigned stale = 0;  // tags only ever grow towards `tag`: any difference is a stale granule
+#pragma unroll
+        for (int j = 0; j < N; ++j)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) stale |= ((uint32_t)v[j][q].y ^ tag) | ((uint32_t)v[j][q].w ^ tag);
+        if (__builtin_amdgcn_ballot_w64(stale != 0u) == 0) {
+#pragma unroll
+            for (int j = 0; j < N; ++j)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    logit[2 * q] += __int_as_float(v[j][q].x);
+                    logit[2 * q + 1] += __int_as_float(v[j][q].z);
+                }
+            return;
+        }
+        if ((++spins & 127u) == 0u) {
+            if (__hip_atomic_load(cx.p->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { cx.fail = 1; return; }
+            const long long now = (long long)wall_clock64();
+            if (spins == 128u) cx.t_start = now;
+            else if (now - cx.t_start > cx.r->timeout_ticks) { wn_give_up(cx, WN_W_LOGITS, e, s); return; }
+        }
+    }
+}
+
+// Sampler role (ONE wave: threads 0-63 of the workgroup; workgroup j of n_smp serves the streams s = j mod n_smp): turns the head's
 // partial logits of evaluation e-1 into the class index that enters evaluation e (teacher forced while priming) -- and then does
 // layer 0's start_conv itself: the row of start_conv^T for that class (+ bias) goes out as layer 0's input granules g0[s][R]
 // (tag e+1, 16-byte pairs), so that layer 0 consumes a ready vector like every other layer (wavenet_model.py:127, 300-302).
+// start_conv^T ([C][R] floats) is copied into the workgroup's LDS at start when it fits (p.start_in_lds: 128 KB at R = 128): the row
+// gather after the draw is an LDS read instead of a dependent L2 / HBM load.
 template <class SH>
-static __device__ void wn_v3_sampler(const WnPlan& p, const WnRun& r, WnCtx& cx, float* lds_smp, int j) {
-    constexpr int R = SH::R;
-    static_assert(R <= 256 && R % 2 == 0, "one start_conv row per sampler workgroup");
-    const int tid = threadIdx.x, ns = p.n_streams;
-    int* failflag = reinterpret_cast<int*>(lds_smp + 48);
-    int* locflags = reinterpret_cast<int*>(lds_smp + 52);
-    if (tid == 0) {
-        *failflag = 0;
-        const int mine = wn_xcc_id();
-        __hip_atomic_store(p.xcc_tab + cx.w, (unsigned)(mine + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        locflags[0] = p.allow_plain ? (int)wn_same_xcd(cx, mine, 0, p.P) : 0;  // the row feeds every slice of layer 0
+static __device__ void wn_v3_sampler(const WnPlan& p, const WnRun& r, WnCtx& cx, float* lds_smp, float* lds_tab, int j) {
+    constexpr int R = SH::R, NP = (R / 2 + 63) / 64;  // pairs of row elements per lane
+    static_assert(R <= 256 && R % 4 == 0, "one start_conv row per sampler wave, copied as float4");
+    const int lane = threadIdx.x, ns = p.n_streams;  // (the caller lets only wave 0 in)
+    const int mine = wn_xcc_id();
+    if (lane == 0) __hip_atomic_store(p.xcc_tab + cx.w, (unsigned)(mine + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool local_i = p.allow_plain && wn_same_xcd(cx, mine, 0, p.P);  // the row feeds every slice of layer 0  (wave-uniform)
+    const __amdgpu_buffer_rsrc_t rs_g0 = wn_rsrc(p.g0), rs_gl = wn_rsrc(p.gl);
+    const float* tab = p.start_t;
+    if (p.start_in_lds) {
+        const float4* src = reinterpret_cast<const float4*>(p.start_t);
+        float4* dst = reinterpret_cast<float4*>(lds_tab);
+        for (int i = lane; i < 256 * R / 4; i += 64) dst[i] = src[i];
+        tab = lds_tab;
     }
-    wn_lds_barrier();
-    const bool local_i = locflags[0] != 0;
-    const __amdgpu_buffer_rsrc_t rs_g0 = wn_rsrc(p.g0);
-    const float bias0 = (p.start_b && tid < R) ? p.start_b[tid] : 0.f;
+    float bias0[NP][2];
+#pragma unroll
+    for (int m = 0; m < NP; ++m) {
+        const int pi = lane + 64 * m;
+        bias0[m][0] = (p.start_b && 2 * pi < R) ? p.start_b[2 * pi] : 0.f;
+        bias0[m][1] = (p.start_b && 2 * pi < R) ? p.start_b[2 * pi + 1] : 0.f;
+    }
     long long* park = reinterpret_cast<long long*>(lds_smp + 64);
+    const unsigned lane32 = (unsigned)lane * 32;  // byte offset of the lane's four granules inside a slice's 256
     for (long long e = 1; e <= r.n_eval; ++e) {
         for (int s = j; s < ns; s += p.n_smp) {
             const long long item = (e - 1) * ns + s;  // stamps (diagnostics): 0 start of the wait, 1 logits complete, 2 row published
             wn_stamp(r, park, item, 0);
-            const float logit = wn_poll_sum<16>(cx, p.gl + (size_t)s * 256 + tid, (size_t)ns * 256, p.PA, (uint32_t)e, WN_W_LOGITS, e, s);
-            if (wn_barrier_failed(cx, failflag)) return;
+            float logit[4] = {0.f, 0.f, 0.f, 0.f};
+            {   // the PA partial logits of the stream, summed in the order h = 0 .. PA-1
+                int h = 0;
+                for (; p.PA - h >= 8; h += 8) wn_poll_logits<8>(cx, rs_gl, lane32, h, s, ns, (uint32_t)e, e, logit);
+                if (p.PA - h >= 4) { wn_poll_logits<4>(cx, rs_gl, lane32, h, s, ns, (uint32_t)e, e, logit); h += 4; }
+                if (p.PA - h >= 2) { wn_poll_logits<2>(cx, rs_gl, lane32, h, s, ns, (uint32_t)e, e, logit); h += 2; }
+                if (p.PA - h >= 1) wn_poll_logits<1>(cx, rs_gl, lane32, h, s, ns, (uint32_t)e, e, logit);
+            }
+            if (cx.fail) return;
             wn_stamp(r, park, item, 1);
             int idx;
             if (e < r.n_given) {
                 idx = r.first[(size_t)s * r.n_given + e];
             } else {
                 const long long g = e - r.n_given;
-                if (r.dbg_logits) r.dbg_logits[((size_t)s * r.num_samples + g) * 256 + tid] = logit;
+                if (r.dbg_logits) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) r.dbg_logits[((size_t)s * r.num_samples + g) * 256 + 4 * lane + k] = logit[k];
+                }
                 const float temp = r.stream_temps ? r.stream_temps[s] : r.temperature;
                 const bool greedy = r.greedy != 0 || !(temp > 0.f);
                 const double u = greedy ? 0. : r.uniforms[(size_t)s * r.num_samples + g];
-                idx = wn_sample_v2(cx, lds_smp, logit, u, greedy, temp);
-                if (tid == 0) r.out_idx[(size_t)s * r.num_samples + g] = idx;
+                idx = wn_sample_1w(r, logit, lane, u, greedy, temp);
+                if (lane == 0) r.out_idx[(size_t)s * r.num_samples + g] = idx;
             }
             if (e < r.n_eval) {
-                const float v = tid < R ? p.start_t[(size_t)idx * R + tid] + bias0 : 0.f;
-                const float v1 = wn_dpp<0xB1>(v);  // quad_perm [1,0,3,2]: the odd neighbour's element
-                if (tid < R && (tid & 1) == 0) wn_st_pair(rs_g0, (unsigned)(((size_t)s * R + tid) * 8), (uint32_t)(e + 1), v, v1, local_i);
+#pragma unroll
+                for (int m = 0; m < NP; ++m) {
+                    const int pi = lane + 64 * m;
+                    if (2 * pi < R) {
+                        const float2 v = *reinterpret_cast<const float2*>(tab + (size_t)idx * R + 2 * pi);
+                        wn_st_pair(rs_g0, (unsigned)(((size_t)s * R + 2 * pi) * 8), (uint32_t)(e + 1), v.x + bias0[m][0], v.y + bias0[m][1], local_i);
+                    }
+                }
             }
             wn_stamp(r, park, item, 2);
             wn_stamp_flush(r, park, cx.w, item);
-            wn_lds_barrier();
         }
     }
 }
@@ -1066,9 +1199,9 @@ void wn_generate_kernel_v3m(WnPlan p, WnRun r) {
         wn_v3_layer<SH, P, G>(p, r, cx, wn_lds3m, w / P, w % P);
         return;
     }
-    if (threadIdx.x >= WN_THREADS) return;  // head and sampler roles are 256-thread roles (wn_kernel_v2.h)
+    if (threadIdx.x >= WN_THREADS) return;  // the head role is a 256-thread role, the sampler role a one-wave role
     if (w < n_layer_wg + p.PA * p.HR) wn_v3_head<SH, P>(p, r, cx, wn_lds3m, w - n_layer_wg);
-    else wn_v3_sampler<SH>(p, r, cx, wn_lds3m + WnV3Lds<SH, 1>::smp, w - n_layer_wg - p.PA * p.HR);
+    else if (threadIdx.x < 64) wn_v3_sampler<SH>(p, r, cx, wn_lds3m + WnV3Lds<SH, 1>::smp, wn_lds3m + WnV3Lds<SH, 1>::pre, w - n_layer_wg - p.PA * p.HR);
 }
 
 #endif  // WN_KERNEL_V3_H

@@ -330,7 +330,10 @@ static inline void wn_make_wg_map(int n_wg, int n_xcd, std::vector<int32_t>& map
 }
 
 // Layer-aligned placement: every layer's P workgroups (and the head's PA) sit on ONE XCD, so that most hand-offs
-// stay inside one XCD's L2.  XCD 0 hosts the head and the first layers (head -> L0 stays local too).
+// stay inside one XCD's L2.  XCD 0 hosts the head, the samplers, the first layers (sampler -> L0 stays local) AND the last layer:
+// the last layer's skip lanes -- S granules from each of its P slices, the widest hand-off of the ring -- reach the head without
+// crossing an XCD boundary (round 3; the ring crosses as many boundaries as before, the crossing moved to the narrow x' hand-off
+// in front of the last layer).
 // map[b] = chain position of block b, or -1 (bystander).  Returns false if the layers do not fit that way.
 static inline bool wn_make_wg_map_layers(int NL, int P, int PA, int n_smp, int n_xcd, int cu_per_xcd, std::vector<int32_t>& map,
                                          int* n_blocks) {
@@ -339,16 +342,20 @@ static inline bool wn_make_wg_map_layers(int NL, int P, int PA, int n_smp, int n
     for (int used = 1; used <= n_xcd; ++used) {
         std::vector<std::vector<int>> S(n_xcd);
         for (int h = 0; h < PA + n_smp; ++h) S[0].push_back(NL * P + h);  // head, then samplers
+        const int tail = (used > 1 && NL >= 2 && (cu_per_xcd - (int)S[0].size()) / P >= 2) ? 1 : 0;  // the last layer next to the head
+        const int body = NL - tail;
         int next = 0;
         for (int x = 0; x < used; ++x) {
-            const int cap = (cu_per_xcd - (int)S[x].size()) / P;
-            const int want = wn_cdiv(NL - next, used - x);
+            const int cap = (cu_per_xcd - (int)S[x].size()) / P - (x == 0 ? tail : 0);
+            const int want = wn_cdiv(body - next, used - x);
             const int take = want < cap ? want : cap;
             for (int l = next; l < next + take; ++l)
                 for (int c = 0; c < P; ++c) S[x].push_back(l * P + c);
             next += take;
         }
-        if (next < NL) continue;
+        if (next < body) continue;
+        for (int l = body; l < NL; ++l)
+            for (int c = 0; c < P; ++c) S[0].push_back(l * P + c);
         size_t per = 0;
         for (int x = 0; x < n_xcd; ++x) per = S[x].size() > per ? S[x].size() : per;
         *n_blocks = (int)per * n_xcd;

@@ -102,6 +102,7 @@ struct WnV2Entry {
     // [g2]: 0 = one stream per pipeline item of a layer workgroup, 1 = two (wn_v3_mode)
     const void* fn_v3[2];
     int (*lds_floats_v3)(int ns, int g2);
+    int lds_pre_v3;  // float offset of the per-stream area = what head / sampler workgroups use in front of their own tables
     void (*launch_v3)(int g2, int grid, size_t lds, hipStream_t st, const WnPlan& p, const WnRun& r);
 };
 
@@ -179,14 +180,18 @@ static WnV2Entry wn_v2_entry() {
         hipLaunchKernelGGL((wn_generate_kernel_v2<R, DC, S, EC>), dim3(grid), dim3(WN_THREADS), lds, st, p, r);
     };
     e.pack = wn_pack_v2<SH>;
-    e.fn_v3[0] = e.fn_v3[1] = nullptr; e.lds_floats_v3 = nullptr; e.launch_v3 = nullptr;
+    e.fn_v3[0] = e.fn_v3[1] = nullptr; e.lds_floats_v3 = nullptr; e.launch_v3 = nullptr; e.lds_pre_v3 = 0;
     if constexpr (wn_v3_fits<SH>()) {
         e.fn_v3[0] = (const void*)wn_generate_kernel_v3m<R, DC, S, EC, PM, 1>;
         e.fn_v3[1] = (const void*)wn_generate_kernel_v3m<R, DC, S, EC, PM, 2>;
+        e.lds_pre_v3 = WnV3Lds<SH, 1>::pre;
         e.lds_floats_v3 = [](int ns, int g2) {
             const int lay = g2 ? WnV3Lds<SH, 2>::floats(ns) : WnV3Lds<SH, 1>::floats(ns);
             const int head = WnV3Lds<SH, 1>::pre + EC * 256;  // + the head lanes' end_conv_2 rows (wn_v3_head)
-            return lay > head ? lay : head;
+            const int smp = WnV3Lds<SH, 1>::pre + 256 * R;    // + start_conv^T in the sampler workgroups (wn_v3_sampler), when it fits
+            int need = lay > head ? lay : head;
+            if (smp * 4 <= WN_LDS_MAX_BYTES && smp > need) need = smp;
+            return need;
         };
         e.launch_v3 = [](int g2, int grid, size_t lds, hipStream_t st, const WnPlan& p, const WnRun& r) {
             if (g2) hipLaunchKernelGGL((wn_generate_kernel_v3m<R, DC, S, EC, PM, 2>), dim3(grid), dim3(WN_THREADS_V3), lds, st, p, r);
@@ -516,7 +521,7 @@ extern "C" int wn_create(const wn_config* cfg, wn_handle** out) {
             wn_plan_geometry(pl, P2, PA2);
             pl.n_smp = wn_sampler_count(cfg->n_streams);  // variant 3 always samples on dedicated workgroups (they also feed layer 0)
             pl.n_wg += pl.n_smp;
-            pl.start_in_lds = 0;
+            pl.start_in_lds = (wn_v2_table()[vi3].lds_pre_v3 + 256 * pl.R) * 4 <= WN_LDS_MAX_BYTES ? 1 : 0;  // the samplers' copy of start_conv^T
             h->w0lds = 0;
             h->v3_mode = wn_v3_mode(pl.n_streams);
             if ((h->v3_mode & 2) && pl.NL * P2 + 2 * PA2 + pl.n_smp <= n_cu) {  // a second set of head workgroups

@@ -65,9 +65,19 @@ def test_layer_aligned_placement(harness, NL, P, heads, n_smp):
     per_xcd = [sum(1 for w in used if xcd[w] == x) for x in range(8)]
     assert max(per_xcd) <= 32
     order = [xcd[l * P] for l in range(NL)]
-    assert order == sorted(order)  # the token crosses an XCD boundary at most 7 times on its way down
     n_used = len(set(order))
     assert (n_used - 1) * 32 < n_wg  # no more XCDs than needed
+    # the token moves down through the XCDs in order; the LAST layer sits next to the head on XCD 0 when the chain spans several
+    # XCDs and XCD 0 has room for two layers (its skip lanes are the widest hand-off of the ring): the ring still crosses exactly
+    # n_used boundaries per trip
+    if n_used > 1 and order[-1] == 0:
+        assert order[:-1] == sorted(order[:-1]) and order[-2] == n_used - 1
+    else:
+        assert order == sorted(order)
+    crossings = sum(1 for a, b in zip(order, order[1:]) if a != b) + (1 if order[-1] != 0 else 0)  # ... + last layer -> head on XCD 0
+    assert crossings == (n_used if n_used > 1 else 0)
+    if n_used > 1 and (32 - heads - n_smp) // P >= 2:
+        assert order[-1] == 0
 
 
 def test_placement_refuses_what_does_not_fit(harness):
