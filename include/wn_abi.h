@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define WN_ABI_VERSION 1
+#define WN_ABI_VERSION 2  /* 2: wn_train_loss; wn_info reports the form of the chain (streams_per_item, head_replicas, n_samplers) */
 
 enum {
     WN_OK = 0,
@@ -126,6 +126,10 @@ typedef struct wn_info {
     int32_t n_chains;        /* independent chains (persistent kernels) the streams are split over: 1; an even number that share
                                 the CUs two by two (variant 2); or the rounds of up to 128 streams a variant-3 job beyond one
                                 chain's capacity runs one after the other; n_workgroups and the byte counts are totals over them */
+    int32_t streams_per_item; /* the FORM that runs (variant 3; 1 elsewhere): streams a layer workgroup processes per pipeline item */
+    int32_t head_replicas;    /* ... replicas of the head workgroups (replica j serves the streams s = j mod head_replicas) */
+    int32_t n_samplers;       /* ... dedicated sampler workgroups (0: layer 0 samples itself, single-stream kernels of variant 1 / 2) */
+    int32_t dev_overrides;    /* 1 iff WN_TESTING=1 let a development override (WN_KERNEL, WN_V3_MODE, ...) change what the planner chose */
 } wn_info;
 
 typedef struct wn_handle wn_handle;

@@ -24,6 +24,9 @@
 #include "wn_kernel.h"
 
 
+#if !defined(WN_EXPERIMENT) && (defined(WN_MULTI_SLEEP) || defined(WN_ABL))
+#error "WN_ABL / WN_MULTI_SLEEP are experiment switches: they need -DWN_EXPERIMENT (never set by build.py)"
+#endif
 #ifndef WN_MULTI_SLEEP
 #define WN_MULTI_SLEEP 0
 #endif

@@ -55,6 +55,11 @@
 #define WN_V3_MIN_STREAMS 1
 #define WN_V3_TAP_AHEAD 6
 #define WN_V3_COMPILER_VGPRS 152  // v152-v167: request sets of the input poll / the queue group's tap FIFO (see wn_ap_*, wn_q_*)
+// ---- experiment switches.  A product build (build.py) leaves every one of them at its default; setting one requires -DWN_EXPERIMENT,
+// which build.py never passes (tools/ builds the A/B variants): a library with wrong-on-purpose timing ablations cannot ship by accident.
+#if !defined(WN_EXPERIMENT) && (defined(WN_V3_QDOT_EARLY) || defined(WN_V3_SKIP_SLEEP) || defined(WN_V3_ABL) || defined(WN_V3_PAIR_ROWS) || defined(WN_V3_PRIO))
+#error "WN_V3_* experiment switches need -DWN_EXPERIMENT"
+#endif
 #ifndef WN_V3_QDOT_EARLY
 #define WN_V3_QDOT_EARLY 0  // 1: a late layer's tap-0 dot runs between barriers A and B (next to the critical group's dot) instead of after B;
                             // 2: only in the two-streams-per-item form
@@ -268,7 +273,9 @@ static __device__ __forceinline__ void wn_ap_spin1(unsigned off, const wn_u64* p
 // (rows of large-d layers miss the L2).  Held in a C++ array the FIFO is loop carried, and the compiler's wait in front of the
 // OLDEST entry is a wait for the YOUNGEST one, requested one item ago: layers with d >= 128 ran 0.06-0.12 us per item slower than
 // the others and set the pace of the 64-stream chain (tools/dilation_probe.py: all dilations <= 64: 930 k samples/s, cfg3: 837 k;
-// three entries hand-scheduled: cfg3 881 k, d <= 128 as fast as d = 1; profiles/r02_v3_tap_fifo.txt).  The entries live in
+// three entries hand-scheduled: cfg3 881 k, d <= 128 as fast as d = 1; profiles/r02_v3_tap_fifo.txt).  The loads carry sc1 (served by the
+// L2, never by this CU's L1): the row was pushed by ANOTHER wave of the workgroup with a plain store as little as one item (two LDS-only
+// barriers) earlier, and the L2 is where that store is ordered with this load.  The entries live in
 // v152-v157 of the queue waves (the critical waves' request sets are other waves' registers of the same numbers).
 // A wave's vector-memory operations per item, in program order: push store (window A), [take], tap load (window B); so the entry
 // taken at item i has AHEAD-1 younger loads and AHEAD younger stores: s_waitcnt vmcnt(2 AHEAD - 1); in the first AHEAD-1 items
@@ -276,7 +283,7 @@ static __device__ __forceinline__ void wn_ap_spin1(unsigned off, const wn_u64* p
 #define WN_Q_STR2(x) #x
 #define WN_Q_STR(x) WN_Q_STR2(x)
 #define WN_Q_ISSUE_CASE(SL, REG) \
-    if constexpr (SLOT == SL) asm volatile("global_load_dword v" #REG ", %0, off" ::"v"(ptr) : "v" #REG, "memory")
+    if constexpr (SLOT == SL) asm volatile("global_load_dword v" #REG ", %0, off sc1" ::"v"(ptr) : "v" #REG, "memory")
 #define WN_Q_TAKE_CASE(SL, REG, CNT) \
     if constexpr (SLOT == SL) asm volatile("s_waitcnt vmcnt(%1)\n\tv_mov_b32_e32 %0, v" #REG : "=v"(v) : "n"(CNT) : "memory")
 template <int SLOT>

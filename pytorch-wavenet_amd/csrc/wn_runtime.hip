@@ -23,6 +23,18 @@ static thread_local int g_chain_member = 0;  // wn_create is building one chain 
 #define WN_CHAIN_MIN_STREAMS 16   // below: the chain is latency-bound, splitting does not pay (measured: 16 neutral, 32 +9 %, 64 +44 %)
 #define WN_CHAIN_MAX_STREAMS 40   // streams per chain that still fit two workgroups per CU at cfg3's shape (78 KB LDS)
 
+// Development overrides (WN_KERNEL, WN_V3_MODE, WN_CHAINS, WN_SAMPLERS, WN_NO_LOCAL_STORES) pick another kernel or form than the
+// planner would: they exist for A/B runs and for the tests that pin a form, and are IGNORED unless WN_TESTING=1 is set as well -- a
+// stray variable in a production environment must not silently change what runs (wn_get_info reports the form that does).
+static thread_local int g_dev_env_used = 0;
+static const char* wn_dev_env(const char* name) {
+    const char* t = getenv("WN_TESTING");
+    if (!t || t[0] != '1') return nullptr;
+    const char* v = getenv(name);
+    if (v) g_dev_env_used = 1;
+    return v;
+}
+
 static int wn_fail(int code, const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
@@ -236,7 +248,7 @@ static int wn_v2_choose(const WnPlan& pl, int n_cu, int n_smp, int forced_P, int
 // dedicated sampler workgroups of a multi-stream chain (each serves the streams s = j mod n): 4 by default
 static int wn_sampler_count(int n_streams) {
     int n = 4;
-    const char* e = getenv("WN_SAMPLERS");
+    const char* e = wn_dev_env("WN_SAMPLERS");
     if (e && atoi(e) >= 1 && atoi(e) <= 16) n = atoi(e);
     return n_streams < n ? n_streams : n;
 }
@@ -247,12 +259,12 @@ static int wn_sampler_count(int n_streams) {
 // the LDS and DPP latencies of the dot products -- bound the throughput, and two streams per item share them (every weight
 // operand is used twice) at the price of a longer trip through each stage.  WN_V3_MODE = 0..3 pins a form (A/B runs, tests).
 // (the rule itself is host-only arithmetic in wn_plan.h: wn_v3_mode_for, tests/test_plan_host.py)
-static int wn_v3_mode(int n_streams) { return wn_v3_mode_for(n_streams, getenv("WN_V3_MODE")); }
+static int wn_v3_mode(int n_streams) { return wn_v3_mode_for(n_streams, wn_dev_env("WN_V3_MODE")); }
 
 // true iff the wave-specialised kernel (variant 3) serves this configuration with ONE chain: an instantiated shape, at least
 // two streams, the parked tap-0 sums of all streams fit the LDS next to the activations, one CU per workgroup
 static bool wn_v3_applicable(const wn_config* cfg, int n_cu, int* out_vi, int* outP, int* outPA) {
-    const char* force = getenv("WN_KERNEL");  // "generic" / "v2" pin the older kernels (A/B runs, tests)
+    const char* force = wn_dev_env("WN_KERNEL");  // "generic" / "v2" pin the older kernels (A/B runs, tests)
     if (force && (!strcmp(force, "generic") || !strcmp(force, "v2"))) return false;
     if (cfg->n_streams < WN_V3_MIN_STREAMS) return false;
     WnPlan pl;
@@ -294,6 +306,7 @@ struct wn_handle {
     int v2_index;  // row of wn_v2_table()
     int lds_bytes;
     int v3_mode;   // variant 3: streams per pipeline item (wn_v3_mode)
+    int dev_overrides = 0;  // a development override was in effect when this handle was planned (wn_dev_env)
     int w0lds;     // multi-stream kernel variant with tap-0 weights in LDS (this handle is one of two chains sharing the chip)
     // Two chains: with >= WN_CHAIN_MIN_STREAMS streams the job is split into two independent chains of n_streams/2 streams,
     // each a complete persistent kernel with its own queues and hand-off buffers, launched on two HIP streams.  Their
@@ -359,6 +372,7 @@ extern "C" int wn_create(const wn_config* cfg, wn_handle** out) {
     g_err[0] = 0;
     if (!cfg || !out) return wn_fail(WN_E_BADARG, "wn_create: NULL argument");
     *out = nullptr;
+    if (!g_chain_member) g_dev_env_used = 0;
     if (cfg->layers < 1 || cfg->blocks < 1 || cfg->dilation_channels < 1 || cfg->residual_channels < 1 ||
         cfg->skip_channels < 1 || cfg->end_channels < 1 || cfg->classes < 2 || cfg->n_streams < 1)
         return wn_fail(WN_E_BADARG, "wn_create: non-positive dimension in wn_config");
@@ -383,7 +397,7 @@ extern "C" int wn_create(const wn_config* cfg, wn_handle** out) {
         if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, cfg->device_id) == hipSuccess && khz > 0) wall_khz = khz;
     }
     {   // rounds of the wave-specialised chain (see wn_handle::rounds)
-        const char* ce = getenv("WN_CHAINS");
+        const char* ce = wn_dev_env("WN_CHAINS");
         const bool off = ce && ce[0] == '1';
         wn_config probe = *cfg;
         probe.n_streams = WN_V3_ROUND_STREAMS;
@@ -436,7 +450,7 @@ extern "C" int wn_create(const wn_config* cfg, wn_handle** out) {
     }
     {   // chains sharing the CUs two by two (see wn_handle::chains): 2 chains up to WN_CHAIN_MAX_STREAMS streams each, more
         // chains (run pairwise, one pair after the other on the two HIP streams) for larger jobs
-        const char* ce = getenv("WN_CHAINS");
+        const char* ce = wn_dev_env("WN_CHAINS");
         const bool off = ce && ce[0] == '1';
         const bool forced = ce && ce[0] == '2' && cfg->n_streams >= 4;
         if (!g_chain_member && !off && !wn_v3_applicable(cfg, n_cu, nullptr, nullptr, nullptr) && (cfg->n_streams >= WN_CHAIN_MIN_STREAMS || forced)) {
@@ -512,7 +526,7 @@ extern "C" int wn_create(const wn_config* cfg, wn_handle** out) {
     pl.HR = 1;
     h->variant = 1; h->v2_index = -1;
     {
-        const char* force = getenv("WN_KERNEL");  // "generic" pins the LDS-resident kernel, "v2" the 256-thread register kernels (A/B runs, tests)
+        const char* force = wn_dev_env("WN_KERNEL");  // "generic" pins the LDS-resident kernel, "v2" the 256-thread register kernels (A/B runs, tests)
         int P2 = 0, PA2 = 0;
         const int n_smp = cfg->n_streams > 1 ? wn_sampler_count(cfg->n_streams) : 0;
         int vi3 = -1;
@@ -576,7 +590,7 @@ extern "C" int wn_create(const wn_config* cfg, wn_handle** out) {
     pl.n_blocks = pl.n_wg;
     pl.allow_plain = 0;
     if (h->variant >= 2 && n_cu % 8 == 0 && wn_make_wg_map_layers(pl.NL, pl.P, pl.PA * pl.HR, pl.n_smp, 8, n_cu / 8, wg_map, &pl.n_blocks)) {
-        const char* np = getenv("WN_NO_LOCAL_STORES");
+        const char* np = wn_dev_env("WN_NO_LOCAL_STORES");
         pl.allow_plain = (np && np[0] == '1') ? 0 : 1;
     } else {
         wn_make_wg_map(pl.n_wg, 8, wg_map);
@@ -624,6 +638,7 @@ extern "C" int wn_create(const wn_config* cfg, wn_handle** out) {
                                     hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes),
                 "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
     if (rc) { wn_destroy(h); return rc; }
+    h->dev_overrides = g_dev_env_used;
     *out = h;
     return WN_OK;
 }
@@ -934,6 +949,10 @@ extern "C" int wn_get_info(wn_handle* h, wn_info* out) {
     out->handoff_bytes = (int64_t)h->gran_count * 8;
     out->evals_done = h->t_base;
     out->n_chains = 1;
+    out->streams_per_item = (h->variant == 3 && (h->v3_mode & 1)) ? 2 : 1;
+    out->head_replicas = pl.HR;
+    out->n_samplers = pl.n_smp;
+    out->dev_overrides = h->dev_overrides;
     return WN_OK;
 }
 

@@ -43,11 +43,14 @@ class wn_generate_args(ctypes.Structure):
                 ("stream_temperatures", ctypes.c_void_p)]
 
 
+ABI_VERSION = 2  # include/wn_abi.h: WN_ABI_VERSION
+
+
 class wn_info(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in ("abi_version", "n_layers", "layer_split", "head_split", "n_workgroups",
                                                "lds_bytes", "n_compute_units", "receptive_field")] + \
                [(n, ctypes.c_int64) for n in ("weight_bytes", "queue_bytes", "handoff_bytes", "evals_done")] + \
-               [("kernel_variant", ctypes.c_int32), ("n_chains", ctypes.c_int32)]
+               [(n, ctypes.c_int32) for n in ("kernel_variant", "n_chains", "streams_per_item", "head_replicas", "n_samplers", "dev_overrides")]
 
 
 EXPORTS = ["wn_abi_version", "wn_create", "wn_destroy", "wn_load_weights", "wn_reset", "wn_generate", "wn_wait",
@@ -62,16 +65,14 @@ class wn_train_layout(ctypes.Structure):
 
 
 class Library:
-    """A loaded wn_abi library.  ``host_memory`` is True only for the test emulator (host pointers)."""
+    """A loaded library that exports include/wn_abi.h."""
 
-    def __init__(self, path, host_memory=False):
+    def __init__(self, path):
         self.path = path
-        self.host_memory = host_memory
-        if not host_memory:
-            # One HIP runtime per process: torch bundles its own libamdhip64.so.7; importing torch FIRST makes the loader
-            # resolve our DT_NEEDED libamdhip64.so.7 to that already-loaded copy, so torch's device pointers and streams
-            # are valid in our launches (two runtimes in one process cannot even both open the device).
-            import torch  # noqa: F401
+        # One HIP runtime per process: torch bundles its own libamdhip64.so.7; importing torch FIRST makes the loader
+        # resolve our DT_NEEDED libamdhip64.so.7 to that already-loaded copy, so torch's device pointers and streams
+        # are valid in our launches (two runtimes in one process cannot even both open the device).
+        import torch  # noqa: F401
         self.dll = ctypes.CDLL(path)
         d = self.dll
         for name in EXPORTS:
@@ -103,8 +104,8 @@ class Library:
         for name in EXPORTS:
             if name not in ("wn_destroy", "wn_last_error"):
                 getattr(d, name).restype = ctypes.c_int
-        if d.wn_abi_version() != 1:
-            raise RuntimeError("%s: ABI version %d, expected 1" % (path, d.wn_abi_version()))
+        if d.wn_abi_version() != ABI_VERSION:
+            raise RuntimeError("%s: ABI version %d, expected %d" % (path, d.wn_abi_version(), ABI_VERSION))
 
     def last_error(self):
         return (self.dll.wn_last_error() or b"").decode("utf-8", "replace")
@@ -125,5 +126,5 @@ def load_product_library():
             raise RuntimeError(
                 "mi355_wavenet: %s not found. Build it with `python pytorch-wavenet_amd/build.py` (needs hipcc, "
                 "targets gfx950). The generation path has no CPU/torch fallback." % PRODUCT_LIB)
-        _product = Library(PRODUCT_LIB, host_memory=False)
+        _product = Library(PRODUCT_LIB)
     return _product

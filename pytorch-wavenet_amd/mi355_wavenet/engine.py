@@ -44,25 +44,8 @@ def regularizer_array(classes, regularize):
     return (r.squeeze() * regularize).numpy().astype(np.float32)
 
 
-class _HostMem:
-    """numpy-backed 'device' memory (test emulator only)."""
-    def upload(self, a):
-        return np.ascontiguousarray(a)
-
-    def empty(self, shape, dtype):
-        return np.zeros(shape, dtype=dtype)
-
-    def ptr(self, a):
-        return a.ctypes.data if a is not None else None
-
-    def download(self, a):
-        return np.array(a, copy=True)
-
-    def stream(self):
-        return None
-
-
 class _TorchMem:
+    """Device memory, streams and transfers through PyTorch-ROCm (the memory provider of every product Engine)."""
     def __init__(self, device_index):
         import torch
         self.torch = torch
@@ -86,13 +69,16 @@ class _TorchMem:
 
 
 class Engine:
-    def __init__(self, cfg, weights, n_streams=1, device_index=0, layer_split=0, head_split=0, lib=None):
+    def __init__(self, cfg, weights, n_streams=1, device_index=0, layer_split=0, head_split=0, lib=None, mem=None):
+        """lib / mem: the loaded C-ABI library and the memory provider (upload / empty / ptr / download / stream); the defaults are
+        the HIP library and torch device memory.  (Dependency injection for the host-logic tests, which pass a test double of the C
+        ABI together with ITS memory provider -- tests/double_lib.py; nothing in this package knows about it.)"""
         self.lib = lib if lib is not None else _abi.load_product_library()
         self.cfg = dict(cfg)
         self.n_streams = int(n_streams)
         self.classes = int(cfg.get("classes", 256))
-        if self.lib.host_memory:
-            self.mem = _HostMem()
+        if mem is not None:
+            self.mem = mem
         else:
             import torch
             if not torch.cuda.is_available():

@@ -43,7 +43,7 @@ def pick_device(dist=None, device_index=None, n_devices=None):
 
 
 def generate_streams(cfg, weights, first_samples, num_samples, temperature=1.0, regularize=0.0, uniforms=None,
-                     dist=None, device_index=None, lib=None):
+                     dist=None, device_index=None, lib=None, mem=None):
     """first_samples (S, n_given) ints, uniforms (S, num_samples) float64 or None (greedy).
     Returns int32 (S, num_samples) on rank 0 (and on every rank when dist is None), else None.
     device_index: this rank's HIP device (default: LOCAL_RANK; checked for collisions across ranks, see pick_device)."""
@@ -54,13 +54,13 @@ def generate_streams(cfg, weights, first_samples, num_samples, temperature=1.0, 
     world = dist.get_world_size() if dist is not None else 1
     lo, hi = shard_bounds(S, rank, world)
     mine = None
-    if lib is None or not lib.host_memory:
+    if mem is None:
         import torch
         device_index = pick_device(dist, device_index, torch.cuda.device_count())
     elif device_index is None:
-        device_index = 0  # host-memory test double: no device
+        device_index = 0  # an injected memory provider (tests): no device to pick
     if hi > lo:
-        eng = engine.Engine(cfg, weights, n_streams=hi - lo, device_index=device_index, lib=lib)
+        eng = engine.Engine(cfg, weights, n_streams=hi - lo, device_index=device_index, lib=lib, mem=mem)
         u = None if uniforms is None else np.asarray(uniforms)[lo:hi]
         mine = eng.generate(num_samples, first_samples[lo:hi], temperature=temperature, regularize=regularize, uniforms=u)
         eng.close()

@@ -306,8 +306,9 @@ class WaveNetModel(nn.Module):
         n_prime = num_given - 1
         n_eval = n_prime + num_samples
         a = 0
+        primed_upto = 0  # priming evaluations whose callbacks were already delivered (batched priming)
         if n_prime >= eng.PRIME_BATCH_MIN and eng.prime_host(first[:, :n_prime]):
-            a = n_prime
+            a = primed_upto = n_prime
             if progress_callback is not None:
                 for i in range(0, n_prime, progress_interval):
                     progress_callback(i, total_samples)
@@ -345,7 +346,7 @@ class WaveNetModel(nn.Module):
                 print("one generating step does take approximately " + str((toc - tic) * 0.01) + " seconds)")
             if progress_callback is not None:
                 if ev < n_prime:
-                    if ev % progress_interval == 0:
+                    if ev >= primed_upto and ev % progress_interval == 0:  # (not a second time after batched priming: num_samples == 0)
                         progress_callback(ev, total_samples)
                 elif (ev - n_prime + num_given) % progress_interval == 0:
                     progress_callback(ev - n_prime + num_given, total_samples)
@@ -432,7 +433,7 @@ class WaveNetModel(nn.Module):
     def __setstate__(self, state):
         """Also accepts snapshots pickled by the REFERENCE's class (torch.save(model), wavenet_training.py:84-88 -- its only
         checkpoint format): their __dict__ has no end_channels / bias / engine fields (wavenet_model.py:42-56)."""
-        self.__dict__.update(state)
+        super().__setstate__(state)   # nn.Module back-fills the hook / buffer attributes that a snapshot of an older torch lacks
         d = self.__dict__
         d.setdefault("_wn_engine", None)
         d.setdefault("_wn_engine_key", None)

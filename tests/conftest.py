@@ -9,6 +9,9 @@ for p in (os.path.join(ROOT, "pytorch-wavenet_amd"), os.path.join(ROOT, "oracle"
         sys.path.insert(0, p)
 
 
+os.environ.setdefault("WN_TESTING", "1")  # lets the tests pin kernels / forms (WN_KERNEL, WN_V3_MODE, ...): ignored by the library otherwise
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "reference: needs /root/reference (authoring container only)")

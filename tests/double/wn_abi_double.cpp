@@ -166,6 +166,7 @@ extern "C" int wn_get_info(wn_handle* h, wn_info* out) {
     out->evals_done = h->t_base;
     out->kernel_variant = 0;  // no kernel: the oracle
     out->n_chains = 1;
+    out->streams_per_item = 1; out->head_replicas = 1; out->n_samplers = 0; out->dev_overrides = 0;
     return WN_OK;
 }
 

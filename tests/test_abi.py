@@ -10,7 +10,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from double_lib import double_library
+from double_lib import double_backend, double_library
 from mi355_wavenet import _abi, engine, synth
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -42,14 +42,14 @@ def test_hip_library_builds_and_exports_every_symbol():
         targets = [t for t in bundle.stdout.split() if "amdgcn" in t]
         assert targets and all("gfx950" in t for t in targets), targets
     lib = _abi.Library(so)  # dlopen + prototype check; no device call
-    assert lib.dll.wn_abi_version() == 1
+    assert lib.dll.wn_abi_version() == _abi.ABI_VERSION == 2
 
 
 def test_struct_sizes_match_header():
     assert ctypes.sizeof(_abi.wn_config) == 16 * 4
     assert ctypes.sizeof(_abi.wn_weight_ptrs) == 14 * 8
     assert ctypes.sizeof(_abi.wn_generate_args) == 8 + 8 + 8 + 4 + 4 + 8 * 5 + 4 + 4 + 8
-    assert ctypes.sizeof(_abi.wn_info) == 8 * 4 + 4 * 8 + 8
+    assert ctypes.sizeof(_abi.wn_info) == 8 * 4 + 4 * 8 + 6 * 4
     assert ctypes.sizeof(_abi.wn_train_layout) == 14 * 8
 
 
@@ -106,13 +106,13 @@ def test_double_mirrors_the_state_codes():
 def test_engine_argument_validation():
     cfg = _cfg()
     W = synth.init_weights(cfg, seed=1)
-    eng = engine.Engine(cfg, W, n_streams=2, lib=double_library())
+    eng = engine.Engine(cfg, W, n_streams=2, **double_backend())
     with pytest.raises(ValueError):
         eng.generate(4, np.array([[1, 2, 300], [1, 2, 3]]))
     with pytest.raises(ValueError):
         eng.generate(4, np.zeros((3, 2), dtype=np.int64))
     with pytest.raises(_abi.WnError):
-        engine.Engine(_cfg(kernel_size=0), W, lib=double_library())
+        engine.Engine(_cfg(kernel_size=0), W, **double_backend())
 
 
 def test_product_library_is_the_only_default(monkeypatch):

@@ -12,7 +12,7 @@ import torch
 import c_oracle
 import wavenet_model
 import wavenet_modules
-from double_lib import double_library
+from double_lib import double_backend, double_library
 from mi355_wavenet import engine, synth
 
 
@@ -137,7 +137,7 @@ def _inject_double(m, monkeypatch):
     real = _REAL_ENGINE
 
     def make(cfg, weights, n_streams=1, device_index=0, **kw):
-        return real(cfg, weights, n_streams=n_streams, device_index=device_index, lib=double_library(), **kw)
+        return real(cfg, weights, n_streams=n_streams, device_index=device_index, **double_backend(), **kw)
 
     monkeypatch.setattr(engine, "Engine", make)
 
@@ -181,6 +181,19 @@ def test_generate_fast_progress_callbacks_match_reference_cadence(monkeypatch):
     g1 = m.generate_fast(30, first_samples=first, temperature=0)
     idx, _ = c_oracle.generate(cfg, W, 30, first.numpy(), 0.0, 0.0)
     assert np.array_equal(g1, c_oracle.expand(idx))
+
+
+def test_priming_callbacks_fire_once_each_after_batched_priming(monkeypatch):
+    """generate_fast(0, first_samples=<102 samples>): 101 priming evaluations (batched: >= 64), callbacks at i % 50 == 0 -> 0, 50, 100,
+    each exactly once (wavenet_model.py:259-269) -- the last priming evaluation (100) is also where the job ends."""
+    m, cfg, W = _model("tiny", 68)
+    _inject_double(m, monkeypatch)
+    first = torch.from_numpy(np.random.RandomState(68).randint(0, 256, 102))
+    calls = []
+    out = m.generate_fast(0, first_samples=first, temperature=0, progress_callback=lambda s, t: calls.append((s, t)), progress_interval=50)
+    assert out.shape == (0,)
+    assert m._wn_last_prime_batched
+    assert calls == [(0, 102), (50, 102), (100, 102)]
 
 
 def test_generate_fast_multi_stream_extension(monkeypatch):
@@ -234,9 +247,20 @@ def test_snapshot_pickled_by_the_reference_class_loads_and_generates(monkeypatch
                              max_length=q.max_length, data=torch.zeros(q.num_channels, q.max_length), dtype=torch.FloatTensor))
         ref_queues.append(rq)
     state["dilated_queues"] = ref_queues
+    # ... and a snapshot of an OLD torch (the reference pins 0.3) lacks the hook / buffer bookkeeping newer nn.Modules expect:
+    # nn.Module.__setstate__ back-fills it, so our __setstate__ must go through it (the first forward() dies otherwise)
+    stripped = [k for k in ("_backward_pre_hooks", "_forward_hooks_with_kwargs", "_forward_hooks_always_called", "_forward_pre_hooks_with_kwargs",
+                            "_state_dict_pre_hooks", "_load_state_dict_post_hooks", "_non_persistent_buffers_set") if k in state]
+    assert stripped
+    for k in stripped:
+        state.pop(k)
     m2 = wavenet_model.WaveNetModel.__new__(wavenet_model.WaveNetModel)
     m2.__setstate__(state)
     assert m2.end_channels == cfg["end_channels"] and m2.bias is False and m2._wn_engine is None
+    assert all(hasattr(m2, k) for k in stripped)
+    x = torch.zeros(1, 256, m2.receptive_field + m2.output_length - 1)
+    x[0, 128, :] = 1.0
+    assert m2(x).shape == (m2.output_length, 256)   # forward() through nn.Module.__call__ (hooks machinery) works
     _inject_double(m2, monkeypatch)
     a = m2.generate_fast(20, temperature=0)
     idx, _ = c_oracle.generate(cfg, W, 20, None, 0.0, 0.0)

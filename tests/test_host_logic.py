@@ -7,14 +7,14 @@ import numpy as np
 
 import c_oracle
 import restated
-from double_lib import double_library
+from double_lib import double_backend, double_library
 from mi355_wavenet import engine
 from parity_common import check_engine, make_case
 
 
 def test_engine_wrapper_round_trip_multi_stream():
     cfg, W, first, uniforms = make_case("tiny_bias", 41, 3, 25, 60)
-    eng = engine.Engine(cfg, W, n_streams=3, lib=double_library())
+    eng = engine.Engine(cfg, W, n_streams=3, **double_backend())
     check_engine(eng, cfg, W, 60, first, 0.0, 0.0, None, "double greedy")
     check_engine(eng, cfg, W, 60, first, 0.85, 0.0015, uniforms, "double sampled")
     eng.close()
@@ -22,7 +22,7 @@ def test_engine_wrapper_round_trip_multi_stream():
 
 def test_default_first_sample_and_no_priming():
     cfg, W, _, uniforms = make_case("tiny", 42, 1, 1, 80)
-    eng = engine.Engine(cfg, W, lib=double_library())
+    eng = engine.Engine(cfg, W, **double_backend())
     idx = eng.generate(80, None, temperature=1.0, uniforms=uniforms)
     o_idx, _ = c_oracle.generate(cfg, W, 80, None, 1.0, 0.0, uniforms[0])  # first_samples=None -> [classes//2]
     assert np.array_equal(idx[0], o_idx)
@@ -32,7 +32,7 @@ def test_continuation_equals_one_shot():
     """generate(N) == generate(a) then generate(N-a, first=[last], reset=False): how the facade implements
     progress callbacks (wavenet_model.py:308-311) with one launch per interval."""
     cfg, W, first, uniforms = make_case("tiny_bias", 43, 2, 9, 90)
-    eng = engine.Engine(cfg, W, n_streams=2, lib=double_library())
+    eng = engine.Engine(cfg, W, n_streams=2, **double_backend())
     full = eng.generate(90, first, temperature=1.0, uniforms=uniforms)
     a = eng.generate(37, first, temperature=1.0, uniforms=uniforms[:, :37])
     b = eng.generate(53, a[:, -1:], temperature=1.0, uniforms=uniforms[:, 37:], reset=False)
@@ -44,7 +44,7 @@ def test_batched_priming_hand_over():
     """Engine.generate primes long given windows through wn_prime and continues with n_given = 1 from the last given
     sample: same indices as per-sample priming."""
     cfg, W, first, uniforms = make_case("tiny", 46, 2, engine.Engine.PRIME_BATCH_MIN + 10, 30)
-    eng = engine.Engine(cfg, W, n_streams=2, lib=double_library())
+    eng = engine.Engine(cfg, W, n_streams=2, **double_backend())
     a = eng.generate(30, first, temperature=1.0, uniforms=uniforms, batched_prime=True)
     b = eng.generate(30, first, temperature=1.0, uniforms=uniforms, batched_prime=False)
     assert np.array_equal(a, b)
@@ -56,7 +56,7 @@ def test_export_queue_matches_reference_queue_layout():
     """wn_export_queue hands out DilatedQueue.data / in_pos / out_pos (wavenet_modules.py:43-57) after the same pushes,
     checked against the torch restatement of the reference queue."""
     cfg, W, first, _ = make_case("tiny", 44, 1, 12, 30)
-    eng = engine.Engine(cfg, W, lib=double_library())
+    eng = engine.Engine(cfg, W, **double_backend())
     idx = eng.generate(30, first, temperature=0.0)
     r = restated.RestatedWaveNet(cfg, W)
     _, ridx, _ = r.generate_fast(30, first_samples=first[0], temperature=0.0, return_details=True)
@@ -70,7 +70,7 @@ def test_export_queue_matches_reference_queue_layout():
 
 def test_zero_samples_and_prime_only():
     cfg, W, first, _ = make_case("tiny", 45, 1, 6, 1)
-    eng = engine.Engine(cfg, W, lib=double_library())
+    eng = engine.Engine(cfg, W, **double_backend())
     idx = eng.generate(0, first, temperature=0.0)
     assert idx.shape == (1, 0)
     assert eng.info()["evals_done"] == 5

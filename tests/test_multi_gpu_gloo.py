@@ -17,7 +17,7 @@ def _worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from double_lib import double_library
+    from double_lib import double_backend, double_library
     from mi355_wavenet import streams, synth
     cfg = synth.CONFIGS["tiny_bias"]
     W = synth.init_weights(cfg, seed=81)
@@ -25,7 +25,7 @@ def _worker(rank, world, port, q):
     S, N = 5, 40  # odd stream count: ranks get 3 and 2
     first = rs.randint(0, 256, (S, 7))
     u = rs.random_sample((S, N))
-    out = streams.generate_streams(cfg, W, first, N, temperature=1.0, uniforms=u, dist=dist, lib=double_library())
+    out = streams.generate_streams(cfg, W, first, N, temperature=1.0, uniforms=u, dist=dist, **double_backend())
     if rank == 0:
         q.put(out)
     else:

@@ -197,7 +197,7 @@ def test_trainer_steps_equal_the_reference_loop(dataset_file):
 def test_per_stream_temperatures_through_the_engine_wrapper():
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import c_oracle
-    from double_lib import double_library
+    from double_lib import double_backend, double_library
     from mi355_wavenet import engine, synth
     cfg = synth.CONFIGS["tiny_bias"]
     W = synth.init_weights(cfg, seed=5)
@@ -205,7 +205,7 @@ def test_per_stream_temperatures_through_the_engine_wrapper():
     rs = np.random.RandomState(9)
     first = rs.randint(0, 256, (4, 3))
     u = rs.random_sample((4, 30))
-    eng = engine.Engine(cfg, W, n_streams=4, lib=double_library())
+    eng = engine.Engine(cfg, W, n_streams=4, **double_backend())
     out = eng.generate(30, first, temperature=np.asarray(temps, dtype=np.float32), uniforms=u)
     eng.close()
     for s, t in enumerate(temps):

@@ -8,6 +8,8 @@ Prints, per chain stage: hand-off latency (producer published -> consumer staged
 import os
 import sys
 
+os.environ.setdefault("WN_TESTING", "1")  # dev tool: WN_V3_MODE / WN_KERNEL pins are honoured
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "pytorch-wavenet_amd"))
 import numpy as np  # noqa: E402

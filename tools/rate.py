@@ -4,6 +4,8 @@
 """
 import os
 import sys
+
+os.environ.setdefault("WN_TESTING", "1")  # dev tool: WN_V3_MODE / WN_KERNEL pins are honoured
 import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
