@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py -- generate_fast() throughput of the MI355X engine (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg3x64] [--samples 2000]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg3x64] [--samples 16000]
 
 A "step" is one ``WaveNetModel.generate_fast(--samples, first_samples=(streams, 1), temperature=1.0)`` call per GPU: every
 stream of the workload generates ``--samples`` audio samples.  Two legs are timed with the same K / W:
@@ -33,6 +33,8 @@ WORKLOADS = {  # name -> (BASELINE.json config, streams per GPU)
     "cfg3x128": ("cfg3", 128), # the same model with twice the streams: the chain's throughput form at its best (not a BASELINE config)
     "cfg2x1": ("cfg2", 1),     # configs[1]
     "cfg1x1": ("cfg1", 1),     # configs[0]
+    "cfg2x64": ("cfg2", 64),   # configs[1]'s model as a multi-stream job
+    "chaconnex1": ("chaconne", 1),  # the only trained-model configuration in the reference tree (train_script.py:17-25: 32/32/1024/512, bias)
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 
@@ -96,13 +98,14 @@ def time_engine(cfgname, n_streams, samples, steps, warmup, dist, device):
     if dist:
         dist.barrier()
     t1 = time.perf_counter()
-    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev[0], ev[1])]))
+    kernel_each = [a.elapsed_time(b) for a, b in zip(ev[0], ev[1])]
+    kernel_ms = float(np.mean(kernel_each))
     gather_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev[1], ev[2])]))
     info = eng.info()
     idx = out.cpu().numpy()
     eng.close()
-    return {"wall": t1 - t0, "kernel_ms": kernel_ms, "gather_ms": gather_ms, "info": info, "cfg": cfg, "W": W,
-            "last_idx": idx, "first": first_h, "uniforms": uni_h}
+    return {"wall": t1 - t0, "kernel_ms": kernel_ms, "kernel_ms_median": float(np.median(kernel_each)), "gather_ms": gather_ms, "info": info,
+            "cfg": cfg, "W": W, "last_idx": idx, "first": first_h, "uniforms": uni_h}
 
 
 def time_facade(cfgname, n_streams, samples, steps, warmup, dist, device):
@@ -144,19 +147,22 @@ def time_facade(cfgname, n_streams, samples, steps, warmup, dist, device):
     if dist:
         dist.barrier()
     t0 = time.perf_counter()
+    marks = [t0]
     for i in range(steps):
         one_step(seed=4321 + 100 * rank + i)
+        marks.append(time.perf_counter())  # (generate_fast returns host audio: every step ends synchronised)
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
     t1 = time.perf_counter()
+    step_ms = [1e3 * (b - a) for a, b in zip(marks, marks[1:])]
     # the uniforms generate_fast drew in the LAST step: same seed, same draw shapes ((streams, 100) then (streams, rest))
     np.random.seed(4321 + 100 * rank + steps - 1)
     cut = 100 if samples >= 100 else samples
     u = np.random.random_sample((n_streams, cut))
     if samples > cut:
         u = np.concatenate([u, np.random.random_sample((n_streams, samples - cut))], axis=1)
-    return {"wall": t1 - t0, "cfg": cfg, "W": W, "last_audio": audio, "first": first.numpy(), "uniforms": u}
+    return {"wall": t1 - t0, "step_ms_median": float(np.median(step_ms)), "cfg": cfg, "W": W, "last_audio": audio, "first": first.numpy(), "uniforms": u}
 
 
 def verify_against_oracle(cfg, W, first, uniforms, idx=None, audio=None, streams=(0, -1), n=300):
@@ -292,43 +298,68 @@ def train5_main(a, dist, rank, local, n_gpus, global_batch=32, L=16000):
         dist.destroy_process_group()
 
 
-def cpu_baseline(cfgname, budget_s=10.0):
-    """The reference's CPU path (torch restatement of generate_fast, oracle/restated.py, proven bit-equal to the real
-    reference in tests/test_oracle_pinning.py) timed on this box's host cores: a bounded single-stream sample.  The path
-    is framework-dispatch bound (203 tiny conv1d calls per sample), so it is timed with 1 thread and with torch's default
-    thread count and the faster of the two is reported."""
+def cpu_baseline(cfgname, budget_s=3.0):
+    """The reference's CPU path (torch restatement of generate_fast, oracle/restated.py, proven bit-equal to the real reference in
+    tests/test_oracle_pinning.py) timed on this box's host cores, as BASELINE.md section 3 plans it: a bounded single-stream sample of
+    cfg1, cfg2 and cfg3, each with 1 torch thread and with torch's default thread count (~3 s of CPU work per cell).  The path is
+    framework-dispatch bound (203 tiny conv1d calls per sample at cfg3): threads do not help.  ``value`` is the headline
+    configuration's best cell; ``matrix`` holds all of them."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import restated
     from mi355_wavenet import synth
-    cfg = synth.CONFIGS[cfgname]
-    W = synth.init_weights(cfg, seed=0)
-    r = restated.RestatedWaveNet(cfg, W)
     default_threads = torch.get_num_threads()
+    matrix = {}
     best = None
-    for threads in (1, default_threads):
-        torch.set_num_threads(threads)
-        np.random.seed(0)
-        r.generate_fast(10, temperature=1.0, return_details=True)  # warm-up
-        n = 40
-        t0 = time.perf_counter()
-        r.generate_fast(n, temperature=1.0, return_details=True)
-        dt = time.perf_counter() - t0
-        n2 = int(max(50, min(3000, budget_s / (dt / n))))
-        t0 = time.perf_counter()
-        r.generate_fast(n2, temperature=1.0, return_details=True)
-        rate = n2 / (time.perf_counter() - t0)
-        if best is None or rate > best[0]:
-            best = (rate, threads, n2)
-        if default_threads == 1:
-            break
+    for name in ("cfg1", "cfg2", "cfg3"):
+        cfg = synth.CONFIGS[name]
+        r = restated.RestatedWaveNet(cfg, synth.init_weights(cfg, seed=0))
+        for threads in sorted({1, default_threads}):
+            torch.set_num_threads(threads)
+            np.random.seed(0)
+            r.generate_fast(5, temperature=1.0, return_details=True)  # warm-up
+            n = 20
+            t0 = time.perf_counter()
+            r.generate_fast(n, temperature=1.0, return_details=True)
+            dt = time.perf_counter() - t0
+            n2 = int(max(20, min(3000, budget_s / (dt / n))))
+            t0 = time.perf_counter()
+            r.generate_fast(n2, temperature=1.0, return_details=True)
+            rate = n2 / (time.perf_counter() - t0)
+            matrix["%s/%d threads" % (name, threads)] = {"samples_per_s": round(rate, 2), "samples": n2}
+            if name == cfgname and (best is None or rate > best[0]):
+                best = (rate, threads, n2)
     torch.set_num_threads(default_threads)
+    if best is None:  # the headline configuration is not one of the three (e.g. chaconne): report cfg3's
+        k = max((k for k in matrix if k.startswith("cfg3")), key=lambda k: matrix[k]["samples_per_s"])
+        best = (matrix[k]["samples_per_s"], int(k.split("/")[1].split()[0]), matrix[k]["samples"])
     return {"value": round(best[0], 2), "unit": "samples/s", "cores": int(best[1]), "kind": "port",
             "kind_rationale": "the reference tree (/root/reference, pure Python) does not exist on the GPU box; oracle/restated.py "
                               "replays its ATen op sequence and is pinned bit-equal to the real reference's generate_fast() "
                               "(tests/test_oracle_pinning.py, fixtures from tests/golden/make_golden.py)",
             "sample": "%s single stream, %d samples of generate_fast(temperature=1.0) through oracle/restated.py "
                       "(op-for-op torch restatement of the reference's CPU path; best of 1 and %d torch threads, "
-                      "host has %d logical cores)" % (cfgname, best[2], default_threads, os.cpu_count())}
+                      "host has %d logical cores)" % (cfgname, best[2], default_threads, os.cpu_count()),
+            "matrix": matrix}
+
+
+def _pmc_traffic(a, info, per_gpu):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json: FETCH_SIZE + WRITE_SIZE of one launch,
+    separate passes), scaled to this launch's timesteps -- hand-off traffic is linear in them.  The file names the kernel, its form and
+    the date it was measured; the figure is REFUSED (traffic null, the reason in traffic_source) when the library that just ran is not
+    that kernel in that form: a stale constant must not pass for a measurement of this build."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if a.scaling != "weak" or not os.path.exists(path):
+        return None, "no PMC passes for this workload / scaling"
+    pmc = json.load(open(path)).get(a.workload)
+    if not pmc:
+        return None, "no PMC passes for workload %s in profiles/pmc_traffic.json" % a.workload
+    want = pmc.get("form", {})
+    have = {k: info.get(k) for k in ("kernel_variant", "streams_per_item", "head_replicas", "n_samplers", "n_workgroups")}
+    if any(want.get(k) != have[k] for k in have) or pmc.get("streams") != per_gpu:
+        return None, "REFUSED: profiles/pmc_traffic.json was measured on %r (%d streams), this run is %r (%d streams)" % (want, pmc.get("streams", -1), have, per_gpu)
+    traffic = int((pmc["fetch_kib"] + pmc["write_kib"]) * 1024 * a.samples / pmc["samples_per_launch"])
+    return traffic, {"file": "profiles/pmc_traffic.json", "kernel": pmc.get("kernel"), "measured": pmc.get("date"), "summary": pmc.get("summary"),
+                     "counters": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, %d timesteps per launch, scaled to %d" % (pmc["samples_per_launch"], a.samples)}
 
 
 def _launch_ranks(n):
@@ -358,7 +389,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="cfg3x64", choices=sorted(WORKLOADS) + ["train5"],
                     help="train5: BASELINE configs[4], the data-parallel training step (global batch 32, strong scaling)")
-    ap.add_argument("--samples", type=int, default=2000, help="audio samples per stream per step")
+    ap.add_argument("--samples", type=int, default=16000, help="audio samples per stream per step (SURVEY.md 8d: 16 000 = one second of audio)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: the workload's streams PER GPU (64 for cfg3x64); strong: BASELINE configs[3], 512 streams in total "
                          "sharded over the GPUs (512 / N per GPU)")
@@ -423,18 +454,14 @@ def main():
     bytes_per_tstep = synth.algorithmic_bytes_per_step(cfg, per_gpu)   # W_touched + streams*(Q+8)
     bytes_per_launch = bytes_per_tstep * a.samples
     achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
-    traffic = None
-    pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, committed
-    if os.path.exists(pmc_path) and a.scaling == "weak":
-        pmc = json.load(open(pmc_path)).get(a.workload)
-        if pmc:  # hand-off traffic is linear in the number of timesteps: scale to this launch
-            traffic = int((pmc["fetch_kib"] + pmc["write_kib"]) * 1024 * a.samples / pmc["samples_per_launch"])
+    traffic, traffic_source = _pmc_traffic(a, info, per_gpu)
     kname = {1: "wn_generate_kernel", 2: "wn_generate_kernel_v2m" if per_gpu > 1 else "wn_generate_kernel_v2",
-             3: "wn_generate_kernel_v3"}.get(info["kernel_variant"], "?")
+             3: "wn_generate_kernel_v3m"}.get(info["kernel_variant"], "?")
     line = {
         "metric": "generate_fast() audio samples/sec (256-class mu-law), whole job over all GPUs",
         "value": round(value, 1), "unit": "samples/s", "n_gpus": n_gpus, "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": round(wall / a.steps * 1e3, 3), "higher_is_better": True, "scaling": a.scaling,
+        "ms_per_step": round(wall / a.steps * 1e3, 3), "median_ms_per_step": round(fac_leg["step_ms_median"], 3),
+        "higher_is_better": True, "scaling": a.scaling,
         "vs_baseline": None, "dtype": "f32", "data": "synthetic (seeded random weights, uniforms from the global numpy RNG)",
         "verified": bool(verified and any_bad == 0.0),
         "config": {"workload": "%s: WaveNetModel(%s).generate_fast(%d, first_samples=(%d, 1), temperature=1.0) per GPU per step"
@@ -443,15 +470,17 @@ def main():
                    "per_stream_samples_per_s": round(value / total_streams, 1),
                    "timed": "wall clock around the facade call: RNG draw, H2D, queue reset, kernels, D2H, mu-law expansion"
                             + ("; + RCCL gather of the audio to rank 0" if n_gpus > 1 else ""),
-                   "chain": {k: info[k] for k in ("kernel_variant", "n_chains", "layer_split", "head_split", "n_workgroups", "lds_bytes")}},
+                   "chain": {k: info[k] for k in ("kernel_variant", "n_chains", "layer_split", "head_split", "n_workgroups", "lds_bytes",
+                                                  "streams_per_item", "head_replicas", "n_samplers", "dev_overrides")}},
         "engine_level": {"value": round(engine_value, 1), "ms_per_step": round(eng_wall / a.steps * 1e3, 3),
                          "note": "the same job through the C ABI with inputs and outputs resident in HBM (one wn_generate per step"
                                  + ("; + RCCL gather of the index blocks" if n_gpus > 1 else "") + ")",
                          "facade_over_engine": round(fac_wall / eng_wall, 4)},
         "per_rank": per_rank,
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                     "kernel": kname, "kernel_ms_per_launch": round(kernel_ms, 3),
+                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source,
+                     "traffic_over_algorithmic": None if traffic is None else round(traffic / bytes_per_launch, 3),
+                     "kernel": kname, "kernel_ms_per_launch": round(kernel_ms, 3), "kernel_ms_per_launch_median": round(eng_leg["kernel_ms_median"], 3),
                      "algorithmic_bytes_per_launch": int(bytes_per_launch),
                      "algorithmic_bytes_per_timestep": int(bytes_per_tstep), "launches_per_step": 1,
                      "note": "engine-level leg: one launch = one wn_generate job of %d timesteps: n_chains persistent kernels running "
@@ -460,7 +489,7 @@ def main():
     }
     if n_gpus == 1 and not a.no_extra:
         extra = {}
-        for wl in ("cfg3x1", "cfg2x1", "cfg3x128"):
+        for wl in ("cfg3x1", "cfg2x1", "cfg1x1", "chaconnex1", "cfg2x64", "cfg3x128"):
             if wl == a.workload:
                 continue
             c2, s2 = WORKLOADS[wl]
@@ -468,7 +497,7 @@ def main():
             leg = time_engine(c2, s2, n2, 2, 1, None, local)
             extra[wl] = {"samples_per_s": round(2 * n2 * s2 / leg["wall"], 1), "kernel_ms_per_launch": round(leg["kernel_ms"], 3),
                          "hbm_frac": round(synth.algorithmic_bytes_per_step(leg["cfg"], s2) * n2 / (leg["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                         "n_workgroups": leg["info"]["n_workgroups"],
+                         "n_workgroups": leg["info"]["n_workgroups"], "kernel_variant": leg["info"]["kernel_variant"],
                          "verified": verify_against_oracle(leg["cfg"], leg["W"], leg["first"], leg["uniforms"], idx=leg["last_idx"], streams=(0,))}
         line["extra"] = extra
         try:

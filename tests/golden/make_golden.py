@@ -3,6 +3,7 @@ oracle/ref_shim.py -- the 3 documented import-time patches, nothing else) in the
 
     python tests/golden/make_golden.py          # golden_v1.npz
     python tests/golden/make_golden.py --v2     # golden_v2.npz (cfg2 / cfg3, a few minutes of reference CPU time)
+    python tests/golden/make_golden.py --v3     # golden_v3.npz (forward() + parameter gradients of the reference: cfg2, the cfg3 stack)
 
 The fixtures pin the oracle (oracle/restated.py, oracle/wn_oracle.c) and, through it, the HIP path.
 Weights are NOT stored: they are regenerated from mi355_wavenet.synth.init_weights(cfg, seed) which is
@@ -170,11 +171,52 @@ def main_v2():
     print("wrote", path, os.path.getsize(path), "bytes;", len(out), "arrays")
 
 
+# golden_v3.npz: forward() AND parameter gradients of the reference (forward -> F.cross_entropy -> backward, wavenet_training.py:64-72)
+# beyond cfg1: BASELINE configs[1] (cfg2) and the 10 x 5 / 128 / 128 / 512 stack of configs[2..4], N = 1, short output_length.
+# case -> (config, weight seed, N, output_length)
+GRAD_CASES = {"cfg2": ("cfg2", 21, 1, 6), "cfg3": ("cfg3", 22, 1, 4), "tiny_bias": ("tiny_bias", 23, 2, 5)}
+
+
+def main_v3():
+    import torch.nn.functional as F
+    sys.path.insert(0, HERE)
+    import digest as dg
+    mdl, wm, ad = ref_shim.load()
+    out = {}
+    for case, (cname, wseed, N, out_len) in GRAD_CASES.items():
+        cfg = synth.CONFIGS[cname]
+        m = build_ref_model(mdl, cfg, wseed, output_length=out_len)
+        L = m.receptive_field + out_len - 1
+        rs = np.random.RandomState(wseed + 1)
+        ids = rs.randint(0, 256, (N, L))
+        target = rs.randint(0, 256, (N * out_len,))
+        x = torch.zeros(N, 256, L)
+        x.scatter_(1, torch.from_numpy(ids).view(N, 1, L), 1.)
+        y = m(x)                                                      # wavenet_model.py:186-196
+        loss = F.cross_entropy(y.squeeze(), torch.from_numpy(target))  # wavenet_training.py:69
+        loss.backward()
+        out["grad_%s_ids" % case] = ids.astype(np.int16)
+        out["grad_%s_target" % case] = target.astype(np.int16)
+        out["grad_%s_out" % case] = y.detach().numpy().astype(np.float32)
+        out["grad_%s_loss" % case] = np.array([float(loss)], dtype=np.float64)
+        out["grad_%s_meta" % case] = np.array([wseed, N, out_len], dtype=np.int64)
+        named = {k: (p.grad.numpy() if p.grad is not None else np.zeros(tuple(p.shape), dtype=np.float32)) for k, p in m.named_parameters()}
+        for k, v in dg.digest(named).items():
+            out["grad_%s_d_%s" % (case, k)] = v
+        print(case, "loss", float(loss), "params", len(named))
+    path = os.path.join(HERE, "golden_v3.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes;", len(out), "arrays")
+
+
 if __name__ == "__main__":
-    if "--v2" in sys.argv:
+    if "--v3" in sys.argv:
+        main_v3()
+    elif "--v2" in sys.argv:
         main_v2()
     elif "--all" in sys.argv:
         main()
         main_v2()
+        main_v3()
     else:
         main()

@@ -35,6 +35,21 @@ def test_forward_reproduces_reference_golden(golden):
     assert np.abs(y - ref).max() <= TOL
 
 
+@pytest.mark.parametrize("case", ["cfg2", "cfg3"])
+def test_forward_reproduces_reference_golden_beyond_cfg1(golden, case):
+    """golden_v3.npz: forward() of the real reference for BASELINE configs[1] and the 10 x 5 / 128 / 128 / 512 stack (N = 1)."""
+    wseed, N, out_len = [int(v) for v in golden["grad_%s_meta" % case]]
+    cfg = synth.CONFIGS[case]
+    eng = engine.Engine(cfg, synth.init_weights(cfg, seed=wseed))
+    y = eng.forward_indices(golden["grad_%s_ids" % case].astype(np.int64), out_len).cpu().numpy()
+    ref = golden["grad_%s_out" % case]
+    assert y.shape == ref.shape
+    dev = float(np.abs(y - ref).max())
+    print(case, "max |dlogit| vs the reference", dev, "scale", float(np.abs(ref).max()))
+    assert dev <= TOL
+    eng.close()
+
+
 CASES = [("cfg1", synth.CONFIGS["cfg1"], 3, 7, 0), ("cfg1_bias", dict(synth.CONFIGS["cfg1"], bias=True), 2, 5, 0),
          ("cfg2", synth.CONFIGS["cfg2"], 2, 9, 0), ("cfg2_long", synth.CONFIGS["cfg2"], 1, 33, 211),
          ("cfg3", synth.CONFIGS["cfg3"], 2, 16, 0)]

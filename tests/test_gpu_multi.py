@@ -106,3 +106,30 @@ def test_bench_two_gpus_as_the_driver_launches_it():
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0
     assert len(line["per_rank"]) == 2 and all(r["kernel_ms"] > 0 for r in line["per_rank"])
     assert line["verified"] is True
+
+
+@two_gpus
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it (how the driver may call it): bench.py re-executes itself as two ranks."""
+    env = {k: v for k, v in _env().items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--samples", "400"]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    line = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and len(line["per_rank"]) == 2 and line["verified"] is True
+
+
+def test_bench_refuses_more_gpus_than_the_node_has():
+    """... and never reports an N-GPU figure it did not measure: --gpus beyond the node's devices exits non-zero without a JSON line."""
+    import torch
+    n = torch.cuda.device_count() + 1
+    env = {k: v for k, v in _env().items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0", "--samples", "100"],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode != 0 and not [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert "exposes" in res.stderr
+    # a launcher that started ANOTHER number of ranks than --gpus says is refused as well (one rank, --gpus 2)
+    env1 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--samples", "100"],
+                         env=env1, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 2 and not [l for l in res.stdout.splitlines() if l.startswith("{")]

@@ -56,3 +56,25 @@ def test_streams_shard_and_gather_world2():
     for s in range(5):
         idx, _ = c_oracle.generate(cfg, W, 40, first[s], 1.0, 0.0, u[s])
         assert np.array_equal(out[s], idx), s
+
+
+def test_bench_self_launch_command(monkeypatch):
+    """bench.py --gpus N without WORLD_SIZE re-executes itself under torch.distributed.run with N ranks on 127.0.0.1 (host logic
+    only: the launch itself is exercised on a 2-GPU box in tests/test_gpu_multi.py)."""
+    import importlib
+    import subprocess
+    import sys
+    import torch
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    seen = {}
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 4)
+    monkeypatch.setattr(subprocess, "call", lambda cmd, env=None: seen.update(cmd=cmd, env=env) or 0)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3"])
+    assert bench._launch_ranks(4) == 0
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "4", "--steps", "3"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
+    assert bench._launch_ranks(4) == 2   # fewer devices than ranks: refused
