@@ -57,7 +57,7 @@
 #define WN_V3_COMPILER_VGPRS 152  // v152-v167: request sets of the input poll / the queue group's tap FIFO (see wn_ap_*, wn_q_*)
 // ---- experiment switches.  A product build (build.py) leaves every one of them at its default; setting one requires -DWN_EXPERIMENT,
 // which build.py never passes (tools/ builds the A/B variants): a library with wrong-on-purpose timing ablations cannot ship by accident.
-#if !defined(WN_EXPERIMENT) && (defined(WN_V3_QDOT_EARLY) || defined(WN_V3_SKIP_SLEEP) || defined(WN_V3_ABL) || defined(WN_V3_PAIR_ROWS) || defined(WN_V3_PRIO))
+#if !defined(WN_EXPERIMENT) && (defined(WN_V3_QDOT_EARLY) || defined(WN_V3_SKIP_SLEEP) || defined(WN_V3_ABL) || defined(WN_V3_PAIR_ROWS) || defined(WN_V3_PRIO) || defined(WN_V3_LAST_SKIP_PRIO))
 #error "WN_V3_* experiment switches need -DWN_EXPERIMENT"
 #endif
 #ifndef WN_V3_QDOT_EARLY
@@ -74,6 +74,9 @@
 #define WN_V3_PAIR_ROWS 2  // a critical lane computes the filter AND the gate row of one channel on a half-width slice of x (see wn_v3_layer):
                            // 0 never, 1 always, 2 in the two-streams-per-item form only (64 streams: 961 -> 974 k samples/s, 128: 1.464 -> 1.478 M;
                            // one stream: 18.87 -> 18.74 k -- the longer lane reduction is on the single token's path; profiles/r02_v3_forms_final.txt)
+#endif
+#ifndef WN_V3_LAST_SKIP_PRIO
+#define WN_V3_LAST_SKIP_PRIO 3  // wave priority of the LAST layer's skip group in the two-streams-per-item form (64 streams: 998.6 -> 1004.5 k)
 #endif
 #ifndef WN_V3_PRIO
 #define WN_V3_PRIO 1  // 1: critical waves at a higher static wave priority (the queue and skip waves share their SIMDs: x64 911 -> 919 k, profiles/r02_v3_tap_fifo.txt)
@@ -217,8 +220,9 @@ static __device__ __forceinline__ void wn_ap_look4(uint32_t tag, float& sum, int
                  : [tag] "s"(tag)
                  : WN_AP_CLOBBERS);
 }
-static __device__ __forceinline__ void wn_ap_spin4(unsigned off, const wn_u64* p0, const wn_u64* p1, const wn_u64* p2, const wn_u64* p3, uint32_t tag, int rounds,
-                                                    float& sum, int& ok) {
+// (returns the double rounds that were left when the last lane was served: rounds - that = how long the wave polled, in round trips)
+static __device__ __forceinline__ int wn_ap_spin4(unsigned off, const wn_u64* p0, const wn_u64* p1, const wn_u64* p2, const wn_u64* p3, uint32_t tag, int rounds,
+                                                   float& sum, int& ok) {
     float t0;
     long long m;
     int cnt;
@@ -226,6 +230,7 @@ static __device__ __forceinline__ void wn_ap_spin4(unsigned off, const wn_u64* p
                  : [sum] "+v"(sum), [ok] "+v"(ok), [t0] "=&v"(t0), [m] "=&s"(m), [cnt] "=&s"(cnt)
                  : [off] "v"(off), [p0] "s"(p0), [p1] "s"(p1), [p2] "s"(p2), [p3] "s"(p3), [tag] "s"(tag), [rounds] "s"(rounds)
                  : WN_AP_CLOBBERS);
+    return cnt;
 }
 // the single-granule form (layer 0: one complete row per stream from the sampler): A = v[152:153], B = v[160:161]
 #define WN_AP_LOOK1_BODY                                                          \
@@ -259,7 +264,7 @@ static __device__ __forceinline__ void wn_ap_look1(uint32_t tag, float& sum, int
                  : [tag] "s"(tag)
                  : WN_AP_CLOBBERS);
 }
-static __device__ __forceinline__ void wn_ap_spin1(unsigned off, const wn_u64* p0, uint32_t tag, int rounds, float& sum, int& ok) {
+static __device__ __forceinline__ int wn_ap_spin1(unsigned off, const wn_u64* p0, uint32_t tag, int rounds, float& sum, int& ok) {
     float t0;
     long long m;
     int cnt;
@@ -267,6 +272,7 @@ static __device__ __forceinline__ void wn_ap_spin1(unsigned off, const wn_u64* p
                  : [sum] "+v"(sum), [ok] "+v"(ok), [t0] "=&v"(t0), [m] "=&s"(m), [cnt] "=&s"(cnt)
                  : [off] "v"(off), [p0] "s"(p0), [tag] "s"(tag), [rounds] "s"(rounds)
                  : WN_AP_CLOBBERS);
+    return cnt;
 }
 
 // ---- The queue group's tap FIFO, hand-scheduled for the same reason.  Queue taps x[t+1-d] are requested WN_V3_TAP_AHEAD items ahead
@@ -429,6 +435,9 @@ static __device__ void wn_v3_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
         if (l == 0) wn_ap_look1(tag2, sum, ok);
         else wn_ap_look4(tag2, sum, ok);
     };
+    // (Round 3 tried a pre-poll sleep here -- a polling wave sleeping through a fraction of its predicted wait before it requests again, to
+    //  take the chain's own polls off the L2s: 3/8 of the wait changed nothing (64 streams 994 k against 991 k), 4/8 and more collapse --
+    //  a token that waits for a sleeping stage lengthens every later wait, which lengthens the sleep: profiles/r03_presleep.txt.)
     // spins until every lane of this wave has its input (bounded like wn_poll_fixed), then stages it
     auto finish_input = [&](long long e2, int s2, float* xb2, float sum, int ok, long long item2) {
         const uint32_t tag2 = (uint32_t)(e2 + 1);
@@ -614,6 +623,11 @@ static __device__ void wn_v3_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
 
     if (group == 1) {
         // ================================================================== skip group
+#if WN_V3_LAST_SKIP_PRIO
+        // the LAST layer's skip lanes are the head's input -- the one place where this group is on the token's critical path (and the
+        // critical group of that layer has nothing to do after barrier B: it publishes no x')
+        if (G >= 2 && l == NL - 1) __builtin_amdgcn_s_setprio(WN_V3_LAST_SKIP_PRIO);
+#endif
         // rows 2h and 2h+1 of this lane's skip slice side by side: one packed FMA (v_pk_fma_f32) per z element and row pair
         wn_f2 w3p[RS / 2][DC];
         float bskip[RS];
