@@ -20,4 +20,5 @@ cd "$ROOT"
   grep -h 'samples/s' /tmp/kt.log | head -1
   python tools/rocprof_summary.py $(find /tmp/prof_kt /tmp/prof_f /tmp/prof_w -name "*.db" | sort)
 } > "$OUT/rocprofv3_$TAG.txt" 2>&1
+python tools/make_pmc_json.py $(find /tmp/prof_f -name "*.db" | head -1) $(find /tmp/prof_w -name "*.db" | head -1) "profiles/${TAG}_rocprofv3_cfg3x64.txt" "$OUT/pmc_traffic.json"
 head -c 3000 "$OUT/rocprofv3_$TAG.txt"
