@@ -147,6 +147,12 @@ static __device__ __forceinline__ void wn_ap_issue_a4(unsigned off, const wn_u64
         "global_load_dwordx2 v[158:159], %0, %4 sc1"
         ::"v"(off), "s"(b0), "s"(b1), "s"(b2), "s"(b3) : WN_AP_CLOBBERS);
 }
+static __device__ __forceinline__ void wn_ap_issue_a2(unsigned off, const wn_u64* b0, const wn_u64* b1) {
+    asm volatile(
+        "global_load_dwordx2 v[152:153], %0, %1 sc1\n\t"
+        "global_load_dwordx2 v[154:155], %0, %2 sc1"
+        ::"v"(off), "s"(b0), "s"(b1) : WN_AP_CLOBBERS);
+}
 static __device__ __forceinline__ void wn_ap_issue_a1(unsigned off, const wn_u64* b0) {
     asm volatile("global_load_dwordx2 v[152:153], %0, %1 sc1" ::"v"(off), "s"(b0) : WN_AP_CLOBBERS);
 }
@@ -232,7 +238,59 @@ static __device__ __forceinline__ int wn_ap_spin4(unsigned off, const wn_u64* p0
                  : WN_AP_CLOBBERS);
     return cnt;
 }
-// the single-granule form (layer 0: one complete row per stream from the sampler): A = v[152:153], B = v[160:161]
+// the two-partial form (layer split 2): A = v[152:155], B = v[160:163]; fixed order (0 + x0) + x1
+#define WN_AP_CHECK2(B0, B1, B2, B3)                     \
+    "v_cmp_eq_u32_e32 vcc, %[tag], v" #B1 "\n\t"         \
+    "v_cmp_eq_u32_e64 %[m], %[tag], v" #B3 "\n\t"        \
+    "s_and_b64 vcc, vcc, %[m]\n\t"                       \
+    "v_add_f32_e32 %[t0], 0, v" #B0 "\n\t"               \
+    "v_add_f32_e32 %[t0], %[t0], v" #B2 "\n\t"           \
+    WN_AP_MERGE
+#define WN_AP_ISSUE2(R0, R1, R2, R3)                                             \
+    "global_load_dwordx2 v[" #R0 ":" #R1 "], %[off], %[p0] sc1\n\t"               \
+    "global_load_dwordx2 v[" #R2 ":" #R3 "], %[off], %[p1] sc1\n\t"
+#define WN_AP_LOOK2_BODY                                                          \
+        "v_mov_b32_e32 %[ok], 0\n\t"                                              \
+        "v_mov_b32_e32 %[sum], 0\n\t"                                             \
+        "s_waitcnt vmcnt(0)\n\t"                                                  \
+        WN_AP_CHECK2(152, 153, 154, 155)
+#define WN_AP_SPIN2_BODY                                                          \
+        "s_mov_b32 %[cnt], %[rounds]\n\t"                                         \
+        WN_AP_ISSUE2(160, 161, 162, 163)                                          \
+        "s_sleep 2\n\t"                                                           \
+        WN_AP_ISSUE2(152, 153, 154, 155)                                          \
+        "1:\n\t"                                                                  \
+        "s_waitcnt vmcnt(2)\n\t"                                                  \
+        WN_AP_CHECK2(160, 161, 162, 163)                                          \
+        "s_cbranch_vccz 2f\n\t"                                                   \
+        WN_AP_ISSUE2(160, 161, 162, 163)                                          \
+        "s_waitcnt vmcnt(2)\n\t"                                                  \
+        WN_AP_CHECK2(152, 153, 154, 155)                                          \
+        "s_cbranch_vccz 2f\n\t"                                                   \
+        WN_AP_ISSUE2(152, 153, 154, 155)                                          \
+        "s_sub_u32 %[cnt], %[cnt], 1\n\t"                                         \
+        "s_cmp_lg_u32 %[cnt], 0\n\t"                                              \
+        "s_cbranch_scc1 1b\n"                                                     \
+        "2:"
+static __device__ __forceinline__ void wn_ap_look2(uint32_t tag, float& sum, int& ok) {
+    float t0;
+    long long m;
+    asm volatile(WN_AP_LOOK2_BODY
+                 : [sum] "=&v"(sum), [ok] "=&v"(ok), [t0] "=&v"(t0), [m] "=&s"(m)
+                 : [tag] "s"(tag)
+                 : WN_AP_CLOBBERS);
+}
+static __device__ __forceinline__ int wn_ap_spin2(unsigned off, const wn_u64* p0, const wn_u64* p1, uint32_t tag, int rounds, float& sum, int& ok) {
+    float t0;
+    long long m;
+    int cnt;
+    asm volatile(WN_AP_SPIN2_BODY
+                 : [sum] "+v"(sum), [ok] "+v"(ok), [t0] "=&v"(t0), [m] "=&s"(m), [cnt] "=&s"(cnt)
+                 : [off] "v"(off), [p0] "s"(p0), [p1] "s"(p1), [tag] "s"(tag), [rounds] "s"(rounds)
+                 : WN_AP_CLOBBERS);
+    return cnt;
+}
+// the single-granule form (layer 0: one complete row per stream from the sampler; layers of an unsplit stack): A = v[152:153], B = v[160:161]
 #define WN_AP_LOOK1_BODY                                                          \
         "v_mov_b32_e32 %[ok], 0\n\t"                                              \
         "v_mov_b32_e32 %[sum], 0\n\t"                                             \
@@ -340,8 +398,14 @@ struct WnV3Lds {
 
 // Shapes whose roles fit the 168 VGPRs a 768-thread workgroup leaves each lane: the skip group holds RS*DC floats, the critical
 // group K1 + K2, a head workgroup its end_conv_1 slice + end_conv_2 rows (K3 + EC); the rest is working set.
+template <class SH, int P>
+static constexpr bool wn_v3_fits() {
+    return (P == 1 || P == 2 || P == 4) && SH::RS * SH::DC <= 100 && SH::K1 + SH::K2 <= 80 && SH::K3 <= 100 && SH::K3 % 4 == 0 && SH::EC % 4 == 0 &&
+           SH::DC % 4 == 0 && SH::R % 4 == 0;
+}
+// ... and the two-streams-per-item form: a critical lane takes the filter AND the gate row of a channel on half an x slice, read as float4
 template <class SH>
-static constexpr bool wn_v3_fits() { return SH::RS % 2 == 0 && SH::RS * SH::DC <= 100 && SH::K1 + SH::K2 <= 80 && SH::K3 + SH::EC <= 130; }
+static constexpr bool wn_v3_g2_fits() { return SH::K1 % 8 == 0 && 2 * SH::T1 <= 16 && 2 * SH::R <= 256; }
 
 // dot of one register weight vector with the G vectors x + g * xstride in LDS (the G streams of an item share every weight operand;
 // per stream the arithmetic is wn_dot_lds's: two packed chains, same summation order -- bit-identical whatever G)
@@ -375,7 +439,7 @@ template <class SH, int P, int G>
 static __device__ void wn_v3_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, float* lds, int l, int c) {
     constexpr int R = SH::R, DC = SH::DC, S = SH::S, T1 = SH::T1, K1 = SH::K1, T2 = SH::T2, K2 = SH::K2, RS = SH::RS;
     using L = WnV3Lds<SH, G>;
-    static_assert(G >= 1 && G * R <= 256 && R % 64 == 0, "the G streams of an item are polled / pushed by G*R lanes, whole waves each");
+    static_assert(G >= 1 && G * R <= 256, "the G streams of an item are polled / pushed by G*R lanes");
     const int tid = threadIdx.x, t = tid & 255;
     const int group = tid >> 8;  // wave-uniform: 0 critical, 1 skip, 2 queue
     const int ns = p.n_streams, NL = p.NL;
@@ -420,19 +484,22 @@ static __device__ void wn_v3_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
     //  next A: profiles/r03_skip_group_polls.txt.  Slower wherever tokens queue: the request just misses the token, the next look comes a
     //  chunk later; and ANY work next to the critical group's filter/gate window doubles that window -- the LDS pipe is what both wait for.)
     // the layer's input granules of stream s2: layer 0 ONE complete row per stream (g0), layers > 0 the P partials of the upstream slices
-    static_assert(P == 4, "the hand-scheduled input poll (wn_ap_look4 / wn_ap_spin4) is written for four partials");
-    const bool poller = t < G * R;  // (whole waves)
+    static_assert(P == 1 || P == 2 || P == 4, "the hand-scheduled input poll is written for one, two and four partials");
+    const bool poller = t < G * R;  // (the polling blocks run under this lane mask: a partly filled wave leaves when ITS active lanes are served)
+    const bool one = l == 0 || P == 1;  // ONE granule per lane: the sampler's complete row (layer 0), the only slice of an unsplit stack
     const wn_u64* xb0 = l == 0 ? p.g0 : p.gx + ((size_t)(l - 1) * P) * ns * R;  // (wave-uniform) partial j: + j * xstep_j
     const size_t xstep_j = (size_t)ns * R;
     const unsigned xlane = (poller ? (unsigned)t : 0u) * 8u;  // this lane's byte offset inside the granules of the item's first stream
     long long* park4 = reinterpret_cast<long long*>(smp + 56);
     auto request = [&](int s2) {  // set A for the item whose first stream is s2
         const unsigned off = xlane + (unsigned)s2 * (unsigned)(R * 8);
-        if (l == 0) wn_ap_issue_a1(off, xb0);
+        if (one) wn_ap_issue_a1(off, xb0);
+        else if constexpr (P == 2) wn_ap_issue_a2(off, xb0, xb0 + xstep_j);
         else wn_ap_issue_a4(off, xb0, xb0 + xstep_j, xb0 + 2 * xstep_j, xb0 + 3 * xstep_j);
     };
     auto look = [&](uint32_t tag2, float& sum, int& ok) {
-        if (l == 0) wn_ap_look1(tag2, sum, ok);
+        if (one) wn_ap_look1(tag2, sum, ok);
+        else if constexpr (P == 2) wn_ap_look2(tag2, sum, ok);
         else wn_ap_look4(tag2, sum, ok);
     };
     // (Round 3 tried a pre-poll sleep here -- a polling wave sleeping through a fraction of its predicted wait before it requests again, to
@@ -444,7 +511,8 @@ static __device__ void wn_v3_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
         const unsigned off = xlane + (unsigned)s2 * (unsigned)(R * 8);
         unsigned spins = 0;
         while (!cx.fail && __builtin_amdgcn_ballot_w64(ok == 0) != 0) {  // the wave leaves together (its lanes share the barrier that follows)
-            if (l == 0) wn_ap_spin1(off, xb0, tag2, 64, sum, ok);
+            if (one) wn_ap_spin1(off, xb0, tag2, 64, sum, ok);
+            else if constexpr (P == 2) wn_ap_spin2(off, xb0, xb0 + xstep_j, tag2, 64, sum, ok);
             else wn_ap_spin4(off, xb0, xb0 + xstep_j, xb0 + 2 * xstep_j, xb0 + 3 * xstep_j, tag2, 64, sum, ok);
             if (__builtin_amdgcn_ballot_w64(ok == 0) == 0) break;
             // slow path: ~64 double rounds between looks at the abort word and the wall clock
@@ -628,30 +696,51 @@ static __device__ void wn_v3_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
         // critical group of that layer has nothing to do after barrier B: it publishes no x')
         if (G >= 2 && l == NL - 1) __builtin_amdgcn_s_setprio(WN_V3_LAST_SKIP_PRIO);
 #endif
-        // rows 2h and 2h+1 of this lane's skip slice side by side: one packed FMA (v_pk_fma_f32) per z element and row pair
-        wn_f2 w3p[RS / 2][DC];
+        // A lane owns the rows t + 256 q (q < RS) of this slice's lane of the running skip sum.  Rows 2h and 2h+1 of a lane sit side by
+        // side: one packed FMA (v_pk_fma_f32) per z element and row pair, one 16-byte hand-off {v(t + 512 h), tag, v(t + 512 h + 256), tag} at
+        // byte 4096 h + 16 t of the lane.  An odd RS (S = 256: one row per lane) leaves a last row without a partner in its lane: its dot runs
+        // as two half-length chains (even / odd channels, packed), and the last 256 rows of the lane are kept in natural order (row
+        // 256 (RS-1) + t at byte 2048 (RS-1) + 8 t) and handed over as the pairs of NEIGHBOURING lanes -- the even lane stores both, every
+        // lane loads the pair that holds its row.
+        constexpr int NPL = RS / 2, ODD = RS % 2, NPR = NPL + ODD;
+        static_assert(DC % 4 == 0 && L::DCP % 4 == 0, "z is read as float4");
+        wn_f2 w3p[NPL > 0 ? NPL : 1][DC];
+        wn_f2 w3o[ODD ? DC / 2 : 1];  // the unpaired row: {w[2k], w[2k+1]}
         float bskip[RS];
 #pragma unroll
-        for (int h2 = 0; h2 < RS / 2; ++h2)
+        for (int h2 = 0; h2 < NPL; ++h2)
 #pragma unroll
             for (int k = 0; k < DC; ++k)
                 w3p[h2][k] = wn_f2{img[(size_t)(2 * K1 + K2 + (2 * h2) * DC + k) * 256], img[(size_t)(2 * K1 + K2 + (2 * h2 + 1) * DC + k) * 256]};
+        if constexpr (ODD) {
+#pragma unroll
+            for (int k = 0; k < DC / 2; ++k)
+                w3o[k] = wn_f2{img[(size_t)(2 * K1 + K2 + (RS - 1) * DC + 2 * k) * 256], img[(size_t)(2 * K1 + K2 + (RS - 1) * DC + 2 * k + 1) * 256]};
+        }
 #pragma unroll
         for (int q = 0; q < RS; ++q) bskip[q] = img[(size_t)(2 * K1 + K2 + RS * DC + 2 + q) * 256];
-        static_assert(RS % 2 == 0, "the skip lane is handed over in 16-byte pairs (rows t, t + 256)");
         const __amdgpu_buffer_rsrc_t rs_gs = wn_rsrc(p.gs);
         const size_t up_wg = (size_t)(l > 0 ? l - 1 : 0) * P + c;  // the upstream slice (l > 0)
+        constexpr unsigned SB = (unsigned)S * 8;                               // bytes between the lanes of consecutive streams
+        constexpr unsigned ODD_BASE = 2048u * (unsigned)(RS - 1);              // byte offset of the natural-order tail inside a lane
+        const unsigned lane16 = (unsigned)t * 16, odd_ld = ODD_BASE + (unsigned)(t & ~1) * 8, odd_st = ODD_BASE + (unsigned)t * 8;
         if (wn_barrier_failed(cx, failflag)) return;  // A(0)
         // The upstream skip lane of the coming item is requested right after barrier A: its producer published it a little after
         // the x' this workgroup has just consumed, so the load returns it, and its round trip runs next to the critical group's
         // filter/gate dot instead of inside this group's chunk after barrier B (requested at B the chunk took 0.57 us at 64 streams,
         // nearly as long as the critical group needs from B to the next A).  One item ahead it would come back stale in the
         // latency-bound regime.
-        wn_v4i sk_req[G][RS / 2];
+        wn_v4i sk_req[G][NPR];
+        auto request_up = [&](int s2) {
 #pragma unroll
-        for (int g = 0; g < G; ++g)
+            for (int g = 0; g < G; ++g) {
+                const unsigned base = (unsigned)(((up_wg * ns + s2 + g) * (size_t)S) * 8);
 #pragma unroll
-            for (int h2 = 0; h2 < RS / 2; ++h2) sk_req[g][h2] = wn_ld_pair(rs_gs, (unsigned)(((up_wg * ns + g) * (size_t)S) * 8) + (unsigned)t * 16 + h2 * 4096);
+                for (int h2 = 0; h2 < NPL; ++h2) sk_req[g][h2] = __builtin_amdgcn_raw_buffer_load_b128(rs_gs, lane16, base + h2 * 4096, 16);
+                if constexpr (ODD) sk_req[g][NPL] = __builtin_amdgcn_raw_buffer_load_b128(rs_gs, odd_ld, base, 16);
+            }
+        };
+        request_up(0);
         long long item = 0;
         for (long long e = 0; e < r.n_eval; ++e) {
             const bool prime = e < n_prime;
@@ -661,9 +750,8 @@ static __device__ void wn_v3_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
                 const bool stamp = r.prof && item < r.prof_items && tid == 256;
                 const long long t0 = stamp ? (long long)wall_clock64() : 0;
                 const int s2 = s + G < ns ? s + G : 0;  // the coming item's first stream
-                constexpr unsigned SB = (unsigned)S * 8;  // bytes between the lanes of consecutive streams
-                const unsigned off_up = (unsigned)(((up_wg * ns + s) * (size_t)S) * 8) + (unsigned)t * 16;    // upstream slice's lane, first stream of the item
-                const unsigned off_me = (unsigned)((((size_t)cx.w * ns + s) * (size_t)S) * 8) + (unsigned)t * 16;
+                const unsigned base_up = (unsigned)(((up_wg * ns + s) * (size_t)S) * 8);    // upstream slice's lane, first stream of the item
+                const unsigned base_me = (unsigned)((((size_t)cx.w * ns + s) * (size_t)S) * 8);
                 // ---- skip 1x1 partial on this lane of the running skip sum          (wavenet_model.py:154-162)
                 float a3[G][RS];
 #pragma unroll
@@ -673,12 +761,13 @@ static __device__ void wn_v3_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
                 const bool work = !prime && !(WN_V3_ABL & 1);
                 if (work) {
                     // per row: bias, then + w[k] z[k] for k = 0..DC-1 in order (one fused multiply-add each), as before the packing
-                    wn_f2 a3p[G][RS / 2];
+                    wn_f2 a3p[G][NPL > 0 ? NPL : 1], a3o[G];
 #pragma unroll
-                    for (int g = 0; g < G; ++g)
+                    for (int g = 0; g < G; ++g) {
 #pragma unroll
-                        for (int h2 = 0; h2 < RS / 2; ++h2) a3p[g][h2] = wn_f2{bskip[2 * h2], bskip[2 * h2 + 1]};
-                    static_assert(DC % 4 == 0 && L::DCP % 4 == 0, "z is read as float4");
+                        for (int h2 = 0; h2 < NPL; ++h2) a3p[g][h2] = wn_f2{bskip[2 * h2], bskip[2 * h2 + 1]};
+                        a3o[g] = wn_f2{ODD ? bskip[RS - 1] : 0.f, 0.f};
+                    }
                     float4 z4[G][DC / 4];
 #pragma unroll
                     for (int g = 0; g < G; ++g)
@@ -689,45 +778,57 @@ static __device__ void wn_v3_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
 #pragma unroll
                         for (int g = 0; g < G; ++g) {  // (the streams' chains interleaved in program order)
 #pragma unroll
-                            for (int h2 = 0; h2 < RS / 2; ++h2) {
+                            for (int h2 = 0; h2 < NPL; ++h2) {
                                 a3p[g][h2] = __builtin_elementwise_fma(w3p[h2][4 * k], wn_f2{z4[g][k].x, z4[g][k].x}, a3p[g][h2]);
                                 a3p[g][h2] = __builtin_elementwise_fma(w3p[h2][4 * k + 1], wn_f2{z4[g][k].y, z4[g][k].y}, a3p[g][h2]);
                                 a3p[g][h2] = __builtin_elementwise_fma(w3p[h2][4 * k + 2], wn_f2{z4[g][k].z, z4[g][k].z}, a3p[g][h2]);
                                 a3p[g][h2] = __builtin_elementwise_fma(w3p[h2][4 * k + 3], wn_f2{z4[g][k].w, z4[g][k].w}, a3p[g][h2]);
                             }
+                            if constexpr (ODD) {
+                                a3o[g] = __builtin_elementwise_fma(w3o[2 * k], wn_f2{z4[g][k].x, z4[g][k].y}, a3o[g]);
+                                a3o[g] = __builtin_elementwise_fma(w3o[2 * k + 1], wn_f2{z4[g][k].z, z4[g][k].w}, a3o[g]);
+                            }
                         }
                     }
 #pragma unroll
-                    for (int g = 0; g < G; ++g)
+                    for (int g = 0; g < G; ++g) {
 #pragma unroll
-                        for (int h2 = 0; h2 < RS / 2; ++h2) { a3[g][2 * h2] = a3p[g][h2].x; a3[g][2 * h2 + 1] = a3p[g][h2].y; }
+                        for (int h2 = 0; h2 < NPL; ++h2) { a3[g][2 * h2] = a3p[g][h2].x; a3[g][2 * h2 + 1] = a3p[g][h2].y; }
+                        if constexpr (ODD) a3[g][RS - 1] = a3o[g].x + a3o[g].y;
+                    }
                     if (l > 0) {
 #pragma unroll
-                        for (int g = 0; g < G; ++g)
+                        for (int g = 0; g < G; ++g) {
 #pragma unroll
-                            for (int h2 = 0; h2 < RS / 2; ++h2) {
+                            for (int h2 = 0; h2 < NPL; ++h2) {
                                 wn_v4i v = sk_req[g][h2];   // (only ever this item's streams: re-requested after every barrier A)
-                                if ((uint32_t)v.y != tag || (uint32_t)v.w != tag) v = wn_poll_pair(cx, rs_gs, off_up + g * SB + h2 * 4096, tag, WN_W_SKIN, e, s + g, WN_V3_SKIP_SLEEP);
+                                if ((uint32_t)v.y != tag || (uint32_t)v.w != tag) v = wn_poll_pair(cx, rs_gs, base_up + g * SB + h2 * 4096 + lane16, tag, WN_W_SKIN, e, s + g, WN_V3_SKIP_SLEEP);
                                 a3[g][2 * h2] += __int_as_float(v.x);
                                 a3[g][2 * h2 + 1] += __int_as_float(v.z);
                             }
+                            if constexpr (ODD) {  // (both halves of the pair come from ONE store of the upstream's even lane)
+                                wn_v4i v = sk_req[g][NPL];
+                                if ((uint32_t)v.y != tag || (uint32_t)v.w != tag) v = wn_poll_pair(cx, rs_gs, base_up + g * SB + odd_ld, tag, WN_W_SKIN, e, s + g, WN_V3_SKIP_SLEEP);
+                                a3[g][RS - 1] += __int_as_float((t & 1) ? v.z : v.x);
+                            }
+                        }
                     }
                 }
                 if (work || l == NL - 1) {  // (priming: only the head's lanes are kept moving, with zeros)
 #pragma unroll
-                    for (int g = 0; g < G; ++g)
+                    for (int g = 0; g < G; ++g) {
 #pragma unroll
-                        for (int h2 = 0; h2 < RS / 2; ++h2) wn_st_pair(rs_gs, off_me + g * SB + h2 * 4096, tag, a3[g][2 * h2], a3[g][2 * h2 + 1], local_s);
+                        for (int h2 = 0; h2 < NPL; ++h2) wn_st_pair(rs_gs, base_me + g * SB + h2 * 4096 + lane16, tag, a3[g][2 * h2], a3[g][2 * h2 + 1], local_s);
+                        if constexpr (ODD) {
+                            const float nb = wn_dpp<0xB1>(a3[g][RS - 1]);  // quad_perm [1,0,3,2]: the odd neighbour's row
+                            if ((t & 1) == 0) wn_st_pair(rs_gs, base_me + g * SB + odd_st, tag, a3[g][RS - 1], nb, local_s);
+                        }
+                    }
                 }
                 if (stamp)  // slot 6: the skip group's B(i) | its chunk length << 40 (10 ns ticks)
                     r.prof[((size_t)cx.w * r.prof_items + item) * WN_STAMPS + 6] = (t0 & 0xffffffffffll) | (((long long)wall_clock64() - t0) << 40);
                 if (wn_barrier_failed(cx, failflag)) return;  // ---- A(i+1)
-                {   // the upstream lane of the coming item
-#pragma unroll
-                    for (int g = 0; g < G; ++g)
-#pragma unroll
-                        for (int h2 = 0; h2 < RS / 2; ++h2) sk_req[g][h2] = wn_ld_pair(rs_gs, (unsigned)(((up_wg * ns + s2 + g) * (size_t)S) * 8) + (unsigned)t * 16 + h2 * 4096);
-                }
+                request_up(s2);  // the upstream lane of the coming item
             }
         }
         (void)wn_barrier_failed(cx, failflag);  // B(N)
@@ -791,6 +892,7 @@ static __device__ void wn_v3_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
     // ... and the push of a late layer is done by the waves that load no taps (lanes R..2R-1, when there are that many): the tap
     // waves then issue nothing but tap loads, and an entry always has exactly D - 1 younger operations
     constexpr bool PUSH_HI = 2 * G * R <= 256;
+    constexpr bool PUSH_SEP = PUSH_HI && (G * R) % 64 == 0;  // ... in waves of their own: only then does a tap wave issue nothing but tap loads
     const bool pusher = late_wg && (PUSH_HI ? (t >= G * R && t < 2 * G * R) : qlane);
     const int pg = PUSH_HI ? (t - G * R) / R : tg, prow = PUSH_HI ? (t - G * R) % R : tr;  // (stream of the item, element) this lane pushes
     int buf = 0;
@@ -841,7 +943,7 @@ static __device__ void wn_v3_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
                     // the NEXT item's tap into the other buffer: D - 1 younger loads; the stores of a wave that also pushes (R > 128:
                     // program order push, load, take) only add to what may stay in flight from item D - 2 on
                     const int ns1 = slot == D - 1 ? 0 : slot + 1;
-                    xo_nxt[xq] = (PUSH_HI || item < D - 2) ? wn_q_take_slot<D - 1>(ns1) : wn_q_take_slot<2 * D - 2>(ns1);
+                    xo_nxt[xq] = (PUSH_SEP || item < D - 2) ? wn_q_take_slot<D - 1>(ns1) : wn_q_take_slot<2 * D - 2>(ns1);
                 }
             }
             slot = slot == D - 1 ? 0 : slot + 1;
@@ -916,23 +1018,25 @@ static __device__ void wn_v3_head(const WnPlan& p, const WnRun& r, WnCtx& cx, fl
     }
     wn_lds_barrier();
     const bool local_l = locflags[0] != 0;
-    static_assert(QS % 2 == 0, "the skip lanes arrive in 16-byte pairs (rows t, t + 256)");
     const __amdgpu_buffer_rsrc_t rs_gs = wn_rsrc(p.gs);
-    // The P lanes of the running skip sum (published by the last layer's skip groups) of the NEXT item are requested as soon as
-    // this item's lanes are staged: the head sits in another XCD than the last layers, a request round trip is ~0.6 us, and with
-    // tokens queued in front of it the head's cycle was compute (0.58 us) PLUS that round trip = 1.19 us per item -- the slowest
-    // stage of the 64-stream chain, whatever the layer stages did (profiles/r02_v3_head_request.txt).  Nothing queued (latency-
-    // bound runs): the early request comes back stale and the lanes are polled when due, as before.
-    wn_v4i nv[QS / 2][P];
+    // The P lanes of the running skip sum (published by the last layer's skip groups; layout: see the skip group) of the NEXT item are
+    // requested early (after this item's long dot): with tokens queued in front of it the head's cycle would otherwise be compute PLUS a
+    // request round trip -- the slowest stage of the 64-stream chain, whatever the layer stages did (profiles/r02_v3_head_request.txt).
+    // Nothing queued (latency-bound runs): the early request comes back stale and the lanes are polled when due.
+    constexpr int NPL = QS / 2, ODD = QS % 2, NPR = NPL + ODD;
+    constexpr unsigned ODD_BASE = 2048u * (unsigned)(QS - 1);
+    wn_v4i nv[NPR][P];
     // (offsets: the lane's part in ONE register, the wave-uniform part of every lane in the scalar offset of the buffer load)
-    const unsigned lane16 = (unsigned)tid * 16, lane8 = (unsigned)tid * 8;
+    const unsigned lane16 = (unsigned)tid * 16, lane8 = (unsigned)tid * 8, odd_ld = ODD_BASE + (unsigned)(tid & ~1) * 8;
     const __amdgpu_buffer_rsrc_t rs_gl = wn_rsrc(p.gl);
     auto request = [&](int s2) {
 #pragma unroll
-        for (int h2 = 0; h2 < QS / 2; ++h2)
+        for (int j = 0; j < P; ++j) {
+            const unsigned base = (unsigned)(((((size_t)(NL - 1) * P + j) * ns + s2) * (size_t)S) * 8);
 #pragma unroll
-            for (int j = 0; j < P; ++j)
-                nv[h2][j] = __builtin_amdgcn_raw_buffer_load_b128(rs_gs, lane16, (unsigned)(((((size_t)(NL - 1) * P + j) * ns + s2) * (size_t)S) * 8) + h2 * 4096, 16);
+            for (int h2 = 0; h2 < NPL; ++h2) nv[h2][j] = __builtin_amdgcn_raw_buffer_load_b128(rs_gs, lane16, base + h2 * 4096, 16);
+            if constexpr (ODD) nv[NPL][j] = __builtin_amdgcn_raw_buffer_load_b128(rs_gs, odd_ld, base, 16);
+        }
     };
     if (n_mine > 0) request(rep);
     for (long long e = 0; e < r.n_eval; ++e) {
@@ -949,7 +1053,7 @@ static __device__ void wn_v3_head(const WnPlan& p, const WnRun& r, WnCtx& cx, fl
                 while (!cx.fail) {
                     bool fresh = true;
 #pragma unroll
-                    for (int h2 = 0; h2 < QS / 2; ++h2)
+                    for (int h2 = 0; h2 < NPR; ++h2)
 #pragma unroll
                         for (int j = 0; j < P; ++j) fresh = fresh && (uint32_t)nv[h2][j].y == tag && (uint32_t)nv[h2][j].w == tag;
                     if (fresh) break;
@@ -963,7 +1067,7 @@ static __device__ void wn_v3_head(const WnPlan& p, const WnRun& r, WnCtx& cx, fl
                 }
             }
 #pragma unroll
-            for (int h2 = 0; h2 < QS / 2; ++h2) {
+            for (int h2 = 0; h2 < NPL; ++h2) {
                 float sum0 = 0.f, sum1 = 0.f;
 #pragma unroll
                 for (int j = 0; j < P; ++j) {  // fixed order j = 0..P-1
@@ -972,6 +1076,12 @@ static __device__ void wn_v3_head(const WnPlan& p, const WnRun& r, WnCtx& cx, fl
                 }
                 sk[SH::skpad(tid + 512 * h2)] = sum0 > 0.f ? sum0 : 0.f;        // relu(skip), rows tid + 512 h2 and tid + 512 h2 + 256
                 sk[SH::skpad(tid + 512 * h2 + 256)] = sum1 > 0.f ? sum1 : 0.f;
+            }
+            if constexpr (ODD) {  // the natural-order tail: row 256 (QS-1) + tid, the half of the pair that is this lane's
+                float sum = 0.f;
+#pragma unroll
+                for (int j = 0; j < P; ++j) sum += __int_as_float((tid & 1) ? nv[NPL][j].z : nv[NPL][j].x);
+                sk[SH::skpad(256 * (QS - 1) + tid)] = sum > 0.f ? sum : 0.f;
             }
             if (wn_barrier_failed(cx, failflag)) return;
             wn_stamp(r, park, item, 1);
@@ -986,15 +1096,20 @@ static __device__ void wn_v3_head(const WnPlan& p, const WnRun& r, WnCtx& cx, fl
                 a = wn_reduce<T3>(a) + b1;
                 if (kq3 == 0) ev[row3] = a > 0.f ? a : 0.f;  // relu(end_conv_1)
                 request(s + HR < ns ? s + HR : rep);  // (after the long dot: its sixteen registers are not live next to that dot's operands)
-                float4 w5r[EC / 4];  // the lane's end_conv_2 row, fetched from LDS while the other waves finish end_conv_1
+                // the lane's end_conv_2 row: fetched from LDS while the other waves finish end_conv_1 where it is short enough to sit in
+                // registers next to end_conv_1's slice (EC <= 32), read chunk by chunk inside the dot otherwise
+                constexpr bool W5PRE = EC <= 32;
+                float4 w5r[W5PRE ? EC / 4 : 1];
+                if constexpr (W5PRE) {
 #pragma unroll
-                for (int k4 = 0; k4 < EC / 4; ++k4) w5r[k4] = w5l[k4 * 256];
+                    for (int k4 = 0; k4 < EC / 4; ++k4) w5r[k4] = w5l[k4 * 256];
+                }
                 wn_lds_barrier();
                 {   // partial end_conv_2: the arithmetic of wn_dot_lds_chunked (two packed chains, same order)
                     wn_f2 a01 = {b2, 0.f}, a23 = {0.f, 0.f};
 #pragma unroll
                     for (int k4 = 0; k4 < EC / 4; ++k4) {
-                        const float4 w = w5r[k4], v = reinterpret_cast<const float4*>(ev)[k4];
+                        const float4 w = W5PRE ? w5r[W5PRE ? k4 : 0] : w5l[k4 * 256], v = reinterpret_cast<const float4*>(ev)[k4];
                         a01 = __builtin_elementwise_fma(wn_f2{w.x, w.y}, wn_f2{v.x, v.y}, a01);
                         a23 = __builtin_elementwise_fma(wn_f2{w.z, w.w}, wn_f2{v.z, v.w}, a23);
                     }

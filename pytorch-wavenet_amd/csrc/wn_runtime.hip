@@ -193,12 +193,13 @@ static WnV2Entry wn_v2_entry() {
     };
     e.pack = wn_pack_v2<SH>;
     e.fn_v3[0] = e.fn_v3[1] = nullptr; e.lds_floats_v3 = nullptr; e.launch_v3 = nullptr; e.lds_pre_v3 = 0;
-    if constexpr (wn_v3_fits<SH>()) {
+    if constexpr (wn_v3_fits<SH, PM>()) {
         e.fn_v3[0] = (const void*)wn_generate_kernel_v3m<R, DC, S, EC, PM, 1>;
-        e.fn_v3[1] = (const void*)wn_generate_kernel_v3m<R, DC, S, EC, PM, 2>;
+        if constexpr (wn_v3_g2_fits<SH>()) e.fn_v3[1] = (const void*)wn_generate_kernel_v3m<R, DC, S, EC, PM, 2>;
         e.lds_pre_v3 = WnV3Lds<SH, 1>::pre;
         e.lds_floats_v3 = [](int ns, int g2) {
-            const int lay = g2 ? WnV3Lds<SH, 2>::floats(ns) : WnV3Lds<SH, 1>::floats(ns);
+            int lay = WnV3Lds<SH, 1>::floats(ns);
+            if constexpr (wn_v3_g2_fits<SH>()) { if (g2) lay = WnV3Lds<SH, 2>::floats(ns); }
             const int head = WnV3Lds<SH, 1>::pre + EC * 256;  // + the head lanes' end_conv_2 rows (wn_v3_head)
             const int smp = WnV3Lds<SH, 1>::pre + 256 * R;    // + start_conv^T in the sampler workgroups (wn_v3_sampler), when it fits
             int need = lay > head ? lay : head;
@@ -206,8 +207,10 @@ static WnV2Entry wn_v2_entry() {
             return need;
         };
         e.launch_v3 = [](int g2, int grid, size_t lds, hipStream_t st, const WnPlan& p, const WnRun& r) {
-            if (g2) hipLaunchKernelGGL((wn_generate_kernel_v3m<R, DC, S, EC, PM, 2>), dim3(grid), dim3(WN_THREADS_V3), lds, st, p, r);
-            else hipLaunchKernelGGL((wn_generate_kernel_v3m<R, DC, S, EC, PM, 1>), dim3(grid), dim3(WN_THREADS_V3), lds, st, p, r);
+            if constexpr (wn_v3_g2_fits<SH>()) {
+                if (g2) { hipLaunchKernelGGL((wn_generate_kernel_v3m<R, DC, S, EC, PM, 2>), dim3(grid), dim3(WN_THREADS_V3), lds, st, p, r); return; }
+            }
+            hipLaunchKernelGGL((wn_generate_kernel_v3m<R, DC, S, EC, PM, 1>), dim3(grid), dim3(WN_THREADS_V3), lds, st, p, r);
         };
     }
     return e;
@@ -276,7 +279,7 @@ static bool wn_v3_applicable(const wn_config* cfg, int n_cu, int* out_vi, int* o
     int P = 0, PA = 0;
     const int vi = wn_v2_choose(pl, n_cu, n_smp, cfg->layer_split, cfg->head_split, &P, &PA);
     if (vi < 0 || !wn_v2_table()[vi].fn_v3[0]) return false;
-    if (wn_v2_table()[vi].lds_floats_v3(cfg->n_streams, wn_v3_mode(cfg->n_streams) & 1) * 4 > WN_LDS_MAX_BYTES) return false;
+    if (wn_v2_table()[vi].lds_floats_v3(cfg->n_streams, (wn_v3_mode(cfg->n_streams) & 1) && wn_v2_table()[vi].fn_v3[1]) * 4 > WN_LDS_MAX_BYTES) return false;
     if (out_vi) *out_vi = vi;
     if (outP) *outP = P;
     if (outPA) *outPA = PA;
@@ -538,6 +541,7 @@ extern "C" int wn_create(const wn_config* cfg, wn_handle** out) {
             pl.start_in_lds = (wn_v2_table()[vi3].lds_pre_v3 + 256 * pl.R) * 4 <= WN_LDS_MAX_BYTES ? 1 : 0;  // the samplers' copy of start_conv^T
             h->w0lds = 0;
             h->v3_mode = wn_v3_mode(pl.n_streams);
+            if (!wn_v2_table()[vi3].fn_v3[1]) h->v3_mode &= ~1;  // (shapes whose filter/gate slices cannot be halved: one stream per item only)
             if ((h->v3_mode & 2) && pl.NL * P2 + 2 * PA2 + pl.n_smp <= n_cu) {  // a second set of head workgroups
                 pl.HR = 2;
                 pl.n_wg += PA2;

@@ -29,12 +29,15 @@ SMALL = [
 ]
 
 
-def _expected_variant(cfg, ns):
-    """3 = wave-specialised kernel (csrc/wn_kernel_v3.h): the cfg3 channel shape (skip rows in 16-byte pairs), any stream count."""
+def _expected_variant(cfg, ns, layer_split=0):
+    """3 = wave-specialised kernel (csrc/wn_kernel_v3.h): every instantiated channel shape whose roles fit its register budget (round 3:
+    also unsplit / two-way split stacks, one skip row per lane, fewer than 64 residual channels) -- all BASELINE configs; the
+    train_script.py shape (32 / 32 / 1024 / 512: 128 skip weights per lane) stays on the 256-thread register kernels (2)."""
     cfg = synth.CONFIGS[cfg] if isinstance(cfg, str) else cfg
-    shape3 = (cfg["residual_channels"], cfg["dilation_channels"], cfg["skip_channels"], cfg["end_channels"]) == (128, 128, 512, 256)
+    shape = (cfg["residual_channels"], cfg["dilation_channels"], cfg["skip_channels"], cfg["end_channels"])
+    on3 = shape in ((128, 128, 512, 256), (64, 64, 256, 256), (32, 32, 256, 256), (16, 16, 256, 128), (16, 32, 256, 64))
     import os
-    return 3 if shape3 and os.environ.get("WN_KERNEL") not in ("v2", "generic") else 2
+    return 3 if on3 and os.environ.get("WN_KERNEL") not in ("v2", "generic") else 2
 
 
 MINI3 = dict(synth.CONFIGS["cfg3"], layers=3, blocks=2)   # cfg3's channel shape, 6 layers: the wave-specialised kernel on 36 workgroups
