@@ -455,7 +455,7 @@ def main():
     bytes_per_launch = bytes_per_tstep * a.samples
     achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
     traffic, traffic_source = _pmc_traffic(a, info, per_gpu)
-    kname = {1: "wn_generate_kernel", 2: "wn_generate_kernel_v2m" if per_gpu > 1 else "wn_generate_kernel_v2",
+    kname = {1: "wn_generate_kernel", 2: "wn_generate_kernel_v2m" if per_gpu > 1 else "wn_generate_kernel_v2",  # (2: the train_script.py shape only)
              3: "wn_generate_kernel_v3m"}.get(info["kernel_variant"], "?")
     line = {
         "metric": "generate_fast() audio samples/sec (256-class mu-law), whole job over all GPUs",

@@ -291,14 +291,17 @@ static inline void wn_pack_blobs(const WnPlan& pl, const WnHostWeights& w, std::
 }
 
 // ---- forms of the wave-specialised kernel (wn_kernel_v3.h), chosen per job by wn_create
-#ifndef WN_V3_G2_MIN_STREAMS
-#define WN_V3_G2_MIN_STREAMS 56   // from here up the throughput form pays (56 streams: 895 k against 887 k samples/s; 48: 783 k against 800 k)
+// The throughput form pays once the ring holds more tokens than it has stages (one stream per item then runs into the stages' cycle):
+// from n_layers + WN_V3_G2_MARGIN streams -- cfg3 (50 layers): 56 streams (895 k against 887 k samples/s; 48: 783 k against 800 k);
+// cfg2 (30 layers): 36 (32 streams: 999 k against 956 k, 64: 1.53 M against 0.96 M); cfg1 (10 layers): 16.
+#ifndef WN_V3_G2_MARGIN
+#define WN_V3_G2_MARGIN 6
 #endif
 #define WN_V3_ROUND_STREAMS 128   // streams per round when a job exceeds what one chain holds (wn_handle::rounds)
 // bit 0: two streams per pipeline item of a layer workgroup (needs an even stream count); bit 1: two replicas of the head
 // workgroups.  `pin`: the WN_V3_MODE environment override ("0".."3"), or NULL.
-static inline int wn_v3_mode_for(int n_streams, const char* pin) {
-    int mode = (n_streams >= WN_V3_G2_MIN_STREAMS) ? 3 : 0;
+static inline int wn_v3_mode_for(int n_streams, const char* pin, int n_layers = 50) {
+    int mode = (n_streams >= n_layers + WN_V3_G2_MARGIN) ? 3 : 0;
     if (pin && pin[0] >= '0' && pin[0] <= '3' && !pin[1]) mode = pin[0] - '0';
     if (n_streams % 2) mode &= ~1;
     if (n_streams < 2) mode = 0;

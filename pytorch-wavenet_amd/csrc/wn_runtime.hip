@@ -262,7 +262,7 @@ static int wn_sampler_count(int n_streams) {
 // the LDS and DPP latencies of the dot products -- bound the throughput, and two streams per item share them (every weight
 // operand is used twice) at the price of a longer trip through each stage.  WN_V3_MODE = 0..3 pins a form (A/B runs, tests).
 // (the rule itself is host-only arithmetic in wn_plan.h: wn_v3_mode_for, tests/test_plan_host.py)
-static int wn_v3_mode(int n_streams) { return wn_v3_mode_for(n_streams, wn_dev_env("WN_V3_MODE")); }
+static int wn_v3_mode(int n_streams, int n_layers) { return wn_v3_mode_for(n_streams, wn_dev_env("WN_V3_MODE"), n_layers); }
 
 // true iff the wave-specialised kernel (variant 3) serves this configuration with ONE chain: an instantiated shape, at least
 // two streams, the parked tap-0 sums of all streams fit the LDS next to the activations, one CU per workgroup
@@ -279,7 +279,7 @@ static bool wn_v3_applicable(const wn_config* cfg, int n_cu, int* out_vi, int* o
     int P = 0, PA = 0;
     const int vi = wn_v2_choose(pl, n_cu, n_smp, cfg->layer_split, cfg->head_split, &P, &PA);
     if (vi < 0 || !wn_v2_table()[vi].fn_v3[0]) return false;
-    if (wn_v2_table()[vi].lds_floats_v3(cfg->n_streams, (wn_v3_mode(cfg->n_streams) & 1) && wn_v2_table()[vi].fn_v3[1]) * 4 > WN_LDS_MAX_BYTES) return false;
+    if (wn_v2_table()[vi].lds_floats_v3(cfg->n_streams, (wn_v3_mode(cfg->n_streams, cfg->layers * cfg->blocks) & 1) && wn_v2_table()[vi].fn_v3[1]) * 4 > WN_LDS_MAX_BYTES) return false;
     if (out_vi) *out_vi = vi;
     if (outP) *outP = P;
     if (outPA) *outPA = PA;
@@ -540,7 +540,7 @@ extern "C" int wn_create(const wn_config* cfg, wn_handle** out) {
             pl.n_wg += pl.n_smp;
             pl.start_in_lds = (wn_v2_table()[vi3].lds_pre_v3 + 256 * pl.R) * 4 <= WN_LDS_MAX_BYTES ? 1 : 0;  // the samplers' copy of start_conv^T
             h->w0lds = 0;
-            h->v3_mode = wn_v3_mode(pl.n_streams);
+            h->v3_mode = wn_v3_mode(pl.n_streams, pl.NL);
             if (!wn_v2_table()[vi3].fn_v3[1]) h->v3_mode &= ~1;  // (shapes whose filter/gate slices cannot be halved: one stream per item only)
             if ((h->v3_mode & 2) && pl.NL * P2 + 2 * PA2 + pl.n_smp <= n_cu) {  // a second set of head workgroups
                 pl.HR = 2;

@@ -35,7 +35,7 @@ def _expected_variant(cfg, ns, layer_split=0):
     train_script.py shape (32 / 32 / 1024 / 512: 128 skip weights per lane) stays on the 256-thread register kernels (2)."""
     cfg = synth.CONFIGS[cfg] if isinstance(cfg, str) else cfg
     shape = (cfg["residual_channels"], cfg["dilation_channels"], cfg["skip_channels"], cfg["end_channels"])
-    on3 = shape in ((128, 128, 512, 256), (64, 64, 256, 256), (32, 32, 256, 256), (16, 16, 256, 128), (16, 32, 256, 64))
+    on3 = shape in ((128, 128, 512, 256), (64, 64, 256, 256), (32, 32, 256, 256), (16, 16, 256, 32), (16, 32, 256, 64))
     import os
     return 3 if on3 and os.environ.get("WN_KERNEL") not in ("v2", "generic") else 2
 
@@ -394,7 +394,8 @@ def test_abi_error_codes_on_a_live_handle():
 
 
 # ---------------------------------------------------------------- wave-specialised multi-stream kernel (csrc/wn_kernel_v3.h)
-V3 = [("mini3_ns1", MINI3, 1, 300, 40), ("mini3_ns2", MINI3, 2, 200, 7), ("mini3_ns3_bias", dict(MINI3, bias=True), 3, 200, 25), ("cfg3_ns1", "cfg3", 1, 100, 600),
+V3 = [("cfg2_ns1", "cfg2", 1, 120, 700), ("cfg2_ns5", "cfg2", 5, 80, 20),
+      ("cfg1_ns1_bias", dict(synth.CONFIGS["cfg1"], bias=True), 1, 200, 70), ("cfg1_ns40", "cfg1", 40, 60, 5), ("mini3_ns1", MINI3, 1, 300, 40), ("mini3_ns2", MINI3, 2, 200, 7), ("mini3_ns3_bias", dict(MINI3, bias=True), 3, 200, 25), ("cfg3_ns1", "cfg3", 1, 100, 600),
       ("mini3_ns4", MINI3, 4, 200, 40), ("mini3_bias_ns5", dict(MINI3, bias=True), 5, 150, 9), ("mini3_ns33", MINI3, 33, 100, 20),
       ("cfg3_ns4", "cfg3", 4, 80, 700), ("cfg3_ns7", "cfg3", 7, 60, 30), ("cfg3_ns40", "cfg3", 40, 40, 3)]
 
@@ -427,7 +428,29 @@ def test_wave_specialised_kernel(label, cfg, ns, N, n_given):
     eng.close()
 
 
-FORMS = [("mini3_ns4", MINI3, 4, 160, 9), ("mini3_ns12", MINI3, 12, 120, 30), ("mini3_bias_ns10", dict(MINI3, bias=True), 10, 120, 4),
+@pytest.mark.parametrize("ns,mode", [(1, 0), (3, 0), (6, 3)])
+def test_wave_specialised_kernel_two_way_split(ns, mode, monkeypatch):
+    """cfg2 with its layers split over TWO workgroups (the two-partial form of the input poll, wn_ap_look2 / wn_ap_spin2), one and two
+    streams per item, priming past the d = 512 wrap."""
+    monkeypatch.setenv("WN_V3_MODE", str(mode))
+    cfg, W, first, uniforms = make_case("cfg2", 83, ns, 600, 70)
+    eng = engine.Engine(cfg, W, n_streams=ns, layer_split=2)
+    info = eng.info()
+    assert info["kernel_variant"] == 3 and info["layer_split"] == 2 and info["streams_per_item"] == (2 if mode & 1 else 1)
+    ids = eng.generate(70, first, temperature=0.0, batched_prime=False, timeout_ms=8000)
+    out = eng.generate(70, first, temperature=0.9, regularize=0.002, uniforms=uniforms, batched_prime=False, timeout_ms=8000)
+    for s in sorted(set((0, ns - 1))):
+        g_idx, g_log = c_oracle.generate(cfg, W, 70, first[s], 0.0, 0.0)
+        if not np.array_equal(ids[s], g_idx):
+            t = int(np.argmax(ids[s] != g_idx))
+            row = np.sort(g_log[t])
+            assert row[-1] - row[-2] <= 1e-4 * max(1.0, float(np.abs(g_log).max())), (s, t)
+        o_idx, _ = c_oracle.generate(cfg, W, 70, first[s], 0.9, 0.002, uniforms[s])
+        assert np.array_equal(out[s], o_idx), s
+    eng.close()
+
+
+FORMS = [("cfg2_ns6", "cfg2", 6, 60, 600), ("cfg1_ns8_bias", dict(synth.CONFIGS["cfg1"], bias=True), 8, 120, 40), ("mini3_ns4", MINI3, 4, 160, 9), ("mini3_ns12", MINI3, 12, 120, 30), ("mini3_bias_ns10", dict(MINI3, bias=True), 10, 120, 4),
          ("mini3_ns7_odd", MINI3, 7, 100, 12), ("cfg3_ns6", "cfg3", 6, 60, 700), ("mini3_ns64", MINI3, 64, 100, 3)]
 
 

@@ -16,7 +16,7 @@ HARNESS = r"""
 #include <cstdlib>
 int main(int argc, char** argv) {
     if (argc >= 2 && argv[1][0] == 'm') {  // m <n_streams> [pin]: the form of the wave-specialised kernel
-        printf("%d\n", wn_v3_mode_for(atoi(argv[2]), argc > 3 ? argv[3] : nullptr));
+        printf("%d\n", wn_v3_mode_for(atoi(argv[2]), (argc > 3 && argv[3][0] != '-') ? argv[3] : nullptr, argc > 4 ? atoi(argv[4]) : 50));
         return 0;
     }
     if (argc >= 2 && argv[1][0] == 'r') {  // r <n_streams>: round sizes
@@ -86,15 +86,19 @@ def test_placement_refuses_what_does_not_fit(harness):
 
 
 def test_form_of_the_wave_specialised_kernel(harness):
-    """bit 0 (two streams per layer item) needs an even stream count, the throughput form starts at 56 streams, WN_V3_MODE pins."""
-    def mode(n, pin=None):
-        return int(subprocess.check_output([harness, "m", str(n)] + ([pin] if pin is not None else [])).decode())
+    """bit 0 (two streams per layer item) needs an even stream count, the throughput form starts at n_layers + 6 streams (cfg3: 56),
+    WN_V3_MODE pins."""
+    def mode(n, pin=None, n_layers=50):
+        return int(subprocess.check_output([harness, "m", str(n), pin if pin is not None else "-", str(n_layers)]).decode())
     assert [mode(n) for n in (1, 2, 16, 48, 55)] == [0, 0, 0, 0, 0]
     assert [mode(n) for n in (56, 64, 128)] == [3, 3, 3]
     assert [mode(n) for n in (57, 63, 129)] == [2, 2, 2]          # odd: one stream per item, two head replicas
     assert [mode(6, p) for p in ("0", "1", "2", "3")] == [0, 1, 2, 3]
     assert [mode(7, p) for p in ("0", "1", "2", "3")] == [0, 0, 2, 2]
     assert mode(1, "3") == 0 and mode(64, "0") == 0 and mode(64, "7") == 3 and mode(64, "12") == 3  # junk is ignored
+    # the threshold follows the ring's length: n_layers + 6 streams (cfg2: 30 layers, cfg1: 10)
+    assert [mode(n, None, 30) for n in (32, 35, 36, 64)] == [0, 0, 3, 3]
+    assert [mode(n, None, 10) for n in (14, 16, 17, 64)] == [0, 3, 2, 3]
 
 
 @pytest.mark.parametrize("ns", [129, 130, 170, 192, 255, 256, 257, 301, 381, 383, 384, 385, 512, 1000])

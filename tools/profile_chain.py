@@ -29,9 +29,8 @@ def main():
     info = eng.info()
     P, PA, NL = info["layer_split"], info["head_split"], info["n_layers"]
     N = 400 if ns == 1 else 60
-    mode = int(os.environ.get("WN_V3_MODE", "3" if ns >= 56 else "0")) if (info["kernel_variant"] == 3 and ns >= 2) else 0
-    G = 2 if (mode & 1 and ns % 2 == 0) else 1   # streams per pipeline item of the layer workgroups
-    HG = 2 if mode & 2 else 1                     # replicas of the head workgroups (each serves every HG-th stream)
+    G = max(1, info.get("streams_per_item", 1))   # streams per pipeline item of the layer workgroups (the form that runs: wn_get_info)
+    HG = max(1, info.get("head_replicas", 1))     # replicas of the head workgroups (each serves every HG-th stream)
     n_total = ns
     nc = max(1, info.get("n_chains", 1))
     ns = ns // nc          # the stamps are those of the first chain: its streams
