@@ -110,7 +110,7 @@ struct WnV2Entry {
     void (*launch)(int grid, size_t lds, hipStream_t st, const WnPlan& p, const WnRun& r);
     void (*launch_multi)(int w0lds, int grid, size_t lds, hipStream_t st, const WnPlan& p, const WnRun& r);
     void (*pack)(const WnPlan& pl, const WnHostWeights& w, std::vector<float>& out);
-    // wave-specialised multi-stream kernel (wn_kernel_v3.h): 512-thread layer workgroups, one chain for all streams
+    // wave-specialised multi-stream kernel (wn_kernel_v3.h): 768-thread layer workgroups, one chain for all streams
     // [g2]: 0 = one stream per pipeline item of a layer workgroup, 1 = two (wn_v3_mode)
     const void* fn_v3[2];
     int (*lds_floats_v3)(int ns, int g2);

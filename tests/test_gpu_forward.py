@@ -87,7 +87,7 @@ def test_forward_refuses_padded_regime_and_facade_uses_it_when_valid():
         y = mg(x.cuda())
     assert mg._wn_forward_calls == 1  # served by wn_forward
     assert np.abs(y.cpu().numpy() - ref).max() <= TOL
-    y2 = mg(x.cuda())  # autograd on: torch path (backward is not native yet)
+    y2 = mg(x.cuda())  # autograd on: the native training forward (wn_train_forward, its backward behind loss.backward()), not wn_forward
     assert mg._wn_forward_calls == 1 and y2.requires_grad
 
 
