@@ -400,7 +400,7 @@ struct WnV3Lds {
 // group K1 + K2, a head workgroup its end_conv_1 slice + end_conv_2 rows (K3 + EC); the rest is working set.
 template <class SH, int P>
 static constexpr bool wn_v3_fits() {
-    return (P == 1 || P == 2 || P == 4) && SH::RS * SH::DC <= 100 && SH::K1 + SH::K2 <= 80 && SH::K3 <= 100 && SH::K3 % 4 == 0 && SH::EC % 4 == 0 &&
+    return (P == 1 || P == 2 || P == 4) && SH::RS * SH::DC <= 100 && SH::K1 + SH::K2 <= 80 && (SH::K3 <= 100 || (SH::K3 <= 128 && SH::EC <= 32)) && SH::K3 % 4 == 0 && SH::EC % 4 == 0 &&
            SH::DC % 4 == 0 && SH::R % 4 == 0;
 }
 // ... and the two-streams-per-item form: a critical lane takes the filter AND the gate row of a channel on half an x slice, read as float4
@@ -991,18 +991,29 @@ static __device__ void wn_v3_head(const WnPlan& p, const WnRun& r, WnCtx& cx, fl
     const int tid = threadIdx.x, ns = p.n_streams, NL = p.NL;
     const int HR = p.HR, h = hw % p.PA, rep = hw / p.PA;  // slice of end_conv_1 / end_conv_2, replica
     const int n_mine = rep < ns ? (ns - rep + HR - 1) / HR : 0;  // streams this replica serves
-    // end_conv_1's slice stays in registers; the lane's end_conv_2 row (EC floats) lives in LDS as float4 [EC / 4][256 lanes] -- a head
-    // workgroup has the LDS to itself, and with the row in registers the role did not fit the 152 registers the compiler may use
-    // (it spilled operands of the long dot into scratch)
-    float w4[K3];
+    // end_conv_1's slice stays in registers and the lane's end_conv_2 row (EC floats) lives in LDS as float4 [EC / 4][256 lanes] -- a head
+    // workgroup has the LDS to itself, and with both in registers the role did not fit the 152 registers the compiler may use.  A slice
+    // too long for the registers (K3 > 100: the train_script.py shape, 1024 skip channels over 8 lanes) swaps places with the row: W4LDS.
+    constexpr bool W4LDS = K3 > 100;
+    static_assert(!W4LDS || EC <= 32, "one of the head's two weight vectors has to fit the registers");
+    static_assert(L::pre % 4 == 0, "the head's LDS-resident weights are read as float4");
+    float w4[W4LDS ? 1 : K3], w5[W4LDS ? EC : 1];
     const float* img = p.blobs + (size_t)NL * P * (SH::NWL * 256) + (size_t)h * (SH::NWH * 256) + tid;
+    float4* wl = reinterpret_cast<float4*>(lds + L::pre) + tid;  // [k4 * 256]: the LDS-resident vector of this lane
+    if constexpr (W4LDS) {
+#pragma unroll 4
+        for (int k4 = 0; k4 < K3 / 4; ++k4)
+            wl[k4 * 256] = float4{img[(size_t)(4 * k4) * 256], img[(size_t)(4 * k4 + 1) * 256], img[(size_t)(4 * k4 + 2) * 256], img[(size_t)(4 * k4 + 3) * 256]};
 #pragma unroll
-    for (int k = 0; k < K3; ++k) w4[k] = img[(size_t)k * 256];
-    static_assert(L::pre % 4 == 0, "the end_conv_2 rows are read as float4");
-    float4* w5l = reinterpret_cast<float4*>(lds + L::pre) + tid;  // [k4 * 256]
+        for (int k = 0; k < EC; ++k) w5[k] = img[(size_t)(K3 + k) * 256];
+    } else {
 #pragma unroll
-    for (int k4 = 0; k4 < EC / 4; ++k4)
-        w5l[k4 * 256] = float4{img[(size_t)(K3 + 4 * k4) * 256], img[(size_t)(K3 + 4 * k4 + 1) * 256], img[(size_t)(K3 + 4 * k4 + 2) * 256], img[(size_t)(K3 + 4 * k4 + 3) * 256]};
+        for (int k = 0; k < K3; ++k) w4[k] = img[(size_t)k * 256];
+#pragma unroll
+        for (int k4 = 0; k4 < EC / 4; ++k4)
+            wl[k4 * 256] = float4{img[(size_t)(K3 + 4 * k4) * 256], img[(size_t)(K3 + 4 * k4 + 1) * 256], img[(size_t)(K3 + 4 * k4 + 2) * 256], img[(size_t)(K3 + 4 * k4 + 3) * 256]};
+    }
+    float4* w5l = wl;
     const float b1 = img[(size_t)(K3 + EC) * 256], b2 = img[(size_t)(K3 + EC + 1) * 256];
     const int kq3 = tid % T3, row3 = tid / T3;
     float* sk = lds + L::sk;
@@ -1092,13 +1103,31 @@ static __device__ void wn_v3_head(const WnPlan& p, const WnRun& r, WnCtx& cx, fl
                 else __builtin_amdgcn_raw_buffer_store_b64(d, rs_gl, lane8, gl_off, 16);  // write-through
             };
             if (!prime) {
-                float a = wn_dot_lds_chunked<K3, CH3>(w4, sk + kq3 * (K3 + 4), 0.f);
+                float a;
+                if constexpr (W4LDS) {  // the arithmetic of wn_dot_lds_chunked (two packed chains, same order), the weights from LDS
+                    wn_f2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
+                    const float4* x4 = reinterpret_cast<const float4*>(sk + kq3 * (K3 + 4));
+#pragma unroll
+                    for (int c0 = 0; c0 < K3 / 4; c0 += CH3) {
+                        float4 wv[CH3], xv[CH3];
+#pragma unroll
+                        for (int k = 0; k < CH3; ++k) { wv[k] = wl[(c0 + k) * 256]; xv[k] = x4[c0 + k]; }
+#pragma unroll
+                        for (int k = 0; k < CH3; ++k) {
+                            a01 = __builtin_elementwise_fma(wn_f2{wv[k].x, wv[k].y}, wn_f2{xv[k].x, xv[k].y}, a01);
+                            a23 = __builtin_elementwise_fma(wn_f2{wv[k].z, wv[k].w}, wn_f2{xv[k].z, xv[k].w}, a23);
+                        }
+                    }
+                    a = (a01.x + a01.y) + (a23.x + a23.y);
+                } else {
+                    a = wn_dot_lds_chunked<K3, CH3>(w4, sk + kq3 * (K3 + 4), 0.f);
+                }
                 a = wn_reduce<T3>(a) + b1;
                 if (kq3 == 0) ev[row3] = a > 0.f ? a : 0.f;  // relu(end_conv_1)
                 request(s + HR < ns ? s + HR : rep);  // (after the long dot: its sixteen registers are not live next to that dot's operands)
                 // the lane's end_conv_2 row: fetched from LDS while the other waves finish end_conv_1 where it is short enough to sit in
                 // registers next to end_conv_1's slice (EC <= 32), read chunk by chunk inside the dot otherwise
-                constexpr bool W5PRE = EC <= 32;
+                constexpr bool W5PRE = !W4LDS && EC <= 32;
                 float4 w5r[W5PRE ? EC / 4 : 1];
                 if constexpr (W5PRE) {
 #pragma unroll
@@ -1109,7 +1138,10 @@ static __device__ void wn_v3_head(const WnPlan& p, const WnRun& r, WnCtx& cx, fl
                     wn_f2 a01 = {b2, 0.f}, a23 = {0.f, 0.f};
 #pragma unroll
                     for (int k4 = 0; k4 < EC / 4; ++k4) {
-                        const float4 w = W5PRE ? w5r[W5PRE ? k4 : 0] : w5l[k4 * 256], v = reinterpret_cast<const float4*>(ev)[k4];
+                        float4 w;
+                        if constexpr (W4LDS) w = float4{w5[W4LDS ? 4 * k4 : 0], w5[W4LDS ? 4 * k4 + 1 : 0], w5[W4LDS ? 4 * k4 + 2 : 0], w5[W4LDS ? 4 * k4 + 3 : 0]};
+                        else w = W5PRE ? w5r[W5PRE ? k4 : 0] : w5l[k4 * 256];
+                        const float4 v = reinterpret_cast<const float4*>(ev)[k4];
                         a01 = __builtin_elementwise_fma(wn_f2{w.x, w.y}, wn_f2{v.x, v.y}, a01);
                         a23 = __builtin_elementwise_fma(wn_f2{w.z, w.w}, wn_f2{v.z, v.w}, a23);
                     }

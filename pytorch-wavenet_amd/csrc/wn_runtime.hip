@@ -200,7 +200,7 @@ static WnV2Entry wn_v2_entry() {
         e.lds_floats_v3 = [](int ns, int g2) {
             int lay = WnV3Lds<SH, 1>::floats(ns);
             if constexpr (wn_v3_g2_fits<SH>()) { if (g2) lay = WnV3Lds<SH, 2>::floats(ns); }
-            const int head = WnV3Lds<SH, 1>::pre + EC * 256;  // + the head lanes' end_conv_2 rows (wn_v3_head)
+            const int head = WnV3Lds<SH, 1>::pre + (SH::K3 > 100 ? SH::K3 : EC) * 256;  // + the head lanes' LDS-resident weights (wn_v3_head)
             const int smp = WnV3Lds<SH, 1>::pre + 256 * R;    // + start_conv^T in the sampler workgroups (wn_v3_sampler), when it fits
             int need = lay > head ? lay : head;
             if (smp * 4 <= WN_LDS_MAX_BYTES && smp > need) need = smp;
@@ -222,7 +222,8 @@ static const std::vector<WnV2Entry>& wn_v2_table() {
         wn_v2_entry<128, 32, 512, 64, 4>(),   // cfg3 with PA=4 (head_split=4)
         wn_v2_entry<64, 64, 256, 64, 1>(),    // cfg2: P=1, PA=4
         wn_v2_entry<32, 32, 256, 64, 1>(),    // cfg1: P=1, PA=4
-        wn_v2_entry<32, 32, 1024, 32, 1>(),   // train_script.py chaconne shape: P=1, PA=16
+        wn_v2_entry<32, 16, 1024, 32, 2>(),   // train_script.py chaconne shape, two-way split: the form whose roles fit variant 3 (PA=16)
+        wn_v2_entry<32, 32, 1024, 32, 1>(),   // ... unsplit: P=1, PA=16 (256-thread kernels)
         wn_v2_entry<64, 32, 256, 64, 2>(),    // cfg2 split in two
         wn_v2_entry<16, 16, 256, 32, 1>(),    // small test shape (P = 1; P = 2 with D = 32 runs single-stream only)
         wn_v2_entry<16, 16, 256, 32, 2>(),    // ... and its two-slice form for multi-stream
@@ -231,11 +232,12 @@ static const std::vector<WnV2Entry>& wn_v2_table() {
 }
 
 // picks an instantiated shape for this model; returns its index or -1
-static int wn_v2_choose(const WnPlan& pl, int n_cu, int n_smp, int forced_P, int forced_PA, int* outP, int* outPA) {
+static int wn_v2_choose(const WnPlan& pl, int n_cu, int n_smp, int forced_P, int forced_PA, int* outP, int* outPA, bool need_v3 = false) {
     if (pl.k != 2 || pl.C != 256) return -1;
     const std::vector<WnV2Entry>& t = wn_v2_table();
     for (size_t i = 0; i < t.size(); ++i) {
         const WnV2Entry& e = t[i];
+        if (need_v3 ? !e.fn_v3[0] : (e.fn_v3[0] && e.Pm == 2 && e.S == 1024)) continue;  // (the two-way split of the train_script shape exists for variant 3 only)
         if (e.R != pl.R || e.S != pl.S || pl.D % e.DC || pl.E % e.EC) continue;
         const int P = pl.D / e.DC, PA = pl.E / e.EC;
         if (P > 8 || PA > 16) continue;
@@ -277,8 +279,8 @@ static bool wn_v3_applicable(const wn_config* cfg, int n_cu, int* out_vi, int* o
     pl.C = cfg->classes; pl.k = cfg->kernel_size; pl.n_streams = cfg->n_streams;
     const int n_smp = wn_sampler_count(cfg->n_streams);
     int P = 0, PA = 0;
-    const int vi = wn_v2_choose(pl, n_cu, n_smp, cfg->layer_split, cfg->head_split, &P, &PA);
-    if (vi < 0 || !wn_v2_table()[vi].fn_v3[0]) return false;
+    const int vi = wn_v2_choose(pl, n_cu, n_smp, cfg->layer_split, cfg->head_split, &P, &PA, true);
+    if (vi < 0) return false;
     if (wn_v2_table()[vi].lds_floats_v3(cfg->n_streams, (wn_v3_mode(cfg->n_streams, cfg->layers * cfg->blocks) & 1) && wn_v2_table()[vi].fn_v3[1]) * 4 > WN_LDS_MAX_BYTES) return false;
     if (out_vi) *out_vi = vi;
     if (outP) *outP = P;

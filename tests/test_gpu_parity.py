@@ -31,11 +31,11 @@ SMALL = [
 
 def _expected_variant(cfg, ns, layer_split=0):
     """3 = wave-specialised kernel (csrc/wn_kernel_v3.h): every instantiated channel shape whose roles fit its register budget (round 3:
-    also unsplit / two-way split stacks, one skip row per lane, fewer than 64 residual channels) -- all BASELINE configs; the
-    train_script.py shape (32 / 32 / 1024 / 512: 128 skip weights per lane) stays on the 256-thread register kernels (2)."""
+    also unsplit / two-way split stacks, one skip row per lane, fewer than 64 residual channels, an end_conv_1 slice in LDS) -- all
+    BASELINE configs and the train_script.py shape (32 / 32 / 1024 / 512, split two ways); 2 = the 256-thread register kernels."""
     cfg = synth.CONFIGS[cfg] if isinstance(cfg, str) else cfg
     shape = (cfg["residual_channels"], cfg["dilation_channels"], cfg["skip_channels"], cfg["end_channels"])
-    on3 = shape in ((128, 128, 512, 256), (64, 64, 256, 256), (32, 32, 256, 256), (16, 16, 256, 32), (16, 32, 256, 64))
+    on3 = shape in ((128, 128, 512, 256), (64, 64, 256, 256), (32, 32, 256, 256), (32, 32, 1024, 512), (16, 16, 256, 32), (16, 32, 256, 64))
     import os
     return 3 if on3 and os.environ.get("WN_KERNEL") not in ("v2", "generic") else 2
 
