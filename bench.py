@@ -455,8 +455,7 @@ def main():
     bytes_per_launch = bytes_per_tstep * a.samples
     achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
     traffic, traffic_source = _pmc_traffic(a, info, per_gpu)
-    kname = {1: "wn_generate_kernel", 2: "wn_generate_kernel_v2m" if per_gpu > 1 else "wn_generate_kernel_v2",  # (2: the train_script.py shape only)
-             3: "wn_generate_kernel_v3m"}.get(info["kernel_variant"], "?")
+    kname = {1: "wn_generate_kernel", 3: "wn_generate_kernel_v3m"}.get(info["kernel_variant"], "?")
     line = {
         "metric": "generate_fast() audio samples/sec (256-class mu-law), whole job over all GPUs",
         "value": round(value, 1), "unit": "samples/s", "n_gpus": n_gpus, "steps": a.steps, "warmup": a.warmup,
@@ -483,9 +482,8 @@ def main():
                      "kernel": kname, "kernel_ms_per_launch": round(kernel_ms, 3), "kernel_ms_per_launch_median": round(eng_leg["kernel_ms_median"], 3),
                      "algorithmic_bytes_per_launch": int(bytes_per_launch),
                      "algorithmic_bytes_per_timestep": int(bytes_per_tstep), "launches_per_step": 1,
-                     "note": "engine-level leg: one launch = one wn_generate job of %d timesteps: n_chains persistent kernels running "
-                             "CONCURRENTLY, timed together with HIP events on the launch stream; rocprofv3 lists them as n_chains "
-                             "overlapping dispatches" % a.samples},
+                     "note": "engine-level leg: one launch = one wn_generate job of %d timesteps = ONE persistent kernel (n_chains > 1: the "
+                             "rounds of a job beyond one chain's capacity, one after the other), timed with HIP events on the launch stream" % a.samples},
     }
     if n_gpus == 1 and not a.no_extra:
         extra = {}

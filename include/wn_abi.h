@@ -17,11 +17,9 @@
  *   - wn_generate jobs are persistent kernels: every workgroup of a job must be resident before the job
  *     makes progress.  A job that finds the device's CUs taken (another handle's job, a long torch
  *     kernel) starts when they free up; its hand-off timeout (timeout_ms) bounds every single hand-off
- *     wait of its workgroups, so size it for the longest job that may run next to it.  Depending on the
- *     shape a job is ONE persistent kernel (kernel_variant 3, any stream count up to ~150) or, on the
- *     256-thread kernels from 16 streams up, several independent chains, two workgroups per CU, on the
- *     caller's stream plus one library-owned stream (forked and joined with events: to the caller it is
- *     one asynchronous job).
+ *     wait of its workgroups, so size it for the longest job that may run next to it.  A job is ONE
+ *     persistent kernel (any stream count up to ~150 at cfg3's shape), or, beyond one chain's capacity,
+ *     rounds of up to 128 streams, one kernel after the other on the caller's stream.
  */
 #ifndef WN_ABI_H
 #define WN_ABI_H
@@ -119,13 +117,13 @@ typedef struct wn_info {
     int64_t handoff_bytes;   /* inter-workgroup granule buffers */
     int64_t evals_done;      /* timesteps evaluated since the last wn_reset (queue time) */
     int32_t kernel_variant;  /* 1 = generic kernel (weights stationary in LDS, any shape)
-                                2 = latency-optimised 256-thread kernels (weights stationary in registers, instantiated shapes)
-                                3 = wave-specialised kernel (768-thread layer workgroups: critical / skip / queue wave groups,
-                                    one chain for up to ~150 streams; from 56 streams up two streams per layer item and two
-                                    replicas of the head workgroups; shapes with an even number of skip rows per lane) */
-    int32_t n_chains;        /* independent chains (persistent kernels) the streams are split over: 1; an even number that share
-                                the CUs two by two (variant 2); or the rounds of up to 128 streams a variant-3 job beyond one
-                                chain's capacity runs one after the other; n_workgroups and the byte counts are totals over them */
+                                3 = wave-specialised kernel (768-thread layer workgroups: critical / skip / queue wave groups, weights
+                                    stationary in registers, one chain for up to ~150 streams; from n_layers + 6 streams two streams per
+                                    layer item and two replicas of the head workgroups): every instantiated shape -- BASELINE configs 1-4
+                                    and the train_script.py shape
+                                (2 = the 256-thread register-resident kernels of ABI version 1: removed) */
+    int32_t n_chains;        /* 1, or the rounds of up to 128 streams a job beyond one chain's capacity runs one after the other;
+                                n_workgroups and the byte counts are totals over them */
     int32_t streams_per_item; /* the FORM that runs (variant 3; 1 elsewhere): streams a layer workgroup processes per pipeline item */
     int32_t head_replicas;    /* ... replicas of the head workgroups (replica j serves the streams s = j mod head_replicas) */
     int32_t n_samplers;       /* ... dedicated sampler workgroups (0: layer 0 samples itself, single-stream kernels of variant 1 / 2) */

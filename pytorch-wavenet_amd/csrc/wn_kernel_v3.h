@@ -47,7 +47,7 @@
 #ifndef WN_KERNEL_V3_H
 #define WN_KERNEL_V3_H
 
-#include "wn_kernel_v2.h"
+#include "wn_chain_regs.h"
 
 #ifndef WN_THREADS_V3
 #define WN_THREADS_V3 768
@@ -389,7 +389,7 @@ static __device__ __forceinline__ int wn_barrier_flag(WnCtx& cx, int* flag) {
 
 template <class SH, int G = 1>
 struct WnV3Lds {
-    using M = WnV2LdsM<SH, G, false>;  // G streams per pipeline item: x, z, taps, the head's staging areas are [G][...]
+    using M = WnV2LdsM<SH, G>;  // G streams per pipeline item: x, z, taps, the head's staging areas are [G][...]
     static constexpr int XR = M::XR, SKP = M::SKP, DCP = M::DCP;
     static constexpr int xs = M::xs, zs = M::zs, xo = M::xo, sk = M::sk, ev = M::ev, smp = M::smp, park = M::park;
     static constexpr int pre = M::pre;        // [n_streams][256]

@@ -13,20 +13,15 @@
 
 #include "../../include/wn_abi.h"
 #include "wn_kernel.h"
-#include "wn_kernel_v2.h"
 #include "wn_kernel_v3.h"
 #include "wn_forward.h"
 
 static thread_local char g_err[512] = "";
-static thread_local int g_chain_member = 0;  // wn_create is building one chain of a two-chain handle
-#define WN_LDS_SHARED_MAX_BYTES (81920 - 1024)  // two workgroups per CU: half of the 160 KB LDS each, minus the static allocation
-#define WN_CHAIN_MIN_STREAMS 16   // below: the chain is latency-bound, splitting does not pay (measured: 16 neutral, 32 +9 %, 64 +44 %)
-#define WN_CHAIN_MAX_STREAMS 40   // streams per chain that still fit two workgroups per CU at cfg3's shape (78 KB LDS)
-
 // Development overrides (WN_KERNEL, WN_V3_MODE, WN_CHAINS, WN_SAMPLERS, WN_NO_LOCAL_STORES) pick another kernel or form than the
 // planner would: they exist for A/B runs and for the tests that pin a form, and are IGNORED unless WN_TESTING=1 is set as well -- a
 // stray variable in a production environment must not silently change what runs (wn_get_info reports the form that does).
 static thread_local int g_dev_env_used = 0;
+static thread_local int g_create_depth = 0;  // wn_create is building the member handles of a rounds front
 static const char* wn_dev_env(const char* name) {
     const char* t = getenv("WN_TESTING");
     if (!t || t[0] != '1') return nullptr;
@@ -95,23 +90,15 @@ __global__ __launch_bounds__(WN_THREADS) void wn_generate_kernel(WnPlan p, WnRun
 }
 
 
-// ------------------------------------------------------------------------------------------------ v2 (register-resident) variants
-// Shapes the latency-optimised kernel is instantiated for: (R, D/P, S, E/PA).  Anything else runs on the generic
-// LDS-resident kernel above.
+// ------------------------------------------------------------------------------------------------ register-resident shapes
+// Shapes the wave-specialised kernel (variant 3, wn_kernel_v3.h) is instantiated for: (R, D/P, S, E/PA, P).  Anything else runs on the
+// generic LDS-resident kernel above.  (Rounds 1-2 also had 256-thread kernels on these shapes -- "variant 2", one chain or several
+// sharing the CUs two by two; round 3 moved every shape to variant 3 and removed them.)
 struct WnV2Entry {
     int R, DC, S, EC, nwl, nwh;
-    int Pm;  // layer split the multi-stream kernel is compiled for (its request code is unrolled over it)
-    const void* fn;
-    const void* fn_multi;     // multi-stream kernel, one workgroup per CU
-    const void* fn_multi_w0;  // ... with the tap-0 weights in LDS: fits 2 workgroups per CU (NULL: shape does not fit 256 VGPRs)
-    int (*lds_floats)(int);
-    int (*lds_floats_with_start)(int);
-    int (*lds_floats_multi)(int ns, int w0lds);
-    void (*launch)(int grid, size_t lds, hipStream_t st, const WnPlan& p, const WnRun& r);
-    void (*launch_multi)(int w0lds, int grid, size_t lds, hipStream_t st, const WnPlan& p, const WnRun& r);
+    int Pm;  // layer split the kernel is compiled for (its input poll is unrolled over it)
     void (*pack)(const WnPlan& pl, const WnHostWeights& w, std::vector<float>& out);
-    // wave-specialised multi-stream kernel (wn_kernel_v3.h): 768-thread layer workgroups, one chain for all streams
-    // [g2]: 0 = one stream per pipeline item of a layer workgroup, 1 = two (wn_v3_mode)
+    // [g2]: 0 = one stream per pipeline item of a layer workgroup, 1 = two (wn_v3_mode; NULL where the shape has no such form)
     const void* fn_v3[2];
     int (*lds_floats_v3)(int ns, int g2);
     int lds_pre_v3;  // float offset of the per-stream area = what head / sampler workgroups use in front of their own tables
@@ -171,29 +158,10 @@ static WnV2Entry wn_v2_entry() {
     using SH = WnV2Shape<R, DC, S, EC>;
     WnV2Entry e;
     e.R = R; e.DC = DC; e.S = S; e.EC = EC; e.nwl = SH::NWL; e.nwh = SH::NWH; e.Pm = PM;
-    e.fn = (const void*)wn_generate_kernel_v2<R, DC, S, EC>;
-    e.fn_multi = (const void*)wn_generate_kernel_v2m<R, DC, S, EC, PM, 1, false>;
-    e.fn_multi_w0 = nullptr;
-    e.lds_floats_multi = [](int ns, int) { return WnV2LdsM<SH, 1, false>::floats(ns); };
-    e.launch_multi = [](int, int grid, size_t lds, hipStream_t st, const WnPlan& p, const WnRun& r) {
-        hipLaunchKernelGGL((wn_generate_kernel_v2m<R, DC, S, EC, PM, 1, false>), dim3(grid), dim3(WN_THREADS), lds, st, p, r);
-    };
-    if constexpr (wn_v2m_shareable(R, DC, S, EC)) {
-        e.fn_multi_w0 = (const void*)wn_generate_kernel_v2m<R, DC, S, EC, PM, 1, true>;
-        e.lds_floats_multi = [](int ns, int w0lds) { return w0lds ? WnV2LdsM<SH, 1, true>::floats(ns) : WnV2LdsM<SH, 1, false>::floats(ns); };
-        e.launch_multi = [](int w0lds, int grid, size_t lds, hipStream_t st, const WnPlan& p, const WnRun& r) {
-            if (w0lds) hipLaunchKernelGGL((wn_generate_kernel_v2m<R, DC, S, EC, PM, 1, true>), dim3(grid), dim3(WN_THREADS), lds, st, p, r);
-            else hipLaunchKernelGGL((wn_generate_kernel_v2m<R, DC, S, EC, PM, 1, false>), dim3(grid), dim3(WN_THREADS), lds, st, p, r);
-        };
-    }
-    e.lds_floats = [](int ns) { return WnV2Lds<SH>::floats(ns); };
-    e.lds_floats_with_start = [](int ns) { return WnV2Lds<SH>::floats_with_start(ns); };
-    e.launch = [](int grid, size_t lds, hipStream_t st, const WnPlan& p, const WnRun& r) {
-        hipLaunchKernelGGL((wn_generate_kernel_v2<R, DC, S, EC>), dim3(grid), dim3(WN_THREADS), lds, st, p, r);
-    };
     e.pack = wn_pack_v2<SH>;
     e.fn_v3[0] = e.fn_v3[1] = nullptr; e.lds_floats_v3 = nullptr; e.launch_v3 = nullptr; e.lds_pre_v3 = 0;
-    if constexpr (wn_v3_fits<SH, PM>()) {
+    static_assert(wn_v3_fits<SH, PM>(), "every table entry runs the wave-specialised kernel");
+    {
         e.fn_v3[0] = (const void*)wn_generate_kernel_v3m<R, DC, S, EC, PM, 1>;
         if constexpr (wn_v3_g2_fits<SH>()) e.fn_v3[1] = (const void*)wn_generate_kernel_v3m<R, DC, S, EC, PM, 2>;
         e.lds_pre_v3 = WnV3Lds<SH, 1>::pre;
@@ -219,30 +187,26 @@ static WnV2Entry wn_v2_entry() {
 static const std::vector<WnV2Entry>& wn_v2_table() {
     static const std::vector<WnV2Entry> t = {
         wn_v2_entry<128, 32, 512, 32, 4>(),   // cfg3: P=4, PA=8 (a 64-row head slice is the slowest pipeline stage)
-        wn_v2_entry<128, 32, 512, 64, 4>(),   // cfg3 with PA=4 (head_split=4)
         wn_v2_entry<64, 64, 256, 64, 1>(),    // cfg2: P=1, PA=4
         wn_v2_entry<32, 32, 256, 64, 1>(),    // cfg1: P=1, PA=4
-        wn_v2_entry<32, 16, 1024, 32, 2>(),   // train_script.py chaconne shape, two-way split: the form whose roles fit variant 3 (PA=16)
-        wn_v2_entry<32, 32, 1024, 32, 1>(),   // ... unsplit: P=1, PA=16 (256-thread kernels)
-        wn_v2_entry<64, 32, 256, 64, 2>(),    // cfg2 split in two
-        wn_v2_entry<16, 16, 256, 32, 1>(),    // small test shape (P = 1; P = 2 with D = 32 runs single-stream only)
-        wn_v2_entry<16, 16, 256, 32, 2>(),    // ... and its two-slice form for multi-stream
+        wn_v2_entry<32, 16, 1024, 32, 2>(),   // train_script.py chaconne shape, split two ways (64 skip weights per lane), PA=16 (end_conv_1 slice in LDS)
+        wn_v2_entry<64, 32, 256, 64, 2>(),    // cfg2 split in two (layer_split=2)
+        wn_v2_entry<16, 16, 256, 32, 1>(),    // small test shape
+        wn_v2_entry<16, 16, 256, 32, 2>(),    // ... and its two-slice form
     };
     return t;
 }
 
 // picks an instantiated shape for this model; returns its index or -1
-static int wn_v2_choose(const WnPlan& pl, int n_cu, int n_smp, int forced_P, int forced_PA, int* outP, int* outPA, bool need_v3 = false) {
+static int wn_v2_choose(const WnPlan& pl, int n_cu, int n_smp, int forced_P, int forced_PA, int* outP, int* outPA) {
     if (pl.k != 2 || pl.C != 256) return -1;
     const std::vector<WnV2Entry>& t = wn_v2_table();
     for (size_t i = 0; i < t.size(); ++i) {
         const WnV2Entry& e = t[i];
-        if (need_v3 ? !e.fn_v3[0] : (e.fn_v3[0] && e.Pm == 2 && e.S == 1024)) continue;  // (the two-way split of the train_script shape exists for variant 3 only)
         if (e.R != pl.R || e.S != pl.S || pl.D % e.DC || pl.E % e.EC) continue;
         const int P = pl.D / e.DC, PA = pl.E / e.EC;
-        if (P > 8 || PA > 16) continue;
+        if (P != e.Pm || PA > 16) continue;  // the kernel is compiled per layer split
         if ((forced_P > 0 && forced_P != P) || (forced_PA > 0 && forced_PA != PA)) continue;
-        if (n_smp > 0 && e.Pm != P) continue;  // the multi-stream kernel is compiled per layer split
         if (pl.NL * P + PA + n_smp > n_cu) continue;
         *outP = P; *outPA = PA;
         return (int)i;
@@ -269,8 +233,8 @@ static int wn_v3_mode(int n_streams, int n_layers) { return wn_v3_mode_for(n_str
 // true iff the wave-specialised kernel (variant 3) serves this configuration with ONE chain: an instantiated shape, at least
 // two streams, the parked tap-0 sums of all streams fit the LDS next to the activations, one CU per workgroup
 static bool wn_v3_applicable(const wn_config* cfg, int n_cu, int* out_vi, int* outP, int* outPA) {
-    const char* force = wn_dev_env("WN_KERNEL");  // "generic" / "v2" pin the older kernels (A/B runs, tests)
-    if (force && (!strcmp(force, "generic") || !strcmp(force, "v2"))) return false;
+    const char* force = wn_dev_env("WN_KERNEL");  // "generic" pins the LDS-resident kernel (A/B runs, tests)
+    if (force && !strcmp(force, "generic")) return false;
     if (cfg->n_streams < WN_V3_MIN_STREAMS) return false;
     WnPlan pl;
     memset(&pl, 0, sizeof(pl));
@@ -279,7 +243,7 @@ static bool wn_v3_applicable(const wn_config* cfg, int n_cu, int* out_vi, int* o
     pl.C = cfg->classes; pl.k = cfg->kernel_size; pl.n_streams = cfg->n_streams;
     const int n_smp = wn_sampler_count(cfg->n_streams);
     int P = 0, PA = 0;
-    const int vi = wn_v2_choose(pl, n_cu, n_smp, cfg->layer_split, cfg->head_split, &P, &PA, true);
+    const int vi = wn_v2_choose(pl, n_cu, n_smp, cfg->layer_split, cfg->head_split, &P, &PA);
     if (vi < 0) return false;
     if (wn_v2_table()[vi].lds_floats_v3(cfg->n_streams, (wn_v3_mode(cfg->n_streams, cfg->layers * cfg->blocks) & 1) && wn_v2_table()[vi].fn_v3[1]) * 4 > WN_LDS_MAX_BYTES) return false;
     if (out_vi) *out_vi = vi;
@@ -303,29 +267,21 @@ struct wn_handle {
     WnPlan plan;
     bool have_weights;
     bool pending;
-    bool broken;   // multi-chain front: a launch failed after some chains had started; the chains' queue times diverged -> wn_reset
+    bool broken;   // rounds front: a launch failed after some rounds had started; the rounds' queue times diverged -> wn_reset
     void* last_stream;
     long long t_base;  // evaluations since the last reset
     int n_cu, wall_khz;
-    int variant;   // 1 = generic LDS-resident kernel, 2 = register-resident kernel
+    int variant;   // 1 = generic LDS-resident kernel, 3 = wave-specialised register-resident kernel (2: the 256-thread kernels of rounds 1-2, removed)
     int v2_index;  // row of wn_v2_table()
     int lds_bytes;
     int v3_mode;   // variant 3: streams per pipeline item (wn_v3_mode)
     int dev_overrides = 0;  // a development override was in effect when this handle was planned (wn_dev_env)
-    int w0lds;     // multi-stream kernel variant with tap-0 weights in LDS (this handle is one of two chains sharing the chip)
-    // Two chains: with >= WN_CHAIN_MIN_STREAMS streams the job is split into two independent chains of n_streams/2 streams,
-    // each a complete persistent kernel with its own queues and hand-off buffers, launched on two HIP streams.  Their
-    // workgroups share the CUs two by two (224 VGPRs, <= 80 KB LDS each) and compute in each other's hand-off waits:
-    // cfg3 x 64 streams 556 k -> 788 k samples/s.  This handle is then only a front that routes every call.
+    // Rounds: more streams than ONE chain holds (its LDS parks a tap-0 sum per stream: cfg3 ~150 streams) are served in rounds of up to
+    // WN_V3_ROUND_STREAMS streams, one round after the other on the caller's stream: this handle is then only a front that routes
+    // every call to its member handles (`chains`, one complete engine per round).
     std::vector<wn_handle*> chains;
-    std::vector<int> chain_first;  // first stream of chain i (chain_first[n_chains] = n_streams)
-    // Rounds: more streams than ONE wave-specialised chain holds (its LDS parks a tap-0 sum per stream: cfg3 ~150 streams) are
-    // served in rounds of up to WN_V3_ROUND_STREAMS streams, one round after the other on the caller's stream -- the member handles
-    // are those of `chains`, only they do not run concurrently.
+    std::vector<int> chain_first;  // first stream of round i (chain_first[n] = n_streams)
     bool rounds;
-    void* side_stream;  // hipStream_t of the second chain
-    void* ev_fork;      // hipEvent_t: user stream -> side stream
-    void* ev_join;      // hipEvent_t: side stream -> user stream
     // owned device allocations
     float *d_blobs, *d_start_t, *d_start_b, *d_rings;
     int32_t *d_dil, *d_wg_map;
@@ -358,9 +314,6 @@ extern "C" void wn_destroy(wn_handle* h) {
     if (!h->chains.empty()) {
         for (wn_handle* c : h->chains) wn_destroy(c);
         (void)hipSetDevice(h->cfg.device_id);
-        if (h->ev_fork) (void)hipEventDestroy((hipEvent_t)h->ev_fork);
-        if (h->ev_join) (void)hipEventDestroy((hipEvent_t)h->ev_join);
-        if (h->side_stream) (void)hipStreamDestroy((hipStream_t)h->side_stream);
         delete h;
         return;
     }
@@ -377,7 +330,7 @@ extern "C" int wn_create(const wn_config* cfg, wn_handle** out) {
     g_err[0] = 0;
     if (!cfg || !out) return wn_fail(WN_E_BADARG, "wn_create: NULL argument");
     *out = nullptr;
-    if (!g_chain_member) g_dev_env_used = 0;
+    if (!g_create_depth) g_dev_env_used = 0;
     if (cfg->layers < 1 || cfg->blocks < 1 || cfg->dilation_channels < 1 || cfg->residual_channels < 1 ||
         cfg->skip_channels < 1 || cfg->end_channels < 1 || cfg->classes < 2 || cfg->n_streams < 1)
         return wn_fail(WN_E_BADARG, "wn_create: non-positive dimension in wn_config");
@@ -406,7 +359,7 @@ extern "C" int wn_create(const wn_config* cfg, wn_handle** out) {
         const bool off = ce && ce[0] == '1';
         wn_config probe = *cfg;
         probe.n_streams = WN_V3_ROUND_STREAMS;
-        if (!g_chain_member && !off && cfg->n_streams > WN_V3_ROUND_STREAMS && !wn_v3_applicable(cfg, n_cu, nullptr, nullptr, nullptr) &&
+        if (!off && cfg->n_streams > WN_V3_ROUND_STREAMS && !wn_v3_applicable(cfg, n_cu, nullptr, nullptr, nullptr) &&
             wn_v3_applicable(&probe, n_cu, nullptr, nullptr, nullptr)) {
             const std::vector<int> sizes = wn_v3_round_sizes(cfg->n_streams, WN_V3_ROUND_STREAMS);
             std::vector<wn_handle*> cs;
@@ -417,7 +370,9 @@ extern "C" int wn_create(const wn_config* cfg, wn_handle** out) {
                 const int n = sizes[i];
                 part.n_streams = n;
                 wn_handle* c = nullptr;
+                ++g_create_depth;
                 rc = wn_create(&part, &c);
+                --g_create_depth;
                 if (rc == WN_OK) {
                     cs.push_back(c);
                     firsts.push_back(firsts.back() + n);
@@ -431,7 +386,7 @@ extern "C" int wn_create(const wn_config* cfg, wn_handle** out) {
                 f->plan = c0->plan;
                 f->plan.n_streams = cfg->n_streams;
                 f->have_weights = false; f->pending = false; f->last_stream = nullptr; f->t_base = 0;
-                f->n_cu = n_cu; f->wall_khz = wall_khz; f->variant = c0->variant; f->v2_index = c0->v2_index; f->lds_bytes = c0->lds_bytes; f->w0lds = 0;
+                f->n_cu = n_cu; f->wall_khz = wall_khz; f->variant = c0->variant; f->v2_index = c0->v2_index; f->lds_bytes = c0->lds_bytes;
                 f->v3_mode = c0->v3_mode;
                 f->d_blobs = f->d_start_t = f->d_start_b = f->d_rings = nullptr;
                 f->d_dil = f->d_wg_map = nullptr; f->d_ring_off = nullptr; f->d_gran = nullptr; f->d_status = nullptr;
@@ -444,7 +399,6 @@ extern "C" int wn_create(const wn_config* cfg, wn_handle** out) {
                 f->chains = cs;
                 f->chain_first = firsts;
                 f->rounds = true;
-                f->side_stream = f->ev_fork = f->ev_join = nullptr;
                 *out = f;
                 return WN_OK;
             }
@@ -453,69 +407,10 @@ extern "C" int wn_create(const wn_config* cfg, wn_handle** out) {
             g_err[0] = 0;
         }
     }
-    {   // chains sharing the CUs two by two (see wn_handle::chains): 2 chains up to WN_CHAIN_MAX_STREAMS streams each, more
-        // chains (run pairwise, one pair after the other on the two HIP streams) for larger jobs
-        const char* ce = wn_dev_env("WN_CHAINS");
-        const bool off = ce && ce[0] == '1';
-        const bool forced = ce && ce[0] == '2' && cfg->n_streams >= 4;
-        if (!g_chain_member && !off && !wn_v3_applicable(cfg, n_cu, nullptr, nullptr, nullptr) && (cfg->n_streams >= WN_CHAIN_MIN_STREAMS || forced)) {
-            const int ns = cfg->n_streams;
-            const int K = 2 * ((ns + 2 * WN_CHAIN_MAX_STREAMS - 1) / (2 * WN_CHAIN_MAX_STREAMS));
-            std::vector<wn_handle*> cs;
-            std::vector<int> firsts(1, 0);
-            int rc = WN_OK;
-            bool fits = true;
-            for (int i = 0; i < K && fits && rc == WN_OK; ++i) {
-                wn_config part = *cfg;
-                part.n_streams = ns / K + (i < ns % K ? 1 : 0);
-                wn_handle* c = nullptr;
-                g_chain_member = 1;
-                rc = wn_create(&part, &c);
-                g_chain_member = 0;
-                if (rc == WN_OK) {
-                    cs.push_back(c);
-                    firsts.push_back(firsts.back() + part.n_streams);
-                    fits = c->w0lds != 0;
-                }
-            }
-            if (rc == WN_OK && fits) {
-                wn_handle* c0 = cs[0];
-                wn_handle* f = new wn_handle();
-                f->cfg = *cfg;
-                f->plan = c0->plan;
-                f->plan.n_streams = cfg->n_streams;
-                f->have_weights = false; f->pending = false; f->last_stream = nullptr; f->t_base = 0;
-                f->n_cu = n_cu; f->wall_khz = wall_khz; f->variant = c0->variant; f->v2_index = c0->v2_index; f->lds_bytes = c0->lds_bytes; f->w0lds = 1;
-                f->d_blobs = f->d_start_t = f->d_start_b = f->d_rings = nullptr;
-                f->d_dil = f->d_wg_map = nullptr; f->d_ring_off = nullptr; f->d_gran = nullptr; f->d_status = nullptr;
-                f->d_prof = nullptr; f->prof_items = 0; f->prof_recorded = 0;
-                f->d_fw = nullptr; f->fw_floats = 0; f->fw_ok = false; f->d_ws = nullptr; f->ws_floats = 0;
-                f->d_fwb = nullptr; f->fwb_elems = 0; f->fwb_ok = false; f->fw_bf16 = 0;
-                f->d_tws = nullptr; f->tws_floats = 0; f->train_valid = false;
-                f->blob_floats = f->ring_floats = f->gran_count = 0;
-                f->dil = c0->dil;
-                f->chains = cs;
-                f->chain_first = firsts;
-                f->rounds = false;
-                f->side_stream = f->ev_fork = f->ev_join = nullptr;
-                hipStream_t ss; hipEvent_t e0, e1;
-                rc = rt_hip(hipStreamCreateWithFlags(&ss, hipStreamNonBlocking), "hipStreamCreate");
-                if (!rc) { f->side_stream = ss; rc = rt_hip(hipEventCreateWithFlags(&e0, hipEventDisableTiming), "hipEventCreate"); }
-                if (!rc) { f->ev_fork = e0; rc = rt_hip(hipEventCreateWithFlags(&e1, hipEventDisableTiming), "hipEventCreate"); }
-                if (!rc) f->ev_join = e1;
-                if (rc) { wn_destroy(f); return rc; }
-                *out = f;
-                return WN_OK;
-            }
-            for (wn_handle* c : cs) wn_destroy(c);  // this shape does not fit two workgroups per CU: one chain
-            if (rc != WN_OK && rc != WN_E_UNSUPPORTED) return rc;
-            g_err[0] = 0;
-        }
-    }
     wn_handle* h = new wn_handle();
     memset(&h->plan, 0, sizeof(h->plan));
     h->cfg = *cfg;
-    h->side_stream = h->ev_fork = h->ev_join = nullptr; h->w0lds = 0; h->v3_mode = 0; h->rounds = false;
+    h->v3_mode = 0; h->rounds = false;
     h->have_weights = false; h->pending = false; h->last_stream = nullptr; h->t_base = 0;
     h->n_cu = n_cu; h->wall_khz = wall_khz;
     h->d_blobs = h->d_start_t = h->d_start_b = h->d_rings = nullptr;
@@ -531,17 +426,14 @@ extern "C" int wn_create(const wn_config* cfg, wn_handle** out) {
     pl.HR = 1;
     h->variant = 1; h->v2_index = -1;
     {
-        const char* force = wn_dev_env("WN_KERNEL");  // "generic" pins the LDS-resident kernel, "v2" the 256-thread register kernels (A/B runs, tests)
         int P2 = 0, PA2 = 0;
-        const int n_smp = cfg->n_streams > 1 ? wn_sampler_count(cfg->n_streams) : 0;
         int vi3 = -1;
-        if (!g_chain_member && wn_v3_applicable(cfg, n_cu, &vi3, &P2, &PA2)) {
+        if (wn_v3_applicable(cfg, n_cu, &vi3, &P2, &PA2)) {
             h->variant = 3; h->v2_index = vi3;
             wn_plan_geometry(pl, P2, PA2);
-            pl.n_smp = wn_sampler_count(cfg->n_streams);  // variant 3 always samples on dedicated workgroups (they also feed layer 0)
+            pl.n_smp = wn_sampler_count(cfg->n_streams);  // sampling runs on dedicated workgroups (they also feed layer 0)
             pl.n_wg += pl.n_smp;
             pl.start_in_lds = (wn_v2_table()[vi3].lds_pre_v3 + 256 * pl.R) * 4 <= WN_LDS_MAX_BYTES ? 1 : 0;  // the samplers' copy of start_conv^T
-            h->w0lds = 0;
             h->v3_mode = wn_v3_mode(pl.n_streams, pl.NL);
             if (!wn_v2_table()[vi3].fn_v3[1]) h->v3_mode &= ~1;  // (shapes whose filter/gate slices cannot be halved: one stream per item only)
             if ((h->v3_mode & 2) && pl.NL * P2 + 2 * PA2 + pl.n_smp <= n_cu) {  // a second set of head workgroups
@@ -551,26 +443,6 @@ extern "C" int wn_create(const wn_config* cfg, wn_handle** out) {
                 h->v3_mode &= 1;
             }
             h->lds_bytes = wn_v2_table()[vi3].lds_floats_v3(pl.n_streams, h->v3_mode & 1) * 4;
-        }
-        const int vi = (h->variant == 3 || (force && !strcmp(force, "generic"))) ? -1 : wn_v2_choose(pl, n_cu, n_smp, cfg->layer_split, cfg->head_split, &P2, &PA2);
-        if (vi >= 0) {
-            h->variant = 2; h->v2_index = vi;
-            wn_plan_geometry(pl, P2, PA2);  // fills P, PA, Dc, Ec, n_wg (the LDS-image fields are unused by v2)
-            pl.n_smp = n_smp;
-            pl.n_wg += n_smp;               // sampler workgroups follow the head in the chain
-            h->lds_bytes = wn_v2_table()[vi].lds_floats(pl.n_streams) * 4;
-            h->w0lds = 0;
-            if (n_smp > 0) {
-                if (g_chain_member && wn_v2_table()[vi].fn_multi_w0 &&
-                    wn_v2_table()[vi].lds_floats_multi(pl.n_streams, 1) * 4 <= WN_LDS_SHARED_MAX_BYTES) h->w0lds = 1;
-                h->lds_bytes = wn_v2_table()[vi].lds_floats_multi(pl.n_streams, h->w0lds) * 4;
-            }
-            pl.start_in_lds = 0;
-            if (n_smp == 0 && wn_v2_table()[vi].lds_floats_with_start(pl.n_streams) * 4 <= WN_LDS_MAX_BYTES) {
-                pl.start_in_lds = 1;
-                h->lds_bytes = wn_v2_table()[vi].lds_floats_with_start(pl.n_streams) * 4;
-            }
-            if (h->lds_bytes > WN_LDS_MAX_BYTES) { h->variant = 1; h->v2_index = -1; pl.n_smp = 0; }
         }
     }
     if (h->variant == 1) {
@@ -595,7 +467,7 @@ extern "C" int wn_create(const wn_config* cfg, wn_handle** out) {
     std::vector<int32_t> wg_map;
     pl.n_blocks = pl.n_wg;
     pl.allow_plain = 0;
-    if (h->variant >= 2 && n_cu % 8 == 0 && wn_make_wg_map_layers(pl.NL, pl.P, pl.PA * pl.HR, pl.n_smp, 8, n_cu / 8, wg_map, &pl.n_blocks)) {
+    if (h->variant == 3 && n_cu % 8 == 0 && wn_make_wg_map_layers(pl.NL, pl.P, pl.PA * pl.HR, pl.n_smp, 8, n_cu / 8, wg_map, &pl.n_blocks)) {
         const char* np = wn_dev_env("WN_NO_LOCAL_STORES");
         pl.allow_plain = (np && np[0] == '1') ? 0 : 1;
     } else {
@@ -606,7 +478,7 @@ extern "C" int wn_create(const wn_config* cfg, wn_handle** out) {
     const size_t g0_n = h->variant == 3 ? (size_t)pl.n_streams * pl.R : 0;
     h->gran_count = gx_n + gs_n + gl_n + (size_t)pl.n_streams + g0_n;
     h->blob_floats = n_lw * pl.blob_layer_floats + (size_t)pl.PA * pl.blob_head_floats;
-    if (h->variant >= 2) {
+    if (h->variant == 3) {
         const WnV2Entry& ve = wn_v2_table()[h->v2_index];
         h->blob_floats = n_lw * (size_t)ve.nwl * 256 + (size_t)pl.PA * ve.nwh * 256;
     }
@@ -639,8 +511,7 @@ extern "C" int wn_create(const wn_config* cfg, wn_handle** out) {
     pl.g0 = pl.gi + pl.n_streams;
     pl.status = h->d_status;
     pl.xcc_tab = h->d_status + 8;
-    rc = rt_hip(hipFuncSetAttribute(h->variant == 3 ? wn_v2_table()[h->v2_index].fn_v3[h->v3_mode & 1] : h->variant == 2 ? (pl.n_smp > 0 ? (h->w0lds ? wn_v2_table()[h->v2_index].fn_multi_w0 : wn_v2_table()[h->v2_index].fn_multi) : wn_v2_table()[h->v2_index].fn)
-                                                    : (const void*)wn_generate_kernel,
+    rc = rt_hip(hipFuncSetAttribute(h->variant == 3 ? wn_v2_table()[h->v2_index].fn_v3[h->v3_mode & 1] : (const void*)wn_generate_kernel,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes),
                 "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
     if (rc) { wn_destroy(h); return rc; }
@@ -667,7 +538,7 @@ extern "C" int wn_load_weights(wn_handle* h, const wn_weight_ptrs* w) {
     WnHostWeights hw = {w->start_w, w->start_b, w->filter_w, w->filter_b, w->gate_w, w->gate_b, w->res_w,
                         w->res_b, w->skip_w, w->skip_b, w->end1_w, w->end1_b, w->end2_w, w->end2_b};
     std::vector<float> blobs;
-    if (h->variant >= 2) wn_v2_table()[h->v2_index].pack(pl, hw, blobs);
+    if (h->variant == 3) wn_v2_table()[h->v2_index].pack(pl, hw, blobs);
     else
         wn_pack_blobs(pl, hw, blobs);
     if (blobs.size() != h->blob_floats) return wn_fail(WN_E_STATE, "wn_load_weights: internal blob size mismatch");
@@ -801,20 +672,14 @@ extern "C" int wn_generate(wn_handle* h, const wn_generate_args* a) {
     g_err[0] = 0;
     if (!h || !a) return wn_fail(WN_E_BADARG, "wn_generate: NULL argument");
     if (!h->have_weights) return wn_fail(WN_E_STATE, "wn_generate: wn_load_weights has not been called");
-    if (!h->chains.empty()) {   // chain i owns streams [chain_first[i], chain_first[i + 1]): fork onto the side stream, join back
+    if (!h->chains.empty()) {   // rounds: member i owns streams [chain_first[i], chain_first[i + 1]); one after the other on the caller's stream
         if (a->n_given < 1 || a->num_samples < 0) return wn_fail(WN_E_BADARG, "wn_generate: n_given must be >= 1 and num_samples >= 0");
         if (!a->first_samples) return wn_fail(WN_E_BADARG, "wn_generate: first_samples is NULL");
         { int rc = rt_hip(hipSetDevice(h->cfg.device_id), "hipSetDevice"); if (rc) return rc; }
         if (h->pending) { int rc = wn_wait(h); if (rc) return rc; }
-        if (h->broken) return wn_fail(WN_E_STATE, "wn_generate: an earlier job failed half way through its chains; call wn_reset");
-        hipStream_t user = (hipStream_t)a->hip_stream, side = h->rounds ? user : (hipStream_t)h->side_stream;
+        if (h->broken) return wn_fail(WN_E_STATE, "wn_generate: an earlier job failed half way through its rounds; call wn_reset");
         int rc = WN_OK;
-        if (!h->rounds) {
-            rc = rt_hip(hipEventRecord((hipEvent_t)h->ev_fork, user), "hipEventRecord");
-            rc = rc ? rc : rt_hip(hipStreamWaitEvent(side, (hipEvent_t)h->ev_fork, 0), "hipStreamWaitEvent");
-        }
-        if (rc) return rc;
-        for (size_t i = 0; i < h->chains.size(); ++i) {  // even chains on the caller's stream, odd ones on the side stream
+        for (size_t i = 0; i < h->chains.size(); ++i) {
             wn_generate_args b = *a;
             const size_t s0 = (size_t)h->chain_first[i];
             b.first_samples = a->first_samples + s0 * (size_t)a->n_given;
@@ -822,17 +687,12 @@ extern "C" int wn_generate(wn_handle* h, const wn_generate_args* a) {
             if (a->out_idx) b.out_idx = a->out_idx + s0 * (size_t)a->num_samples;
             if (a->dbg_logits) b.dbg_logits = a->dbg_logits + s0 * (size_t)a->num_samples * h->plan.C;
             if (a->stream_temperatures) b.stream_temperatures = a->stream_temperatures + s0;
-            b.hip_stream = i % 2 == 0 ? (void*)user : (void*)side;
             if (i == 0 && h->prof_items > 0) { h->chains[0]->prof_items = h->prof_items; h->prof_items = 0; }
             rc = wn_generate(h->chains[i], &b);
             if (rc) {
-                if (i > 0) {  // chains 0..i-1 are running: drain them, then refuse further jobs until the queues are reset
+                if (i > 0) {  // rounds 0..i-1 are enqueued: drain them, then refuse further jobs until the queues are reset
                     char msg[sizeof(g_err)];
                     memcpy(msg, g_err, sizeof(msg));
-                    if (!h->rounds) {
-                        (void)hipEventRecord((hipEvent_t)h->ev_join, side);
-                        (void)hipStreamWaitEvent(user, (hipEvent_t)h->ev_join, 0);
-                    }
                     h->pending = true; h->last_stream = a->hip_stream;
                     (void)wn_wait(h);
                     h->broken = true;
@@ -841,11 +701,6 @@ extern "C" int wn_generate(wn_handle* h, const wn_generate_args* a) {
                 return rc;
             }
         }
-        if (!h->rounds) {
-            rc = rt_hip(hipEventRecord((hipEvent_t)h->ev_join, side), "hipEventRecord");
-            rc = rc ? rc : rt_hip(hipStreamWaitEvent(user, (hipEvent_t)h->ev_join, 0), "hipStreamWaitEvent");
-        }
-        if (rc) return rc;
         h->pending = true;
         h->last_stream = a->hip_stream;
         h->t_base = h->chains[0]->t_base;
@@ -885,10 +740,6 @@ extern "C" int wn_generate(wn_handle* h, const wn_generate_args* a) {
     if (rc) return rc;
     if (h->variant == 3)
         wn_v2_table()[h->v2_index].launch_v3(h->v3_mode & 1, h->plan.n_blocks, (size_t)h->lds_bytes, (hipStream_t)a->hip_stream, h->plan, r);
-    else if (h->variant == 2 && h->plan.n_smp > 0)
-        wn_v2_table()[h->v2_index].launch_multi(h->w0lds, h->plan.n_blocks, (size_t)h->lds_bytes, (hipStream_t)a->hip_stream, h->plan, r);
-    else if (h->variant == 2)
-        wn_v2_table()[h->v2_index].launch(h->plan.n_blocks, (size_t)h->lds_bytes, (hipStream_t)a->hip_stream, h->plan, r);
     else
         hipLaunchKernelGGL(wn_generate_kernel, dim3(h->plan.n_blocks), dim3(WN_THREADS), (size_t)h->lds_bytes,
                            (hipStream_t)a->hip_stream, h->plan, r);

@@ -5,7 +5,7 @@
 
 What is different underneath:
   * ``generate_fast()`` does not run the Python per-sample loop.  It hands the whole job to the MI355X
-    engine (mi355_wavenet.engine -> C ABI include/wn_abi.h -> HIP kernels csrc/wn_kernel_v3.h / wn_kernel_v2.h / wn_kernel.h): one persistent
+    engine (mi355_wavenet.engine -> C ABI include/wn_abi.h -> HIP kernels csrc/wn_kernel_v3.h / wn_kernel.h): one persistent
     kernel launch per call (per progress interval when a callback is given).  There is NO CPU fallback: without
     a gfx950 GPU and the built library it raises.
   * the global numpy RNG is consumed exactly as the reference does (one ``random_sample`` per generated

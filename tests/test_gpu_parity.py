@@ -30,14 +30,14 @@ SMALL = [
 
 
 def _expected_variant(cfg, ns, layer_split=0):
-    """3 = wave-specialised kernel (csrc/wn_kernel_v3.h): every instantiated channel shape whose roles fit its register budget (round 3:
-    also unsplit / two-way split stacks, one skip row per lane, fewer than 64 residual channels, an end_conv_1 slice in LDS) -- all
-    BASELINE configs and the train_script.py shape (32 / 32 / 1024 / 512, split two ways); 2 = the 256-thread register kernels."""
+    """3 = wave-specialised kernel (csrc/wn_kernel_v3.h): every instantiated channel shape -- all BASELINE configs and the
+    train_script.py shape (32 / 32 / 1024 / 512, split two ways); 1 = the generic LDS-resident kernel (any other shape, or pinned).
+    (2 was the 256-thread register kernels of rounds 1-2: removed in round 3.)"""
     cfg = synth.CONFIGS[cfg] if isinstance(cfg, str) else cfg
     shape = (cfg["residual_channels"], cfg["dilation_channels"], cfg["skip_channels"], cfg["end_channels"])
     on3 = shape in ((128, 128, 512, 256), (64, 64, 256, 256), (32, 32, 256, 256), (32, 32, 1024, 512), (16, 16, 256, 32), (16, 32, 256, 64))
     import os
-    return 3 if on3 and os.environ.get("WN_KERNEL") not in ("v2", "generic") else 2
+    return 3 if on3 and os.environ.get("WN_KERNEL") != "generic" else 1
 
 
 MINI3 = dict(synth.CONFIGS["cfg3"], layers=3, blocks=2)   # cfg3's channel shape, 6 layers: the wave-specialised kernel on 36 workgroups
@@ -286,49 +286,7 @@ def test_batched_priming_equals_chain_priming(cfgname, ns, n_given):
     eng.close()
 
 
-def test_two_chains_sharing_the_cus(monkeypatch):
-    """With >= 16 streams (or WN_CHAINS=2) the job runs as two independent chains of n_streams/2 streams whose workgroups
-    share the CUs two by two (wn_info.n_chains == 2): same samples as one chain and as the oracle, queues exported per
-    stream, batched priming split per chain, per-stream temperatures routed to the owning chain."""
-    monkeypatch.setenv("WN_KERNEL", "v2")   # the 256-thread kernels; by default these jobs run on the wave-specialised kernel
-    cfg, W, first, uniforms = make_case("cfg3", 61, 16, 70, 90)   # 70 given samples: batched priming + generation
-    eng = engine.Engine(cfg, W, n_streams=16)
-    info = eng.info()
-    assert info["n_chains"] == 2 and info["kernel_variant"] == 2 and info["n_workgroups"] == 2 * (50 * 4 + 8 + 4)
-    assert info["lds_bytes"] <= 80 * 1024
-    check_engine(eng, cfg, W, 90, first, 1.0, 0.0, uniforms, "cfg3 two chains sampled")
-    check_engine(eng, cfg, W, 90, first, 0.0, 0.3, None, "cfg3 two chains greedy + regulariser")
-    temps = np.where(np.arange(16) % 3 == 0, 0.0, 0.5 + 0.1 * np.arange(16)).astype(np.float32)
-    out = eng.generate(40, first[:, :3], temperature=temps, uniforms=uniforms[:, :40])
-    for s in (0, 7, 8, 15):
-        idx, _ = c_oracle.generate(cfg, W, 40, first[s, :3], float(temps[s]), 0.0, uniforms[s, :40] if temps[s] > 0 else None)
-        assert np.array_equal(out[s], idx), s
-    q8, ip, op = eng.export_queue(3, 8)
-    eng.close()
-    monkeypatch.setenv("WN_CHAINS", "1")
-    one = engine.Engine(cfg, W, n_streams=16)
-    assert one.info()["n_chains"] == 1
-    out1 = one.generate(40, first[:, :3], temperature=temps, uniforms=uniforms[:, :40])
-    q8_1, ip1, op1 = one.export_queue(3, 8)
-    one.close()
-    assert np.array_equal(out, out1)
-    # the two kernel variants keep tap-0 weights in LDS / in registers: same sums, scheduled differently -> equal to rounding
-    assert np.allclose(q8, q8_1, rtol=1e-5, atol=1e-6) and (ip, op) == (ip1, op1)
-    monkeypatch.delenv("WN_CHAINS")
-    cfg4, W4, first4, uni4 = make_case("cfg3", 63, 90, 2, 24)   # > 80 streams: four chains (23 + 23 + 22 + 22), run pairwise
-    e4 = engine.Engine(cfg4, W4, n_streams=90)
-    assert e4.info()["n_chains"] == 4
-    check_engine(e4, cfg4, W4, 24, first4, 1.0, 0.0, uni4, "cfg3 four chains")
-    e4.close()
-    monkeypatch.setenv("WN_CHAINS", "2")   # forced for a small stream count, small model (P = 1)
-    cfg2, W2, first2, uni2 = make_case("cfg2", 62, 6, 5, 60)
-    e2 = engine.Engine(cfg2, W2, n_streams=6)
-    assert e2.info()["n_chains"] == 2
-    check_engine(e2, cfg2, W2, 60, first2, 0.9, 0.0, uni2, "cfg2 two chains")
-    e2.close()
-
-
-@pytest.mark.parametrize("kernel", ["default", "v2"])
+@pytest.mark.parametrize("kernel", ["default", "generic"])
 def test_per_stream_temperatures(kernel, monkeypatch):
     """wn_generate_args.stream_temperatures: every stream samples at its own temperature (<= 0: argmax), all kernels."""
     from mi355_wavenet import engine, synth
@@ -348,28 +306,6 @@ def test_per_stream_temperatures(kernel, monkeypatch):
             idx, _ = c_oracle.generate(cfg, W, 50, first[s], t if t > 0 else 0.0, 0.0, u[s] if t > 0 else None)
             agree = int((out[s] == idx).sum())
             assert agree == 50, (cfgname, ns, s, t, agree)
-
-
-def test_two_chain_front_edge_cases(monkeypatch):
-    """The multi-chain front handle on the calls the facade makes around a job: prime-only (zero samples), continuation
-    without reset (progress callbacks), an odd stream count (chains of 9 + 8), a single generated sample."""
-    monkeypatch.setenv("WN_KERNEL", "v2")
-    cfg, W, first, uniforms = make_case("cfg2", 71, 17, 6, 64)
-    eng = engine.Engine(cfg, W, n_streams=17)
-    assert eng.info()["n_chains"] == 2
-    idx = eng.generate(0, first, temperature=0.0)
-    assert idx.shape == (17, 0) and eng.info()["evals_done"] == 5
-    full = eng.generate(64, first, temperature=1.0, uniforms=uniforms)
-    a = eng.generate(23, first, temperature=1.0, uniforms=uniforms[:, :23])
-    b = eng.generate(41, a[:, -1:], temperature=1.0, uniforms=uniforms[:, 23:], reset=False)
-    assert np.array_equal(np.concatenate([a, b], axis=1), full)
-    assert eng.info()["evals_done"] == 6 - 1 + 64
-    one = eng.generate(1, first, temperature=1.0, uniforms=uniforms[:, :1])
-    assert np.array_equal(one, full[:, :1])
-    for s in (0, 8, 9, 16):  # both sides of the chain boundary
-        o_idx, _ = c_oracle.generate(cfg, W, 64, first[s], 1.0, 0.0, uniforms[s])
-        assert np.array_equal(full[s], o_idx), s
-    eng.close()
 
 
 def test_abi_error_codes_on_a_live_handle():
@@ -504,7 +440,7 @@ def test_wave_specialised_kernel_rounds(ns):
 
 def test_wave_specialised_kernel_host_calls():
     """The calls the facade makes around a job on variant 3: prime-only, continuation without reset, one generated sample,
-    per-stream temperatures, queue export, and equality with the 256-thread kernels on the same job."""
+    per-stream temperatures, queue export, and equality with the generic kernel on the same job."""
     cfg, W, first, uniforms = make_case(MINI3, 82, 9, 6, 64)
     eng = engine.Engine(cfg, W, n_streams=9)
     assert eng.info()["kernel_variant"] == 3
@@ -528,10 +464,10 @@ def test_wave_specialised_kernel_host_calls():
         assert np.array_equal(out[s], o_idx), s
     eng.close()
     import os
-    os.environ["WN_KERNEL"] = "v2"
+    os.environ["WN_KERNEL"] = "generic"   # the same job on the generic LDS-resident kernel: same samples, same queues (to rounding)
     try:
         old = engine.Engine(cfg, W, n_streams=9)
-        assert old.info()["kernel_variant"] == 2
+        assert old.info()["kernel_variant"] == 1
         a2 = old.generate(23, first, temperature=1.0, uniforms=uniforms[:, :23])
         old.generate(41, a2[:, -1:], temperature=1.0, uniforms=uniforms[:, 23:], reset=False)
         q2 = [old.export_queue(l, 4) for l in (0, 2, 5)]
