@@ -1,13 +1,11 @@
 #!/bin/bash
 mkdir -p gpurun_out
 cd /root/repo
-O=gpurun_out/r03_presleep.txt
+O=gpurun_out/r03_dedicated_fetcher.txt
 : > $O
-echo "# pre-poll sleep of the critical group's polling waves (WN_V3_PRESLEEP eighths of the predicted wait; all variants with the last layer's skip group at priority 3)" >> $O
-echo "## product build (no sleep)" >> $O; for n in 1 16 32 48 64 96 128; do timeout 120 python tools/rate.py cfg3 $n 3000 2 2>&1 | grep "samples/s" >> $O; done
-for v in 3 4 5 6; do
-  echo "## WN_V3_PRESLEEP=$v" >> $O
-  for n in 1 64; do WN_DEV_LIB=tools/variants/libwn_ps$v.so timeout 120 python tools/quick_check.py cfg3 $n 2>&1 | grep quick_check >> $O; done
-  for n in 1 16 32 48 64 96 128; do WN_DEV_LIB=tools/variants/libwn_ps$v.so timeout 120 python tools/rate.py cfg3 $n 3000 2 2>&1 | grep "samples/s" >> $O; done
+echo "# timing experiment (results wrong: no skip work at all, WN_V3_ABL=1): the critical group fetches its input (baseline) vs the idle skip group as a DEDICATED fetcher" >> $O
+for v in abl1 fetch; do
+  echo "## $v" >> $O
+  for m in 0 3; do for n in 16 32 48 64 96 128; do WN_V3_MODE=$m WN_DEV_LIB=tools/variants/libwn_$v.so timeout 50 python tools/rate.py cfg3 $n 3000 1 2>&1 | grep "samples/s" | sed "s/^/mode $m: /" >> $O; done; done
 done
 cat $O
