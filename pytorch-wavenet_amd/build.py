@@ -38,8 +38,8 @@ def check_hand_scheduled_registers(so, objdump=OBJDUMP):
     """The variant-3 kernels keep loads in flight into v152-v167 across their inline-assembly blocks (input poll sets, the queue
     group's tap FIFO).  The kernels carry amdgpu_num_vgpr so that the compiler's own allocation ends below them; this check
     DISASSEMBLES the built library and raises unless (1) every instruction of those kernels that names a reserved register is one
-    the blocks emit, in the operand position they emit it, (2) nothing touches a register above v167, (3) the kernels use no
-    scratch (a spill in a persistent hot loop is a performance bug, and spill code is where an allocator would reach for "free"
+    the blocks emit, in the operand position they emit it -- a tap-FIFO take directly behind one of the FIFO's hand-counted
+    `s_waitcnt vmcnt(n)` --, (2) nothing touches a register above v167, (3) the kernels use no scratch (a spill in a persistent hot loop is a performance bug, and spill code is where an allocator would reach for "free"
     registers).  Called by build_hip(): a library that breaks the invariant is never left in place."""
     import re
     import tempfile
@@ -54,7 +54,8 @@ def check_hand_scheduled_registers(so, objdump=OBJDUMP):
         dis = subprocess.check_output([objdump, "-d", os.path.join(tmp, co[0])]).decode()
     reserved = set(range(RESERVED_FIRST, RESERVED_LAST + 1))
     is_res = lambda tok: bool(_regs(tok) & reserved)  # noqa: E731
-    seen, current = 0, None
+    seen, current, prev = 0, None, ""
+    fifo_waits = {"s_waitcnt vmcnt(%d)" % n for n in (5, 6, 10, 11)}  # WN_V3_TAP_AHEAD = 6: D - 1, D, 2 D - 2, 2 D - 1 younger operations
     for line in dis.splitlines():
         m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
         if m:
@@ -66,6 +67,7 @@ def check_hand_scheduled_registers(so, objdump=OBJDUMP):
         text = line.split("//")[0].strip()
         if not text:
             continue
+        before, prev = prev, text
         op, _, rest = text.partition(" ")
         ops = [o.strip() for o in rest.split(",")]
         regs = _regs(text)
@@ -86,8 +88,8 @@ def check_hand_scheduled_registers(so, objdump=OBJDUMP):
             ok = is_res(ops[-1]) and not any(is_res(o) for o in ops[:-1])
         elif op == "v_add_f32_e32":          # t0 = t0 + v<reserved>: never the destination
             ok = not is_res(ops[0]) and is_res(ops[-1])
-        elif op == "v_mov_b32_e32":          # FIFO take: source only
-            ok = not is_res(ops[0]) and is_res(ops[1])
+        elif op == "v_mov_b32_e32":          # FIFO take: source only, and directly behind one of the FIFO's hand-counted waits
+            ok = not is_res(ops[0]) and is_res(ops[1]) and before in fifo_waits
         else:
             ok = False
         if not ok:

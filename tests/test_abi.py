@@ -164,11 +164,12 @@ def test_reserved_poll_registers_belong_to_the_hand_scheduled_blocks_only(tmp_pa
         return build.check_hand_scheduled_registers(str(lib), objdump=str(fake))
 
     good = ["global_load_dwordx2 v[152:153], v1, s[2:3] sc1", "v_cmp_eq_u32_e32 vcc, s5, v153", "v_add_f32_e32 v3, v3, v152",
-            "global_load_dword v154, v[4:5], off", "v_mov_b32_e32 v7, v154", "v_cmp_eq_u32_e64 s[8:9], s5, v155"]
+            "global_load_dword v154, v[4:5], off sc1", "s_waitcnt vmcnt(11)", "v_mov_b32_e32 v7, v154", "v_cmp_eq_u32_e64 s[8:9], s5, v155"]
     assert run(good) == 1
     for bad in ("v_mov_b64_e32 v[156:157], s[18:19]",            # the compiler parking a value there
                 "v_add_f32_e32 v152, v3, v4",                     # a reserved register as a destination
                 "v_mov_b32_e32 v160, v3",
+                "v_mov_b32_e32 v9, v153",                         # a FIFO take that is not directly behind one of the FIFO's waits
                 "v_cmp_eq_u32_e32 vcc, v153, v9",                 # ... in the wrong operand position
                 "global_load_dwordx2 v[10:11], v[152:153], off",  # ... as an address
                 "global_load_dword v158, v[4:5], off",            # FIFO entries are v152-v157
@@ -176,3 +177,14 @@ def test_reserved_poll_registers_belong_to_the_hand_scheduled_blocks_only(tmp_pa
                 "scratch_load_dword v3, off, off"):               # a spill
         with pytest.raises(RuntimeError):
             run(good + [bad])
+
+
+def test_graft_entry_build_runs():
+    """The driver's "does it build" check (__graft_entry__.build()): builds the HIP library (checked: build.check_hand_scheduled_registers),
+    the C oracle, loads the library through the binding and imports the facade -- on the CPU."""
+    import importlib
+    import sys
+    sys.path.insert(0, ROOT)
+    ge = importlib.import_module("__graft_entry__")
+    so = ge.build()
+    assert os.path.basename(so) == "libwn_mi355.so"
