@@ -57,12 +57,8 @@
 #define WN_V3_COMPILER_VGPRS 152  // v152-v167: request sets of the input poll / the queue group's tap FIFO (see wn_ap_*, wn_q_*)
 // ---- experiment switches.  A product build (build.py) leaves every one of them at its default; setting one requires -DWN_EXPERIMENT,
 // which build.py never passes (tools/ builds the A/B variants): a library with wrong-on-purpose timing ablations cannot ship by accident.
-#if !defined(WN_EXPERIMENT) && (defined(WN_V3_QDOT_EARLY) || defined(WN_V3_SKIP_SLEEP) || defined(WN_V3_ABL) || defined(WN_V3_PAIR_ROWS) || defined(WN_V3_PRIO) || defined(WN_V3_LAST_SKIP_PRIO))
+#if !defined(WN_EXPERIMENT) && (defined(WN_V3_SKIP_SLEEP) || defined(WN_V3_ABL) || defined(WN_V3_PAIR_ROWS) || defined(WN_V3_PRIO) || defined(WN_V3_LAST_SKIP_PRIO))
 #error "WN_V3_* experiment switches need -DWN_EXPERIMENT"
-#endif
-#ifndef WN_V3_QDOT_EARLY
-#define WN_V3_QDOT_EARLY 0  // 1: a late layer's tap-0 dot runs between barriers A and B (next to the critical group's dot) instead of after B;
-                            // 2: only in the two-streams-per-item form
 #endif
 #ifndef WN_V3_SKIP_SLEEP
 #define WN_V3_SKIP_SLEEP 0  // s_sleep between the skip group's poll retries (the skip lane is not latency critical; fewer polls on the fabric)
@@ -836,11 +832,71 @@ static __device__ void wn_v3_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
     }
 
     // ====================================================================== queue group
-    float w0[K1];
+    // In the two-streams-per-item form a lane takes the filter AND the gate row of a channel on HALF a tap slice, like the critical
+    // group's lanes (QPAIR): half the LDS reads per row pair -- the LDS pipe is what the groups of a workgroup share, and this group's
+    // dot is its longest piece (128 streams: its 0.76 us after barrier B set the pace).  The lane pair of a slice adds its halves (one
+    // DPP move) and the even lane parks both rows' sums where the image lanes' sums go: pre[] keeps its layout.
+    constexpr int QT8 = 2 * T1, QK8 = K1 / 2;
+    constexpr bool QPAIR = (WN_V3_PAIR_ROWS == 1 || (WN_V3_PAIR_ROWS == 2 && G >= 2)) && K1 % 8 == 0 && QT8 <= 16;
+    const int qch8 = t / QT8, qkq8 = t % QT8, qhalf8 = qkq8 & 1;
+    const int qt_f = (2 * qch8) * T1 + qkq8 / 2;  // the image lane of the channel's filter row (gate row: + T1)
+    float w0[QPAIR ? 1 : K1];
+    wn_f2 wq0[QPAIR ? QK8 : 1];
+    const float* imwq = p.blobs + (size_t)cx.w * (SH::NWL * 256);
+    if constexpr (QPAIR) {
 #pragma unroll
-    for (int k = 0; k < K1; ++k) w0[k] = img[(size_t)(K1 + k) * 256];
+        for (int k = 0; k < QK8; ++k)
+            wq0[k] = wn_f2{imwq[(size_t)(K1 + qhalf8 * QK8 + k) * 256 + qt_f], imwq[(size_t)(K1 + qhalf8 * QK8 + k) * 256 + qt_f + T1]};
+    } else {
+#pragma unroll
+        for (int k = 0; k < K1; ++k) w0[k] = img[(size_t)(K1 + k) * 256];
+    }
     const float bfg = img[(size_t)(2 * K1 + K2 + RS * DC) * 256];
     const float bfg0 = kq1 == 0 ? bfg : 0.f;
+    // (QPAIR: the biases of the two rows this lane parks, on the lanes of slice 0)
+    const float qbf = (QPAIR && qkq8 == 0) ? imwq[(size_t)(2 * K1 + K2 + RS * DC) * 256 + qt_f] : 0.f;
+    const float qbg = (QPAIR && qkq8 == 0) ? imwq[(size_t)(2 * K1 + K2 + RS * DC) * 256 + qt_f + T1] : 0.f;
+    // tap-0 sums of the G streams of an item from the staged taps xo, parked in pre[] (image-lane layout)
+    auto tap0_dot = [&](const float* xo_c, int s) {
+        if constexpr (QPAIR) {
+            wn_f2 a0[G], a1[G];
+            float4 v[G][QK8 / 4];
+            const float* xsl = xo_c + (qkq8 / 2) * (K1 + 4) + qhalf8 * QK8;
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                a0[g] = wn_f2{qbf, qbg};
+                a1[g] = wn_f2{0.f, 0.f};
+#pragma unroll
+                for (int k = 0; k < QK8 / 4; ++k) v[g][k] = reinterpret_cast<const float4*>(xsl + g * L::XR)[k];
+            }
+#pragma unroll
+            for (int k = 0; k < QK8 / 4; ++k)
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    a0[g] = __builtin_elementwise_fma(wq0[4 * k], wn_f2{v[g][k].x, v[g][k].x}, a0[g]);
+                    a1[g] = __builtin_elementwise_fma(wq0[4 * k + 1], wn_f2{v[g][k].y, v[g][k].y}, a1[g]);
+                    a0[g] = __builtin_elementwise_fma(wq0[4 * k + 2], wn_f2{v[g][k].z, v[g][k].z}, a0[g]);
+                    a1[g] = __builtin_elementwise_fma(wq0[4 * k + 3], wn_f2{v[g][k].w, v[g][k].w}, a1[g]);
+                }
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                float f = a0[g].x + a1[g].x, gt = a0[g].y + a1[g].y;
+                f += wn_partner<1>(f);    // the other half of the slice (the DPP moves outside any lane-dependent branch)
+                gt += wn_partner<1>(gt);
+                if (qhalf8 == 0) {
+                    pre[(s + g) * 256 + qt_f] = f;
+                    pre[(s + g) * 256 + qt_f + T1] = gt;
+                }
+            }
+        } else {
+            float acc[G], bin[G];
+#pragma unroll
+            for (int g = 0; g < G; ++g) bin[g] = bfg0;
+            wn_dot_lds_gp<K1, G>(w0, xo_c + kq1 * (K1 + 4), L::XR, bin, acc);
+#pragma unroll
+            for (int g = 0; g < G; ++g) pre[(s + g) * 256 + t] = acc[g];
+        }
+    };
 #pragma clang loop vectorize(disable) interleave(disable)
     for (int s = 0; s < ns; ++s) {  // tap 0 of the first evaluation of every stream: x[t_base - d] from the queue (zeros after reset)
         const float* ring = p.rings + p.ring_off[l] + ((size_t)c * ns + s) * (size_t)ML * R;
@@ -848,7 +904,7 @@ static __device__ void wn_v3_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
         if (pos < 0) pos += ML;
         float acc = bfg0;
 #pragma unroll
-        for (int k = 0; k < K1; ++k) acc += w0[k] * ring[(size_t)pos * R + kq1 * K1 + k];
+        for (int k = 0; k < K1; ++k) acc += img[(size_t)(K1 + k) * 256] * ring[(size_t)pos * R + kq1 * K1 + k];  // (once per job: the weights straight from the image)
         pre[s * 256 + t] = acc;
     }
     float* rings_l = p.rings + p.ring_off[l] + (size_t)c * ns * (size_t)ML * R;  // stream s: + s * ML * R
@@ -872,9 +928,7 @@ static __device__ void wn_v3_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
             const long long t1 = stamp ? (long long)wall_clock64() : 0;
             // tap-0 half of the dilated conv for the NEXT timestep: x[t+1-d] sits in slot (t + 2) mod (d + 1) (d = 1: the row just pushed)
             const int tap = tmod + 2 >= ML ? tmod + 2 - ML : tmod + 2;
-            float bin[1] = {bfg0}, acc[1];
-            wn_dot_lds_gp<K1, 1>(w0, lring + (tap >= ML ? tap - ML : tap) * L::XR + kq1 * (K1 + 4), L::XR, bin, acc);
-            pre[t] = acc[0];
+            tap0_dot(lring + tap * L::XR, 0);
             if (stamp)
                 r.prof[((size_t)cx.w * r.prof_items + e) * WN_STAMPS + 7] =
                     (t0 & 0xffffffffffll) | (((t1 - t0) & 0xfff) << 40) | ((((long long)wall_clock64() - t1) & 0xfff) << 52);
@@ -954,21 +1008,12 @@ static __device__ void wn_v3_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
                 for (int j = D - 1; j > 0; --j) hx[j] = hx[j - 1];
                 hx[0] = xv;
             }
-            // a late layer's tap was staged an item ago: its tap-0 dot runs HERE, next to the critical group's dot (this group has
-            // nothing else to do between A and B), and is parked in a register until the critical group has read pre[s] (barrier B)
-            float acc_late[G], bin[G];
-#pragma unroll
-            for (int g = 0; g < G; ++g) { acc_late[g] = 0.f; bin[g] = bfg0; }
-            constexpr bool QDE = WN_V3_QDOT_EARLY == 1 || (WN_V3_QDOT_EARLY == 2 && G >= 2);
-            if (QDE && late_wg) wn_dot_lds_gp<K1, G>(w0, xo_cur + kq1 * (K1 + 4), L::XR, bin, acc_late);
             if (wn_barrier_failed(cx, failflag)) return;  // ---- B(i): the tap is staged
             const long long t1 = stamp ? (long long)wall_clock64() : 0;
             // ---- tap-0 half of the dilated conv for the NEXT timestep of this stream, parked for the critical group
             if (!(WN_V3_ABL & 2)) {
                 if (pusher) rings_l[((size_t)(s + pg) * ML + tmod) * R + prow] = xs[buf * (G * L::XR) + pg * L::XR + SH::xpad(prow)];  // the push, off the A -> B window
-                if (!(QDE && late_wg)) wn_dot_lds_gp<K1, G>(w0, xo_cur + kq1 * (K1 + 4), L::XR, bin, acc_late);
-#pragma unroll
-                for (int g = 0; g < G; ++g) pre[(s + g) * 256 + t] = acc_late[g];
+                tap0_dot(xo_cur, s);
                 if (fifo) wn_q_issue_slot(slot, next_tap_ptr());  // the tap of item i + D goes into the entry item i has just given up
                 if (late && item + 1 < n_items) {
                     // the NEXT item's tap into the other buffer: D - 1 younger loads; the stores of a wave that also pushes (R > 128:

@@ -1,9 +1,9 @@
 #!/bin/bash
 mkdir -p gpurun_out
 cd /root/repo
-O=gpurun_out/r03_lds_queues.txt
+O=gpurun_out/r03_queue_pair_rows.txt
 : > $O
-for c in cfg3 cfg2 cfg1 chaconne; do timeout 50 python tools/quick_check.py $c 1 2>&1 | grep quick_check >> $O; done
-for c in cfg3 cfg3 cfg2 cfg1 chaconne; do timeout 50 python tools/rate.py $c 1 6000 2 2>&1 | grep "samples/s" >> $O; done
-( timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_facade.py -m gpu -q -x -k "ns1 or full_size or export_queue or queue_state or golden or host_calls or baseline_configs or batched_priming" 2>&1 | tail -3 ) >> $O 2>&1
+for c in "cfg3 64" "cfg3 6" "cfg2 64" "cfg1 40" "cfg3 1"; do set -- $c; WN_V3_MODE=3 timeout 50 python tools/quick_check.py $1 $2 2>&1 | grep quick_check >> $O; done
+for n in 64 64 96 128; do timeout 50 python tools/rate.py cfg3 $n 3000 2 2>&1 | grep "samples/s" >> $O; done
+timeout 50 python tools/rate.py cfg2 64 3000 2 2>&1 | grep "samples/s" >> $O
 cat $O
