@@ -68,6 +68,12 @@ class _TorchMem:
         return self.torch.cuda.current_stream(self.device).cuda_stream
 
 
+class _Resident:
+    """uniforms already uploaded (Engine.upload_uniforms)"""
+    def __init__(self, dev, shape):
+        self.dev, self.shape = dev, tuple(shape)
+
+
 class Engine:
     def __init__(self, cfg, weights, n_streams=1, device_index=0, layer_split=0, head_split=0, lib=None, mem=None):
         """lib / mem: the loaded C-ABI library and the memory provider (upload / empty / ptr / download / stream); the defaults are
@@ -185,14 +191,22 @@ class Engine:
             return True
         return self.prime(self.mem.upload(fs), fs.shape[1], fs.shape[1])
 
+    def upload_uniforms(self, u):
+        """float64 (n_streams, n) uniforms -> a resident handle ``generate(uniforms=...)`` accepts"""
+        u = np.ascontiguousarray(np.asarray(u, dtype=np.float64))
+        return _Resident(self.mem.upload(u), u.shape)
+
     # -- convenience: one synchronous generate_fast-shaped job
     PRIME_BATCH_MIN = 64  # given samples from which the GEMM priming path beats the per-sample chain passes
 
     def generate(self, num_samples, first_samples=None, temperature=1.0, regularize=0.0, uniforms=None,
-                 want_logits=False, reset=True, timeout_ms=0, batched_prime=True):
+                 want_logits=False, reset=True, timeout_ms=0, batched_prime=True, while_running=None):
         """first_samples: (n_streams, n_given) or (n_given,) ints (broadcast to every stream) or None -> classes//2.
         uniforms: float64 (n_streams, num_samples) (np.random.random_sample draws) or None -> greedy.
         temperature: a number, or one per stream (a stream with temperature <= 0 is greedy and ignores its uniforms row).
+        uniforms may also be what ``upload_uniforms`` returned (already resident: drawn and uploaded while an earlier job ran).
+        while_running: optional callable, invoked after the job has been enqueued and before this call waits for it -- host work
+        that overlaps the kernel (the facade draws and uploads the NEXT piece's uniforms there).
         Returns indices int32 (n_streams, num_samples) [, logits float32 (n_streams, num_samples, classes)]."""
         ns, C = self.n_streams, self.classes
         if first_samples is None:
@@ -213,8 +227,12 @@ class Engine:
         greedy = not (temperature > 0) or uniforms is None
         uni_dev = None
         if not greedy:
-            u = np.ascontiguousarray(np.asarray(uniforms, dtype=np.float64).reshape(ns, num_samples))
-            uni_dev = self.mem.upload(u)
+            if isinstance(uniforms, _Resident):
+                if uniforms.shape != (ns, num_samples):
+                    raise ValueError("resident uniforms have shape %r, the job needs %r" % (uniforms.shape, (ns, num_samples)))
+                uni_dev = uniforms.dev
+            else:
+                uni_dev = self.mem.upload(np.ascontiguousarray(np.asarray(uniforms, dtype=np.float64).reshape(ns, num_samples)))
         reg_dev = self.mem.upload(regularizer_array(C, regularize)) if regularize else None
         first_dev = self.mem.upload(fs)
         out_dev = self.mem.empty((ns, max(num_samples, 1)), np.int32)
@@ -226,6 +244,8 @@ class Engine:
                 first_dev = self.mem.upload(np.ascontiguousarray(fs[:, -1:]))  # the last given sample is the next input
                 n_given = 1
         self.launch(first_dev, n_given, num_samples, temperature, reg_dev, uni_dev, out_dev, logits_dev, timeout_ms, temps_dev)
+        if while_running is not None:
+            while_running()
         self.wait()
         idx = self.mem.download(out_dev)[:, :num_samples]
         if want_logits:

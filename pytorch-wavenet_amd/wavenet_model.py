@@ -321,19 +321,40 @@ class WaveNetModel(nn.Module):
         if progress_callback is not None:
             cuts.update(i + 1 for i in range(a, n_prime) if i % progress_interval == 0)
             cuts.update(n_prime + i + 1 for i in range(num_samples) if (i + num_given) % progress_interval == 0)
+        def callback_due(ev):  # the reference calls back after evaluation ev (:266-269, :308-311)
+            if progress_callback is None or ev < 0:
+                return False
+            if ev < n_prime:
+                return ev >= primed_upto and ev % progress_interval == 0
+            return (ev - n_prime + num_given) % progress_interval == 0
+
+        def n_generated(a0, b0):  # samples the piece [a0, b0) of evaluations generates
+            return (b0 - a0) - max(0, min(b0, n_prime) - a0)
+
         pieces = []
         last = None
         tic = time.time()
-        for b in sorted(cuts):
+        ends = sorted(c for c in cuts if c > a)
+        drawn = None  # the NEXT piece's uniforms, drawn and uploaded while the current piece's kernel ran
+        for k, b in enumerate(sorted(cuts)):
             if b > a:
                 if a == n_prime:
                     tic = time.time()  # :275
                 seg_prime = max(0, min(b, n_prime) - a)
                 n_new = (b - a) - seg_prime
                 head = first[:, a:a + seg_prime + 1] if a < num_given else last
-                # one uniform per generated sample from the GLOBAL numpy RNG, drawn right before the piece runs
-                u = np.random.random_sample((n_streams, n_new)) if (sampled and n_new > 0) else None
-                out = eng.generate(n_new, head, temperature=temperature, regularize=regularize, uniforms=u, reset=False)
+                # one uniform per generated sample from the GLOBAL numpy RNG, drawn right before the piece runs -- or, when nothing
+                # of the caller's runs between two pieces (no callback due at the cut: e.g. the cut behind generating step 99 that only
+                # exists for the reference's timing print), while the PREVIOUS piece's kernel runs: same draws, same order
+                u = drawn if drawn is not None else (np.random.random_sample((n_streams, n_new)) if (sampled and n_new > 0) else None)
+                drawn = None
+                nxt = [c for c in ends if c > b]
+                overlap = None
+                if sampled and nxt and not callback_due(b - 1) and n_generated(b, nxt[0]) > 0:
+                    def overlap(n_next=n_generated(b, nxt[0])):
+                        nonlocal drawn
+                        drawn = eng.upload_uniforms(np.random.random_sample((n_streams, n_next)))
+                out = eng.generate(n_new, head, temperature=temperature, regularize=regularize, uniforms=u, reset=False, while_running=overlap)
                 if n_new > 0:
                     pieces.append(out)
                     last = out[:, -1:].astype(np.int64)
@@ -344,12 +365,8 @@ class WaveNetModel(nn.Module):
             if ev >= n_prime and ev - n_prime + 1 == 100:
                 toc = time.time()
                 print("one generating step does take approximately " + str((toc - tic) * 0.01) + " seconds)")
-            if progress_callback is not None:
-                if ev < n_prime:
-                    if ev >= primed_upto and ev % progress_interval == 0:  # (not a second time after batched priming: num_samples == 0)
-                        progress_callback(ev, total_samples)
-                elif (ev - n_prime + num_given) % progress_interval == 0:
-                    progress_callback(ev - n_prime + num_given, total_samples)
+            if callback_due(ev):  # (priming: not a second time after batched priming)
+                progress_callback(ev if ev < n_prime else ev - n_prime + num_given, total_samples)
         idx = np.concatenate(pieces, axis=1) if pieces else np.zeros((n_streams, 0), dtype=np.int32)
         self._defer_queues(eng)
         self.train()

@@ -1,9 +1,8 @@
 #!/bin/bash
 mkdir -p gpurun_out
 cd /root/repo
-O=gpurun_out/r03_queue_pair_rows.txt
+O=gpurun_out/r03_facade_overlap.txt
 : > $O
-for c in "cfg3 64" "cfg3 6" "cfg2 64" "cfg1 40" "cfg3 1"; do set -- $c; WN_V3_MODE=3 timeout 50 python tools/quick_check.py $1 $2 2>&1 | grep quick_check >> $O; done
-for n in 64 64 96 128; do timeout 50 python tools/rate.py cfg3 $n 3000 2 2>&1 | grep "samples/s" >> $O; done
-timeout 50 python tools/rate.py cfg2 64 3000 2 2>&1 | grep "samples/s" >> $O
+( timeout 600 python -m pytest tests/test_gpu_facade.py -m gpu -q -x 2>&1 | tail -2 ) >> $O 2>&1
+timeout 300 python bench.py --no-extra --no-cpu-baseline --steps 4 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('facade', d['value'], 'ms', d['ms_per_step'], 'median', d['median_ms_per_step'], 'engine', d['engine_level']['value'], 'ratio', d['engine_level']['facade_over_engine'], 'verified', d['verified'])" >> $O
 cat $O
