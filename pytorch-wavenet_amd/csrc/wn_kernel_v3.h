@@ -909,32 +909,37 @@ static __device__ void wn_v3_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
     }
     float* rings_l = p.rings + p.ring_off[l] + (size_t)c * ns * (size_t)ML * R;  // stream s: + s * ML * R
     int tmod = (int)(r.t_base % ML);  // queue slot of x[t] of the current item, kept incrementally
-    // ---- Single stream: the layer's dilation queue lives in LDS (round 3; wavenet_modules.py:42-77).  One stream leaves the workgroup's
+    // ---- Few streams: the layer's dilation queues live in LDS (round 3; wavenet_modules.py:42-77).  One stream leaves the workgroup's
     // LDS nearly empty (6 KB of activations), and a ring of (d + 1) rows of R floats fits it up to d = 256 (148 KB in the padded row
-    // layout of x); the d = 512 layers keep their rings in HBM (below).  The ring is loaded when the job starts and written back when
-    // it ends (queues outlive a job: continuation, wn_export_queue, DilatedQueue objects of the facade); in between push and tap are
-    // LDS accesses and the tap-0 dot reads its row in place -- no staging copy, no prefetch FIFO, no HBM traffic at all.
-    if (G == 1 && ns == 1 && (long long)L::floats(1) + (long long)ML * L::XR <= (long long)p.lds_floats && !(WN_V3_ABL & 2)) {
-        float* lring = lds + L::floats(1);  // [ML][XR]
-        for (int i = t; i < ML * R; i += 256) lring[(i / R) * L::XR + SH::xpad(i % R)] = rings_l[i];
+    // layout of x); n streams fit up to d + 1 <= 256 / n rows each, the other layers keep their rings in HBM (below).  The rings are
+    // loaded when the job starts and written back when it ends (queues outlive a job: continuation, wn_export_queue, DilatedQueue
+    // objects of the facade); in between push and tap are LDS accesses and the tap-0 dot reads its row in place -- no staging copy,
+    // no prefetch FIFO, no HBM traffic at all.
+    if (G == 1 && (long long)L::floats(ns) + (long long)ns * ML * L::XR <= (long long)p.lds_floats && !(WN_V3_ABL & 2)) {
+        float* lring = lds + L::floats(ns);  // [n_streams][ML][XR]
+        for (int i = t; i < ns * ML * R; i += 256) lring[(i / R) * L::XR + SH::xpad(i % R)] = rings_l[i];
         const int xq1 = SH::xpad(tr);
         int bufq = 0;
-        for (long long e = 0; e < r.n_eval; ++e, tmod = (tmod + 1 == ML) ? 0 : tmod + 1, bufq ^= 1) {
-            if (wn_barrier_failed(cx, failflag)) return;  // ---- A(i): x of this item staged
-            const bool stamp = r.prof && e < r.prof_items && tid == 512;
-            const long long t0 = stamp ? (long long)wall_clock64() : 0;
-            if (t < R) lring[tmod * L::XR + xq1] = xs[bufq * L::XR + xq1];  // the push (wavenet_modules.py:55-57)
-            if (wn_barrier_failed(cx, failflag)) return;  // ---- B(i)
-            const long long t1 = stamp ? (long long)wall_clock64() : 0;
+        long long itemq = 0;
+        for (long long e = 0; e < r.n_eval; ++e, tmod = (tmod + 1 == ML) ? 0 : tmod + 1) {
             // tap-0 half of the dilated conv for the NEXT timestep: x[t+1-d] sits in slot (t + 2) mod (d + 1) (d = 1: the row just pushed)
             const int tap = tmod + 2 >= ML ? tmod + 2 - ML : tmod + 2;
-            tap0_dot(lring + tap * L::XR, 0);
-            if (stamp)
-                r.prof[((size_t)cx.w * r.prof_items + e) * WN_STAMPS + 7] =
-                    (t0 & 0xffffffffffll) | (((t1 - t0) & 0xfff) << 40) | ((((long long)wall_clock64() - t1) & 0xfff) << 52);
+            for (int s = 0; s < ns; ++s, bufq ^= 1, ++itemq) {
+                float* ring_s = lring + (size_t)s * ML * L::XR;
+                if (wn_barrier_failed(cx, failflag)) return;  // ---- A(i): x of this item staged
+                const bool stamp = r.prof && itemq < r.prof_items && tid == 512;
+                const long long t0 = stamp ? (long long)wall_clock64() : 0;
+                if (t < R) ring_s[tmod * L::XR + xq1] = xs[bufq * L::XR + xq1];  // the push (wavenet_modules.py:55-57)
+                if (wn_barrier_failed(cx, failflag)) return;  // ---- B(i)
+                const long long t1 = stamp ? (long long)wall_clock64() : 0;
+                tap0_dot(ring_s + tap * L::XR, s);
+                if (stamp)
+                    r.prof[((size_t)cx.w * r.prof_items + itemq) * WN_STAMPS + 7] =
+                        (t0 & 0xffffffffffll) | (((t1 - t0) & 0xfff) << 40) | ((((long long)wall_clock64() - t1) & 0xfff) << 52);
+            }
         }
         if (wn_barrier_failed(cx, failflag)) return;  // A(N)
-        for (int i = t; i < ML * R; i += 256) rings_l[i] = lring[(i / R) * L::XR + SH::xpad(i % R)];  // the queue's state back to HBM
+        for (int i = t; i < ns * ML * R; i += 256) rings_l[i] = lring[(i / R) * L::XR + SH::xpad(i % R)];  // the queues' state back to HBM
         (void)wn_barrier_failed(cx, failflag);        // B(N)
         return;
     }

@@ -443,7 +443,7 @@ extern "C" int wn_create(const wn_config* cfg, wn_handle** out) {
                 h->v3_mode &= 1;
             }
             h->lds_bytes = wn_v2_table()[vi3].lds_floats_v3(pl.n_streams, h->v3_mode & 1) * 4;
-            if (pl.n_streams == 1) h->lds_bytes = WN_LDS_MAX_BYTES;  // single stream: the layers' dilation queues live in LDS where they fit (wn_v3_layer)
+            if (pl.n_streams <= 4 && !(h->v3_mode & 1)) h->lds_bytes = WN_LDS_MAX_BYTES;  // 1-4 streams (8: measured level, profiles/r03_few_stream_lds_queues.txt): the layers' dilation queues live in LDS where they fit (wn_v3_layer)
             pl.lds_floats = h->lds_bytes / 4;
         }
     }
