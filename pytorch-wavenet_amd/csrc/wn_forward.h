@@ -55,8 +55,79 @@ struct WnGemmArgs {
     float* gate_g;
     WnRowMap c2;          // WN_EPI_GATE only: rows whose index inside the batch entry is >= c2_first_row are ALSO written here
     int c2_first_row;     //   (at row index - c2_first_row): the z block the grouped skip GEMM consumes.  base == NULL -> off
-    int pad;
+    int gate_packed;      // WN_EPI_GATE: gate_t receives ONE dword per element, {bf16 tanh (low half), bf16 sigmoid (high half)}; gate_g unused
+    // Row windows: view v of A reads as ZERO on the first a_skip_lo[v] and the last a_skip_hi[v] rows of every batch entry, cin adds
+    // nothing on the first cin_skip_lo rows (their addresses are never formed into loads).  One product can then sum two
+    // row-shifted views of a matrix whose shifts run off its ends (the backward's dx_l = dx' + dfg(t).W1 + dfg(t+d).W0).
+    int a_skip_lo[2], a_skip_hi[2], cin_skip_lo;
+    const float* bt1;     // optional: rows k >= k_split of B^T come from here (row k - k_split), so the two halves need not be adjacent
 };
+static __device__ __forceinline__ const float* wn_row_at(const WnRowMap& r, unsigned q, unsigned rem) {
+    return r.base + (long long)q * r.batch_stride + (r.t0 + (long long)rem) * r.row_stride;
+}
+
+static __device__ __forceinline__ unsigned wn_pack_bf16(float lo, float hi) {  // two RNE-rounded bf16 in one dword
+    unsigned a = __float_as_uint(lo), b = __float_as_uint(hi);
+    a += 0x7fffu + ((a >> 16) & 1u);
+    b += 0x7fffu + ((b >> 16) & 1u);
+    return (a >> 16) | (b & 0xffff0000u);
+}
+
+// Epilogue of a wave's 32 x 128 strip (4 accumulator tiles; C/D layout of 32x32: col = lane & 31, row = (i & 3) + 8 * (i >> 2) +
+// 4 * (lane >> 5)): rows mw.., logical columns nw.. .  WN_EPI_GATE: the 128 columns are [F(32) | G(32) | F(32) | G(32)] and the
+// strip emits 64 columns of tanh(F+bf) * sigmoid(G+bg).
+template <int EPI>
+static __device__ __forceinline__ void wn_gemm_epilogue(const WnGemmArgs& g, const wn_f16v (&acc)[4], long long mw, int nw, int lane) {
+    const int col = lane & 31;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int r = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+        const long long m = mw + r;
+        if (m >= g.M) continue;
+        // M < 2^31 (checked on the host): 32-bit division, a 64-bit one is ~100 instructions and the epilogue does 16 of them
+        const unsigned q = (unsigned)m / (unsigned)g.rows_per_batch, rem = (unsigned)m - q * (unsigned)g.rows_per_batch;
+        float* crow = const_cast<float*>(wn_row_at(g.c, q, rem));
+        const float* addrow = (g.cin.base && (int)rem >= g.cin_skip_lo) ? wn_row_at(g.cin, q, rem) : nullptr;
+        if (EPI == WN_EPI_GATE) {
+            float* c2row = nullptr;
+            if (g.c2.base && (int)rem >= g.c2_first_row)
+                c2row = const_cast<float*>(g.c2.base) + (long long)q * g.c2.batch_stride + (g.c2.t0 + (long long)rem - g.c2_first_row) * g.c2.row_stride;
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const int nf = nw + 64 * p + col, ng = nf + 32;  // logical columns of F and G
+                if (ng >= g.N) continue;
+                const float f = acc[2 * p][i] + (g.bias ? g.bias[nf] : 0.f);
+                const float gg = acc[2 * p + 1][i] + (g.bias ? g.bias[ng] : 0.f);
+                // tanh(f) = 2 sigmoid(2f) - 1 on the branch-free exp of the generation kernels (absolute error ~1e-7), 1-ulp reciprocals
+                const float th = fmaf(2.0f, __builtin_amdgcn_rcpf(1.0f + wn_exp(-2.0f * f)), -1.0f), sg = __builtin_amdgcn_rcpf(1.0f + wn_exp(-gg));
+                const float z = th * sg;
+                const int zc = (nw >> 1) + 32 * p + col;
+                crow[zc] = z;
+                if (c2row) c2row[zc] = z;
+                if (g.gate_t) {
+                    if (g.gate_packed) {
+                        reinterpret_cast<unsigned*>(g.gate_t)[m * (g.N >> 1) + zc] = wn_pack_bf16(th, sg);
+                    } else {
+                        g.gate_t[m * (g.N >> 1) + zc] = th;
+                        g.gate_g[m * (g.N >> 1) + zc] = sg;
+                    }
+                }
+            }
+        } else {
+            const float* mrow = g.mask ? g.mask + (crow - g.c.base) : nullptr;  // the mask shares the output's row layout
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = nw + 32 * j + col;
+                if (n >= g.N) continue;
+                float v = acc[j][i] + (g.bias ? g.bias[n] : 0.f);
+                if (addrow) v += addrow[n];
+                if (g.relu_c) v = fmaxf(v, 0.f);
+                if (mrow && !(mrow[n] > 0.f)) v = 0.f;
+                crow[n] = v;
+            }
+        }
+    }
+}
 
 // C[M][N] (+)= A[M][K] . B^T[K][N]; 128 x 128 tile per workgroup, 4 waves, wave w owns rows 32w..32w+31 and all 128
 // columns (4 accumulator tiles of 32x32).  WN_EPI_GATE: the 128 columns are [F(32) | G(32) | F(32) | G(32)] and the tile
@@ -88,17 +159,21 @@ __global__ __launch_bounds__(256, WN_GEMM_MINB) void wn_fwd_gemm(WnGemmArgs g) {
     const int arow = tid >> 1, ahalf = tid & 1;
     const long long am = m0 + arow;
     const bool arow_ok = am < g.M;
-    const float* a0p = arow_ok ? wn_row(g.a0, am, g.rows_per_batch) : nullptr;
-    const float* a1p = arow_ok ? wn_row(g.a1, am, g.rows_per_batch) : nullptr;
+    const unsigned aq = arow_ok ? (unsigned)am / (unsigned)g.rows_per_batch : 0u, arem = arow_ok ? (unsigned)am - aq * (unsigned)g.rows_per_batch : 0u;
+    const bool ok0 = arow_ok && (int)arem >= g.a_skip_lo[0] && (int)arem < g.rows_per_batch - g.a_skip_hi[0];
+    const bool ok1 = arow_ok && (int)arem >= g.a_skip_lo[1] && (int)arem < g.rows_per_batch - g.a_skip_hi[1];
+    const float* a0p = wn_row_at(g.a0, aq, arem);
+    const float* a1p = wn_row_at(g.a1, aq, arem);
     const int brow = tid / BT, bcol = (tid % BT) * (KC / 2);
 
     float4 va[NQ], vb[NQ];  // staging registers of the chunk in flight
     auto fetch = [&](int kc) {  // global -> registers (issued before the multiply of the current chunk)
         const int k0 = kc * KC;
-        const float* src = k0 < g.k_split ? a0p + k0 : a1p + (k0 - g.k_split);
+        const bool first = k0 < g.k_split, ok = first ? ok0 : ok1;
+        const float* src = first ? a0p + k0 : a1p + (k0 - g.k_split);
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) va[q] = arow_ok ? *reinterpret_cast<const float4*>(src + ahalf * (KC / 2) + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-        const float* bsrc = g.bt + (size_t)(k0 + brow) * g.N + n0 + bcol;
+        for (int q = 0; q < NQ; ++q) va[q] = ok ? *reinterpret_cast<const float4*>(src + ahalf * (KC / 2) + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float* bsrc = ((first || !g.bt1) ? g.bt + (size_t)(k0 + brow) * g.N : g.bt1 + (size_t)(k0 - g.k_split + brow) * g.N) + n0 + bcol;
 #pragma unroll
         for (int q = 0; q < NQ; ++q)
             vb[q] = (n0 + bcol + q * 4 < g.N) ? *reinterpret_cast<const float4*>(bsrc + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -140,52 +215,7 @@ __global__ __launch_bounds__(256, WN_GEMM_MINB) void wn_fwd_gemm(WnGemmArgs g) {
         __syncthreads();
     }
 
-    // epilogue.  C/D layout of 32x32: col = lane & 31, row = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5)
-    const int col = lane & 31;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int r = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
-        const long long m = m0 + 32 * wv + r;
-        if (m >= g.M) continue;
-        float* crow = const_cast<float*>(wn_row(g.c, m, g.rows_per_batch));
-        const float* addrow = g.cin.base ? wn_row(g.cin, m, g.rows_per_batch) : nullptr;
-        if (EPI == WN_EPI_GATE) {
-            float* c2row = nullptr;
-            if (g.c2.base) {
-                const unsigned q = (unsigned)m / (unsigned)g.rows_per_batch, rem = (unsigned)m - q * (unsigned)g.rows_per_batch;
-                if ((int)rem >= g.c2_first_row)
-                    c2row = const_cast<float*>(g.c2.base) + (long long)q * g.c2.batch_stride + (g.c2.t0 + (long long)rem - g.c2_first_row) * g.c2.row_stride;
-            }
-#pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                const int nf = n0 + 64 * p + col, ng = nf + 32;  // logical columns of F and G
-                if (ng >= g.N) continue;
-                const float f = acc[2 * p][i] + (g.bias ? g.bias[nf] : 0.f);
-                const float gg = acc[2 * p + 1][i] + (g.bias ? g.bias[ng] : 0.f);
-                // tanh(f) = 2 sigmoid(2f) - 1 on the branch-free exp of the generation kernels (absolute error ~1e-7), 1-ulp reciprocals
-                const float th = fmaf(2.0f, __builtin_amdgcn_rcpf(1.0f + wn_exp(-2.0f * f)), -1.0f), sg = __builtin_amdgcn_rcpf(1.0f + wn_exp(-gg));
-                const float z = th * sg;
-                crow[(n0 >> 1) + 32 * p + col] = z;
-                if (c2row) c2row[(n0 >> 1) + 32 * p + col] = z;
-                if (g.gate_t) {
-                    g.gate_t[m * (g.N >> 1) + (n0 >> 1) + 32 * p + col] = th;
-                    g.gate_g[m * (g.N >> 1) + (n0 >> 1) + 32 * p + col] = sg;
-                }
-            }
-        } else {
-            const float* mrow = g.mask ? g.mask + (crow - g.c.base) : nullptr;  // the mask shares the output's row layout
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int n = n0 + 32 * j + col;
-                if (n >= g.N) continue;
-                float v = acc[j][i] + (g.bias ? g.bias[n] : 0.f);
-                if (addrow) v += addrow[n];
-                if (g.relu_c) v = fmaxf(v, 0.f);
-                if (mrow && !(mrow[n] > 0.f)) v = 0.f;
-                crow[n] = v;
-            }
-        }
-    }
+    wn_gemm_epilogue<EPI>(g, acc, m0 + 32 * wv, n0, lane);
 }
 
 
@@ -196,16 +226,11 @@ __global__ __launch_bounds__(256, WN_GEMM_MINB) void wn_fwd_gemm(WnGemmArgs g) {
 // the 1e-2 level of the logit scale -- the usual bf16 training trade -- so the fp32 kernel stays the parity default.
 typedef __bf16 wn_bf16x8 __attribute__((ext_vector_type(8)));
 
-static __device__ __forceinline__ unsigned wn_pack_bf16(float lo, float hi) {  // two RNE-rounded bf16 in one dword
-    unsigned a = __float_as_uint(lo), b = __float_as_uint(hi);
-    a += 0x7fffu + ((a >> 16) & 1u);
-    b += 0x7fffu + ((b >> 16) & 1u);
-    return (a >> 16) | (b & 0xffff0000u);
-}
-
 struct WnGemmArgsBf16 {
-    WnGemmArgs g;              // as the fp32 kernel; g.bt unused
-    const unsigned short* bn;  // B as bf16 [N][K] row-major (K contiguous: the weights' natural (out, in) layout)
+    WnGemmArgs g;              // as the fp32 kernel; g.bt / g.bt1 unused
+    const unsigned short* bn;  // B as bf16 [N][ldb] row-major (K contiguous: the weights' natural (out, in) layout)
+    const unsigned short* bn1; // optional: columns k >= k_split of B come from here ([N][ldb], column k - k_split)
+    int ldb;                   // 0 -> K
 };
 
 #ifndef WN_GEMM_BF16_KC
@@ -214,14 +239,21 @@ struct WnGemmArgsBf16 {
 #ifndef WN_GEMM_BF16_MINB
 #define WN_GEMM_BF16_MINB 3
 #endif
-template <int EPI>
-__global__ __launch_bounds__(256, WN_GEMM_BF16_MINB) void wn_fwd_gemm_bf16(WnGemmArgsBf16 ga) {
+// WAVES = 4: 128 x 128 tile (wave w: rows 32w.., all 128 columns).  WAVES = 8: 128 x 256 tile (wave w: rows 32 (w & 3).., column half
+// w >> 2) for products with N >= 256 -- these GEMMs are streams over A (K is 128-512, M is 350 k-500 k rows), and a 128-column
+// tile makes every further column block re-read A from HBM (the gate product: 4 x 262 MB instead of 2 x); the wide tile stages A
+// once for all 256 columns.
+template <int EPI, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? WN_GEMM_BF16_MINB : 4) void wn_fwd_gemm_bf16(WnGemmArgsBf16 ga) {
     const WnGemmArgs& g = ga.g;
-    constexpr int TM = 128, TN = 128, KC = WN_GEMM_BF16_KC, LD = KC + 8;  // LD: padded row length (bf16): 144- / 80-byte rows, conflict-free b128 reads
-    constexpr int HK = KC / 2;   // k values per loader thread (two threads per row)
+    constexpr int NT = 64 * WAVES, TM = 128, TN = 32 * WAVES, KC = WN_GEMM_BF16_KC, LD = KC + 8;  // LD: padded row length (bf16): 80-byte rows, conflict-free b128 reads
+    constexpr int TPR = NT / TM;   // loader threads per A row (2 / 4)
+    constexpr int HK = KC / TPR;   // k values per A loader thread and chunk (16 / 8)
+    constexpr int HB = KC / 2;     // B: two loader threads per column, KC/2 bf16 each (NT == 2 TN)
+    static_assert(HK % 8 == 0 && HB % 8 == 0, "loader pieces are 16-byte LDS stores");
     __shared__ __attribute__((aligned(16))) unsigned short a_s[2][TM * LD];
     __shared__ __attribute__((aligned(16))) unsigned short b_s[2][TN * LD];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wr = wv & 3, wc = wv >> 2;
     const long long m0 = (long long)blockIdx.x * TM;
     const int n0 = blockIdx.y * TN;
     wn_f16v acc[4];
@@ -229,27 +261,34 @@ __global__ __launch_bounds__(256, WN_GEMM_BF16_MINB) void wn_fwd_gemm_bf16(WnGem
     for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
-    const int lrow = tid >> 1, lhalf = tid & 1;  // loader: row (A) / column (B) tid/2, 32 of the 64 k each
+    const int lrow = tid / TPR, lpart = tid % TPR;
     const long long am = m0 + lrow;
     const bool arow_ok = am < g.M;
-    const float* a0p = arow_ok ? wn_row(g.a0, am, g.rows_per_batch) : nullptr;
-    const float* a1p = arow_ok ? wn_row(g.a1, am, g.rows_per_batch) : nullptr;
-    const bool bcol_ok = n0 + lrow < g.N;
-    const unsigned short* bp = ga.bn + (size_t)(n0 + lrow) * g.K;
+    const unsigned aq = arow_ok ? (unsigned)am / (unsigned)g.rows_per_batch : 0u, arem = arow_ok ? (unsigned)am - aq * (unsigned)g.rows_per_batch : 0u;
+    const bool ok0 = arow_ok && (int)arem >= g.a_skip_lo[0] && (int)arem < g.rows_per_batch - g.a_skip_hi[0];
+    const bool ok1 = arow_ok && (int)arem >= g.a_skip_lo[1] && (int)arem < g.rows_per_batch - g.a_skip_hi[1];
+    const float* a0p = wn_row_at(g.a0, aq, arem) + lpart * HK;
+    const float* a1p = wn_row_at(g.a1, aq, arem) + lpart * HK;
+    const int bcol = tid >> 1, bhalf = tid & 1;
+    const bool bcol_ok = n0 + bcol < g.N;
+    const int ldb = ga.ldb ? ga.ldb : g.K;
+    const unsigned short* bp0 = ga.bn + (size_t)(n0 + bcol) * ldb + bhalf * HB;
+    const unsigned short* bp1 = ga.bn1 ? ga.bn1 + (size_t)(n0 + bcol) * ldb + bhalf * HB : bp0 + g.k_split;
 
     float4 va[HK / 4];
-    uint4 vb[HK / 8];
+    uint4 vb[HB / 8];
     auto fetch = [&](int kc) {
         const int k0 = kc * KC;
-        const float* src = (k0 < g.k_split ? a0p + k0 : a1p + (k0 - g.k_split)) + lhalf * HK;
+        const bool first = k0 < g.k_split, ok = first ? ok0 : ok1;
+        const float* src = first ? a0p + k0 : a1p + (k0 - g.k_split);
 #pragma unroll
-        for (int q = 0; q < HK / 4; ++q) va[q] = arow_ok ? *reinterpret_cast<const float4*>(src + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-        const uint4* bsrc = reinterpret_cast<const uint4*>(bp + k0 + lhalf * HK);
+        for (int q = 0; q < HK / 4; ++q) va[q] = ok ? *reinterpret_cast<const float4*>(src + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const uint4* bsrc = reinterpret_cast<const uint4*>(first ? bp0 + k0 : bp1 + (k0 - g.k_split));
 #pragma unroll
-        for (int q = 0; q < HK / 8; ++q) vb[q] = bcol_ok ? bsrc[q] : make_uint4(0u, 0u, 0u, 0u);
+        for (int q = 0; q < HB / 8; ++q) vb[q] = bcol_ok ? bsrc[q] : make_uint4(0u, 0u, 0u, 0u);
     };
     auto stash = [&](int buf) {
-        uint4* ad = reinterpret_cast<uint4*>(a_s[buf] + lrow * LD + lhalf * HK);
+        uint4* ad = reinterpret_cast<uint4*>(a_s[buf] + lrow * LD + lpart * HK);
 #pragma unroll
         for (int q = 0; q < HK / 8; ++q) {
             float4 x = va[2 * q], y = va[2 * q + 1];
@@ -259,9 +298,9 @@ __global__ __launch_bounds__(256, WN_GEMM_BF16_MINB) void wn_fwd_gemm_bf16(WnGem
             }
             ad[q] = make_uint4(wn_pack_bf16(x.x, x.y), wn_pack_bf16(x.z, x.w), wn_pack_bf16(y.x, y.y), wn_pack_bf16(y.z, y.w));
         }
-        uint4* bd = reinterpret_cast<uint4*>(b_s[buf] + lrow * LD + lhalf * HK);
+        uint4* bd = reinterpret_cast<uint4*>(b_s[buf] + bcol * LD + bhalf * HB);
 #pragma unroll
-        for (int q = 0; q < HK / 8; ++q) bd[q] = vb[q];
+        for (int q = 0; q < HB / 8; ++q) bd[q] = vb[q];
     };
 
     const int nchunks = g.K / KC;
@@ -271,8 +310,8 @@ __global__ __launch_bounds__(256, WN_GEMM_BF16_MINB) void wn_fwd_gemm_bf16(WnGem
     for (int kc = 0; kc < nchunks; ++kc) {
         const int buf = kc & 1;
         if (kc + 1 < nchunks) fetch(kc + 1);
-        const unsigned short* ar = a_s[buf] + (32 * wv + (lane & 31)) * LD + 8 * (lane >> 5);
-        const unsigned short* br = b_s[buf] + (lane & 31) * LD + 8 * (lane >> 5);
+        const unsigned short* ar = a_s[buf] + (32 * wr + (lane & 31)) * LD + 8 * (lane >> 5);
+        const unsigned short* br = b_s[buf] + (128 * wc + (lane & 31)) * LD + 8 * (lane >> 5);
 #pragma unroll
         for (int ks = 0; ks < KC / 16; ++ks) {
             const wn_bf16x8 a = *reinterpret_cast<const wn_bf16x8*>(ar + 16 * ks);
@@ -285,52 +324,7 @@ __global__ __launch_bounds__(256, WN_GEMM_BF16_MINB) void wn_fwd_gemm_bf16(WnGem
         if (kc + 1 < nchunks) stash(buf ^ 1);
         __syncthreads();
     }
-
-    const int col = lane & 31;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int r = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
-        const long long m = m0 + 32 * wv + r;
-        if (m >= g.M) continue;
-        float* crow = const_cast<float*>(wn_row(g.c, m, g.rows_per_batch));
-        const float* addrow = g.cin.base ? wn_row(g.cin, m, g.rows_per_batch) : nullptr;
-        if (EPI == WN_EPI_GATE) {
-            float* c2row = nullptr;
-            if (g.c2.base) {
-                const unsigned q = (unsigned)m / (unsigned)g.rows_per_batch, rem = (unsigned)m - q * (unsigned)g.rows_per_batch;
-                if ((int)rem >= g.c2_first_row)
-                    c2row = const_cast<float*>(g.c2.base) + (long long)q * g.c2.batch_stride + (g.c2.t0 + (long long)rem - g.c2_first_row) * g.c2.row_stride;
-            }
-#pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                const int nf = n0 + 64 * p + col, ng = nf + 32;
-                if (ng >= g.N) continue;
-                const float f = acc[2 * p][i] + (g.bias ? g.bias[nf] : 0.f);
-                const float gg = acc[2 * p + 1][i] + (g.bias ? g.bias[ng] : 0.f);
-                // tanh(f) = 2 sigmoid(2f) - 1 on the branch-free exp of the generation kernels (absolute error ~1e-7), 1-ulp reciprocals
-                const float th = fmaf(2.0f, __builtin_amdgcn_rcpf(1.0f + wn_exp(-2.0f * f)), -1.0f), sg = __builtin_amdgcn_rcpf(1.0f + wn_exp(-gg));
-                const float z = th * sg;
-                crow[(n0 >> 1) + 32 * p + col] = z;
-                if (c2row) c2row[(n0 >> 1) + 32 * p + col] = z;
-                if (g.gate_t) {
-                    g.gate_t[m * (g.N >> 1) + (n0 >> 1) + 32 * p + col] = th;
-                    g.gate_g[m * (g.N >> 1) + (n0 >> 1) + 32 * p + col] = sg;
-                }
-            }
-        } else {
-            const float* mrow = g.mask ? g.mask + (crow - g.c.base) : nullptr;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int n = n0 + 32 * j + col;
-                if (n >= g.N) continue;
-                float v = acc[j][i] + (g.bias ? g.bias[n] : 0.f);
-                if (addrow) v += addrow[n];
-                if (g.relu_c) v = fmaxf(v, 0.f);
-                if (mrow && !(mrow[n] > 0.f)) v = 0.f;
-                crow[n] = v;
-            }
-        }
-    }
+    wn_gemm_epilogue<EPI>(g, acc, m0 + 32 * wr, n0 + 128 * wc, lane);
 }
 
 // out[i] = bf16(in[i]) (round to nearest even): the backward products' weight operands, [N][K] row-major, are the forward
@@ -476,12 +470,15 @@ __global__ __launch_bounds__(256, WN_GEMM_MINB) void wn_bwd_gemm_tn(WnGemmTnArgs
 #ifndef WN_TN_BF16_MINB
 #define WN_TN_BF16_MINB 3
 #endif
-__global__ __launch_bounds__(256, WN_TN_BF16_MINB) void wn_bwd_gemm_tn_bf16(WnGemmTnArgs g) {
-    constexpr int T = 128, KC = 32, LD = KC + 8;  // LDS rows: [column][KC rows of the chunk] bf16, padded to 80 bytes
+// WAVES = 4: 128 x 128 tile of C.  WAVES = 8: 128 (Ka) x 256 (Nb) tile for Nb >= 256 (wave w: ka strip 32 (w & 3).., nb half w >> 2), so
+// that A -- the layer input x in the filter/gate weight gradient, 262 MB -- is streamed once instead of once per 128 columns of B.
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? WN_TN_BF16_MINB : 4) void wn_bwd_gemm_tn_bf16(WnGemmTnArgs g) {
+    constexpr int T = 128, TB = 32 * WAVES, KC = 32, LD = KC + 8;  // LDS rows: [column][KC rows of the chunk] bf16, padded to 80 bytes
     __shared__ __attribute__((aligned(16))) unsigned short a_s[2][T * LD];
-    __shared__ __attribute__((aligned(16))) unsigned short b_s[2][T * LD];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int ka0 = blockIdx.x * T, nb0 = blockIdx.y * T;
+    __shared__ __attribute__((aligned(16))) unsigned short b_s[2][TB * LD];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wr = wv & 3, wc = wv >> 2;
+    const int ka0 = blockIdx.x * T, nb0 = blockIdx.y * TB;
     const long long m_begin = (long long)blockIdx.z * g.rows_per_split;
     long long m_end = m_begin + g.rows_per_split;
     if (m_end > g.M) m_end = g.M;
@@ -491,12 +488,15 @@ __global__ __launch_bounds__(256, WN_TN_BF16_MINB) void wn_bwd_gemm_tn_bf16(WnGe
     for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
-    // loader: threads 0-127 feed A, 128-255 feed B; unit = 8 rows (group mg) x 4 columns (group cg)
-    const bool is_b = tid >= 128;
+    // loader: threads 0-127 feed A, the next 128 (256) feed B, 128 columns each (WAVES = 8: the last 128 threads load nothing);
+    // unit = 8 rows (group mg) x 4 columns (group cg)
+    const int role = tid >> 7;                    // 0: A;  1 ..: B columns 128 (role - 1) ..
+    const bool is_b = role >= 1, loads = role <= TB / 128;
     const int u = tid & 127, mg = u >> 5, cg = u & 31;
     const WnRowMap& rm = is_b ? g.b : g.a;
-    const int col0 = (is_b ? nb0 : ka0) + 4 * cg, ncols = is_b ? g.Nb : g.Ka;
-    const bool col_ok = col0 < ncols;
+    const int lcol = is_b ? 128 * (role - 1) + 4 * cg : 4 * cg;   // column inside the tile
+    const int col0 = (is_b ? nb0 : ka0) + lcol, ncols = is_b ? g.Nb : g.Ka;
+    const bool col_ok = loads && col0 < ncols;
     const bool relu = !is_b && g.relu_a;
     float4 v[8];
     auto fetch = [&](long long mc) {
@@ -515,7 +515,8 @@ __global__ __launch_bounds__(256, WN_TN_BF16_MINB) void wn_bwd_gemm_tn_bf16(WnGe
         }
     };
     auto stash = [&](int buf) {
-        unsigned short* dst = (is_b ? b_s[buf] : a_s[buf]) + (4 * cg) * LD + mg * 8;
+        if (!loads) return;
+        unsigned short* dst = (is_b ? b_s[buf] : a_s[buf]) + lcol * LD + mg * 8;
         if (relu) {
 #pragma unroll
             for (int rr = 0; rr < 8; ++rr) { v[rr].x = fmaxf(v[rr].x, 0.f); v[rr].y = fmaxf(v[rr].y, 0.f); v[rr].z = fmaxf(v[rr].z, 0.f); v[rr].w = fmaxf(v[rr].w, 0.f); }
@@ -531,8 +532,8 @@ __global__ __launch_bounds__(256, WN_TN_BF16_MINB) void wn_bwd_gemm_tn_bf16(WnGe
     int buf = 0;
     for (long long mc = m_begin; mc < m_end; mc += KC, buf ^= 1) {
         if (mc + KC < m_end) fetch(mc + KC);
-        const unsigned short* ar = a_s[buf] + (32 * wv + (lane & 31)) * LD + 8 * (lane >> 5);
-        const unsigned short* br = b_s[buf] + (lane & 31) * LD + 8 * (lane >> 5);
+        const unsigned short* ar = a_s[buf] + (32 * wr + (lane & 31)) * LD + 8 * (lane >> 5);
+        const unsigned short* br = b_s[buf] + (128 * wc + (lane & 31)) * LD + 8 * (lane >> 5);
 #pragma unroll
         for (int ks = 0; ks < KC / 16; ++ks) {
             const wn_bf16x8 a = *reinterpret_cast<const wn_bf16x8*>(ar + 16 * ks);
@@ -548,11 +549,11 @@ __global__ __launch_bounds__(256, WN_TN_BF16_MINB) void wn_bwd_gemm_tn_bf16(WnGe
     const int col = lane & 31;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-        const int ka = ka0 + 32 * wv + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+        const int ka = ka0 + 32 * wr + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
         if (ka >= g.Ka) continue;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int nb = nb0 + 32 * j + col;
+            const int nb = nb0 + 128 * wc + 32 * j + col;
             if (nb < g.Nb) unsafeAtomicAdd(g.c + (size_t)ka * g.ldc + nb, acc[j][i]);
         }
     }
@@ -561,6 +562,8 @@ __global__ __launch_bounds__(256, WN_TN_BF16_MINB) void wn_bwd_gemm_tn_bf16(WnGe
 // dF = dz * G * (1 - T^2), dG = dz * T * G * (1 - G), written in the packed [F(32) | G(32)] column order of Wfg^T.
 // dzg != NULL: the skip path's share of dz -- column block of the per-block product dskip . Wskip^T, [N*out_len][ldg] -- is
 // added on the last out_len rows of every batch entry (the rows the skip conv saw).
+// PACKED: th holds one dword per element, {bf16 tanh (low half), bf16 sigmoid (high half)} (the bf16 step's saved gates); sg unused.
+template <bool PACKED>
 __global__ void wn_bwd_gate(const float* dz, const float* th, const float* sg, float* dfg, long long M, int D,
                             const float* dzg, int ldg, int rows, int out_len) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -572,7 +575,13 @@ __global__ void wn_bwd_gate(const float* dz, const float* th, const float* sg, f
         const unsigned n = (unsigned)m / (unsigned)rows, tt = (unsigned)m - n * (unsigned)rows;
         if ((int)tt >= rows - out_len) d += dzg[((long long)n * out_len + ((int)tt - (rows - out_len))) * ldg + ch];
     }
-    const float t = th[i], s = sg[i];
+    float t, s;
+    if (PACKED) {
+        const unsigned ts = reinterpret_cast<const unsigned*>(th)[i];
+        t = __uint_as_float(ts << 16); s = __uint_as_float(ts & 0xffff0000u);
+    } else {
+        t = th[i]; s = sg[i];
+    }
     const int nf = 64 * (ch >> 5) + (ch & 31);
     dfg[m * 2 * D + nf] = d * s * (1.f - t * t);
     dfg[m * 2 * D + nf + 32] = d * t * s * (1.f - s);

@@ -38,6 +38,28 @@ static int wn_fail(int code, const char* fmt, ...) {
     return code;
 }
 
+// One "NN" product C = A . B^T of wn_forward.h.  bn != NULL: bf16 operands (B given as [N][K] bf16 -- or as two [N][ldb] halves
+// bn / bn1 --, A rounded while staged), fp32 accumulation; else fp32 operands.  Products with N % 256 == 0 take the 128 x 256 tile.
+static void wn_launch_nn(hipStream_t st, int epi, const WnGemmArgs& a, const unsigned short* bn = nullptr, const unsigned short* bn1 = nullptr, int ldb = 0) {
+    if (bn) {
+        WnGemmArgsBf16 b;
+        b.g = a; b.bn = bn; b.bn1 = bn1; b.ldb = ldb;
+        if (a.N % 256 == 0) {
+            const dim3 grid((unsigned)((a.M + 127) / 128), (unsigned)(a.N / 256));
+            if (epi == WN_EPI_GATE) hipLaunchKernelGGL((wn_fwd_gemm_bf16<WN_EPI_GATE, 8>), grid, dim3(512), 0, st, b);
+            else hipLaunchKernelGGL((wn_fwd_gemm_bf16<WN_EPI_PLAIN, 8>), grid, dim3(512), 0, st, b);
+        } else {
+            const dim3 grid((unsigned)((a.M + 127) / 128), (unsigned)((a.N + 127) / 128));
+            if (epi == WN_EPI_GATE) hipLaunchKernelGGL((wn_fwd_gemm_bf16<WN_EPI_GATE, 4>), grid, dim3(256), 0, st, b);
+            else hipLaunchKernelGGL((wn_fwd_gemm_bf16<WN_EPI_PLAIN, 4>), grid, dim3(256), 0, st, b);
+        }
+        return;
+    }
+    const dim3 grid((unsigned)((a.M + 127) / 128), (unsigned)((a.N + 127) / 128));
+    if (epi == WN_EPI_GATE) hipLaunchKernelGGL(wn_fwd_gemm<WN_EPI_GATE>, grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(wn_fwd_gemm<WN_EPI_PLAIN>, grid, dim3(256), 0, st, a);
+}
+
 // ------------------------------------------------------------------------------------------------ runtime shim
 static const char* g_hip_what = "";
 static int rt_hip(hipError_t e, const char* what) {
@@ -906,16 +928,7 @@ extern "C" int wn_forward(wn_handle* h, const int32_t* indices, int64_t N, int64
                            pl.has_bias ? h->d_start_b : nullptr, xa, rows, R);
     }
     const bool bf16 = h->fw_bf16 && h->fwb_ok;
-    auto launch = [&](int epi, const WnGemmArgs& a, const unsigned short* bn) {
-        dim3 grid((unsigned)((a.M + 127) / 128), (unsigned)((a.N + 127) / 128));
-        if (bf16) {
-            WnGemmArgsBf16 b;
-            b.g = a; b.bn = bn;
-            if (epi == WN_EPI_GATE) hipLaunchKernelGGL(wn_fwd_gemm_bf16<WN_EPI_GATE>, grid, dim3(256), 0, st, b);
-            else hipLaunchKernelGGL(wn_fwd_gemm_bf16<WN_EPI_PLAIN>, grid, dim3(256), 0, st, b);
-        } else if (epi == WN_EPI_GATE) hipLaunchKernelGGL(wn_fwd_gemm<WN_EPI_GATE>, grid, dim3(256), 0, st, a);
-        else hipLaunchKernelGGL(wn_fwd_gemm<WN_EPI_PLAIN>, grid, dim3(256), 0, st, a);
-    };
+    auto launch = [&](int epi, const WnGemmArgs& a, const unsigned short* bn) { wn_launch_nn(st, epi, a, bf16 ? bn : nullptr); };
     const unsigned short* fwb = h->d_fwb;
     const float* fw = h->d_fw;
     float* xin = xa; float* xout = xb;
@@ -1034,11 +1047,7 @@ extern "C" int wn_prime(wn_handle* h, const int32_t* first_samples, int64_t n_pr
         hipLaunchKernelGGL(wn_fwd_start, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, first_samples + (size_t)s * row_stride,
                            h->d_start_t, pl.has_bias ? h->d_start_b : nullptr, xa + ((size_t)s * Lt + Lp) * R, n, R);
     }
-    auto launch = [&](int epi, const WnGemmArgs& a) {
-        dim3 grid((unsigned)((a.M + 127) / 128), (unsigned)((a.N + 127) / 128));
-        if (epi == WN_EPI_GATE) hipLaunchKernelGGL(wn_fwd_gemm<WN_EPI_GATE>, grid, dim3(256), 0, st, a);
-        else hipLaunchKernelGGL(wn_fwd_gemm<WN_EPI_PLAIN>, grid, dim3(256), 0, st, a);
-    };
+    auto launch = [&](int epi, const WnGemmArgs& a) { wn_launch_nn(st, epi, a); };
     const float* fw = h->d_fw;
     float* xin = xa; float* xout = xb;
     for (int l = 0; l < NL; ++l) {

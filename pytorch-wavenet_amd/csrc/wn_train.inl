@@ -77,18 +77,6 @@ extern "C" int wn_train_export_params(wn_handle* h, float* params, void* hip_str
     return rt_hip(hipMemcpyAsync(params, h->d_fw, h->fw_floats * 4, hipMemcpyDeviceToDevice, (hipStream_t)hip_stream), "hipMemcpyAsync(params)");
 }
 
-// bn != NULL: bf16 operands (B given as [N][K] bf16, A rounded while staged), fp32 accumulation; else fp32 operands
-static void wn_launch_nn(hipStream_t st, int epi, const WnGemmArgs& a, const unsigned short* bn = nullptr) {
-    dim3 grid((unsigned)((a.M + 127) / 128), (unsigned)((a.N + 127) / 128));
-    if (bn) {
-        WnGemmArgsBf16 b;
-        b.g = a; b.bn = bn;
-        if (epi == WN_EPI_GATE) hipLaunchKernelGGL(wn_fwd_gemm_bf16<WN_EPI_GATE>, grid, dim3(256), 0, st, b);
-        else hipLaunchKernelGGL(wn_fwd_gemm_bf16<WN_EPI_PLAIN>, grid, dim3(256), 0, st, b);
-    } else if (epi == WN_EPI_GATE) hipLaunchKernelGGL(wn_fwd_gemm<WN_EPI_GATE>, grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(wn_fwd_gemm<WN_EPI_PLAIN>, grid, dim3(256), 0, st, a);
-}
-
 static void wn_launch_cvt_t(hipStream_t st, const float* in, long long in_batch_stride, unsigned short* out, int rows, int cols, int batches) {
     hipLaunchKernelGGL(wn_cvt_bf16_transposed, dim3((unsigned)((cols + 31) / 32), (unsigned)((rows + 31) / 32), (unsigned)batches), dim3(256), 0, st,
                        in, in_batch_stride, out, rows, cols);
@@ -96,9 +84,13 @@ static void wn_launch_cvt_t(hipStream_t st, const float* in, long long in_batch_
 
 static void wn_launch_tn(hipStream_t st, WnGemmTnArgs a, bool bf16 = false) {
     // Split the rows so that ~1024 workgroups exist (four are resident per CU), but never below 256 rows per
-    // split: every split ends with a 128x128 tile of atomics.
-    const int tiles = ((a.Ka + 127) / 128) * ((a.Nb + 127) / 128);
-    long long splits = 1024 / tiles > 1 ? 1024 / tiles : 1;
+    // split: every split ends with a tile of atomics.  bf16 products with Nb % 256 == 0 take the 128 x 256 tile (A streamed once per
+    // 256 columns of B).
+    const bool wide = bf16 && !a.a_idx && a.Nb % 256 == 0;
+    const int tb = wide ? 256 : 128;
+    const int tiles = ((a.Ka + 127) / 128) * ((a.Nb + tb - 1) / tb);
+    const int want = wide ? 512 : 1024;
+    long long splits = want / tiles > 1 ? want / tiles : 1;
     const long long most = (a.M + 255) / 256;
     if (splits > most) splits = most;
     if (splits < 1) splits = 1;
@@ -106,8 +98,9 @@ static void wn_launch_tn(hipStream_t st, WnGemmTnArgs a, bool bf16 = false) {
     rps = (rps + 31) / 32 * 32;
     splits = (a.M + rps - 1) / rps;
     a.rows_per_split = rps;
-    const dim3 grid((unsigned)((a.Ka + 127) / 128), (unsigned)((a.Nb + 127) / 128), (unsigned)splits);
-    if (bf16 && !a.a_idx) hipLaunchKernelGGL(wn_bwd_gemm_tn_bf16, grid, dim3(256), 0, st, a);  // bf16 matrix operands, fp32 accumulation
+    const dim3 grid((unsigned)((a.Ka + 127) / 128), (unsigned)((a.Nb + tb - 1) / tb), (unsigned)splits);
+    if (wide) hipLaunchKernelGGL(wn_bwd_gemm_tn_bf16<8>, grid, dim3(512), 0, st, a);
+    else if (bf16 && !a.a_idx) hipLaunchKernelGGL(wn_bwd_gemm_tn_bf16<4>, grid, dim3(256), 0, st, a);  // bf16 matrix operands, fp32 accumulation
     else hipLaunchKernelGGL(wn_bwd_gemm_tn, grid, dim3(256), 0, st, a);
 }
 
@@ -207,6 +200,7 @@ extern "C" int wn_train_forward(wn_handle* h, const float* params, const int32_t
         a.c2 = WnRowMap{zg + (size_t)gi * D, out_len * (long long)G * D, (long long)G * D, 0};
         a.c2_first_row = (int)(rows - out_len);
         a.gate_t = ws + t.th[l]; a.gate_g = ws + t.sg[l];
+        a.gate_packed = bf16 ? 1 : 0;  // bf16 step: tanh and sigmoid saved as one {bf16, bf16} dword per element (half the bytes, written once)
         a.M = N * rows; a.rows_per_batch = (int)rows;
         wn_launch_nn(st, WN_EPI_GATE, a, bf16 ? bt_fg + (size_t)l * 2 * D * 2 * R : nullptr);
         if (l < NL - 1) {
@@ -350,8 +344,12 @@ extern "C" int wn_train_backward(wn_handle* h, const float* params, const float*
         }
         {   // [dF | dG] of dz + this layer's share of dzg
             const long long work = M * D;
-            hipLaunchKernelGGL(wn_bwd_gate, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, dz, ws + t.th[l], ws + t.sg[l], dfg, M, D,
-                               dzg + (size_t)gi * D, cnt * D, (int)rows, (int)out_len);
+            if (t.bf16)
+                hipLaunchKernelGGL(wn_bwd_gate<true>, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, dz, ws + t.th[l], ws + t.sg[l], dfg, M, D,
+                                   dzg + (size_t)gi * D, cnt * D, (int)rows, (int)out_len);
+            else
+                hipLaunchKernelGGL(wn_bwd_gate<false>, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, dz, ws + t.th[l], ws + t.sg[l], dfg, M, D,
+                                   dzg + (size_t)gi * D, cnt * D, (int)rows, (int)out_len);
         }
         for (int tap = 0; tap < 2; ++tap) {  // dWfg^T rows tap*R.. = x_l(t - (1-tap) d)^T . dfg
             memset(&g, 0, sizeof(g));
@@ -361,32 +359,35 @@ extern "C" int wn_train_backward(wn_handle* h, const float* params, const float*
             wn_launch_tn(st, g, t.bf16);
         }
         if (pl.has_bias) wn_launch_colsum(st, WnRowMap{dfg, rows * 2 * D, 2 * D, 0}, M, (int)rows, 2 * D, grads + h->fw_off_bfg + (size_t)l * 2 * D);
-        // dx_l: rows [L - need[l], L); everything the two products below do not write must read as zero
-        rc = rt_hip(hipMemsetAsync(dxc, 0, (size_t)N * L * R * 4, st), "hipMemsetAsync(dx)");
-        if (rc) return rc;
-        memset(&a, 0, sizeof(a));   // dx_l(t) = dfg(t) . Wfg(tap 1) + dx'(t)
-        a.a0 = a.a1 = WnRowMap{dfg, rows * 2 * D, 2 * D, 0};
-        a.k_split = 2 * D; a.K = 2 * D; a.bt = ws + t.fgb1 + (size_t)l * 2 * D * R; a.N = R;
-        if (has_res) a.cin = WnRowMap{dxn, L * (long long)R, R, t0};
-        a.c = WnRowMap{dxc, L * (long long)R, R, t0};
-        a.M = M; a.rows_per_batch = (int)rows;
-        wn_launch_nn(st, WN_EPI_PLAIN, a, bw ? bw + h->fw_off_fg + (size_t)l * 2 * R * 2 * D + (size_t)R * 2 * D : nullptr);
-        memset(&a, 0, sizeof(a));   // dx_l(t - d) += dfg(t) . Wfg(tap 0)
-        a.a0 = a.a1 = WnRowMap{dfg, rows * 2 * D, 2 * D, 0};
-        a.k_split = 2 * D; a.K = 2 * D; a.bt = ws + t.fgb0 + (size_t)l * 2 * D * R; a.N = R;
-        a.cin = WnRowMap{dxc, L * (long long)R, R, t0 - d};
+        // dx_l on its rows [t0 - d, L) (= the last need[l] time steps) in ONE product over two row-shifted views of dfg:
+        //     dx_l(t) = dx'(t) [t >= t0]  +  dfg(t) . Wfg(tap 1) [t >= t0]  +  dfg(t + d) . Wfg(tap 0) [t < L - d]
+        // K = 4D: columns 0..2D-1 take dfg(t) against tap 1's rows, columns 2D.. take dfg(t + d) against tap 0's.  The views' row
+        // windows (a_skip_*) read as zero where a shift runs off dfg, so nothing is cleared first and dx_l is written exactly once
+        // (round 2: a memset of dx and two read-modify-write products per layer).
+        memset(&a, 0, sizeof(a));
+        a.a0 = WnRowMap{dfg, rows * 2 * D, 2 * D, -d};   // dfg(t):     row (t - t0) = rem - d, valid from rem = d
+        a.a1 = WnRowMap{dfg, rows * 2 * D, 2 * D, 0};    // dfg(t + d): row rem, valid up to rem = rows - 1
+        a.a_skip_lo[0] = (int)d; a.a_skip_hi[1] = (int)d;
+        a.k_split = 2 * D; a.K = 4 * D; a.bt = ws + t.fgb1 + (size_t)l * 2 * D * R; a.bt1 = ws + t.fgb0 + (size_t)l * 2 * D * R; a.N = R;
+        if (has_res) { a.cin = WnRowMap{dxn, L * (long long)R, R, t0 - d}; a.cin_skip_lo = (int)d; }
         a.c = WnRowMap{dxc, L * (long long)R, R, t0 - d};
-        a.M = M; a.rows_per_batch = (int)rows;
-        wn_launch_nn(st, WN_EPI_PLAIN, a, bw ? bw + h->fw_off_fg + (size_t)l * 2 * R * 2 * D : nullptr);
+        a.M = N * (rows + d); a.rows_per_batch = (int)(rows + d);
+        {
+            const unsigned short* w = bw ? bw + h->fw_off_fg + (size_t)l * 2 * R * 2 * D : nullptr;  // native [2R][2D]: rows 0..R-1 tap 0, R.. tap 1
+            wn_launch_nn(st, WN_EPI_PLAIN, a, w ? w + (size_t)R * 2 * D : nullptr, w, 2 * D);
+        }
         float* tmp = dxn; dxn = dxc; dxc = tmp;
     }
-    // ---- start_conv: dstart^T [C][R] = onehot(indices)^T . dx_0
-    memset(&g, 0, sizeof(g));
-    g.a = WnRowMap{nullptr, L, 1, 0}; g.a_idx = reinterpret_cast<const int32_t*>(ws + t.idx);
-    g.b = WnRowMap{dxn, L * (long long)R, R, 0};
-    g.Ka = C; g.Nb = R; g.c = grads + h->fw_off_start_t; g.ldc = R; g.M = N * L; g.rows_per_batch = (int)L;
-    wn_launch_tn(st, g, t.bf16);
-    if (pl.has_bias) wn_launch_colsum(st, WnRowMap{dxn, L * (long long)R, R, 0}, N * L, (int)L, R, grads + h->fw_off_start_b);
+    // ---- start_conv: dstart^T [C][R] = onehot(indices)^T . dx_0 over the rows dx_0 exists on (the last need[0] time steps)
+    {
+        const long long r0 = t.need[0], f0 = L - r0;
+        memset(&g, 0, sizeof(g));
+        g.a = WnRowMap{nullptr, L, 1, f0}; g.a_idx = reinterpret_cast<const int32_t*>(ws + t.idx);
+        g.b = WnRowMap{dxn, L * (long long)R, R, f0};
+        g.Ka = C; g.Nb = R; g.c = grads + h->fw_off_start_t; g.ldc = R; g.M = N * r0; g.rows_per_batch = (int)r0;
+        wn_launch_tn(st, g, t.bf16);
+        if (pl.has_bias) wn_launch_colsum(st, WnRowMap{dxn, L * (long long)R, R, f0}, N * r0, (int)r0, R, grads + h->fw_off_start_b);
+    }
     return rt_hip(hipGetLastError(), "wn_train_backward launches");
 }
 
