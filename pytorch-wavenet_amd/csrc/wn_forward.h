@@ -37,7 +37,7 @@ static __device__ __forceinline__ const float* wn_row(const WnRowMap& r, long lo
     return r.base + (long long)q * r.batch_stride + (r.t0 + (long long)rem) * r.row_stride;
 }
 
-enum { WN_EPI_PLAIN = 0, WN_EPI_GATE = 1 };
+enum { WN_EPI_PLAIN = 0, WN_EPI_GATE = 1, WN_EPI_GATE_BWD = 2 };
 
 struct WnGemmArgs {
     WnRowMap a0, a1;      // A = [a0 (k < k_split) | a1 (k >= k_split)], rows of K floats in total
@@ -112,6 +112,30 @@ static __device__ __forceinline__ void wn_gemm_epilogue(const WnGemmArgs& g, con
                         g.gate_g[m * (g.N >> 1) + zc] = sg;
                     }
                 }
+            }
+        } else if (EPI == WN_EPI_GATE_BWD) {
+            // The product is dz = dx' . Wres (N = D channels); the strip emits [dF | dG] = dz * {G (1 - T^2), T G (1 - G)} in the packed
+            // [F(32) | G(32)] column order of Wfg^T (2N columns per row of c).  gate_t / gate_g are the forward's saved gates (INPUTS
+            // here, row m, N columns; gate_packed as in the forward); c2 is the skip path's share of dz (READ here: rows >=
+            // c2_first_row of a batch entry add c2's row (index - c2_first_row)).  dz itself never reaches HBM.
+            const float* zrow = nullptr;
+            if (g.c2.base && (int)rem >= g.c2_first_row)
+                zrow = g.c2.base + (long long)q * g.c2.batch_stride + (g.c2.t0 + (long long)rem - g.c2_first_row) * g.c2.row_stride;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int ch = nw + 32 * j + col;
+                if (ch >= g.N) continue;
+                float d = acc[j][i];
+                if (zrow) d += zrow[ch];
+                float t, s2;
+                if (g.gate_packed) {
+                    const unsigned ts = reinterpret_cast<const unsigned*>(g.gate_t)[m * g.N + ch];
+                    t = __uint_as_float(ts << 16); s2 = __uint_as_float(ts & 0xffff0000u);
+                } else {
+                    t = g.gate_t[m * g.N + ch]; s2 = g.gate_g[m * g.N + ch];
+                }
+                crow[2 * nw + 64 * j + col] = d * s2 * (1.f - t * t);
+                crow[2 * nw + 64 * j + col + 32] = d * t * s2 * (1.f - s2);
             }
         } else {
             const float* mrow = g.mask ? g.mask + (crow - g.c.base) : nullptr;  // the mask shares the output's row layout
@@ -376,6 +400,9 @@ struct WnGemmTnArgs {
     int rows_per_batch;
     int relu_a;            // A := max(A, 0)
     long long rows_per_split;
+    WnRowMap a1;           // ka_split > 0: columns ka >= ka_split of A are columns (ka - ka_split) of this second row view (ka_split % 128 == 0):
+    int ka_split;          //   the two taps of the filter/gate weight gradient in one launch -- their workgroups read the same rows of B
+    int pad;               //   at the same time, so the second read is served by the caches instead of HBM
 };
 
 __global__ __launch_bounds__(256, WN_GEMM_MINB) void wn_bwd_gemm_tn(WnGemmTnArgs g) {
@@ -394,6 +421,9 @@ __global__ __launch_bounds__(256, WN_GEMM_MINB) void wn_bwd_gemm_tn(WnGemmTnArgs
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
     const int lrow = tid / LT, lcol = (tid % LT) * (KC / 2);  // loader: row of the chunk, KC/2 floats of its 128
+    const bool second = g.ka_split > 0 && ka0 >= g.ka_split;
+    const WnRowMap& amap = second ? g.a1 : g.a;
+    const int kap0 = second ? ka0 - g.ka_split : ka0;          // first column of this tile inside its view
     float4 va[NQ], vb[NQ];
     auto fetch = [&](long long mc) {
         const long long m = mc + lrow;
@@ -410,7 +440,7 @@ __global__ __launch_bounds__(256, WN_GEMM_MINB) void wn_bwd_gemm_tn(WnGemmTnArgs
                 va[q] = make_float4(cls == k ? 1.f : 0.f, cls == k + 1 ? 1.f : 0.f, cls == k + 2 ? 1.f : 0.f, cls == k + 3 ? 1.f : 0.f);
             }
         } else {
-            const float* ap = ok ? wn_row(g.a, m, g.rows_per_batch) + ka0 + lcol : nullptr;
+            const float* ap = ok ? wn_row(amap, m, g.rows_per_batch) + kap0 + lcol : nullptr;
 #pragma unroll
             for (int q = 0; q < NQ; ++q) va[q] = (ok && ka0 + lcol + q * 4 < g.Ka) ? *reinterpret_cast<const float4*>(ap + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
@@ -493,22 +523,24 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? WN_TN_BF16_MINB : 4) void 
     const int role = tid >> 7;                    // 0: A;  1 ..: B columns 128 (role - 1) ..
     const bool is_b = role >= 1, loads = role <= TB / 128;
     const int u = tid & 127, mg = u >> 5, cg = u & 31;
-    const WnRowMap& rm = is_b ? g.b : g.a;
+    const bool second = g.ka_split > 0 && ka0 >= g.ka_split;
+    const WnRowMap& rm = is_b ? g.b : (second ? g.a1 : g.a);
     const int lcol = is_b ? 128 * (role - 1) + 4 * cg : 4 * cg;   // column inside the tile
     const int col0 = (is_b ? nb0 : ka0) + lcol, ncols = is_b ? g.Nb : g.Ka;
+    const int pcol0 = (!is_b && second) ? col0 - g.ka_split : col0;   // column inside the row view
     const bool col_ok = loads && col0 < ncols;
     const bool relu = !is_b && g.relu_a;
     float4 v[8];
     auto fetch = [&](long long mc) {
         long long m = mc + mg * 8;
         unsigned q = (unsigned)m / (unsigned)g.rows_per_batch, rem = (unsigned)m - q * (unsigned)g.rows_per_batch;
-        const float* ptr = rm.base + (long long)q * rm.batch_stride + (rm.t0 + (long long)rem) * rm.row_stride + col0;
+        const float* ptr = rm.base + (long long)q * rm.batch_stride + (rm.t0 + (long long)rem) * rm.row_stride + pcol0;
 #pragma unroll
         for (int rr = 0; rr < 8; ++rr) {
             v[rr] = (col_ok && m + rr < m_end) ? *reinterpret_cast<const float4*>(ptr) : make_float4(0.f, 0.f, 0.f, 0.f);
             if (++rem == (unsigned)g.rows_per_batch) {  // next row is in the next batch entry
                 rem = 0; ++q;
-                ptr = rm.base + (long long)q * rm.batch_stride + rm.t0 * rm.row_stride + col0;
+                ptr = rm.base + (long long)q * rm.batch_stride + rm.t0 * rm.row_stride + pcol0;
             } else {
                 ptr += rm.row_stride;
             }

@@ -44,19 +44,21 @@ static void wn_launch_nn(hipStream_t st, int epi, const WnGemmArgs& a, const uns
     if (bn) {
         WnGemmArgsBf16 b;
         b.g = a; b.bn = bn; b.bn1 = bn1; b.ldb = ldb;
-        if (a.N % 256 == 0) {
+        if (a.N % 256 == 0 && epi != WN_EPI_GATE_BWD) {
             const dim3 grid((unsigned)((a.M + 127) / 128), (unsigned)(a.N / 256));
             if (epi == WN_EPI_GATE) hipLaunchKernelGGL((wn_fwd_gemm_bf16<WN_EPI_GATE, 8>), grid, dim3(512), 0, st, b);
             else hipLaunchKernelGGL((wn_fwd_gemm_bf16<WN_EPI_PLAIN, 8>), grid, dim3(512), 0, st, b);
         } else {
             const dim3 grid((unsigned)((a.M + 127) / 128), (unsigned)((a.N + 127) / 128));
             if (epi == WN_EPI_GATE) hipLaunchKernelGGL((wn_fwd_gemm_bf16<WN_EPI_GATE, 4>), grid, dim3(256), 0, st, b);
+            else if (epi == WN_EPI_GATE_BWD) hipLaunchKernelGGL((wn_fwd_gemm_bf16<WN_EPI_GATE_BWD, 4>), grid, dim3(256), 0, st, b);
             else hipLaunchKernelGGL((wn_fwd_gemm_bf16<WN_EPI_PLAIN, 4>), grid, dim3(256), 0, st, b);
         }
         return;
     }
     const dim3 grid((unsigned)((a.M + 127) / 128), (unsigned)((a.N + 127) / 128));
     if (epi == WN_EPI_GATE) hipLaunchKernelGGL(wn_fwd_gemm<WN_EPI_GATE>, grid, dim3(256), 0, st, a);
+    else if (epi == WN_EPI_GATE_BWD) hipLaunchKernelGGL(wn_fwd_gemm<WN_EPI_GATE_BWD>, grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL(wn_fwd_gemm<WN_EPI_PLAIN>, grid, dim3(256), 0, st, a);
 }
 

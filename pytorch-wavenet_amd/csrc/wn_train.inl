@@ -82,6 +82,9 @@ static void wn_launch_cvt_t(hipStream_t st, const float* in, long long in_batch_
                        in, in_batch_stride, out, rows, cols);
 }
 
+#ifndef WN_TN_MERGE_TAPS
+#define WN_TN_MERGE_TAPS 1
+#endif
 static void wn_launch_tn(hipStream_t st, WnGemmTnArgs a, bool bf16 = false) {
     // Split the rows so that ~1024 workgroups exist (four are resident per CU), but never below 256 rows per
     // split: every split ends with a tile of atomics.  bf16 products with Nb % 256 == 0 take the 128 x 256 tile (A streamed once per
@@ -307,25 +310,9 @@ extern "C" int wn_train_backward(wn_handle* h, const float* params, const float*
         const float* xin = ws + t.x[l];
         const float* z = ws + t.z[l];
         const bool has_res = l < NL - 1;
-        if (has_res) {          // dz = dx' . Wres ;  dWres^T [D][R] = z^T . dx'
-            memset(&a, 0, sizeof(a));
-            a.a0 = a.a1 = WnRowMap{dxn, L * (long long)R, R, t0};
-            a.k_split = R; a.K = R; a.bt = ws + t.res_o + (size_t)l * R * D; a.N = D;
-            a.c = WnRowMap{dz, rows * D, D, 0};
-            a.M = M; a.rows_per_batch = (int)rows;
-            wn_launch_nn(st, WN_EPI_PLAIN, a, bw ? bw + h->fw_off_res + (size_t)l * D * R : nullptr);
-            memset(&g, 0, sizeof(g));
-            g.a = WnRowMap{z, rows * D, D, 0}; g.b = WnRowMap{dxn, L * (long long)R, R, t0};
-            g.Ka = D; g.Nb = R; g.c = grads + h->fw_off_res + (size_t)l * D * R; g.ldc = R; g.M = M; g.rows_per_batch = (int)rows;
-            wn_launch_tn(st, g, t.bf16);
-            if (pl.has_bias) wn_launch_colsum(st, WnRowMap{dxn, L * (long long)R, R, t0}, M, (int)rows, R, grads + h->fw_off_bres + (size_t)l * R);
-        } else {
-            rc = rt_hip(hipMemsetAsync(dz, 0, (size_t)M * D * 4, st), "hipMemsetAsync(dz)");
-            if (rc) return rc;
-        }
         // The skip path, one block of G layers at a time (as in the forward): entering a block from above,
         //   dzg [Mo][cnt*D] = dskip . [Wskip of the block's layers]      dWskip^T of the block [cnt*D][S] = zg^T . dskip
-        // so dskip (0.7 GB at config 5) is read twice per block instead of twice per layer; the gate kernel below adds
+        // so dskip (0.7 GB at config 5) is read twice per block instead of twice per layer; the gate step below adds
         // this layer's column block of dzg to dz on the skip rows.
         const int gi = l % t.G, first = l - gi, cnt = NL - first < t.G ? NL - first : t.G;
         float* dzg = ws + t.dzg;
@@ -342,7 +329,26 @@ extern "C" int wn_train_backward(wn_handle* h, const float* params, const float*
             g.Ka = cnt * D; g.Nb = S; g.c = grads + h->fw_off_skip + (size_t)first * D * S; g.ldc = S; g.M = Mo; g.rows_per_batch = (int)out_len;
             wn_launch_tn(st, g, t.bf16);
         }
-        {   // [dF | dG] of dz + this layer's share of dzg
+        if (has_res) {
+            // [dF | dG] straight from the product dz = dx' . Wres (+ this layer's share of dzg on the skip rows): the gate derivative is
+            // the product's epilogue (WN_EPI_GATE_BWD), dz is never written (round 2: dz to HBM, then a streaming gate kernel).
+            memset(&a, 0, sizeof(a));
+            a.a0 = a.a1 = WnRowMap{dxn, L * (long long)R, R, t0};
+            a.k_split = R; a.K = R; a.bt = ws + t.res_o + (size_t)l * R * D; a.N = D;
+            a.c = WnRowMap{dfg, rows * 2 * D, 2 * D, 0};
+            a.c2 = WnRowMap{dzg + (size_t)gi * D, out_len * (long long)cnt * D, (long long)cnt * D, 0};
+            a.c2_first_row = (int)(rows - out_len);
+            a.gate_t = ws + t.th[l]; a.gate_g = ws + t.sg[l]; a.gate_packed = t.bf16 ? 1 : 0;
+            a.M = M; a.rows_per_batch = (int)rows;
+            wn_launch_nn(st, WN_EPI_GATE_BWD, a, bw ? bw + h->fw_off_res + (size_t)l * D * R : nullptr);
+            memset(&g, 0, sizeof(g));   // dWres^T [D][R] = z^T . dx'
+            g.a = WnRowMap{z, rows * D, D, 0}; g.b = WnRowMap{dxn, L * (long long)R, R, t0};
+            g.Ka = D; g.Nb = R; g.c = grads + h->fw_off_res + (size_t)l * D * R; g.ldc = R; g.M = M; g.rows_per_batch = (int)rows;
+            wn_launch_tn(st, g, t.bf16);
+            if (pl.has_bias) wn_launch_colsum(st, WnRowMap{dxn, L * (long long)R, R, t0}, M, (int)rows, R, grads + h->fw_off_bres + (size_t)l * R);
+        } else {   // the last layer has no residual output: dz is its share of dzg alone
+            rc = rt_hip(hipMemsetAsync(dz, 0, (size_t)M * D * 4, st), "hipMemsetAsync(dz)");
+            if (rc) return rc;
             const long long work = M * D;
             if (t.bf16)
                 hipLaunchKernelGGL(wn_bwd_gate<true>, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, dz, ws + t.th[l], ws + t.sg[l], dfg, M, D,
@@ -351,12 +357,22 @@ extern "C" int wn_train_backward(wn_handle* h, const float* params, const float*
                 hipLaunchKernelGGL(wn_bwd_gate<false>, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, dz, ws + t.th[l], ws + t.sg[l], dfg, M, D,
                                    dzg + (size_t)gi * D, cnt * D, (int)rows, (int)out_len);
         }
-        for (int tap = 0; tap < 2; ++tap) {  // dWfg^T rows tap*R.. = x_l(t - (1-tap) d)^T . dfg
-            memset(&g, 0, sizeof(g));
-            g.a = WnRowMap{xin, L * (long long)R, R, tap ? t0 : t0 - d}; g.b = WnRowMap{dfg, rows * 2 * D, 2 * D, 0};
-            g.Ka = R; g.Nb = 2 * D; g.c = grads + h->fw_off_fg + (size_t)l * 2 * R * 2 * D + (size_t)tap * R * 2 * D; g.ldc = 2 * D;
-            g.M = M; g.rows_per_batch = (int)rows;
+        // dWfg^T [2R][2D]: rows 0..R-1 = x_l(t - d)^T . dfg (tap 0), rows R.. = x_l(t)^T . dfg (tap 1) -- one launch, the taps are two
+        // row views of A (ka_split): the workgroups of the two taps run side by side and read the same rows of dfg.
+        memset(&g, 0, sizeof(g));
+        g.a = WnRowMap{xin, L * (long long)R, R, t0 - d}; g.a1 = WnRowMap{xin, L * (long long)R, R, t0}; g.ka_split = R;
+        g.b = WnRowMap{dfg, rows * 2 * D, 2 * D, 0};
+        g.Ka = 2 * R; g.Nb = 2 * D; g.c = grads + h->fw_off_fg + (size_t)l * 2 * R * 2 * D; g.ldc = 2 * D;
+        g.M = M; g.rows_per_batch = (int)rows;
+#if WN_TN_MERGE_TAPS
+        if (R % 128 == 0) {
             wn_launch_tn(st, g, t.bf16);
+        } else
+#endif
+        for (int tap = 0; tap < 2; ++tap) {
+            WnGemmTnArgs g1 = g;
+            g1.a = tap ? g.a1 : g.a; g1.ka_split = 0; g1.Ka = R; g1.c = g.c + (size_t)tap * R * 2 * D;
+            wn_launch_tn(st, g1, t.bf16);
         }
         if (pl.has_bias) wn_launch_colsum(st, WnRowMap{dfg, rows * 2 * D, 2 * D, 0}, M, (int)rows, 2 * D, grads + h->fw_off_bfg + (size_t)l * 2 * D);
         // dx_l on its rows [t0 - d, L) (= the last need[l] time steps) in ONE product over two row-shifted views of dfg:

@@ -14,6 +14,10 @@ import torch  # noqa: E402
 
 import wavenet_model  # noqa: E402
 
+if os.environ.get("WN_DEV_LIB"):  # A/B runs: another build of the library
+    from mi355_wavenet import _abi
+    _abi.PRODUCT_LIB = os.path.abspath(os.environ["WN_DEV_LIB"])
+
 
 def main():
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
