@@ -39,6 +39,19 @@ static __device__ __forceinline__ const float* wn_row(const WnRowMap& r, long lo
 
 enum { WN_EPI_PLAIN = 0, WN_EPI_GATE = 1, WN_EPI_GATE_BWD = 2 };
 
+// Workgroup -> tile, XCD-aware.  The products here are streams over their row operand, and every tile that shares rows with another one
+// (the column tiles of one row tile; the weight-gradient tiles of one row split) re-reads them.  Workgroups are dispatched in id order,
+// round-robin over the 8 XCDs (id % 8), each with its own L2: the `nshare` tiles of a sharing group are given ids 8 apart and
+// consecutive in time -- same XCD, same moment -- so the group's rows come from HBM once and from that L2 afterwards.
+// Grids are 1-D: 8 * nshare * ceil(ngroups / 8) workgroups; returns false for the padding (group >= ngroups).
+static __device__ __forceinline__ bool wn_tile_of(unsigned id, unsigned nshare, unsigned ngroups, unsigned& group, unsigned& member) {
+    const unsigned xcd = id & 7u, slot = id >> 3;
+    member = slot % nshare;
+    group = (slot / nshare) * 8u + xcd;
+    return group < ngroups;
+}
+
+
 struct WnGemmArgs {
     WnRowMap a0, a1;      // A = [a0 (k < k_split) | a1 (k >= k_split)], rows of K floats in total
     int k_split, K;       // K % 32 == 0, k_split % 32 == 0
@@ -171,8 +184,9 @@ __global__ __launch_bounds__(256, WN_GEMM_MINB) void wn_fwd_gemm(WnGemmArgs g) {
     __shared__ float a_t[2][KC * AP];                         // [k][row]
     __shared__ float b_s[2][KC * TN];                         // [k][col]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const long long m0 = (long long)blockIdx.x * TM;
-    const int n0 = blockIdx.y * TN;
+    const unsigned mtiles = (unsigned)((g.M + TM - 1) / TM), tm_i = blockIdx.x % mtiles, tn_i = blockIdx.x / mtiles;  // row tiles fastest
+    const long long m0 = (long long)tm_i * TM;
+    const int n0 = (int)tn_i * TN;
     wn_f16v acc[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -261,8 +275,9 @@ struct WnGemmArgsBf16 {
 #define WN_GEMM_BF16_KC 32    // config-5 forward: 64 (73.7 KB LDS, 2 workgroups per CU) 52.7 ms; 32 (41 KB, 3 per CU, 152 VGPRs) 40.8 ms
 #endif
 #ifndef WN_GEMM_BF16_MINB
-#define WN_GEMM_BF16_MINB 3
+#define WN_GEMM_BF16_MINB 4   // 4-wave form: 4 workgroups per CU (exactly the CU's 160 KB of LDS, 128 VGPRs): 3 -> 4 took the residual / dx products from 346 to 314 us
 #endif
+
 // WAVES = 4: 128 x 128 tile (wave w: rows 32w.., all 128 columns).  WAVES = 8: 128 x 256 tile (wave w: rows 32 (w & 3).., column half
 // w >> 2) for products with N >= 256 -- these GEMMs are streams over A (K is 128-512, M is 350 k-500 k rows), and a 128-column
 // tile makes every further column block re-read A from HBM (the gate product: 4 x 262 MB instead of 2 x); the wide tile stages A
@@ -278,8 +293,9 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? WN_GEMM_BF16_MINB : 4) voi
     __shared__ __attribute__((aligned(16))) unsigned short a_s[2][TM * LD];
     __shared__ __attribute__((aligned(16))) unsigned short b_s[2][TN * LD];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wr = wv & 3, wc = wv >> 2;
-    const long long m0 = (long long)blockIdx.x * TM;
-    const int n0 = blockIdx.y * TN;
+    const unsigned mtiles = (unsigned)((g.M + TM - 1) / TM), tm_i = blockIdx.x % mtiles, tn_i = blockIdx.x / mtiles;  // row tiles fastest
+    const long long m0 = (long long)tm_i * TM;
+    const int n0 = (int)tn_i * TN;
     wn_f16v acc[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -299,19 +315,24 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? WN_GEMM_BF16_MINB : 4) voi
     const unsigned short* bp0 = ga.bn + (size_t)(n0 + bcol) * ldb + bhalf * HB;
     const unsigned short* bp1 = ga.bn1 ? ga.bn1 + (size_t)(n0 + bcol) * ldb + bhalf * HB : bp0 + g.k_split;
 
-    float4 va[HK / 4];
+    // Staging registers of the chunk in flight.  (Two A chunks in flight per workgroup -- a second register set, chunk kc + 2 fetched
+    // while kc + 1 waits to be staged -- measured level in both forms: profiles/r03_train_step_experiments.txt.)
+    float4 va0[HK / 4];
     uint4 vb[HB / 8];
-    auto fetch = [&](int kc) {
+    auto fetch_a = [&](int kc, float4 (&va)[HK / 4]) {
         const int k0 = kc * KC;
         const bool first = k0 < g.k_split, ok = first ? ok0 : ok1;
         const float* src = first ? a0p + k0 : a1p + (k0 - g.k_split);
 #pragma unroll
         for (int q = 0; q < HK / 4; ++q) va[q] = ok ? *reinterpret_cast<const float4*>(src + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-        const uint4* bsrc = reinterpret_cast<const uint4*>(first ? bp0 + k0 : bp1 + (k0 - g.k_split));
+    };
+    auto fetch_b = [&](int kc) {
+        const int k0 = kc * KC;
+        const uint4* bsrc = reinterpret_cast<const uint4*>(k0 < g.k_split ? bp0 + k0 : bp1 + (k0 - g.k_split));
 #pragma unroll
         for (int q = 0; q < HB / 8; ++q) vb[q] = bcol_ok ? bsrc[q] : make_uint4(0u, 0u, 0u, 0u);
     };
-    auto stash = [&](int buf) {
+    auto stash = [&](int buf, const float4 (&va)[HK / 4]) {
         uint4* ad = reinterpret_cast<uint4*>(a_s[buf] + lrow * LD + lpart * HK);
 #pragma unroll
         for (int q = 0; q < HK / 8; ++q) {
@@ -326,14 +347,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? WN_GEMM_BF16_MINB : 4) voi
 #pragma unroll
         for (int q = 0; q < HB / 8; ++q) bd[q] = vb[q];
     };
-
-    const int nchunks = g.K / KC;
-    fetch(0);
-    stash(0);
-    __syncthreads();
-    for (int kc = 0; kc < nchunks; ++kc) {
-        const int buf = kc & 1;
-        if (kc + 1 < nchunks) fetch(kc + 1);
+    auto multiply = [&](int buf) {
         const unsigned short* ar = a_s[buf] + (32 * wr + (lane & 31)) * LD + 8 * (lane >> 5);
         const unsigned short* br = b_s[buf] + (128 * wc + (lane & 31)) * LD + 8 * (lane >> 5);
 #pragma unroll
@@ -345,8 +359,21 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? WN_GEMM_BF16_MINB : 4) voi
                 acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[j], 0, 0, 0);
             }
         }
-        if (kc + 1 < nchunks) stash(buf ^ 1);
+    };
+
+    const int nchunks = g.K / KC;
+    {
+        fetch_a(0, va0);
+        fetch_b(0);
+        stash(0, va0);
         __syncthreads();
+        for (int kc = 0; kc < nchunks; ++kc) {
+            const int buf = kc & 1;
+            if (kc + 1 < nchunks) { fetch_a(kc + 1, va0); fetch_b(kc + 1); }
+            multiply(buf);
+            if (kc + 1 < nchunks) stash(buf ^ 1, va0);
+            __syncthreads();
+        }
     }
     wn_gemm_epilogue<EPI>(g, acc, m0 + 32 * wr, n0 + 128 * wc, lane);
 }
@@ -400,6 +427,7 @@ struct WnGemmTnArgs {
     int rows_per_batch;
     int relu_a;            // A := max(A, 0)
     long long rows_per_split;
+    int tiles_ka, n_splits; // grid: 8 * (tiles_ka * tiles_nb) * ceil(n_splits / 8) workgroups (wn_tile_of: the tiles of a row split share an XCD)
     WnRowMap a1;           // ka_split > 0: columns ka >= ka_split of A are columns (ka - ka_split) of this second row view (ka_split % 128 == 0):
     int ka_split;          //   the two taps of the filter/gate weight gradient in one launch -- their workgroups read the same rows of B
     int pad;               //   at the same time, so the second read is served by the caches instead of HBM
@@ -410,8 +438,10 @@ __global__ __launch_bounds__(256, WN_GEMM_MINB) void wn_bwd_gemm_tn(WnGemmTnArgs
     __shared__ float a_s[2][KC * T];  // [m][ka]
     __shared__ float b_s[2][KC * T];  // [m][nb]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int ka0 = blockIdx.x * T, nb0 = blockIdx.y * T;
-    const long long m_begin = (long long)blockIdx.z * g.rows_per_split;
+    unsigned split, tile;
+    if (!wn_tile_of(blockIdx.x, (unsigned)(g.tiles_ka * ((g.Nb + T - 1) / T)), (unsigned)g.n_splits, split, tile)) return;
+    const int ka0 = (int)(tile % (unsigned)g.tiles_ka) * T, nb0 = (int)(tile / (unsigned)g.tiles_ka) * T;
+    const long long m_begin = (long long)split * g.rows_per_split;
     long long m_end = m_begin + g.rows_per_split;
     if (m_end > g.M) m_end = g.M;
     if (m_begin >= m_end) return;
@@ -508,8 +538,10 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? WN_TN_BF16_MINB : 4) void 
     __shared__ __attribute__((aligned(16))) unsigned short a_s[2][T * LD];
     __shared__ __attribute__((aligned(16))) unsigned short b_s[2][TB * LD];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wr = wv & 3, wc = wv >> 2;
-    const int ka0 = blockIdx.x * T, nb0 = blockIdx.y * TB;
-    const long long m_begin = (long long)blockIdx.z * g.rows_per_split;
+    unsigned split, tile;
+    if (!wn_tile_of(blockIdx.x, (unsigned)(g.tiles_ka * ((g.Nb + TB - 1) / TB)), (unsigned)g.n_splits, split, tile)) return;
+    const int ka0 = (int)(tile % (unsigned)g.tiles_ka) * T, nb0 = (int)(tile / (unsigned)g.tiles_ka) * TB;
+    const long long m_begin = (long long)split * g.rows_per_split;
     long long m_end = m_begin + g.rows_per_split;
     if (m_end > g.M) m_end = g.M;
     if (m_begin >= m_end) return;

@@ -41,22 +41,22 @@ static int wn_fail(int code, const char* fmt, ...) {
 // One "NN" product C = A . B^T of wn_forward.h.  bn != NULL: bf16 operands (B given as [N][K] bf16 -- or as two [N][ldb] halves
 // bn / bn1 --, A rounded while staged), fp32 accumulation; else fp32 operands.  Products with N % 256 == 0 take the 128 x 256 tile.
 static void wn_launch_nn(hipStream_t st, int epi, const WnGemmArgs& a, const unsigned short* bn = nullptr, const unsigned short* bn1 = nullptr, int ldb = 0) {
+    const bool wide = bn && a.N % 256 == 0 && epi != WN_EPI_GATE_BWD;
+    const unsigned mt = (unsigned)((a.M + 127) / 128), nt = (unsigned)(wide ? a.N / 256 : (a.N + 127) / 128);
+    const dim3 grid(mt * nt);   // 1-D (M / 128 can exceed a grid's y limit): row tiles fastest, then column tiles
     if (bn) {
         WnGemmArgsBf16 b;
         b.g = a; b.bn = bn; b.bn1 = bn1; b.ldb = ldb;
-        if (a.N % 256 == 0 && epi != WN_EPI_GATE_BWD) {
-            const dim3 grid((unsigned)((a.M + 127) / 128), (unsigned)(a.N / 256));
+        if (wide) {
             if (epi == WN_EPI_GATE) hipLaunchKernelGGL((wn_fwd_gemm_bf16<WN_EPI_GATE, 8>), grid, dim3(512), 0, st, b);
             else hipLaunchKernelGGL((wn_fwd_gemm_bf16<WN_EPI_PLAIN, 8>), grid, dim3(512), 0, st, b);
         } else {
-            const dim3 grid((unsigned)((a.M + 127) / 128), (unsigned)((a.N + 127) / 128));
             if (epi == WN_EPI_GATE) hipLaunchKernelGGL((wn_fwd_gemm_bf16<WN_EPI_GATE, 4>), grid, dim3(256), 0, st, b);
             else if (epi == WN_EPI_GATE_BWD) hipLaunchKernelGGL((wn_fwd_gemm_bf16<WN_EPI_GATE_BWD, 4>), grid, dim3(256), 0, st, b);
             else hipLaunchKernelGGL((wn_fwd_gemm_bf16<WN_EPI_PLAIN, 4>), grid, dim3(256), 0, st, b);
         }
         return;
     }
-    const dim3 grid((unsigned)((a.M + 127) / 128), (unsigned)((a.N + 127) / 128));
     if (epi == WN_EPI_GATE) hipLaunchKernelGGL(wn_fwd_gemm<WN_EPI_GATE>, grid, dim3(256), 0, st, a);
     else if (epi == WN_EPI_GATE_BWD) hipLaunchKernelGGL(wn_fwd_gemm<WN_EPI_GATE_BWD>, grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL(wn_fwd_gemm<WN_EPI_PLAIN>, grid, dim3(256), 0, st, a);

@@ -96,12 +96,14 @@ static void wn_launch_tn(hipStream_t st, WnGemmTnArgs a, bool bf16 = false) {
     long long splits = want / tiles > 1 ? want / tiles : 1;
     const long long most = (a.M + 255) / 256;
     if (splits > most) splits = most;
+    if (splits >= 8) splits -= splits % 8;   // the tiles of a split share an XCD (wn_tile_of): whole rounds of 8 keep the XCDs level
     if (splits < 1) splits = 1;
     long long rps = (a.M + splits - 1) / splits;
     rps = (rps + 31) / 32 * 32;
     splits = (a.M + rps - 1) / rps;
     a.rows_per_split = rps;
-    const dim3 grid((unsigned)((a.Ka + 127) / 128), (unsigned)((a.Nb + tb - 1) / tb), (unsigned)splits);
+    a.tiles_ka = (a.Ka + 127) / 128; a.n_splits = (int)splits;
+    const dim3 grid(8u * (unsigned)tiles * (unsigned)((splits + 7) / 8));   // wn_tile_of: the tiles of a row split share an XCD
     if (wide) hipLaunchKernelGGL(wn_bwd_gemm_tn_bf16<8>, grid, dim3(512), 0, st, a);
     else if (bf16 && !a.a_idx) hipLaunchKernelGGL(wn_bwd_gemm_tn_bf16<4>, grid, dim3(256), 0, st, a);  // bf16 matrix operands, fp32 accumulation
     else hipLaunchKernelGGL(wn_bwd_gemm_tn, grid, dim3(256), 0, st, a);
