@@ -74,6 +74,10 @@ struct WnGemmArgs {
     // row-shifted views of a matrix whose shifts run off its ends (the backward's dx_l = dx' + dfg(t).W1 + dfg(t+d).W0).
     int a_skip_lo[2], a_skip_hi[2], cin_skip_lo;
     const float* bt1;     // optional: rows k >= k_split of B^T come from here (row k - k_split), so the two halves need not be adjacent
+    // bf16 STORAGE (the bf16 training step's [dF|dG]; bf16 kernels only).  The row maps of a bf16 matrix point at unsigned short and
+    // count their strides in bf16 elements.
+    int a_bf16;           // A (both views) is stored as bf16: staged into LDS as it is          (wn_fwd_gemm_bf16<*, *, true>)
+    int c_bf16;           // WN_EPI_GATE_BWD: c receives bf16 (round to nearest even)
 };
 static __device__ __forceinline__ const float* wn_row_at(const WnRowMap& r, unsigned q, unsigned rem) {
     return r.base + (long long)q * r.batch_stride + (r.t0 + (long long)rem) * r.row_stride;
@@ -147,8 +151,16 @@ static __device__ __forceinline__ void wn_gemm_epilogue(const WnGemmArgs& g, con
                 } else {
                     t = g.gate_t[m * g.N + ch]; s2 = g.gate_g[m * g.N + ch];
                 }
-                crow[2 * nw + 64 * j + col] = d * s2 * (1.f - t * t);
-                crow[2 * nw + 64 * j + col + 32] = d * t * s2 * (1.f - s2);
+                const float df = d * s2 * (1.f - t * t), dg = d * t * s2 * (1.f - s2);
+                if (g.c_bf16) {
+                    unsigned short* c16 = const_cast<unsigned short*>(reinterpret_cast<const unsigned short*>(g.c.base)) +
+                                          (long long)q * g.c.batch_stride + (g.c.t0 + (long long)rem) * g.c.row_stride;
+                    c16[2 * nw + 64 * j + col] = (unsigned short)wn_pack_bf16(df, 0.f);
+                    c16[2 * nw + 64 * j + col + 32] = (unsigned short)wn_pack_bf16(dg, 0.f);
+                } else {
+                    crow[2 * nw + 64 * j + col] = df;
+                    crow[2 * nw + 64 * j + col + 32] = dg;
+                }
             }
         } else {
             const float* mrow = g.mask ? g.mask + (crow - g.c.base) : nullptr;  // the mask shares the output's row layout
@@ -282,7 +294,8 @@ struct WnGemmArgsBf16 {
 // w >> 2) for products with N >= 256 -- these GEMMs are streams over A (K is 128-512, M is 350 k-500 k rows), and a 128-column
 // tile makes every further column block re-read A from HBM (the gate product: 4 x 262 MB instead of 2 x); the wide tile stages A
 // once for all 256 columns.
-template <int EPI, int WAVES>
+// A16: A is stored as bf16 (g.a_bf16): its pieces go to LDS as they are.
+template <int EPI, int WAVES, bool A16 = false>
 __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? WN_GEMM_BF16_MINB : 4) void wn_fwd_gemm_bf16(WnGemmArgsBf16 ga) {
     const WnGemmArgs& g = ga.g;
     constexpr int NT = 64 * WAVES, TM = 128, TN = 32 * WAVES, KC = WN_GEMM_BF16_KC, LD = KC + 8;  // LD: padded row length (bf16): 80-byte rows, conflict-free b128 reads
@@ -307,8 +320,11 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? WN_GEMM_BF16_MINB : 4) voi
     const unsigned aq = arow_ok ? (unsigned)am / (unsigned)g.rows_per_batch : 0u, arem = arow_ok ? (unsigned)am - aq * (unsigned)g.rows_per_batch : 0u;
     const bool ok0 = arow_ok && (int)arem >= g.a_skip_lo[0] && (int)arem < g.rows_per_batch - g.a_skip_hi[0];
     const bool ok1 = arow_ok && (int)arem >= g.a_skip_lo[1] && (int)arem < g.rows_per_batch - g.a_skip_hi[1];
-    const float* a0p = wn_row_at(g.a0, aq, arem) + lpart * HK;
-    const float* a1p = wn_row_at(g.a1, aq, arem) + lpart * HK;
+    // (A16: the same arithmetic in bf16 elements -- half the bytes per element)
+    const float* a0p = A16 ? reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(g.a0.base) + (long long)aq * g.a0.batch_stride + (g.a0.t0 + (long long)arem) * g.a0.row_stride + lpart * HK)
+                           : wn_row_at(g.a0, aq, arem) + lpart * HK;
+    const float* a1p = A16 ? reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(g.a1.base) + (long long)aq * g.a1.batch_stride + (g.a1.t0 + (long long)arem) * g.a1.row_stride + lpart * HK)
+                           : wn_row_at(g.a1, aq, arem) + lpart * HK;
     const int bcol = tid >> 1, bhalf = tid & 1;
     const bool bcol_ok = n0 + bcol < g.N;
     const int ldb = ga.ldb ? ga.ldb : g.K;
@@ -317,14 +333,20 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? WN_GEMM_BF16_MINB : 4) voi
 
     // Staging registers of the chunk in flight.  (Two A chunks in flight per workgroup -- a second register set, chunk kc + 2 fetched
     // while kc + 1 waits to be staged -- measured level in both forms: profiles/r03_train_step_experiments.txt.)
-    float4 va0[HK / 4];
+    float4 va0[HK / 4];   // A16: only the first HK / 8 hold data (HK bf16)
     uint4 vb[HB / 8];
     auto fetch_a = [&](int kc, float4 (&va)[HK / 4]) {
         const int k0 = kc * KC;
         const bool first = k0 < g.k_split, ok = first ? ok0 : ok1;
-        const float* src = first ? a0p + k0 : a1p + (k0 - g.k_split);
+        if constexpr (A16) {
+            const unsigned short* src = reinterpret_cast<const unsigned short*>(first ? a0p : a1p) + (first ? k0 : k0 - g.k_split);
 #pragma unroll
-        for (int q = 0; q < HK / 4; ++q) va[q] = ok ? *reinterpret_cast<const float4*>(src + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int q = 0; q < HK / 8; ++q) va[q] = ok ? *reinterpret_cast<const float4*>(src + q * 8) : make_float4(0.f, 0.f, 0.f, 0.f);
+        } else {
+            const float* src = first ? a0p + k0 : a1p + (k0 - g.k_split);
+#pragma unroll
+            for (int q = 0; q < HK / 4; ++q) va[q] = ok ? *reinterpret_cast<const float4*>(src + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
     };
     auto fetch_b = [&](int kc) {
         const int k0 = kc * KC;
@@ -334,6 +356,10 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? WN_GEMM_BF16_MINB : 4) voi
     };
     auto stash = [&](int buf, const float4 (&va)[HK / 4]) {
         uint4* ad = reinterpret_cast<uint4*>(a_s[buf] + lrow * LD + lpart * HK);
+        if constexpr (A16) {
+#pragma unroll
+            for (int q = 0; q < HK / 8; ++q) reinterpret_cast<float4*>(ad)[q] = va[q];
+        } else
 #pragma unroll
         for (int q = 0; q < HK / 8; ++q) {
             float4 x = va[2 * q], y = va[2 * q + 1];
@@ -430,7 +456,9 @@ struct WnGemmTnArgs {
     int tiles_ka, n_splits; // grid: 8 * (tiles_ka * tiles_nb) * ceil(n_splits / 8) workgroups (wn_tile_of: the tiles of a row split share an XCD)
     WnRowMap a1;           // ka_split > 0: columns ka >= ka_split of A are columns (ka - ka_split) of this second row view (ka_split % 128 == 0):
     int ka_split;          //   the two taps of the filter/gate weight gradient in one launch -- their workgroups read the same rows of B
-    int pad;               //   at the same time, so the second read is served by the caches instead of HBM
+    int b_bf16;            //   at the same time, so the second read is served by the caches instead of HBM
+                           // b_bf16: B is STORED as bf16 (b.base points at unsigned short, b's strides count bf16 elements): the bf16
+                           // step's [dF|dG].  wn_bwd_gemm_tn_bf16<*, true> only.
 };
 
 __global__ __launch_bounds__(256, WN_GEMM_MINB) void wn_bwd_gemm_tn(WnGemmTnArgs g) {
@@ -532,11 +560,22 @@ __global__ __launch_bounds__(256, WN_GEMM_MINB) void wn_bwd_gemm_tn(WnGemmTnArgs
 #endif
 // WAVES = 4: 128 x 128 tile of C.  WAVES = 8: 128 (Ka) x 256 (Nb) tile for Nb >= 256 (wave w: ka strip 32 (w & 3).., nb half w >> 2), so
 // that A -- the layer input x in the filter/gate weight gradient, 262 MB -- is streamed once instead of once per 128 columns of B.
-template <int WAVES>
+// B16: B is stored as bf16 rows.  Its chunk is copied to LDS as it is -- row-major [KC rows][TB columns], 16-byte pieces, no conversion,
+// no register transpose -- and the MFMA operand (8 consecutive ROWS of one column per lane) is gathered by the transposing LDS read
+// ds_read_b64_tr_b16: lane p of a 16-lane group passes the address of 4 contiguous bf16 of row (p >> 2), columns 4 (p & 3)..; it
+// receives column p of that [4 rows][16 columns] block (checked on the device: tools/tr_probe.hip).  Two reads (rows +0..3, +4..7) make
+// one operand.  Row stride TB * 2 + 64 bytes: the four rows of a block and the two column blocks of a 32-lane half land in 64
+// different banks.
+typedef short wn_s4 __attribute__((ext_vector_type(4)));
+typedef short wn_s8 __attribute__((ext_vector_type(8)));
+template <int WAVES, bool B16>
 __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? WN_TN_BF16_MINB : 4) void wn_bwd_gemm_tn_bf16(WnGemmTnArgs g) {
     constexpr int T = 128, TB = 32 * WAVES, KC = 32, LD = KC + 8;  // LDS rows: [column][KC rows of the chunk] bf16, padded to 80 bytes
+    constexpr int RSB = TB * 2 + 64;                               // B16: bytes per row of the row-major B image
+    constexpr int BSZ = B16 ? KC * RSB / 2 : TB * LD;              // shorts per B buffer
+    constexpr int PPR = TB / 8;                                    // B16: 16-byte pieces per row
     __shared__ __attribute__((aligned(16))) unsigned short a_s[2][T * LD];
-    __shared__ __attribute__((aligned(16))) unsigned short b_s[2][TB * LD];
+    __shared__ __attribute__((aligned(16))) unsigned short b_s[2][BSZ];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wr = wv & 3, wc = wv >> 2;
     unsigned split, tile;
     if (!wn_tile_of(blockIdx.x, (unsigned)(g.tiles_ka * ((g.Nb + TB - 1) / TB)), (unsigned)g.n_splits, split, tile)) return;
@@ -551,7 +590,8 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? WN_TN_BF16_MINB : 4) void 
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
     // loader: threads 0-127 feed A, the next 128 (256) feed B, 128 columns each (WAVES = 8: the last 128 threads load nothing);
-    // unit = 8 rows (group mg) x 4 columns (group cg)
+    // fp32 operands: unit = 8 rows (group mg) x 4 columns (group cg);  B16: thread bt of the B loaders copies the 16-byte pieces
+    // (row bt / PPR + 8 q, piece bt % PPR), q = 0..3 -- consecutive threads, consecutive 16 bytes of a row
     const int role = tid >> 7;                    // 0: A;  1 ..: B columns 128 (role - 1) ..
     const bool is_b = role >= 1, loads = role <= TB / 128;
     const int u = tid & 127, mg = u >> 5, cg = u & 31;
@@ -562,8 +602,28 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? WN_TN_BF16_MINB : 4) void 
     const int pcol0 = (!is_b && second) ? col0 - g.ka_split : col0;   // column inside the row view
     const bool col_ok = loads && col0 < ncols;
     const bool relu = !is_b && g.relu_a;
+    const int bt = tid - 128, brow = bt / PPR, bpiece = bt % PPR;   // B16 loader coordinates
+    const bool b16_ok = B16 && is_b && loads && nb0 + 8 * bpiece < g.Nb;
     float4 v[8];
     auto fetch = [&](long long mc) {
+        if (B16 && is_b) {
+            const unsigned short* base16 = reinterpret_cast<const unsigned short*>(g.b.base);
+            const long long m = mc + brow;
+            unsigned q = (unsigned)m / (unsigned)g.rows_per_batch, rem = (unsigned)m - q * (unsigned)g.rows_per_batch;
+            const unsigned short* ptr = base16 + (long long)q * g.b.batch_stride + (g.b.t0 + (long long)rem) * g.b.row_stride + nb0 + 8 * bpiece;
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+                v[qq] = (b16_ok && m + 8 * qq < m_end) ? *reinterpret_cast<const float4*>(ptr) : make_float4(0.f, 0.f, 0.f, 0.f);   // 8 bf16, moved as bits
+                rem += 8;
+                if (rem >= (unsigned)g.rows_per_batch) {   // the row 8 further down is in a later batch entry
+                    do { rem -= (unsigned)g.rows_per_batch; ++q; } while (rem >= (unsigned)g.rows_per_batch);
+                    ptr = base16 + (long long)q * g.b.batch_stride + (g.b.t0 + (long long)rem) * g.b.row_stride + nb0 + 8 * bpiece;
+                } else {
+                    ptr += 8 * g.b.row_stride;
+                }
+            }
+            return;
+        }
         long long m = mc + mg * 8;
         unsigned q = (unsigned)m / (unsigned)g.rows_per_batch, rem = (unsigned)m - q * (unsigned)g.rows_per_batch;
         const float* ptr = rm.base + (long long)q * rm.batch_stride + (rm.t0 + (long long)rem) * rm.row_stride + pcol0;
@@ -580,6 +640,12 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? WN_TN_BF16_MINB : 4) void 
     };
     auto stash = [&](int buf) {
         if (!loads) return;
+        if (B16 && is_b) {
+            char* img = reinterpret_cast<char*>(b_s[buf]);
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) *reinterpret_cast<float4*>(img + (brow + 8 * qq) * RSB + 16 * bpiece) = v[qq];
+            return;
+        }
         unsigned short* dst = (is_b ? b_s[buf] : a_s[buf]) + lcol * LD + mg * 8;
         if (relu) {
 #pragma unroll
@@ -590,6 +656,9 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? WN_TN_BF16_MINB : 4) void 
         *reinterpret_cast<uint4*>(dst + 2 * LD) = make_uint4(wn_pack_bf16(v[0].z, v[1].z), wn_pack_bf16(v[2].z, v[3].z), wn_pack_bf16(v[4].z, v[5].z), wn_pack_bf16(v[6].z, v[7].z));
         *reinterpret_cast<uint4*>(dst + 3 * LD) = make_uint4(wn_pack_bf16(v[0].w, v[1].w), wn_pack_bf16(v[2].w, v[3].w), wn_pack_bf16(v[4].w, v[5].w), wn_pack_bf16(v[6].w, v[7].w));
     };
+    // B16: byte offset of this lane's first transposing read inside a B buffer (ks = 0, j = 0, rows +0..3)
+    const int tp = lane & 15, tg = (lane >> 4) & 1, th = lane >> 5;
+    const int tr_off = (8 * th + (tp >> 2)) * RSB + (128 * wc + 16 * tg + 4 * (tp & 3)) * 2;
     fetch(m_begin);
     stash(0);
     __syncthreads();
@@ -598,12 +667,22 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? WN_TN_BF16_MINB : 4) void 
         if (mc + KC < m_end) fetch(mc + KC);
         const unsigned short* ar = a_s[buf] + (32 * wr + (lane & 31)) * LD + 8 * (lane >> 5);
         const unsigned short* br = b_s[buf] + (128 * wc + (lane & 31)) * LD + 8 * (lane >> 5);
+        const char* bt_img = reinterpret_cast<const char*>(b_s[buf]) + tr_off;
 #pragma unroll
         for (int ks = 0; ks < KC / 16; ++ks) {
             const wn_bf16x8 a = *reinterpret_cast<const wn_bf16x8*>(ar + 16 * ks);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const wn_bf16x8 b = *reinterpret_cast<const wn_bf16x8*>(br + 32 * j * LD + 16 * ks);
+                wn_bf16x8 b;
+                if constexpr (B16) {
+                    typedef __attribute__((address_space(3))) wn_s4 lds_s4;
+                    const char* at = bt_img + ks * 16 * RSB + j * 64;
+                    const wn_s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(at));
+                    const wn_s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(at + 4 * RSB));
+                    b = __builtin_bit_cast(wn_bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                } else {
+                    b = *reinterpret_cast<const wn_bf16x8*>(br + 32 * j * LD + 16 * ks);
+                }
                 acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[j], 0, 0, 0);
             }
         }
@@ -647,8 +726,14 @@ __global__ void wn_bwd_gate(const float* dz, const float* th, const float* sg, f
         t = th[i]; s = sg[i];
     }
     const int nf = 64 * (ch >> 5) + (ch & 31);
-    dfg[m * 2 * D + nf] = d * s * (1.f - t * t);
-    dfg[m * 2 * D + nf + 32] = d * t * s * (1.f - s);
+    if (PACKED) {   // the bf16 step stores [dF|dG] as bf16
+        unsigned short* o = reinterpret_cast<unsigned short*>(dfg) + m * 2 * D + nf;
+        o[0] = (unsigned short)wn_pack_bf16(d * s * (1.f - t * t), 0.f);
+        o[32] = (unsigned short)wn_pack_bf16(d * t * s * (1.f - s), 0.f);
+    } else {
+        dfg[m * 2 * D + nf] = d * s * (1.f - t * t);
+        dfg[m * 2 * D + nf + 32] = d * t * s * (1.f - s);
+    }
 }
 
 // ---- fused softmax cross-entropy (wavenet_training.py:69-70): one wave per row of 256 logits, four classes per lane.
@@ -696,12 +781,21 @@ __global__ __launch_bounds__(1024) void wn_xent_reduce(const float* row_loss, lo
 }
 
 // out[n] += sum over rows of x[row][n]   (bias gradients); x rows addressed through a row map
+// X16: x is stored as bf16 (base points at unsigned short, strides in bf16 elements)
+template <bool X16>
 __global__ void wn_bwd_colsum(WnRowMap x, long long M, int rows_per_batch, int N, float* out) {
     const int n = blockIdx.y * blockDim.x + threadIdx.x;
     const long long m0 = (long long)blockIdx.x * 512;
     if (n >= N) return;
     float s = 0.f;
-    for (long long m = m0; m < m0 + 512 && m < M; ++m) s += wn_row(x, m, rows_per_batch)[n];
+    for (long long m = m0; m < m0 + 512 && m < M; ++m) {
+        if (X16) {
+            const unsigned q = (unsigned)m / (unsigned)rows_per_batch, rem = (unsigned)m - q * (unsigned)rows_per_batch;
+            s += __uint_as_float((unsigned)(reinterpret_cast<const unsigned short*>(x.base) + (long long)q * x.batch_stride + (x.t0 + (long long)rem) * x.row_stride)[n] << 16);
+        } else {
+            s += wn_row(x, m, rows_per_batch)[n];
+        }
+    }
     unsafeAtomicAdd(out + n, s);
 }
 

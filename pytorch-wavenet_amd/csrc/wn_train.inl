@@ -104,13 +104,16 @@ static void wn_launch_tn(hipStream_t st, WnGemmTnArgs a, bool bf16 = false) {
     a.rows_per_split = rps;
     a.tiles_ka = (a.Ka + 127) / 128; a.n_splits = (int)splits;
     const dim3 grid(8u * (unsigned)tiles * (unsigned)((splits + 7) / 8));   // wn_tile_of: the tiles of a row split share an XCD
-    if (wide) hipLaunchKernelGGL(wn_bwd_gemm_tn_bf16<8>, grid, dim3(512), 0, st, a);
-    else if (bf16 && !a.a_idx) hipLaunchKernelGGL(wn_bwd_gemm_tn_bf16<4>, grid, dim3(256), 0, st, a);  // bf16 matrix operands, fp32 accumulation
+    if (wide && a.b_bf16) hipLaunchKernelGGL((wn_bwd_gemm_tn_bf16<8, true>), grid, dim3(512), 0, st, a);   // B stored as bf16: the filter/gate weight gradient
+    else if (wide) hipLaunchKernelGGL((wn_bwd_gemm_tn_bf16<8, false>), grid, dim3(512), 0, st, a);
+    else if (bf16 && !a.a_idx && a.b_bf16) hipLaunchKernelGGL((wn_bwd_gemm_tn_bf16<4, true>), grid, dim3(256), 0, st, a);
+    else if (bf16 && !a.a_idx) hipLaunchKernelGGL((wn_bwd_gemm_tn_bf16<4, false>), grid, dim3(256), 0, st, a);  // bf16 matrix operands, fp32 accumulation
     else hipLaunchKernelGGL(wn_bwd_gemm_tn, grid, dim3(256), 0, st, a);
 }
 
-static void wn_launch_colsum(hipStream_t st, const WnRowMap& x, long long M, int rows_per_batch, int N, float* out) {
-    hipLaunchKernelGGL(wn_bwd_colsum, dim3((unsigned)((M + 511) / 512), (unsigned)((N + 63) / 64)), dim3(64), 0, st, x, M, rows_per_batch, N, out);
+static void wn_launch_colsum(hipStream_t st, const WnRowMap& x, long long M, int rows_per_batch, int N, float* out, bool x16 = false) {
+    if (x16) { hipLaunchKernelGGL(wn_bwd_colsum<true>, dim3((unsigned)((M + 511) / 512), (unsigned)((N + 63) / 64)), dim3(64), 0, st, x, M, rows_per_batch, N, out); return; }
+    hipLaunchKernelGGL(wn_bwd_colsum<false>, dim3((unsigned)((M + 511) / 512), (unsigned)((N + 63) / 64)), dim3(64), 0, st, x, M, rows_per_batch, N, out);
 }
 
 static void wn_launch_transpose(hipStream_t st, const float* in, long long in_batch_stride, float* out, int rows, int cols, int batches) {
@@ -337,7 +340,7 @@ extern "C" int wn_train_backward(wn_handle* h, const float* params, const float*
             memset(&a, 0, sizeof(a));
             a.a0 = a.a1 = WnRowMap{dxn, L * (long long)R, R, t0};
             a.k_split = R; a.K = R; a.bt = ws + t.res_o + (size_t)l * R * D; a.N = D;
-            a.c = WnRowMap{dfg, rows * 2 * D, 2 * D, 0};
+            a.c = WnRowMap{dfg, rows * 2 * D, 2 * D, 0}; a.c_bf16 = t.bf16 ? 1 : 0;   // bf16 step: [dF|dG] is STORED as bf16 (it only ever feeds bf16 matrix operands)
             a.c2 = WnRowMap{dzg + (size_t)gi * D, out_len * (long long)cnt * D, (long long)cnt * D, 0};
             a.c2_first_row = (int)(rows - out_len);
             a.gate_t = ws + t.th[l]; a.gate_g = ws + t.sg[l]; a.gate_packed = t.bf16 ? 1 : 0;
@@ -363,7 +366,7 @@ extern "C" int wn_train_backward(wn_handle* h, const float* params, const float*
         // row views of A (ka_split): the workgroups of the two taps run side by side and read the same rows of dfg.
         memset(&g, 0, sizeof(g));
         g.a = WnRowMap{xin, L * (long long)R, R, t0 - d}; g.a1 = WnRowMap{xin, L * (long long)R, R, t0}; g.ka_split = R;
-        g.b = WnRowMap{dfg, rows * 2 * D, 2 * D, 0};
+        g.b = WnRowMap{dfg, rows * 2 * D, 2 * D, 0}; g.b_bf16 = t.bf16 ? 1 : 0;
         g.Ka = 2 * R; g.Nb = 2 * D; g.c = grads + h->fw_off_fg + (size_t)l * 2 * R * 2 * D; g.ldc = 2 * D;
         g.M = M; g.rows_per_batch = (int)rows;
 #if WN_TN_MERGE_TAPS
@@ -376,7 +379,7 @@ extern "C" int wn_train_backward(wn_handle* h, const float* params, const float*
             g1.a = tap ? g.a1 : g.a; g1.ka_split = 0; g1.Ka = R; g1.c = g.c + (size_t)tap * R * 2 * D;
             wn_launch_tn(st, g1, t.bf16);
         }
-        if (pl.has_bias) wn_launch_colsum(st, WnRowMap{dfg, rows * 2 * D, 2 * D, 0}, M, (int)rows, 2 * D, grads + h->fw_off_bfg + (size_t)l * 2 * D);
+        if (pl.has_bias) wn_launch_colsum(st, WnRowMap{dfg, rows * 2 * D, 2 * D, 0}, M, (int)rows, 2 * D, grads + h->fw_off_bfg + (size_t)l * 2 * D, t.bf16);
         // dx_l on its rows [t0 - d, L) (= the last need[l] time steps) in ONE product over two row-shifted views of dfg:
         //     dx_l(t) = dx'(t) [t >= t0]  +  dfg(t) . Wfg(tap 1) [t >= t0]  +  dfg(t + d) . Wfg(tap 0) [t < L - d]
         // K = 4D: columns 0..2D-1 take dfg(t) against tap 1's rows, columns 2D.. take dfg(t + d) against tap 0's.  The views' row
@@ -385,7 +388,7 @@ extern "C" int wn_train_backward(wn_handle* h, const float* params, const float*
         memset(&a, 0, sizeof(a));
         a.a0 = WnRowMap{dfg, rows * 2 * D, 2 * D, -d};   // dfg(t):     row (t - t0) = rem - d, valid from rem = d
         a.a1 = WnRowMap{dfg, rows * 2 * D, 2 * D, 0};    // dfg(t + d): row rem, valid up to rem = rows - 1
-        a.a_skip_lo[0] = (int)d; a.a_skip_hi[1] = (int)d;
+        a.a_skip_lo[0] = (int)d; a.a_skip_hi[1] = (int)d; a.a_bf16 = t.bf16 ? 1 : 0;
         a.k_split = 2 * D; a.K = 4 * D; a.bt = ws + t.fgb1 + (size_t)l * 2 * D * R; a.bt1 = ws + t.fgb0 + (size_t)l * 2 * D * R; a.N = R;
         if (has_res) { a.cin = WnRowMap{dxn, L * (long long)R, R, t0 - d}; a.cin_skip_lo = (int)d; }
         a.c = WnRowMap{dxc, L * (long long)R, R, t0 - d};

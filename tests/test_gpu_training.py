@@ -326,6 +326,29 @@ def test_bf16_operands_for_the_training_step():
     assert torch.allclose(o1, o2, atol=1e-6)
 
 
+def test_bf16_step_at_the_headline_channel_widths():
+    """The bf16 step at config 5's channel widths (128 / 128 / 512 / 256, bias, 2 x 4 layers, N = 2, three time steps more than the
+    minimum): the forms only these widths select -- 128 x 256 tiles for the gate product and the wide weight gradients, both taps of
+    the filter/gate weight gradient in one launch, [dF|dG] STORED as bf16 (row-major LDS image + transposing LDS reads in the weight
+    gradient, bf16 rows staged as they are in the dx product), packed bf16 gates, dx as one product over two row-windowed views --
+    against the fp32 step of the same model, same bounds as the 64-channel test above."""
+    m = _model(True, layers=4, blocks=2, ch=128, skip=512, end=256, out_len=24, seed=3, gain=1.5)
+    x, target = _batch(m, 2, 3)
+    out32, loss32, g32 = _step(m, x, target, torch_path=False)
+    m.matrix_precision = "bf16"
+    out16, loss16, g16 = _step(m, x, target, torch_path=False)
+    scale = float(out32.abs().max())
+    assert 0 < float((out16 - out32).abs().max()) <= 1e-2 * scale
+    assert abs(loss16 - loss32) <= 1e-3 * abs(loss32)
+    for k in g32:
+        if g32[k] is None:
+            assert g16[k] is None
+            continue
+        rel = float((g16[k] - g32[k]).norm() / (g32[k].norm() + 1e-30))
+        cos = float((g16[k] * g32[k]).sum() / (g16[k].norm() * g32[k].norm() + 1e-30))
+        assert rel <= (5e-3 if k.startswith("end_conv_2") else 0.15) and cos >= 0.99, (k, rel, cos)
+
+
 def test_training_abi_error_codes():
     """wn_train_* through the C ABI: call-order and shape errors come back as codes with a message, nothing throws."""
     import ctypes

@@ -15,6 +15,10 @@ if [ "${PMC:-0}" = "1" ]; then   # HBM traffic per kernel: counters in their own
   timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/prof_trf -o f -- $CMD > /tmp/trf.log 2>&1
   timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/prof_trw -o w -- $CMD > /tmp/trw.log 2>&1
 fi
+if [ "${SQ:-0}" = "1" ]; then    # where the waves' cycles go (quad-cycles; WAIT_ANY = parked on s_waitcnt / barrier) and the LDS conflict share
+  rm -rf /tmp/prof_trs
+  timeout 400 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS -d /tmp/prof_trs -o s -- $CMD > /tmp/trs.log 2>&1
+fi
 cd "$ROOT"
 DB=$(find /tmp/prof_tr -name "*.db" | head -1)
 {
@@ -26,6 +30,11 @@ DB=$(find /tmp/prof_tr -name "*.db" | head -1)
   if [ "${PMC:-0}" = "1" ]; then
     echo "# PMC passes (FETCH_SIZE / WRITE_SIZE in KiB per dispatch; raw counter values)"
     python tools/rocprof_summary.py $(find /tmp/prof_trf /tmp/prof_trw -name "*.db" | sort) | grep -v "^kernel stats\|^name \|^void at::\|^__amd\|^## " | grep "n=" | grep "wn_"
+  fi
+  if [ "${SQ:-0}" = "1" ]; then
+    echo "# SQ pass (per dispatch averages)"
+    python tools/rocprof_summary.py $(find /tmp/prof_trs -name "*.db" | sort) | grep "n=" | grep "wn_.*gemm"
+    tail -3 /tmp/trs.log
   fi
 } > "$OUT/rocprofv3_train_$TAG.txt" 2>&1
 head -c 6000 "$OUT/rocprofv3_train_$TAG.txt"
