@@ -24,6 +24,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 typedef float wn_f16v __attribute__((ext_vector_type(16)));
 
 // address of logical row m of a (batch, time) matrix: base + (m / rows_per_batch) * batch_stride + (t0 + m % rows_per_batch) * row_stride
@@ -77,7 +79,7 @@ struct WnGemmArgs {
     // bf16 STORAGE (the bf16 training step's [dF|dG]; bf16 kernels only).  The row maps of a bf16 matrix point at unsigned short and
     // count their strides in bf16 elements.
     int a_bf16;           // A (both views) is stored as bf16: staged into LDS as it is          (wn_fwd_gemm_bf16<*, *, true>)
-    int c_bf16;           // WN_EPI_GATE_BWD: c receives bf16 (round to nearest even)
+    int c_bf16;           // WN_EPI_GATE_BWD: c receives bf16 (round to nearest even); WN_EPI_GATE: c and c2 do
 };
 static __device__ __forceinline__ const float* wn_row_at(const WnRowMap& r, unsigned q, unsigned rem) {
     return r.base + (long long)q * r.batch_stride + (r.t0 + (long long)rem) * r.row_stride;
@@ -119,8 +121,14 @@ static __device__ __forceinline__ void wn_gemm_epilogue(const WnGemmArgs& g, con
                 const float th = fmaf(2.0f, __builtin_amdgcn_rcpf(1.0f + wn_exp(-2.0f * f)), -1.0f), sg = __builtin_amdgcn_rcpf(1.0f + wn_exp(-gg));
                 const float z = th * sg;
                 const int zc = (nw >> 1) + 32 * p + col;
-                crow[zc] = z;
-                if (c2row) c2row[zc] = z;
+                if (g.c_bf16) {   // the bf16 step stores z (and its copy on the skip rows) as bf16: it only ever feeds bf16 matrix operands
+                    const unsigned short zb = (unsigned short)wn_pack_bf16(z, 0.f);
+                    (const_cast<unsigned short*>(reinterpret_cast<const unsigned short*>(g.c.base)) + (long long)q * g.c.batch_stride + (g.c.t0 + (long long)rem) * g.c.row_stride)[zc] = zb;
+                    if (c2row) (const_cast<unsigned short*>(reinterpret_cast<const unsigned short*>(g.c2.base)) + (long long)q * g.c2.batch_stride + (g.c2.t0 + (long long)rem - g.c2_first_row) * g.c2.row_stride)[zc] = zb;
+                } else {
+                    crow[zc] = z;
+                    if (c2row) c2row[zc] = z;
+                }
                 if (g.gate_t) {
                     if (g.gate_packed) {
                         reinterpret_cast<unsigned*>(g.gate_t)[m * (g.N >> 1) + zc] = wn_pack_bf16(th, sg);
@@ -457,9 +465,10 @@ struct WnGemmTnArgs {
     WnRowMap a1;           // ka_split > 0: columns ka >= ka_split of A are columns (ka - ka_split) of this second row view (ka_split % 128 == 0):
     int ka_split;          //   the two taps of the filter/gate weight gradient in one launch -- their workgroups read the same rows of B
     int b_bf16;            //   at the same time, so the second read is served by the caches instead of HBM
-                           // b_bf16: B is STORED as bf16 (b.base points at unsigned short, b's strides count bf16 elements): the bf16
-                           // step's [dF|dG].  wn_bwd_gemm_tn_bf16<*, true> only.
-};
+                           // b_bf16: B is STORED as bf16 (its base points at unsigned short, its strides count bf16 elements): the bf16
+                           // step's [dF|dG] and z.  wn_bwd_gemm_tn_bf16<*, true> only.
+    int c_trans, a_bf16;   // c_trans: C is stored transposed, element (ka, nb) at c[nb * ldc + ka] (operands swapped by the caller so that the
+};                         // bf16-stored one is B);  a_bf16: A is stored as bf16 (excludes ka_split, relu_a, a_idx)
 
 __global__ __launch_bounds__(256, WN_GEMM_MINB) void wn_bwd_gemm_tn(WnGemmTnArgs g) {
     constexpr int T = 128, KC = WN_GEMM_KC, NQ = KC / 8, LT = 256 / KC;  // NQ float4 per thread per operand, LT threads per row
@@ -568,13 +577,16 @@ __global__ __launch_bounds__(256, WN_GEMM_MINB) void wn_bwd_gemm_tn(WnGemmTnArgs
 // different banks.
 typedef short wn_s4 __attribute__((ext_vector_type(4)));
 typedef short wn_s8 __attribute__((ext_vector_type(8)));
-template <int WAVES, bool B16>
+// A16: A is stored as bf16 (same image, same reads, on the A side).  Measured a little slower than an fp32-stored A (160 vs 148 us in the
+// residual weight gradient) where B16 is a clear gain (211 -> 160 us in the filter/gate one), so where the choice exists the bf16-stored
+// operand goes in as B (operands swapped, c_trans) -- but only for few row splits: a transposed tile of atomics touches 32x the cache
+// lines (residual weight gradient, ~1000 splits: 598 us).
+template <int WAVES, bool A16, bool B16>
 __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? WN_TN_BF16_MINB : 4) void wn_bwd_gemm_tn_bf16(WnGemmTnArgs g) {
-    constexpr int T = 128, TB = 32 * WAVES, KC = 32, LD = KC + 8;  // LDS rows: [column][KC rows of the chunk] bf16, padded to 80 bytes
-    constexpr int RSB = TB * 2 + 64;                               // B16: bytes per row of the row-major B image
-    constexpr int BSZ = B16 ? KC * RSB / 2 : TB * LD;              // shorts per B buffer
-    constexpr int PPR = TB / 8;                                    // B16: 16-byte pieces per row
-    __shared__ __attribute__((aligned(16))) unsigned short a_s[2][T * LD];
+    constexpr int T = 128, TB = 32 * WAVES, KC = 32, LD = KC + 8;  // fp32-stored operand: LDS rows [column][KC rows of the chunk] bf16, padded to 80 bytes
+    constexpr int RSA = T * 2 + 64, RSB = TB * 2 + 64;             // bf16-stored operand: bytes per row of its row-major image
+    constexpr int ASZ = A16 ? KC * RSA / 2 : T * LD, BSZ = B16 ? KC * RSB / 2 : TB * LD;   // shorts per buffer
+    __shared__ __attribute__((aligned(16))) unsigned short a_s[2][ASZ];
     __shared__ __attribute__((aligned(16))) unsigned short b_s[2][BSZ];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wr = wv & 3, wc = wv >> 2;
     unsigned split, tile;
@@ -589,41 +601,51 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? WN_TN_BF16_MINB : 4) void 
     for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
-    // loader: threads 0-127 feed A, the next 128 (256) feed B, 128 columns each (WAVES = 8: the last 128 threads load nothing);
-    // fp32 operands: unit = 8 rows (group mg) x 4 columns (group cg);  B16: thread bt of the B loaders copies the 16-byte pieces
-    // (row bt / PPR + 8 q, piece bt % PPR), q = 0..3 -- consecutive threads, consecutive 16 bytes of a row
+    // loader: threads 0-127 feed A, the next 128 (256) feed B, 128 columns each (WAVES = 8: the last 128 threads load nothing).
+    // fp32-stored operand: unit = 8 rows (group mg) x 4 columns (group cg), transposed in registers on the way to LDS.
+    // bf16-stored operand: loader thread lt of the operand copies the 16-byte pieces (row lt / PPR + 8 q, piece lt % PPR), q = 0..3
+    // (PPR = pieces per row) -- consecutive threads, consecutive 16 bytes of a row.
     const int role = tid >> 7;                    // 0: A;  1 ..: B columns 128 (role - 1) ..
     const bool is_b = role >= 1, loads = role <= TB / 128;
     const int u = tid & 127, mg = u >> 5, cg = u & 31;
-    const bool second = g.ka_split > 0 && ka0 >= g.ka_split;
+    const bool second = !A16 && g.ka_split > 0 && ka0 >= g.ka_split;
     const WnRowMap& rm = is_b ? g.b : (second ? g.a1 : g.a);
     const int lcol = is_b ? 128 * (role - 1) + 4 * cg : 4 * cg;   // column inside the tile
     const int col0 = (is_b ? nb0 : ka0) + lcol, ncols = is_b ? g.Nb : g.Ka;
     const int pcol0 = (!is_b && second) ? col0 - g.ka_split : col0;   // column inside the row view
     const bool col_ok = loads && col0 < ncols;
     const bool relu = !is_b && g.relu_a;
-    const int bt = tid - 128, brow = bt / PPR, bpiece = bt % PPR;   // B16 loader coordinates
-    const bool b16_ok = B16 && is_b && loads && nb0 + 8 * bpiece < g.Nb;
     float4 v[8];
-    auto fetch = [&](long long mc) {
-        if (B16 && is_b) {
-            const unsigned short* base16 = reinterpret_cast<const unsigned short*>(g.b.base);
-            const long long m = mc + brow;
-            unsigned q = (unsigned)m / (unsigned)g.rows_per_batch, rem = (unsigned)m - q * (unsigned)g.rows_per_batch;
-            const unsigned short* ptr = base16 + (long long)q * g.b.batch_stride + (g.b.t0 + (long long)rem) * g.b.row_stride + nb0 + 8 * bpiece;
+    // bf16-stored operand `map` (g.a or g.b named directly: its fields stay scalar), tile origin `org`, PPR pieces per row, loader thread lt
+    auto fetch16 = [&](const WnRowMap& map, int org, int ncols16, auto pprc, int lt, long long mc) {
+        constexpr int PPR = decltype(pprc)::value;
+        const int row16 = lt / PPR, piece16 = lt % PPR;
+        const bool ok16 = org + 8 * piece16 < ncols16;
+        const unsigned short* base16 = reinterpret_cast<const unsigned short*>(map.base);
+        const long long m = mc + row16;
+        unsigned q = (unsigned)m / (unsigned)g.rows_per_batch, rem = (unsigned)m - q * (unsigned)g.rows_per_batch;
+        const unsigned short* ptr = base16 + (long long)q * map.batch_stride + (map.t0 + (long long)rem) * map.row_stride + org + 8 * piece16;
 #pragma unroll
-            for (int qq = 0; qq < 4; ++qq) {
-                v[qq] = (b16_ok && m + 8 * qq < m_end) ? *reinterpret_cast<const float4*>(ptr) : make_float4(0.f, 0.f, 0.f, 0.f);   // 8 bf16, moved as bits
-                rem += 8;
-                if (rem >= (unsigned)g.rows_per_batch) {   // the row 8 further down is in a later batch entry
-                    do { rem -= (unsigned)g.rows_per_batch; ++q; } while (rem >= (unsigned)g.rows_per_batch);
-                    ptr = base16 + (long long)q * g.b.batch_stride + (g.b.t0 + (long long)rem) * g.b.row_stride + nb0 + 8 * bpiece;
-                } else {
-                    ptr += 8 * g.b.row_stride;
-                }
+        for (int qq = 0; qq < 4; ++qq) {
+            v[qq] = (ok16 && m + 8 * qq < m_end) ? *reinterpret_cast<const float4*>(ptr) : make_float4(0.f, 0.f, 0.f, 0.f);   // 8 bf16, moved as bits
+            rem += 8;
+            if (rem >= (unsigned)g.rows_per_batch) {   // the row 8 further down is in a later batch entry
+                do { rem -= (unsigned)g.rows_per_batch; ++q; } while (rem >= (unsigned)g.rows_per_batch);
+                ptr = base16 + (long long)q * map.batch_stride + (map.t0 + (long long)rem) * map.row_stride + org + 8 * piece16;
+            } else {
+                ptr += 8 * map.row_stride;
             }
-            return;
         }
+    };
+    auto stash16 = [&](unsigned short* imgs, int rs, auto pprc, int lt) {
+        constexpr int PPR = decltype(pprc)::value;
+        char* img = reinterpret_cast<char*>(imgs);
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) *reinterpret_cast<float4*>(img + (lt / PPR + 8 * qq) * rs + 16 * (lt % PPR)) = v[qq];
+    };
+    auto fetch = [&](long long mc) {
+        if (B16 && is_b) { if (loads) fetch16(g.b, nb0, g.Nb, std::integral_constant<int, TB / 8>{}, tid - 128, mc); return; }
+        if (A16 && !is_b) { fetch16(g.a, ka0, g.Ka, std::integral_constant<int, T / 8>{}, tid, mc); return; }
         long long m = mc + mg * 8;
         unsigned q = (unsigned)m / (unsigned)g.rows_per_batch, rem = (unsigned)m - q * (unsigned)g.rows_per_batch;
         const float* ptr = rm.base + (long long)q * rm.batch_stride + (rm.t0 + (long long)rem) * rm.row_stride + pcol0;
@@ -640,12 +662,8 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? WN_TN_BF16_MINB : 4) void 
     };
     auto stash = [&](int buf) {
         if (!loads) return;
-        if (B16 && is_b) {
-            char* img = reinterpret_cast<char*>(b_s[buf]);
-#pragma unroll
-            for (int qq = 0; qq < 4; ++qq) *reinterpret_cast<float4*>(img + (brow + 8 * qq) * RSB + 16 * bpiece) = v[qq];
-            return;
-        }
+        if (B16 && is_b) { stash16(b_s[buf], RSB, std::integral_constant<int, TB / 8>{}, tid - 128); return; }
+        if (A16 && !is_b) { stash16(a_s[buf], RSA, std::integral_constant<int, T / 8>{}, tid); return; }
         unsigned short* dst = (is_b ? b_s[buf] : a_s[buf]) + lcol * LD + mg * 8;
         if (relu) {
 #pragma unroll
@@ -656,26 +674,36 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? WN_TN_BF16_MINB : 4) void 
         *reinterpret_cast<uint4*>(dst + 2 * LD) = make_uint4(wn_pack_bf16(v[0].z, v[1].z), wn_pack_bf16(v[2].z, v[3].z), wn_pack_bf16(v[4].z, v[5].z), wn_pack_bf16(v[6].z, v[7].z));
         *reinterpret_cast<uint4*>(dst + 3 * LD) = make_uint4(wn_pack_bf16(v[0].w, v[1].w), wn_pack_bf16(v[2].w, v[3].w), wn_pack_bf16(v[4].w, v[5].w), wn_pack_bf16(v[6].w, v[7].w));
     };
-    // B16: byte offset of this lane's first transposing read inside a B buffer (ks = 0, j = 0, rows +0..3)
+    // bf16-stored operands: byte offset of this lane's first transposing read inside a buffer (ks = 0, j = 0, rows +0..3)
+    typedef __attribute__((address_space(3))) wn_s4 lds_s4;
     const int tp = lane & 15, tg = (lane >> 4) & 1, th = lane >> 5;
-    const int tr_off = (8 * th + (tp >> 2)) * RSB + (128 * wc + 16 * tg + 4 * (tp & 3)) * 2;
+    const int tra_off = (8 * th + (tp >> 2)) * RSA + (32 * wr + 16 * tg + 4 * (tp & 3)) * 2;
+    const int trb_off = (8 * th + (tp >> 2)) * RSB + (128 * wc + 16 * tg + 4 * (tp & 3)) * 2;
     fetch(m_begin);
     stash(0);
     __syncthreads();
     int buf = 0;
     for (long long mc = m_begin; mc < m_end; mc += KC, buf ^= 1) {
         if (mc + KC < m_end) fetch(mc + KC);
-        const unsigned short* ar = a_s[buf] + (32 * wr + (lane & 31)) * LD + 8 * (lane >> 5);
-        const unsigned short* br = b_s[buf] + (128 * wc + (lane & 31)) * LD + 8 * (lane >> 5);
-        const char* bt_img = reinterpret_cast<const char*>(b_s[buf]) + tr_off;
+        const unsigned short* ar = a_s[buf] + (A16 ? 0 : (32 * wr + (lane & 31)) * LD + 8 * (lane >> 5));
+        const unsigned short* br = b_s[buf] + (B16 ? 0 : (128 * wc + (lane & 31)) * LD + 8 * (lane >> 5));
+        const char* at_img = reinterpret_cast<const char*>(a_s[buf]) + tra_off;
+        const char* bt_img = reinterpret_cast<const char*>(b_s[buf]) + trb_off;
 #pragma unroll
         for (int ks = 0; ks < KC / 16; ++ks) {
-            const wn_bf16x8 a = *reinterpret_cast<const wn_bf16x8*>(ar + 16 * ks);
+            wn_bf16x8 a;
+            if constexpr (A16) {
+                const char* at = at_img + ks * 16 * RSA;
+                const wn_s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(at));
+                const wn_s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(at + 4 * RSA));
+                a = __builtin_bit_cast(wn_bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            } else {
+                a = *reinterpret_cast<const wn_bf16x8*>(ar + 16 * ks);
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 wn_bf16x8 b;
                 if constexpr (B16) {
-                    typedef __attribute__((address_space(3))) wn_s4 lds_s4;
                     const char* at = bt_img + ks * 16 * RSB + j * 64;
                     const wn_s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(at));
                     const wn_s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(at + 4 * RSB));
@@ -697,7 +725,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? WN_TN_BF16_MINB : 4) void 
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int nb = nb0 + 128 * wc + 32 * j + col;
-            if (nb < g.Nb) unsafeAtomicAdd(g.c + (size_t)ka * g.ldc + nb, acc[j][i]);
+            if (nb < g.Nb) unsafeAtomicAdd(g.c + (g.c_trans ? (size_t)nb * g.ldc + ka : (size_t)ka * g.ldc + nb), acc[j][i]);
         }
     }
 }

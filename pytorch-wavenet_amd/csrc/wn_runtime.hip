@@ -41,7 +41,7 @@ static int wn_fail(int code, const char* fmt, ...) {
 // One "NN" product C = A . B^T of wn_forward.h.  bn != NULL: bf16 operands (B given as [N][K] bf16 -- or as two [N][ldb] halves
 // bn / bn1 --, A rounded while staged), fp32 accumulation; else fp32 operands.  Products with N % 256 == 0 take the 128 x 256 tile.
 static void wn_launch_nn(hipStream_t st, int epi, const WnGemmArgs& a, const unsigned short* bn = nullptr, const unsigned short* bn1 = nullptr, int ldb = 0) {
-    const bool wide = bn && a.N % 256 == 0 && epi != WN_EPI_GATE_BWD && !a.a_bf16;
+    const bool wide = bn && a.N % 256 == 0 && epi != WN_EPI_GATE_BWD;
     const unsigned mt = (unsigned)((a.M + 127) / 128), nt = (unsigned)(wide ? a.N / 256 : (a.N + 127) / 128);
     const dim3 grid(mt * nt);   // 1-D (M / 128 can exceed a grid's y limit): row tiles fastest, then column tiles
     if (bn) {
@@ -49,11 +49,12 @@ static void wn_launch_nn(hipStream_t st, int epi, const WnGemmArgs& a, const uns
         b.g = a; b.bn = bn; b.bn1 = bn1; b.ldb = ldb;
         if (wide) {
             if (epi == WN_EPI_GATE) hipLaunchKernelGGL((wn_fwd_gemm_bf16<WN_EPI_GATE, 8>), grid, dim3(512), 0, st, b);
+            else if (a.a_bf16) hipLaunchKernelGGL((wn_fwd_gemm_bf16<WN_EPI_PLAIN, 8, true>), grid, dim3(512), 0, st, b);   // (bf16-stored A: the grouped skip product)
             else hipLaunchKernelGGL((wn_fwd_gemm_bf16<WN_EPI_PLAIN, 8>), grid, dim3(512), 0, st, b);
         } else {
             if (epi == WN_EPI_GATE) hipLaunchKernelGGL((wn_fwd_gemm_bf16<WN_EPI_GATE, 4>), grid, dim3(256), 0, st, b);
             else if (epi == WN_EPI_GATE_BWD) hipLaunchKernelGGL((wn_fwd_gemm_bf16<WN_EPI_GATE_BWD, 4>), grid, dim3(256), 0, st, b);
-            else if (a.a_bf16) hipLaunchKernelGGL((wn_fwd_gemm_bf16<WN_EPI_PLAIN, 4, true>), grid, dim3(256), 0, st, b);   // (bf16-stored A: the dx product)
+            else if (a.a_bf16) hipLaunchKernelGGL((wn_fwd_gemm_bf16<WN_EPI_PLAIN, 4, true>), grid, dim3(256), 0, st, b);   // (bf16-stored A: the residual and dx products)
             else hipLaunchKernelGGL((wn_fwd_gemm_bf16<WN_EPI_PLAIN, 4>), grid, dim3(256), 0, st, b);
         }
         return;

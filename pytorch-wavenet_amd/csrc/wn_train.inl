@@ -89,7 +89,7 @@ static void wn_launch_tn(hipStream_t st, WnGemmTnArgs a, bool bf16 = false) {
     // Split the rows so that ~1024 workgroups exist (four are resident per CU), but never below 256 rows per
     // split: every split ends with a tile of atomics.  bf16 products with Nb % 256 == 0 take the 128 x 256 tile (A streamed once per
     // 256 columns of B).
-    const bool wide = bf16 && !a.a_idx && a.Nb % 256 == 0;
+    const bool wide = bf16 && !a.a_idx && !a.a_bf16 && a.Nb % 256 == 0;
     const int tb = wide ? 256 : 128;
     const int tiles = ((a.Ka + 127) / 128) * ((a.Nb + tb - 1) / tb);
     const int want = wide ? 512 : 1024;
@@ -104,10 +104,12 @@ static void wn_launch_tn(hipStream_t st, WnGemmTnArgs a, bool bf16 = false) {
     a.rows_per_split = rps;
     a.tiles_ka = (a.Ka + 127) / 128; a.n_splits = (int)splits;
     const dim3 grid(8u * (unsigned)tiles * (unsigned)((splits + 7) / 8));   // wn_tile_of: the tiles of a row split share an XCD
-    if (wide && a.b_bf16) hipLaunchKernelGGL((wn_bwd_gemm_tn_bf16<8, true>), grid, dim3(512), 0, st, a);   // B stored as bf16: the filter/gate weight gradient
-    else if (wide) hipLaunchKernelGGL((wn_bwd_gemm_tn_bf16<8, false>), grid, dim3(512), 0, st, a);
-    else if (bf16 && !a.a_idx && a.b_bf16) hipLaunchKernelGGL((wn_bwd_gemm_tn_bf16<4, true>), grid, dim3(256), 0, st, a);
-    else if (bf16 && !a.a_idx) hipLaunchKernelGGL((wn_bwd_gemm_tn_bf16<4, false>), grid, dim3(256), 0, st, a);  // bf16 matrix operands, fp32 accumulation
+    // (b_bf16 / a_bf16: that operand is stored as bf16 -- [dF|dG] in the filter/gate weight gradient, z in the residual and skip ones)
+    if (wide && a.b_bf16) hipLaunchKernelGGL((wn_bwd_gemm_tn_bf16<8, false, true>), grid, dim3(512), 0, st, a);
+    else if (wide) hipLaunchKernelGGL((wn_bwd_gemm_tn_bf16<8, false, false>), grid, dim3(512), 0, st, a);
+    else if (bf16 && !a.a_idx && a.b_bf16) hipLaunchKernelGGL((wn_bwd_gemm_tn_bf16<4, false, true>), grid, dim3(256), 0, st, a);
+    else if (bf16 && !a.a_idx && a.a_bf16) hipLaunchKernelGGL((wn_bwd_gemm_tn_bf16<4, true, false>), grid, dim3(256), 0, st, a);
+    else if (bf16 && !a.a_idx) hipLaunchKernelGGL((wn_bwd_gemm_tn_bf16<4, false, false>), grid, dim3(256), 0, st, a);  // bf16 matrix operands, fp32 accumulation
     else hipLaunchKernelGGL(wn_bwd_gemm_tn, grid, dim3(256), 0, st, a);
 }
 
@@ -205,10 +207,12 @@ extern "C" int wn_train_forward(wn_handle* h, const float* params, const int32_t
         a.k_split = R; a.K = 2 * R; a.bt = fw + h->fw_off_fg + (size_t)l * 2 * R * 2 * D; a.N = 2 * D;
         a.bias = pl.has_bias ? fw + h->fw_off_bfg + (size_t)l * 2 * D : nullptr;
         a.c = WnRowMap{z, rows * D, D, 0};
-        a.c2 = WnRowMap{zg + (size_t)gi * D, out_len * (long long)G * D, (long long)G * D, 0};
+        // (column block gi of zg; in the bf16 step zg holds bf16 and the offset counts bf16 elements)
+        a.c2 = WnRowMap{bf16 ? reinterpret_cast<float*>(reinterpret_cast<unsigned short*>(zg) + (size_t)gi * D) : zg + (size_t)gi * D, out_len * (long long)G * D, (long long)G * D, 0};
         a.c2_first_row = (int)(rows - out_len);
         a.gate_t = ws + t.th[l]; a.gate_g = ws + t.sg[l];
         a.gate_packed = bf16 ? 1 : 0;  // bf16 step: tanh and sigmoid saved as one {bf16, bf16} dword per element (half the bytes, written once)
+        a.c_bf16 = bf16 ? 1 : 0;       //            z (and its copy on the skip rows, zg) stored as bf16
         a.M = N * rows; a.rows_per_batch = (int)rows;
         wn_launch_nn(st, WN_EPI_GATE, a, bf16 ? bt_fg + (size_t)l * 2 * D * 2 * R : nullptr);
         if (l < NL - 1) {
@@ -218,7 +222,7 @@ extern "C" int wn_train_forward(wn_handle* h, const float* params, const int32_t
             a.bias = pl.has_bias ? fw + h->fw_off_bres + (size_t)l * R : nullptr;
             a.cin = WnRowMap{xin, (long long)L * R, R, t0};
             a.c = WnRowMap{ws + t.x[l + 1], (long long)L * R, R, t0};
-            a.M = N * rows; a.rows_per_batch = (int)rows;
+            a.M = N * rows; a.rows_per_batch = (int)rows; a.a_bf16 = bf16 ? 1 : 0;
             wn_launch_nn(st, WN_EPI_PLAIN, a, bf16 ? bt_res + (size_t)l * R * D : nullptr);
         }
         if (gi == G - 1 || l == NL - 1) {
@@ -229,7 +233,7 @@ extern "C" int wn_train_forward(wn_handle* h, const float* params, const int32_t
             a.bias = (pl.has_bias && first == 0) ? ws + t.bskip_total : nullptr;
             if (first > 0) a.cin = WnRowMap{skip, out_len * S, S, 0};
             a.c = WnRowMap{skip, out_len * S, S, 0};
-            a.M = N * out_len; a.rows_per_batch = (int)out_len;
+            a.M = N * out_len; a.rows_per_batch = (int)out_len; a.a_bf16 = bf16 ? 1 : 0;
             wn_launch_nn(st, WN_EPI_PLAIN, a, bf16 ? bt_skip + (size_t)(first / G) * S * G * D : nullptr);
         }
     }
@@ -332,6 +336,9 @@ extern "C" int wn_train_backward(wn_handle* h, const float* params, const float*
             memset(&g, 0, sizeof(g));
             g.a = WnRowMap{zg, out_len * (long long)t.G * D, (long long)t.G * D, 0}; g.b = WnRowMap{dskip, out_len * S, S, 0};
             g.Ka = cnt * D; g.Nb = S; g.c = grads + h->fw_off_skip + (size_t)first * D * S; g.ldc = S; g.M = Mo; g.rows_per_batch = (int)out_len;
+            if (t.bf16) {   // zg is stored as bf16: it goes in as B (operands swapped, C written transposed -- same [cnt*D][S] gradient)
+                WnRowMap zmap = g.a; g.a = g.b; g.b = zmap; g.Ka = S; g.Nb = cnt * D; g.b_bf16 = 1; g.c_trans = 1;
+            }
             wn_launch_tn(st, g, t.bf16);
         }
         if (has_res) {
@@ -349,6 +356,7 @@ extern "C" int wn_train_backward(wn_handle* h, const float* params, const float*
             memset(&g, 0, sizeof(g));   // dWres^T [D][R] = z^T . dx'
             g.a = WnRowMap{z, rows * D, D, 0}; g.b = WnRowMap{dxn, L * (long long)R, R, t0};
             g.Ka = D; g.Nb = R; g.c = grads + h->fw_off_res + (size_t)l * D * R; g.ldc = R; g.M = M; g.rows_per_batch = (int)rows;
+            g.a_bf16 = t.bf16 ? 1 : 0;   // z is stored as bf16 in the bf16 step (here as A: ~1000 row splits, see wn_bwd_gemm_tn_bf16)
             wn_launch_tn(st, g, t.bf16);
             if (pl.has_bias) wn_launch_colsum(st, WnRowMap{dxn, L * (long long)R, R, t0}, M, (int)rows, R, grads + h->fw_off_bres + (size_t)l * R);
         } else {   // the last layer has no residual output: dz is its share of dzg alone
