@@ -224,7 +224,7 @@ def train_step_cfg5(device, N=32, L=16000, reps=3, precision="fp32"):
     ms = (time.perf_counter() - t0) / reps * 1e3
     peak = 157.3 if precision == "fp32" else 2500.0  # dense MFMA peaks, TFLOP/s (MI355X_MICROARCH.md)
     return {"ms_per_step": round(ms, 2), "clips": N, "clip_samples": L, "output_length": out_len,
-            "dtype": "f32 (matrix cores)" if precision == "fp32" else "bf16 matrix operands (forward, activation- and weight-gradient products), f32 accumulation and storage",
+            "dtype": "f32 (matrix cores)" if precision == "fp32" else "bf16 matrix operands (forward, activation- and weight-gradient products), f32 accumulation, f32 residual stream; z, gates and [dF|dG] stored as bf16",
             "tflop_per_step": round(3 * fwd / 1e12, 2), "tflops": round(3 * fwd / ms / 1e9, 1),
             "mfma_peak_tflops": peak, "mfma_peak_frac": round(3 * fwd / ms / 1e9 / peak, 4), "loss": round(float(loss.detach()), 4)}
 
