@@ -240,6 +240,8 @@ def train5_main(a, dist, rank, local, n_gpus, global_batch=32, L=16000):
     m = wavenet_model.WaveNetModel(layers=10, blocks=5, dilation_channels=128, residual_channels=128, skip_channels=512,
                                    end_channels=256, classes=256, output_length=1, kernel_size=2, bias=False).cuda(local)
     m.output_length = out_len = L - m.receptive_field + 1
+    bf16 = getattr(a, "train_precision", "bf16") == "bf16"
+    m.matrix_precision = "bf16" if bf16 else "fp32"
     n_local = global_batch // n_gpus
     g = torch.Generator().manual_seed(1 + rank)
     idx = torch.randint(0, 256, (n_local, L), generator=g).cuda(local)
@@ -286,14 +288,16 @@ def train5_main(a, dist, rank, local, n_gpus, global_batch=32, L=16000):
         print(json.dumps({
             "metric": "training step throughput, one-second 16 kHz clips per second (forward + backward + Adam), whole job",
             "value": round(global_batch / (ms * 1e-3), 2), "unit": "clips/s", "n_gpus": n_gpus, "steps": a.steps, "warmup": max(a.warmup, 1),
-            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "bf16 matrix operands, f32 accumulation and residual stream" if bf16 else "f32",
             "data": "synthetic (seeded random weights, uniform random class indices and targets)",
             "config": {"workload": "train5: WaveNetModel(layers=10, blocks=5, 128/128/512/256), global batch %d clips x %d samples, "
                                    "output_length %d, data parallel over %d GPU(s), one flat gradient all-reduce per step"
                                    % (global_batch, L, out_len, n_gpus), "global_batch": global_batch, "clips_per_gpu": n_local},
-            "roofline": {"bound": "mfma", "achieved": round(tflops, 2), "peak": 157.3 * n_gpus, "unit": "TFLOP/s",
-                         "frac": round(tflops / (157.3 * n_gpus), 4), "traffic": None,
-                         "kernel": "wn_fwd_gemm / wn_bwd_gemm_tn (fp32 MFMA)", "flop_per_step": int(3 * fwd)}}))
+            "roofline": {"bound": "mfma", "achieved": round(tflops, 2), "peak": (2500.0 if bf16 else 157.3) * n_gpus, "unit": "TFLOP/s",
+                         "frac": round(tflops / ((2500.0 if bf16 else 157.3) * n_gpus), 4), "traffic": None,
+                         "kernel": "wn_fwd_gemm_bf16 / wn_bwd_gemm_tn_bf16 (bf16 MFMA; the products are HBM streams at K = 128-512: DESIGN.md 2c)" if bf16
+                                   else "wn_fwd_gemm / wn_bwd_gemm_tn (fp32 MFMA)", "flop_per_step": int(3 * fwd)}}))
     if dist:
         dist.destroy_process_group()
 
@@ -393,6 +397,8 @@ def main():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: the workload's streams PER GPU (64 for cfg3x64); strong: BASELINE configs[3], 512 streams in total "
                          "sharded over the GPUs (512 / N per GPU)")
+    ap.add_argument("--train-precision", default="bf16", choices=["bf16", "fp32"],
+                    help="train5 only: matrix operand precision (BASELINE configs[4] names bf16 MFMA; fp32 = the parity default of the facade)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
     a = ap.parse_args()
