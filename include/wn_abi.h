@@ -135,7 +135,11 @@ typedef struct wn_handle wn_handle;
 int wn_abi_version(void);
 
 /* WaveNetModel.__init__ (wavenet_model.py:28-123): plans the workgroup chain, allocates queues/hand-off
- * buffers on cfg->device_id.  No weights yet. */
+ * buffers on cfg->device_id.  No weights yet.
+ * Channel counts the wave-specialised kernel is not compiled for are served by zero padding (kernel_size 2, 256 classes,
+ * no pinned split): the handle then runs the next instantiated shape that holds the model, wn_load_weights pads the
+ * caller's arrays with zeros, results are those of the caller's model, wn_export_queue returns the caller's channels,
+ * wn_train_* return WN_E_UNSUPPORTED (weight_bytes / queue_bytes of wn_info are the padded model's). */
 int wn_create(const wn_config* cfg, wn_handle** out);
 void wn_destroy(wn_handle* h);
 

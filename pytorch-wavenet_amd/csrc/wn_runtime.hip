@@ -302,6 +302,11 @@ struct wn_handle {
     int lds_bytes;
     int v3_mode;   // variant 3: streams per pipeline item (wn_v3_mode)
     int dev_overrides = 0;  // a development override was in effect when this handle was planned (wn_dev_env)
+    // Zero padding: a channel shape the wave-specialised kernel is not compiled for runs as the next instantiated shape that holds it,
+    // its weights padded with zeros (wn_pad_config).  cfg / plan then carry the PADDED channel counts; these are the caller's.
+    bool padded = false;
+    int user_R = 0, user_D = 0, user_S = 0, user_E = 0;
+    int export_R = 0;       // rows wn_export_queue returns (0: plan.R); set on a padded handle and on the member handles of its rounds
     // Rounds: more streams than ONE chain holds (its LDS parks a tap-0 sum per stream: cfg3 ~150 streams) are served in rounds of up to
     // WN_V3_ROUND_STREAMS streams, one round after the other on the caller's stream: this handle is then only a front that routes
     // every call to its member handles (`chains`, one complete engine per round).
@@ -352,11 +357,65 @@ extern "C" void wn_destroy(wn_handle* h) {
     delete h;
 }
 
+static int wn_create_impl(const wn_config* cfg, wn_handle** out);
+
+// Zero padding of the channel counts.  Extra residual channels stay 0 for ever (zero rows in start_conv and the residual convs), extra
+// dilation channels give tanh(0) * sigmoid(0) = 0, extra skip / end channels give relu(0) = 0 against zero weights: the padded network
+// computes the same logits, and every product only gains exact zeros.  So a kernel_size-2, 256-class model whose channel shape is not
+// in the table of the wave-specialised kernel (e.g. 48 / 48 / 300 / 200) runs as the cheapest instantiated shape that holds it instead
+// of on the generic LDS-resident kernel (last measured 6-13x slower).  Not applied when the caller pins layer_split / head_split.
+static bool wn_pad_config(const wn_config* cfg, int n_cu, wn_config* padded) {
+    if (cfg->kernel_size != 2 || cfg->classes != 256 || cfg->layer_split > 0 || cfg->head_split > 0) return false;
+    wn_config probe = *cfg;
+    if (probe.n_streams > WN_V3_ROUND_STREAMS) probe.n_streams = WN_V3_ROUND_STREAMS;
+    if (wn_v3_applicable(&probe, n_cu, nullptr, nullptr, nullptr)) return false;   // served as it is
+    long long best = -1;
+    for (const WnV2Entry& e : wn_v2_table()) {
+        const int D2 = e.DC * e.Pm, E2 = (cfg->end_channels + e.EC - 1) / e.EC * e.EC;
+        if (e.R < cfg->residual_channels || e.S < cfg->skip_channels || D2 < cfg->dilation_channels || E2 / e.EC > 16) continue;
+        wn_config c = probe;
+        c.residual_channels = e.R; c.dilation_channels = D2; c.skip_channels = e.S; c.end_channels = E2;
+        if (!wn_v3_applicable(&c, n_cu, nullptr, nullptr, nullptr)) continue;
+        // cheapest: fewest workgroups on the token's path, then the least arithmetic
+        const long long cost = ((long long)cfg->layers * cfg->blocks * e.Pm + E2 / e.EC) * 100000000ll + (long long)e.R * D2 + (long long)e.S * (D2 + E2);
+        if (best < 0 || cost < best) { best = cost; *padded = *cfg; padded->residual_channels = e.R; padded->dilation_channels = D2; padded->skip_channels = e.S; padded->end_channels = E2; }
+    }
+    return best >= 0;
+}
+
 extern "C" int wn_create(const wn_config* cfg, wn_handle** out) {
     g_err[0] = 0;
     if (!cfg || !out) return wn_fail(WN_E_BADARG, "wn_create: NULL argument");
     *out = nullptr;
     if (!g_create_depth) g_dev_env_used = 0;
+    if (!g_create_depth && cfg->layers >= 1 && cfg->blocks >= 1 && cfg->dilation_channels >= 1 && cfg->residual_channels >= 1 && cfg->skip_channels >= 1 &&
+        cfg->end_channels >= 1 && cfg->n_streams >= 1 && cfg->layers <= 24) {
+        int ndev = 0, n_cu = 0;
+        if (hipGetDeviceCount(&ndev) == hipSuccess && cfg->device_id >= 0 && cfg->device_id < ndev &&
+            hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, cfg->device_id) == hipSuccess) {
+            wn_config eff;
+            if (wn_pad_config(cfg, n_cu, &eff)) {
+                const int rc = wn_create_impl(&eff, out);
+                if (rc == WN_OK && (*out)->variant == 3) {
+                    wn_handle* h = *out;
+                    h->padded = true;
+                    h->user_R = cfg->residual_channels; h->user_D = cfg->dilation_channels; h->user_S = cfg->skip_channels; h->user_E = cfg->end_channels;
+                    h->export_R = h->user_R;
+                    for (wn_handle* c : h->chains) c->export_R = h->user_R;
+                    return WN_OK;
+                }
+                if (rc == WN_OK) { wn_destroy(*out); *out = nullptr; }   // (not the kernel the padding was for: plan the caller's shape instead)
+                g_err[0] = 0;
+            }
+        }
+    }
+    return wn_create_impl(cfg, out);
+}
+
+static int wn_create_impl(const wn_config* cfg, wn_handle** out) {
+    g_err[0] = 0;
+    if (!cfg || !out) return wn_fail(WN_E_BADARG, "wn_create: NULL argument");
+    *out = nullptr;
     if (cfg->layers < 1 || cfg->blocks < 1 || cfg->dilation_channels < 1 || cfg->residual_channels < 1 ||
         cfg->skip_channels < 1 || cfg->end_channels < 1 || cfg->classes < 2 || cfg->n_streams < 1)
         return wn_fail(WN_E_BADARG, "wn_create: non-positive dimension in wn_config");
@@ -548,7 +607,44 @@ extern "C" int wn_create(const wn_config* cfg, wn_handle** out) {
     return WN_OK;
 }
 
+// the caller's weights copied into zero-filled arrays of the padded shape
+static int wn_load_weights_padded(wn_handle* h, const wn_weight_ptrs* w) {
+    const WnPlan& pl = h->plan;
+    const int R = h->user_R, D = h->user_D, S = h->user_S, E = h->user_E, R2 = pl.R, D2 = pl.D, S2 = pl.S, E2 = pl.E, C = pl.C, NL = pl.NL, k = pl.k;
+    if (!w->start_w || !w->filter_w || !w->gate_w || !w->res_w || !w->skip_w || !w->end1_w || !w->end1_b || !w->end2_w || !w->end2_b)
+        return wn_fail(WN_E_BADARG, "wn_load_weights: a mandatory weight pointer is NULL");
+    if (pl.has_bias && (!w->start_b || !w->filter_b || !w->gate_b || !w->res_b || !w->skip_b))
+        return wn_fail(WN_E_BADARG, "wn_load_weights: cfg.bias=1 but a stack bias pointer is NULL");
+    // dst[n][a][b] (extents A2, B2, inner run of `in` floats) <- src[n][a][b] (extents A, B)
+    auto pad3 = [](const float* src, int n, int A, int B, int A2, int B2, int in) {
+        std::vector<float> dst((size_t)n * A2 * B2 * in, 0.f);
+        for (int i = 0; i < n; ++i)
+            for (int a = 0; a < A; ++a)
+                memcpy(dst.data() + (((size_t)i * A2 + a) * B2) * in, src + (((size_t)i * A + a) * B) * in, (size_t)B * in * 4);
+        return dst;
+    };
+    std::vector<float> start_w = pad3(w->start_w, 1, R, C, R2, C, 1);
+    std::vector<float> filter_w = pad3(w->filter_w, NL, D, R, D2, R2, k), gate_w = pad3(w->gate_w, NL, D, R, D2, R2, k);
+    std::vector<float> res_w = pad3(w->res_w, NL, R, D, R2, D2, 1), skip_w = pad3(w->skip_w, NL, S, D, S2, D2, 1);
+    std::vector<float> end1_w = pad3(w->end1_w, 1, E, S, E2, S2, 1), end1_b = pad3(w->end1_b, 1, 1, E, 1, E2, 1);
+    std::vector<float> end2_w = pad3(w->end2_w, 1, C, E, C, E2, 1);
+    std::vector<float> start_b, filter_b, gate_b, res_b, skip_b;
+    wn_weight_ptrs p = *w;
+    p.start_w = start_w.data(); p.filter_w = filter_w.data(); p.gate_w = gate_w.data(); p.res_w = res_w.data(); p.skip_w = skip_w.data();
+    p.end1_w = end1_w.data(); p.end1_b = end1_b.data(); p.end2_w = end2_w.data();
+    if (pl.has_bias) {
+        start_b = pad3(w->start_b, 1, 1, R, 1, R2, 1); filter_b = pad3(w->filter_b, NL, 1, D, 1, D2, 1); gate_b = pad3(w->gate_b, NL, 1, D, 1, D2, 1);
+        res_b = pad3(w->res_b, NL, 1, R, 1, R2, 1); skip_b = pad3(w->skip_b, NL, 1, S, 1, S2, 1);
+        p.start_b = start_b.data(); p.filter_b = filter_b.data(); p.gate_b = gate_b.data(); p.res_b = res_b.data(); p.skip_b = skip_b.data();
+    }
+    h->padded = false;   // (the padded arrays are this handle's shape)
+    const int rc = wn_load_weights(h, &p);
+    h->padded = true;
+    return rc;
+}
+
 extern "C" int wn_load_weights(wn_handle* h, const wn_weight_ptrs* w) {
+    if (h && w && h->padded) { g_err[0] = 0; return wn_load_weights_padded(h, w); }
     if (h && !h->chains.empty()) {
         for (wn_handle* c : h->chains) { int rc = wn_load_weights(c, w); if (rc) return rc; }
         h->have_weights = true;
@@ -861,7 +957,8 @@ extern "C" int wn_export_queue(wn_handle* h, int32_t layer, int32_t stream, floa
     // slice c = 0 holds the layer's queue (all P slices keep identical copies)
     int rc = rt_d2h(tmp.data(), h->d_rings + h->ring_off[layer] + (size_t)stream * ML * pl.R, tmp.size() * 4);
     if (rc) return rc;
-    for (int r = 0; r < pl.R; ++r)
+    const int R_out = h->export_R ? h->export_R : pl.R;   // (zero padding: the caller's channels are the first ones)
+    for (int r = 0; r < R_out; ++r)
         for (int m = 0; m < ML; ++m) host_data[(size_t)r * ML + m] = tmp[(size_t)m * pl.R + r];  // (slot, R) -> (R, max_length)
     if (in_pos) *in_pos = (int32_t)(h->t_base % ML);  // one enqueue + one dequeue per evaluation
     if (out_pos) *out_pos = (int32_t)(h->t_base % ML);

@@ -59,6 +59,7 @@ extern "C" int wn_train_get_layout(wn_handle* h, wn_train_layout* out) {
     if (!h->chains.empty()) return wn_train_get_layout(h->chains[0], out);
     if (!h->have_weights) return wn_fail(WN_E_STATE, "wn_train_get_layout: wn_load_weights has not been called");
     if (!h->fw_ok) return wn_fail(WN_E_UNSUPPORTED, "wn_train: needs kernel_size 2 and channel counts that are multiples of 32");
+    if (h->padded) return wn_fail(WN_E_UNSUPPORTED, "wn_train: this handle runs a zero-padded channel shape (its parameter layout is not the caller's)");
     out->total = (int64_t)h->fw_floats;
     out->fg = h->fw_off_fg; out->bfg = h->fw_off_bfg; out->res = h->fw_off_res; out->bres = h->fw_off_bres;
     out->skip = h->fw_off_skip; out->bskip = h->fw_off_bskip; out->bskip_total = h->fw_off_bskip_total;
@@ -73,6 +74,7 @@ extern "C" int wn_train_export_params(wn_handle* h, float* params, void* hip_str
     if (!h->chains.empty()) return wn_train_export_params(h->chains[0], params, hip_stream);
     if (!h->have_weights) return wn_fail(WN_E_STATE, "wn_train_export_params: wn_load_weights has not been called");
     if (!h->fw_ok) return wn_fail(WN_E_UNSUPPORTED, "wn_train: needs kernel_size 2 and channel counts that are multiples of 32");
+    if (h->padded) return wn_fail(WN_E_UNSUPPORTED, "wn_train: this handle runs a zero-padded channel shape (its parameter layout is not the caller's)");
     { int rc = rt_hip(hipSetDevice(h->cfg.device_id), "hipSetDevice"); if (rc) return rc; }
     return rt_hip(hipMemcpyAsync(params, h->d_fw, h->fw_floats * 4, hipMemcpyDeviceToDevice, (hipStream_t)hip_stream), "hipMemcpyAsync(params)");
 }
@@ -133,6 +135,7 @@ extern "C" int wn_train_forward(wn_handle* h, const float* params, const int32_t
     const WnPlan& pl = h->plan;
     const int R = pl.R, D = pl.D, S = pl.S, E = pl.E, C = pl.C, NL = pl.NL;
     if (!h->fw_ok) return wn_fail(WN_E_UNSUPPORTED, "wn_train_forward: needs kernel_size 2 and channel counts that are multiples of 32");
+    if (h->padded) return wn_fail(WN_E_UNSUPPORTED, "wn_train_forward: this handle runs a zero-padded channel shape (its parameter layout is not the caller's)");
     const long long rf = 1 + (long long)pl.blocks * ((1 << pl.layers) - 1);
     if (L < rf + out_len - 1)
         return wn_fail(WN_E_UNSUPPORTED, "wn_train_forward: L=%lld < receptive_field + output_length - 1 = %lld (the reference zero-pads "

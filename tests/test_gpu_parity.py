@@ -31,7 +31,8 @@ SMALL = [
 
 def _expected_variant(cfg, ns, layer_split=0):
     """3 = wave-specialised kernel (csrc/wn_kernel_v3.h): every instantiated channel shape -- all BASELINE configs and the
-    train_script.py shape (32 / 32 / 1024 / 512, split two ways); 1 = the generic LDS-resident kernel (any other shape, or pinned).
+    train_script.py shape (32 / 32 / 1024 / 512, split two ways); 1 = the generic LDS-resident kernel (pinned, or pinned splits; other
+    shapes are zero-padded into a table shape: test_zero_padded_channel_shapes).
     (2 was the 256-thread register kernels of rounds 1-2: removed in round 3.)"""
     cfg = synth.CONFIGS[cfg] if isinstance(cfg, str) else cfg
     shape = (cfg["residual_channels"], cfg["dilation_channels"], cfg["skip_channels"], cfg["end_channels"])
@@ -361,6 +362,46 @@ def test_wave_specialised_kernel(label, cfg, ns, N, n_given):
             o_idx, _ = c_oracle.generate(cfg, W, N, first[s], 0.9, 0.002, uniforms[s])
             assert np.array_equal(out[s], o_idx), (label, s)
     print(label, sres, info)
+    eng.close()
+
+
+PADDED = [
+    # label, channel shape (dilation, residual, skip, end), layers x blocks, bias, streams: shapes the wave-specialised kernel is NOT compiled for
+    ("pad_to_cfg1_shape", (24, 24, 200, 100), (4, 2), True, 2),     # -> 32 / 32 / 256 / 128
+    ("pad_to_cfg2_shape", (20, 40, 256, 250), (3, 2), False, 1),    # -> 64 / 64 / 256 / 256 (residual != dilation channels)
+    ("pad_to_cfg3_shape", (48, 48, 300, 200), (4, 2), True, 5),     # -> 128 / 128 / 512 / 224
+    ("odd_counts", (10, 7, 13, 9), (4, 2), True, 2),                # the ODD shape without pinned splits
+]
+
+
+@pytest.mark.parametrize("label,chans,depth,bias,ns", PADDED, ids=[c[0] for c in PADDED])
+def test_zero_padded_channel_shapes(label, chans, depth, bias, ns):
+    """A kernel_size-2, 256-class model whose channel counts are not an instantiated shape runs on the wave-specialised kernel as the
+    next shape that holds it, weights padded with zeros (wn_pad_config): same indices and logits as the oracle of the UNPADDED model,
+    queues exported with the caller's channel count, batched priming included; wn_train_* refuse such a handle."""
+    import ctypes
+    from mi355_wavenet import _abi
+    cfg = dict(layers=depth[0], blocks=depth[1], dilation_channels=chans[0], residual_channels=chans[1], skip_channels=chans[2],
+               end_channels=chans[3], classes=256, kernel_size=2, bias=bias)
+    N, n_given = 120, 40
+    cfg, W, first, uniforms = make_case(cfg, 91, ns, n_given, N)
+    eng = engine.Engine(cfg, W, n_streams=ns)
+    info = eng.info()
+    assert info["kernel_variant"] == 3, info
+    g = check_engine(eng, cfg, W, N, first, 0.0, 0.0, None, label + " greedy")
+    s = check_engine(eng, cfg, W, N, first, 0.9, 0.001, uniforms, label + " sampled")
+    a = eng.generate(N, first, temperature=0.0)   # (batched priming: wn_prime on the padded banks where the padded shape has them)
+    r = restated.RestatedWaveNet(cfg, W)
+    _, ridx, _ = r.generate_fast(N, first_samples=first[ns - 1], temperature=0.0, return_details=True)
+    assert np.array_equal(a[ns - 1], ridx)
+    for layer in (0, cfg["layers"] - 1, cfg["layers"] * cfg["blocks"] - 1):
+        data, ip, op = eng.export_queue(layer, stream=ns - 1)
+        q = r.queues[layer]
+        assert data.shape == tuple(q.data.shape) and (ip, op) == (q.in_pos, q.out_pos)
+        assert np.allclose(data, q.data.numpy(), rtol=0, atol=5e-6)
+    lay = _abi.wn_train_layout()
+    assert eng.lib.dll.wn_train_get_layout(eng._h, ctypes.byref(lay)) == _abi.WN_E_UNSUPPORTED
+    print(label, "greedy", g, "sampled", s, info)
     eng.close()
 
 
