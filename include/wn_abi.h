@@ -57,7 +57,7 @@ typedef struct wn_config {
     int32_t device_id;         /* HIP device ordinal */
     int32_t layer_split;       /* workgroups (CUs) that share one layer; 0 = choose automatically */
     int32_t head_split;        /* workgroups that share end_conv_1/end_conv_2; 0 = automatic */
-    int32_t reserved[3];       /* must be 0 */
+    int32_t reserved[3];       /* [0]: bit 0 = WN_CFG_NO_PADDING, every other bit 0; [1], [2]: must be 0 */
 } wn_config;
 
 /* Host pointers to fp32 parameters in the reference's nn.Conv1d layout (out, in, k), the per-layer
@@ -130,6 +130,10 @@ typedef struct wn_info {
     int32_t dev_overrides;    /* 1 iff WN_TESTING=1 let a development override (WN_KERNEL, WN_V3_MODE, ...) change what the planner chose */
 } wn_info;
 
+/* wn_config.reserved[0]: plan the model's OWN channel shape (no zero padding into a compiled kernel shape, see wn_create): what a
+ * handle that serves wn_train_* needs, whose parameter layout must be the caller's. */
+#define WN_CFG_NO_PADDING 1
+
 typedef struct wn_handle wn_handle;
 
 int wn_abi_version(void);
@@ -139,7 +143,8 @@ int wn_abi_version(void);
  * Channel counts the wave-specialised kernel is not compiled for are served by zero padding (kernel_size 2, 256 classes,
  * no pinned split): the handle then runs the next instantiated shape that holds the model, wn_load_weights pads the
  * caller's arrays with zeros, results are those of the caller's model, wn_export_queue returns the caller's channels,
- * wn_train_* return WN_E_UNSUPPORTED (weight_bytes / queue_bytes of wn_info are the padded model's). */
+ * wn_train_* return WN_E_UNSUPPORTED (weight_bytes / queue_bytes of wn_info are the padded model's).
+ * cfg->reserved[0] & WN_CFG_NO_PADDING switches the padding off. */
 int wn_create(const wn_config* cfg, wn_handle** out);
 void wn_destroy(wn_handle* h);
 

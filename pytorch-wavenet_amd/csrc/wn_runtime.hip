@@ -365,7 +365,7 @@ static int wn_create_impl(const wn_config* cfg, wn_handle** out);
 // in the table of the wave-specialised kernel (e.g. 48 / 48 / 300 / 200) runs as the cheapest instantiated shape that holds it instead
 // of on the generic LDS-resident kernel (last measured 6-13x slower).  Not applied when the caller pins layer_split / head_split.
 static bool wn_pad_config(const wn_config* cfg, int n_cu, wn_config* padded) {
-    if (cfg->kernel_size != 2 || cfg->classes != 256 || cfg->layer_split > 0 || cfg->head_split > 0) return false;
+    if (cfg->kernel_size != 2 || cfg->classes != 256 || cfg->layer_split > 0 || cfg->head_split > 0 || (cfg->reserved[0] & WN_CFG_NO_PADDING)) return false;
     wn_config probe = *cfg;
     if (probe.n_streams > WN_V3_ROUND_STREAMS) probe.n_streams = WN_V3_ROUND_STREAMS;
     if (wn_v3_applicable(&probe, n_cu, nullptr, nullptr, nullptr)) return false;   // served as it is
@@ -421,7 +421,7 @@ static int wn_create_impl(const wn_config* cfg, wn_handle** out) {
         return wn_fail(WN_E_BADARG, "wn_create: non-positive dimension in wn_config");
     if (cfg->kernel_size < 1) return wn_fail(WN_E_BADARG, "wn_create: kernel_size must be >= 1");
     if (cfg->layers > 24) return wn_fail(WN_E_UNSUPPORTED, "wn_create: layers > 24 (dilation 2^layers overflows the queue)");
-    if (cfg->layer_split < 0 || cfg->head_split < 0 || cfg->reserved[0] || cfg->reserved[1] || cfg->reserved[2])
+    if (cfg->layer_split < 0 || cfg->head_split < 0 || (cfg->reserved[0] & ~WN_CFG_NO_PADDING) || cfg->reserved[1] || cfg->reserved[2])
         return wn_fail(WN_E_BADARG, "wn_create: negative split / non-zero reserved field");
     int n_cu = 256, wall_khz = 100000;
     {

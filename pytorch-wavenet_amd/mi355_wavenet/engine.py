@@ -75,10 +75,11 @@ class _Resident:
 
 
 class Engine:
-    def __init__(self, cfg, weights, n_streams=1, device_index=0, layer_split=0, head_split=0, lib=None, mem=None):
+    def __init__(self, cfg, weights, n_streams=1, device_index=0, layer_split=0, head_split=0, lib=None, mem=None, pad_channels=True):
         """lib / mem: the loaded C-ABI library and the memory provider (upload / empty / ptr / download / stream); the defaults are
         the HIP library and torch device memory.  (Dependency injection for the host-logic tests, which pass a test double of the C
-        ABI together with ITS memory provider -- tests/double_lib.py; nothing in this package knows about it.)"""
+        ABI together with ITS memory provider -- tests/double_lib.py; nothing in this package knows about it.)
+        pad_channels=False: no zero padding of a channel shape the fast kernel is not compiled for (include/wn_abi.h: wn_create)."""
         self.lib = lib if lib is not None else _abi.load_product_library()
         self.cfg = dict(cfg)
         self.n_streams = int(n_streams)
@@ -94,6 +95,8 @@ class Engine:
         c = _abi.wn_config(cfg["layers"], cfg["blocks"], cfg["dilation_channels"], cfg["residual_channels"],
                            cfg["skip_channels"], cfg["end_channels"], self.classes, cfg.get("kernel_size", 2),
                            int(bool(cfg.get("bias", False))), self.n_streams, device_index, layer_split, head_split)
+        if not pad_channels:  # WN_CFG_NO_PADDING: plan the model's own channel shape (a handle that serves wn_train_* must)
+            c.reserved[0] = 1
         self._h = ctypes.c_void_p()
         self.lib.check(self.lib.dll.wn_create(ctypes.byref(c), ctypes.byref(self._h)))
         self.load_weights(weights)

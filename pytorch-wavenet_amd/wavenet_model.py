@@ -181,7 +181,7 @@ class WaveNetModel(nn.Module):
         runner = getattr(self, "_wn_train_runner", None)
         dev = next(self.parameters()).device
         if runner is None or runner.device != dev:
-            eng = engine.Engine(self._config(), dict(self.state_dict()), n_streams=1, device_index=dev.index or 0)
+            eng = engine.Engine(self._config(), dict(self.state_dict()), n_streams=1, device_index=dev.index or 0, pad_channels=False)
             runner = training.StackRunner(eng)  # the handle only provides plan, layout and workspace: parameters are passed per call
             self._wn_train_runner = runner
         names, tensors = [], []

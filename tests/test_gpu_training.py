@@ -135,7 +135,7 @@ def test_packed_layout_matches_the_c_side():
     from mi355_wavenet import engine, training
     for bias in (False, True):
         m = _model(bias)
-        eng = engine.Engine(m._config(), dict(m.state_dict()), n_streams=1, device_index=0)
+        eng = engine.Engine(m._config(), dict(m.state_dict()), n_streams=1, device_index=0, pad_channels=False)  # (a training handle keeps the model's own shape)
         r = training.StackRunner(eng)
         sd = m.state_dict()
         NL = m.layers * m.blocks
@@ -354,7 +354,7 @@ def test_training_abi_error_codes():
     import ctypes
     from mi355_wavenet import _abi, engine, training
     m = _model(False)
-    eng = engine.Engine(m._config(), dict(m.state_dict()), n_streams=1, device_index=0)
+    eng = engine.Engine(m._config(), dict(m.state_dict()), n_streams=1, device_index=0, pad_channels=False)  # (a training handle keeps the model's own shape)
     r = training.StackRunner(eng)
     d = eng.lib.dll
     flat = r.export_params()
