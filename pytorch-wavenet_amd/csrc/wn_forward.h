@@ -26,6 +26,8 @@
 
 #include <type_traits>
 
+#include "wn_plan.h"
+
 typedef float wn_f16v __attribute__((ext_vector_type(16)));
 
 // address of logical row m of a (batch, time) matrix: base + (m / rows_per_batch) * batch_stride + (t0 + m % rows_per_batch) * row_stride
@@ -41,17 +43,7 @@ static __device__ __forceinline__ const float* wn_row(const WnRowMap& r, long lo
 
 enum { WN_EPI_PLAIN = 0, WN_EPI_GATE = 1, WN_EPI_GATE_BWD = 2 };
 
-// Workgroup -> tile, XCD-aware.  The products here are streams over their row operand, and every tile that shares rows with another one
-// (the column tiles of one row tile; the weight-gradient tiles of one row split) re-reads them.  Workgroups are dispatched in id order,
-// round-robin over the 8 XCDs (id % 8), each with its own L2: the `nshare` tiles of a sharing group are given ids 8 apart and
-// consecutive in time -- same XCD, same moment -- so the group's rows come from HBM once and from that L2 afterwards.
-// Grids are 1-D: 8 * nshare * ceil(ngroups / 8) workgroups; returns false for the padding (group >= ngroups).
-static __device__ __forceinline__ bool wn_tile_of(unsigned id, unsigned nshare, unsigned ngroups, unsigned& group, unsigned& member) {
-    const unsigned xcd = id & 7u, slot = id >> 3;
-    member = slot % nshare;
-    group = (slot / nshare) * 8u + xcd;
-    return group < ngroups;
-}
+// (workgroup -> tile mapping of the weight-gradient products: wn_tile_of, wn_plan.h)
 
 
 struct WnGemmArgs {

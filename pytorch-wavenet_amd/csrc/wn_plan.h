@@ -369,4 +369,63 @@ static inline bool wn_make_wg_map_layers(int NL, int P, int PA, int n_smp, int n
     }
     return false;
 }
+
+// ---- batched products (wn_forward.h): tile mapping and grids
+#if defined(__HIPCC__)
+#define WN_HD __host__ __device__
+#else
+#define WN_HD
+#endif
+// Workgroup -> tile, XCD-aware.  The weight-gradient products are streams over their row operands, and every tile of one row split
+// re-reads the split's rows.  Workgroups are dispatched in id order, round-robin over the 8 XCDs (id % 8), each with its own L2: the
+// `nshare` tiles of a sharing group are given ids 8 apart and consecutive in time -- same XCD, same moment -- so the group's rows
+// come from HBM once and from that L2 afterwards.  Grids are 1-D: 8 * nshare * ceil(ngroups / 8) workgroups; returns false for the
+// padding (group >= ngroups).
+static inline WN_HD bool wn_tile_of(unsigned id, unsigned nshare, unsigned ngroups, unsigned& group, unsigned& member) {
+    const unsigned xcd = id & 7u, slot = id >> 3;
+    member = slot % nshare;
+    group = (slot / nshare) * 8u + xcd;
+    return group < ngroups;
+}
+// Grid of a weight-gradient product C[Ka][Nb] += A^T B over M rows with tiles of 128 x tile_nb: the rows are split so that about
+// `want` workgroups exist (the resident ones), never below 256 rows per split (every split ends with a tile of atomics), in whole
+// rounds of 8 splits where there are that many (wn_tile_of puts a split's tiles on one XCD: 25 splits would load one XCD with four
+// splits and the others with three), each a multiple of 32 rows.
+struct WnTnGrid { int tiles_ka, tiles_nb, splits; long long rows_per_split; unsigned blocks; };
+static inline WnTnGrid wn_tn_grid(long long M, int Ka, int Nb, int tile_nb, int want) {
+    WnTnGrid g;
+    g.tiles_ka = (Ka + 127) / 128; g.tiles_nb = (Nb + tile_nb - 1) / tile_nb;
+    const int tiles = g.tiles_ka * g.tiles_nb;
+    long long splits = want / tiles > 1 ? want / tiles : 1;
+    const long long most = (M + 255) / 256;
+    if (splits > most) splits = most;
+    if (splits >= 8) splits -= splits % 8;
+    if (splits < 1) splits = 1;
+    long long rps = (M + splits - 1) / splits;
+    rps = (rps + 31) / 32 * 32;
+    splits = (M + rps - 1) / rps;
+    g.splits = (int)splits; g.rows_per_split = rps;
+    g.blocks = 8u * (unsigned)tiles * (unsigned)((splits + 7) / 8);
+    return g;
+}
+
+// ---- zero padding of channel shapes (wn_create): the cheapest compiled shape that HOLDS the model.  `rows`: the kernel table
+// (residual channels, dilation-channel slice, skip channels, end-channel slice, slices per layer); `usable(R, D, S, E)`: the caller's
+// check that the padded configuration can be planned (LDS, CU count).  Cost: workgroups on the token's path first (layers x slices +
+// head slices), then the arithmetic.  Returns the row's index or -1; the padded counts in out[4] = {R, D, S, E}.
+struct WnShapeRow { int R, DC, S, EC, Pm; };
+template <class Usable>
+static inline int wn_pad_pick(const WnShapeRow* rows, int n_rows, int R, int D, int S, int E, int n_layers, Usable usable, int out[4]) {
+    long long best = -1;
+    int pick = -1;
+    for (int i = 0; i < n_rows; ++i) {
+        const WnShapeRow& e = rows[i];
+        const int D2 = e.DC * e.Pm, E2 = (E + e.EC - 1) / e.EC * e.EC;
+        if (e.R < R || e.S < S || D2 < D || E2 / e.EC > 16) continue;
+        if (!usable(e.R, D2, e.S, E2)) continue;
+        const long long cost = ((long long)n_layers * e.Pm + E2 / e.EC) * 100000000ll + (long long)e.R * D2 + (long long)e.S * (D2 + E2);
+        if (best < 0 || cost < best) { best = cost; pick = i; out[0] = e.R; out[1] = D2; out[2] = e.S; out[3] = E2; }
+    }
+    return pick;
+}
 #endif  // WN_PLAN_H

@@ -369,18 +369,19 @@ static bool wn_pad_config(const wn_config* cfg, int n_cu, wn_config* padded) {
     wn_config probe = *cfg;
     if (probe.n_streams > WN_V3_ROUND_STREAMS) probe.n_streams = WN_V3_ROUND_STREAMS;
     if (wn_v3_applicable(&probe, n_cu, nullptr, nullptr, nullptr)) return false;   // served as it is
-    long long best = -1;
-    for (const WnV2Entry& e : wn_v2_table()) {
-        const int D2 = e.DC * e.Pm, E2 = (cfg->end_channels + e.EC - 1) / e.EC * e.EC;
-        if (e.R < cfg->residual_channels || e.S < cfg->skip_channels || D2 < cfg->dilation_channels || E2 / e.EC > 16) continue;
-        wn_config c = probe;
-        c.residual_channels = e.R; c.dilation_channels = D2; c.skip_channels = e.S; c.end_channels = E2;
-        if (!wn_v3_applicable(&c, n_cu, nullptr, nullptr, nullptr)) continue;
-        // cheapest: fewest workgroups on the token's path, then the least arithmetic
-        const long long cost = ((long long)cfg->layers * cfg->blocks * e.Pm + E2 / e.EC) * 100000000ll + (long long)e.R * D2 + (long long)e.S * (D2 + E2);
-        if (best < 0 || cost < best) { best = cost; *padded = *cfg; padded->residual_channels = e.R; padded->dilation_channels = D2; padded->skip_channels = e.S; padded->end_channels = E2; }
-    }
-    return best >= 0;
+    std::vector<WnShapeRow> rows;
+    for (const WnV2Entry& e : wn_v2_table()) rows.push_back(WnShapeRow{e.R, e.DC, e.S, e.EC, e.Pm});
+    int dims[4];
+    const int pick = wn_pad_pick(rows.data(), (int)rows.size(), cfg->residual_channels, cfg->dilation_channels, cfg->skip_channels, cfg->end_channels,
+                                 cfg->layers * cfg->blocks, [&](int R2, int D2, int S2, int E2) {
+                                     wn_config c = probe;
+                                     c.residual_channels = R2; c.dilation_channels = D2; c.skip_channels = S2; c.end_channels = E2;
+                                     return wn_v3_applicable(&c, n_cu, nullptr, nullptr, nullptr);
+                                 }, dims);
+    if (pick < 0) return false;
+    *padded = *cfg;
+    padded->residual_channels = dims[0]; padded->dilation_channels = dims[1]; padded->skip_channels = dims[2]; padded->end_channels = dims[3];
+    return true;
 }
 
 extern "C" int wn_create(const wn_config* cfg, wn_handle** out) {

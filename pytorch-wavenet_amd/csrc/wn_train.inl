@@ -88,24 +88,12 @@ static void wn_launch_cvt_t(hipStream_t st, const float* in, long long in_batch_
 #define WN_TN_MERGE_TAPS 1
 #endif
 static void wn_launch_tn(hipStream_t st, WnGemmTnArgs a, bool bf16 = false) {
-    // Split the rows so that ~1024 workgroups exist (four are resident per CU), but never below 256 rows per
-    // split: every split ends with a tile of atomics.  bf16 products with Nb % 256 == 0 take the 128 x 256 tile (A streamed once per
-    // 256 columns of B).
+    // bf16 products with Nb % 256 == 0 take the 128 x 256 tile (A streamed once per 256 columns of B); rows split by wn_tn_grid (wn_plan.h)
     const bool wide = bf16 && !a.a_idx && !a.a_bf16 && a.Nb % 256 == 0;
-    const int tb = wide ? 256 : 128;
-    const int tiles = ((a.Ka + 127) / 128) * ((a.Nb + tb - 1) / tb);
-    const int want = wide ? 512 : 1024;
-    long long splits = want / tiles > 1 ? want / tiles : 1;
-    const long long most = (a.M + 255) / 256;
-    if (splits > most) splits = most;
-    if (splits >= 8) splits -= splits % 8;   // the tiles of a split share an XCD (wn_tile_of): whole rounds of 8 keep the XCDs level
-    if (splits < 1) splits = 1;
-    long long rps = (a.M + splits - 1) / splits;
-    rps = (rps + 31) / 32 * 32;
-    splits = (a.M + rps - 1) / rps;
-    a.rows_per_split = rps;
-    a.tiles_ka = (a.Ka + 127) / 128; a.n_splits = (int)splits;
-    const dim3 grid(8u * (unsigned)tiles * (unsigned)((splits + 7) / 8));   // wn_tile_of: the tiles of a row split share an XCD
+    const WnTnGrid tg = wn_tn_grid(a.M, a.Ka, a.Nb, wide ? 256 : 128, wide ? 512 : 1024);
+    a.rows_per_split = tg.rows_per_split;
+    a.tiles_ka = tg.tiles_ka; a.n_splits = tg.splits;
+    const dim3 grid(tg.blocks);   // wn_tile_of: the tiles of a row split share an XCD
     // (b_bf16 / a_bf16: that operand is stored as bf16 -- [dF|dG] in the filter/gate weight gradient, z in the residual and skip ones)
     if (wide && a.b_bf16) hipLaunchKernelGGL((wn_bwd_gemm_tn_bf16<8, false, true>), grid, dim3(512), 0, st, a);
     else if (wide) hipLaunchKernelGGL((wn_bwd_gemm_tn_bf16<8, false, false>), grid, dim3(512), 0, st, a);

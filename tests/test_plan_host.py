@@ -23,6 +23,34 @@ int main(int argc, char** argv) {
         for (int n : wn_v3_round_sizes(atoi(argv[2]), WN_V3_ROUND_STREAMS)) printf("%d\n", n);
         return 0;
     }
+    if (argc >= 2 && argv[1][0] == 't') {  // t <nshare> <ngroups>: workgroup id -> (group, member) of the weight-gradient grids
+        const unsigned nshare = atoi(argv[2]), ngroups = atoi(argv[3]), blocks = 8u * nshare * ((ngroups + 7u) / 8u);
+        for (unsigned id = 0; id < blocks; ++id) {
+            unsigned g, m;
+            const bool ok = wn_tile_of(id, nshare, ngroups, g, m);
+            printf("%u %d %u %u\n", id, ok ? 1 : 0, g, m);
+        }
+        return 0;
+    }
+    if (argc >= 2 && argv[1][0] == 'g') {  // g <M> <Ka> <Nb> <tile_nb> <want>: grid of a weight-gradient product
+        const WnTnGrid g = wn_tn_grid(atoll(argv[2]), atoi(argv[3]), atoi(argv[4]), atoi(argv[5]), atoi(argv[6]));
+        printf("%d %d %d %lld %u\n", g.tiles_ka, g.tiles_nb, g.splits, g.rows_per_split, g.blocks);
+        return 0;
+    }
+    if (argc >= 2 && argv[1][0] == 'p') {  // p <R> <D> <S> <E> <n_layers> [max_workgroups]: the compiled shape a model is zero-padded into
+        const WnShapeRow rows[] = {{128, 32, 512, 32, 4}, {64, 64, 256, 64, 1}, {32, 32, 256, 64, 1}, {32, 16, 1024, 32, 2}, {64, 32, 256, 64, 2},
+                                   {16, 16, 256, 32, 1}, {16, 16, 256, 32, 2}};   // csrc/wn_runtime.hip: wn_v2_table()
+        const int NL = atoi(argv[6]), cap = argc > 7 ? atoi(argv[7]) : 252;
+        int out[4] = {0, 0, 0, 0};
+        const int pick = wn_pad_pick(rows, 7, atoi(argv[2]), atoi(argv[3]), atoi(argv[4]), atoi(argv[5]), NL,
+                                     [&](int R2, int D2, int S2, int E2) {   // (stand-in for wn_v3_applicable: the chain must fit the CUs)
+                                         for (const WnShapeRow& e : rows)
+                                             if (e.R == R2 && e.S == S2 && e.DC * e.Pm == D2 && E2 % e.EC == 0) return NL * e.Pm + E2 / e.EC <= cap;
+                                         return false;
+                                     }, out);
+        printf("%d %d %d %d %d\n", pick, out[0], out[1], out[2], out[3]);
+        return 0;
+    }
     const int NL = atoi(argv[1]), P = atoi(argv[2]), heads = atoi(argv[3]), n_smp = atoi(argv[4]);
     std::vector<int32_t> m;
     int nb = 0;
@@ -109,3 +137,61 @@ def test_round_sizes(harness, ns):
     assert max(sizes) - min(sizes) <= 3
     assert sum(1 for n in sizes if n % 2) <= 1  # at most the last round is odd
     assert all(n % 2 == 0 for n in sizes[:-1])
+
+
+@pytest.mark.parametrize("nshare,ngroups", [(1, 1), (2, 997), (2, 24), (20, 24), (20, 25), (5, 7), (3, 8)])
+def test_weight_gradient_tiles_share_an_xcd(harness, nshare, ngroups):
+    """wn_tile_of: every (row split, tile) exactly once, the padding rejected, all tiles of a split on ONE XCD (workgroup id % 8) and
+    next to each other in dispatch order (ids 8 apart), splits spread round-robin over the XCDs."""
+    rows = [tuple(int(x) for x in l.split()) for l in subprocess.check_output([harness, "t", str(nshare), str(ngroups)]).decode().splitlines()]
+    assert len(rows) == 8 * nshare * ((ngroups + 7) // 8)
+    live = [(g, m, i) for i, ok, g, m in rows if ok]
+    assert sorted((g, m) for g, m, _ in live) == [(g, m) for g in range(ngroups) for m in range(nshare)]
+    assert all(g >= ngroups for i, ok, g, m in rows if not ok)
+    for g in range(ngroups):
+        ids = sorted(i for gg, m, i in live if gg == g)
+        assert len({i % 8 for i in ids}) == 1 and ids == list(range(ids[0], ids[0] + 8 * nshare, 8))
+        assert ids[0] % 8 == g % 8
+
+
+@pytest.mark.parametrize("M,Ka,Nb,tile_nb,want", [(348320, 256, 256, 256, 512), (512000, 128, 128, 128, 1024), (348320, 512, 1280, 256, 512),
+                                                  (348320, 1280, 512, 256, 512), (700, 128, 128, 128, 1024), (64, 32, 64, 128, 1024), (5000, 256, 256, 256, 512)])
+def test_weight_gradient_grid(harness, M, Ka, Nb, tile_nb, want):
+    """wn_tn_grid: the splits cover every row, are multiples of 32 rows, never shorter than 256 rows unless there is only one, come in
+    whole rounds of 8 where there are that many (level XCDs), and the grid has room for every (split, tile)."""
+    tka, tnb, splits, rps, blocks = (int(x) for x in subprocess.check_output([harness, "g", str(M), str(Ka), str(Nb), str(tile_nb), str(want)]).decode().split())
+    assert tka == -(-Ka // 128) and tnb == -(-Nb // tile_nb)
+    assert rps % 32 == 0 and splits * rps >= M and (splits - 1) * rps < M
+    assert splits == 1 or rps >= 256
+    assert splits * tka * tnb <= max(want, tka * tnb) + 8 * tka * tnb   # about `want` workgroups
+    assert blocks == 8 * tka * tnb * -(-splits // 8) and blocks >= splits * tka * tnb
+    if M >= 8 * 256 * 2 and want // (tka * tnb) >= 8:
+        assert splits % 8 == 0 or splits * rps - M < rps    # whole rounds of 8 (the last split may be cut off by the row count)
+
+
+@pytest.mark.parametrize("model,n_layers,expect", [
+    ((24, 24, 200, 100), 8, (32, 32, 256, 128)),        # the cfg1-shape kernel
+    ((40, 20, 256, 250), 6, (64, 64, 256, 256)),        # residual != dilation channels: the unsplit 64-channel kernel (fewest workgroups)
+    ((48, 48, 300, 200), 8, (128, 128, 512, 224)),      # only the cfg3-shape kernel holds 300 skip channels next to 48 residual ones
+    ((7, 10, 13, 9), 8, (16, 16, 256, 32)),             # (R, D, S, E) of the tests' odd shape
+    ((32, 32, 1000, 500), 30, (32, 32, 1024, 512)),     # the train_script.py shape's kernel
+    ((32, 32, 256, 256), 10, (32, 32, 256, 256)),       # an exact table shape maps to itself
+    ((200, 128, 512, 256), 8, None),                    # wider than any compiled shape: not padded (generic kernel)
+    ((32, 32, 2000, 256), 8, None),
+])
+def test_zero_padding_picks_the_cheapest_shape_that_holds_the_model(harness, model, n_layers, expect):
+    out = [int(x) for x in subprocess.check_output([harness, "p"] + [str(x) for x in model] + [str(n_layers)]).decode().split()]
+    if expect is None:
+        assert out[0] == -1
+    else:
+        assert out[0] >= 0 and tuple(out[1:]) == expect
+        assert all(p >= m for p, m in zip(expect, model))
+
+
+def test_zero_padding_respects_the_planner(harness):
+    """A padded shape the chain cannot be planned for (here: more workgroups than CUs) is skipped for the next one that can."""
+    # 60 layers of 64 / 64 / 256: the two-slice 64-channel kernel needs 60 x 2 + 4 workgroups, the unsplit one 60 + 4
+    out = [int(x) for x in subprocess.check_output([harness, "p", "64", "64", "256", "256", "60", "100"]).decode().split()]
+    assert tuple(out[1:]) == (64, 64, 256, 256) and out[0] == 1
+    out = [int(x) for x in subprocess.check_output([harness, "p", "100", "100", "256", "256", "60", "100"]).decode().split()]
+    assert out[0] == -1   # only the cfg3-shape kernel holds 100 channels, and 60 x 4 slices do not fit 100 workgroups
