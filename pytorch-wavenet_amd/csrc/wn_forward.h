@@ -12,8 +12,11 @@
 //
 // evaluated only on the positions that can still reach the returned outputs (need_i = output_length + sum of the
 // dilations above layer i), then  logits = W2 . relu(W1 . relu(SKIP) + b1) + b2  on the last output_length positions.
-// All GEMMs run on v_mfma_f32_32x32x2_f32: fp32 in, fp32 accumulate, bit-for-bit an fmaf chain (MI355X guide), so the
-// result matches the reference's fp32 forward to rounding (tests: 1e-4).  bf16 operands are the obvious next step.
+// The default GEMMs run on v_mfma_f32_32x32x2_f32: fp32 in, fp32 accumulate, bit-for-bit an fmaf chain (MI355X guide), so the
+// result matches the reference's fp32 forward to rounding (tests: 1e-4).  wn_set_forward_precision selects the bf16 forms
+// (v_mfma_f32_32x32x16_bf16, fp32 accumulation): operands rounded while they are staged, and in the training step the activations
+// that only ever feed such operands stored as bf16 -- the products are HBM streams (K = 128-512), so the bytes are what they cost.
+// The same file holds the backward products of the training step (wn_train.inl is their host side).
 //
 // Valid when every returned position has a full receptive field: L >= receptive_field + output_length - 1 (the
 // reference's own training shape, train_script.py:39).  Shorter inputs hit the reference's zero-padding quirk
@@ -284,7 +287,7 @@ struct WnGemmArgsBf16 {
 };
 
 #ifndef WN_GEMM_BF16_KC
-#define WN_GEMM_BF16_KC 32    // config-5 forward: 64 (73.7 KB LDS, 2 workgroups per CU) 52.7 ms; 32 (41 KB, 3 per CU, 152 VGPRs) 40.8 ms
+#define WN_GEMM_BF16_KC 32    // config-5 forward (round 2): 64 (73.7 KB LDS, 2 workgroups per CU) 52.7 ms; 32 (41 KB, 3 per CU, 152 VGPRs) 40.8 ms
 #endif
 #ifndef WN_GEMM_BF16_MINB
 #define WN_GEMM_BF16_MINB 4   // 4-wave form: 4 workgroups per CU (exactly the CU's 160 KB of LDS, 128 VGPRs): 3 -> 4 took the residual / dx products from 346 to 314 us
