@@ -286,6 +286,9 @@ struct WnGemmArgsBf16 {
     int ldb;                   // 0 -> K
 };
 
+#ifndef WN_NN_COL_ADJ
+#define WN_NN_COL_ADJ 1   // column tiles of a row tile next to each other in dispatch order: grouped skip product 1176 -> 1097 us, dzg 1215 -> 1171 us
+#endif
 #ifndef WN_GEMM_BF16_KC
 #define WN_GEMM_BF16_KC 32    // config-5 forward (round 2): 64 (73.7 KB LDS, 2 workgroups per CU) 52.7 ms; 32 (41 KB, 3 per CU, 152 VGPRs) 40.8 ms
 #endif
@@ -309,7 +312,12 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? WN_GEMM_BF16_MINB : 4) voi
     __shared__ __attribute__((aligned(16))) unsigned short a_s[2][TM * LD];
     __shared__ __attribute__((aligned(16))) unsigned short b_s[2][TN * LD];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wr = wv & 3, wc = wv >> 2;
+#if WN_NN_COL_ADJ   // the column tiles of a row tile next to each other in dispatch order (different XCDs, same moment: the second read of the
+                    // row tile's A is served by the memory-side cache; the XCD-local variant of this -- ids 8 apart -- measured slower)
+    const unsigned ntiles = (unsigned)((g.N + TN - 1) / TN), tm_i = blockIdx.x / ntiles, tn_i = blockIdx.x % ntiles;
+#else
     const unsigned mtiles = (unsigned)((g.M + TM - 1) / TM), tm_i = blockIdx.x % mtiles, tn_i = blockIdx.x / mtiles;  // row tiles fastest
+#endif
     const long long m0 = (long long)tm_i * TM;
     const int n0 = (int)tn_i * TN;
     wn_f16v acc[4];
