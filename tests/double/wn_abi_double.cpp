@@ -68,6 +68,8 @@ extern "C" int wn_create(const wn_config* cfg, wn_handle** out) {
         return fail(WN_E_BADARG, "wn_create: non-positive dimension in wn_config");
     if (cfg->kernel_size < 1) return fail(WN_E_BADARG, "wn_create: kernel_size must be >= 1");
     if (cfg->layers > 24) return fail(WN_E_UNSUPPORTED, "wn_create: layers > 24");
+    if (cfg->layer_split < 0 || cfg->head_split < 0 || (cfg->reserved[0] & ~WN_CFG_NO_PADDING) || cfg->reserved[1] || cfg->reserved[2])
+        return fail(WN_E_BADARG, "wn_create: negative split / non-zero reserved field");   // (WN_CFG_NO_PADDING is accepted and means nothing here)
     wn_handle* h = new wn_handle();
     h->cfg = *cfg;
     h->oc = wno_config{cfg->layers, cfg->blocks, cfg->dilation_channels, cfg->residual_channels, cfg->skip_channels, cfg->end_channels,

@@ -74,3 +74,43 @@ def test_zero_samples_and_prime_only():
     idx = eng.generate(0, first, temperature=0.0)
     assert idx.shape == (1, 0)
     assert eng.info()["evals_done"] == 5
+
+
+def test_engine_passes_the_no_padding_flag_and_the_abi_rejects_other_reserved_bits():
+    """Engine(pad_channels=False) sets wn_config.reserved[0] = WN_CFG_NO_PADDING (a handle that serves wn_train_* keeps the model's own
+    channel shape: include/wn_abi.h); every other reserved bit is an argument error -- the same rule in the double as in the product."""
+    import ctypes
+    from mi355_wavenet import _abi, synth
+    cfg = synth.CONFIGS["tiny"]
+    W = synth.init_weights(cfg, seed=3)
+    seen = []
+    be = double_backend()
+    lib = be["lib"]
+    real = lib.dll.wn_create
+
+    class Spy:
+        def __init__(self, dll):
+            self._dll = dll
+
+        def __getattr__(self, name):
+            if name == "wn_create":
+                def create(cfg_ref, out):
+                    seen.append(int(ctypes.cast(cfg_ref, ctypes.POINTER(_abi.wn_config)).contents.reserved[0]))
+                    return real(cfg_ref, out)
+                return create
+            return getattr(self._dll, name)
+
+    dll = lib.dll
+    lib.dll = Spy(dll)
+    try:
+        engine.Engine(cfg, W, **be).close()
+        engine.Engine(cfg, W, pad_channels=False, **be).close()
+    finally:
+        lib.dll = dll
+    assert seen == [0, 1]
+    h = ctypes.c_void_p()
+    for bad in ((2, 0, 0), (0, 1, 0), (1, 0, 7)):
+        c = _abi.wn_config(cfg["layers"], cfg["blocks"], cfg["dilation_channels"], cfg["residual_channels"], cfg["skip_channels"],
+                           cfg["end_channels"], 256, 2, 0, 1, 0, 0, 0)
+        c.reserved[0], c.reserved[1], c.reserved[2] = bad
+        assert dll.wn_create(ctypes.byref(c), ctypes.byref(h)) == _abi.WN_E_BADARG
