@@ -142,12 +142,16 @@ class WaveNetModel(nn.Module):
         receptive field, shapes the GEMM kernels support.  Returns None otherwise -- the caller then runs the torch path,
         which also reproduces the reference's zero-padding quirk for short inputs.  A library that is not built is NOT a
         reason to fall back: on a CUDA tensor that raises (the product must not run silently without its kernels)."""
-        if not input.is_cuda or input.dim() != 3 or input.size(1) != self.classes or not self._native_supported():
+        if not input.is_cuda or input.dim() != 3 or input.size(1) != self.classes or self.kernel_size != 2:
             return None
         n, _, l = input.shape
         if l < self.receptive_field + self.output_length - 1:
             return None
         want_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        # Without autograd the engine decides: a channel shape that is not a multiple of 32 may still run natively, zero-padded into a
+        # compiled shape (include/wn_abi.h: wn_create); with autograd the handle keeps the model's own shape and needs the multiples.
+        if (want_grad or getattr(self, "_wn_forward_unsupported", False)) and not self._native_supported():
+            return None
         if torch.is_grad_enabled() and input.requires_grad:
             return None  # a gradient w.r.t. the one-hot input itself: torch path
         if want_grad and (input.dtype != torch.float32 or os.environ.get("WN_TORCH_BACKWARD") == "1"):
@@ -164,6 +168,8 @@ class WaveNetModel(nn.Module):
             out = eng.forward_indices(idx, self.output_length)
         except _abi.WnError as e:
             if e.code == _abi.WN_E_UNSUPPORTED:
+                if not want_grad and not self._native_supported():
+                    self._wn_forward_unsupported = True  # this channel shape has no native forward: do not ask again
                 return None  # e.g. N*L >= 2^31 rows: the torch graph handles it
             raise
         self._wn_forward_calls = getattr(self, "_wn_forward_calls", 0) + 1

@@ -150,3 +150,36 @@ def test_forward_equals_queue_path_logits_after_priming(cfgname):
         _, logits = eng.generate(1, window, temperature=0.0, want_logits=True, batched_prime=batched)
         assert np.abs(logits[:, 0, :] - fwd).max() <= 1e-5 * scale, (cfgname, batched, float(np.abs(logits[:, 0, :] - fwd).max()))
     eng.close()
+
+
+def test_forward_of_a_zero_padded_channel_shape():
+    """Channel counts that are not multiples of 32 (48 / 48 / 300 / 200, bias): the handle runs the model zero-padded into a compiled
+    shape (wn_pad_config), so forward() has a NATIVE path for it too -- same logits as the torch graph of the unpadded model, through the
+    engine and through the facade (no autograd)."""
+    cfg = dict(layers=3, blocks=2, dilation_channels=48, residual_channels=48, skip_channels=300, end_channels=200, classes=256,
+               kernel_size=2, bias=True)
+    m, W = _model(cfg, 95, 6)
+    ids = np.random.RandomState(95).randint(0, 256, (2, m.receptive_field + 6 - 1 + 4))
+    x = _onehot(ids)
+    with torch.no_grad():
+        ref = m(x).numpy()
+    eng = engine.Engine(cfg, W)
+    assert eng.info()["kernel_variant"] == 3
+    y = eng.forward_indices(ids, 6).cpu().numpy()
+    eng.close()
+    mg = m.cuda()
+    with torch.no_grad():
+        yf = mg(x.cuda())
+    calls = getattr(mg, "_wn_forward_calls", 0)
+    dev_e, dev_f, scale = float(np.abs(y - ref).max()), float(np.abs(yf.cpu().numpy() - ref).max()), float(np.abs(ref).max())
+    print("padded forward: engine dev", dev_e, "facade dev", dev_f, "scale", scale, "native facade calls", calls)
+    assert y.shape == ref.shape and dev_e <= TOL * max(1.0, scale), ("engine", dev_e, scale)
+    assert dev_f <= TOL * max(1.0, scale), ("facade", dev_f, scale)
+    assert calls == 1, "the facade did not take the native path"
+    tiny = wavenet_model.WaveNetModel(layers=2, blocks=2, dilation_channels=8, residual_channels=8, skip_channels=16, end_channels=16,
+                                      classes=256, output_length=4, kernel_size=2, bias=False).cuda()
+    xt = _onehot(np.random.RandomState(96).randint(0, 256, (1, tiny.receptive_field + 3))).cuda()
+    with torch.no_grad():
+        a = tiny(xt)     # 8 channels pad into the 16-channel kernel, which has no GEMM banks: the torch graph answers, once and for all
+        b = tiny(xt)
+    assert torch.equal(a, b) and getattr(tiny, "_wn_forward_calls", 0) == 0 and tiny._wn_forward_unsupported
