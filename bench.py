@@ -37,6 +37,7 @@ WORKLOADS = {  # name -> (BASELINE.json config, streams per GPU)
     "chaconnex1": ("chaconne", 1),  # the only trained-model configuration in the reference tree (train_script.py:17-25: 32/32/1024/512, bias)
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+CPU_CELL_REPS = 3      # timed runs per cell of the CPU baseline matrix (the median is reported)
 
 
 def _rank_stats(dist, kernel_ms, gather_ms, facade_ms=None):
@@ -306,8 +307,8 @@ def cpu_baseline(cfgname, budget_s=3.0):
     """The reference's CPU path (torch restatement of generate_fast, oracle/restated.py, proven bit-equal to the real reference in
     tests/test_oracle_pinning.py) timed on this box's host cores, as BASELINE.md section 3 plans it: a bounded single-stream sample of
     cfg1, cfg2 and cfg3, each with 1 torch thread and with torch's default thread count (~3 s of CPU work per cell).  The path is
-    framework-dispatch bound (203 tiny conv1d calls per sample at cfg3): threads do not help.  ``value`` is the headline
-    configuration's best cell; ``matrix`` holds all of them."""
+    framework-dispatch bound (203 tiny conv1d calls per sample at cfg3): threads do not help.  Every cell is the MEDIAN of
+    CPU_CELL_REPS timed runs; ``value`` is the headline configuration's best cell; ``matrix`` holds all of them."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import restated
     from mi355_wavenet import synth
@@ -325,11 +326,14 @@ def cpu_baseline(cfgname, budget_s=3.0):
             t0 = time.perf_counter()
             r.generate_fast(n, temperature=1.0, return_details=True)
             dt = time.perf_counter() - t0
-            n2 = int(max(20, min(3000, budget_s / (dt / n))))
-            t0 = time.perf_counter()
-            r.generate_fast(n2, temperature=1.0, return_details=True)
-            rate = n2 / (time.perf_counter() - t0)
-            matrix["%s/%d threads" % (name, threads)] = {"samples_per_s": round(rate, 2), "samples": n2}
+            n2 = int(max(20, min(3000, budget_s / CPU_CELL_REPS / (dt / n))))
+            rates = []
+            for _ in range(CPU_CELL_REPS):   # median of CPU_CELL_REPS timed runs: one run is at the mercy of the box's other tenants
+                t0 = time.perf_counter()
+                r.generate_fast(n2, temperature=1.0, return_details=True)
+                rates.append(n2 / (time.perf_counter() - t0))
+            rate = float(np.median(rates))
+            matrix["%s/%d threads" % (name, threads)] = {"samples_per_s": round(rate, 2), "samples": n2, "runs": [round(v, 2) for v in rates]}
             if name == cfgname and (best is None or rate > best[0]):
                 best = (rate, threads, n2)
     torch.set_num_threads(default_threads)
@@ -341,7 +345,7 @@ def cpu_baseline(cfgname, budget_s=3.0):
                               "replays its ATen op sequence and is pinned bit-equal to the real reference's generate_fast() "
                               "(tests/test_oracle_pinning.py, fixtures from tests/golden/make_golden.py)",
             "sample": "%s single stream, %d samples of generate_fast(temperature=1.0) through oracle/restated.py "
-                      "(op-for-op torch restatement of the reference's CPU path; best of 1 and %d torch threads, "
+                      "(op-for-op torch restatement of the reference's CPU path; median of 3 runs per cell, best of 1 and %d torch threads, "
                       "host has %d logical cores)" % (cfgname, best[2], default_threads, os.cpu_count()),
             "matrix": matrix}
 
@@ -349,7 +353,7 @@ def cpu_baseline(cfgname, budget_s=3.0):
 def _pmc_traffic(a, info, per_gpu):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json: FETCH_SIZE + WRITE_SIZE of one launch,
     separate passes), scaled to this launch's timesteps -- hand-off traffic is linear in them.  The file names the kernel, its form and
-    the date it was measured; the figure is REFUSED (traffic null, the reason in traffic_source) when the library that just ran is not
+    the date it was measured; the figure is REFUSED (traffic null, the reason in traffic_replayed_from) when the library that just ran is not
     that kernel in that form: a stale constant must not pass for a measurement of this build."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if a.scaling != "weak" or not os.path.exists(path):
@@ -399,6 +403,9 @@ def main():
                          "sharded over the GPUs (512 / N per GPU)")
     ap.add_argument("--train-precision", default="bf16", choices=["bf16", "fp32"],
                     help="train5 only: matrix operand precision (BASELINE configs[4] names bf16 MFMA; fp32 = the parity default of the facade)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="run through the distributed code path (RCCL process group, pick_device, gather, all-reduce of the timings) even "
+                         "with ONE rank: the multi-GPU path exercised on a 1-GPU box")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
     a = ap.parse_args()
@@ -409,9 +416,15 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    if world > 1 or a.force_dist:
         import torch.distributed as dist_mod
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if "WORLD_SIZE" not in os.environ:  # --force-dist without a launcher: a one-rank group of our own on 127.0.0.1
+            import socket
+            with socket.socket() as sock:
+                sock.bind(("127.0.0.1", 0))
+                port = sock.getsockname()[1]
+            os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0"})
         torch.cuda.set_device(local)
         dist_mod.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
         dist = dist_mod
@@ -474,16 +487,20 @@ def main():
                    "streams_per_gpu": per_gpu, "samples_per_stream_per_step": a.samples,
                    "per_stream_samples_per_s": round(value / total_streams, 1),
                    "timed": "wall clock around the facade call: RNG draw, H2D, queue reset, kernels, D2H, mu-law expansion"
-                            + ("; + RCCL gather of the audio to rank 0" if n_gpus > 1 else ""),
+                            + ("; + RCCL gather of the audio to rank 0" if dist else ""),
                    "chain": {k: info[k] for k in ("kernel_variant", "n_chains", "layer_split", "head_split", "n_workgroups", "lds_bytes",
                                                   "streams_per_item", "head_replicas", "n_samplers", "dev_overrides")}},
         "engine_level": {"value": round(engine_value, 1), "ms_per_step": round(eng_wall / a.steps * 1e3, 3),
                          "note": "the same job through the C ABI with inputs and outputs resident in HBM (one wn_generate per step"
-                                 + ("; + RCCL gather of the index blocks" if n_gpus > 1 else "") + ")",
+                                 + ("; + RCCL gather of the index blocks" if dist else "") + ")",
                          "facade_over_engine": round(fac_wall / eng_wall, 4)},
         "per_rank": per_rank,
+        "rccl_ranks": dist.get_world_size() if dist else 0, "dist_backend": dist.get_backend() if dist else None,
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source,
+                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                     "traffic_kind": None if traffic is None else "replayed: PMC passes of an EARLIER run of this kernel in this form (rocprofv3 cannot "
+                                     "wrap the driver's own bench run), scaled to this launch's timesteps -- not a measurement of this run",
+                     "traffic_replayed_from": traffic_source,
                      "traffic_over_algorithmic": None if traffic is None else round(traffic / bytes_per_launch, 3),
                      "kernel": kname, "kernel_ms_per_launch": round(kernel_ms, 3), "kernel_ms_per_launch_median": round(eng_leg["kernel_ms_median"], 3),
                      "algorithmic_bytes_per_launch": int(bytes_per_launch),

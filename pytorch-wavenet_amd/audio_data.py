@@ -31,14 +31,18 @@ def quantize_data(data, classes):  # audio_data.py:133-137
     return np.digitize(mu_x, bins) - 1
 
 
-def list_all_audio_files(location):  # audio_data.py:140-148
-    audio_files = []
-    for dirpath, _dirnames, filenames in os.walk(location):
-        for filename in [f for f in filenames if f.endswith((".mp3", ".wav", ".aif", "aiff"))]:
-            audio_files.append(os.path.join(dirpath, filename))
-    if len(audio_files) == 0:
+AUDIO_SUFFIXES = (".mp3", ".wav", ".aif", "aiff")
+
+
+def list_all_audio_files(location):
+    """Every audio file below `location`, in os.walk order (same result as the reference's helper, audio_data.py:140-148:
+    the dataset builder depends on that order); prints the reference's notice when there is none."""
+    found = [os.path.join(folder, name)
+             for folder, _subdirs, names in os.walk(location)
+             for name in names if name.endswith(AUDIO_SUFFIXES)]
+    if not found:
         print("found no audio files in " + location)
-    return audio_files
+    return found
 
 
 def _load_audio(path, sampling_rate, mono):

@@ -30,11 +30,32 @@ def hipcc_path():
     raise RuntimeError("hipcc not found (need ROCm >= 7.0 to build the gfx950 engine)")
 
 
-OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+def objdump_path():
+    """llvm-objdump of the ROCm installation whose hipcc builds the library: $LLVM_OBJDUMP, next to the hipcc that was found
+    (<rocm>/bin/hipcc -> <rocm>/lib/llvm/bin), $ROCM_PATH, /opt/rocm, then PATH.  Raises with the list of places tried."""
+    tried = []
+    cands = [os.environ.get("LLVM_OBJDUMP")]
+    try:
+        rocm = os.path.dirname(os.path.dirname(os.path.realpath(hipcc_path())))
+        cands += [os.path.join(rocm, "lib", "llvm", "bin", "llvm-objdump"), os.path.join(rocm, "llvm", "bin", "llvm-objdump")]
+    except RuntimeError:
+        pass
+    if os.environ.get("ROCM_PATH"):
+        cands.append(os.path.join(os.environ["ROCM_PATH"], "lib", "llvm", "bin", "llvm-objdump"))
+    cands += ["/opt/rocm/lib/llvm/bin/llvm-objdump", shutil.which("llvm-objdump")]
+    for c in cands:
+        if not c:
+            continue
+        tried.append(c)
+        if os.path.exists(c):
+            return c
+    raise RuntimeError("llvm-objdump not found (tried %s; set LLVM_OBJDUMP): cannot verify the hand-scheduled register reservation" % ", ".join(tried))
+
+
 RESERVED_FIRST, RESERVED_LAST = 152, 167   # csrc/wn_kernel_v3.h: WN_V3_COMPILER_VGPRS .. the last register a 768-thread workgroup leaves a lane
 
 
-def check_hand_scheduled_registers(so, objdump=OBJDUMP):
+def check_hand_scheduled_registers(so, objdump=None):
     """The variant-3 kernels keep loads in flight into v152-v167 across their inline-assembly blocks (input poll sets, the queue
     group's tap FIFO).  The kernels carry amdgpu_num_vgpr so that the compiler's own allocation ends below them; this check
     DISASSEMBLES the built library and raises unless (1) every instruction of those kernels that names a reserved register is one
@@ -43,8 +64,10 @@ def check_hand_scheduled_registers(so, objdump=OBJDUMP):
     registers).  Called by build_hip(): a library that breaks the invariant is never left in place."""
     import re
     import tempfile
+    objdump = objdump or objdump_path()
     if not os.path.exists(objdump):
         raise RuntimeError("llvm-objdump not found at %s: cannot verify the hand-scheduled register reservation" % objdump)
+    so = os.path.abspath(so)   # (everything below runs inside a temporary directory: nothing is ever written next to `so`)
     with tempfile.TemporaryDirectory() as tmp:
         local = shutil.copy(so, os.path.join(tmp, "lib.so"))
         subprocess.check_call([objdump, "--offloading", local], cwd=tmp, stdout=subprocess.DEVNULL)

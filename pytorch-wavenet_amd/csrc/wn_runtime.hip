@@ -608,6 +608,8 @@ static int wn_create_impl(const wn_config* cfg, wn_handle** out) {
     return WN_OK;
 }
 
+static int wn_load_weights_impl(wn_handle* h, const wn_weight_ptrs* w);
+
 // the caller's weights copied into zero-filled arrays of the padded shape
 static int wn_load_weights_padded(wn_handle* h, const wn_weight_ptrs* w) {
     const WnPlan& pl = h->plan;
@@ -638,16 +640,18 @@ static int wn_load_weights_padded(wn_handle* h, const wn_weight_ptrs* w) {
         res_b = pad3(w->res_b, NL, 1, R, 1, R2, 1); skip_b = pad3(w->skip_b, NL, 1, S, 1, S2, 1);
         p.start_b = start_b.data(); p.filter_b = filter_b.data(); p.gate_b = gate_b.data(); p.res_b = res_b.data(); p.skip_b = skip_b.data();
     }
-    h->padded = false;   // (the padded arrays are this handle's shape)
-    const int rc = wn_load_weights(h, &p);
-    h->padded = true;
-    return rc;
+    return wn_load_weights_impl(h, &p);   // (the padded arrays are this handle's shape; the handle's state is not touched on the way)
 }
 
 extern "C" int wn_load_weights(wn_handle* h, const wn_weight_ptrs* w) {
     if (h && w && h->padded) { g_err[0] = 0; return wn_load_weights_padded(h, w); }
+    return wn_load_weights_impl(h, w);
+}
+
+// weights in the handle's own (possibly padded) channel shape
+static int wn_load_weights_impl(wn_handle* h, const wn_weight_ptrs* w) {
     if (h && !h->chains.empty()) {
-        for (wn_handle* c : h->chains) { int rc = wn_load_weights(c, w); if (rc) return rc; }
+        for (wn_handle* c : h->chains) { int rc = wn_load_weights_impl(c, w); if (rc) return rc; }
         h->have_weights = true;
         return WN_OK;
     }

@@ -29,14 +29,16 @@ def print_last_validation_result(opt):
     print("validation loss: ", opt.validation_results[-1])
 
 
-def average_gradients(parameters, process_group=None):
+def average_gradients(parameters, process_group=None, always=False):
     """Data-parallel gradient exchange: ONE all-reduce over the flattened gradients of ``parameters`` (30 MB at BASELINE
-    config 5: latency-bound on xGMI, so a single bucket), then every .grad <- mean over ranks.  No-op without a group."""
+    config 5: latency-bound on xGMI, so a single bucket), then every .grad <- mean over ranks.  No-op without a group and
+    in a group of one rank -- unless ``always`` (the collective then runs all the same: how a 1-GPU box exercises the RCCL
+    call of the N-GPU path, tests/test_gpu_multi.py)."""
     import torch.distributed as dist
     if process_group is None and not (dist.is_available() and dist.is_initialized()):
         return
     world = dist.get_world_size(process_group)
-    if world == 1:
+    if world == 1 and not always:
         return
     grads = [p.grad for p in parameters if p.grad is not None]
     if not grads:

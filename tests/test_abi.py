@@ -147,8 +147,13 @@ def test_reserved_poll_registers_belong_to_the_hand_scheduled_blocks_only(tmp_pa
     import sys
     sys.path.insert(0, os.path.join(ROOT, "pytorch-wavenet_amd"))
     import build
-    assert os.path.exists(build.OBJDUMP), "llvm-objdump is part of the ROCm image: the register check must not be skipped"
+    assert os.path.exists(build.objdump_path()), "llvm-objdump is part of the ROCm image: the register check must not be skipped"
+    before = set(os.listdir(os.path.dirname(build.OUT)))
     assert build.check_hand_scheduled_registers(build.build_hip()) >= 2   # one kernel per form (and shape)
+    assert set(os.listdir(os.path.dirname(build.OUT))) == before, "the check extracts the code object into a temporary directory only"
+    cwd_before = set(os.listdir("."))
+    assert build.check_hand_scheduled_registers(os.path.relpath(build.OUT)) >= 2   # (a relative path, from whatever the cwd is)
+    assert set(os.listdir(".")) == cwd_before
 
     fake = tmp_path / "objdump.py"   # a stand-in disassembler: feeds the checker hand-written listings
 

@@ -1,7 +1,10 @@
 """-m gpu, needs >= 2 GPUs (skipped otherwise): the N > 1 path on the real backend -- two ranks, backend "nccl" (= RCCL over
 xGMI), streams sharded by mi355_wavenet.streams, the finished index blocks gathered to rank 0 -- against the oracle; and
 bench.py launched the way the driver launches it (python -m torch.distributed.run --nproc-per-node 2).  On a 1-GPU box only
-the device-collision guard is exercised (two ranks on one device must be refused, not silently serialised)."""
+the device-collision guard is exercised (two ranks on one device must be refused, not silently serialised) -- and, since round 4,
+the SAME code paths in a process group of ONE rank on the real backend (`init_process_group("nccl")`, `pick_device`, the RCCL
+gather of the index blocks, the flat gradient all-reduce, `bench.py --force-dist`): the driver's first 8-GPU run must not be the
+first time this code meets RCCL."""
 import json
 import os
 import subprocess
@@ -69,6 +72,94 @@ def _run(tmp_path, extra_env, nproc=2):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
            "--master-port", str(port), str(script)]
     return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600), env["WN_TEST_OUT"]
+
+
+def test_one_rank_over_rccl_matches_the_oracle(tmp_path):
+    """The N-GPU job in a group of ONE rank over RCCL on the real device: init_process_group("nccl"), streams.pick_device (LOCAL_RANK),
+    the shard of all 7 streams, the gather of the index block through dist.gather on a CUDA tensor -- result == oracle."""
+    import c_oracle
+    from mi355_wavenet import synth
+    res, out_path = _run(tmp_path, {}, nproc=1)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    assert "REFUSED" not in res.stdout
+    out = np.load(out_path)
+    cfg = synth.CONFIGS["cfg2"]
+    W = synth.init_weights(cfg, seed=91)
+    rs = np.random.RandomState(91)
+    first = rs.randint(0, 256, (7, 9))
+    u = rs.random_sample((7, 120))
+    for s in range(7):
+        idx, _ = c_oracle.generate(cfg, W, 120, first[s], 1.0, 0.0, u[s])
+        assert np.array_equal(out[s], idx), s
+
+
+GRAD_WORKER = r"""
+import os, sys
+import numpy as np, torch
+import torch.distributed as dist
+local = int(os.environ["LOCAL_RANK"])
+torch.cuda.set_device(local)
+dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+assert dist.get_backend() == "nccl"
+import wavenet_model, wavenet_training
+torch.manual_seed(5)
+m = wavenet_model.WaveNetModel(layers=3, blocks=2, dilation_channels=32, residual_channels=32, skip_channels=64, end_channels=64,
+                               classes=256, output_length=8).cuda(local)
+g = torch.Generator().manual_seed(6 + dist.get_rank())
+idx = torch.randint(0, 256, (2, m.receptive_field + 7), generator=g).cuda(local)
+target = torch.randint(0, 256, (2 * 8,), generator=g).cuda(local)
+loss = torch.nn.functional.cross_entropy(m.train_forward_indices(idx), target)   # native forward + backward
+loss.backward()
+before = [p.grad.clone() for p in m.parameters() if p.grad is not None]
+wavenet_training.average_gradients(m.parameters(), dist.group.WORLD, always=True)   # ONE flat all-reduce over RCCL
+after = [p.grad for p in m.parameters() if p.grad is not None]
+world = dist.get_world_size()
+if world == 1:
+    assert all(torch.equal(a, b) for a, b in zip(before, after)), "mean over one rank must be the identity"
+else:  # every rank holds the same mean afterwards
+    flat = torch.cat([a.reshape(-1) for a in after])
+    ref = flat.clone()
+    dist.broadcast(ref, src=0)
+    assert torch.equal(flat, ref)
+t = torch.tensor([float(len(after))], device="cuda")
+dist.all_reduce(t)
+print("GRADS_OK", world, int(t.item()))
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def test_gradient_all_reduce_over_rccl_in_a_group_of_one(tmp_path):
+    """wavenet_training.average_gradients on the real backend (always=True: the all-reduce runs although one rank has nothing to average),
+    behind the native training step."""
+    script = tmp_path / "grad_worker.py"
+    script.write_text(GRAD_WORKER)
+    port = 29700 + os.getpid() % 1000
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(script)]
+    res = subprocess.run(cmd, env=_env(), capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    assert "GRADS_OK 1" in res.stdout
+
+
+@pytest.mark.parametrize("launcher", ["plain", "torchrun"])
+def test_bench_one_gpu_through_the_distributed_path(launcher):
+    """bench.py --gpus 1 --force-dist: the N-GPU code path (RCCL group, pick_device, gather of index blocks and audio inside the timed
+    region, all-reduce of the timings) with one rank; the line says which backend carried it."""
+    env = {k: v for k, v in _env().items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    tail = [os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "--steps", "2", "--warmup", "1", "--samples", "400", "--no-extra", "--no-cpu-baseline"]
+    if launcher == "plain":
+        cmd = [sys.executable] + tail
+    else:
+        port = 29600 + os.getpid() % 1000
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", str(port)] + tail
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    line = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["rccl_ranks"] == 1 and line["dist_backend"] == "nccl"
+    assert line["verified"] is True and line["value"] > 0
+    assert len(line["per_rank"]) == 1 and line["per_rank"][0]["gather_ms"] >= 0
+    assert "RCCL gather" in line["config"]["timed"]
 
 
 @two_gpus
