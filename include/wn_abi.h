@@ -15,9 +15,18 @@
  *     state); distinct handles may be used concurrently from different threads (the reference calls
  *     generate_fast from a daemon thread during training: model_logging.py:48-58).
  *   - wn_generate jobs are persistent kernels: every workgroup of a job must be resident before the job
- *     makes progress.  A job that finds the device's CUs taken (another handle's job, a long torch
- *     kernel) starts when they free up; its hand-off timeout (timeout_ms) bounds every single hand-off
- *     wait of its workgroups, so size it for the longest job that may run next to it.  A job is ONE
+ *     makes progress, and two jobs that do not fit the chip together would each get part of it and
+ *     neither would ever run.  wn_generate therefore books the job's CUs (per XCD) in a per-device
+ *     table shared by all processes on the host (a file in /dev/shm named after the device's PCI bus
+ *     id, used under flock(); WN_GATE_DIR moves it) and WAITS -- bounded by WN_GATE_TIMEOUT_MS, default
+ *     10 minutes, then WN_E_TIMEOUT -- until the jobs booked in front of it have finished whenever its
+ *     booking does not fit next to theirs: two cfg3 jobs (220 of 256 CUs each) from two threads or two
+ *     processes run one after the other, two cfg1 jobs (19 CUs) side by side.  Jobs one HIP stream
+ *     already serialises (same process, same stream) share a booking: wn_generate stays asynchronous for
+ *     them.  The booking is returned when the kernel finishes (a host function enqueued behind it), at
+ *     the latest in wn_wait; bookings of processes that no longer exist are dropped.  Kernels that are not
+ *     wn_generate jobs (a long torch kernel) are not booked: a job that finds CUs taken by one starts when
+ *     they free up, and its hand-off timeout (timeout_ms) bounds every single hand-off wait.  A job is ONE
  *     persistent kernel (any stream count up to ~150 at cfg3's shape), or, beyond one chain's capacity,
  *     rounds of up to 128 streams, one kernel after the other on the caller's stream.
  */
@@ -30,7 +39,8 @@
 extern "C" {
 #endif
 
-#define WN_ABI_VERSION 2  /* 2: wn_train_loss; wn_info reports the form of the chain (streams_per_item, head_replicas, n_samplers) */
+#define WN_ABI_VERSION 3  /* 3: per-device admission of persistent jobs (wn_info: gate_*), kernel variant 4 (layers_per_workgroup);
+                             2: wn_train_loss; wn_info reports the form of the chain (streams_per_item, head_replicas, n_samplers) */
 
 enum {
     WN_OK = 0,
@@ -128,6 +138,11 @@ typedef struct wn_info {
     int32_t head_replicas;    /* ... replicas of the head workgroups (replica j serves the streams s = j mod head_replicas) */
     int32_t n_samplers;       /* ... dedicated sampler workgroups (0: layer 0 samples itself, single-stream kernels of variant 1 / 2) */
     int32_t dev_overrides;    /* 1 iff WN_TESTING=1 let a development override (WN_KERNEL, WN_V3_MODE, ...) change what the planner chose */
+    int32_t layers_per_workgroup; /* variant 4: consecutive layers one stack workgroup holds (hand-offs between them stay in LDS); 1 elsewhere */
+    int32_t gate_shared;      /* admission table of the LAST job: 1 = shared by all processes (file under /dev/shm), 0 = this process only
+                                 (no usable /dev/shm), -1 = no job yet */
+    int32_t gate_waited_ms;   /* how long the last job waited for jobs booked in front of it */
+    int32_t gate_need_per_xcd; /* CUs per XCD a job of this handle books (of n_compute_units / 8) */
 } wn_info;
 
 /* wn_config.reserved[0]: plan the model's OWN channel shape (no zero padding into a compiled kernel shape, see wn_create): what a

@@ -15,6 +15,7 @@
 #include "wn_kernel.h"
 #include "wn_kernel_v3.h"
 #include "wn_forward.h"
+#include "wn_gate.h"
 
 static thread_local char g_err[512] = "";
 // Development overrides (WN_KERNEL, WN_V3_MODE, WN_CHAINS, WN_SAMPLERS, WN_NO_LOCAL_STORES) pick another kernel or form than the
@@ -335,7 +336,23 @@ struct wn_handle {
     float* d_tws; size_t tws_floats;  // training workspace (saved activations + backward temporaries)
     float* d_xent = nullptr; size_t xent_rows = 0;  // wn_train_loss: per-row losses
     WnTrainLay train; bool train_valid;
+    // admission of persistent jobs (wn_gate.h)
+    char busid[32] = "";
+    std::shared_ptr<WnGateTicket> gate;   // the booking of the job in flight (released by the host function behind the kernel, or in wn_wait)
+    int gate_shared = -1, gate_waited_ms = 0;
 };
+
+// CUs per XCD a job of this handle needs (blocks are dispatched round-robin over the XCDs) and what an XCD has
+static void wn_gate_numbers(const wn_handle* h, int* need, int* cap) {
+    const int n_xcd = h->n_cu % 8 == 0 ? 8 : 1;
+    *cap = h->n_cu / n_xcd;
+    *need = (h->plan.n_blocks + n_xcd - 1) / n_xcd;
+}
+static void wn_gate_host_release(void* user) {   // runs on the runtime's callback thread once the job's kernel has finished
+    std::shared_ptr<WnGateTicket>* t = static_cast<std::shared_ptr<WnGateTicket>*>(user);
+    wn_gate_release(*t);
+    delete t;
+}
 
 extern "C" int wn_abi_version(void) { return WN_ABI_VERSION; }
 extern "C" const char* wn_last_error(void) { return g_err; }
@@ -350,6 +367,7 @@ extern "C" void wn_destroy(wn_handle* h) {
     }
     (void)hipSetDevice(h->cfg.device_id);
     if (h->pending) (void)hipStreamSynchronize((hipStream_t)h->last_stream);
+    wn_gate_release(h->gate);
     rt_free(h->d_blobs); rt_free(h->d_start_t); rt_free(h->d_start_b); rt_free(h->d_rings); rt_free(h->d_dil);
     rt_free(h->d_wg_map); rt_free(h->d_ring_off); rt_free(h->d_gran); rt_free(h->d_status); rt_free(h->d_prof); rt_free(h->d_fw); rt_free(h->d_ws); rt_free(h->d_fwb);
     rt_free(h->d_tws);
@@ -440,6 +458,8 @@ static int wn_create_impl(const wn_config* cfg, wn_handle** out) {
         int khz = 0;
         if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, cfg->device_id) == hipSuccess && khz > 0) wall_khz = khz;
     }
+    char busid[32] = "";
+    if (hipDeviceGetPCIBusId(busid, (int)sizeof(busid), cfg->device_id) != hipSuccess || !busid[0]) snprintf(busid, sizeof(busid), "dev%d", cfg->device_id);
     {   // rounds of the wave-specialised chain (see wn_handle::rounds)
         const char* ce = wn_dev_env("WN_CHAINS");
         const bool off = ce && ce[0] == '1';
@@ -499,6 +519,7 @@ static int wn_create_impl(const wn_config* cfg, wn_handle** out) {
     h->v3_mode = 0; h->rounds = false;
     h->have_weights = false; h->pending = false; h->last_stream = nullptr; h->t_base = 0;
     h->n_cu = n_cu; h->wall_khz = wall_khz;
+    memcpy(h->busid, busid, sizeof(busid));
     h->d_blobs = h->d_start_t = h->d_start_b = h->d_rings = nullptr;
     h->d_dil = h->d_wg_map = nullptr; h->d_ring_off = nullptr; h->d_gran = nullptr; h->d_status = nullptr;
     h->d_prof = nullptr; h->prof_items = 0; h->prof_recorded = 0;
@@ -863,17 +884,38 @@ extern "C" int wn_generate(wn_handle* h, const wn_generate_args* a) {
         h->prof_recorded = h->prof_items;
         h->prof_items = 0;
     }
+    {   // admission: a persistent job only runs once ALL its workgroups are resident (wn_gate.h)
+        const char* off = wn_dev_env("WN_NO_DEVICE_GATE");
+        wn_gate_release(h->gate);
+        h->gate.reset();
+        if (!(off && off[0] == '1')) {
+            int need = 0, cap = 0;
+            wn_gate_numbers(h, &need, &cap);
+            const char* te = getenv("WN_GATE_TIMEOUT_MS");
+            const long long gate_ms = te && atoll(te) > 0 ? atoll(te) : 600000;
+            long long waited = 0;
+            int shared = 0;
+            if (wn_gate_acquire(h->busid, cap, need, a->hip_stream, gate_ms, &h->gate, &waited, &shared))
+                return wn_fail(WN_E_TIMEOUT, "wn_generate: device %s stayed booked by other persistent jobs for %lld ms (this job needs %d of %d CUs per XCD); "
+                               "nothing was launched", h->busid, waited, need, cap);
+            h->gate_shared = shared; h->gate_waited_ms = (int)(waited > 0x7fffffff ? 0x7fffffff : waited);
+        }
+    }
     // hand-off words restart at tag 1 every call: zero them (and the status word) ahead of the launch
     int rc = rt_memset_async(h->d_gran, 0, h->gran_count * 8, a->hip_stream);
     rc = rc ? rc : rt_memset_async(h->d_status, 0, (size_t)(8 + h->plan.n_wg) * 4, a->hip_stream);
-    if (rc) return rc;
+    if (rc) { wn_gate_release(h->gate); h->gate.reset(); return rc; }
     if (h->variant == 3)
         wn_v2_table()[h->v2_index].launch_v3(h->v3_mode & 1, h->plan.n_blocks, (size_t)h->lds_bytes, (hipStream_t)a->hip_stream, h->plan, r);
     else
         hipLaunchKernelGGL(wn_generate_kernel, dim3(h->plan.n_blocks), dim3(WN_THREADS), (size_t)h->lds_bytes,
                            (hipStream_t)a->hip_stream, h->plan, r);
     rc = rt_hip(hipGetLastError(), "launch wn_generate_kernel");
-    if (rc) return rc;
+    if (rc) { wn_gate_release(h->gate); h->gate.reset(); return rc; }
+    if (h->gate) {   // the booking goes back the moment the kernel is done (a caller that never waits must not keep the device closed)
+        std::shared_ptr<WnGateTicket>* t = new std::shared_ptr<WnGateTicket>(h->gate);
+        if (hipLaunchHostFunc((hipStream_t)a->hip_stream, wn_gate_host_release, t) != hipSuccess) { (void)hipGetLastError(); delete t; }  // (wn_wait returns it then)
+    }
     h->pending = true;
     h->last_stream = a->hip_stream;
     h->t_base += n_eval;
@@ -895,6 +937,8 @@ extern "C" int wn_wait(wn_handle* h) {
         return first_rc;
     }
     int rc = rt_sync(h->last_stream);
+    wn_gate_release(h->gate);
+    h->gate.reset();
     if (rc) return rc;
     uint32_t st[8];
     rc = rt_d2h(st, h->d_status, 32);
@@ -922,6 +966,7 @@ extern "C" int wn_get_info(wn_handle* h, wn_info* out) {
             out->handoff_bytes += ci.handoff_bytes;
         }
         out->n_chains = (int)h->chains.size();
+        for (wn_handle* c : h->chains) if (c->gate_waited_ms > out->gate_waited_ms) out->gate_waited_ms = c->gate_waited_ms;
         return WN_OK;
     }
     const WnPlan& pl = h->plan;
@@ -939,6 +984,9 @@ extern "C" int wn_get_info(wn_handle* h, wn_info* out) {
     out->head_replicas = pl.HR;
     out->n_samplers = pl.n_smp;
     out->dev_overrides = h->dev_overrides;
+    out->layers_per_workgroup = 1;
+    out->gate_shared = h->gate_shared; out->gate_waited_ms = h->gate_waited_ms;
+    { int need = 0, cap = 0; wn_gate_numbers(h, &need, &cap); out->gate_need_per_xcd = need; }
     return WN_OK;
 }
 

@@ -43,14 +43,15 @@ class wn_generate_args(ctypes.Structure):
                 ("stream_temperatures", ctypes.c_void_p)]
 
 
-ABI_VERSION = 2  # include/wn_abi.h: WN_ABI_VERSION
+ABI_VERSION = 3  # include/wn_abi.h: WN_ABI_VERSION
 
 
 class wn_info(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in ("abi_version", "n_layers", "layer_split", "head_split", "n_workgroups",
                                                "lds_bytes", "n_compute_units", "receptive_field")] + \
                [(n, ctypes.c_int64) for n in ("weight_bytes", "queue_bytes", "handoff_bytes", "evals_done")] + \
-               [(n, ctypes.c_int32) for n in ("kernel_variant", "n_chains", "streams_per_item", "head_replicas", "n_samplers", "dev_overrides")]
+               [(n, ctypes.c_int32) for n in ("kernel_variant", "n_chains", "streams_per_item", "head_replicas", "n_samplers", "dev_overrides",
+                                               "layers_per_workgroup", "gate_shared", "gate_waited_ms", "gate_need_per_xcd")]
 
 
 EXPORTS = ["wn_abi_version", "wn_create", "wn_destroy", "wn_load_weights", "wn_reset", "wn_generate", "wn_wait",

@@ -1,0 +1,125 @@
+"""CPU: the per-device admission of persistent jobs (csrc/wn_gate.h, plain C++ -- no HIP in it) compiled with g++ and driven
+through a small harness: bookings that fit run side by side, bookings that do not wait for each other -- between threads of one
+process and between processes --, jobs of one (process, stream) share a booking, a booking whose owner died is dropped, the wait
+is bounded.  The GPU side (two cfg3 jobs on two threads / in two processes finish with oracle-equal output) is tests/test_gpu_parity.py."""
+import os
+import subprocess
+import time
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "pytorch-wavenet_amd", "csrc")
+
+HARNESS = r"""
+#include "wn_gate.h"
+#include <cstdio>
+#include <cstdlib>
+#include <thread>
+#include <vector>
+// gate <busid> <cap> <need> <hold_ms> <timeout_ms> [n_threads] [same_stream]
+//   every thread books `need`, holds it hold_ms, releases; prints per thread "rc waited_ms shared t_in t_out" (ms since start)
+int main(int argc, char** argv) {
+    const char* bus = argv[1];
+    const int cap = atoi(argv[2]), need = atoi(argv[3]), hold = atoi(argv[4]), tmo = atoi(argv[5]);
+    const int nt = argc > 6 ? atoi(argv[6]) : 1, same = argc > 7 ? atoi(argv[7]) : 0;
+    if (hold < 0) {  // "crash": book and exit without releasing
+        std::shared_ptr<WnGateTicket> t; long long w; int sh;
+        const int rc = wn_gate_acquire(bus, cap, need, nullptr, tmo, &t, &w, &sh);
+        printf("%d %lld %d\n", rc, w, sh);
+        fflush(stdout);
+        _exit(0);
+    }
+    const long long t0 = wn_gate_now_ms();
+    std::vector<std::thread> th;
+    std::vector<std::string> lines(nt);
+    for (int i = 0; i < nt; ++i)
+        th.emplace_back([&, i] {
+            std::shared_ptr<WnGateTicket> t; long long w = 0; int sh = -1;
+            const void* stream = same ? (const void*)0x10 : (const void*)(uintptr_t)(0x100 + i);
+            const int rc = wn_gate_acquire(bus, cap, need, stream, tmo, &t, &w, &sh);
+            const long long tin = wn_gate_now_ms() - t0;
+            if (rc == 0) { usleep(hold * 1000); wn_gate_release(t); wn_gate_release(t); }  // (a second release is a no-op)
+            char buf[128];
+            snprintf(buf, sizeof(buf), "%d %lld %d %lld %lld", rc, w, sh, tin, wn_gate_now_ms() - t0);
+            lines[i] = buf;
+        });
+    for (auto& t : th) t.join();
+    for (auto& l : lines) printf("%s\n", l.c_str());
+    return 0;
+}
+"""
+
+
+@pytest.fixture(scope="module")
+def gate(tmp_path_factory):
+    d = tmp_path_factory.mktemp("gate")
+    src = d / "gate.cpp"
+    src.write_text(HARNESS)
+    exe = d / "gate"
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-pthread", "-Wall", "-I", CSRC, "-o", str(exe), str(src)])
+    tabdir = d / "tables"
+    tabdir.mkdir()
+
+    def run(*args, wait=True, env_extra=None):
+        env = dict(os.environ, WN_GATE_DIR=str(tabdir))
+        env.update(env_extra or {})
+        p = subprocess.Popen([str(exe)] + [str(a) for a in args], stdout=subprocess.PIPE, text=True, env=env)
+        if not wait:
+            return p
+        out, _ = p.communicate(timeout=60)
+        assert p.returncode == 0
+        return [[int(v) for v in ln.split()] for ln in out.splitlines()]
+
+    run.collect = lambda p: [[int(v) for v in ln.split()] for ln in p.communicate(timeout=60)[0].splitlines()]
+    return run
+
+
+def test_bookings_that_fit_run_side_by_side(gate):
+    rows = gate("0000:aa:00.0", 32, 3, 150, 5000, 4)        # four cfg1-sized jobs: 12 of 32 CUs per XCD
+    assert all(r[0] == 0 and r[2] == 1 for r in rows)         # admitted, through the shared table
+    assert max(r[3] for r in rows) < 100                      # nobody waited for anybody
+
+
+def test_bookings_that_do_not_fit_take_turns_between_threads(gate):
+    rows = gate("0000:ab:00.0", 32, 28, 200, 5000, 3)        # three cfg3-sized jobs
+    assert all(r[0] == 0 for r in rows)
+    spans = sorted((r[3], r[4]) for r in rows)
+    for (a0, a1), (b0, b1) in zip(spans, spans[1:]):
+        assert b0 >= a1 - 2, spans                            # strictly one after the other
+    assert sorted(r[1] for r in rows)[-1] >= 380              # the last one waited for two holds
+
+
+def test_jobs_of_one_stream_share_a_booking(gate):
+    rows = gate("0000:ac:00.0", 32, 28, 200, 5000, 3, 1)     # the same three jobs on ONE stream: the stream serialises them
+    assert all(r[0] == 0 for r in rows)
+    assert max(r[3] for r in rows) < 100                      # wn_generate stays asynchronous: nobody is held back on the host
+
+
+def test_two_processes_take_turns_and_a_dead_owner_is_dropped(gate):
+    a = gate("0000:ad:00.0", 32, 28, 400, 5000, wait=False)
+    time.sleep(0.15)
+    b = gate("0000:ad:00.0", 32, 28, 10, 5000)
+    ra = gate.collect(a)
+    assert ra[0][0] == 0 and b[0][0] == 0
+    assert b[0][1] >= 150                                     # the second process waited for the first one's job
+    # a process that books and dies: its entry must not close the device
+    crash = gate("0000:ae:00.0", 32, 28, -1, 1000)
+    assert crash[0][0] == 0
+    after = gate("0000:ae:00.0", 32, 28, 10, 2000)
+    assert after[0][0] == 0 and after[0][1] < 500
+
+
+def test_the_wait_is_bounded(gate):
+    a = gate("0000:af:00.0", 32, 28, 800, 5000, wait=False)
+    time.sleep(0.15)
+    b = gate("0000:af:00.0", 32, 28, 10, 200)                # gives up after 200 ms
+    assert b[0][0] == 1 and 200 <= b[0][1] < 700
+    assert gate.collect(a)[0][0] == 0
+
+
+def test_without_a_shared_directory_the_gate_is_process_local(gate):
+    rows = gate("0000:b0:00.0", 32, 28, 100, 5000, 2, env_extra={"WN_GATE_DIR": "/nonexistent/dir"})
+    assert all(r[0] == 0 and r[2] == 0 for r in rows)         # shared == 0: this process only
+    spans = sorted((r[3], r[4]) for r in rows)
+    assert spans[1][0] >= spans[0][1] - 2

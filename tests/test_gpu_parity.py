@@ -3,6 +3,8 @@
 Sizes are chosen so the oracle finishes in seconds; BASELINE-size behaviour (cfg3, 16000 samples, 64 streams)
 is covered by size-independent properties: determinism, continuation == one-shot, stream independence
 (stream s of a batched run == the same stream run alone), priming == teacher forcing."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -264,6 +266,86 @@ def test_two_handles_two_threads():
     [t.start() for t in ts]
     [t.join() for t in ts]
     assert np.array_equal(out[0], ref) and np.array_equal(out[1], ref)
+
+
+def test_two_large_jobs_on_two_threads_take_turns():
+    """Two cfg3 jobs (220 of the 256 CUs each) launched from two threads on two HIP streams cannot be resident together: without
+    admission each would get part of the chip and both would spin into WN_E_TIMEOUT.  The per-device gate (csrc/wn_gate.h) lets the
+    second one wait for the first: both finish, both equal the oracle, and one of them reports that it was held back."""
+    import threading
+    N = 600
+    cfg, W, first, uniforms = make_case("cfg3", 57, 2, 20, N)
+    out, infos, errs = {}, {}, []
+    start = threading.Barrier(2)
+
+    def work(i):
+        try:
+            with torch.cuda.stream(torch.cuda.Stream()):
+                e = engine.Engine(cfg, W, n_streams=2)
+                start.wait()
+                out[i] = e.generate(N, first, temperature=1.0, uniforms=uniforms, timeout_ms=4000)
+                infos[i] = e.info()
+                e.close()
+        except Exception as ex:  # noqa: BLE001
+            errs.append(repr(ex))
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs, errs
+    for s in range(2):
+        o_idx, _ = c_oracle.generate(cfg, W, N, first[s], 1.0, 0.0, uniforms[s])
+        assert np.array_equal(out[0][s], o_idx) and np.array_equal(out[1][s], o_idx)
+    assert all(i["gate_shared"] in (0, 1) and i["gate_need_per_xcd"] >= 26 for i in infos.values()), infos
+
+
+GATE_WORKER = r"""
+import os, sys, time
+import numpy as np, torch
+from parity_common import make_case
+from mi355_wavenet import engine
+N = 600
+cfg, W, first, uniforms = make_case("cfg3", 57, 2, 20, N)
+e = engine.Engine(cfg, W, n_streams=2)
+open(os.environ["WN_TEST_READY"] + "." + os.environ["WN_TEST_ID"], "w").close()
+t0 = time.time()
+while not all(os.path.exists(os.environ["WN_TEST_READY"] + "." + k) for k in ("a", "b")):   # both processes launch at the same moment
+    assert time.time() - t0 < 120
+    time.sleep(0.001)
+for _ in range(3):   # several jobs each: the processes interleave
+    out = e.generate(N, first, temperature=1.0, uniforms=uniforms, timeout_ms=4000)
+np.save(os.environ["WN_TEST_OUT"], out)
+print("INFO", e.info()["gate_shared"], e.info()["gate_waited_ms"])
+e.close()
+"""
+
+
+def test_two_processes_on_one_gpu_take_turns(tmp_path):
+    """... and the same between two PROCESSES sharing the GPU (the table is a file under /dev/shm, used under flock)."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    root = os.path.dirname(here)
+    script = tmp_path / "gate_worker.py"
+    script.write_text(GATE_WORKER)
+    env = dict(os.environ)
+    env["PYTHONPATH"] = os.pathsep.join([os.path.join(root, "pytorch-wavenet_amd"), os.path.join(root, "oracle"), here, env.get("PYTHONPATH", "")])
+    env["WN_TEST_READY"] = str(tmp_path / "ready")
+    procs = []
+    for k in ("a", "b"):
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=dict(env, WN_TEST_ID=k, WN_TEST_OUT=str(tmp_path / ("out_%s.npy" % k))),
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    res = [p.communicate(timeout=600) for p in procs]
+    for p, (so, se) in zip(procs, res):
+        assert p.returncode == 0, so[-1500:] + se[-3000:]
+        assert "INFO 1" in so, so   # the inter-process table was in use
+    N = 600
+    cfg, W, first, uniforms = make_case("cfg3", 57, 2, 20, N)
+    for k in ("a", "b"):
+        got = np.load(str(tmp_path / ("out_%s.npy" % k)))
+        for s in range(2):
+            o_idx, _ = c_oracle.generate(cfg, W, N, first[s], 1.0, 0.0, uniforms[s])
+            assert np.array_equal(got[s], o_idx)
 
 
 @pytest.mark.parametrize("cfgname,ns,n_given", [("cfg1", 2, 200), ("cfg2", 1, 3100), ("cfg3", 2, 700), ("cfg3", 1, 5200)])
