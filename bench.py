@@ -474,7 +474,7 @@ def main():
     bytes_per_launch = bytes_per_tstep * a.samples
     achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
     traffic, traffic_source = _pmc_traffic(a, info, per_gpu)
-    kname = {1: "wn_generate_kernel", 3: "wn_generate_kernel_v3m"}.get(info["kernel_variant"], "?")
+    kname = {1: "wn_generate_kernel", 3: "wn_generate_kernel_v3m", 4: "wn_generate_kernel_v4"}.get(info["kernel_variant"], "?")
     line = {
         "metric": "generate_fast() audio samples/sec (256-class mu-law), whole job over all GPUs",
         "value": round(value, 1), "unit": "samples/s", "n_gpus": n_gpus, "steps": a.steps, "warmup": a.warmup,

@@ -1069,7 +1069,7 @@ static __device__ void wn_v3_head(const WnPlan& p, const WnRun& r, WnCtx& cx, fl
     constexpr int CH3 = (K3 / 4) % 4 == 0 ? 4 : (K3 / 4) % 2 == 0 ? 2 : 1;  // (float4 reads of the long dot in flight together)
     static_assert(K3 % 4 == 0 && EC % 4 == 0, "head slices are read as float4");
     using L = WnV3Lds<SH>;
-    const int tid = threadIdx.x, ns = p.n_streams, NL = p.NL;
+    const int tid = threadIdx.x, ns = p.n_streams;
     const int HR = p.HR, h = hw % p.PA, rep = hw / p.PA;  // slice of end_conv_1 / end_conv_2, replica
     const int n_mine = rep < ns ? (ns - rep + HR - 1) / HR : 0;  // streams this replica serves
     // end_conv_1's slice stays in registers and the lane's end_conv_2 row (EC floats) lives in LDS as float4 [EC / 4][256 lanes] -- a head
@@ -1079,7 +1079,7 @@ static __device__ void wn_v3_head(const WnPlan& p, const WnRun& r, WnCtx& cx, fl
     static_assert(!W4LDS || EC <= 32, "one of the head's two weight vectors has to fit the registers");
     static_assert(L::pre % 4 == 0, "the head's LDS-resident weights are read as float4");
     float w4[W4LDS ? 1 : K3], w5[W4LDS ? EC : 1];
-    const float* img = p.blobs + (size_t)NL * P * (SH::NWL * 256) + (size_t)h * (SH::NWH * 256) + tid;
+    const float* img = p.blobs + p.head_blob_off + (size_t)h * (SH::NWH * 256) + tid;
     float4* wl = reinterpret_cast<float4*>(lds + L::pre) + tid;  // [k4 * 256]: the LDS-resident vector of this lane
     if constexpr (W4LDS) {
 #pragma unroll 4
@@ -1106,7 +1106,7 @@ static __device__ void wn_v3_head(const WnPlan& p, const WnRun& r, WnCtx& cx, fl
         *failflag = 0;
         const int mine = wn_xcc_id();
         __hip_atomic_store(p.xcc_tab + cx.w, (unsigned)(mine + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        locflags[0] = p.allow_plain ? (int)wn_same_xcd(cx, mine, NL * P + p.PA * p.HR, p.n_smp) : 0;  // logits feed the samplers
+        locflags[0] = p.allow_plain ? (int)wn_same_xcd(cx, mine, p.n_lw + p.PA * p.HR, p.n_smp) : 0;  // logits feed the samplers
     }
     wn_lds_barrier();
     const bool local_l = locflags[0] != 0;
@@ -1124,7 +1124,7 @@ static __device__ void wn_v3_head(const WnPlan& p, const WnRun& r, WnCtx& cx, fl
     auto request = [&](int s2) {
 #pragma unroll
         for (int j = 0; j < P; ++j) {
-            const unsigned base = (unsigned)(((((size_t)(NL - 1) * P + j) * ns + s2) * (size_t)S) * 8);
+            const unsigned base = (unsigned)(((((size_t)(p.n_lw - P) + j) * ns + s2) * (size_t)S) * 8);   // the last layer-role workgroups' lanes
 #pragma unroll
             for (int h2 = 0; h2 < NPL; ++h2) nv[h2][j] = __builtin_amdgcn_raw_buffer_load_b128(rs_gs, lane16, base + h2 * 4096, 16);
             if constexpr (ODD) nv[NPL][j] = __builtin_amdgcn_raw_buffer_load_b128(rs_gs, odd_ld, base, 16);

@@ -79,6 +79,10 @@ struct WnPlan {
     uint32_t* xcc_tab;        // [n_wg] XCC id + 1 of every chain position, written by the workgroups at start
     int32_t n_blocks;         // grid size (>= n_wg; blocks mapped to -1 exit at once)
     int32_t allow_plain;      // same-XCD producers may publish with L2-resident (non write-through) stores
+    // chain positions: [0, n_lw) layer-role workgroups, then PA * HR head workgroups, then the samplers.  Variant 3: n_lw = NL * P
+    // (one layer slice each); variant 4: n_lw stack workgroups of LPW consecutive layers each (wn_kernel_v4.h)
+    int32_t n_lw, LPW;
+    int64_t head_blob_off;    // float offset of head workgroup 0's weight image inside `blobs` (variants 3 and 4)
 };
 
 struct WnRun {

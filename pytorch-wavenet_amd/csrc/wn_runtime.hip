@@ -14,6 +14,7 @@
 #include "../../include/wn_abi.h"
 #include "wn_kernel.h"
 #include "wn_kernel_v3.h"
+#include "wn_kernel_v4.h"
 #include "wn_forward.h"
 #include "wn_gate.h"
 
@@ -279,6 +280,133 @@ static bool wn_v3_applicable(const wn_config* cfg, int n_cu, int* out_vi, int* o
     return true;
 }
 
+// ------------------------------------------------------------------------------------------------ stacked layers (variant 4)
+// Shapes the stacked kernel (wn_kernel_v4.h: LPW consecutive layers per 512-thread workgroup) is instantiated for: (R, D, S, E / PA, LPW).
+// LPW is what one CU's register file holds next to the working set: cfg2 60 registers per layer and lane (tap 0 lives in LDS), cfg1 32,
+// the train_script.py shape 83 (its 1024 skip rows).
+struct WnV4Entry {
+    int R, D, S, EC, LPW, nwpl, nwh;
+    void (*pack)(const WnPlan& pl, const WnHostWeights& w, std::vector<float>& out);
+    const void* fn;
+    int (*lds_floats)(int ns);
+    int lds_pre_head;   // float offset of the head / sampler workgroups' own tables (WnV3Lds<SH>::pre)
+    void (*launch)(int grid, size_t lds, hipStream_t st, const WnPlan& p, const WnRun& r);
+};
+
+template <int R, int D, int S, int EC, int LPW>
+static void wn_pack_v4(const WnPlan& pl, const WnHostWeights& w, std::vector<float>& out) {
+    using V = WnV4Shape<R, D, S>;
+    using SH = WnV2Shape<R, D, S, EC>;
+    constexpr int KF = V::KF, KR = V::KR, KS = V::KS, RS = V::RS, T = WN_THREADS_V4;
+    const int NL = pl.NL, n_stack = pl.n_lw, E = pl.E;
+    const size_t per_wg = (size_t)LPW * V::NWPL * T;
+    out.assign((size_t)n_stack * per_wg + (size_t)pl.PA * SH::NWH * 256, 0.f);
+    for (int wg = 0; wg < n_stack; ++wg)
+        for (int li = 0; li < LPW; ++li) {
+            const int l = wg * LPW + li;
+            if (l >= NL) continue;   // (a last workgroup with fewer layers: zeros)
+            float* img = out.data() + (size_t)wg * per_wg + (size_t)li * V::NWPL * T;
+            const float* fw = w.filter_w + (size_t)l * D * R * 2;
+            const float* gw = w.gate_w + (size_t)l * D * R * 2;
+            const float* rw = w.res_w + (size_t)l * R * D;
+            const float* sw = w.skip_w + (size_t)l * S * D;
+            for (int t = 0; t < T; ++t) {
+                const int g8 = t >> 3, kq = t & 7, sr = t >> 1, kh = t & 1;
+                auto put = [&](int j, float v) { img[(size_t)j * T + t] = v; };
+                if (g8 < D) {   // filter / gate rows of channel g8 on x[kq KF .. ): pairs {f, g}; tap 1 = x[t], tap 0 = x[t-d] (Appendix A item 1)
+                    for (int k = 0; k < KF; ++k) {
+                        const size_t at = ((size_t)g8 * R + kq * KF + k) * 2;
+                        put(V::O_W1 + 2 * k, fw[at + 1]); put(V::O_W1 + 2 * k + 1, gw[at + 1]);
+                        put(V::O_W0 + 2 * k, fw[at + 0]); put(V::O_W0 + 2 * k + 1, gw[at + 0]);
+                    }
+                    if (pl.has_bias && kq == 0) { put(V::O_B0, w.filter_b[(size_t)l * D + g8]); put(V::O_B0 + 1, w.gate_b[(size_t)l * D + g8]); }
+                }
+                if (g8 < R) {   // residual row g8 on z[kq KR .. )
+                    for (int k = 0; k < KR; ++k) put(V::O_WR + k, rw[(size_t)g8 * D + kq * KR + k]);
+                    if (pl.has_bias && kq == 0) put(V::O_BRES, w.res_b[(size_t)l * R + g8]);
+                }
+                // skip rows sr + 256 q on z[kh KS .. ): rows 2h, 2h+1 side by side; a single row in natural order
+                if (RS % 2 == 0) {
+                    for (int h = 0; h < RS / 2; ++h)
+                        for (int k = 0; k < KS; ++k) {
+                            put(V::O_WS + 2 * (h * KS + k), sw[(size_t)(sr + 256 * (2 * h)) * D + kh * KS + k]);
+                            put(V::O_WS + 2 * (h * KS + k) + 1, sw[(size_t)(sr + 256 * (2 * h + 1)) * D + kh * KS + k]);
+                        }
+                } else {
+                    for (int k = 0; k < KS; ++k) put(V::O_WS + k, sw[(size_t)sr * D + kh * KS + k]);
+                }
+                if (pl.has_bias && kh == 0)
+                    for (int q = 0; q < RS; ++q) put(V::O_BSKIP + q, w.skip_b[(size_t)l * S + sr + 256 * q]);
+            }
+        }
+    for (int h = 0; h < pl.PA; ++h) {   // head images: variant 3's (wn_pack_v2)
+        float* img = out.data() + (size_t)n_stack * per_wg + (size_t)h * SH::NWH * 256;
+        for (int tid = 0; tid < 256; ++tid) {
+            const int kq3 = tid % SH::T3, row3 = tid / SH::T3, e = h * EC + row3;
+            int j = 0;
+            for (int k = 0; k < SH::K3; ++k) img[(size_t)(j++) * 256 + tid] = w.end1_w[(size_t)e * S + kq3 * SH::K3 + k];
+            for (int k = 0; k < EC; ++k) img[(size_t)(j++) * 256 + tid] = w.end2_w[(size_t)tid * E + h * EC + k];
+            img[(size_t)(j++) * 256 + tid] = kq3 == 0 ? w.end1_b[e] : 0.f;
+            img[(size_t)(j++) * 256 + tid] = h == 0 ? w.end2_b[tid] : 0.f;
+        }
+    }
+}
+
+template <int R, int D, int S, int EC, int LPW>
+static WnV4Entry wn_v4_entry() {
+    using V = WnV4Shape<R, D, S>;
+    using SH = WnV2Shape<R, D, S, EC>;
+    WnV4Entry e;
+    e.R = R; e.D = D; e.S = S; e.EC = EC; e.LPW = LPW; e.nwpl = V::NWPL; e.nwh = SH::NWH;
+    e.pack = wn_pack_v4<R, D, S, EC, LPW>;
+    e.fn = (const void*)wn_generate_kernel_v4<R, D, S, EC, LPW>;
+    e.lds_pre_head = WnV3Lds<SH, 1>::pre;
+    e.lds_floats = [](int ns) {
+        int need = WnV4Lds<V, LPW>::floats(ns);
+        const int head = WnV3Lds<SH, 1>::pre + (SH::K3 > 100 ? SH::K3 : EC) * 256;   // the head lanes' LDS-resident weights (wn_v3_head)
+        const int smp = WnV3Lds<SH, 1>::pre + 256 * R;                               // start_conv^T in the sampler workgroups
+        if (head > need) need = head;
+        if (smp * 4 <= WN_LDS_MAX_BYTES && smp > need) need = smp;
+        return need;
+    };
+    e.launch = [](int grid, size_t lds, hipStream_t st, const WnPlan& p, const WnRun& r) {
+        hipLaunchKernelGGL((wn_generate_kernel_v4<R, D, S, EC, LPW>), dim3(grid), dim3(WN_THREADS_V4), lds, st, p, r);
+    };
+    return e;
+}
+
+static const std::vector<WnV4Entry>& wn_v4_table() {
+    static const std::vector<WnV4Entry> t = {
+        wn_v4_entry<64, 64, 256, 64, 3>(),     // cfg2 (BASELINE configs[1]): 10 stack workgroups
+        wn_v4_entry<32, 32, 256, 64, 5>(),     // cfg1 (configs[0]): 2
+        wn_v4_entry<32, 32, 1024, 32, 2>(),    // train_script.py:17-25, the reference's only trained model shape: 15
+    };
+    return t;
+}
+
+// true iff the stacked kernel serves this configuration: an instantiated shape exactly, few streams, no pinned split
+static bool wn_v4_applicable(const wn_config* cfg, int n_cu, int* out_vi, int* outPA) {
+    const char* force = wn_dev_env("WN_KERNEL");  // "v3" / "generic" pin another kernel (A/B runs, tests); "v4" lifts the stream limit
+    if (force && (!strcmp(force, "generic") || !strcmp(force, "v3"))) return false;
+    const bool forced = force && !strcmp(force, "v4");
+    if (cfg->kernel_size != 2 || cfg->classes != 256 || cfg->layer_split > 0 || cfg->head_split > 0) return false;
+    if (cfg->n_streams < 1 || (cfg->n_streams > WN_V4_MAX_STREAMS && !(forced && cfg->n_streams <= 16))) return false;
+    const std::vector<WnV4Entry>& t = wn_v4_table();
+    for (size_t i = 0; i < t.size(); ++i) {
+        const WnV4Entry& e = t[i];
+        if (e.R != cfg->residual_channels || e.D != cfg->dilation_channels || e.S != cfg->skip_channels || cfg->end_channels % e.EC) continue;
+        const int PA = cfg->end_channels / e.EC, NL = cfg->layers * cfg->blocks, n_stack = (NL + e.LPW - 1) / e.LPW;
+        if (PA > 16) continue;
+        const int n_smp = wn_sampler_count(cfg->n_streams);
+        if (n_stack + PA + n_smp > n_cu) continue;
+        if (e.lds_floats(cfg->n_streams) * 4 > WN_LDS_MAX_BYTES) continue;
+        if (out_vi) *out_vi = (int)i;
+        if (outPA) *outPA = PA;
+        return true;
+    }
+    return false;
+}
+
 // ------------------------------------------------------------------------------------------------ handle
 struct WnTrainLay {
     long long N, L, out_len;
@@ -386,7 +514,7 @@ static bool wn_pad_config(const wn_config* cfg, int n_cu, wn_config* padded) {
     if (cfg->kernel_size != 2 || cfg->classes != 256 || cfg->layer_split > 0 || cfg->head_split > 0 || (cfg->reserved[0] & WN_CFG_NO_PADDING)) return false;
     wn_config probe = *cfg;
     if (probe.n_streams > WN_V3_ROUND_STREAMS) probe.n_streams = WN_V3_ROUND_STREAMS;
-    if (wn_v3_applicable(&probe, n_cu, nullptr, nullptr, nullptr)) return false;   // served as it is
+    if (wn_v4_applicable(&probe, n_cu, nullptr, nullptr) || wn_v3_applicable(&probe, n_cu, nullptr, nullptr, nullptr)) return false;   // served as it is
     std::vector<WnShapeRow> rows;
     for (const WnV2Entry& e : wn_v2_table()) rows.push_back(WnShapeRow{e.R, e.DC, e.S, e.EC, e.Pm});
     int dims[4];
@@ -415,7 +543,7 @@ extern "C" int wn_create(const wn_config* cfg, wn_handle** out) {
             wn_config eff;
             if (wn_pad_config(cfg, n_cu, &eff)) {
                 const int rc = wn_create_impl(&eff, out);
-                if (rc == WN_OK && (*out)->variant == 3) {
+                if (rc == WN_OK && (*out)->variant >= 3) {
                     wn_handle* h = *out;
                     h->padded = true;
                     h->user_R = cfg->residual_channels; h->user_D = cfg->dilation_channels; h->user_S = cfg->skip_channels; h->user_E = cfg->end_channels;
@@ -534,8 +662,19 @@ static int wn_create_impl(const wn_config* cfg, wn_handle** out) {
     h->variant = 1; h->v2_index = -1;
     {
         int P2 = 0, PA2 = 0;
-        int vi3 = -1;
-        if (wn_v3_applicable(cfg, n_cu, &vi3, &P2, &PA2)) {
+        int vi3 = -1, vi4 = -1;
+        if (wn_v4_applicable(cfg, n_cu, &vi4, &PA2)) {
+            const WnV4Entry& ve = wn_v4_table()[vi4];
+            h->variant = 4; h->v2_index = vi4;
+            wn_plan_geometry(pl, 1, PA2);
+            pl.LPW = ve.LPW;
+            pl.n_lw = (pl.NL + ve.LPW - 1) / ve.LPW;
+            pl.n_smp = wn_sampler_count(cfg->n_streams);
+            pl.n_wg = pl.n_lw + PA2 + pl.n_smp;
+            pl.start_in_lds = (ve.lds_pre_head + 256 * pl.R) * 4 <= WN_LDS_MAX_BYTES ? 1 : 0;
+            h->lds_bytes = ve.lds_floats(pl.n_streams) * 4;
+            pl.lds_floats = h->lds_bytes / 4;
+        } else if (wn_v3_applicable(cfg, n_cu, &vi3, &P2, &PA2)) {
             h->variant = 3; h->v2_index = vi3;
             wn_plan_geometry(pl, P2, PA2);
             pl.n_smp = wn_sampler_count(cfg->n_streams);  // sampling runs on dedicated workgroups (they also feed layer 0)
@@ -576,20 +715,29 @@ static int wn_create_impl(const wn_config* cfg, wn_handle** out) {
     std::vector<int32_t> wg_map;
     pl.n_blocks = pl.n_wg;
     pl.allow_plain = 0;
-    if (h->variant == 3 && n_cu % 8 == 0 && wn_make_wg_map_layers(pl.NL, pl.P, pl.PA * pl.HR, pl.n_smp, 8, n_cu / 8, wg_map, &pl.n_blocks)) {
+    if ((h->variant == 3 || h->variant == 4) && n_cu % 8 == 0 &&
+        wn_make_wg_map_layers(h->variant == 4 ? pl.n_lw : pl.NL, pl.P, pl.PA * pl.HR, pl.n_smp, 8, n_cu / 8, wg_map, &pl.n_blocks)) {
         const char* np = wn_dev_env("WN_NO_LOCAL_STORES");
         pl.allow_plain = (np && np[0] == '1') ? 0 : 1;
     } else {
         wn_make_wg_map(pl.n_wg, 8, wg_map);
     }
-    const size_t n_lw = (size_t)pl.NL * pl.P;
+    const size_t n_lw = h->variant == 4 ? (size_t)pl.n_lw : (size_t)pl.NL * pl.P;
     const size_t gx_n = n_lw * pl.n_streams * pl.R, gs_n = n_lw * pl.n_streams * pl.S, gl_n = (size_t)pl.PA * pl.n_streams * pl.C;
-    const size_t g0_n = h->variant == 3 ? (size_t)pl.n_streams * pl.R : 0;
+    const size_t g0_n = h->variant >= 3 ? (size_t)pl.n_streams * pl.R : 0;
     h->gran_count = gx_n + gs_n + gl_n + (size_t)pl.n_streams + g0_n;
     h->blob_floats = n_lw * pl.blob_layer_floats + (size_t)pl.PA * pl.blob_head_floats;
+    pl.n_lw = (int32_t)n_lw; pl.head_blob_off = (int64_t)n_lw * pl.blob_layer_floats;
+    if (h->variant != 4) pl.LPW = 1;
+    if (h->variant == 4) {
+        const WnV4Entry& ve = wn_v4_table()[h->v2_index];
+        pl.head_blob_off = (int64_t)n_lw * ve.LPW * ve.nwpl * WN_THREADS_V4;
+        h->blob_floats = (size_t)pl.head_blob_off + (size_t)pl.PA * ve.nwh * 256;
+    }
     if (h->variant == 3) {
         const WnV2Entry& ve = wn_v2_table()[h->v2_index];
         h->blob_floats = n_lw * (size_t)ve.nwl * 256 + (size_t)pl.PA * ve.nwh * 256;
+        pl.head_blob_off = (int64_t)n_lw * ve.nwl * 256;
     }
     h->d_blobs = (float*)rt_malloc(h->blob_floats * 4);
     h->d_start_t = (float*)rt_malloc((size_t)pl.C * pl.R * 4);
@@ -620,7 +768,7 @@ static int wn_create_impl(const wn_config* cfg, wn_handle** out) {
     pl.g0 = pl.gi + pl.n_streams;
     pl.status = h->d_status;
     pl.xcc_tab = h->d_status + 8;
-    rc = rt_hip(hipFuncSetAttribute(h->variant == 3 ? wn_v2_table()[h->v2_index].fn_v3[h->v3_mode & 1] : (const void*)wn_generate_kernel,
+    rc = rt_hip(hipFuncSetAttribute(h->variant == 4 ? wn_v4_table()[h->v2_index].fn : h->variant == 3 ? wn_v2_table()[h->v2_index].fn_v3[h->v3_mode & 1] : (const void*)wn_generate_kernel,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes),
                 "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
     if (rc) { wn_destroy(h); return rc; }
@@ -688,7 +836,8 @@ static int wn_load_weights_impl(wn_handle* h, const wn_weight_ptrs* w) {
     WnHostWeights hw = {w->start_w, w->start_b, w->filter_w, w->filter_b, w->gate_w, w->gate_b, w->res_w,
                         w->res_b, w->skip_w, w->skip_b, w->end1_w, w->end1_b, w->end2_w, w->end2_b};
     std::vector<float> blobs;
-    if (h->variant == 3) wn_v2_table()[h->v2_index].pack(pl, hw, blobs);
+    if (h->variant == 4) wn_v4_table()[h->v2_index].pack(pl, hw, blobs);
+    else if (h->variant == 3) wn_v2_table()[h->v2_index].pack(pl, hw, blobs);
     else
         wn_pack_blobs(pl, hw, blobs);
     if (blobs.size() != h->blob_floats) return wn_fail(WN_E_STATE, "wn_load_weights: internal blob size mismatch");
@@ -905,7 +1054,9 @@ extern "C" int wn_generate(wn_handle* h, const wn_generate_args* a) {
     int rc = rt_memset_async(h->d_gran, 0, h->gran_count * 8, a->hip_stream);
     rc = rc ? rc : rt_memset_async(h->d_status, 0, (size_t)(8 + h->plan.n_wg) * 4, a->hip_stream);
     if (rc) { wn_gate_release(h->gate); h->gate.reset(); return rc; }
-    if (h->variant == 3)
+    if (h->variant == 4)
+        wn_v4_table()[h->v2_index].launch(h->plan.n_blocks, (size_t)h->lds_bytes, (hipStream_t)a->hip_stream, h->plan, r);
+    else if (h->variant == 3)
         wn_v2_table()[h->v2_index].launch_v3(h->v3_mode & 1, h->plan.n_blocks, (size_t)h->lds_bytes, (hipStream_t)a->hip_stream, h->plan, r);
     else
         hipLaunchKernelGGL(wn_generate_kernel, dim3(h->plan.n_blocks), dim3(WN_THREADS), (size_t)h->lds_bytes,
@@ -984,7 +1135,8 @@ extern "C" int wn_get_info(wn_handle* h, wn_info* out) {
     out->head_replicas = pl.HR;
     out->n_samplers = pl.n_smp;
     out->dev_overrides = h->dev_overrides;
-    out->layers_per_workgroup = 1;
+    out->layers_per_workgroup = h->variant == 4 ? pl.LPW : 1;
+    if (h->variant == 4) out->n_workgroups = pl.n_wg;
     out->gate_shared = h->gate_shared; out->gate_waited_ms = h->gate_waited_ms;
     { int need = 0, cap = 0; wn_gate_numbers(h, &need, &cap); out->gate_need_per_xcd = need; }
     return WN_OK;

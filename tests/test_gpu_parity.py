@@ -32,15 +32,21 @@ SMALL = [
 
 
 def _expected_variant(cfg, ns, layer_split=0):
-    """3 = wave-specialised kernel (csrc/wn_kernel_v3.h): every instantiated channel shape -- all BASELINE configs and the
+    """4 = stacked kernel (csrc/wn_kernel_v4.h: several layers per workgroup): cfg1, cfg2 and the train_script.py shape at 1-4 streams;
+    3 = wave-specialised kernel (csrc/wn_kernel_v3.h): every instantiated channel shape -- all BASELINE configs and the
     train_script.py shape (32 / 32 / 1024 / 512, split two ways); 1 = the generic LDS-resident kernel (pinned, or pinned splits; other
     shapes are zero-padded into a table shape: test_zero_padded_channel_shapes).
     (2 was the 256-thread register kernels of rounds 1-2: removed in round 3.)"""
     cfg = synth.CONFIGS[cfg] if isinstance(cfg, str) else cfg
     shape = (cfg["residual_channels"], cfg["dilation_channels"], cfg["skip_channels"], cfg["end_channels"])
     on3 = shape in ((128, 128, 512, 256), (64, 64, 256, 256), (32, 32, 256, 256), (32, 32, 1024, 512), (16, 16, 256, 32), (16, 32, 256, 64))
-    import os
-    return 3 if on3 and os.environ.get("WN_KERNEL") != "generic" else 1
+    on4 = shape in ((64, 64, 256, 256), (32, 32, 256, 256), (32, 32, 1024, 512)) and ns <= 4 and not layer_split
+    pin = os.environ.get("WN_KERNEL")
+    if pin == "generic":
+        return 1
+    if on4 and pin != "v3":
+        return 4
+    return 3 if on3 else 1
 
 
 MINI3 = dict(synth.CONFIGS["cfg3"], layers=3, blocks=2)   # cfg3's channel shape, 6 layers: the wave-specialised kernel on 36 workgroups
@@ -420,9 +426,11 @@ V3 = [("cfg2_ns1", "cfg2", 1, 120, 700), ("cfg2_ns5", "cfg2", 5, 80, 20),
 
 
 @pytest.mark.parametrize("label,cfg,ns,N,n_given", V3, ids=[c[0] for c in V3])
-def test_wave_specialised_kernel(label, cfg, ns, N, n_given):
+def test_wave_specialised_kernel(label, cfg, ns, N, n_given, monkeypatch):
     """Variant 3 (768-thread layer workgroups: critical, skip and queue wave groups; n_streams >= 4) against the oracle: greedy, sampled with a
-    regulariser, priming through the chain (n_given - 1 teacher-forced evaluations, batched priming off), every stream."""
+    regulariser, priming through the chain (n_given - 1 teacher-forced evaluations, batched priming off), every stream.
+    (WN_KERNEL=v3: the small shapes at few streams would otherwise take the stacked kernel, test_stacked_kernel.)"""
+    monkeypatch.setenv("WN_KERNEL", "v3")
     cfg, W, first, uniforms = make_case(cfg, 81, ns, n_given, N)
     eng = engine.Engine(cfg, W, n_streams=ns)
     info = eng.info()
@@ -447,6 +455,89 @@ def test_wave_specialised_kernel(label, cfg, ns, N, n_given):
     eng.close()
 
 
+# ---------------------------------------------------------------- stacked kernel (csrc/wn_kernel_v4.h): several layers per workgroup
+CHAC = "chaconne"
+V4 = [("cfg2_ns1", "cfg2", 1, 120, 700, None), ("cfg2_ns3", "cfg2", 3, 80, 20, None), ("cfg2_ns4_bias", dict(synth.CONFIGS["cfg2"], bias=True), 4, 60, 9, None),
+      ("cfg1_ns1_bias", dict(synth.CONFIGS["cfg1"], bias=True), 1, 200, 70, None), ("cfg1_ns4", "cfg1", 4, 150, 40, None),
+      ("chaconne_ns1", CHAC, 1, 100, 600, None), ("chaconne_ns2", CHAC, 2, 80, 30, None),
+      ("cfg2_8_layers", dict(synth.CONFIGS["cfg2"], layers=4, blocks=2), 2, 150, 20, None),      # 3 + 3 + 2 layers: a last workgroup that is not full
+      ("cfg1_7_layers", dict(synth.CONFIGS["cfg1"], layers=7, blocks=1), 1, 200, 140, None),     # 5 + 2
+      ("cfg1_1_layer", dict(synth.CONFIGS["cfg1"], layers=1, blocks=1), 2, 100, 5, None),         # the network's last layer is the first
+      ("cfg2_ns8_forced", "cfg2", 8, 60, 12, "v4")]                                                # beyond the planner's stream limit (WN_KERNEL=v4)
+
+
+@pytest.mark.parametrize("label,cfg,ns,N,n_given,pin", V4, ids=[c[0] for c in V4])
+def test_stacked_kernel(label, cfg, ns, N, n_given, pin, monkeypatch):
+    """Variant 4 (512-thread stack workgroups holding 2-5 consecutive layers; head and sampler roles of variant 3) against the oracle: greedy with
+    logits, sampled with a regulariser, priming through the chain past the queue wraps (batched priming off), every stream."""
+    if pin:
+        monkeypatch.setenv("WN_KERNEL", pin)
+    cfg, W, first, uniforms = make_case(cfg, 84, ns, n_given, N)
+    eng = engine.Engine(cfg, W, n_streams=ns)
+    info = eng.info()
+    assert info["kernel_variant"] == 4 and info["layers_per_workgroup"] >= 2 and info["n_chains"] == 1, info
+    ids, logits = eng.generate(N, first, temperature=0.0, want_logits=True, batched_prime=False, timeout_ms=8000)
+    for s in range(ns):
+        o_idx, o_log = c_oracle.generate(cfg, W, N, first[s], 0.0, 0.0)
+        tol = 1e-5 * max(1.0, float(np.abs(o_log).max()))
+        if not np.array_equal(ids[s], o_idx):  # an argmax flip is legitimate rounding only where the top-2 gap is degenerate ...
+            t = int(np.argmax(ids[s] != o_idx))
+            row = np.sort(o_log[t])
+            assert row[-1] - row[-2] <= 10 * tol, (label, s, t)
+            _, o_log = c_oracle.generate(cfg, W, N, first[s], 0.0, 0.0, forced=ids[s])
+        assert float(np.abs(logits[s] - o_log).max()) <= tol, (label, s)
+    sres = check_engine(eng, cfg, W, N, first, 0.9, 0.002, uniforms, label + " sampled")
+    print(label, sres, info)
+    eng.close()
+
+
+def test_stacked_kernel_host_calls(monkeypatch):
+    """The calls the facade makes around a job, on variant 4: prime-only, continuation without reset, one generated sample, per-stream
+    temperatures, batched priming (wn_prime fills the same rings), queue export -- and equality with variant 3 on the same job."""
+    cfg, W, first, uniforms = make_case("cfg2", 85, 3, 6, 64)
+    eng = engine.Engine(cfg, W, n_streams=3)
+    assert eng.info()["kernel_variant"] == 4
+    idx = eng.generate(0, first, temperature=0.0)
+    assert idx.shape == (3, 0) and eng.info()["evals_done"] == 5
+    full = eng.generate(64, first, temperature=1.0, uniforms=uniforms)
+    a = eng.generate(23, first, temperature=1.0, uniforms=uniforms[:, :23])
+    b = eng.generate(41, a[:, -1:], temperature=1.0, uniforms=uniforms[:, 23:], reset=False)
+    assert np.array_equal(np.concatenate([a, b], axis=1), full)
+    assert eng.info()["evals_done"] == 6 - 1 + 64
+    q4 = [eng.export_queue(l, 2) for l in (0, 2, 9, 29)]
+    one = eng.generate(1, first, temperature=1.0, uniforms=uniforms[:, :1])
+    assert np.array_equal(one, full[:, :1])
+    for s in range(3):
+        o_idx, _ = c_oracle.generate(cfg, W, 64, first[s], 1.0, 0.0, uniforms[s])
+        assert np.array_equal(full[s], o_idx), s
+    temps = np.array([0.0, 0.7, 1.3], dtype=np.float32)
+    out = eng.generate(40, first[:, :3], temperature=temps, uniforms=uniforms[:, :40])
+    for s in range(3):
+        o_idx, _ = c_oracle.generate(cfg, W, 40, first[s, :3], float(temps[s]), 0.0, uniforms[s, :40] if temps[s] > 0 else None)
+        assert np.array_equal(out[s], o_idx), s
+    # a long given window: batched priming (wn_prime) and chain priming leave the same queues behind
+    cfg, W, first2, u2 = make_case("cfg2", 86, 3, 3100, 50)
+    pa = eng2 = None
+    eng.load_weights(W)
+    pa = eng.generate(50, first2, temperature=1.0, uniforms=u2, batched_prime=True)
+    pb = eng.generate(50, first2, temperature=1.0, uniforms=u2, batched_prime=False, timeout_ms=8000)
+    assert np.array_equal(pa, pb)
+    o_idx, _ = c_oracle.generate(cfg, W, 50, first2[1], 1.0, 0.0, u2[1])
+    assert np.array_equal(pa[1], o_idx)
+    eng.close()
+    monkeypatch.setenv("WN_KERNEL", "v3")   # the first job again on the wave-specialised kernel: same samples, same queues (to rounding)
+    cfg, W, first, uniforms = make_case("cfg2", 85, 3, 6, 64)
+    old = engine.Engine(cfg, W, n_streams=3)
+    assert old.info()["kernel_variant"] == 3
+    a3 = old.generate(23, first, temperature=1.0, uniforms=uniforms[:, :23])
+    old.generate(41, a3[:, -1:], temperature=1.0, uniforms=uniforms[:, 23:], reset=False)
+    q3 = [old.export_queue(l, 2) for l in (0, 2, 9, 29)]
+    old.close()
+    assert np.array_equal(a3, a)
+    for (d4, i4, o4), (d3, i3, o3) in zip(q4, q3):   # (two fp32 summation orders, up to 30 layers deep)
+        assert (i4, o4) == (i3, o3) and np.abs(d4 - d3).max() <= 1e-5 * max(1.0, float(np.abs(d3).max()))
+
+
 PADDED = [
     # label, channel shape (dilation, residual, skip, end), layers x blocks, bias, streams: shapes the wave-specialised kernel is NOT compiled for
     ("pad_to_cfg1_shape", (24, 24, 200, 100), (4, 2), True, 2),     # -> 32 / 32 / 256 / 128
@@ -469,7 +560,7 @@ def test_zero_padded_channel_shapes(label, chans, depth, bias, ns):
     cfg, W, first, uniforms = make_case(cfg, 91, ns, n_given, N)
     eng = engine.Engine(cfg, W, n_streams=ns)
     info = eng.info()
-    assert info["kernel_variant"] == 3, info
+    assert info["kernel_variant"] in (3, 4), info   # (4: padded into cfg1's / cfg2's shape at few streams)
     g = check_engine(eng, cfg, W, N, first, 0.0, 0.0, None, label + " greedy")
     s = check_engine(eng, cfg, W, N, first, 0.9, 0.001, uniforms, label + " sampled")
     a = eng.generate(N, first, temperature=0.0)   # (batched priming: wn_prime on the padded banks where the padded shape has them)
