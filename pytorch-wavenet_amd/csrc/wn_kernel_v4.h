@@ -65,9 +65,13 @@ struct WnV4Lds {
     static __host__ __device__ int floats(int ns) { return pre + ns * LPW * 2 * V::D; }
 };
 
-static __device__ __forceinline__ float wn_v4_gate(float f, float g) {   // tanh(f) * sigmoid(g), the arithmetic of wn_v3_layer
-    const float rf = __builtin_amdgcn_rcpf(1.0f + wn_exp(-2.0f * f));
-    const float rg = __builtin_amdgcn_rcpf(1.0f + wn_exp(-g));
+// tanh(f) * sigmoid(g) = (2 s(2f) - 1) s(g), s(v) = 1 / (1 + e^-v).  e^-v is taken as exp2(-v log2 e) -- two operations on the token's path
+// instead of the eight of wn_exp (variant 3 carries the product -v log2 e in two floats).  The single rounding of that product moves
+// e^-v by |v| 6e-8 relative, and s damps it by s (1 - s) <= 1/4 and exponentially beyond |v| ~ 2: |ds| <= max |v| s (1 - s) 6e-8 = 1.4e-8,
+// a quarter of an fp32 ulp of the result -- below the rounding of the sums that feed it (the parity tests' bars are unchanged).
+static __device__ __forceinline__ float wn_v4_gate(float f, float g) {
+    const float rf = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(f * -2.88539008177792681f));   // -2 log2(e)
+    const float rg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(g * -1.44269504088896341f));
     return fmaf(2.0f, rf, -1.0f) * rg;
 }
 static __device__ __forceinline__ float wn_ld_sc1(const float* p) {   // served by the L2, never by this CU's L1
@@ -232,15 +236,18 @@ static __device__ void wn_v4_stack(const WnPlan& p, const WnRun& r, WnCtx& cx, f
                     for (int k4 = 0; k4 < KF / 4; ++k4) xv[k4] = reinterpret_cast<const float4*>(x + V::xpad(kq * KF))[k4];
                     const wn_f2 pf = *reinterpret_cast<const wn_f2*>(pre + ((size_t)s * LPW + li) * 2 * D + 2 * c8);
                     const float xres = x[V::xpad(r8)];
-                    wn_f2 a0 = kq == 0 ? pf : wn_f2{0.f, 0.f}, a1 = {0.f, 0.f};
+                    wn_f2 acc[4];   // four independent chains (KF = 8: two FMAs deep)
+                    acc[0] = kq == 0 ? pf : wn_f2{0.f, 0.f};
+                    acc[1] = acc[2] = acc[3] = wn_f2{0.f, 0.f};
 #pragma unroll
                     for (int k4 = 0; k4 < KF / 4; ++k4) {
-                        a0 = __builtin_elementwise_fma(w1[li][4 * k4], wn_f2{xv[k4].x, xv[k4].x}, a0);
-                        a1 = __builtin_elementwise_fma(w1[li][4 * k4 + 1], wn_f2{xv[k4].y, xv[k4].y}, a1);
-                        a0 = __builtin_elementwise_fma(w1[li][4 * k4 + 2], wn_f2{xv[k4].z, xv[k4].z}, a0);
-                        a1 = __builtin_elementwise_fma(w1[li][4 * k4 + 3], wn_f2{xv[k4].w, xv[k4].w}, a1);
+                        acc[0] = __builtin_elementwise_fma(w1[li][4 * k4], wn_f2{xv[k4].x, xv[k4].x}, acc[0]);
+                        acc[1] = __builtin_elementwise_fma(w1[li][4 * k4 + 1], wn_f2{xv[k4].y, xv[k4].y}, acc[1]);
+                        acc[2] = __builtin_elementwise_fma(w1[li][4 * k4 + 2], wn_f2{xv[k4].z, xv[k4].z}, acc[2]);
+                        acc[3] = __builtin_elementwise_fma(w1[li][4 * k4 + 3], wn_f2{xv[k4].w, xv[k4].w}, acc[3]);
                     }
-                    const float f = wn_reduce<8>(a0.x + a1.x), g = wn_reduce<8>(a0.y + a1.y);
+                    const wn_f2 asum = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+                    const float f = wn_reduce<8>(asum.x), g = wn_reduce<8>(asum.y);
                     const float z = wn_v4_gate(f, g);
                     if (fg_on && kq == 0) zl[li * ZP + V::xpad(c8)] = z;
                     if (li == 0 && fail_in) return;
@@ -250,13 +257,13 @@ static __device__ void wn_v4_stack(const WnPlan& p, const WnRun& r, WnCtx& cx, f
                         float4 zv[KR / 4];
 #pragma unroll
                         for (int k4 = 0; k4 < KR / 4; ++k4) zv[k4] = reinterpret_cast<const float4*>(zl + li * ZP + V::xpad(kq * KR))[k4];
-                        wn_f2 b = {0.f, 0.f};
+                        wn_f2 b = {0.f, 0.f}, b2 = {0.f, 0.f};
 #pragma unroll
                         for (int k4 = 0; k4 < KR / 4; ++k4) {
                             b = __builtin_elementwise_fma(wn_f2{wr[li][4 * k4], wr[li][4 * k4 + 1]}, wn_f2{zv[k4].x, zv[k4].y}, b);
-                            b = __builtin_elementwise_fma(wn_f2{wr[li][4 * k4 + 2], wr[li][4 * k4 + 3]}, wn_f2{zv[k4].z, zv[k4].w}, b);
+                            b2 = __builtin_elementwise_fma(wn_f2{wr[li][4 * k4 + 2], wr[li][4 * k4 + 3]}, wn_f2{zv[k4].z, zv[k4].w}, b2);
                         }
-                        const float xn = (wn_reduce<8>(b.x + b.y) + bres[li]) + xres;
+                        const float xn = (wn_reduce<8>((b.x + b.y) + (b2.x + b2.y)) + bres[li]) + xres;
                         if (li + 1 < nl) {
                             if (rs_on && kq == 0) xl[(li + 1) * XP + V::xpad(r8)] = xn;
                             wn_lds_barrier();
@@ -298,9 +305,13 @@ static __device__ void wn_v4_stack(const WnPlan& p, const WnRun& r, WnCtx& cx, f
 #pragma unroll
                 for (int q = 0; q < RS; ++q) a3[q] = 0.f;
                 if (work) {
-                    wn_f2 ap[NPL > 0 ? NPL : 1], ao = {0.f, 0.f};
+                    // (independent chains: a single accumulator over the workgroup's layers is one dependent chain of LPW KS / 2 packed FMAs --
+                    //  on the token's path in the LAST workgroup, whose lane the head waits for)
+                    wn_f2 ap[NPL > 0 ? NPL : 1][2], ao[4];
 #pragma unroll
-                    for (int h2 = 0; h2 < NPL; ++h2) ap[h2] = wn_f2{0.f, 0.f};
+                    for (int h2 = 0; h2 < NPL; ++h2) ap[h2][0] = ap[h2][1] = wn_f2{0.f, 0.f};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) ao[k] = wn_f2{0.f, 0.f};
 #pragma unroll
                     for (int li = 0; li < LPW; ++li) {
                         if (li < nl) {
@@ -314,30 +325,35 @@ static __device__ void wn_v4_stack(const WnPlan& p, const WnRun& r, WnCtx& cx, f
                                 for (int k = 0; k < 4; ++k) {
                                     const int kk = 4 * (c4 + k);
                                     if constexpr (ODD) {   // one row: {w[2j], w[2j+1]} . {z[2j], z[2j+1]}
-                                        ao = __builtin_elementwise_fma(ws[li][kk / 2], wn_f2{zv[k].x, zv[k].y}, ao);
-                                        ao = __builtin_elementwise_fma(ws[li][kk / 2 + 1], wn_f2{zv[k].z, zv[k].w}, ao);
+                                        ao[k] = __builtin_elementwise_fma(ws[li][kk / 2], wn_f2{zv[k].x, zv[k].y}, ao[k]);
+                                        ao[k] = __builtin_elementwise_fma(ws[li][kk / 2 + 1], wn_f2{zv[k].z, zv[k].w}, ao[k]);
                                     }
 #pragma unroll
                                     for (int h2 = 0; h2 < NPL; ++h2) {   // rows 2h, 2h+1 side by side: {w[2h][k], w[2h+1][k]} . z[k]
-                                        ap[h2] = __builtin_elementwise_fma(ws[li][h2 * KS + kk], wn_f2{zv[k].x, zv[k].x}, ap[h2]);
-                                        ap[h2] = __builtin_elementwise_fma(ws[li][h2 * KS + kk + 1], wn_f2{zv[k].y, zv[k].y}, ap[h2]);
-                                        ap[h2] = __builtin_elementwise_fma(ws[li][h2 * KS + kk + 2], wn_f2{zv[k].z, zv[k].z}, ap[h2]);
-                                        ap[h2] = __builtin_elementwise_fma(ws[li][h2 * KS + kk + 3], wn_f2{zv[k].w, zv[k].w}, ap[h2]);
+                                        ap[h2][0] = __builtin_elementwise_fma(ws[li][h2 * KS + kk], wn_f2{zv[k].x, zv[k].x}, ap[h2][0]);
+                                        ap[h2][1] = __builtin_elementwise_fma(ws[li][h2 * KS + kk + 1], wn_f2{zv[k].y, zv[k].y}, ap[h2][1]);
+                                        ap[h2][0] = __builtin_elementwise_fma(ws[li][h2 * KS + kk + 2], wn_f2{zv[k].z, zv[k].z}, ap[h2][0]);
+                                        ap[h2][1] = __builtin_elementwise_fma(ws[li][h2 * KS + kk + 3], wn_f2{zv[k].w, zv[k].w}, ap[h2][1]);
                                     }
                                 }
                             }
 #pragma unroll
-                            for (int h2 = 0; h2 < NPL; ++h2) ap[h2] += wn_f2{bskip[li][2 * h2], bskip[li][2 * h2 + 1]};
-                            if constexpr (ODD) ao.x += bskip[li][RS - 1];
+                            for (int h2 = 0; h2 < NPL; ++h2) ap[h2][0] += wn_f2{bskip[li][2 * h2], bskip[li][2 * h2 + 1]};
+                            if constexpr (ODD) ao[0].x += bskip[li][RS - 1];
                         }
                     }
                     // the two halves of z (lanes 2 sr, 2 sr + 1), then the upstream lane
 #pragma unroll
                     for (int h2 = 0; h2 < NPL; ++h2) {
-                        a3[2 * h2] = ap[h2].x + wn_partner<1>(ap[h2].x);
-                        a3[2 * h2 + 1] = ap[h2].y + wn_partner<1>(ap[h2].y);
+                        const wn_f2 v = ap[h2][0] + ap[h2][1];
+                        a3[2 * h2] = v.x + wn_partner<1>(v.x);
+                        a3[2 * h2 + 1] = v.y + wn_partner<1>(v.y);
                     }
-                    if constexpr (ODD) { const float v = ao.x + ao.y; a3[RS - 1] = v + wn_partner<1>(v); }
+                    if constexpr (ODD) {
+                        const wn_f2 v2 = (ao[0] + ao[1]) + (ao[2] + ao[3]);
+                        const float v = v2.x + v2.y;
+                        a3[RS - 1] = v + wn_partner<1>(v);
+                    }
                     if (w > 0) {
 #pragma unroll
                         for (int h2 = 0; h2 < NPL; ++h2) {
