@@ -57,7 +57,7 @@
 #define WN_V3_COMPILER_VGPRS 152  // v152-v167: request sets of the input poll / the queue group's tap FIFO (see wn_ap_*, wn_q_*)
 // ---- experiment switches.  A product build (build.py) leaves every one of them at its default; setting one requires -DWN_EXPERIMENT,
 // which build.py never passes (tools/ builds the A/B variants): a library with wrong-on-purpose timing ablations cannot ship by accident.
-#if !defined(WN_EXPERIMENT) && (defined(WN_V3_SKIP_SLEEP) || defined(WN_V3_ABL) || defined(WN_V3_PAIR_ROWS) || defined(WN_V3_PRIO) || defined(WN_V3_LAST_SKIP_PRIO))
+#if !defined(WN_EXPERIMENT) && (defined(WN_V3_SKIP_SLEEP) || defined(WN_V3_ABL) || defined(WN_V3_PAIR_ROWS) || defined(WN_V3_PRIO) || defined(WN_V3_LAST_SKIP_PRIO) || defined(WN_V3_SKIP_CHAINS) || defined(WN_V3_FG_CHAINS))
 #error "WN_V3_* experiment switches need -DWN_EXPERIMENT"
 #endif
 #ifndef WN_V3_SKIP_SLEEP
@@ -73,6 +73,12 @@
 #endif
 #ifndef WN_V3_LAST_SKIP_PRIO
 #define WN_V3_LAST_SKIP_PRIO 3  // wave priority of the LAST layer's skip group in the two-streams-per-item form (64 streams: 998.6 -> 1004.5 k)
+#endif
+#ifndef WN_V3_SKIP_CHAINS
+#define WN_V3_SKIP_CHAINS 1  // independent FMA chains per row pair of the skip group's dot (1: one chain of DC packed FMAs, the arithmetic of rounds 2-3)
+#endif
+#ifndef WN_V3_FG_CHAINS
+#define WN_V3_FG_CHAINS 4    // ... per stream of the critical group's filter/gate dot in the pair-rows form (2: rounds 2-3; 4: 64 streams 1000 -> 1010 k, profiles/r04_fma_chain_experiments.txt)
 #endif
 #ifndef WN_V3_PRIO
 #define WN_V3_PRIO 1  // 1: critical waves at a higher static wave priority (the queue and skip waves share their SIMDs: x64 911 -> 919 k, profiles/r02_v3_tap_fifo.txt)
@@ -587,12 +593,12 @@ static __device__ void wn_v3_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
                 }
                 if constexpr (PAIR) {
                     // the parked tap-0 sums are per image lane (row, kq1): the lane with the first half of slice kq1 takes both rows' sums
-                    wn_f2 a0[G], a1[G];
+                    wn_f2 a0[G], a1[G], a2[G], a3x[G];
 #pragma unroll
                     for (int g = 0; g < G; ++g) {
                         const float pf = pre[(s + g) * 256 + t_f], pg = pre[(s + g) * 256 + t_f + T1];
                         a0[g] = half8 ? wn_f2{0.f, 0.f} : wn_f2{pf, pg};
-                        a1[g] = wn_f2{0.f, 0.f};
+                        a1[g] = a2[g] = a3x[g] = wn_f2{0.f, 0.f};
                     }
                     float4 v[G][K8 / 4];
                     const float* xsl = xb + (kq8 / 2) * (K1 + 4) + half8 * K8;
@@ -603,12 +609,21 @@ static __device__ void wn_v3_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
 #pragma unroll
                     for (int k = 0; k < K8 / 4; ++k)
 #pragma unroll
-                        for (int g = 0; g < G; ++g) {  // two chains of packed {filter, gate} FMAs per stream, the streams interleaved
+                        for (int g = 0; g < G; ++g) {  // two (or four) chains of packed {filter, gate} FMAs per stream, the streams interleaved
                             a0[g] = __builtin_elementwise_fma(wfg[4 * k], wn_f2{v[g][k].x, v[g][k].x}, a0[g]);
                             a1[g] = __builtin_elementwise_fma(wfg[4 * k + 1], wn_f2{v[g][k].y, v[g][k].y}, a1[g]);
-                            a0[g] = __builtin_elementwise_fma(wfg[4 * k + 2], wn_f2{v[g][k].z, v[g][k].z}, a0[g]);
-                            a1[g] = __builtin_elementwise_fma(wfg[4 * k + 3], wn_f2{v[g][k].w, v[g][k].w}, a1[g]);
+                            if constexpr (WN_V3_FG_CHAINS == 4) {
+                                a2[g] = __builtin_elementwise_fma(wfg[4 * k + 2], wn_f2{v[g][k].z, v[g][k].z}, a2[g]);
+                                a3x[g] = __builtin_elementwise_fma(wfg[4 * k + 3], wn_f2{v[g][k].w, v[g][k].w}, a3x[g]);
+                            } else {
+                                a0[g] = __builtin_elementwise_fma(wfg[4 * k + 2], wn_f2{v[g][k].z, v[g][k].z}, a0[g]);
+                                a1[g] = __builtin_elementwise_fma(wfg[4 * k + 3], wn_f2{v[g][k].w, v[g][k].w}, a1[g]);
+                            }
                         }
+                    if constexpr (WN_V3_FG_CHAINS == 4) {
+#pragma unroll
+                        for (int g = 0; g < G; ++g) { a0[g] = a0[g] + a2[g]; a1[g] = a1[g] + a3x[g]; }
+                    }
                     // tanh(f) * sigmoid(g): even lanes of the channel's group evaluate the filter factor 2 sigmoid(2f) - 1, odd lanes the gate
                     // factor sigmoid(g) (one exp and one reciprocal per lane), and each takes the other from its neighbour
                     float z[G];
@@ -757,11 +772,17 @@ static __device__ void wn_v3_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
                 const bool work = !prime && !(WN_V3_ABL & 1);
                 if (work) {
                     // per row: bias, then + w[k] z[k] for k = 0..DC-1 in order (one fused multiply-add each), as before the packing
-                    wn_f2 a3p[G][NPL > 0 ? NPL : 1], a3o[G];
+                    constexpr int SC = WN_V3_SKIP_CHAINS;
+                    static_assert(SC == 1 || SC == 2 || SC == 4, "chains per row pair");
+                    wn_f2 a3c[G][NPL > 0 ? NPL : 1][SC], a3o[G];
 #pragma unroll
                     for (int g = 0; g < G; ++g) {
 #pragma unroll
-                        for (int h2 = 0; h2 < NPL; ++h2) a3p[g][h2] = wn_f2{bskip[2 * h2], bskip[2 * h2 + 1]};
+                        for (int h2 = 0; h2 < NPL; ++h2) {
+                            a3c[g][h2][0] = wn_f2{bskip[2 * h2], bskip[2 * h2 + 1]};
+#pragma unroll
+                            for (int c2 = 1; c2 < SC; ++c2) a3c[g][h2][c2] = wn_f2{0.f, 0.f};
+                        }
                         a3o[g] = wn_f2{ODD ? bskip[RS - 1] : 0.f, 0.f};
                     }
                     float4 z4[G][DC / 4];
@@ -774,11 +795,11 @@ static __device__ void wn_v3_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
 #pragma unroll
                         for (int g = 0; g < G; ++g) {  // (the streams' chains interleaved in program order)
 #pragma unroll
-                            for (int h2 = 0; h2 < NPL; ++h2) {
-                                a3p[g][h2] = __builtin_elementwise_fma(w3p[h2][4 * k], wn_f2{z4[g][k].x, z4[g][k].x}, a3p[g][h2]);
-                                a3p[g][h2] = __builtin_elementwise_fma(w3p[h2][4 * k + 1], wn_f2{z4[g][k].y, z4[g][k].y}, a3p[g][h2]);
-                                a3p[g][h2] = __builtin_elementwise_fma(w3p[h2][4 * k + 2], wn_f2{z4[g][k].z, z4[g][k].z}, a3p[g][h2]);
-                                a3p[g][h2] = __builtin_elementwise_fma(w3p[h2][4 * k + 3], wn_f2{z4[g][k].w, z4[g][k].w}, a3p[g][h2]);
+                            for (int h2 = 0; h2 < NPL; ++h2) {   // (chain j takes the z elements 4 k + j', j' = j mod SC)
+                                a3c[g][h2][0] = __builtin_elementwise_fma(w3p[h2][4 * k], wn_f2{z4[g][k].x, z4[g][k].x}, a3c[g][h2][0]);
+                                a3c[g][h2][1 % SC] = __builtin_elementwise_fma(w3p[h2][4 * k + 1], wn_f2{z4[g][k].y, z4[g][k].y}, a3c[g][h2][1 % SC]);
+                                a3c[g][h2][2 % SC] = __builtin_elementwise_fma(w3p[h2][4 * k + 2], wn_f2{z4[g][k].z, z4[g][k].z}, a3c[g][h2][2 % SC]);
+                                a3c[g][h2][3 % SC] = __builtin_elementwise_fma(w3p[h2][4 * k + 3], wn_f2{z4[g][k].w, z4[g][k].w}, a3c[g][h2][3 % SC]);
                             }
                             if constexpr (ODD) {
                                 a3o[g] = __builtin_elementwise_fma(w3o[2 * k], wn_f2{z4[g][k].x, z4[g][k].y}, a3o[g]);
@@ -789,7 +810,12 @@ static __device__ void wn_v3_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
 #pragma unroll
                     for (int g = 0; g < G; ++g) {
 #pragma unroll
-                        for (int h2 = 0; h2 < NPL; ++h2) { a3[g][2 * h2] = a3p[g][h2].x; a3[g][2 * h2 + 1] = a3p[g][h2].y; }
+                        for (int h2 = 0; h2 < NPL; ++h2) {
+                            wn_f2 v = a3c[g][h2][0];
+                            if constexpr (SC == 2) v = v + a3c[g][h2][1];
+                            if constexpr (SC == 4) v = (v + a3c[g][h2][1]) + (a3c[g][h2][2] + a3c[g][h2][3]);
+                            a3[g][2 * h2] = v.x; a3[g][2 * h2 + 1] = v.y;
+                        }
                         if constexpr (ODD) a3[g][RS - 1] = a3o[g].x + a3o[g].y;
                     }
                     if (l > 0) {
