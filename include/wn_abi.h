@@ -192,9 +192,14 @@ int wn_export_queue(wn_handle* h, int32_t layer, int32_t stream, float* host_dat
 /* WaveNetModel.forward() (wavenet_model.py:186-196) for one-hot inputs given as class indices: `indices` is a DEVICE
  * pointer to int32 [N][L]; writes fp32 logits [N*output_length][classes] (row = n*output_length + t, like the reference's
  * transpose+view at :194-196) to the DEVICE pointer `logits`.  The dilated-conv stack runs as fp32 matrix-core GEMMs
- * (csrc/wn_forward.h).  Asynchronous on hip_stream.  WN_E_UNSUPPORTED when L < receptive_field + output_length - 1 (the
- * reference then zero-pads activations, Appendix A item 18 of SURVEY.md), kernel_size != 2, or channel counts that are not
- * multiples of 32: callers use the torch path for those. */
+ * (csrc/wn_forward.h).  Asynchronous on hip_stream.  Clips shorter than receptive_field + output_length - 1 are served too: the
+ * reference left-pads the layers' inputs with zero activations where their length is not a multiple of the dilation
+ * (wavenet_modules.py:24-27) and the kernels read the tap x(t - d) as zero on exactly those rows
+ * (round 4; the same holds for wn_train_forward / wn_train_backward: pad zeros carry no gradient).  WN_E_UNSUPPORTED for clip
+ * lengths at which the reference itself has no defined result -- a layer left without an output position, the skip path's
+ * un-dilation quirk at a per-row length of 1 (Appendix A item 17), fewer than output_length final positions; the message names
+ * the layer --, for kernel_size != 2 and for channel counts that are not multiples of 32 (after zero padding): callers use the
+ * torch path for those, which reproduces what the reference does there. */
 int wn_forward(wn_handle* h, const int32_t* indices, int64_t N, int64_t L, int64_t output_length, float* logits, void* hip_stream);
 
 /* Operand precision of wn_forward, wn_train_forward and the products of wn_train_backward (activation gradients AND weight

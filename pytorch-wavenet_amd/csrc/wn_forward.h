@@ -471,7 +471,9 @@ struct WnGemmTnArgs {
                            // b_bf16: B is STORED as bf16 (its base points at unsigned short, its strides count bf16 elements): the bf16
                            // step's [dF|dG] and z.  wn_bwd_gemm_tn_bf16<*, true> only.
     int c_trans, a_bf16;   // c_trans: C is stored transposed, element (ka, nb) at c[nb * ldc + ka] (operands swapped by the caller so that the
-};                         // bf16-stored one is B);  a_bf16: A is stored as bf16 (excludes ka_split, relu_a, a_idx)
+                           // bf16-stored one is B);  a_bf16: A is stored as bf16 (excludes ka_split, relu_a, a_idx)
+    int a_skip_lo;         // row window of view `a` (not a1): it reads as ZERO on the first a_skip_lo rows of every batch entry (their addresses are
+};                         // never formed into loads) -- the tap x(t - d) where the reference's left zero padding stands in for it (fp32-stored A only)
 
 __global__ __launch_bounds__(256, WN_GEMM_MINB) void wn_bwd_gemm_tn(WnGemmTnArgs g) {
     constexpr int T = 128, KC = WN_GEMM_KC, NQ = KC / 8, LT = 256 / KC;  // NQ float4 per thread per operand, LT threads per row
@@ -510,9 +512,11 @@ __global__ __launch_bounds__(256, WN_GEMM_MINB) void wn_bwd_gemm_tn(WnGemmTnArgs
                 va[q] = make_float4(cls == k ? 1.f : 0.f, cls == k + 1 ? 1.f : 0.f, cls == k + 2 ? 1.f : 0.f, cls == k + 3 ? 1.f : 0.f);
             }
         } else {
-            const float* ap = ok ? wn_row(amap, m, g.rows_per_batch) + kap0 + lcol : nullptr;
+            bool oka = ok;
+            if (ok && !second && g.a_skip_lo > 0) oka = (int)((unsigned)m % (unsigned)g.rows_per_batch) >= g.a_skip_lo;
+            const float* ap = oka ? wn_row(amap, m, g.rows_per_batch) + kap0 + lcol : nullptr;
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) va[q] = (ok && ka0 + lcol + q * 4 < g.Ka) ? *reinterpret_cast<const float4*>(ap + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int q = 0; q < NQ; ++q) va[q] = (oka && ka0 + lcol + q * 4 < g.Ka) ? *reinterpret_cast<const float4*>(ap + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
         const float* bp = ok ? wn_row(g.b, m, g.rows_per_batch) + nb0 + lcol : nullptr;
 #pragma unroll
@@ -652,9 +656,10 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? WN_TN_BF16_MINB : 4) void 
         long long m = mc + mg * 8;
         unsigned q = (unsigned)m / (unsigned)g.rows_per_batch, rem = (unsigned)m - q * (unsigned)g.rows_per_batch;
         const float* ptr = rm.base + (long long)q * rm.batch_stride + (rm.t0 + (long long)rem) * rm.row_stride + pcol0;
+        const int win_lo = (is_b || second) ? 0 : g.a_skip_lo;   // (view `a` only)
 #pragma unroll
         for (int rr = 0; rr < 8; ++rr) {
-            v[rr] = (col_ok && m + rr < m_end) ? *reinterpret_cast<const float4*>(ptr) : make_float4(0.f, 0.f, 0.f, 0.f);
+            v[rr] = (col_ok && m + rr < m_end && (int)rem >= win_lo) ? *reinterpret_cast<const float4*>(ptr) : make_float4(0.f, 0.f, 0.f, 0.f);
             if (++rem == (unsigned)g.rows_per_batch) {  // next row is in the next batch entry
                 rem = 0; ++q;
                 ptr = rm.base + (long long)q * rm.batch_stride + rm.t0 * rm.row_stride + pcol0;

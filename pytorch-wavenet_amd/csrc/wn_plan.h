@@ -432,4 +432,32 @@ static inline int wn_pad_pick(const WnShapeRow* rows, int n_rows, int R, int D, 
     }
     return pick;
 }
+
+// ---- time geometry of WaveNetModel.forward() (wn_forward / wn_train_*; comment: wn_runtime.hip above wn_forward_geometry)
+struct WnFwdGeom { std::vector<long long> a, rows, zlo; };
+// dil[l] = dilation of layer l.  Returns "" and fills g, or the reason why the reference has no defined result for clips of L samples.
+static inline std::string wn_forward_geometry_host(const int32_t* dil, int NL, long long L, long long out_len, WnFwdGeom& g) {
+    g.a.assign(NL + 1, 0); g.rows.assign(NL + 1, 0); g.zlo.assign(NL, 0);
+    for (int l = 0; l < NL; ++l) {
+        const long long d = dil[l], len = L - g.a[l];
+        if (len < 1) return "L=" + std::to_string(L) + " leaves layer " + std::to_string(l) + " without input (the reference's conv fails there)";
+        const long long pad = (d - len % d) % d, steps = (len + pad) / d;   // per-row length of the dilated layout
+        if (steps < 2) return "L=" + std::to_string(L) + " leaves layer " + std::to_string(l) + " (dilation " + std::to_string(d) + ") no output position";
+        if (steps == 2 && d > 1)
+            return "L=" + std::to_string(L) + " gives layer " + std::to_string(l) + " (dilation " + std::to_string(d) + ") a per-row output length of 1: the reference "
+                   "skips the skip path's un-dilation there (wavenet_model.py:155) and its shapes no longer match";
+        g.a[l + 1] = g.a[l] - pad + d;
+    }
+    if (L - g.a[NL] < out_len)
+        return "L=" + std::to_string(L) + " yields " + std::to_string(L - g.a[NL]) + " output positions, output_length is " + std::to_string(out_len) +
+               " (the reference's view(n * l, c) fails)";
+    g.rows[NL] = out_len;
+    for (int l = NL - 1; l >= 0; --l) {
+        const long long want = g.rows[l + 1] + dil[l], have = L - g.a[l];
+        g.rows[l] = want < have ? want : have;
+        const long long z = g.a[l] + dil[l] - (L - g.rows[l + 1]);
+        g.zlo[l] = z > 0 ? z : 0;
+    }
+    return std::string();
+}
 #endif  // WN_PLAN_H

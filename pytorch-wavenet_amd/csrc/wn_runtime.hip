@@ -410,7 +410,8 @@ static bool wn_v4_applicable(const wn_config* cfg, int n_cu, int* out_vi, int* o
 // ------------------------------------------------------------------------------------------------ handle
 struct WnTrainLay {
     long long N, L, out_len;
-    std::vector<long long> need;          // need[l] = trailing time steps of layer l's input the loss depends on
+    std::vector<long long> need;          // need[l] = trailing time steps of layer l's input the loss depends on (and that exist: wn_forward_geometry)
+    std::vector<long long> zlo;           // zlo[l] = leading output rows of layer l whose tap x(t - d) is one of the reference's pad zeros
     std::vector<size_t> x, z, th, sg;     // per layer offsets (floats) into the training workspace
     size_t skip, ev, zg, dzg, bskip_total, res_o, skip_o, w1_o, w2_o, fgb0, fgb1, dskip, de, dz, dfg, dxa, dxb, colsum_tmp, idx, total;
     size_t bw, bt_fg, bt_res, bt_skip, bt_w1, bt_w2;  // bf16 operand banks (offsets in floats)
@@ -1191,6 +1192,22 @@ extern "C" int wn_profile_read(wn_handle* h, int64_t* host_out, int64_t capacity
     return rt_d2h(host_out, h->d_prof, (size_t)n * 8);
 }
 
+// Time geometry of WaveNetModel.forward() for clips of L samples (wavenet_modules.py:10-39 `dilate`, wavenet_model.py:125-196).
+// In absolute time every layer's sequence ends at L (a kernel-size-2 dilated conv drops its input's first d positions).  Where the
+// length of a layer's input is not a multiple of its dilation the reference left-pads it with ZERO ACTIVATIONS (wavenet_modules.py:24-27),
+// so layer l's input lives on [a[l], L) preceded by pad[l] = (-(L - a[l])) mod d zeros, and its output on [a[l+1], L) with
+// a[l+1] = a[l] - pad[l] + d.  With L >= receptive_field + output_length - 1 none of the returned positions can see a pad zero (the
+// regime of rounds 1-3); shorter clips can: the tap x(t - d) then reads as zero for t - d < a[l] (row windows of the GEMMs' A views).
+//   rows[l] = trailing positions of layer l's input that are computed = min(rows[l+1] + d, L - a[l]);   zlo[l] = leading output rows of
+//   layer l whose tap is a pad zero.
+// Returns WN_E_UNSUPPORTED where the reference itself has no defined result: a layer left with no output position, the skip
+// un-dilation quirk at a per-row length of 1, fewer than output_length final positions (its view fails).
+static int wn_forward_geometry(const wn_handle* h, long long L, long long out_len, WnFwdGeom& g, const char* who) {
+    const std::string why = wn_forward_geometry_host(h->dil.data(), h->plan.NL, L, out_len, g);   // (wn_plan.h: plain host arithmetic, tested with g++)
+    if (!why.empty()) return wn_fail(WN_E_UNSUPPORTED, "%s: %s", who, why.c_str());
+    return WN_OK;
+}
+
 // WaveNetModel.forward() for one-hot inputs (class indices), see wn_forward.h.  Asynchronous on hip_stream.
 extern "C" int wn_forward(wn_handle* h, const int32_t* indices, int64_t N, int64_t L, int64_t out_len, float* logits, void* hip_stream) {
     g_err[0] = 0;
@@ -1201,15 +1218,11 @@ extern "C" int wn_forward(wn_handle* h, const int32_t* indices, int64_t N, int64
     const WnPlan& pl = h->plan;
     const int R = pl.R, D = pl.D, S = pl.S, E = pl.E, C = pl.C, NL = pl.NL;
     if (!h->fw_ok) return wn_fail(WN_E_UNSUPPORTED, "wn_forward: needs kernel_size 2 and channel counts that are multiples of 32");
-    const long long rf = 1 + (long long)pl.blocks * ((1 << pl.layers) - 1);
-    if (L < rf + out_len - 1)
-        return wn_fail(WN_E_UNSUPPORTED, "wn_forward: L=%lld < receptive_field + output_length - 1 = %lld (the reference zero-pads "
-                       "activations there; use the torch path)", (long long)L, (long long)(rf + out_len - 1));
     if ((long long)N * L >= 0x7fffffffll) return wn_fail(WN_E_UNSUPPORTED, "wn_forward: N*L must stay below 2^31 rows");
     { int rc = rt_hip(hipSetDevice(h->cfg.device_id), "hipSetDevice"); if (rc) return rc; }
-    std::vector<long long> need(NL + 1);
-    need[NL] = out_len;
-    for (int l = NL - 1; l >= 0; --l) need[l] = need[l + 1] + h->dil[l];
+    WnFwdGeom geo;
+    { int rc = wn_forward_geometry(h, L, out_len, geo, "wn_forward"); if (rc) return rc; }
+    const std::vector<long long>& need = geo.rows;
     const size_t x_fl = (size_t)N * L * R, z_fl = (size_t)N * need[1 < NL ? 1 : NL] * D > (size_t)N * need[NL] * D ? (size_t)N * need[1 < NL ? 1 : NL] * D : (size_t)N * need[NL] * D;
     // The skip sum over layers is accumulated G layers at a time: the gate epilogue also drops z (last output_length rows)
     // into column block (l mod G) of ZG [N*out_len][G*D], and one GEMM with K = G*D adds the group to SKIP -- instead of a
@@ -1245,6 +1258,7 @@ extern "C" int wn_forward(wn_handle* h, const int32_t* indices, int64_t N, int64
         memset(&a, 0, sizeof(a));
         // z = gate([x(t-d) | x(t)] . Wfg^T)
         a.a0 = WnRowMap{xin, (long long)L * R, R, t0 - d};
+        a.a_skip_lo[0] = (int)geo.zlo[l];   // (short clips: the reference's left zero padding stands in for x(t - d) there)
         a.a1 = WnRowMap{xin, (long long)L * R, R, t0};
         a.k_split = R; a.K = 2 * R; a.bt = fw + h->fw_off_fg + (size_t)l * 2 * R * 2 * D; a.N = 2 * D;
         a.bias = pl.has_bias ? fw + h->fw_off_bfg + (size_t)l * 2 * D : nullptr;

@@ -19,13 +19,16 @@
 //   "TN" products (weight gradients) use wn_bwd_gemm_tn; bias gradients are column sums.
 
 
-static void wn_train_layout_ws(const wn_handle* h, long long N, long long L, long long out_len, WnTrainLay& t) {
+static int wn_train_layout_ws(const wn_handle* h, long long N, long long L, long long out_len, WnTrainLay& t) {
     const WnPlan& pl = h->plan;
     const int R = pl.R, D = pl.D, S = pl.S, E = pl.E, C = pl.C, NL = pl.NL;
     t.N = N; t.L = L; t.out_len = out_len;
-    t.need.assign(NL + 1, 0);
-    t.need[NL] = out_len;
-    for (int l = NL - 1; l >= 0; --l) t.need[l] = t.need[l + 1] + h->dil[l];
+    {   // need[l]: trailing positions of layer l's input the loss depends on AND that exist; zlo[l]: rows whose tap is a pad zero (wn_forward_geometry)
+        WnFwdGeom geo;
+        const int rc = wn_forward_geometry(h, L, out_len, geo, "wn_train_forward");
+        if (rc) return rc;
+        t.need = geo.rows; t.zlo = geo.zlo;
+    }
     t.G = pl.layers < NL ? pl.layers : NL;
     size_t o = 0;
     auto take = [&](size_t n) { size_t r = o; o += (n + 63) & ~(size_t)63; return r; };
@@ -51,6 +54,7 @@ static void wn_train_layout_ws(const wn_handle* h, long long N, long long L, lon
     t.bt_fg = take((size_t)NL * 2 * D * 2 * R / 2); t.bt_res = take((size_t)NL * R * D / 2); t.bt_skip = take((size_t)NL * S * D / 2);
     t.bt_w1 = take((size_t)E * S / 2); t.bt_w2 = take((size_t)C * E / 2);
     t.total = o;
+    return WN_OK;
 }
 
 extern "C" int wn_train_get_layout(wn_handle* h, wn_train_layout* out) {
@@ -124,15 +128,11 @@ extern "C" int wn_train_forward(wn_handle* h, const float* params, const int32_t
     const int R = pl.R, D = pl.D, S = pl.S, E = pl.E, C = pl.C, NL = pl.NL;
     if (!h->fw_ok) return wn_fail(WN_E_UNSUPPORTED, "wn_train_forward: needs kernel_size 2 and channel counts that are multiples of 32");
     if (h->padded) return wn_fail(WN_E_UNSUPPORTED, "wn_train_forward: this handle runs a zero-padded channel shape (its parameter layout is not the caller's)");
-    const long long rf = 1 + (long long)pl.blocks * ((1 << pl.layers) - 1);
-    if (L < rf + out_len - 1)
-        return wn_fail(WN_E_UNSUPPORTED, "wn_train_forward: L=%lld < receptive_field + output_length - 1 = %lld (the reference zero-pads "
-                       "activations there; use the torch path)", (long long)L, (long long)(rf + out_len - 1));
     if ((long long)N * L >= 0x7fffffffll) return wn_fail(WN_E_UNSUPPORTED, "wn_train_forward: N*L must stay below 2^31 rows");
     { int rc = rt_hip(hipSetDevice(h->cfg.device_id), "hipSetDevice"); if (rc) return rc; }
     WnTrainLay& t = h->train;
     h->train_valid = false;
-    wn_train_layout_ws(h, N, L, out_len, t);
+    { int rc = wn_train_layout_ws(h, N, L, out_len, t); if (rc) return rc; }
     if (h->tws_floats < t.total) {
         (void)hipDeviceSynchronize();
         rt_free(h->d_tws);
@@ -194,6 +194,7 @@ extern "C" int wn_train_forward(wn_handle* h, const float* params, const int32_t
         WnGemmArgs a;
         memset(&a, 0, sizeof(a));
         a.a0 = WnRowMap{xin, (long long)L * R, R, t0 - d};
+        a.a_skip_lo[0] = (int)t.zlo[l];   // (short clips: the reference's left zero padding stands in for x(t - d) on these rows)
         a.a1 = WnRowMap{xin, (long long)L * R, R, t0};
         a.k_split = R; a.K = 2 * R; a.bt = fw + h->fw_off_fg + (size_t)l * 2 * R * 2 * D; a.N = 2 * D;
         a.bias = pl.has_bias ? fw + h->fw_off_bfg + (size_t)l * 2 * D : nullptr;
@@ -368,6 +369,7 @@ extern "C" int wn_train_backward(wn_handle* h, const float* params, const float*
         g.b = WnRowMap{dfg, rows * 2 * D, 2 * D, 0}; g.b_bf16 = t.bf16 ? 1 : 0;
         g.Ka = 2 * R; g.Nb = 2 * D; g.c = grads + h->fw_off_fg + (size_t)l * 2 * R * 2 * D; g.ldc = 2 * D;
         g.M = M; g.rows_per_batch = (int)rows;
+        g.a_skip_lo = (int)t.zlo[l];   // tap 0 on the rows where the forward read a pad zero: no contribution
 #if WN_TN_MERGE_TAPS
         if (R % 128 == 0) {
             wn_launch_tn(st, g, t.bf16);
@@ -376,22 +378,26 @@ extern "C" int wn_train_backward(wn_handle* h, const float* params, const float*
         for (int tap = 0; tap < 2; ++tap) {
             WnGemmTnArgs g1 = g;
             g1.a = tap ? g.a1 : g.a; g1.ka_split = 0; g1.Ka = R; g1.c = g.c + (size_t)tap * R * 2 * D;
+            if (tap) g1.a_skip_lo = 0;
             wn_launch_tn(st, g1, t.bf16);
         }
         if (pl.has_bias) wn_launch_colsum(st, WnRowMap{dfg, rows * 2 * D, 2 * D, 0}, M, (int)rows, 2 * D, grads + h->fw_off_bfg + (size_t)l * 2 * D, t.bf16);
-        // dx_l on its rows [t0 - d, L) (= the last need[l] time steps) in ONE product over two row-shifted views of dfg:
+        // dx_l on ITS rows [lo, L) (the last need[l] time steps; lo = t0 - sh with sh = d, or less where the clip is so short that layer
+        // l's input starts later than t0 - d) in ONE product over two row-shifted views of dfg:
         //     dx_l(t) = dx'(t) [t >= t0]  +  dfg(t) . Wfg(tap 1) [t >= t0]  +  dfg(t + d) . Wfg(tap 0) [t < L - d]
         // K = 4D: columns 0..2D-1 take dfg(t) against tap 1's rows, columns 2D.. take dfg(t + d) against tap 0's.  The views' row
         // windows (a_skip_*) read as zero where a shift runs off dfg, so nothing is cleared first and dx_l is written exactly once
-        // (round 2: a memset of dx and two read-modify-write products per layer).
+        // (round 2: a memset of dx and two read-modify-write products per layer).  (Positions before lo do not exist: what the forward
+        // read there were the reference's pad zeros, which have no gradient.)
+        const long long rows_l = t.need[l], sh = rows_l - rows;   // 0 <= sh <= d
         memset(&a, 0, sizeof(a));
-        a.a0 = WnRowMap{dfg, rows * 2 * D, 2 * D, -d};   // dfg(t):     row (t - t0) = rem - d, valid from rem = d
-        a.a1 = WnRowMap{dfg, rows * 2 * D, 2 * D, 0};    // dfg(t + d): row rem, valid up to rem = rows - 1
-        a.a_skip_lo[0] = (int)d; a.a_skip_hi[1] = (int)d; a.a_bf16 = t.bf16 ? 1 : 0;
+        a.a0 = WnRowMap{dfg, rows * 2 * D, 2 * D, -sh};      // dfg(t):     row (t - t0) = rem - sh, valid from rem = sh
+        a.a1 = WnRowMap{dfg, rows * 2 * D, 2 * D, d - sh};   // dfg(t + d): row rem + d - sh, valid while rem < rows_l - d
+        a.a_skip_lo[0] = (int)sh; a.a_skip_hi[1] = (int)d; a.a_bf16 = t.bf16 ? 1 : 0;
         a.k_split = 2 * D; a.K = 4 * D; a.bt = ws + t.fgb1 + (size_t)l * 2 * D * R; a.bt1 = ws + t.fgb0 + (size_t)l * 2 * D * R; a.N = R;
-        if (has_res) { a.cin = WnRowMap{dxn, L * (long long)R, R, t0 - d}; a.cin_skip_lo = (int)d; }
-        a.c = WnRowMap{dxc, L * (long long)R, R, t0 - d};
-        a.M = N * (rows + d); a.rows_per_batch = (int)(rows + d);
+        if (has_res) { a.cin = WnRowMap{dxn, L * (long long)R, R, t0 - sh}; a.cin_skip_lo = (int)sh; }
+        a.c = WnRowMap{dxc, L * (long long)R, R, t0 - sh};
+        a.M = N * rows_l; a.rows_per_batch = (int)rows_l;
         {
             const unsigned short* w = bw ? bw + h->fw_off_fg + (size_t)l * 2 * R * 2 * D : nullptr;  // native [2R][2D]: rows 0..R-1 tap 0, R.. tap 1
             wn_launch_nn(st, WN_EPI_PLAIN, a, w ? w + (size_t)R * 2 * D : nullptr, w, 2 * D);

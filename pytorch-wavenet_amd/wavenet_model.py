@@ -14,9 +14,11 @@ What is different underneath:
   * extension: ``first_samples`` may be 2-D ``(streams, n_given)``; the result is then ``(streams, num_samples)``.
   * the priming window (``first_samples`` of length n > 64) is evaluated as one batched matrix-core pass (wn_prime).
   * ``forward()`` on a CUDA one-hot batch runs natively on the matrix cores (wn_forward; wn_train_forward / wn_train_backward
-    behind a torch.autograd.Function when gradients are wanted); CPU tensors, inputs shorter than
-    receptive_field + output_length - 1 (the reference's zero-padding regime), non-one-hot inputs and channel counts that
-    are not multiples of 32 run the reference's algorithm with torch ops on whatever device the module lives on.
+    behind a torch.autograd.Function when gradients are wanted) -- including clips shorter than receptive_field +
+    output_length - 1, where the reference left-pads the layers' activations with zeros (wavenet_modules.py:24-27: per-layer row
+    windows in the kernels).  The reference's algorithm with torch ops remains for: CPU tensors, inputs that are not one-hot,
+    gradients w.r.t. the input, autograd on channel counts that are not multiples of 32 (without autograd those run natively,
+    zero-padded), and the input lengths for which the reference itself has no defined result (its error, or its shapes, are reproduced).
 """
 import os
 import os.path
@@ -138,19 +140,18 @@ class WaveNetModel(nn.Module):
 
     def _native_forward(self, input):
         """Matrix-core forward (C ABI wn_forward, or wn_train_forward + wn_train_backward behind a torch.autograd.Function
-        when gradients are wanted) when it applies: CUDA input that is exactly one-hot, every returned position with a full
-        receptive field, shapes the GEMM kernels support.  Returns None otherwise -- the caller then runs the torch path,
-        which also reproduces the reference's zero-padding quirk for short inputs.  A library that is not built is NOT a
-        reason to fall back: on a CUDA tensor that raises (the product must not run silently without its kernels)."""
+        when gradients are wanted) when it applies: CUDA input that is exactly one-hot, shapes the GEMM kernels support.  Returns
+        None otherwise -- the caller then runs the torch path.  Short clips (the reference's zero-padding regime) are served natively;
+        the engine answers WN_E_UNSUPPORTED only for lengths at which the reference has no defined result, and the torch path then
+        reproduces what the reference does there.  A library that is not built is NOT a reason to fall back: on a CUDA tensor that
+        raises (the product must not run silently without its kernels)."""
         if not input.is_cuda or input.dim() != 3 or input.size(1) != self.classes or self.kernel_size != 2:
-            return None
-        n, _, l = input.shape
-        if l < self.receptive_field + self.output_length - 1:
             return None
         want_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
         # Without autograd the engine decides: a channel shape that is not a multiple of 32 may still run natively, zero-padded into a
         # compiled shape (include/wn_abi.h: wn_create); with autograd the handle keeps the model's own shape and needs the multiples.
-        if (want_grad or getattr(self, "_wn_forward_unsupported", False)) and not self._native_supported():
+        no_native = getattr(self, "_wn_forward_unsupported", None) == self._forward_shape_key(input.device)
+        if (want_grad or no_native) and not self._native_supported():
             return None
         if torch.is_grad_enabled() and input.requires_grad:
             return None  # a gradient w.r.t. the one-hot input itself: torch path
@@ -163,17 +164,34 @@ class WaveNetModel(nn.Module):
         try:
             if want_grad:
                 return self._native_train_forward(idx)
-            eng = self._engine(1)
+            eng = self._forward_engine()
             self._apply_precision(eng)
             out = eng.forward_indices(idx, self.output_length)
         except _abi.WnError as e:
             if e.code == _abi.WN_E_UNSUPPORTED:
-                if not want_grad and not self._native_supported():
-                    self._wn_forward_unsupported = True  # this channel shape has no native forward: do not ask again
-                return None  # e.g. N*L >= 2^31 rows: the torch graph handles it
+                if not want_grad and "multiples of 32" in str(e):
+                    # THIS channel shape has no native forward on this device (not zero-padded into a compiled shape): do not ask again.
+                    # (Other refusals -- N*L >= 2^31 rows, a length the reference has no result for -- say nothing about the next call.)
+                    self._wn_forward_unsupported = self._forward_shape_key(input.device)
+                return None
             raise
         self._wn_forward_calls = getattr(self, "_wn_forward_calls", 0) + 1
         return out.to(input.dtype)
+
+    def _forward_shape_key(self, device):
+        return (str(device), self.residual_channels, self.dilation_channels, self.skip_channels, self.end_channels, self.classes)
+
+    def _forward_engine(self):
+        """The engine forward() runs on: the generation engine when it holds the current parameters -- whatever its stream count, so that a
+        validation forward between two generate_fast() calls leaves it (and its deferred queues) alone --, else a one-stream engine."""
+        eng = self._wn_engine
+        if eng is not None and self._wn_engine_key is not None:
+            plist = list(self.parameters())
+            dev = plist[0].device
+            index = dev.index if dev.type == "cuda" and dev.index is not None else int(os.environ.get("WN_DEVICE", "0"))
+            if self._wn_engine_key[1:] == (index, tuple((v.data_ptr(), v._version) for v in plist)):
+                return eng
+        return self._engine(1)
 
     def _apply_precision(self, eng):
         want = getattr(self, "matrix_precision", "fp32") == "bf16"
@@ -221,9 +239,8 @@ class WaveNetModel(nn.Module):
             raise ValueError("the index-based forward needs kernel_size 2 and channel counts that are multiples of 32 "
                              "(residual %d, dilation %d, skip %d, end %d, classes %d)" % (
                                  self.residual_channels, self.dilation_channels, self.skip_channels, self.end_channels, self.classes))
-        if idx.size(1) < self.receptive_field + self.output_length - 1:
-            raise ValueError("items of %d samples are shorter than receptive_field + output_length - 1 = %d"
-                             % (idx.size(1), self.receptive_field + self.output_length - 1))
+        if idx.size(1) < 2:
+            raise ValueError("items of %d sample(s): forward() needs at least two" % idx.size(1))
         if check and idx.numel() and (int(idx.min()) < 0 or int(idx.max()) >= self.classes):
             raise ValueError("class indices outside [0, %d)" % self.classes)  # they address rows of start_conv^T on the GPU
         return idx
@@ -233,16 +250,29 @@ class WaveNetModel(nn.Module):
         dataset holds before audio_data.py:119-121 inflates it 256x.  Inference only (matrix-core path, no autograd).
         ``check=False`` skips the range check of the indices (one device sync) when the producer guarantees it."""
         idx = self._checked_indices(indices, check)
-        eng = self._engine(1)
+        eng = self._forward_engine()
         self._apply_precision(eng)
-        out = eng.forward_indices(idx, self.output_length)
+        out = self._index_call(lambda: eng.forward_indices(idx, self.output_length))
         self._wn_forward_calls = getattr(self, "_wn_forward_calls", 0) + 1
         return out
+
+    @staticmethod
+    def _index_call(fn):
+        """The index-based extensions have no torch path to fall back to: a clip length the engine refuses (one the reference has no
+        defined result for either, include/wn_abi.h: wn_forward) is the caller's ValueError, with the engine's reason."""
+        from mi355_wavenet import _abi
+        try:
+            return fn()
+        except _abi.WnError as e:
+            if e.code == _abi.WN_E_UNSUPPORTED:
+                raise ValueError(str(e)) from e
+            raise
 
     def train_forward_indices(self, indices, check=True):
         """Extension: the differentiable forward() on class indices (N, L) -- the training-time sibling of forward_indices:
         logits (N*output_length, classes) whose backward runs natively (see _native_train_forward).  MI355X only."""
-        return self._native_train_forward(self._checked_indices(indices, check))
+        idx = self._checked_indices(indices, check)
+        return self._index_call(lambda: self._native_train_forward(idx))
 
     def forward(self, input):
         """(N, classes, L) one-hot -> (N*output_length, classes) logits (wavenet_model.py:186-196)."""
@@ -451,6 +481,7 @@ class WaveNetModel(nn.Module):
         state["_wn_engine_key"] = None
         state["_wn_train_runner"] = None
         state.pop("_wn_expansion", None)
+        state.pop("_wn_forward_unsupported", None)   # (an answer about THIS device's library: not part of the model)
         return state
 
     def __setstate__(self, state):

@@ -29,11 +29,12 @@ def pytest_collection_modifyitems(config, items):
 @pytest.fixture(scope="session")
 def golden():
     """golden_v1.npz (tiny / cfg1, queue and dilate known answers, forward) + golden_v2.npz (cfg2 / cfg3 generate_fast) +
-    golden_v3.npz (forward() outputs, loss and parameter-gradient digests of the reference for cfg2 and the cfg3 stack):
+    golden_v3.npz (forward() outputs, loss and parameter-gradient digests of the reference for cfg2 and the cfg3 stack) +
+    golden_v4.npz (the same for clips in the reference's zero-padding regime, shorter than receptive_field + output_length - 1):
     everything in them was produced by the real reference (tests/golden/make_golden.py)."""
     import numpy as np
     merged = {}
-    for name in ("golden_v1.npz", "golden_v2.npz", "golden_v3.npz"):
+    for name in ("golden_v1.npz", "golden_v2.npz", "golden_v3.npz", "golden_v4.npz"):
         z = np.load(os.path.join(ROOT, "tests", "golden", name))
         merged.update({k: z[k] for k in z.files})
     return merged

@@ -4,6 +4,8 @@ oracle/ref_shim.py -- the 3 documented import-time patches, nothing else) in the
     python tests/golden/make_golden.py          # golden_v1.npz
     python tests/golden/make_golden.py --v2     # golden_v2.npz (cfg2 / cfg3, a few minutes of reference CPU time)
     python tests/golden/make_golden.py --v3     # golden_v3.npz (forward() + parameter gradients of the reference: cfg2, the cfg3 stack)
+    python tests/golden/make_golden.py --v4     # golden_v4.npz (the same for clips SHORTER than receptive_field + output_length - 1: the
+                                                #   reference left-pads the layers' activations with zeros there, wavenet_modules.py:24-27)
 
 The fixtures pin the oracle (oracle/restated.py, oracle/wn_oracle.c) and, through it, the HIP path.
 Weights are NOT stored: they are regenerated from mi355_wavenet.synth.init_weights(cfg, seed) which is
@@ -177,6 +179,54 @@ def main_v2():
 GRAD_CASES = {"cfg2": ("cfg2", 21, 1, 6), "cfg3": ("cfg3", 22, 1, 4), "tiny_bias": ("tiny_bias", 23, 2, 5)}
 
 
+# golden_v4.npz: the zero-padding regime of forward() -- clips shorter than receptive_field + output_length - 1, whose returned positions
+# see the zero activations `dilate` pads the layers' inputs with on the left.  case -> (config, weight seed, N, output_length, L)
+SHORT_CASES = {
+    "short_cfg1": ("cfg1", 31, 2, 5, 64),            # rf 63: three samples short (shorter clips run into the skip path quirk, Appendix A item 17)
+    "short_cfg1_by1": ("cfg1", 32, 1, 8, 69),        # rf + out_len - 2: one sample short
+    "short_tiny_bias": ("tiny_bias", 33, 3, 4, 16),
+    "short_chaconne": ("chaconne", 34, 1, 16, 2600),  # train_script.py shape (rf 3070): 485 samples short
+    "short_cfg2": ("cfg2", 35, 1, 6, 2751),
+}
+
+
+def _grad_case(mdl, out, case, cname, wseed, N, out_len, L=None):
+    import torch.nn.functional as F
+    import digest as dg
+    if True:
+        cfg = synth.CONFIGS[cname]
+        m = build_ref_model(mdl, cfg, wseed, output_length=out_len)
+        L = m.receptive_field + out_len - 1 if L is None else L
+        rs = np.random.RandomState(wseed + 1)
+        ids = rs.randint(0, 256, (N, L))
+        target = rs.randint(0, 256, (N * out_len,))
+        x = torch.zeros(N, 256, L)
+        x.scatter_(1, torch.from_numpy(ids).view(N, 1, L), 1.)
+        y = m(x)                                                      # wavenet_model.py:186-196
+        loss = F.cross_entropy(y.squeeze(), torch.from_numpy(target))  # wavenet_training.py:69
+        loss.backward()
+        out["grad_%s_ids" % case] = ids.astype(np.int16)
+        out["grad_%s_target" % case] = target.astype(np.int16)
+        out["grad_%s_out" % case] = y.detach().numpy().astype(np.float32)
+        out["grad_%s_loss" % case] = np.array([float(loss)], dtype=np.float64)
+        out["grad_%s_meta" % case] = np.array([wseed, N, out_len, L, m.receptive_field], dtype=np.int64)
+        named = {k: (p.grad.numpy() if p.grad is not None else np.zeros(tuple(p.shape), dtype=np.float32)) for k, p in m.named_parameters()}
+        for k, v in dg.digest(named).items():
+            out["grad_%s_d_%s" % (case, k)] = v
+        print(case, "L", L, "rf", m.receptive_field, "loss", float(loss), "params", len(named))
+
+
+def main_v4():
+    sys.path.insert(0, HERE)
+    mdl, wm, ad = ref_shim.load()
+    out = {}
+    for case, (cname, wseed, N, out_len, L) in SHORT_CASES.items():
+        _grad_case(mdl, out, case, cname, wseed, N, out_len, L)
+    path = os.path.join(HERE, "golden_v4.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes;", len(out), "arrays")
+
+
 def main_v3():
     import torch.nn.functional as F
     sys.path.insert(0, HERE)
@@ -210,7 +260,9 @@ def main_v3():
 
 
 if __name__ == "__main__":
-    if "--v3" in sys.argv:
+    if "--v4" in sys.argv:
+        main_v4()
+    elif "--v3" in sys.argv:
         main_v3()
     elif "--v2" in sys.argv:
         main_v2()
@@ -218,5 +270,6 @@ if __name__ == "__main__":
         main()
         main_v2()
         main_v3()
+        main_v4()
     else:
         main()

@@ -70,25 +70,59 @@ def test_forward_matches_torch_reference_path(label, cfg, N, out_len, extra):
     assert dev <= TOL
 
 
-def test_forward_refuses_padded_regime_and_facade_uses_it_when_valid():
+def test_forward_refuses_lengths_the_reference_has_no_result_for_and_the_facade_stays_native():
     cfg = synth.CONFIGS["cfg1"]
     m, W = _model(cfg, 92, 4)
     eng = engine.Engine(cfg, W)
     with pytest.raises(_abi.WnError) as ei:
-        eng.forward_indices(np.zeros((1, m.receptive_field + 1), dtype=np.int64), 4)  # needs rf + 3
-    assert ei.value.code == _abi.WN_E_UNSUPPORTED
-    # the facade: CUDA one-hot input without autograd -> native kernel; result equals its own torch path
-    ids = np.random.RandomState(92).randint(0, 256, (2, m.receptive_field + 3))
-    x = _onehot(ids)
-    with torch.no_grad():
-        ref = m(x).numpy()
+        eng.forward_indices(np.zeros((1, 41), dtype=np.int64), 4)  # the skip path's un-dilation quirk
+    assert ei.value.code == _abi.WN_E_UNSUPPORTED and "un-dilation" in str(ei.value)
+    with pytest.raises(_abi.WnError) as ei:
+        eng.forward_indices(np.zeros((1, m.receptive_field + 1), dtype=np.int64), 40)  # rf + 1 samples leave 32 output positions
+    assert ei.value.code == _abi.WN_E_UNSUPPORTED and "output positions" in str(ei.value)
+    # the facade: CUDA one-hot input without autograd -> native kernel; result equals its own torch path -- for a full-length clip
+    # and for one in the reference's zero-padding regime (rf + 1 < rf + output_length - 1)
+    mg = None
+    for k, L in enumerate((m.receptive_field + 3, m.receptive_field + 1)):
+        ids = np.random.RandomState(92 + k).randint(0, 256, (2, L))
+        x = _onehot(ids)
+        with torch.no_grad():
+            ref = m.cpu()(x).numpy()
+        mg = m.cuda()
+        with torch.no_grad():
+            y = mg(x.cuda())
+        assert mg._wn_forward_calls == k + 1  # served by wn_forward
+        assert np.abs(y.cpu().numpy() - ref).max() <= TOL
+    y2 = mg(x.cuda())  # autograd on: the native training forward (wn_train_forward, its backward behind loss.backward()), not wn_forward
+    assert mg._wn_forward_calls == 2 and y2.requires_grad and mg._wn_train_calls >= 1
+
+
+SHORT = ["short_cfg1", "short_cfg1_by1", "short_chaconne", "short_cfg2"]
+
+
+@pytest.mark.parametrize("case", SHORT)
+def test_forward_of_short_clips_reproduces_the_reference_golden(golden, case):
+    """golden_v4.npz: forward() of the REAL reference on clips shorter than receptive_field + output_length - 1 -- the layers' inputs are
+    left-padded with zero activations there (wavenet_modules.py:24-27) and returned positions see them.  The native kernels read the
+    tap x(t - d) as zero on exactly those rows (wn_forward_geometry): same logits, through the engine and through the facade."""
+    cfgname = {"short_cfg1": "cfg1", "short_cfg1_by1": "cfg1", "short_chaconne": "chaconne", "short_cfg2": "cfg2"}[case]
+    wseed, N, out_len, L, rf = [int(v) for v in golden["grad_%s_meta" % case]]
+    assert L < rf + out_len - 1
+    cfg = synth.CONFIGS[cfgname]
+    m, W = _model(cfg, wseed, out_len)
+    ids = golden["grad_%s_ids" % case].astype(np.int64)
+    ref = golden["grad_%s_out" % case]
+    eng = engine.Engine(cfg, W)
+    y = eng.forward_indices(ids, out_len).cpu().numpy()
+    eng.close()
+    assert y.shape == ref.shape
+    dev = float(np.abs(y - ref).max())
+    print(case, "L", L, "rf", rf, "max |dlogit| vs the reference", dev, "scale", float(np.abs(ref).max()))
+    assert dev <= TOL
     mg = m.cuda()
     with torch.no_grad():
-        y = mg(x.cuda())
-    assert mg._wn_forward_calls == 1  # served by wn_forward
-    assert np.abs(y.cpu().numpy() - ref).max() <= TOL
-    y2 = mg(x.cuda())  # autograd on: the native training forward (wn_train_forward, its backward behind loss.backward()), not wn_forward
-    assert mg._wn_forward_calls == 1 and y2.requires_grad
+        yf = mg(_onehot(ids).cuda())
+    assert mg._wn_forward_calls == 1 and float(np.abs(yf.cpu().numpy() - ref).max()) <= TOL
 
 
 @pytest.mark.parametrize("cfgname,N,out_len", [("cfg2", 2, 40), ("cfg3", 2, 64)])

@@ -51,6 +51,18 @@ int main(int argc, char** argv) {
         printf("%d %d %d %d %d\n", pick, out[0], out[1], out[2], out[3]);
         return 0;
     }
+    if (argc >= 2 && argv[1][0] == 'f') {  // f <layers> <blocks> <L> <out_len>: time geometry of forward() (a | rows | zlo), or the refusal
+        const int layers = atoi(argv[2]), blocks = atoi(argv[3]);
+        std::vector<int32_t> dil;
+        for (int b = 0; b < blocks; ++b) for (int i = 0; i < layers; ++i) dil.push_back(1 << i);
+        WnFwdGeom g;
+        const std::string why = wn_forward_geometry_host(dil.data(), (int)dil.size(), atoll(argv[4]), atoll(argv[5]), g);
+        if (!why.empty()) { printf("REFUSED %s\n", why.c_str()); return 0; }
+        for (long long v : g.a) printf("%lld ", v); printf("| ");
+        for (long long v : g.rows) printf("%lld ", v); printf("| ");
+        for (long long v : g.zlo) printf("%lld ", v); printf("\n");
+        return 0;
+    }
     const int NL = atoi(argv[1]), P = atoi(argv[2]), heads = atoi(argv[3]), n_smp = atoi(argv[4]);
     std::vector<int32_t> m;
     int nb = 0;
@@ -195,3 +207,58 @@ def test_zero_padding_respects_the_planner(harness):
     assert tuple(out[1:]) == (64, 64, 256, 256) and out[0] == 1
     out = [int(x) for x in subprocess.check_output([harness, "p", "100", "100", "256", "256", "60", "100"]).decode().split()]
     assert out[0] == -1   # only the cfg3-shape kernel holds 100 channels, and 60 x 4 slices do not fit 100 workgroups
+
+
+def _geometry(harness, layers, blocks, L, out_len):
+    out = subprocess.check_output([harness, "f", str(layers), str(blocks), str(L), str(out_len)]).decode().strip()
+    if out.startswith("REFUSED"):
+        return None
+    a, rows, zlo = [[int(v) for v in part.split()] for part in out.split("|")]
+    return a, rows, zlo
+
+
+def test_forward_geometry_of_full_and_short_clips(harness):
+    """wn_forward_geometry_host (csrc/wn_plan.h): where every layer's sequence starts once the reference's left zero padding is
+    accounted for (wavenet_modules.py:24-27), which rows are computed and which of them read a pad zero as their tap."""
+    # a clip of receptive_field + output_length - 1 samples: no returned position sees a pad zero, rows grow by d per layer downwards
+    a, rows, zlo = _geometry(harness, 5, 2, 63 + 8 - 1, 8)
+    d = [1, 2, 4, 8, 16] * 2
+    assert rows[-1] == 8 and all(rows[l] == rows[l + 1] + d[l] for l in range(10)) and rows[0] == 70 and not any(zlo)
+    # the golden_v4 cases (made by the real reference): accepted, and some returned rows DO read pad zeros
+    for layers, blocks, L, out_len in ((5, 2, 64, 5), (5, 2, 69, 8), (3, 2, 16, 4), (10, 3, 2600, 16), (10, 3, 2751, 6)):
+        g = _geometry(harness, layers, blocks, L, out_len)
+        assert g is not None, (layers, blocks, L)
+        a, rows, zlo = g
+        assert any(zlo), (layers, blocks, L)
+        assert all(rows[l] <= L - a[l] for l in range(len(rows))) and rows[-1] == out_len
+        assert all(a[l + 1] > a[l] for l in range(len(a) - 1))
+    # lengths at which the reference has no defined result are refused
+    assert _geometry(harness, 5, 2, 41, 5) is None      # the skip path's un-dilation quirk (SURVEY.md Appendix A item 17)
+    assert _geometry(harness, 5, 2, 63, 5) is None      # fewer than output_length positions left
+    assert _geometry(harness, 3, 2, 1, 1) is None
+
+
+@pytest.mark.reference
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="needs the reference tree (authoring container)")
+def test_forward_geometry_agrees_with_the_live_reference(harness):
+    """Every clip length 2 .. rf + output_length + 2 of a small model: the geometry accepts a length exactly when the real reference's
+    forward() returns (N * output_length, classes) logits -- and refuses it exactly when the reference raises or returns another shape."""
+    import sys
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(ROOT, "pytorch-wavenet_amd"))
+    import ref_shim
+    mdl, _wm, _ad = ref_shim.load()
+    for layers, blocks, out_len, N in ((3, 2, 4, 2), (4, 2, 3, 1), (5, 1, 6, 3)):
+        m = mdl.WaveNetModel(layers=layers, blocks=blocks, dilation_channels=4, residual_channels=4, skip_channels=8, end_channels=8,
+                             classes=16, output_length=out_len)
+        for L in range(2, m.receptive_field + out_len + 3):
+            x = torch.zeros(N, 16, L)
+            x[:, 0, :] = 1.
+            try:
+                with torch.no_grad():
+                    y = m(x)
+                ok = tuple(y.shape) == (N * out_len, 16)
+            except Exception:   # noqa: BLE001 -- whatever the reference raises there
+                ok = False
+            assert (_geometry(harness, layers, blocks, L, out_len) is not None) == ok, (layers, blocks, out_len, N, L, ok)
