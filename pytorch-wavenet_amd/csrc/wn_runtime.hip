@@ -443,6 +443,8 @@ struct wn_handle {
     std::vector<wn_handle*> chains;
     std::vector<int> chain_first;  // first stream of round i (chain_first[n] = n_streams)
     bool rounds;
+    bool shares_weights = false;   // member i > 0 of a rounds front: its weight images, start_conv^T and GEMM banks ARE member 0's (immutable during a
+                                   // job, identical for every member -- the image layout depends on the channel shape, not on the stream count): not freed here
     // owned device allocations
     float *d_blobs, *d_start_t, *d_start_b, *d_rings;
     int32_t *d_dil, *d_wg_map;
@@ -497,8 +499,9 @@ extern "C" void wn_destroy(wn_handle* h) {
     (void)hipSetDevice(h->cfg.device_id);
     if (h->pending) (void)hipStreamSynchronize((hipStream_t)h->last_stream);
     wn_gate_release(h->gate);
-    rt_free(h->d_blobs); rt_free(h->d_start_t); rt_free(h->d_start_b); rt_free(h->d_rings); rt_free(h->d_dil);
-    rt_free(h->d_wg_map); rt_free(h->d_ring_off); rt_free(h->d_gran); rt_free(h->d_status); rt_free(h->d_prof); rt_free(h->d_fw); rt_free(h->d_ws); rt_free(h->d_fwb);
+    if (!h->shares_weights) { rt_free(h->d_blobs); rt_free(h->d_start_t); rt_free(h->d_start_b); rt_free(h->d_fw); rt_free(h->d_fwb); }
+    rt_free(h->d_rings); rt_free(h->d_dil);
+    rt_free(h->d_wg_map); rt_free(h->d_ring_off); rt_free(h->d_gran); rt_free(h->d_status); rt_free(h->d_prof); rt_free(h->d_ws);
     rt_free(h->d_tws);
     rt_free(h->d_xent);
     delete h;
@@ -821,7 +824,29 @@ extern "C" int wn_load_weights(wn_handle* h, const wn_weight_ptrs* w) {
 // weights in the handle's own (possibly padded) channel shape
 static int wn_load_weights_impl(wn_handle* h, const wn_weight_ptrs* w) {
     if (h && !h->chains.empty()) {
-        for (wn_handle* c : h->chains) { int rc = wn_load_weights_impl(c, w); if (rc) return rc; }
+        // Rounds: ONE copy of the weights.  Member 0 packs and uploads; the others point at its images and banks (round 3 uploaded the
+        // weight images, start_conv^T and both GEMM banks into every member: 4 x 120 MB at cfg3 x 512 streams).
+        wn_handle* c0 = h->chains[0];
+        { int rc = wn_load_weights_impl(c0, w); if (rc) return rc; }
+        for (size_t i = 1; i < h->chains.size(); ++i) {
+            wn_handle* c = h->chains[i];
+            if (c->blob_floats != c0->blob_floats || c->plan.P != c0->plan.P || c->plan.PA != c0->plan.PA || c->variant != c0->variant || c->v2_index != c0->v2_index)
+                return wn_fail(WN_E_STATE, "wn_load_weights: the rounds of this handle were planned with different geometries");
+            { int rc = rt_hip(hipSetDevice(c->cfg.device_id), "hipSetDevice"); if (rc) return rc; }
+            if (c->pending) { int rc = wn_wait(c); if (rc) return rc; }
+            if (!c->shares_weights) { rt_free(c->d_blobs); rt_free(c->d_start_t); rt_free(c->d_start_b); rt_free(c->d_fw); rt_free(c->d_fwb); }
+            c->shares_weights = true;
+            c->d_blobs = c0->d_blobs; c->d_start_t = c0->d_start_t; c->d_start_b = c0->d_start_b;
+            c->plan.blobs = c0->plan.blobs; c->plan.start_t = c0->plan.start_t; c->plan.start_b = c0->plan.start_b;
+            c->d_fw = c0->d_fw; c->fw_floats = c0->fw_floats; c->fw_ok = c0->fw_ok;
+            c->fw_off_fg = c0->fw_off_fg; c->fw_off_bfg = c0->fw_off_bfg; c->fw_off_res = c0->fw_off_res; c->fw_off_bres = c0->fw_off_bres;
+            c->fw_off_skip = c0->fw_off_skip; c->fw_off_bskip = c0->fw_off_bskip; c->fw_off_bskip_total = c0->fw_off_bskip_total;
+            c->fw_off_w1 = c0->fw_off_w1; c->fw_off_b1 = c0->fw_off_b1; c->fw_off_w2 = c0->fw_off_w2; c->fw_off_b2 = c0->fw_off_b2;
+            c->fw_off_start_t = c0->fw_off_start_t; c->fw_off_start_b = c0->fw_off_start_b;
+            c->d_fwb = c0->d_fwb; c->fwb_elems = c0->fwb_elems; c->fwb_ok = c0->fwb_ok;
+            c->fwb_off_fg = c0->fwb_off_fg; c->fwb_off_res = c0->fwb_off_res; c->fwb_off_skip = c0->fwb_off_skip; c->fwb_off_w1 = c0->fwb_off_w1; c->fwb_off_w2 = c0->fwb_off_w2;
+            c->have_weights = true;
+        }
         h->have_weights = true;
         return WN_OK;
     }
@@ -1114,7 +1139,8 @@ extern "C" int wn_get_info(wn_handle* h, wn_info* out) {
         for (size_t i = 1; i < h->chains.size(); ++i) {
             wn_info ci;
             if ((rc = wn_get_info(h->chains[i], &ci))) return rc;
-            out->n_workgroups += ci.n_workgroups; out->weight_bytes += ci.weight_bytes; out->queue_bytes += ci.queue_bytes;
+            out->n_workgroups += ci.n_workgroups; out->queue_bytes += ci.queue_bytes;
+            if (!h->chains[i]->shares_weights) out->weight_bytes += ci.weight_bytes;   // (after wn_load_weights the rounds share member 0's)
             out->handoff_bytes += ci.handoff_bytes;
         }
         out->n_chains = (int)h->chains.size();

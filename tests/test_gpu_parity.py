@@ -642,6 +642,9 @@ def test_wave_specialised_kernel_rounds(ns):
     eng = engine.Engine(cfg, W, n_streams=ns)
     info = eng.info()
     assert info["kernel_variant"] == 3 and info["n_chains"] == 2
+    one = engine.Engine(cfg, W, n_streams=64)
+    assert info["weight_bytes"] == one.info()["weight_bytes"], "the rounds share ONE copy of the weight images and banks (round 4)"
+    one.close()
     out = eng.generate(N, first, temperature=1.0, uniforms=uniforms, timeout_ms=8000)
     a = eng.generate(40, first, temperature=1.0, uniforms=uniforms[:, :40], timeout_ms=8000)
     b = eng.generate(N - 40, a[:, -1:], temperature=1.0, uniforms=uniforms[:, 40:], reset=False, timeout_ms=8000)
