@@ -184,6 +184,34 @@ def verify_against_oracle(cfg, W, first, uniforms, idx=None, audio=None, streams
     return ok
 
 
+def train_algorithmic_bytes(N, L, out_len, bf16, layers=10, blocks=5, R=128, D=128, S=512, E=256, C=256):
+    """HBM bytes one training step has to move when every saved activation is written once and read once (DESIGN.md section 2c states the
+    same formula).  Per layer l, on its M_l = N * need[l+1] rows (need = the trailing time steps the loss depends on):
+      forward   read x_l (4R), write x_{l+1} (4R), write z (zb D), write the gate pair tanh | sigmoid (gb D)
+      backward  read dx' (4R), read the gate pair (gb D), write and read [dF|dG] (2 fb 2D), read z (zb D: dWres), read x_l (4R: dWfg), write dx_l (4R)
+    with zb / gb / fb bytes per element: 2 / 4 / 2 in the bf16 step (z, the packed pair and [dF|dG] stored as bf16), 4 / 8 / 4 in the fp32 step.
+    Skip path on the Mo = N * output_length skip rows: z on the skip rows written once and read twice (zb D per layer), dskip read twice per
+    block (4S), dzg written and read (4D per layer), skip read-modify-write per block (8S); head: logits and dlogits (4C each), e and de (2 x 4E
+    each), skip and dskip once more (4S each).  Weights and their gradients (30 MB each) are noise next to the activations."""
+    zb, gb, fb = (2, 4, 2) if bf16 else (4, 8, 4)
+    NL = layers * blocks
+    dil = [2 ** (i % layers) for i in range(NL)]
+    need = [0] * (NL + 1)
+    need[NL] = out_len
+    for l in range(NL - 1, -1, -1):
+        need[l] = min(need[l + 1] + dil[l], L)
+    total = 0
+    for l in range(NL):
+        M = N * need[l + 1]
+        res = 1 if l < NL - 1 else 0
+        total += M * (4 * R + 4 * R * res + zb * D + gb * D)                                     # forward
+        total += M * (4 * R * res + gb * D + 2 * fb * 2 * D + zb * D * res + 4 * R + 4 * R)     # backward
+    Mo = N * out_len
+    total += Mo * NL * (3 * zb * D + 2 * 4 * D) + Mo * blocks * (2 * 4 * S + 8 * S)
+    total += Mo * (2 * 4 * C + 4 * 4 * E + 2 * 4 * S)
+    return int(total)
+
+
 def train_step_cfg5(device, N=32, L=16000, reps=3, precision="fp32"):
     """BASELINE configs[4] (SURVEY.md 8d "cfg5"): one training step -- model(x), F.cross_entropy, backward, Adam -- at
     layers=10 blocks=5 128/128/512, N one-second 16 kHz clips given as class indices, through the facade's native
@@ -224,7 +252,10 @@ def train_step_cfg5(device, N=32, L=16000, reps=3, precision="fp32"):
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / reps * 1e3
     peak = 157.3 if precision == "fp32" else 2500.0  # dense MFMA peaks, TFLOP/s (MI355X_MICROARCH.md)
+    hbm = train_algorithmic_bytes(N, L, out_len, precision != "fp32")
     return {"ms_per_step": round(ms, 2), "clips": N, "clip_samples": L, "output_length": out_len,
+            "hbm_algorithmic_bytes_per_step": hbm, "hbm_gbs": round(hbm / (ms * 1e-3) / 1e9, 1), "hbm_frac": round(hbm / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "hbm_measured": _train_pmc(precision, N, L),
             "dtype": "f32 (matrix cores)" if precision == "fp32" else "bf16 matrix operands (forward, activation- and weight-gradient products), f32 accumulation, f32 residual stream; z, gates and [dF|dG] stored as bf16",
             "tflop_per_step": round(3 * fwd / 1e12, 2), "tflops": round(3 * fwd / ms / 1e9, 1),
             "mfma_peak_tflops": peak, "mfma_peak_frac": round(3 * fwd / ms / 1e9 / peak, 4), "loss": round(float(loss.detach()), 4)}
@@ -286,6 +317,8 @@ def train5_main(a, dist, rank, local, n_gpus, global_batch=32, L=16000):
         fwd += 2 * global_batch * out_len * (S * E + E * C)
         ms = wall / a.steps * 1e3
         tflops = 3 * fwd / ms / 1e9
+        hbm = train_algorithmic_bytes(global_batch, L, out_len, bf16)   # (all ranks together: the activations shard with the batch)
+        measured = _train_pmc("bf16" if bf16 else "fp32", global_batch, L) if n_gpus == 1 else None
         print(json.dumps({
             "metric": "training step throughput, one-second 16 kHz clips per second (forward + backward + Adam), whole job",
             "value": round(global_batch / (ms * 1e-3), 2), "unit": "clips/s", "n_gpus": n_gpus, "steps": a.steps, "warmup": max(a.warmup, 1),
@@ -296,7 +329,11 @@ def train5_main(a, dist, rank, local, n_gpus, global_batch=32, L=16000):
                                    "output_length %d, data parallel over %d GPU(s), one flat gradient all-reduce per step"
                                    % (global_batch, L, out_len, n_gpus), "global_batch": global_batch, "clips_per_gpu": n_local},
             "roofline": {"bound": "mfma", "achieved": round(tflops, 2), "peak": (2500.0 if bf16 else 157.3) * n_gpus, "unit": "TFLOP/s",
-                         "frac": round(tflops / ((2500.0 if bf16 else 157.3) * n_gpus), 4), "traffic": None,
+                         "frac": round(tflops / ((2500.0 if bf16 else 157.3) * n_gpus), 4),
+                         "traffic": None if measured is None else measured["bytes_per_step"], "traffic_kind": None if measured is None else measured["kind"],
+                         "hbm": {"algorithmic_bytes_per_step": hbm, "achieved_gbs": round(hbm / (ms * 1e-3) / 1e9, 1), "peak_gbs": HBM_PEAK_GBS * n_gpus,
+                                 "frac": round(hbm / (ms * 1e-3) / 1e9 / (HBM_PEAK_GBS * n_gpus), 4),
+                                 "note": "the step is a stream over saved activations: this is the roofline that binds (formula: bench.py train_algorithmic_bytes)"},
                          "kernel": "wn_fwd_gemm_bf16 / wn_bwd_gemm_tn_bf16 (bf16 MFMA; the products are HBM streams at K = 128-512: DESIGN.md 2c)" if bf16
                                    else "wn_fwd_gemm / wn_bwd_gemm_tn (fp32 MFMA)", "flop_per_step": int(3 * fwd)}}))
     if dist:
@@ -368,6 +405,18 @@ def _pmc_traffic(a, info, per_gpu):
     traffic = int((pmc["fetch_kib"] + pmc["write_kib"]) * 1024 * a.samples / pmc["samples_per_launch"])
     return traffic, {"file": "profiles/pmc_traffic.json", "kernel": pmc.get("kernel"), "measured": pmc.get("date"), "summary": pmc.get("summary"),
                      "counters": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, %d timesteps per launch, scaled to %d" % (pmc["samples_per_launch"], a.samples)}
+
+
+def _train_pmc(precision, N, L):
+    """FETCH_SIZE + WRITE_SIZE of one training step summed over its kernels, from the committed rocprofv3 PMC passes of tools/collect_train_profiles.sh
+    (profiles/pmc_traffic_train.json) -- replayed, like roofline.traffic of the generation line; None when there are none for this precision / size."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic_train.json")
+    if not os.path.exists(path):
+        return None
+    doc = json.load(open(path)).get("train5_%s" % precision)
+    if not doc or doc.get("clips") != N or doc.get("clip_samples") != L:
+        return None
+    return {"bytes_per_step": int((doc["fetch_kib"] + doc["write_kib"]) * 1024), "kind": "replayed from profiles/pmc_traffic_train.json (%s, %s)" % (doc.get("date"), doc.get("summary"))}
 
 
 def _launch_ranks(n):

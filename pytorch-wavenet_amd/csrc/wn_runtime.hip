@@ -413,7 +413,7 @@ struct WnTrainLay {
     std::vector<long long> need;          // need[l] = trailing time steps of layer l's input the loss depends on (and that exist: wn_forward_geometry)
     std::vector<long long> zlo;           // zlo[l] = leading output rows of layer l whose tap x(t - d) is one of the reference's pad zeros
     std::vector<size_t> x, z, th, sg;     // per layer offsets (floats) into the training workspace
-    size_t skip, ev, zg, dzg, bskip_total, res_o, skip_o, w1_o, w2_o, fgb0, fgb1, dskip, de, dz, dfg, dxa, dxb, colsum_tmp, idx, total;
+    size_t skip, ev, zg, dzg, bskip_total, res_o, skip_o, w1_o, w2_o, fgb0, fgb1, dskip, de, dz, dfg, dfg2, dxa, dxb, colsum_tmp, idx, total;
     size_t bw, bt_fg, bt_res, bt_skip, bt_w1, bt_w2;  // bf16 operand banks (offsets in floats)
     int G, nblk;  // layers per skip block, blocks
     bool bf16;  // the saved forward ran with bf16 operands: so does its backward
@@ -468,6 +468,9 @@ struct wn_handle {
     float* d_xent = nullptr; size_t xent_rows = 0;  // wn_train_loss: per-row losses
     WnTrainLay train; bool train_valid;
     // admission of persistent jobs (wn_gate.h)
+    // wn_train_backward: the weight-gradient products run on a second stream next to the activation-gradient chain (wn_train.inl)
+    hipStream_t side_stream = nullptr;
+    std::vector<hipEvent_t> events;
     char busid[32] = "";
     std::shared_ptr<WnGateTicket> gate;   // the booking of the job in flight (released by the host function behind the kernel, or in wn_wait)
     int gate_shared = -1, gate_waited_ms = 0;
@@ -498,6 +501,8 @@ extern "C" void wn_destroy(wn_handle* h) {
     }
     (void)hipSetDevice(h->cfg.device_id);
     if (h->pending) (void)hipStreamSynchronize((hipStream_t)h->last_stream);
+    if (h->side_stream) { (void)hipStreamSynchronize(h->side_stream); (void)hipStreamDestroy(h->side_stream); }
+    for (hipEvent_t e : h->events) (void)hipEventDestroy(e);
     wn_gate_release(h->gate);
     if (!h->shares_weights) { rt_free(h->d_blobs); rt_free(h->d_start_t); rt_free(h->d_start_b); rt_free(h->d_fw); rt_free(h->d_fwb); }
     rt_free(h->d_rings); rt_free(h->d_dil);

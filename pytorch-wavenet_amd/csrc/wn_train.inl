@@ -41,10 +41,10 @@ static int wn_train_layout_ws(const wn_handle* h, long long N, long long L, long
         t.z[l] = take(zl); t.th[l] = take(zl); t.sg[l] = take(zl);
     }
     const size_t Mo = (size_t)N * out_len;
-    t.skip = take(Mo * S); t.ev = take(Mo * E); t.nblk = (NL + t.G - 1) / t.G; t.zg = take((size_t)t.nblk * Mo * t.G * D); t.dzg = take(Mo * t.G * D); t.bskip_total = take(S);
+    t.skip = take(Mo * S); t.ev = take(Mo * E); t.nblk = (NL + t.G - 1) / t.G; t.zg = take((size_t)t.nblk * Mo * t.G * D); t.dzg = take((size_t)t.nblk * Mo * t.G * D); t.bskip_total = take(S);
     t.res_o = take((size_t)NL * R * D); t.skip_o = take((size_t)NL * S * D); t.w1_o = take((size_t)E * S); t.w2_o = take((size_t)C * E);
     t.fgb0 = take((size_t)NL * 2 * D * R); t.fgb1 = take((size_t)NL * 2 * D * R);
-    t.dskip = take(Mo * S); t.de = take(Mo * E); t.dz = take(zmax); t.dfg = take(2 * zmax);
+    t.dskip = take(Mo * S); t.de = take(Mo * E); t.dz = take(zmax); t.dfg = take(2 * zmax); t.dfg2 = take(2 * zmax);
     t.dxa = take((size_t)N * L * R); t.dxb = take((size_t)N * L * R);
     t.colsum_tmp = take(S);
     t.idx = take((size_t)N * L);
@@ -185,6 +185,27 @@ extern "C" int wn_train_forward(wn_handle* h, const float* params, const int32_t
                            pl.has_bias ? fw + h->fw_off_start_b : nullptr, ws + t.x[0], rows, R);
     }
     float* skip = ws + t.skip; float* ev = ws + t.ev;
+    // The grouped skip product of a block (zg . [Wskip of its layers]: 1.2 ms at config 5) hangs off the layer chain -- the next block's
+    // layers do not need it, only the head does: it runs on the side stream next to them (see wn_train_backward for the two-stream scheme).
+    const char* one_env = wn_dev_env("WN_TRAIN_ONE_STREAM");
+    const bool two = !(one_env && one_env[0] == '1');
+    if (two && !h->side_stream) {
+        rc = rt_hip(hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking), "hipStreamCreateWithFlags");
+        if (rc) return rc;
+    }
+    hipStream_t sd = two ? h->side_stream : st;
+    size_t ev_next = 0;
+    auto signal = [&](hipStream_t from) -> hipEvent_t {
+        if (ev_next == h->events.size()) {
+            hipEvent_t e = nullptr;
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+            h->events.push_back(e);
+        }
+        hipEvent_t e = h->events[ev_next++];
+        (void)hipEventRecord(e, from);
+        return e;
+    };
+    auto wait_for = [&](hipStream_t who, hipEvent_t e) { if (two && e) (void)hipStreamWaitEvent(who, e, 0); };
     for (int l = 0; l < NL; ++l) {
         const long long d = h->dil[l], rows = t.need[l + 1], t0 = L - rows;
         const int gi = l % G;
@@ -226,9 +247,11 @@ extern "C" int wn_train_forward(wn_handle* h, const float* params, const int32_t
             if (first > 0) a.cin = WnRowMap{skip, out_len * S, S, 0};
             a.c = WnRowMap{skip, out_len * S, S, 0};
             a.M = N * out_len; a.rows_per_batch = (int)out_len; a.a_bf16 = bf16 ? 1 : 0;
-            wn_launch_nn(st, WN_EPI_PLAIN, a, bf16 ? bt_skip + (size_t)(first / G) * S * G * D : nullptr);
+            wait_for(sd, signal(st));   // the block's zg is complete (every gate product of the block ran on the caller's stream)
+            wn_launch_nn(sd, WN_EPI_PLAIN, a, bf16 ? bt_skip + (size_t)(first / G) * S * G * D : nullptr);
         }
     }
+    wait_for(st, signal(sd));   // skip is complete
     {
         WnGemmArgs a;
         memset(&a, 0, sizeof(a));
@@ -265,7 +288,36 @@ extern "C" int wn_train_backward(wn_handle* h, const float* params, const float*
     (void)params;  // the operand layouts of this step's parameters were rebuilt by wn_train_forward
     int rc = rt_hip(hipMemsetAsync(grads, 0, h->fw_floats * 4, st), "hipMemsetAsync(grads)");
     if (rc) return rc;
-    float* dskip = ws + t.dskip; float* de = ws + t.de; float* dz = ws + t.dz; float* dfg = ws + t.dfg;
+    float* dskip = ws + t.dskip; float* de = ws + t.de; float* dz = ws + t.dz;
+    // Two streams.  The activation-gradient chain (dz -> [dF|dG] -> dx, layer after layer) is strictly sequential; the weight-gradient
+    // products only hang off it (dWres needs dx', dWfg needs [dF|dG], the grouped dWskip needs dskip) and nobody waits for them before
+    // the optimizer.  They run on a side stream, ordered by events: every product of the chain then has a second, independent kernel
+    // next to it that fills its tail (a 128-row-tile product of 3250 workgroups leaves the last of its four waves of workgroups 17 % full)
+    // and uses the memory system while the other one computes.  [dF|dG] is double buffered (layer l writes buffer l & 1): the side
+    // stream may still read layer l's while the chain writes layer l-1's; the chain waits for the side stream only where it would
+    // overwrite something the side stream has not read yet (dx ping-pong buffer: dWres of layer l before dx of layer l-1; [dF|dG]
+    // buffer: dWfg of layer l before the gate derivative of layer l-2).  WN_TRAIN_ONE_STREAM=1 (with WN_TESTING=1) keeps everything on
+    // the caller's stream (A/B runs).
+    const char* one_env = wn_dev_env("WN_TRAIN_ONE_STREAM");
+    const bool two = !(one_env && one_env[0] == '1');
+    if (two && !h->side_stream) {
+        rc = rt_hip(hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking), "hipStreamCreateWithFlags");
+        if (rc) return rc;
+    }
+    hipStream_t sd = two ? h->side_stream : st;
+    size_t ev_next = 0;
+    auto signal = [&](hipStream_t from) -> hipEvent_t {   // an event recorded on `from` now
+        if (ev_next == h->events.size()) {
+            hipEvent_t e = nullptr;
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+            h->events.push_back(e);
+        }
+        hipEvent_t e = h->events[ev_next++];
+        (void)hipEventRecord(e, from);
+        return e;
+    };
+    auto wait_for = [&](hipStream_t who, hipEvent_t e) { if (two && e) (void)hipStreamWaitEvent(who, e, 0); };
+    std::vector<hipEvent_t> res_read(NL, nullptr), fg_read(NL, nullptr);   // side stream: dWres / dWfg of layer l have read their operands
     // bf16 mode: the "NN" products take their weight operand ([N][K] bf16) straight from the bf16 copy of the parameter blob
     const unsigned short* bw = t.bf16 ? reinterpret_cast<const unsigned short*>(ws + t.bw) : nullptr;
     const float* skip = ws + t.skip; const float* ev = ws + t.ev;
@@ -303,6 +355,32 @@ extern "C" int wn_train_backward(wn_handle* h, const float* params, const float*
             if (rc) return rc;
         }
     }
+    wait_for(sd, signal(st));   // grads cleared, dskip complete: the side stream may start
+    // The skip path's gradients, one block of G layers at a time (as in the forward):
+    //   dzg_b [Mo][cnt*D] = dskip . [Wskip of the block's layers]      dWskip^T of the block [cnt*D][S] = zg^T . dskip
+    // so dskip (0.7 GB at config 5) is read twice per block instead of twice per layer; the gate step of a layer adds its column block of
+    // dzg_b to dz on the skip rows.  Both products only need dskip: all blocks are enqueued NOW on the side stream, last block first --
+    // the chain waits 1.2 ms for the last block's dzg (as it always did) and finds the others ready (one dzg buffer per block).
+    std::vector<hipEvent_t> dzg_ready(t.nblk, nullptr);
+    for (int b = t.nblk - 1; b >= 0; --b) {
+        const int first = b * t.G, cnt = NL - first < t.G ? NL - first : t.G;
+        float* dzg_b = ws + t.dzg + (size_t)b * ((size_t)Mo * t.G * D);
+        const float* zg = ws + t.zg + (size_t)b * ((size_t)Mo * t.G * D);
+        memset(&a, 0, sizeof(a));
+        a.a0 = a.a1 = WnRowMap{dskip, out_len * S, S, 0};
+        a.k_split = S; a.K = S; a.bt = ws + t.skip_o + (size_t)first * S * D; a.N = cnt * D;
+        a.c = WnRowMap{dzg_b, out_len * (long long)cnt * D, (long long)cnt * D, 0};
+        a.M = Mo; a.rows_per_batch = (int)out_len;
+        wn_launch_nn(sd, WN_EPI_PLAIN, a, bw ? bw + h->fw_off_skip + (size_t)first * D * S : nullptr);
+        if (two) dzg_ready[b] = signal(sd);
+        memset(&g, 0, sizeof(g));
+        g.a = WnRowMap{zg, out_len * (long long)t.G * D, (long long)t.G * D, 0}; g.b = WnRowMap{dskip, out_len * S, S, 0};
+        g.Ka = cnt * D; g.Nb = S; g.c = grads + h->fw_off_skip + (size_t)first * D * S; g.ldc = S; g.M = Mo; g.rows_per_batch = (int)out_len;
+        if (t.bf16) {   // zg is stored as bf16: it goes in as B (operands swapped, C written transposed -- same [cnt*D][S] gradient)
+            WnRowMap zmap = g.a; g.a = g.b; g.b = zmap; g.Ka = S; g.Nb = cnt * D; g.b_bf16 = 1; g.c_trans = 1;
+        }
+        wn_launch_tn(sd, g, t.bf16);
+    }
     // ---- layers, last to first
     float* dxn = ws + t.dxa;  // dLoss/dx_{l+1}
     float* dxc = ws + t.dxb;  // dLoss/dx_l
@@ -311,28 +389,11 @@ extern "C" int wn_train_backward(wn_handle* h, const float* params, const float*
         const float* xin = ws + t.x[l];
         const float* z = ws + t.z[l];
         const bool has_res = l < NL - 1;
-        // The skip path, one block of G layers at a time (as in the forward): entering a block from above,
-        //   dzg [Mo][cnt*D] = dskip . [Wskip of the block's layers]      dWskip^T of the block [cnt*D][S] = zg^T . dskip
-        // so dskip (0.7 GB at config 5) is read twice per block instead of twice per layer; the gate step below adds
-        // this layer's column block of dzg to dz on the skip rows.
+        float* dfg = ws + ((l & 1) ? t.dfg2 : t.dfg);
+        if (l + 2 < NL) wait_for(st, fg_read[l + 2]);   // (this layer's [dF|dG] overwrites the buffer of layer l + 2)
         const int gi = l % t.G, first = l - gi, cnt = NL - first < t.G ? NL - first : t.G;
-        float* dzg = ws + t.dzg;
-        if (gi == cnt - 1) {
-            const float* zg = ws + t.zg + (size_t)(l / t.G) * ((size_t)Mo * t.G * D);
-            memset(&a, 0, sizeof(a));
-            a.a0 = a.a1 = WnRowMap{dskip, out_len * S, S, 0};
-            a.k_split = S; a.K = S; a.bt = ws + t.skip_o + (size_t)first * S * D; a.N = cnt * D;
-            a.c = WnRowMap{dzg, out_len * (long long)cnt * D, (long long)cnt * D, 0};
-            a.M = Mo; a.rows_per_batch = (int)out_len;
-            wn_launch_nn(st, WN_EPI_PLAIN, a, bw ? bw + h->fw_off_skip + (size_t)first * D * S : nullptr);
-            memset(&g, 0, sizeof(g));
-            g.a = WnRowMap{zg, out_len * (long long)t.G * D, (long long)t.G * D, 0}; g.b = WnRowMap{dskip, out_len * S, S, 0};
-            g.Ka = cnt * D; g.Nb = S; g.c = grads + h->fw_off_skip + (size_t)first * D * S; g.ldc = S; g.M = Mo; g.rows_per_batch = (int)out_len;
-            if (t.bf16) {   // zg is stored as bf16: it goes in as B (operands swapped, C written transposed -- same [cnt*D][S] gradient)
-                WnRowMap zmap = g.a; g.a = g.b; g.b = zmap; g.Ka = S; g.Nb = cnt * D; g.b_bf16 = 1; g.c_trans = 1;
-            }
-            wn_launch_tn(st, g, t.bf16);
-        }
+        float* dzg = ws + t.dzg + (size_t)(l / t.G) * ((size_t)Mo * t.G * D);
+        if (gi == cnt - 1) wait_for(st, dzg_ready[l / t.G]);   // entering a block from above: its dzg (side stream, enqueued before the loop)
         if (has_res) {
             // [dF | dG] straight from the product dz = dx' . Wres (+ this layer's share of dzg on the skip rows): the gate derivative is
             // the product's epilogue (WN_EPI_GATE_BWD), dz is never written (round 2: dz to HBM, then a streaming gate kernel).
@@ -349,8 +410,9 @@ extern "C" int wn_train_backward(wn_handle* h, const float* params, const float*
             g.a = WnRowMap{z, rows * D, D, 0}; g.b = WnRowMap{dxn, L * (long long)R, R, t0};
             g.Ka = D; g.Nb = R; g.c = grads + h->fw_off_res + (size_t)l * D * R; g.ldc = R; g.M = M; g.rows_per_batch = (int)rows;
             g.a_bf16 = t.bf16 ? 1 : 0;   // z is stored as bf16 in the bf16 step (here as A: ~1000 row splits, see wn_bwd_gemm_tn_bf16)
-            wn_launch_tn(st, g, t.bf16);
-            if (pl.has_bias) wn_launch_colsum(st, WnRowMap{dxn, L * (long long)R, R, t0}, M, (int)rows, R, grads + h->fw_off_bres + (size_t)l * R);
+            wn_launch_tn(sd, g, t.bf16);   // (dx' is complete: the side stream waited for the dx product of layer l + 1, below)
+            if (pl.has_bias) wn_launch_colsum(sd, WnRowMap{dxn, L * (long long)R, R, t0}, M, (int)rows, R, grads + h->fw_off_bres + (size_t)l * R);
+            if (two) res_read[l] = signal(sd);
         } else {   // the last layer has no residual output: dz is its share of dzg alone
             rc = rt_hip(hipMemsetAsync(dz, 0, (size_t)M * D * 4, st), "hipMemsetAsync(dz)");
             if (rc) return rc;
@@ -362,6 +424,7 @@ extern "C" int wn_train_backward(wn_handle* h, const float* params, const float*
                 hipLaunchKernelGGL(wn_bwd_gate<false>, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, dz, ws + t.th[l], ws + t.sg[l], dfg, M, D,
                                    dzg + (size_t)gi * D, cnt * D, (int)rows, (int)out_len);
         }
+        wait_for(sd, signal(st));   // [dF|dG] of this layer is complete
         // dWfg^T [2R][2D]: rows 0..R-1 = x_l(t - d)^T . dfg (tap 0), rows R.. = x_l(t)^T . dfg (tap 1) -- one launch, the taps are two
         // row views of A (ka_split): the workgroups of the two taps run side by side and read the same rows of dfg.
         memset(&g, 0, sizeof(g));
@@ -372,16 +435,17 @@ extern "C" int wn_train_backward(wn_handle* h, const float* params, const float*
         g.a_skip_lo = (int)t.zlo[l];   // tap 0 on the rows where the forward read a pad zero: no contribution
 #if WN_TN_MERGE_TAPS
         if (R % 128 == 0) {
-            wn_launch_tn(st, g, t.bf16);
+            wn_launch_tn(sd, g, t.bf16);
         } else
 #endif
         for (int tap = 0; tap < 2; ++tap) {
             WnGemmTnArgs g1 = g;
             g1.a = tap ? g.a1 : g.a; g1.ka_split = 0; g1.Ka = R; g1.c = g.c + (size_t)tap * R * 2 * D;
             if (tap) g1.a_skip_lo = 0;
-            wn_launch_tn(st, g1, t.bf16);
+            wn_launch_tn(sd, g1, t.bf16);
         }
-        if (pl.has_bias) wn_launch_colsum(st, WnRowMap{dfg, rows * 2 * D, 2 * D, 0}, M, (int)rows, 2 * D, grads + h->fw_off_bfg + (size_t)l * 2 * D, t.bf16);
+        if (pl.has_bias) wn_launch_colsum(sd, WnRowMap{dfg, rows * 2 * D, 2 * D, 0}, M, (int)rows, 2 * D, grads + h->fw_off_bfg + (size_t)l * 2 * D, t.bf16);
+        if (two) fg_read[l] = signal(sd);
         // dx_l on ITS rows [lo, L) (the last need[l] time steps; lo = t0 - sh with sh = d, or less where the clip is so short that layer
         // l's input starts later than t0 - d) in ONE product over two row-shifted views of dfg:
         //     dx_l(t) = dx'(t) [t >= t0]  +  dfg(t) . Wfg(tap 1) [t >= t0]  +  dfg(t + d) . Wfg(tap 0) [t < L - d]
@@ -390,6 +454,7 @@ extern "C" int wn_train_backward(wn_handle* h, const float* params, const float*
         // (round 2: a memset of dx and two read-modify-write products per layer).  (Positions before lo do not exist: what the forward
         // read there were the reference's pad zeros, which have no gradient.)
         const long long rows_l = t.need[l], sh = rows_l - rows;   // 0 <= sh <= d
+        if (l + 1 < NL) wait_for(st, res_read[l + 1]);   // (dx_l goes into the buffer dWres of layer l + 1 read dx_{l+2} from)
         memset(&a, 0, sizeof(a));
         a.a0 = WnRowMap{dfg, rows * 2 * D, 2 * D, -sh};      // dfg(t):     row (t - t0) = rem - sh, valid from rem = sh
         a.a1 = WnRowMap{dfg, rows * 2 * D, 2 * D, d - sh};   // dfg(t + d): row rem + d - sh, valid while rem < rows_l - d
@@ -402,8 +467,10 @@ extern "C" int wn_train_backward(wn_handle* h, const float* params, const float*
             const unsigned short* w = bw ? bw + h->fw_off_fg + (size_t)l * 2 * R * 2 * D : nullptr;  // native [2R][2D]: rows 0..R-1 tap 0, R.. tap 1
             wn_launch_nn(st, WN_EPI_PLAIN, a, w ? w + (size_t)R * 2 * D : nullptr, w, 2 * D);
         }
+        wait_for(sd, signal(st));   // dx_l is complete: dWres of layer l - 1 may read it
         float* tmp = dxn; dxn = dxc; dxc = tmp;
     }
+    wait_for(st, signal(sd));   // join: every weight gradient is complete before the caller's stream goes on
     // ---- start_conv: dstart^T [C][R] = onehot(indices)^T . dx_0 over the rows dx_0 exists on (the last need[0] time steps)
     {
         const long long r0 = t.need[0], f0 = L - r0;

@@ -61,9 +61,10 @@ def main():
         return ms
 
     a = timed("native fp32 matrix-core step", 3) if "--only-bf16" not in sys.argv else 0.0
-    m.matrix_precision = "bf16"
-    timed("native step, bf16 operands for forward + activation gradients", 3)
-    m.matrix_precision = "fp32"
+    if "--only-fp32" not in sys.argv:
+        m.matrix_precision = "bf16"
+        timed("native step, bf16 operands for forward + activation gradients", 3)
+        m.matrix_precision = "fp32"
     peak = torch.cuda.max_memory_allocated() / 2**30
     print("torch-allocated peak %.1f GiB (the native workspace is allocated by the library, not by torch)" % peak)
     if "--no-torch" not in sys.argv:

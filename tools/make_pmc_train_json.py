@@ -1,0 +1,41 @@
+"""Runs on the GPU box after tools/collect_train_profiles.sh: sums FETCH_SIZE / WRITE_SIZE (rocprofv3 PMC passes, KiB per dispatch) over EVERY kernel of the
+profiled training run and divides by the number of steps (= dispatches of wn_fwd_start, one per forward): HBM bytes per training step, into the
+pmc_traffic_train.json that bench.py replays next to the algorithmic figure.
+    python tools/make_pmc_train_json.py <fetch.db> <write.db> <bf16|fp32> <summary file> <out.json>"""
+import datetime
+import json
+import os
+import sqlite3
+import sys
+
+
+def total(db, name):
+    con = sqlite3.connect(db)
+    tot, n = con.execute("select sum(value), count(*) from counters_collection where counter_name = ?", (name,)).fetchone()
+    steps = con.execute("select count(*) from counters_collection where counter_name = ? and kernel_name like '%wn_fwd_start%'", (name,)).fetchone()[0]
+    top = con.execute("select kernel_name, sum(value), count(*) from counters_collection where counter_name = ? group by kernel_name order by sum(value) desc limit 8",
+                      (name,)).fetchall()
+    return float(tot), int(n), int(steps), top
+
+
+def main():
+    fdb, wdb, prec, summary, out = sys.argv[1:6]
+    f, nf, sf, topf = total(fdb, "FETCH_SIZE")
+    w, nw, sw, topw = total(wdb, "WRITE_SIZE")
+    assert sf > 0 and sw > 0, (sf, sw)
+    doc = json.load(open(out)) if os.path.exists(out) else {}
+    doc["_comment"] = ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, KiB per dispatch) summed over every kernel of tools/bench_train.py 32 16000 "
+                       "and divided by the steps of the run (dispatches of wn_fwd_start); raw counter values (MI355X_MICROARCH.md: FETCH_SIZE may read 2x for wide "
+                       "coalesced streams on gfx950 -- the ratio to the algorithmic bytes in bench.py is therefore an upper bound)")
+    doc["train5_%s" % prec] = {"clips": 32, "clip_samples": 16000, "steps_profiled": sf, "dispatches": nf, "fetch_kib": round(f / sf, 1), "write_kib": round(w / sw, 1),
+                               "date": datetime.date.today().isoformat(), "summary": summary}
+    json.dump(doc, open(out, "w"), indent=1)
+    print("# HBM bytes per step from the PMC passes (%s): FETCH %.1f GB + WRITE %.1f GB over %d dispatches / %d steps" % (prec, f / sf * 1024 / 1e9, w / sw * 1024 / 1e9, nf, sf))
+    for label, top, steps in (("FETCH_SIZE", topf, sf), ("WRITE_SIZE", topw, sw)):
+        print("# largest by %s (GB per step):" % label)
+        for k, v, c in top:
+            print("#   %-90s %8.2f GB  (%d dispatches)" % (k[:90], v / steps * 1024 / 1e9, c))
+
+
+if __name__ == "__main__":
+    main()
