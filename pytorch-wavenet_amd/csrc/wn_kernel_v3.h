@@ -57,14 +57,16 @@
 #define WN_V3_COMPILER_VGPRS 152  // v152-v167: request sets of the input poll / the queue group's tap FIFO (see wn_ap_*, wn_q_*)
 // ---- experiment switches.  A product build (build.py) leaves every one of them at its default; setting one requires -DWN_EXPERIMENT,
 // which build.py never passes (tools/ builds the A/B variants): a library with wrong-on-purpose timing ablations cannot ship by accident.
-#if !defined(WN_EXPERIMENT) && (defined(WN_V3_SKIP_SLEEP) || defined(WN_V3_ABL) || defined(WN_V3_PAIR_ROWS) || defined(WN_V3_PRIO) || defined(WN_V3_LAST_SKIP_PRIO) || defined(WN_V3_SKIP_CHAINS) || defined(WN_V3_FG_CHAINS))
+#if !defined(WN_EXPERIMENT) && (defined(WN_V3_SKIP_SLEEP) || defined(WN_V3_ABL) || defined(WN_V3_PAIR_ROWS) || defined(WN_V3_PRIO) || defined(WN_V3_LAST_SKIP_PRIO) || defined(WN_V3_SKIP_CHAINS) || defined(WN_V3_FG_CHAINS) || defined(WN_V3_SKIP_SLOTS))
 #error "WN_V3_* experiment switches need -DWN_EXPERIMENT"
 #endif
 #ifndef WN_V3_SKIP_SLEEP
 #define WN_V3_SKIP_SLEEP 0  // s_sleep between the skip group's poll retries (the skip lane is not latency critical; fewer polls on the fabric)
 #endif
 #ifndef WN_V3_ABL
-#define WN_V3_ABL 0  // timing ablations (results are WRONG when != 0): 1 the skip group only polls the input and passes its barriers, 2 the queue group, 3 both
+#define WN_V3_ABL 0  // timing ablations (results are WRONG when != 0): 1 the skip group only polls the input and passes its barriers, 2 the queue group, 3 both;
+                     // 4: the skip group publishes its own dot WITHOUT the upstream lane (no chain through the layers), 8: the upstream lane is taken as it
+                     // comes back from the request at barrier A, fresh or not (no polling)
 #endif
 #ifndef WN_V3_PAIR_ROWS
 #define WN_V3_PAIR_ROWS 2  // a critical lane computes the filter AND the gate row of one channel on a half-width slice of x (see wn_v3_layer):
@@ -73,6 +75,11 @@
 #endif
 #ifndef WN_V3_LAST_SKIP_PRIO
 #define WN_V3_LAST_SKIP_PRIO 3  // wave priority of the LAST layer's skip group in the two-streams-per-item form (64 streams: 998.6 -> 1004.5 k)
+#endif
+#ifndef WN_V3_SKIP_SLOTS
+#define WN_V3_SKIP_SLOTS 0   // > 0: hand-off slots of a skip lane that stays inside one XCD are re-used per in-flight ITEM instead of one per stream (0: per
+                             // stream).  Correct, cuts the job's L2 <-> fabric traffic, and LOSES 3-13 %: the back-pressure look sits in front of the skip
+                             // chain's store, and that chain is as long as the x' chain (profiles/r04_skip_lane_slot_reuse_experiment.txt).
 #endif
 #ifndef WN_V3_SKIP_CHAINS
 #define WN_V3_SKIP_CHAINS 1  // independent FMA chains per row pair of the skip group's dot (1: one chain of DC packed FMAs, the arithmetic of rounds 2-3)
@@ -465,16 +472,18 @@ static __device__ void wn_v3_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
         *failflag = 0;
         const int mine = wn_xcc_id();
         __hip_atomic_store(p.xcc_tab + cx.w, (unsigned)(mine + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        int lx = 0, lsk = 0;
+        int lx = 0, lsk = 0, lup = 0, lcons = 0;
         if (p.allow_plain) {
             if (l < NL - 1) {
                 lx = wn_same_xcd(cx, mine, (l + 1) * P, P);
                 lsk = wn_same_xcd(cx, mine, (l + 1) * P + c, 1);
+                if (l < NL - 2) lcons = lsk && wn_same_xcd(cx, mine, (l + 2) * P + c, 1);   // ... and the consumer's consumer (slot re-use, skip group)
             } else {
                 lsk = wn_same_xcd(cx, mine, NL * P, p.PA * p.HR);
             }
+            if (l > 0) lup = wn_same_xcd(cx, mine, (l - 1) * P + c, 1);
         }
-        locflags[0] = lx; locflags[1] = lsk;
+        locflags[0] = lx; locflags[1] = lsk; locflags[2] = lup; locflags[3] = lcons;
     }
     __syncthreads();
     const bool local_x = locflags[0] != 0, local_s = locflags[1] != 0;
@@ -735,6 +744,26 @@ static __device__ void wn_v3_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
         constexpr unsigned SB = (unsigned)S * 8;                               // bytes between the lanes of consecutive streams
         constexpr unsigned ODD_BASE = 2048u * (unsigned)(RS - 1);              // byte offset of the natural-order tail inside a lane
         const unsigned lane16 = (unsigned)t * 16, odd_ld = ODD_BASE + (unsigned)(t & ~1) * 8, odd_st = ODD_BASE + (unsigned)t * 8;
+        // ---- Slot re-use.  A lane is S granules per STREAM: 50 layers x 4 slices x 64 streams x 4 KB = 52 MB that is written once and read once per
+        // timestep -- it never fits the 4 MB of an XCD's L2, so every line goes out to the fabric once (rocprofv3 PMC: WRITE_SIZE 142 GB per 2000
+        // timesteps, 2/3 of the job's traffic, 3.3x its algorithmic bytes) although producer and consumer sit on the same XCD.  Where they do
+        // (same XCD: the store is L2-resident anyway), the lane of pipeline ITEM i goes into slot i mod NSLOT instead: NSLOT x G x 4 KB per
+        // workgroup stay dirty in the L2 and are overwritten there.  A slot may only be overwritten once its reader is done with it; the reader
+        // (the next layer's skip group, same slice) publishes ITS item j after it has read ours, so the producer of item i looks at one pair
+        // of the reader's own lane of item i - NSLOT before it stores (requested a window ahead, next to the upstream request: normally fresh).
+        // Tags of re-used slots count items (item + 1), the others evaluations (e + 1) as before.  The last layer's lanes (read by the head
+        // replicas, which publish no lane) and every lane that crosses an XCD boundary keep one slot per stream.
+#ifndef WN_V3_SLOT_DEBUG
+#define WN_V3_SLOT_DEBUG 0   // timing experiments (-DWN_EXPERIMENT): 1 = re-used slots WITHOUT the back-pressure look (unsafe), 2 = the look without re-use
+#endif
+        constexpr int NSLOT_C = WN_V3_SKIP_SLOTS;
+        const int NSLOT = NSLOT_C > 0 && NSLOT_C * G <= ns ? NSLOT_C : 0;
+        const bool slot_look = NSLOT > 0 && l < NL - 1 && local_s && WN_V3_SLOT_DEBUG != 1;
+        const bool slot_out = NSLOT > 0 && l < NL - 1 && local_s && WN_V3_SLOT_DEBUG != 2;                 // my lane: re-used slots
+        const bool slot_in = NSLOT > 0 && l > 0 && locflags[2] != 0 && WN_V3_SLOT_DEBUG != 2;              // the upstream's lane (its slot_out: the same relation seen from the other side)
+        const bool slot_cons = NSLOT > 0 && l < NL - 2 && locflags[3] != 0;       // the reader's OWN lane (where its progress is visible)
+        const size_t cons_wg = (size_t)(l < NL - 1 ? l + 1 : l) * P + c;
+        int slot = 0;   // item mod NSLOT
         if (wn_barrier_failed(cx, failflag)) return;  // A(0)
         // The upstream skip lane of the coming item is requested right after barrier A: its producer published it a little after
         // the x' this workgroup has just consumed, so the load returns it, and its round trip runs next to the critical group's
@@ -742,16 +771,25 @@ static __device__ void wn_v3_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
         // nearly as long as the critical group needs from B to the next A).  One item ahead it would come back stale in the
         // latency-bound regime.
         wn_v4i sk_req[G][NPR];
-        auto request_up = [&](int s2) {
+        wn_v4i ck_req = {0, 0, 0, 0};   // one pair of the reader's lane of the item whose slot the coming item re-uses
+        // where the reader's lane of item (ej, sj) lives: its slot (the same index as ours: both count items) or its stream
+        auto check_off = [&](int slot2, int sj) -> unsigned {
+            return (unsigned)(((cons_wg * ns + (slot_cons ? slot2 * G : sj)) * (size_t)S) * 8) + (NPL > 0 ? lane16 : odd_ld);
+        };
+        auto request_up = [&](int s2, int slot2) {
 #pragma unroll
             for (int g = 0; g < G; ++g) {
-                const unsigned base = (unsigned)(((up_wg * ns + s2 + g) * (size_t)S) * 8);
+                const unsigned base = (unsigned)(((up_wg * ns + (slot_in ? slot2 * G : s2) + g) * (size_t)S) * 8);
 #pragma unroll
                 for (int h2 = 0; h2 < NPL; ++h2) sk_req[g][h2] = __builtin_amdgcn_raw_buffer_load_b128(rs_gs, lane16, base + h2 * 4096, 16);
                 if constexpr (ODD) sk_req[g][NPL] = __builtin_amdgcn_raw_buffer_load_b128(rs_gs, odd_ld, base, 16);
             }
+            if (slot_look) {
+                const int sj = s2 - NSLOT * G < 0 ? s2 - NSLOT * G + ns : s2 - NSLOT * G;
+                ck_req = wn_ld_pair(rs_gs, check_off(slot2, sj));
+            }
         };
-        request_up(0);
+        request_up(0, 0);
         long long item = 0;
         for (long long e = 0; e < r.n_eval; ++e) {
             const bool prime = e < n_prime;
@@ -761,8 +799,10 @@ static __device__ void wn_v3_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
                 const bool stamp = r.prof && item < r.prof_items && tid == 256;
                 const long long t0 = stamp ? (long long)wall_clock64() : 0;
                 const int s2 = s + G < ns ? s + G : 0;  // the coming item's first stream
-                const unsigned base_up = (unsigned)(((up_wg * ns + s) * (size_t)S) * 8);    // upstream slice's lane, first stream of the item
-                const unsigned base_me = (unsigned)((((size_t)cx.w * ns + s) * (size_t)S) * 8);
+                const int slot2 = NSLOT > 0 && slot + 1 < NSLOT ? slot + 1 : 0;
+                const uint32_t tag_in = slot_in ? (uint32_t)(item + 1) : tag, tag_out = slot_out ? (uint32_t)(item + 1) : tag;
+                const unsigned base_up = (unsigned)(((up_wg * ns + (slot_in ? slot * G : s)) * (size_t)S) * 8);    // upstream slice's lane, first stream of the item
+                const unsigned base_me = (unsigned)((((size_t)cx.w * ns + (slot_out ? slot * G : s)) * (size_t)S) * 8);
                 // ---- skip 1x1 partial on this lane of the running skip sum          (wavenet_model.py:154-162)
                 float a3[G][RS];
 #pragma unroll
@@ -818,39 +858,60 @@ static __device__ void wn_v3_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
                         }
                         if constexpr (ODD) a3[g][RS - 1] = a3o[g].x + a3o[g].y;
                     }
-                    if (l > 0) {
+                    if (l > 0 && !(WN_V3_ABL & 4)) {
 #pragma unroll
                         for (int g = 0; g < G; ++g) {
 #pragma unroll
                             for (int h2 = 0; h2 < NPL; ++h2) {
                                 wn_v4i v = sk_req[g][h2];   // (only ever this item's streams: re-requested after every barrier A)
-                                if ((uint32_t)v.y != tag || (uint32_t)v.w != tag) v = wn_poll_pair(cx, rs_gs, base_up + g * SB + h2 * 4096 + lane16, tag, WN_W_SKIN, e, s + g, WN_V3_SKIP_SLEEP);
+                                if (!(WN_V3_ABL & 8) && ((uint32_t)v.y != tag_in || (uint32_t)v.w != tag_in)) v = wn_poll_pair(cx, rs_gs, base_up + g * SB + h2 * 4096 + lane16, tag_in, WN_W_SKIN, e, s + g, WN_V3_SKIP_SLEEP);
                                 a3[g][2 * h2] += __int_as_float(v.x);
                                 a3[g][2 * h2 + 1] += __int_as_float(v.z);
                             }
                             if constexpr (ODD) {  // (both halves of the pair come from ONE store of the upstream's even lane)
                                 wn_v4i v = sk_req[g][NPL];
-                                if ((uint32_t)v.y != tag || (uint32_t)v.w != tag) v = wn_poll_pair(cx, rs_gs, base_up + g * SB + odd_ld, tag, WN_W_SKIN, e, s + g, WN_V3_SKIP_SLEEP);
+                                if ((uint32_t)v.y != tag_in || (uint32_t)v.w != tag_in) v = wn_poll_pair(cx, rs_gs, base_up + g * SB + odd_ld, tag_in, WN_W_SKIN, e, s + g, WN_V3_SKIP_SLEEP);
                                 a3[g][RS - 1] += __int_as_float((t & 1) ? v.z : v.x);
                             }
                         }
                     }
                 }
                 if (work || l == NL - 1) {  // (priming: only the head's lanes are kept moving, with zeros)
+                    if (slot_look) {
+                        // back-pressure: the slot still holds item - NSLOT until its reader has read it -- visible as the reader's own publication of that
+                        // item (tags only grow: anything at or beyond it will do).  Items of the priming phase were never published, nor read.
+                        const int sj = s - NSLOT * G < 0 ? s - NSLOT * G + ns : s - NSLOT * G;
+                        const long long ej = s - NSLOT * G < 0 ? e - 1 : e;
+                        if (ej >= n_prime && ej >= 0) {
+                            const uint32_t want = WN_V3_SLOT_DEBUG == 2 ? 0u : slot_cons ? (uint32_t)(item - NSLOT + 1) : (uint32_t)(ej + 1);
+                            wn_v4i v = ck_req;
+                            unsigned spins = 0;
+                            while ((int32_t)((uint32_t)v.y - want) < 0 && !cx.fail) {   // (bounded like wn_poll_pair)
+                                v = wn_ld_pair(rs_gs, check_off(slot, sj));
+                                if ((++spins & 127u) == 0u) {
+                                    if (__hip_atomic_load(cx.p->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { cx.fail = 1; break; }
+                                    const long long now = (long long)wall_clock64();
+                                    if (spins == 128u) cx.t_start = now;
+                                    else if (now - cx.t_start > cx.r->timeout_ticks) { wn_give_up(cx, WN_W_SKIN, e, s); break; }
+                                }
+                            }
+                        }
+                    }
 #pragma unroll
                     for (int g = 0; g < G; ++g) {
 #pragma unroll
-                        for (int h2 = 0; h2 < NPL; ++h2) wn_st_pair(rs_gs, base_me + g * SB + h2 * 4096 + lane16, tag, a3[g][2 * h2], a3[g][2 * h2 + 1], local_s);
+                        for (int h2 = 0; h2 < NPL; ++h2) wn_st_pair(rs_gs, base_me + g * SB + h2 * 4096 + lane16, tag_out, a3[g][2 * h2], a3[g][2 * h2 + 1], local_s);
                         if constexpr (ODD) {
                             const float nb = wn_dpp<0xB1>(a3[g][RS - 1]);  // quad_perm [1,0,3,2]: the odd neighbour's row
-                            if ((t & 1) == 0) wn_st_pair(rs_gs, base_me + g * SB + odd_st, tag, a3[g][RS - 1], nb, local_s);
+                            if ((t & 1) == 0) wn_st_pair(rs_gs, base_me + g * SB + odd_st, tag_out, a3[g][RS - 1], nb, local_s);
                         }
                     }
                 }
                 if (stamp)  // slot 6: the skip group's B(i) | its chunk length << 40 (10 ns ticks)
                     r.prof[((size_t)cx.w * r.prof_items + item) * WN_STAMPS + 6] = (t0 & 0xffffffffffll) | (((long long)wall_clock64() - t0) << 40);
                 if (wn_barrier_failed(cx, failflag)) return;  // ---- A(i+1)
-                request_up(s2);  // the upstream lane of the coming item
+                request_up(s2, slot2);  // the upstream lane of the coming item (and the reader's progress on the slot it re-uses)
+                slot = slot2;
             }
         }
         (void)wn_barrier_failed(cx, failflag);  // B(N)

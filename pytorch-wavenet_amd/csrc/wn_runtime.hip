@@ -1042,7 +1042,8 @@ extern "C" int wn_generate(wn_handle* h, const wn_generate_args* a) {
     if (a->flags != 0 || a->reserved != 0) return wn_fail(WN_E_BADARG, "wn_generate: flags/reserved must be 0");
     const bool greedy = (!(a->temperature > 0.f) && !a->stream_temperatures) || a->uniforms == nullptr;
     const long long n_eval = a->n_given - 1 + a->num_samples;
-    if (n_eval + 1 >= 0xFFFFFFFFll) return wn_fail(WN_E_BADARG, "wn_generate: job too long for 32-bit hand-off tags");
+    if (n_eval + 1 >= 0xFFFFFFFFll || (n_eval + 1) * (long long)h->plan.n_streams >= 0xFFFFFFFFll)   // (re-used slots count pipeline items, not evaluations)
+        return wn_fail(WN_E_BADARG, "wn_generate: job too long for 32-bit hand-off tags");
     { int rc = rt_hip(hipSetDevice(h->cfg.device_id), "hipSetDevice"); if (rc) return rc; }
     if (h->pending) { int rc = wn_wait(h); if (rc) return rc; }
     if (n_eval == 0) return WN_OK;
