@@ -90,92 +90,237 @@ static __device__ __forceinline__ unsigned wn_pack_bf16(float lo, float hi) {  /
 // Epilogue of a wave's 32 x 128 strip (4 accumulator tiles; C/D layout of 32x32: col = lane & 31, row = (i & 3) + 8 * (i >> 2) +
 // 4 * (lane >> 5)): rows mw.., logical columns nw.. .  WN_EPI_GATE: the 128 columns are [F(32) | G(32) | F(32) | G(32)] and the
 // strip emits 64 columns of tanh(F+bf) * sigmoid(G+bg).
+//
+// Round 4: every global access of the epilogue is 16 bytes per lane.  In the MFMA layout a lane holds ONE column of 16 rows, so the
+// straightforward epilogue (rounds 1-3) read cin / the saved gates and wrote C with 4-byte (bf16 outputs: 2-byte) accesses, 128 of them
+// per lane and strip -- and those accesses, not the products, were half of the training step: with the epilogues compiled out the bf16
+// config-5 step took 47.5 ms instead of 94.5 (profiles/r04_train_epilogue_experiment.txt); narrow vector-memory accesses retire per
+// lane, not per byte (MI355X guide).  Each 32 x 32 tile now goes through a wave-private LDS tile (`stage`: the GEMM's own operand
+// buffers, free once the K loop is done; row pitch 36 floats) and comes back row-wise: a lane takes 4 (fp32) or 8 (bf16-stored)
+// consecutive columns of a row.  No barrier: a wave's LDS operations execute in order.
+#define WN_EPI_PITCH 36
+#define WN_EPI_TILE_FLOATS (32 * WN_EPI_PITCH)
+static __device__ __forceinline__ void wn_epi_put(float* stage, const float (&v)[16], int lane) {
+    float* dst = stage + (4 * (lane >> 5)) * WN_EPI_PITCH + (lane & 31);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) dst[((i & 3) + 8 * (i >> 2)) * WN_EPI_PITCH] = v[i];
+}
+static __device__ __forceinline__ uint2 wn_pack_bf16x4(float4 a) { return make_uint2(wn_pack_bf16(a.x, a.y), wn_pack_bf16(a.z, a.w)); }
+static __device__ __forceinline__ uint4 wn_pack_bf16x8(float4 a, float4 b) {
+    return make_uint4(wn_pack_bf16(a.x, a.y), wn_pack_bf16(a.z, a.w), wn_pack_bf16(b.x, b.y), wn_pack_bf16(b.z, b.w));
+}
 template <int EPI>
-static __device__ __forceinline__ void wn_gemm_epilogue(const WnGemmArgs& g, const wn_f16v (&acc)[4], long long mw, int nw, int lane) {
+static __device__ __forceinline__ void wn_gemm_epilogue(const WnGemmArgs& g, const wn_f16v (&acc)[4], long long mw, int nw, int lane, float* stage) {
     const int col = lane & 31;
+#ifdef WN_EPI_TIMING_SKIP   // timing experiment (results wrong): one store per lane instead of the strip's epilogue
+    if (acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3] == 12345.678f) const_cast<float*>(g.c.base)[lane] = 1.f;
+    return;
+#endif
+    // row-wise lane roles: 4 columns per lane, 8 rows per pass (fp32 rows);  8 columns per lane, 16 rows per pass (bf16-stored rows)
+    const int r4 = lane >> 3, c4 = 4 * (lane & 7);
+    const int r8 = lane >> 2, c8 = 8 * (lane & 3);
+    // (q, rem) of row m: M < 2^31 (checked on the host): 32-bit division, a 64-bit one is ~100 instructions
+    auto split = [&](long long m, unsigned& q, unsigned& rem) { q = (unsigned)m / (unsigned)g.rows_per_batch; rem = (unsigned)m - q * (unsigned)g.rows_per_batch; };
+    if (EPI == WN_EPI_GATE) {
+        const int NH = g.N >> 1;   // channels per row of z / the gate pair
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int r = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
-        const long long m = mw + r;
-        if (m >= g.M) continue;
-        // M < 2^31 (checked on the host): 32-bit division, a 64-bit one is ~100 instructions and the epilogue does 16 of them
-        const unsigned q = (unsigned)m / (unsigned)g.rows_per_batch, rem = (unsigned)m - q * (unsigned)g.rows_per_batch;
-        float* crow = const_cast<float*>(wn_row_at(g.c, q, rem));
-        const float* addrow = (g.cin.base && (int)rem >= g.cin_skip_lo) ? wn_row_at(g.cin, q, rem) : nullptr;
-        if (EPI == WN_EPI_GATE) {
-            float* c2row = nullptr;
-            if (g.c2.base && (int)rem >= g.c2_first_row)
-                c2row = const_cast<float*>(g.c2.base) + (long long)q * g.c2.batch_stride + (g.c2.t0 + (long long)rem - g.c2_first_row) * g.c2.row_stride;
+        for (int p = 0; p < 2; ++p) {
+            const int nf = nw + 64 * p + col, ng = nf + 32;  // logical columns of F and G
+            if (nw + 64 * p + 32 >= g.N) continue;           // (wave-uniform)
+            float z[16], th[16], sg[16];
+            const float bf = g.bias ? g.bias[nf] : 0.f, bg = g.bias ? g.bias[ng] : 0.f;
 #pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                const int nf = nw + 64 * p + col, ng = nf + 32;  // logical columns of F and G
-                if (ng >= g.N) continue;
-                const float f = acc[2 * p][i] + (g.bias ? g.bias[nf] : 0.f);
-                const float gg = acc[2 * p + 1][i] + (g.bias ? g.bias[ng] : 0.f);
+            for (int i = 0; i < 16; ++i) {
+                const float f = acc[2 * p][i] + bf, gg = acc[2 * p + 1][i] + bg;
                 // tanh(f) = 2 sigmoid(2f) - 1 on the branch-free exp of the generation kernels (absolute error ~1e-7), 1-ulp reciprocals
-                const float th = fmaf(2.0f, __builtin_amdgcn_rcpf(1.0f + wn_exp(-2.0f * f)), -1.0f), sg = __builtin_amdgcn_rcpf(1.0f + wn_exp(-gg));
-                const float z = th * sg;
-                const int zc = (nw >> 1) + 32 * p + col;
-                if (g.c_bf16) {   // the bf16 step stores z (and its copy on the skip rows) as bf16: it only ever feeds bf16 matrix operands
-                    const unsigned short zb = (unsigned short)wn_pack_bf16(z, 0.f);
-                    (const_cast<unsigned short*>(reinterpret_cast<const unsigned short*>(g.c.base)) + (long long)q * g.c.batch_stride + (g.c.t0 + (long long)rem) * g.c.row_stride)[zc] = zb;
-                    if (c2row) (const_cast<unsigned short*>(reinterpret_cast<const unsigned short*>(g.c2.base)) + (long long)q * g.c2.batch_stride + (g.c2.t0 + (long long)rem - g.c2_first_row) * g.c2.row_stride)[zc] = zb;
-                } else {
-                    crow[zc] = z;
-                    if (c2row) c2row[zc] = z;
+                th[i] = fmaf(2.0f, __builtin_amdgcn_rcpf(1.0f + wn_exp(-2.0f * f)), -1.0f);
+                sg[i] = __builtin_amdgcn_rcpf(1.0f + wn_exp(-gg));
+                z[i] = th[i] * sg[i];
+            }
+            const int zc0 = (nw >> 1) + 32 * p;   // first of this tile's 32 channels
+            // ---- z (and its copy on the skip rows)
+            wn_epi_put(stage, z, lane);
+            if (g.c_bf16) {   // the bf16 step stores z as bf16: it only ever feeds bf16 matrix operands
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int row = r8 + 16 * k;
+                    const long long m = mw + row;
+                    if (m >= g.M) continue;
+                    unsigned q, rem;
+                    split(m, q, rem);
+                    const float* sp = stage + row * WN_EPI_PITCH + c8;
+                    const uint4 zb = wn_pack_bf16x8(*reinterpret_cast<const float4*>(sp), *reinterpret_cast<const float4*>(sp + 4));
+                    unsigned short* c16 = const_cast<unsigned short*>(reinterpret_cast<const unsigned short*>(g.c.base)) + (long long)q * g.c.batch_stride + (g.c.t0 + (long long)rem) * g.c.row_stride;
+                    *reinterpret_cast<uint4*>(c16 + zc0 + c8) = zb;
+                    if (g.c2.base && (int)rem >= g.c2_first_row) {
+                        unsigned short* d16 = const_cast<unsigned short*>(reinterpret_cast<const unsigned short*>(g.c2.base)) + (long long)q * g.c2.batch_stride +
+                                              (g.c2.t0 + (long long)rem - g.c2_first_row) * g.c2.row_stride;
+                        *reinterpret_cast<uint4*>(d16 + zc0 + c8) = zb;
+                    }
                 }
-                if (g.gate_t) {
-                    if (g.gate_packed) {
-                        reinterpret_cast<unsigned*>(g.gate_t)[m * (g.N >> 1) + zc] = wn_pack_bf16(th, sg);
-                    } else {
-                        g.gate_t[m * (g.N >> 1) + zc] = th;
-                        g.gate_g[m * (g.N >> 1) + zc] = sg;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int row = r4 + 8 * k;
+                    const long long m = mw + row;
+                    if (m >= g.M) continue;
+                    unsigned q, rem;
+                    split(m, q, rem);
+                    const float4 zv = *reinterpret_cast<const float4*>(stage + row * WN_EPI_PITCH + c4);
+                    *reinterpret_cast<float4*>(const_cast<float*>(wn_row_at(g.c, q, rem)) + zc0 + c4) = zv;
+                    if (g.c2.base && (int)rem >= g.c2_first_row)
+                        *reinterpret_cast<float4*>(const_cast<float*>(g.c2.base) + (long long)q * g.c2.batch_stride + (g.c2.t0 + (long long)rem - g.c2_first_row) * g.c2.row_stride + zc0 + c4) = zv;
+                }
+            }
+            // ---- the saved gates (the backward's inputs): one {bf16 tanh, bf16 sigmoid} dword per element, or two fp32 matrices
+            if (g.gate_t) {
+                if (g.gate_packed) {
+                    float pk[16];
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) pk[i] = __uint_as_float(wn_pack_bf16(th[i], sg[i]));
+                    wn_epi_put(stage, pk, lane);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int row = r4 + 8 * k;
+                        const long long m = mw + row;
+                        if (m >= g.M) continue;
+                        *reinterpret_cast<float4*>(g.gate_t + m * NH + zc0 + c4) = *reinterpret_cast<const float4*>(stage + row * WN_EPI_PITCH + c4);
+                    }
+                } else {
+#pragma unroll
+                    for (int which = 0; which < 2; ++which) {
+                        wn_epi_put(stage, which ? sg : th, lane);
+                        float* dstm = which ? g.gate_g : g.gate_t;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const int row = r4 + 8 * k;
+                            const long long m = mw + row;
+                            if (m >= g.M) continue;
+                            *reinterpret_cast<float4*>(dstm + m * NH + zc0 + c4) = *reinterpret_cast<const float4*>(stage + row * WN_EPI_PITCH + c4);
+                        }
                     }
                 }
             }
-        } else if (EPI == WN_EPI_GATE_BWD) {
-            // The product is dz = dx' . Wres (N = D channels); the strip emits [dF | dG] = dz * {G (1 - T^2), T G (1 - G)} in the packed
-            // [F(32) | G(32)] column order of Wfg^T (2N columns per row of c).  gate_t / gate_g are the forward's saved gates (INPUTS
-            // here, row m, N columns; gate_packed as in the forward); c2 is the skip path's share of dz (READ here: rows >=
-            // c2_first_row of a batch entry add c2's row (index - c2_first_row)).  dz itself never reaches HBM.
-            const float* zrow = nullptr;
-            if (g.c2.base && (int)rem >= g.c2_first_row)
-                zrow = g.c2.base + (long long)q * g.c2.batch_stride + (g.c2.t0 + (long long)rem - g.c2_first_row) * g.c2.row_stride;
+        }
+    } else if (EPI == WN_EPI_GATE_BWD) {
+        // The product is dz = dx' . Wres (N = D channels); the strip emits [dF | dG] = dz * {G (1 - T^2), T G (1 - G)} in the packed
+        // [F(32) | G(32)] column order of Wfg^T (2N columns per row of c).  gate_t / gate_g are the forward's saved gates (INPUTS
+        // here, row m, N columns; gate_packed as in the forward); c2 is the skip path's share of dz (READ here: rows >=
+        // c2_first_row of a batch entry add c2's row (index - c2_first_row)).  dz itself never reaches HBM.
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int ch = nw + 32 * j + col;
-                if (ch >= g.N) continue;
-                float d = acc[j][i];
-                if (zrow) d += zrow[ch];
-                float t, s2;
-                if (g.gate_packed) {
-                    const unsigned ts = reinterpret_cast<const unsigned*>(g.gate_t)[m * g.N + ch];
-                    t = __uint_as_float(ts << 16); s2 = __uint_as_float(ts & 0xffff0000u);
-                } else {
-                    t = g.gate_t[m * g.N + ch]; s2 = g.gate_g[m * g.N + ch];
-                }
-                const float df = d * s2 * (1.f - t * t), dg = d * t * s2 * (1.f - s2);
-                if (g.c_bf16) {
+        for (int j = 0; j < 4; ++j) {
+            const int ch0 = nw + 32 * j;
+            if (ch0 >= g.N) continue;   // (wave-uniform)
+            float d[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) d[i] = acc[j][i];
+            wn_epi_put(stage, d, lane);
+            if (g.c_bf16) {   // [dF|dG] STORED as bf16 (the bf16 step): 8 channels per lane
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int row = r8 + 16 * k;
+                    const long long m = mw + row;
+                    if (m >= g.M) continue;
+                    unsigned q, rem;
+                    split(m, q, rem);
+                    const float* sp = stage + row * WN_EPI_PITCH + c8;
+                    float dz[8], t[8], s2[8];
+                    { const float4 a = *reinterpret_cast<const float4*>(sp), b = *reinterpret_cast<const float4*>(sp + 4);
+                      dz[0] = a.x; dz[1] = a.y; dz[2] = a.z; dz[3] = a.w; dz[4] = b.x; dz[5] = b.y; dz[6] = b.z; dz[7] = b.w; }
+                    if (g.c2.base && (int)rem >= g.c2_first_row) {
+                        const float* zrow = g.c2.base + (long long)q * g.c2.batch_stride + (g.c2.t0 + (long long)rem - g.c2_first_row) * g.c2.row_stride + ch0 + c8;
+                        const float4 a = *reinterpret_cast<const float4*>(zrow), b = *reinterpret_cast<const float4*>(zrow + 4);
+                        dz[0] += a.x; dz[1] += a.y; dz[2] += a.z; dz[3] += a.w; dz[4] += b.x; dz[5] += b.y; dz[6] += b.z; dz[7] += b.w;
+                    }
+                    if (g.gate_packed) {
+                        const unsigned* gp = reinterpret_cast<const unsigned*>(g.gate_t) + m * g.N + ch0 + c8;
+                        const uint4 a = *reinterpret_cast<const uint4*>(gp), b = *reinterpret_cast<const uint4*>(gp + 4);
+                        const unsigned ts[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) { t[e] = __uint_as_float(ts[e] << 16); s2[e] = __uint_as_float(ts[e] & 0xffff0000u); }
+                    } else {
+                        const float* tp = g.gate_t + m * g.N + ch0 + c8;
+                        const float* gp = g.gate_g + m * g.N + ch0 + c8;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) { t[e] = tp[e]; s2[e] = gp[e]; }
+                    }
+                    float df[8], dg[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { df[e] = dz[e] * s2[e] * (1.f - t[e] * t[e]); dg[e] = dz[e] * t[e] * s2[e] * (1.f - s2[e]); }
                     unsigned short* c16 = const_cast<unsigned short*>(reinterpret_cast<const unsigned short*>(g.c.base)) +
-                                          (long long)q * g.c.batch_stride + (g.c.t0 + (long long)rem) * g.c.row_stride;
-                    c16[2 * nw + 64 * j + col] = (unsigned short)wn_pack_bf16(df, 0.f);
-                    c16[2 * nw + 64 * j + col + 32] = (unsigned short)wn_pack_bf16(dg, 0.f);
-                } else {
-                    crow[2 * nw + 64 * j + col] = df;
-                    crow[2 * nw + 64 * j + col + 32] = dg;
+                                          (long long)q * g.c.batch_stride + (g.c.t0 + (long long)rem) * g.c.row_stride + 2 * nw + 64 * j + c8;
+                    *reinterpret_cast<uint4*>(c16) = wn_pack_bf16x8(float4{df[0], df[1], df[2], df[3]}, float4{df[4], df[5], df[6], df[7]});
+                    *reinterpret_cast<uint4*>(c16 + 32) = wn_pack_bf16x8(float4{dg[0], dg[1], dg[2], dg[3]}, float4{dg[4], dg[5], dg[6], dg[7]});
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int row = r4 + 8 * k;
+                    const long long m = mw + row;
+                    if (m >= g.M) continue;
+                    unsigned q, rem;
+                    split(m, q, rem);
+                    float4 dzv = *reinterpret_cast<const float4*>(stage + row * WN_EPI_PITCH + c4);
+                    if (g.c2.base && (int)rem >= g.c2_first_row) {
+                        const float4 a = *reinterpret_cast<const float4*>(g.c2.base + (long long)q * g.c2.batch_stride + (g.c2.t0 + (long long)rem - g.c2_first_row) * g.c2.row_stride + ch0 + c4);
+                        dzv.x += a.x; dzv.y += a.y; dzv.z += a.z; dzv.w += a.w;
+                    }
+                    float dz[4] = {dzv.x, dzv.y, dzv.z, dzv.w}, t[4], s2[4];
+                    if (g.gate_packed) {
+                        const uint4 a = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned*>(g.gate_t) + m * g.N + ch0 + c4);
+                        const unsigned ts[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { t[e] = __uint_as_float(ts[e] << 16); s2[e] = __uint_as_float(ts[e] & 0xffff0000u); }
+                    } else {
+                        const float4 a = *reinterpret_cast<const float4*>(g.gate_t + m * g.N + ch0 + c4), b = *reinterpret_cast<const float4*>(g.gate_g + m * g.N + ch0 + c4);
+                        t[0] = a.x; t[1] = a.y; t[2] = a.z; t[3] = a.w; s2[0] = b.x; s2[1] = b.y; s2[2] = b.z; s2[3] = b.w;
+                    }
+                    float4 df, dg;
+                    df.x = dz[0] * s2[0] * (1.f - t[0] * t[0]); dg.x = dz[0] * t[0] * s2[0] * (1.f - s2[0]);
+                    df.y = dz[1] * s2[1] * (1.f - t[1] * t[1]); dg.y = dz[1] * t[1] * s2[1] * (1.f - s2[1]);
+                    df.z = dz[2] * s2[2] * (1.f - t[2] * t[2]); dg.z = dz[2] * t[2] * s2[2] * (1.f - s2[2]);
+                    df.w = dz[3] * s2[3] * (1.f - t[3] * t[3]); dg.w = dz[3] * t[3] * s2[3] * (1.f - s2[3]);
+                    float* crow = const_cast<float*>(wn_row_at(g.c, q, rem)) + 2 * nw + 64 * j + c4;
+                    *reinterpret_cast<float4*>(crow) = df;
+                    *reinterpret_cast<float4*>(crow + 32) = dg;
                 }
             }
-        } else {
-            const float* mrow = g.mask ? g.mask + (crow - g.c.base) : nullptr;  // the mask shares the output's row layout
+        }
+    } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int n = nw + 32 * j + col;
-                if (n >= g.N) continue;
-                float v = acc[j][i] + (g.bias ? g.bias[n] : 0.f);
-                if (addrow) v += addrow[n];
-                if (g.relu_c) v = fmaxf(v, 0.f);
-                if (mrow && !(mrow[n] > 0.f)) v = 0.f;
-                crow[n] = v;
+        for (int j = 0; j < 4; ++j) {
+            const int n0 = nw + 32 * j;
+            if (n0 >= g.N) continue;   // (wave-uniform)
+            float v16[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v16[i] = acc[j][i];
+            wn_epi_put(stage, v16, lane);
+            const int n = n0 + c4;
+            float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (g.bias) bias = *reinterpret_cast<const float4*>(g.bias + n);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int row = r4 + 8 * k;
+                const long long m = mw + row;
+                if (m >= g.M) continue;
+                unsigned q, rem;
+                split(m, q, rem);
+                float* crow = const_cast<float*>(wn_row_at(g.c, q, rem));
+                float4 v = *reinterpret_cast<const float4*>(stage + row * WN_EPI_PITCH + c4);
+                v.x += bias.x; v.y += bias.y; v.z += bias.z; v.w += bias.w;
+                if (g.cin.base && (int)rem >= g.cin_skip_lo) {
+                    const float4 a = *reinterpret_cast<const float4*>(wn_row_at(g.cin, q, rem) + n);
+                    v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+                }
+                if (g.relu_c) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                if (g.mask) {  // the mask shares the output's row layout
+                    const float4 mk = *reinterpret_cast<const float4*>(g.mask + (crow - g.c.base) + n);
+                    if (!(mk.x > 0.f)) v.x = 0.f;
+                    if (!(mk.y > 0.f)) v.y = 0.f;
+                    if (!(mk.z > 0.f)) v.z = 0.f;
+                    if (!(mk.w > 0.f)) v.w = 0.f;
+                }
+                *reinterpret_cast<float4*>(crow + n) = v;
             }
         }
     }
@@ -196,8 +341,11 @@ __global__ __launch_bounds__(256, WN_GEMM_MINB) void wn_fwd_gemm(WnGemmArgs g) {
     constexpr int TM = 128, TN = 128, KC = WN_GEMM_KC, AP = TM + 1;  // AP: padded row length of the transposed A chunk
     constexpr int NQ = KC / 8;          // float4 per thread per operand and chunk
     constexpr int BT = 256 / KC;        // threads per B row
-    __shared__ float a_t[2][KC * AP];                         // [k][row]
-    __shared__ float b_s[2][KC * TN];                         // [k][col]
+    // (ONE block: the epilogue re-uses it as the waves' staging tiles once the K loop is done)
+    __shared__ __attribute__((aligned(16))) float smem_f[2 * KC * AP + 2 * KC * TN + (2 * KC * AP) % 4];
+    static_assert(2 * KC * AP + 2 * KC * TN >= 4 * WN_EPI_TILE_FLOATS, "the operand buffers hold the four waves' staging tiles");
+    float (*a_t)[KC * AP] = reinterpret_cast<float (*)[KC * AP]>(smem_f);                                        // [2][k][row]
+    float (*b_s)[KC * TN] = reinterpret_cast<float (*)[KC * TN]>(smem_f + ((2 * KC * AP + 3) & ~3));               // [2][k][col]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const unsigned mtiles = (unsigned)((g.M + TM - 1) / TM), tm_i = blockIdx.x % mtiles, tn_i = blockIdx.x / mtiles;  // row tiles fastest
     const long long m0 = (long long)tm_i * TM;
@@ -268,7 +416,7 @@ __global__ __launch_bounds__(256, WN_GEMM_MINB) void wn_fwd_gemm(WnGemmArgs g) {
         __syncthreads();
     }
 
-    wn_gemm_epilogue<EPI>(g, acc, m0 + 32 * wv, n0, lane);
+    wn_gemm_epilogue<EPI>(g, acc, m0 + 32 * wv, n0, lane, smem_f + wv * WN_EPI_TILE_FLOATS);   // (the loop's last barrier: nobody reads the operand buffers any more)
 }
 
 
@@ -309,8 +457,11 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? WN_GEMM_BF16_MINB : 4) voi
     constexpr int HK = KC / TPR;   // k values per A loader thread and chunk (16 / 8)
     constexpr int HB = KC / 2;     // B: two loader threads per column, KC/2 bf16 each (NT == 2 TN)
     static_assert(HK % 8 == 0 && HB % 8 == 0, "loader pieces are 16-byte LDS stores");
-    __shared__ __attribute__((aligned(16))) unsigned short a_s[2][TM * LD];
-    __shared__ __attribute__((aligned(16))) unsigned short b_s[2][TN * LD];
+    // (ONE block: the epilogue re-uses it as the waves' staging tiles once the K loop is done)
+    __shared__ __attribute__((aligned(16))) unsigned short smem_h[2 * TM * LD + 2 * TN * LD];
+    static_assert((2 * TM * LD + 2 * TN * LD) * 2 >= WAVES * WN_EPI_TILE_FLOATS * 4, "the operand buffers hold the waves' staging tiles");
+    unsigned short (*a_s)[TM * LD] = reinterpret_cast<unsigned short (*)[TM * LD]>(smem_h);
+    unsigned short (*b_s)[TN * LD] = reinterpret_cast<unsigned short (*)[TN * LD]>(smem_h + 2 * TM * LD);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wr = wv & 3, wc = wv >> 2;
 #if WN_NN_COL_ADJ   // the column tiles of a row tile next to each other in dispatch order (different XCDs, same moment: the second read of the
                     // row tile's A is served by the memory-side cache; the XCD-local variant of this -- ids 8 apart -- measured slower)
@@ -412,7 +563,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? WN_GEMM_BF16_MINB : 4) voi
             __syncthreads();
         }
     }
-    wn_gemm_epilogue<EPI>(g, acc, m0 + 32 * wr, n0 + 128 * wc, lane);
+    wn_gemm_epilogue<EPI>(g, acc, m0 + 32 * wr, n0 + 128 * wc, lane, reinterpret_cast<float*>(smem_h) + wv * WN_EPI_TILE_FLOATS);   // (after the loop's last barrier)
 }
 
 // out[i] = bf16(in[i]) (round to nearest even): the backward products' weight operands, [N][K] row-major, are the forward
