@@ -10,8 +10,8 @@
 // needs ceil(n / 8) CUs on every XCD, and a full XCD stalls the dispatch however empty the others are) in a small table shared by
 // all processes that use the device -- a file in /dev/shm named after the device's PCI bus id, read and written under flock().
 // A job is admitted when its booking fits next to the bookings already there; otherwise wn_generate WAITS (bounded) until the
-// jobs in front of it have finished.  Bookings carry the owner's pid; entries of processes that no longer exist are dropped, so
-// a crashed owner cannot close the device for everyone else.  Jobs that a HIP stream already serialises (same process, same
+// jobs in front of it have finished.  Bookings carry the owner's pid and start time; entries of processes that no longer exist (or whose
+// pid now belongs to another process) are dropped, so a crashed owner cannot close the device for everyone else.  Jobs that a HIP stream already serialises (same process, same
 // stream: the rounds of a large job, back-to-back calls of one caller) share ONE booking -- the launch stays asynchronous there.
 // The booking is released by a host function enqueued behind the kernel (hipLaunchHostFunc), at the latest by wn_wait.
 //
@@ -38,9 +38,29 @@
 #include <string>
 
 #define WN_GATE_SLOTS 64
-struct WnGateSlot { int32_t pid; int32_t need; int64_t token; };   // need: CUs per XCD; pid 0 = free
+struct WnGateSlot { int32_t pid; int32_t need; int64_t token; int64_t born; };   // need: CUs per XCD; pid 0 = free; born: the owner's start time
 struct WnGateFile { uint32_t magic, version; WnGateSlot slot[WN_GATE_SLOTS]; };
-#define WN_GATE_MAGIC 0x474e5731u  /* "1WNG" */
+#define WN_GATE_MAGIC 0x474e5732u  /* "2WNG" */
+
+// Start time of a process in clock ticks since boot (/proc/<pid>/stat, field 22), 0 if it does not exist: a pid alone does not identify the
+// owner of a booking -- pids are re-used, and an entry left behind by a process that died mid-job must not be kept alive by a stranger.
+static inline int64_t wn_gate_born(int pid) {
+    char path[64], buf[1024];
+    snprintf(path, sizeof(path), "/proc/%d/stat", pid);
+    FILE* f = fopen(path, "r");
+    if (!f) return 0;
+    const size_t n = fread(buf, 1, sizeof(buf) - 1, f);
+    fclose(f);
+    buf[n] = 0;
+    const char* p = strrchr(buf, ')');   // (the command name may contain spaces and parentheses: fields resume behind the LAST one)
+    if (!p) return 0;
+    long long v = 0;
+    int field = 2;
+    for (p += 1; *p && field < 22; ++p)
+        if (*p == ' ' && p[1] != ' ') ++field;
+    if (field == 22 && sscanf(p, "%lld", &v) == 1 && v > 0) return (int64_t)v;
+    return 0;
+}
 
 struct WnGateBooking {           // one booking in the shared table; shared by the jobs of one (process, stream)
     std::string path;            // "" = process-local only
@@ -76,13 +96,16 @@ static inline int wn_gate_open_locked(const std::string& path, WnGateFile* tab) 
     (void)fchmod(fd, 0666);  // (other users of the same device must be able to book as well; the umask may have cut the mode)
     if (flock(fd, LOCK_EX) != 0) { close(fd); return -1; }
     const ssize_t n = pread(fd, tab, sizeof(*tab), 0);
-    if (n != (ssize_t)sizeof(*tab) || tab->magic != WN_GATE_MAGIC || tab->version != 1) {
+    if (n != (ssize_t)sizeof(*tab) || tab->magic != WN_GATE_MAGIC || tab->version != 2) {
         memset(tab, 0, sizeof(*tab));
-        tab->magic = WN_GATE_MAGIC; tab->version = 1;
+        tab->magic = WN_GATE_MAGIC; tab->version = 2;
     }
     for (int i = 0; i < WN_GATE_SLOTS; ++i) {  // bookings of processes that are gone
         WnGateSlot& s = tab->slot[i];
-        if (s.pid > 0 && kill((pid_t)s.pid, 0) != 0 && errno == ESRCH) memset(&s, 0, sizeof(s));
+        if (s.pid <= 0) continue;
+        const bool gone = kill((pid_t)s.pid, 0) != 0 && errno == ESRCH;
+        const int64_t born = gone ? 0 : wn_gate_born(s.pid);   // (0: /proc not readable -- keep the entry, the pid answers)
+        if (gone || (born != 0 && s.born != 0 && born != s.born)) memset(&s, 0, sizeof(s));
     }
     return fd;
 }
@@ -136,6 +159,7 @@ static inline int wn_gate_acquire(const char* busid, int cap, int need, const vo
                 }
                 if (used + need <= cap && free_slot >= 0) {
                     tab.slot[free_slot].pid = (int32_t)getpid(); tab.slot[free_slot].need = need; tab.slot[free_slot].token = b->token;
+                    tab.slot[free_slot].born = wn_gate_born((int)getpid());
                     b->path = path;
                     ok = true;
                 }

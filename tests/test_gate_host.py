@@ -23,6 +23,14 @@ int main(int argc, char** argv) {
     const char* bus = argv[1];
     const int cap = atoi(argv[2]), need = atoi(argv[3]), hold = atoi(argv[4]), tmo = atoi(argv[5]);
     const int nt = argc > 6 ? atoi(argv[6]) : 1, same = argc > 7 ? atoi(argv[7]) : 0;
+    if (hold == -2) {  // forge an entry of a LIVE pid (our parent's) with another start time: a re-used pid must not keep a dead owner's booking alive
+        WnGateFile tab;
+        const int fd = wn_gate_open_locked(wn_gate_path(bus), &tab);
+        tab.slot[0].pid = (int32_t)getppid(); tab.slot[0].need = need; tab.slot[0].token = 77; tab.slot[0].born = wn_gate_born((int)getppid()) + 12345;
+        wn_gate_close(fd, &tab, true);
+        printf("0 0 1\n");
+        return 0;
+    }
     if (hold < 0) {  // "crash": book and exit without releasing
         std::shared_ptr<WnGateTicket> t; long long w; int sh;
         const int rc = wn_gate_acquire(bus, cap, need, nullptr, tmo, &t, &w, &sh);
@@ -108,6 +116,10 @@ def test_two_processes_take_turns_and_a_dead_owner_is_dropped(gate):
     assert crash[0][0] == 0
     after = gate("0000:ae:00.0", 32, 28, 10, 2000)
     assert after[0][0] == 0 and after[0][1] < 500
+    # ... nor may a stranger that inherited the pid: an entry whose owner's start time is not the live process's is stale
+    gate("0000:b1:00.0", 32, 28, -2, 1000)
+    again = gate("0000:b1:00.0", 32, 28, 10, 2000)
+    assert again[0][0] == 0 and again[0][1] < 500
 
 
 def test_the_wait_is_bounded(gate):
