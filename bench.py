@@ -402,9 +402,10 @@ def _pmc_traffic(a, info, per_gpu):
     have = {k: info.get(k) for k in ("kernel_variant", "streams_per_item", "head_replicas", "n_samplers", "n_workgroups")}
     if any(want.get(k) != have[k] for k in have) or pmc.get("streams") != per_gpu:
         return None, "REFUSED: profiles/pmc_traffic.json was measured on %r (%d streams), this run is %r (%d streams)" % (want, pmc.get("streams", -1), have, per_gpu)
-    traffic = int((pmc["fetch_kib"] + pmc["write_kib"]) * 1024 * a.samples / pmc["samples_per_launch"])
+    traffic = int((pmc.get("fetch_correction", 1.0) * pmc["fetch_kib"] + pmc["write_kib"]) * 1024 * a.samples / pmc["samples_per_launch"])
     return traffic, {"file": "profiles/pmc_traffic.json", "kernel": pmc.get("kernel"), "measured": pmc.get("date"), "summary": pmc.get("summary"),
-                     "counters": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, %d timesteps per launch, scaled to %d" % (pmc["samples_per_launch"], a.samples)}
+                     "counters": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, %d timesteps per launch, scaled to %d; traffic = %.1f x FETCH_SIZE + WRITE_SIZE (%s)"
+                                 % (pmc["samples_per_launch"], a.samples, pmc.get("fetch_correction", 1.0), pmc.get("calibration", "uncalibrated"))}
 
 
 def _train_pmc(precision, N, L):
@@ -416,7 +417,7 @@ def _train_pmc(precision, N, L):
     doc = json.load(open(path)).get("train5_%s" % precision)
     if not doc or doc.get("clips") != N or doc.get("clip_samples") != L:
         return None
-    return {"bytes_per_step": int((doc["fetch_kib"] + doc["write_kib"]) * 1024), "kind": "replayed from profiles/pmc_traffic_train.json (%s, %s)" % (doc.get("date"), doc.get("summary"))}
+    return {"bytes_per_step": int((doc.get("fetch_correction", 1.0) * doc["fetch_kib"] + doc["write_kib"]) * 1024), "kind": "replayed from profiles/pmc_traffic_train.json (%s, %s)" % (doc.get("date"), doc.get("summary"))}
 
 
 def _launch_ranks(n):

@@ -31,11 +31,13 @@ def main():
     eng.close()
     doc = {
         "_comment": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, KiB per dispatch, averages over %d / %d dispatches) on MI355X for one "
-                    "64-stream job of %d timesteps (tools/collect_profiles.sh -> tools/make_pmc_json.py); raw counter values: the gfx950 2x FETCH_SIZE correction of "
-                    "MI355X_MICROARCH.md applies to wide coalesced streams, not to granule accesses, so none is applied" % (n1, n2, samples),
+                    "64-stream job of %d timesteps (tools/collect_profiles.sh -> tools/make_pmc_json.py); raw counter values; traffic = fetch_correction x fetch_kib + write_kib "
+                    "(calibrated on the hand-offs' own access patterns: profiles/r04_pmc_calibration.txt)" % (n1, n2, samples),
         "cfg3x64": {
             "streams": streams, "samples_per_launch": samples, "fetch_kib": round(fetch, 1), "write_kib": round(write, 1), "kernels_per_job": 1,
             "kernel": kname, "date": datetime.date.today().isoformat(), "summary": summary,
+            "fetch_correction": 2.0,
+            "calibration": "profiles/r04_pmc_calibration.txt: WRITE_SIZE exact, FETCH_SIZE reports half of the missed bytes for 8- and 16-byte sc1 loads",
             "form": {k: info[k] for k in ("kernel_variant", "streams_per_item", "head_replicas", "n_samplers", "n_workgroups")},
         },
     }

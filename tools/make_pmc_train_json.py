@@ -25,12 +25,14 @@ def main():
     assert sf > 0 and sw > 0, (sf, sw)
     doc = json.load(open(out)) if os.path.exists(out) else {}
     doc["_comment"] = ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, KiB per dispatch) summed over every kernel of tools/bench_train.py 32 16000 "
-                       "and divided by the steps of the run (dispatches of wn_fwd_start); raw counter values (MI355X_MICROARCH.md: FETCH_SIZE may read 2x for wide "
-                       "coalesced streams on gfx950 -- the ratio to the algorithmic bytes in bench.py is therefore an upper bound)")
+                       "and divided by the steps of the run (dispatches of wn_fwd_start); raw counter values; traffic = fetch_correction x fetch_kib + write_kib "
+                       "(MI355X_MICROARCH.md and profiles/r04_pmc_calibration.txt: FETCH_SIZE reports half of the bytes of a coalesced streaming read on gfx950)")
     doc["train5_%s" % prec] = {"clips": 32, "clip_samples": 16000, "steps_profiled": sf, "dispatches": nf, "fetch_kib": round(f / sf, 1), "write_kib": round(w / sw, 1),
-                               "date": datetime.date.today().isoformat(), "summary": summary}
+                               "date": datetime.date.today().isoformat(), "summary": summary, "fetch_correction": 2.0,
+                               "calibration": "profiles/r04_pmc_calibration.txt (and MI355X_MICROARCH.md: FETCH_SIZE reports half of a coalesced streaming read)"}
     json.dump(doc, open(out, "w"), indent=1)
-    print("# HBM bytes per step from the PMC passes (%s): FETCH %.1f GB + WRITE %.1f GB over %d dispatches / %d steps" % (prec, f / sf * 1024 / 1e9, w / sw * 1024 / 1e9, nf, sf))
+    print("# HBM bytes per step from the PMC passes (%s): 2 x FETCH_SIZE %.1f GB + WRITE_SIZE %.1f GB = %.1f GB over %d dispatches / %d steps (FETCH_SIZE counts half: profiles/r04_pmc_calibration.txt)" % (
+        prec, 2 * f / sf * 1024 / 1e9, w / sw * 1024 / 1e9, (2 * f / sf + w / sw) * 1024 / 1e9, nf, sf))
     for label, top, steps in (("FETCH_SIZE", topf, sf), ("WRITE_SIZE", topw, sw)):
         print("# largest by %s (GB per step):" % label)
         for k, v, c in top:
