@@ -33,7 +33,6 @@
 #include "wn_kernel_v3.h"
 
 #define WN_THREADS_V4 512
-#define WN_V4_MAX_STREAMS 4   // beyond that the one-layer-per-workgroup pipeline of variant 3 wins (more stages = more tokens in flight)
 
 template <int R_, int D_, int S_>
 struct WnV4Shape {

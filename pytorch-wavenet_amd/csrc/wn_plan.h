@@ -433,6 +433,9 @@ static inline int wn_pad_pick(const WnShapeRow* rows, int n_rows, int R, int D, 
     return pick;
 }
 
+// ---- variant 4 (wn_kernel_v4.h): streams up to which the stacked chain of n_stack workgroups beats variant 3's longer pipeline
+static inline int wn_v4_stream_limit(int n_stack) { const int n = (n_stack + 2) / 2; return n < 1 ? 1 : n; }
+
 // ---- time geometry of WaveNetModel.forward() (wn_forward / wn_train_*; comment: wn_runtime.hip above wn_forward_geometry)
 struct WnFwdGeom { std::vector<long long> a, rows, zlo; };
 // dil[l] = dilation of layer l.  Returns "" and fills g, or the reason why the reference has no defined result for clips of L samples.

@@ -390,13 +390,17 @@ static bool wn_v4_applicable(const wn_config* cfg, int n_cu, int* out_vi, int* o
     if (force && (!strcmp(force, "generic") || !strcmp(force, "v3"))) return false;
     const bool forced = force && !strcmp(force, "v4");
     if (cfg->kernel_size != 2 || cfg->classes != 256 || cfg->layer_split > 0 || cfg->head_split > 0) return false;
-    if (cfg->n_streams < 1 || (cfg->n_streams > WN_V4_MAX_STREAMS && !(forced && cfg->n_streams <= 16))) return false;
+    if (cfg->n_streams < 1 || cfg->n_streams > 16) return false;
     const std::vector<WnV4Entry>& t = wn_v4_table();
     for (size_t i = 0; i < t.size(); ++i) {
         const WnV4Entry& e = t[i];
         if (e.R != cfg->residual_channels || e.D != cfg->dilation_channels || e.S != cfg->skip_channels || cfg->end_channels % e.EC) continue;
         const int PA = cfg->end_channels / e.EC, NL = cfg->layers * cfg->blocks, n_stack = (NL + e.LPW - 1) / e.LPW;
         if (PA > 16) continue;
+        // The stacked chain is a short pipeline (n_stack + 2 stages, each busy ~3 us per item): it saturates at about half a token per stage,
+        // beyond that the one-layer-per-workgroup pipeline of variant 3 wins (measured, profiles/r04_v4_vs_v3_streams.txt: cfg2 -- 10 stack
+        // workgroups -- up to 6 streams, cfg1 -- 2 -- up to 2, the train_script shape -- 15 -- up to 8).
+        if (!forced && cfg->n_streams > wn_v4_stream_limit(n_stack)) continue;
         const int n_smp = wn_sampler_count(cfg->n_streams);
         if (n_stack + PA + n_smp > n_cu) continue;
         if (e.lds_floats(cfg->n_streams) * 4 > WN_LDS_MAX_BYTES) continue;

@@ -40,7 +40,9 @@ def _expected_variant(cfg, ns, layer_split=0):
     cfg = synth.CONFIGS[cfg] if isinstance(cfg, str) else cfg
     shape = (cfg["residual_channels"], cfg["dilation_channels"], cfg["skip_channels"], cfg["end_channels"])
     on3 = shape in ((128, 128, 512, 256), (64, 64, 256, 256), (32, 32, 256, 256), (32, 32, 1024, 512), (16, 16, 256, 32), (16, 32, 256, 64))
-    on4 = shape in ((64, 64, 256, 256), (32, 32, 256, 256), (32, 32, 1024, 512)) and ns <= 4 and not layer_split
+    lpw = {(64, 64, 256, 256): 3, (32, 32, 256, 256): 5, (32, 32, 1024, 512): 2}.get(shape)
+    n_stack = -(-cfg["layers"] * cfg["blocks"] // lpw) if lpw else 0
+    on4 = lpw is not None and ns <= max(1, (n_stack + 2) // 2) and not layer_split   # csrc/wn_plan.h: wn_v4_stream_limit
     pin = os.environ.get("WN_KERNEL")
     if pin == "generic":
         return 1
@@ -458,11 +460,11 @@ def test_wave_specialised_kernel(label, cfg, ns, N, n_given, monkeypatch):
 # ---------------------------------------------------------------- stacked kernel (csrc/wn_kernel_v4.h): several layers per workgroup
 CHAC = "chaconne"
 V4 = [("cfg2_ns1", "cfg2", 1, 120, 700, None), ("cfg2_ns3", "cfg2", 3, 80, 20, None), ("cfg2_ns4_bias", dict(synth.CONFIGS["cfg2"], bias=True), 4, 60, 9, None),
-      ("cfg1_ns1_bias", dict(synth.CONFIGS["cfg1"], bias=True), 1, 200, 70, None), ("cfg1_ns4", "cfg1", 4, 150, 40, None),
+      ("cfg1_ns1_bias", dict(synth.CONFIGS["cfg1"], bias=True), 1, 200, 70, None), ("cfg1_ns2", "cfg1", 2, 150, 40, None), ("cfg1_ns4_forced", "cfg1", 4, 150, 40, "v4"),
       ("chaconne_ns1", CHAC, 1, 100, 600, None), ("chaconne_ns2", CHAC, 2, 80, 30, None),
       ("cfg2_8_layers", dict(synth.CONFIGS["cfg2"], layers=4, blocks=2), 2, 150, 20, None),      # 3 + 3 + 2 layers: a last workgroup that is not full
       ("cfg1_7_layers", dict(synth.CONFIGS["cfg1"], layers=7, blocks=1), 1, 200, 140, None),     # 5 + 2
-      ("cfg1_1_layer", dict(synth.CONFIGS["cfg1"], layers=1, blocks=1), 2, 100, 5, None),         # the network's last layer is the first
+      ("cfg1_1_layer", dict(synth.CONFIGS["cfg1"], layers=1, blocks=1), 2, 100, 5, "v4"),         # the network's last layer is the first
       ("cfg2_ns8_forced", "cfg2", 8, 60, 12, "v4")]                                                # beyond the planner's stream limit (WN_KERNEL=v4)
 
 
@@ -475,7 +477,7 @@ def test_stacked_kernel(label, cfg, ns, N, n_given, pin, monkeypatch):
     cfg, W, first, uniforms = make_case(cfg, 84, ns, n_given, N)
     eng = engine.Engine(cfg, W, n_streams=ns)
     info = eng.info()
-    assert info["kernel_variant"] == 4 and info["layers_per_workgroup"] >= 2 and info["n_chains"] == 1, info
+    assert info["kernel_variant"] == 4 and info["layers_per_workgroup"] >= 2 and info["n_chains"] == 1, info   # (the planner's own choice unless pinned)
     ids, logits = eng.generate(N, first, temperature=0.0, want_logits=True, batched_prime=False, timeout_ms=8000)
     for s in range(ns):
         o_idx, o_log = c_oracle.generate(cfg, W, N, first[s], 0.0, 0.0)

@@ -51,6 +51,7 @@ int main(int argc, char** argv) {
         printf("%d %d %d %d %d\n", pick, out[0], out[1], out[2], out[3]);
         return 0;
     }
+    if (argc >= 2 && argv[1][0] == 'v') { printf("%d\n", wn_v4_stream_limit(atoi(argv[2]))); return 0; }   // v <n_stack>: stream limit of the stacked kernel
     if (argc >= 2 && argv[1][0] == 'f') {  // f <layers> <blocks> <L> <out_len>: time geometry of forward() (a | rows | zlo), or the refusal
         const int layers = atoi(argv[2]), blocks = atoi(argv[3]);
         std::vector<int32_t> dil;
@@ -262,3 +263,9 @@ def test_forward_geometry_agrees_with_the_live_reference(harness):
             except Exception:   # noqa: BLE001 -- whatever the reference raises there
                 ok = False
             assert (_geometry(harness, layers, blocks, L, out_len) is not None) == ok, (layers, blocks, out_len, N, L, ok)
+
+
+def test_stream_limit_of_the_stacked_kernel(harness):
+    """wn_v4_stream_limit: up to how many streams variant 4's short pipeline beats variant 3's (measured on MI355X, profiles/r04_v4_vs_v3_streams.txt)."""
+    lim = lambda n: int(subprocess.check_output([harness, "v", str(n)]).decode())
+    assert lim(10) == 6 and lim(2) == 2 and lim(15) == 8 and lim(1) == 1 and lim(0) == 1

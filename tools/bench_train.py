@@ -51,6 +51,12 @@ def main():
         for _ in range(2):
             loss = step()
         torch.cuda.synchronize()
+        if "--enqueue-time" in sys.argv:   # host time to ENQUEUE one step (every call returns before the GPU work is done): what a hipGraph could save at most
+            t0 = time.perf_counter()
+            loss = step()
+            host_ms = (time.perf_counter() - t0) * 1e3
+            torch.cuda.synchronize()
+            print("%s: host time to enqueue one step %.2f ms" % (label, host_ms))
         t0 = time.perf_counter()
         for _ in range(reps):
             loss = step()
