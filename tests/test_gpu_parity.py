@@ -614,6 +614,7 @@ def test_wave_specialised_kernel_throughput_forms(label, cfg, ns, N, n_given, mo
     priming through the chain, an odd stream count (bit 0 must fall back to one stream per item), bias; against the oracle on
     streams of both parities."""
     monkeypatch.setenv("WN_V3_MODE", str(mode))
+    monkeypatch.setenv("WN_KERNEL", "v3")   # (cfg2 at 6 streams would otherwise take the stacked kernel)
     cfg, W, first, uniforms = make_case(cfg, 83 + mode, ns, n_given, N)
     eng = engine.Engine(cfg, W, n_streams=ns)
     info = eng.info()
