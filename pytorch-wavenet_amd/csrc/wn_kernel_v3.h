@@ -1347,8 +1347,8 @@ static __device__ __forceinline__ int wn_sample_1w(const WnRun& r, const float (
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         x[k] = logit[k];
-        if (r.reg) x[k] -= r.reg[4 * lane + k];
-        if (!greedy) x[k] = x[k] / temperature;
+        if (r.reg) x[k] -= r.reg[4 * lane + k];   // (rare option, loaded behind the logits: four more registers live across the poll cost the kernel a stack slot)
+        if (!greedy && temperature != 1.0f) x[k] = x[k] / temperature;   // (x / 1 == x exactly: the four divisions are ~40 instructions of the ring)
     }
     const float gm = wn_wave_max(fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3])));
     if (greedy) {  // first index of the maximum (torch.max semantics)
@@ -1437,17 +1437,50 @@ static __device__ __forceinline__ void wn_poll_logits(WnCtx& cx, __amdgpu_buffer
     }
 }
 
+// Wide form of the sampler's wait (WIDE: all 256 threads of the workgroup, thread c = class c): the N partial logits of class c from
+// the head slices h0 .. h0 + N - 1, one 8-byte granule each, re-requested together until all carry the tag; added in the order h0, h0 + 1, ...
+template <int N>
+static __device__ __forceinline__ void wn_poll_class(WnCtx& cx, __amdgpu_buffer_rsrc_t rs_gl, unsigned c8, int h0, int s, int ns, uint32_t tag, long long e, float& logit) {
+    if (cx.fail) return;
+    unsigned spins = 0;
+    for (;;) {
+        wn_v2i v[N];
+#pragma unroll
+        for (int j = 0; j < N; ++j) v[j] = __builtin_amdgcn_raw_buffer_load_b64(rs_gl, c8, (unsigned)((((size_t)(h0 + j) * ns + s) * 256) * 8), 16);  // sc1
+        unsigned stale = 0;
+#pragma unroll
+        for (int j = 0; j < N; ++j) stale |= (uint32_t)v[j].y ^ tag;
+        if (__builtin_amdgcn_ballot_w64(stale != 0u) == 0) {
+#pragma unroll
+            for (int j = 0; j < N; ++j) logit += __int_as_float(v[j].x);
+            return;
+        }
+        if ((++spins & 127u) == 0u) {
+            if (__hip_atomic_load(cx.p->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { cx.fail = 1; return; }
+            const long long now = (long long)wall_clock64();
+            if (spins == 128u) cx.t_start = now;
+            else if (now - cx.t_start > cx.r->timeout_ticks) { wn_give_up(cx, WN_W_LOGITS, e, s); return; }
+        }
+    }
+}
+
 // Sampler role (ONE wave: threads 0-63 of the workgroup; workgroup j of n_smp serves the streams s = j mod n_smp): turns the head's
 // partial logits of evaluation e-1 into the class index that enters evaluation e (teacher forced while priming) -- and then does
 // layer 0's start_conv itself: the row of start_conv^T for that class (+ bias) goes out as layer 0's input granules g0[s][R]
 // (tag e+1, 16-byte pairs), so that layer 0 consumes a ready vector like every other layer (wavenet_model.py:127, 300-302).
 // start_conv^T ([C][R] floats) is copied into the workgroup's LDS at start when it fits (p.start_in_lds: 128 KB at R = 128): the row
 // gather after the draw is an LDS read instead of a dependent L2 / HBM load.
-template <class SH>
-static __device__ void wn_v3_sampler(const WnPlan& p, const WnRun& r, WnCtx& cx, float* lds_smp, float* lds_tab, int j) {
+// WIDE (many head slices, a single stream's ring: 16 slices are 32 KB of granules per token -- one wave needs ~0.6 us per look at them):
+// the caller lets the workgroup's first FOUR waves in, thread c collects class c from every slice (8-byte loads, 16 in flight), the
+// sums meet in LDS (lds_lg, 256 floats) and wave 0 draws as in the one-wave form -- same sums in the same order, two LDS barriers more.
+template <class SH, bool WIDE = false>
+static __device__ void wn_v3_sampler(const WnPlan& p, const WnRun& r, WnCtx& cx, float* lds_smp, float* lds_tab, int j, float* lds_lg = nullptr) {
     constexpr int R = SH::R, NP = (R / 2 + 63) / 64;  // pairs of row elements per lane
+    constexpr int NT = WIDE ? 256 : 64;
     static_assert(R <= 256 && R % 4 == 0, "one start_conv row per sampler wave, copied as float4");
-    const int lane = threadIdx.x, ns = p.n_streams;  // (the caller lets only wave 0 in)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, ns = p.n_streams;  // (one-wave form: the caller lets only wave 0 in)
+    int* failflag = reinterpret_cast<int*>(lds_smp + 48);
+    if (WIDE && threadIdx.x == 0) *failflag = 0;
     const int mine = wn_xcc_id();
     if (lane == 0) __hip_atomic_store(p.xcc_tab + cx.w, (unsigned)(mine + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const bool local_i = p.allow_plain && wn_same_xcd(cx, mine, 0, p.P);  // the row feeds every slice of layer 0  (wave-uniform)
@@ -1456,7 +1489,7 @@ static __device__ void wn_v3_sampler(const WnPlan& p, const WnRun& r, WnCtx& cx,
     if (p.start_in_lds) {
         const float4* src = reinterpret_cast<const float4*>(p.start_t);
         float4* dst = reinterpret_cast<float4*>(lds_tab);
-        for (int i = lane; i < 256 * R / 4; i += 64) dst[i] = src[i];
+        for (int i = threadIdx.x; i < 256 * R / 4; i += NT) dst[i] = src[i];   // (WIDE: the per-item barriers order the copy before wave 0's first read)
         tab = lds_tab;
     }
     float bias0[NP][2];
@@ -1468,32 +1501,56 @@ static __device__ void wn_v3_sampler(const WnPlan& p, const WnRun& r, WnCtx& cx,
     }
     long long* park = reinterpret_cast<long long*>(lds_smp + 64);
     const unsigned lane32 = (unsigned)lane * 32;  // byte offset of the lane's four granules inside a slice's 256
+    if constexpr (WIDE) wn_lds_barrier();  // (the fail flag is initialised)
+    const int lane0 = (int)threadIdx.x >> 8;
     for (long long e = 1; e <= r.n_eval; ++e) {
         for (int s = j; s < ns; s += p.n_smp) {
             const long long item = (e - 1) * ns + s;  // stamps (diagnostics): 0 start of the wait, 1 logits complete, 2 row published
             wn_stamp(r, park, item, 0);
+            // what the draw needs besides the logits is requested BEFORE the wait for them: a global load behind the logits' arrival
+            // would sit on the ring (a single stream's timestep is 8 - 20 us, an HBM miss is half a microsecond of it)
+            // (+ lane0: 0 for every lane of this wave, unknown to the compiler -- vector loads into VGPRs; as scalar loads the values sit in
+            //  SGPRs across the poll, and the kernel's scalar registers are already spilling into VGPR lanes)
+            const long long g = e - r.n_given;
+            const float temp = r.stream_temps ? r.stream_temps[s + lane0] : r.temperature;
+            const bool greedy = r.greedy != 0 || !(temp > 0.f);
+            const double u = (g >= 0 && !greedy) ? r.uniforms[(size_t)s * r.num_samples + g + lane0] : 0.;
+            const int given = g < 0 ? r.first[(size_t)s * r.n_given + e + lane0] : 0;
             float logit[4] = {0.f, 0.f, 0.f, 0.f};
-            {   // the PA partial logits of the stream, summed in the order h = 0 .. PA-1
+            if constexpr (WIDE) {   // class threadIdx.x: the PA partial logits summed in the order h = 0 .. PA-1, then four classes per lane of wave 0
+                float mine1 = 0.f;
+                const unsigned c8 = threadIdx.x * 8;
+                int h = 0;
+                for (; p.PA - h >= 16; h += 16) wn_poll_class<16>(cx, rs_gl, c8, h, s, ns, (uint32_t)e, e, mine1);
+                if (p.PA - h >= 8) { wn_poll_class<8>(cx, rs_gl, c8, h, s, ns, (uint32_t)e, e, mine1); h += 8; }
+                if (p.PA - h >= 4) { wn_poll_class<4>(cx, rs_gl, c8, h, s, ns, (uint32_t)e, e, mine1); h += 4; }
+                if (p.PA - h >= 2) { wn_poll_class<2>(cx, rs_gl, c8, h, s, ns, (uint32_t)e, e, mine1); h += 2; }
+                if (p.PA - h >= 1) wn_poll_class<1>(cx, rs_gl, c8, h, s, ns, (uint32_t)e, e, mine1);
+                lds_lg[threadIdx.x] = mine1;
+                if (wn_barrier_failed(cx, failflag)) return;
+                if (wave == 0) {
+                    const float4 v = reinterpret_cast<const float4*>(lds_lg)[lane];
+                    logit[0] = v.x; logit[1] = v.y; logit[2] = v.z; logit[3] = v.w;
+                }
+                wn_lds_barrier();   // (lds_lg is free for the next item)
+                if (wave != 0) continue;
+            } else {   // the PA partial logits of the stream, summed in the order h = 0 .. PA-1
                 int h = 0;
                 for (; p.PA - h >= 8; h += 8) wn_poll_logits<8>(cx, rs_gl, lane32, h, s, ns, (uint32_t)e, e, logit);
                 if (p.PA - h >= 4) { wn_poll_logits<4>(cx, rs_gl, lane32, h, s, ns, (uint32_t)e, e, logit); h += 4; }
                 if (p.PA - h >= 2) { wn_poll_logits<2>(cx, rs_gl, lane32, h, s, ns, (uint32_t)e, e, logit); h += 2; }
                 if (p.PA - h >= 1) wn_poll_logits<1>(cx, rs_gl, lane32, h, s, ns, (uint32_t)e, e, logit);
+                if (cx.fail) return;
             }
-            if (cx.fail) return;
             wn_stamp(r, park, item, 1);
             int idx;
-            if (e < r.n_given) {
-                idx = r.first[(size_t)s * r.n_given + e];
+            if (g < 0) {
+                idx = given;
             } else {
-                const long long g = e - r.n_given;
                 if (r.dbg_logits) {
 #pragma unroll
                     for (int k = 0; k < 4; ++k) r.dbg_logits[((size_t)s * r.num_samples + g) * 256 + 4 * lane + k] = logit[k];
                 }
-                const float temp = r.stream_temps ? r.stream_temps[s] : r.temperature;
-                const bool greedy = r.greedy != 0 || !(temp > 0.f);
-                const double u = greedy ? 0. : r.uniforms[(size_t)s * r.num_samples + g];
                 idx = wn_sample_1w(r, logit, lane, u, greedy, temp);
                 if (lane == 0) r.out_idx[(size_t)s * r.num_samples + g] = idx;
             }

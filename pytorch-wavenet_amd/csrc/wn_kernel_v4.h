@@ -409,8 +409,10 @@ __global__ __launch_bounds__(WN_THREADS_V4) void wn_generate_kernel_v4(WnPlan p,
         wn_v4_stack<V, LPW>(p, r, cx, wn_lds4, w);
         return;
     }
-    if (threadIdx.x >= WN_THREADS) return;  // the head role is a 256-thread role, the sampler role a one-wave role
+    if (threadIdx.x >= WN_THREADS) return;  // the head role is a 256-thread role, the sampler role a one-wave (or, collecting many head slices, four-wave) role
     if (w < p.n_lw + p.PA * p.HR) wn_v3_head<SH, 1>(p, r, cx, wn_lds4, w - p.n_lw);
+    else if (p.PA >= 8)   // many head slices: the sampler collects them with four waves (the head's staging area is free in this workgroup)
+        wn_v3_sampler<SH, true>(p, r, cx, wn_lds4 + WnV3Lds<SH, 1>::smp, wn_lds4 + WnV3Lds<SH, 1>::pre, w - p.n_lw - p.PA * p.HR, wn_lds4 + WnV3Lds<SH, 1>::sk);
     else if (threadIdx.x < 64) wn_v3_sampler<SH>(p, r, cx, wn_lds4 + WnV3Lds<SH, 1>::smp, wn_lds4 + WnV3Lds<SH, 1>::pre, w - p.n_lw - p.PA * p.HR);
 }
 
