@@ -54,6 +54,9 @@
 #endif
 #define WN_V3_MIN_STREAMS 1
 #define WN_V3_TAP_AHEAD 6
+#ifndef WN_V3_WIDE_SAMPLER
+#define WN_V3_WIDE_SAMPLER 0  // experiment: head slices from which the samplers of variant 3 collect the logits with four waves (0 = never)
+#endif
 #define WN_V3_COMPILER_VGPRS 152  // v152-v167: request sets of the input poll / the queue group's tap FIFO (see wn_ap_*, wn_q_*)
 // ---- experiment switches.  A product build (build.py) leaves every one of them at its default; setting one requires -DWN_EXPERIMENT,
 // which build.py never passes (tools/ builds the A/B variants): a library with wrong-on-purpose timing ablations cannot ship by accident.
@@ -1594,6 +1597,10 @@ void wn_generate_kernel_v3m(WnPlan p, WnRun r) {
     }
     if (threadIdx.x >= WN_THREADS) return;  // the head role is a 256-thread role, the sampler role a one-wave role
     if (w < n_layer_wg + p.PA * p.HR) wn_v3_head<SH, P>(p, r, cx, wn_lds3m, w - n_layer_wg);
+#if WN_V3_WIDE_SAMPLER
+    else if (p.PA >= WN_V3_WIDE_SAMPLER)
+        wn_v3_sampler<SH, true>(p, r, cx, wn_lds3m + WnV3Lds<SH, 1>::smp, wn_lds3m + WnV3Lds<SH, 1>::pre, w - n_layer_wg - p.PA * p.HR, wn_lds3m + WnV3Lds<SH, 1>::sk);
+#endif
     else if (threadIdx.x < 64) wn_v3_sampler<SH>(p, r, cx, wn_lds3m + WnV3Lds<SH, 1>::smp, wn_lds3m + WnV3Lds<SH, 1>::pre, w - n_layer_wg - p.PA * p.HR);
 }
 
