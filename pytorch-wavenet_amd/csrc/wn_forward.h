@@ -75,6 +75,9 @@ struct WnGemmArgs {
     // count their strides in bf16 elements.
     int a_bf16;           // A (both views) is stored as bf16: staged into LDS as it is          (wn_fwd_gemm_bf16<*, *, true>)
     int c_bf16;           // WN_EPI_GATE_BWD: c receives bf16 (round to nearest even); WN_EPI_GATE: c and c2 do
+    unsigned short* c_h;  // WN_EPI_PLAIN: optional bf16 COPY of the output (round to nearest even), laid out like c (same strides, in elements):
+                          // the bf16 training step's shadow of the residual stream -- every matrix operand read of x takes half the bytes,
+                          // with the bits the fp32-stored operand would be rounded to on its way to LDS
 };
 static __device__ __forceinline__ const float* wn_row_at(const WnRowMap& r, unsigned q, unsigned rem) {
     return r.base + (long long)q * r.batch_stride + (r.t0 + (long long)rem) * r.row_stride;
@@ -321,6 +324,7 @@ static __device__ __forceinline__ void wn_gemm_epilogue(const WnGemmArgs& g, con
                     if (!(mk.w > 0.f)) v.w = 0.f;
                 }
                 *reinterpret_cast<float4*>(crow + n) = v;
+                if (g.c_h) *reinterpret_cast<uint2*>(g.c_h + (crow - g.c.base) + n) = wn_pack_bf16x4(v);
             }
         }
     }
@@ -588,7 +592,7 @@ __global__ void wn_cvt_bf16_transposed(const float* in, long long in_batch_strid
 }
 
 // x0[(n,t)][r] = start_conv.weight[r][idx[n][t]] (+ bias): the one-hot input makes start_conv a column gather (wavenet_model.py:127)
-__global__ void wn_fwd_start(const int32_t* idx, const float* start_t, const float* start_b, float* x, long long rows, int R) {
+__global__ void wn_fwd_start(const int32_t* idx, const float* start_t, const float* start_b, float* x, long long rows, int R, unsigned short* xh = nullptr) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long row = i / (R / 4);
     const int q = (int)(i % (R / 4));
@@ -596,6 +600,7 @@ __global__ void wn_fwd_start(const int32_t* idx, const float* start_t, const flo
     float4 v = *reinterpret_cast<const float4*>(start_t + (size_t)idx[row] * R + q * 4);
     if (start_b) { v.x += start_b[q * 4]; v.y += start_b[q * 4 + 1]; v.z += start_b[q * 4 + 2]; v.w += start_b[q * 4 + 3]; }
     *reinterpret_cast<float4*>(x + row * R + q * 4) = v;
+    if (xh) *reinterpret_cast<uint2*>(xh + row * R + q * 4) = wn_pack_bf16x4(v);   // (the bf16 step's shadow of x, see WnGemmArgs::c_h)
 }
 
 
@@ -622,9 +627,9 @@ struct WnGemmTnArgs {
                            // b_bf16: B is STORED as bf16 (its base points at unsigned short, its strides count bf16 elements): the bf16
                            // step's [dF|dG] and z.  wn_bwd_gemm_tn_bf16<*, true> only.
     int c_trans, a_bf16;   // c_trans: C is stored transposed, element (ka, nb) at c[nb * ldc + ka] (operands swapped by the caller so that the
-                           // bf16-stored one is B);  a_bf16: A is stored as bf16 (excludes ka_split, relu_a, a_idx)
+                           // bf16-stored one is B);  a_bf16: A is stored as bf16 (excludes relu_a, a_idx)
     int a_skip_lo;         // row window of view `a` (not a1): it reads as ZERO on the first a_skip_lo rows of every batch entry (their addresses are
-};                         // never formed into loads) -- the tap x(t - d) where the reference's left zero padding stands in for it (fp32-stored A only)
+};                         // never formed into loads) -- the tap x(t - d) where the reference's left zero padding stands in for it
 
 __global__ __launch_bounds__(256, WN_GEMM_MINB) void wn_bwd_gemm_tn(WnGemmTnArgs g) {
     constexpr int T = 128, KC = WN_GEMM_KC, NQ = KC / 8, LT = 256 / KC;  // NQ float4 per thread per operand, LT threads per row
@@ -766,7 +771,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? WN_TN_BF16_MINB : 4) void 
     const int role = tid >> 7;                    // 0: A;  1 ..: B columns 128 (role - 1) ..
     const bool is_b = role >= 1, loads = role <= TB / 128;
     const int u = tid & 127, mg = u >> 5, cg = u & 31;
-    const bool second = !A16 && g.ka_split > 0 && ka0 >= g.ka_split;
+    const bool second = g.ka_split > 0 && ka0 >= g.ka_split;
     const WnRowMap& rm = is_b ? g.b : (second ? g.a1 : g.a);
     const int lcol = is_b ? 128 * (role - 1) + 4 * cg : 4 * cg;   // column inside the tile
     const int col0 = (is_b ? nb0 : ka0) + lcol, ncols = is_b ? g.Nb : g.Ka;
@@ -775,7 +780,8 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? WN_TN_BF16_MINB : 4) void 
     const bool relu = !is_b && g.relu_a;
     float4 v[8];
     // bf16-stored operand `map` (g.a or g.b named directly: its fields stay scalar), tile origin `org`, PPR pieces per row, loader thread lt
-    auto fetch16 = [&](const WnRowMap& map, int org, int ncols16, auto pprc, int lt, long long mc) {
+    // win_lo: rows whose index inside the batch entry is below it read as ZERO (never loaded)
+    auto fetch16 = [&](const WnRowMap& map, int org, int ncols16, auto pprc, int lt, long long mc, int win_lo = 0) {
         constexpr int PPR = decltype(pprc)::value;
         const int row16 = lt / PPR, piece16 = lt % PPR;
         const bool ok16 = org + 8 * piece16 < ncols16;
@@ -785,7 +791,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? WN_TN_BF16_MINB : 4) void 
         const unsigned short* ptr = base16 + (long long)q * map.batch_stride + (map.t0 + (long long)rem) * map.row_stride + org + 8 * piece16;
 #pragma unroll
         for (int qq = 0; qq < 4; ++qq) {
-            v[qq] = (ok16 && m + 8 * qq < m_end) ? *reinterpret_cast<const float4*>(ptr) : make_float4(0.f, 0.f, 0.f, 0.f);   // 8 bf16, moved as bits
+            v[qq] = (ok16 && m + 8 * qq < m_end && (int)rem >= win_lo) ? *reinterpret_cast<const float4*>(ptr) : make_float4(0.f, 0.f, 0.f, 0.f);   // 8 bf16, moved as bits
             rem += 8;
             if (rem >= (unsigned)g.rows_per_batch) {   // the row 8 further down is in a later batch entry
                 do { rem -= (unsigned)g.rows_per_batch; ++q; } while (rem >= (unsigned)g.rows_per_batch);
@@ -803,7 +809,11 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? WN_TN_BF16_MINB : 4) void 
     };
     auto fetch = [&](long long mc) {
         if (B16 && is_b) { if (loads) fetch16(g.b, nb0, g.Nb, std::integral_constant<int, TB / 8>{}, tid - 128, mc); return; }
-        if (A16 && !is_b) { fetch16(g.a, ka0, g.Ka, std::integral_constant<int, T / 8>{}, tid, mc); return; }
+        if (A16 && !is_b) {   // (the two tap views of the filter/gate weight gradient: block-uniform choice, the maps' fields stay scalar)
+            if (second) fetch16(g.a1, ka0 - g.ka_split, g.Ka - g.ka_split, std::integral_constant<int, T / 8>{}, tid, mc);
+            else fetch16(g.a, ka0, g.ka_split > 0 ? g.ka_split : g.Ka, std::integral_constant<int, T / 8>{}, tid, mc, g.a_skip_lo);
+            return;
+        }
         long long m = mc + mg * 8;
         unsigned q = (unsigned)m / (unsigned)g.rows_per_batch, rem = (unsigned)m - q * (unsigned)g.rows_per_batch;
         const float* ptr = rm.base + (long long)q * rm.batch_stride + (rm.t0 + (long long)rem) * rm.row_stride + pcol0;

@@ -50,11 +50,12 @@ static void wn_launch_nn(hipStream_t st, int epi, const WnGemmArgs& a, const uns
         WnGemmArgsBf16 b;
         b.g = a; b.bn = bn; b.bn1 = bn1; b.ldb = ldb;
         if (wide) {
-            if (epi == WN_EPI_GATE) hipLaunchKernelGGL((wn_fwd_gemm_bf16<WN_EPI_GATE, 8>), grid, dim3(512), 0, st, b);
+            if (epi == WN_EPI_GATE && a.a_bf16) hipLaunchKernelGGL((wn_fwd_gemm_bf16<WN_EPI_GATE, 8, true>), grid, dim3(512), 0, st, b);   // (bf16-stored A: the shadow of x)
+            else if (epi == WN_EPI_GATE) hipLaunchKernelGGL((wn_fwd_gemm_bf16<WN_EPI_GATE, 8>), grid, dim3(512), 0, st, b);
             else if (a.a_bf16) hipLaunchKernelGGL((wn_fwd_gemm_bf16<WN_EPI_PLAIN, 8, true>), grid, dim3(512), 0, st, b);   // (bf16-stored A: the grouped skip product)
             else hipLaunchKernelGGL((wn_fwd_gemm_bf16<WN_EPI_PLAIN, 8>), grid, dim3(512), 0, st, b);
         } else {
-            if (epi == WN_EPI_GATE) hipLaunchKernelGGL((wn_fwd_gemm_bf16<WN_EPI_GATE, 4>), grid, dim3(256), 0, st, b);
+            if (epi == WN_EPI_GATE) hipLaunchKernelGGL((wn_fwd_gemm_bf16<WN_EPI_GATE, 4>), grid, dim3(256), 0, st, b);   // (never with a bf16-stored A: wn_train_layout_ws)
             else if (epi == WN_EPI_GATE_BWD) hipLaunchKernelGGL((wn_fwd_gemm_bf16<WN_EPI_GATE_BWD, 4>), grid, dim3(256), 0, st, b);
             else if (a.a_bf16) hipLaunchKernelGGL((wn_fwd_gemm_bf16<WN_EPI_PLAIN, 4, true>), grid, dim3(256), 0, st, b);   // (bf16-stored A: the residual and dx products)
             else hipLaunchKernelGGL((wn_fwd_gemm_bf16<WN_EPI_PLAIN, 4>), grid, dim3(256), 0, st, b);
@@ -417,6 +418,7 @@ struct WnTrainLay {
     std::vector<long long> need;          // need[l] = trailing time steps of layer l's input the loss depends on (and that exist: wn_forward_geometry)
     std::vector<long long> zlo;           // zlo[l] = leading output rows of layer l whose tap x(t - d) is one of the reference's pad zeros
     std::vector<size_t> x, z, th, sg;     // per layer offsets (floats) into the training workspace
+    std::vector<size_t> xh;               // bf16 step: the bf16 shadow of x[l] (same shape; offsets in floats, N * L * R / 2 floats each); empty otherwise
     size_t skip, ev, zg, dzg, bskip_total, res_o, skip_o, w1_o, w2_o, fgb0, fgb1, dskip, de, dz, dfg, dfg2, dxa, dxb, colsum_tmp, idx, total;
     size_t bw, bt_fg, bt_res, bt_skip, bt_w1, bt_w2;  // bf16 operand banks (offsets in floats)
     int G, nblk;  // layers per skip block, blocks

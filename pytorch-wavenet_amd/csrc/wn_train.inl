@@ -40,6 +40,16 @@ static int wn_train_layout_ws(const wn_handle* h, long long N, long long L, long
         t.x[l] = take((size_t)N * L * R);
         t.z[l] = take(zl); t.th[l] = take(zl); t.sg[l] = take(zl);
     }
+    // The bf16 step keeps a bf16 SHADOW of the residual stream next to the fp32 one.  x_l is a matrix operand four times per step (the
+    // two tap views of the filter/gate product and of its weight gradient) and an addend once (the residual); the operand reads convert
+    // it to bf16 on their way to LDS anyway.  Written once by the product that produces x_l (WnGemmArgs::c_h), the shadow gives those
+    // four reads the same bits at half the bytes: +0.13 GB written, -0.5 GB read per layer at config 5.  The fp32 stream stays what the
+    // residual adds run on.
+    t.xh.clear();
+    if (h->fw_bf16 && h->fwb_ok && R % 128 == 0 && (2 * D) % 256 == 0) {   // (the shapes whose filter/gate products take the 256-column tiles: the forms compiled for a bf16-stored x)
+        t.xh.resize(NL);
+        for (int l = 0; l < NL; ++l) t.xh[l] = take(((size_t)N * L * R + 1) / 2);
+    }
     const size_t Mo = (size_t)N * out_len;
     t.skip = take(Mo * S); t.ev = take(Mo * E); t.nblk = (NL + t.G - 1) / t.G; t.zg = take((size_t)t.nblk * Mo * t.G * D); t.dzg = take((size_t)t.nblk * Mo * t.G * D); t.bskip_total = take(S);
     t.res_o = take((size_t)NL * R * D); t.skip_o = take((size_t)NL * S * D); t.w1_o = take((size_t)E * S); t.w2_o = take((size_t)C * E);
@@ -93,13 +103,15 @@ static void wn_launch_cvt_t(hipStream_t st, const float* in, long long in_batch_
 #endif
 static void wn_launch_tn(hipStream_t st, WnGemmTnArgs a, bool bf16 = false) {
     // bf16 products with Nb % 256 == 0 take the 128 x 256 tile (A streamed once per 256 columns of B); rows split by wn_tn_grid (wn_plan.h)
-    const bool wide = bf16 && !a.a_idx && !a.a_bf16 && a.Nb % 256 == 0;
+    const bool wide16 = bf16 && !a.a_idx && a.a_bf16 && a.b_bf16 && a.ka_split > 0 && a.Nb % 256 == 0;   // (both operands stored as bf16: the filter/gate weight gradient on the shadow of x)
+    const bool wide = wide16 || (bf16 && !a.a_idx && !a.a_bf16 && a.Nb % 256 == 0);
     const WnTnGrid tg = wn_tn_grid(a.M, a.Ka, a.Nb, wide ? 256 : 128, wide ? 512 : 1024);
     a.rows_per_split = tg.rows_per_split;
     a.tiles_ka = tg.tiles_ka; a.n_splits = tg.splits;
     const dim3 grid(tg.blocks);   // wn_tile_of: the tiles of a row split share an XCD
     // (b_bf16 / a_bf16: that operand is stored as bf16 -- [dF|dG] in the filter/gate weight gradient, z in the residual and skip ones)
-    if (wide && a.b_bf16) hipLaunchKernelGGL((wn_bwd_gemm_tn_bf16<8, false, true>), grid, dim3(512), 0, st, a);
+    if (wide16) hipLaunchKernelGGL((wn_bwd_gemm_tn_bf16<8, true, true>), grid, dim3(512), 0, st, a);
+    else if (wide && a.b_bf16) hipLaunchKernelGGL((wn_bwd_gemm_tn_bf16<8, false, true>), grid, dim3(512), 0, st, a);
     else if (wide) hipLaunchKernelGGL((wn_bwd_gemm_tn_bf16<8, false, false>), grid, dim3(512), 0, st, a);
     else if (bf16 && !a.a_idx && a.b_bf16) hipLaunchKernelGGL((wn_bwd_gemm_tn_bf16<4, false, true>), grid, dim3(256), 0, st, a);
     else if (bf16 && !a.a_idx && a.a_bf16) hipLaunchKernelGGL((wn_bwd_gemm_tn_bf16<4, true, false>), grid, dim3(256), 0, st, a);
@@ -182,7 +194,8 @@ extern "C" int wn_train_forward(wn_handle* h, const float* params, const int32_t
     {
         const long long rows = N * L, work = rows * (R / 4);
         hipLaunchKernelGGL(wn_fwd_start, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, indices, fw + h->fw_off_start_t,
-                           pl.has_bias ? fw + h->fw_off_start_b : nullptr, ws + t.x[0], rows, R);
+                           pl.has_bias ? fw + h->fw_off_start_b : nullptr, ws + t.x[0], rows, R,
+                           (bf16 && !t.xh.empty()) ? reinterpret_cast<unsigned short*>(ws + t.xh[0]) : (unsigned short*)nullptr);
     }
     float* skip = ws + t.skip; float* ev = ws + t.ev;
     // The grouped skip product of a block (zg . [Wskip of its layers]: 1.2 ms at config 5) hangs off the layer chain -- the next block's
@@ -214,9 +227,12 @@ extern "C" int wn_train_forward(wn_handle* h, const float* params, const int32_t
         float* z = ws + t.z[l];
         WnGemmArgs a;
         memset(&a, 0, sizeof(a));
-        a.a0 = WnRowMap{xin, (long long)L * R, R, t0 - d};
+        const bool shadow = bf16 && !t.xh.empty();   // matrix operand reads of x take its bf16 shadow (wn_train_layout_ws)
+        const float* xop = shadow ? ws + t.xh[l] : xin;   // (a bf16 matrix behind a float pointer: the row maps count bf16 elements then)
+        a.a0 = WnRowMap{xop, (long long)L * R, R, t0 - d};
         a.a_skip_lo[0] = (int)t.zlo[l];   // (short clips: the reference's left zero padding stands in for x(t - d) on these rows)
-        a.a1 = WnRowMap{xin, (long long)L * R, R, t0};
+        a.a1 = WnRowMap{xop, (long long)L * R, R, t0};
+        a.a_bf16 = shadow ? 1 : 0;
         a.k_split = R; a.K = 2 * R; a.bt = fw + h->fw_off_fg + (size_t)l * 2 * R * 2 * D; a.N = 2 * D;
         a.bias = pl.has_bias ? fw + h->fw_off_bfg + (size_t)l * 2 * D : nullptr;
         a.c = WnRowMap{z, rows * D, D, 0};
@@ -235,6 +251,7 @@ extern "C" int wn_train_forward(wn_handle* h, const float* params, const int32_t
             a.bias = pl.has_bias ? fw + h->fw_off_bres + (size_t)l * R : nullptr;
             a.cin = WnRowMap{xin, (long long)L * R, R, t0};
             a.c = WnRowMap{ws + t.x[l + 1], (long long)L * R, R, t0};
+            if (shadow) a.c_h = reinterpret_cast<unsigned short*>(ws + t.xh[l + 1]);
             a.M = N * rows; a.rows_per_batch = (int)rows; a.a_bf16 = bf16 ? 1 : 0;
             wn_launch_nn(st, WN_EPI_PLAIN, a, bf16 ? bt_res + (size_t)l * R * D : nullptr);
         }
@@ -428,7 +445,10 @@ extern "C" int wn_train_backward(wn_handle* h, const float* params, const float*
         // dWfg^T [2R][2D]: rows 0..R-1 = x_l(t - d)^T . dfg (tap 0), rows R.. = x_l(t)^T . dfg (tap 1) -- one launch, the taps are two
         // row views of A (ka_split): the workgroups of the two taps run side by side and read the same rows of dfg.
         memset(&g, 0, sizeof(g));
-        g.a = WnRowMap{xin, L * (long long)R, R, t0 - d}; g.a1 = WnRowMap{xin, L * (long long)R, R, t0}; g.ka_split = R;
+        const bool shadow = t.bf16 && !t.xh.empty();   // (the bf16 shadow of x: both operands of this product are stored as bf16 then)
+        const float* xop = shadow ? ws + t.xh[l] : xin;
+        g.a = WnRowMap{xop, L * (long long)R, R, t0 - d}; g.a1 = WnRowMap{xop, L * (long long)R, R, t0}; g.ka_split = R;
+        g.a_bf16 = shadow ? 1 : 0;
         g.b = WnRowMap{dfg, rows * 2 * D, 2 * D, 0}; g.b_bf16 = t.bf16 ? 1 : 0;
         g.Ka = 2 * R; g.Nb = 2 * D; g.c = grads + h->fw_off_fg + (size_t)l * 2 * R * 2 * D; g.ldc = 2 * D;
         g.M = M; g.rows_per_batch = (int)rows;
