@@ -112,8 +112,11 @@ static __device__ __forceinline__ uint2 wn_pack_bf16x4(float4 a) { return make_u
 static __device__ __forceinline__ uint4 wn_pack_bf16x8(float4 a, float4 b) {
     return make_uint4(wn_pack_bf16(a.x, a.y), wn_pack_bf16(a.z, a.w), wn_pack_bf16(b.x, b.y), wn_pack_bf16(b.z, b.w));
 }
-template <int EPI>
-static __device__ __forceinline__ void wn_gemm_epilogue(const WnGemmArgs& g, const wn_f16v (&acc)[4], long long mw, int nw, int lane, float* stage) {
+// NTILES: accumulator tiles of the strip that exist (WN_EPI_PLAIN; 32 columns each).  zl (WN_EPI_GATE with c_bf16): the strip's rows of an
+// LDS image of z, [row][zld bf16] -- the fused layer kernel's operand for the residual product; g.c.base may then be NULL (z not stored).
+template <int EPI, int NTILES = 4>
+static __device__ __forceinline__ void wn_gemm_epilogue(const WnGemmArgs& g, const wn_f16v (&acc)[NTILES], long long mw, int nw, int lane, float* stage,
+                                                        unsigned short* zl = nullptr, int zld = 0) {
     const int col = lane & 31;
 #ifdef WN_EPI_TIMING_SKIP   // timing experiment (results wrong): one store per lane instead of the strip's epilogue
     if (acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3] == 12345.678f) const_cast<float*>(g.c.base)[lane] = 1.f;
@@ -124,7 +127,8 @@ static __device__ __forceinline__ void wn_gemm_epilogue(const WnGemmArgs& g, con
     const int r8 = lane >> 2, c8 = 8 * (lane & 3);
     // (q, rem) of row m: M < 2^31 (checked on the host): 32-bit division, a 64-bit one is ~100 instructions
     auto split = [&](long long m, unsigned& q, unsigned& rem) { q = (unsigned)m / (unsigned)g.rows_per_batch; rem = (unsigned)m - q * (unsigned)g.rows_per_batch; };
-    if (EPI == WN_EPI_GATE) {
+    static_assert(EPI == WN_EPI_PLAIN || NTILES == 4, "the gate epilogues take the whole 128-column strip");
+    if constexpr (EPI == WN_EPI_GATE && NTILES == 4) {
         const int NH = g.N >> 1;   // channels per row of z / the gate pair
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
@@ -153,8 +157,11 @@ static __device__ __forceinline__ void wn_gemm_epilogue(const WnGemmArgs& g, con
                     split(m, q, rem);
                     const float* sp = stage + row * WN_EPI_PITCH + c8;
                     const uint4 zb = wn_pack_bf16x8(*reinterpret_cast<const float4*>(sp), *reinterpret_cast<const float4*>(sp + 4));
-                    unsigned short* c16 = const_cast<unsigned short*>(reinterpret_cast<const unsigned short*>(g.c.base)) + (long long)q * g.c.batch_stride + (g.c.t0 + (long long)rem) * g.c.row_stride;
-                    *reinterpret_cast<uint4*>(c16 + zc0 + c8) = zb;
+                    if (zl) *reinterpret_cast<uint4*>(zl + row * zld + zc0 + c8) = zb;
+                    if (g.c.base) {
+                        unsigned short* c16 = const_cast<unsigned short*>(reinterpret_cast<const unsigned short*>(g.c.base)) + (long long)q * g.c.batch_stride + (g.c.t0 + (long long)rem) * g.c.row_stride;
+                        *reinterpret_cast<uint4*>(c16 + zc0 + c8) = zb;
+                    }
                     if (g.c2.base && (int)rem >= g.c2_first_row) {
                         unsigned short* d16 = const_cast<unsigned short*>(reinterpret_cast<const unsigned short*>(g.c2.base)) + (long long)q * g.c2.batch_stride +
                                               (g.c2.t0 + (long long)rem - g.c2_first_row) * g.c2.row_stride;
@@ -205,7 +212,7 @@ static __device__ __forceinline__ void wn_gemm_epilogue(const WnGemmArgs& g, con
                 }
             }
         }
-    } else if (EPI == WN_EPI_GATE_BWD) {
+    } else if constexpr (EPI == WN_EPI_GATE_BWD && NTILES == 4) {
         // The product is dz = dx' . Wres (N = D channels); the strip emits [dF | dG] = dz * {G (1 - T^2), T G (1 - G)} in the packed
         // [F(32) | G(32)] column order of Wfg^T (2N columns per row of c).  gate_t / gate_g are the forward's saved gates (INPUTS
         // here, row m, N columns; gate_packed as in the forward); c2 is the skip path's share of dz (READ here: rows >=
@@ -291,7 +298,7 @@ static __device__ __forceinline__ void wn_gemm_epilogue(const WnGemmArgs& g, con
         }
     } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < NTILES; ++j) {
             const int n0 = nw + 32 * j;
             if (n0 >= g.N) continue;   // (wave-uniform)
             float v16[16];
@@ -568,6 +575,160 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? WN_GEMM_BF16_MINB : 4) voi
         }
     }
     wn_gemm_epilogue<EPI>(g, acc, m0 + 32 * wr, n0 + 128 * wc, lane, reinterpret_cast<float*>(smem_h) + wv * WN_EPI_TILE_FLOATS);   // (after the loop's last barrier)
+}
+
+// ---- One layer of the forward in ONE kernel (bf16 operands; the shape whose filter/gate product is ONE 256-column tile: D = 128, and
+// R = 128): the filter/gate product of a 128-row tile (K = 2R over the two tap views of x), its gate epilogue -- z, the saved gates and
+// the copy on the skip rows go out as in wn_fwd_gemm_bf16<WN_EPI_GATE, 8> --, and then the residual product of the SAME rows on the z tile
+// where it lies: z (128 x 128 bf16) stays in LDS as the second product's A operand, Wres streams through LDS in four 32-column chunks,
+// x' = z . Wres^T + bias + x leaves through the plain epilogue.  Unfused, z makes a round trip through HBM between two launches
+// (0.13 GB per layer at config 5) and each launch pays its own tail (3250 workgroups = 3.2 rounds of the chip); the second product adds
+// ~20 % to the tile's MFMA work and nothing to its global reads but the addend.  Same operands, same chunk order, same accumulation as
+// the two kernels: the results are theirs bit for bit.  g.c.base == NULL: z itself is not stored (forward only: nothing reads it again).
+struct WnLayerArgs {
+    const unsigned short* bn;  // Wres as bf16 [R][D] row-major (K = D contiguous)
+    const float* bias;         // [R] or NULL
+    WnRowMap cin, c;           // the addend x_l and the output x_{l+1}: rows of R floats, row index as in the gate product
+    unsigned short* c_h;       // optional bf16 copy of the output (WnGemmArgs::c_h)
+    int N;                     // R
+};
+template <bool A16>
+__global__ __launch_bounds__(512, 4) void wn_fwd_layer_bf16(WnGemmArgsBf16 ga, WnLayerArgs la) {
+    const WnGemmArgs& g = ga.g;
+    constexpr int NT = 512, TM = 128, TN = 256, KC = WN_GEMM_BF16_KC, LD = KC + 8;
+    constexpr int TPR = NT / TM, HK = KC / TPR, HB = KC / 2;
+    constexpr int D2 = 128, N2 = 128, LD2 = D2 + 8;   // the second product: K = D2 channels of z, N2 = R output columns
+    static_assert(KC == 32 && HK % 8 == 0 && HB % 8 == 0, "loader pieces are 16-byte LDS stores");
+    constexpr int STAGE_SHORTS = 8 * WN_EPI_TILE_FLOATS * 2;            // the eight waves' epilogue tiles (fp32) at the start of the block
+    constexpr int OPER_SHORTS = 2 * TM * LD + 2 * TN * LD;              // the first product's operand buffers (same place)
+    constexpr int ZOFF = STAGE_SHORTS;   // the z image [128][LD2] bf16 sits behind the staging tiles, over the (by then dead) operand buffers
+    static_assert(2 * N2 * LD <= STAGE_SHORTS, "the second product's B chunks live where the staging tiles are");
+    constexpr int SMEM_SHORTS = ZOFF + TM * LD2 > OPER_SHORTS ? ZOFF + TM * LD2 : OPER_SHORTS;   // 71 680 bytes: two workgroups per CU
+    __shared__ __attribute__((aligned(16))) unsigned short smem_h[SMEM_SHORTS];
+    unsigned short (*a_s)[TM * LD] = reinterpret_cast<unsigned short (*)[TM * LD]>(smem_h);
+    unsigned short (*b_s)[TN * LD] = reinterpret_cast<unsigned short (*)[TN * LD]>(smem_h + 2 * TM * LD);
+    unsigned short* z_s = smem_h + ZOFF;
+    unsigned short (*b2_s)[N2 * LD] = reinterpret_cast<unsigned short (*)[N2 * LD]>(smem_h);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wr = wv & 3, wc = wv >> 2;
+    const long long m0 = (long long)blockIdx.x * TM;
+    wn_f16v acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
+    {   // ---- first product: wn_fwd_gemm_bf16<WN_EPI_GATE, 8, A16> with ONE column tile (n0 = 0)
+        const int lrow = tid / TPR, lpart = tid % TPR;
+        const long long am = m0 + lrow;
+        const bool arow_ok = am < g.M;
+        const unsigned aq = arow_ok ? (unsigned)am / (unsigned)g.rows_per_batch : 0u, arem = arow_ok ? (unsigned)am - aq * (unsigned)g.rows_per_batch : 0u;
+        const bool ok0 = arow_ok && (int)arem >= g.a_skip_lo[0] && (int)arem < g.rows_per_batch - g.a_skip_hi[0];
+        const bool ok1 = arow_ok && (int)arem >= g.a_skip_lo[1] && (int)arem < g.rows_per_batch - g.a_skip_hi[1];
+        const float* a0p = A16 ? reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(g.a0.base) + (long long)aq * g.a0.batch_stride + (g.a0.t0 + (long long)arem) * g.a0.row_stride + lpart * HK)
+                               : wn_row_at(g.a0, aq, arem) + lpart * HK;
+        const float* a1p = A16 ? reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(g.a1.base) + (long long)aq * g.a1.batch_stride + (g.a1.t0 + (long long)arem) * g.a1.row_stride + lpart * HK)
+                               : wn_row_at(g.a1, aq, arem) + lpart * HK;
+        const int bcol = tid >> 1, bhalf = tid & 1;
+        const bool bcol_ok = bcol < g.N;
+        const int ldb = ga.ldb ? ga.ldb : g.K;
+        const unsigned short* bp0 = ga.bn + (size_t)bcol * ldb + bhalf * HB;
+        const unsigned short* bp1 = ga.bn1 ? ga.bn1 + (size_t)bcol * ldb + bhalf * HB : bp0 + g.k_split;
+        float4 va[HK / 4];
+        uint4 vb[HB / 8];
+        auto fetch = [&](int kc) {
+            const int k0 = kc * KC;
+            const bool first = k0 < g.k_split, ok = first ? ok0 : ok1;
+            if constexpr (A16) {
+                const unsigned short* src = reinterpret_cast<const unsigned short*>(first ? a0p : a1p) + (first ? k0 : k0 - g.k_split);
+#pragma unroll
+                for (int q = 0; q < HK / 8; ++q) va[q] = ok ? *reinterpret_cast<const float4*>(src + q * 8) : make_float4(0.f, 0.f, 0.f, 0.f);
+            } else {
+                const float* src = first ? a0p + k0 : a1p + (k0 - g.k_split);
+#pragma unroll
+                for (int q = 0; q < HK / 4; ++q) va[q] = ok ? *reinterpret_cast<const float4*>(src + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            const uint4* bsrc = reinterpret_cast<const uint4*>(first ? bp0 + k0 : bp1 + (k0 - g.k_split));
+#pragma unroll
+            for (int q = 0; q < HB / 8; ++q) vb[q] = bcol_ok ? bsrc[q] : make_uint4(0u, 0u, 0u, 0u);
+        };
+        auto stash = [&](int buf) {
+            uint4* ad = reinterpret_cast<uint4*>(a_s[buf] + lrow * LD + lpart * HK);
+            if constexpr (A16) {
+#pragma unroll
+                for (int q = 0; q < HK / 8; ++q) reinterpret_cast<float4*>(ad)[q] = va[q];
+            } else {
+#pragma unroll
+                for (int q = 0; q < HK / 8; ++q) {
+                    const float4 x = va[2 * q], y = va[2 * q + 1];
+                    ad[q] = make_uint4(wn_pack_bf16(x.x, x.y), wn_pack_bf16(x.z, x.w), wn_pack_bf16(y.x, y.y), wn_pack_bf16(y.z, y.w));
+                }
+            }
+            uint4* bd = reinterpret_cast<uint4*>(b_s[buf] + bcol * LD + bhalf * HB);
+#pragma unroll
+            for (int q = 0; q < HB / 8; ++q) bd[q] = vb[q];
+        };
+        const int nchunks = g.K / KC;
+        fetch(0);
+        stash(0);
+        __syncthreads();
+        for (int kc = 0; kc < nchunks; ++kc) {
+            const int buf = kc & 1;
+            if (kc + 1 < nchunks) fetch(kc + 1);
+            const unsigned short* ar = a_s[buf] + (32 * wr + (lane & 31)) * LD + 8 * (lane >> 5);
+            const unsigned short* br = b_s[buf] + (128 * wc + (lane & 31)) * LD + 8 * (lane >> 5);
+#pragma unroll
+            for (int ks = 0; ks < KC / 16; ++ks) {
+                const wn_bf16x8 a = *reinterpret_cast<const wn_bf16x8*>(ar + 16 * ks);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const wn_bf16x8 b = *reinterpret_cast<const wn_bf16x8*>(br + 32 * j * LD + 16 * ks);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[j], 0, 0, 0);
+                }
+            }
+            if (kc + 1 < nchunks) stash(buf ^ 1);
+            __syncthreads();
+        }
+    }
+    float* stage = reinterpret_cast<float*>(smem_h) + wv * WN_EPI_TILE_FLOATS;
+    // ---- gate epilogue: z (bf16) to HBM where it is wanted, and ALWAYS into the LDS image (rows 32 wr .., this wave's 64 channels)
+    wn_gemm_epilogue<WN_EPI_GATE>(g, acc, m0 + 32 * wr, 128 * wc, lane, stage, z_s + (32 * wr) * LD2, LD2);
+    __syncthreads();   // z_s complete; the staging tiles are free: the second product's B chunks take their place
+    // ---- second product: x' tile [128 rows][128 columns] = z_s . Wres^T, wave (wr, wc): rows 32 wr .., columns 64 wc ..
+    wn_f16v acc2[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc2[j][i] = 0.f;
+    {
+        const int bcol = tid >> 2, bpart = tid & 3;   // 128 columns x 4 pieces of 8 bf16 per chunk
+        const unsigned short* bp = la.bn + (size_t)bcol * D2 + bpart * 8;
+        uint4 vb2 = *reinterpret_cast<const uint4*>(bp);
+        *reinterpret_cast<uint4*>(b2_s[0] + bcol * LD + bpart * 8) = vb2;
+        __syncthreads();
+        const unsigned short* zr = z_s + (32 * wr + (lane & 31)) * LD2 + 8 * (lane >> 5);
+#pragma unroll
+        for (int kc = 0; kc < D2 / KC; ++kc) {
+            const int buf = kc & 1;
+            if (kc + 1 < D2 / KC) vb2 = *reinterpret_cast<const uint4*>(bp + (kc + 1) * KC);
+            const unsigned short* br = b2_s[buf] + (64 * wc + (lane & 31)) * LD + 8 * (lane >> 5);
+#pragma unroll
+            for (int ks = 0; ks < KC / 16; ++ks) {
+                const wn_bf16x8 a = *reinterpret_cast<const wn_bf16x8*>(zr + KC * kc + 16 * ks);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const wn_bf16x8 b = *reinterpret_cast<const wn_bf16x8*>(br + 32 * j * LD + 16 * ks);
+                    acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc2[j], 0, 0, 0);
+                }
+            }
+            if (kc + 1 < D2 / KC) *reinterpret_cast<uint4*>(b2_s[buf ^ 1] + bcol * LD + bpart * 8) = vb2;
+            __syncthreads();
+        }
+    }
+    WnGemmArgs g2;   // the plain epilogue's view of the second product (rows as in the first)
+    g2.a0 = g2.a1 = WnRowMap{nullptr, 0, 0, 0};
+    g2.k_split = g2.K = D2; g2.bt = nullptr; g2.N = la.N; g2.bias = la.bias; g2.cin = la.cin; g2.c = la.c; g2.M = g.M; g2.rows_per_batch = g.rows_per_batch;
+    g2.relu_a = g2.relu_c = 0; g2.mask = nullptr; g2.gate_t = g2.gate_g = nullptr; g2.c2 = WnRowMap{nullptr, 0, 0, 0}; g2.c2_first_row = 0; g2.gate_packed = 0;
+    g2.a_skip_lo[0] = g2.a_skip_lo[1] = g2.a_skip_hi[0] = g2.a_skip_hi[1] = 0; g2.cin_skip_lo = 0; g2.bt1 = nullptr; g2.a_bf16 = 0; g2.c_bf16 = 0; g2.c_h = la.c_h;
+    wn_gemm_epilogue<WN_EPI_PLAIN, 2>(g2, acc2, m0 + 32 * wr, 64 * wc, lane, stage);   // (after the loop's last barrier: the B chunks are done with)
 }
 
 // out[i] = bf16(in[i]) (round to nearest even): the backward products' weight operands, [N][K] row-major, are the forward

@@ -67,6 +67,23 @@ static void wn_launch_nn(hipStream_t st, int epi, const WnGemmArgs& a, const uns
     else hipLaunchKernelGGL(wn_fwd_gemm<WN_EPI_PLAIN>, grid, dim3(256), 0, st, a);
 }
 
+// One forward layer in one launch (wn_fwd_layer_bf16): `a` = the filter/gate product's arguments (bf16 operands, c_bf16 = 1; a.c.base may be
+// NULL: z is not stored), `r` = the residual product's (its bias, cin, c, c_h are used).  Returns false when the shape is not the fused
+// kernel's (the caller launches the two products).  WN_NO_FUSED_LAYER=1 (with WN_TESTING=1) switches it off for A/B runs.
+static bool wn_fused_layer_enabled() { const char* off = wn_dev_env("WN_NO_FUSED_LAYER"); return !(off && off[0] == '1'); }
+static bool wn_launch_layer(hipStream_t st, const WnGemmArgs& a, const unsigned short* bn_fg, const WnGemmArgs& r, const unsigned short* bn_res) {
+    if (!bn_fg || !bn_res || a.N != 256 || r.N != 128 || r.K != 128 || a.K % 32 != 0 || !a.c_bf16 || a.relu_a || r.relu_a || r.relu_c || r.mask || r.cin_skip_lo) return false;
+    if (!wn_fused_layer_enabled()) return false;
+    WnGemmArgsBf16 b;
+    b.g = a; b.bn = bn_fg; b.bn1 = nullptr; b.ldb = 0;
+    WnLayerArgs la;
+    la.bn = bn_res; la.bias = r.bias; la.cin = r.cin; la.c = r.c; la.c_h = r.c_h; la.N = r.N;
+    const dim3 grid((unsigned)((a.M + 127) / 128));
+    if (a.a_bf16) hipLaunchKernelGGL((wn_fwd_layer_bf16<true>), grid, dim3(512), 0, st, b, la);
+    else hipLaunchKernelGGL((wn_fwd_layer_bf16<false>), grid, dim3(512), 0, st, b, la);
+    return true;
+}
+
 // ------------------------------------------------------------------------------------------------ runtime shim
 static const char* g_hip_what = "";
 static int rt_hip(hipError_t e, const char* what) {
@@ -1267,7 +1284,12 @@ extern "C" int wn_forward(wn_handle* h, const int32_t* indices, int64_t N, int64
     // read-modify-write of the whole SKIP matrix per layer (1.4 GB per layer at config 5).
     const int G = pl.layers < NL ? pl.layers : NL;
     const size_t skip_fl = (size_t)N * out_len * S, e_fl = (size_t)N * out_len * E, zg_fl = (size_t)N * out_len * G * D;
-    const size_t total = 2 * x_fl + z_fl + skip_fl + e_fl + zg_fl;
+    // bf16 operands at the 128 / 128 shape: a layer is ONE launch (wn_fwd_layer_bf16: z goes from the gate epilogue to the residual product
+    // through LDS and is never stored), its matrix operand reads of x take a bf16 shadow written next to x (WnGemmArgs::c_h), z on the skip
+    // rows (zg) is stored as bf16.  Same roundings as the two-launch form (every value is rounded to bf16 once, where it becomes an operand).
+    const bool fuse = h->fw_bf16 && h->fwb_ok && R == 128 && D == 128 && wn_fused_layer_enabled();
+    const size_t xh_fl = fuse ? ((x_fl + 1) / 2 + 63) / 64 * 64 : 0;
+    const size_t total = 2 * x_fl + z_fl + skip_fl + e_fl + zg_fl + 2 * xh_fl;
     if (h->ws_floats < total) {
         if (h->pending) { int rc = wn_wait(h); if (rc) return rc; }
         rt_free(h->d_ws);
@@ -1277,48 +1299,66 @@ extern "C" int wn_forward(wn_handle* h, const int32_t* indices, int64_t N, int64
     }
     float* xa = h->d_ws; float* xb = xa + x_fl; float* z = xb + x_fl; float* skip = z + z_fl; float* ev = skip + skip_fl;
     float* zg = ev + e_fl;
+    unsigned short* xha = fuse ? reinterpret_cast<unsigned short*>(zg + zg_fl) : nullptr;
+    unsigned short* xhb = fuse ? reinterpret_cast<unsigned short*>(zg + zg_fl + xh_fl) : nullptr;
     hipStream_t st = (hipStream_t)hip_stream;
     {
         const long long rows = N * L;
         const long long work = rows * (R / 4);
         hipLaunchKernelGGL(wn_fwd_start, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, indices, h->d_start_t,
-                           pl.has_bias ? h->d_start_b : nullptr, xa, rows, R);
+                           pl.has_bias ? h->d_start_b : nullptr, xa, rows, R, xha);
     }
     const bool bf16 = h->fw_bf16 && h->fwb_ok;
     auto launch = [&](int epi, const WnGemmArgs& a, const unsigned short* bn) { wn_launch_nn(st, epi, a, bf16 ? bn : nullptr); };
     const unsigned short* fwb = h->d_fwb;
     const float* fw = h->d_fw;
     float* xin = xa; float* xout = xb;
+    unsigned short* xhin = xha; unsigned short* xhout = xhb;
     for (int l = 0; l < NL; ++l) {
         const long long d = h->dil[l], rows = need[l + 1], t0 = L - rows;
         const int gi = l % G;
         WnGemmArgs a;
         memset(&a, 0, sizeof(a));
         // z = gate([x(t-d) | x(t)] . Wfg^T)
-        a.a0 = WnRowMap{xin, (long long)L * R, R, t0 - d};
+        const float* xop = fuse ? reinterpret_cast<const float*>(xhin) : xin;   // (fuse: the bf16 shadow, the row maps count bf16 elements)
+        a.a0 = WnRowMap{xop, (long long)L * R, R, t0 - d};
         a.a_skip_lo[0] = (int)geo.zlo[l];   // (short clips: the reference's left zero padding stands in for x(t - d) there)
-        a.a1 = WnRowMap{xin, (long long)L * R, R, t0};
+        a.a1 = WnRowMap{xop, (long long)L * R, R, t0};
+        a.a_bf16 = fuse ? 1 : 0;
         a.k_split = R; a.K = 2 * R; a.bt = fw + h->fw_off_fg + (size_t)l * 2 * R * 2 * D; a.N = 2 * D;
         a.bias = pl.has_bias ? fw + h->fw_off_bfg + (size_t)l * 2 * D : nullptr;
         a.c = WnRowMap{z, rows * D, D, 0};
-        a.c2 = WnRowMap{zg + (size_t)gi * D, out_len * (long long)G * D, (long long)G * D, 0};
+        a.c_bf16 = fuse ? 1 : 0;   // (fuse: z and zg hold bf16)
+        a.c2 = WnRowMap{fuse ? reinterpret_cast<float*>(reinterpret_cast<unsigned short*>(zg) + (size_t)gi * D) : zg + (size_t)gi * D, out_len * (long long)G * D, (long long)G * D, 0};
         a.c2_first_row = (int)(rows - out_len);
         a.M = N * rows; a.rows_per_batch = (int)rows;
-        launch(WN_EPI_GATE, a, bf16 ? fwb + h->fwb_off_fg + (size_t)l * 2 * D * 2 * R : nullptr);
-        if (l < NL - 1) {  // x' = z . Wres^T + x(t)   (the last layer's residual output is never consumed, also upstream)
-            memset(&a, 0, sizeof(a));
-            a.a0 = a.a1 = WnRowMap{z, rows * D, D, 0};
-            a.k_split = D; a.K = D; a.bt = fw + h->fw_off_res + (size_t)l * D * R; a.N = R;
-            a.bias = pl.has_bias ? fw + h->fw_off_bres + (size_t)l * R : nullptr;
-            a.cin = WnRowMap{xin, (long long)L * R, R, t0};
-            a.c = WnRowMap{xout, (long long)L * R, R, t0};
-            a.M = N * rows; a.rows_per_batch = (int)rows;
-            launch(WN_EPI_PLAIN, a, bf16 ? fwb + h->fwb_off_res + (size_t)l * R * D : nullptr);
+        WnGemmArgs ar;  // x' = z . Wres^T + x(t)   (the last layer's residual output is never consumed, also upstream)
+        memset(&ar, 0, sizeof(ar));
+        if (l < NL - 1) {
+            ar.a0 = ar.a1 = WnRowMap{z, rows * D, D, 0};
+            ar.a_bf16 = fuse ? 1 : 0;
+            ar.k_split = D; ar.K = D; ar.bt = fw + h->fw_off_res + (size_t)l * D * R; ar.N = R;
+            ar.bias = pl.has_bias ? fw + h->fw_off_bres + (size_t)l * R : nullptr;
+            ar.cin = WnRowMap{xin, (long long)L * R, R, t0};
+            ar.c = WnRowMap{xout, (long long)L * R, R, t0};
+            ar.c_h = fuse ? xhout : nullptr;
+            ar.M = N * rows; ar.rows_per_batch = (int)rows;
+        }
+        bool fused = false;
+        if (fuse && l < NL - 1) {
+            WnGemmArgs af = a;
+            af.c.base = nullptr;   // z itself is not stored: nothing reads it again
+            fused = wn_launch_layer(st, af, fwb + h->fwb_off_fg + (size_t)l * 2 * D * 2 * R, ar, fwb + h->fwb_off_res + (size_t)l * R * D);
+        }
+        if (!fused) {
+            launch(WN_EPI_GATE, a, bf16 ? fwb + h->fwb_off_fg + (size_t)l * 2 * D * 2 * R : nullptr);
+            if (l < NL - 1) launch(WN_EPI_PLAIN, ar, bf16 ? fwb + h->fwb_off_res + (size_t)l * R * D : nullptr);
         }
         if (gi == G - 1 || l == NL - 1) {  // skip (+)= ZG . [Wskip of the group's layers]^T   (K = layers_in_group * D)
             const int first = l - gi, cnt = gi + 1;
             memset(&a, 0, sizeof(a));
             a.a0 = a.a1 = WnRowMap{zg, out_len * (long long)G * D, (long long)G * D, 0};
+            a.a_bf16 = fuse ? 1 : 0;
             a.k_split = cnt * D; a.K = cnt * D; a.bt = fw + h->fw_off_skip + (size_t)first * D * S; a.N = S;
             a.bias = (pl.has_bias && first == 0) ? fw + h->fw_off_bskip_total : nullptr;
             if (first > 0) a.cin = WnRowMap{skip, out_len * S, S, 0};
@@ -1327,6 +1367,7 @@ extern "C" int wn_forward(wn_handle* h, const int32_t* indices, int64_t N, int64
             launch(WN_EPI_PLAIN, a, bf16 ? fwb + h->fwb_off_skip + (size_t)(first / G) * S * G * D : nullptr);
         }
         float* t = xin; xin = xout; xout = t;
+        unsigned short* th = xhin; xhin = xhout; xhout = th;
     }
     {   // head: relu(skip) -> end_conv_1 (+b, relu) -> end_conv_2 (+b)     wavenet_model.py:167-169
         WnGemmArgs a;

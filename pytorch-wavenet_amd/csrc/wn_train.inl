@@ -243,17 +243,22 @@ extern "C" int wn_train_forward(wn_handle* h, const float* params, const int32_t
         a.gate_packed = bf16 ? 1 : 0;  // bf16 step: tanh and sigmoid saved as one {bf16, bf16} dword per element (half the bytes, written once)
         a.c_bf16 = bf16 ? 1 : 0;       //            z (and its copy on the skip rows, zg) stored as bf16
         a.M = N * rows; a.rows_per_batch = (int)rows;
-        wn_launch_nn(st, WN_EPI_GATE, a, bf16 ? bt_fg + (size_t)l * 2 * D * 2 * R : nullptr);
+        WnGemmArgs ar;   // the residual product x_{l+1} = z . Wres^T + bias + x_l
+        memset(&ar, 0, sizeof(ar));
         if (l < NL - 1) {
-            memset(&a, 0, sizeof(a));
-            a.a0 = a.a1 = WnRowMap{z, rows * D, D, 0};
-            a.k_split = D; a.K = D; a.bt = fw + h->fw_off_res + (size_t)l * D * R; a.N = R;
-            a.bias = pl.has_bias ? fw + h->fw_off_bres + (size_t)l * R : nullptr;
-            a.cin = WnRowMap{xin, (long long)L * R, R, t0};
-            a.c = WnRowMap{ws + t.x[l + 1], (long long)L * R, R, t0};
-            if (shadow) a.c_h = reinterpret_cast<unsigned short*>(ws + t.xh[l + 1]);
-            a.M = N * rows; a.rows_per_batch = (int)rows; a.a_bf16 = bf16 ? 1 : 0;
-            wn_launch_nn(st, WN_EPI_PLAIN, a, bf16 ? bt_res + (size_t)l * R * D : nullptr);
+            ar.a0 = ar.a1 = WnRowMap{z, rows * D, D, 0};
+            ar.k_split = D; ar.K = D; ar.bt = fw + h->fw_off_res + (size_t)l * D * R; ar.N = R;
+            ar.bias = pl.has_bias ? fw + h->fw_off_bres + (size_t)l * R : nullptr;
+            ar.cin = WnRowMap{xin, (long long)L * R, R, t0};
+            ar.c = WnRowMap{ws + t.x[l + 1], (long long)L * R, R, t0};
+            if (shadow) ar.c_h = reinterpret_cast<unsigned short*>(ws + t.xh[l + 1]);
+            ar.M = N * rows; ar.rows_per_batch = (int)rows; ar.a_bf16 = bf16 ? 1 : 0;
+        }
+        // (bf16 step, the 128/128 shape: both products of the layer in one launch, z handed over in LDS -- wn_fwd_layer_bf16)
+        const bool fused = bf16 && l < NL - 1 && wn_launch_layer(st, a, bt_fg + (size_t)l * 2 * D * 2 * R, ar, bt_res + (size_t)l * R * D);
+        if (!fused) {
+            wn_launch_nn(st, WN_EPI_GATE, a, bf16 ? bt_fg + (size_t)l * 2 * D * 2 * R : nullptr);
+            if (l < NL - 1) wn_launch_nn(st, WN_EPI_PLAIN, ar, bf16 ? bt_res + (size_t)l * R * D : nullptr);
         }
         if (gi == G - 1 || l == NL - 1) {
             const int first = l - gi, cnt = gi + 1;

@@ -149,6 +149,43 @@ def test_forward_bf16_operands_close_to_fp32(cfgname, N, out_len):
     assert np.array_equal(y16.argmax(1)[clear], y32.argmax(1)[clear])
 
 
+@pytest.mark.parametrize("L_extra", [63, -40])
+def test_forward_bf16_one_launch_per_layer_equals_the_two_launch_form(monkeypatch, L_extra):
+    """bf16 operands at the 128 / 128 shape: a layer is ONE launch (wn_fwd_layer_bf16: z handed from the gate epilogue to the residual
+    product through LDS, operand reads of x from its bf16 shadow).  Every value is rounded to bf16 once, where it becomes an operand, in
+    both forms, and the products accumulate in the same order: the logits are the two-launch form's BIT FOR BIT -- on a clip longer
+    than the receptive field and on one in the reference's left-zero-pad regime (row windows in the fused kernel's loader)."""
+    monkeypatch.setenv("WN_TESTING", "1")
+    cfg = synth.CONFIGS["cfg3"]
+    W = synth.init_weights(cfg, seed=7)
+    eng = engine.Engine(cfg, W)
+    out_len = 64
+    L = synth.receptive_field(cfg) + out_len - 1 + L_extra
+    eng.set_forward_precision(True)
+    if L_extra < 0:   # a short length the reference has a result for (its padding rule refuses most of them: the library says which)
+        full = L - L_extra
+        for cand in range(L, full):
+            try:
+                eng.forward_indices(np.zeros((1, cand), dtype=np.int64), out_len)
+                L = cand
+                break
+            except (ValueError, _abi.WnError):
+                continue
+        else:
+            pytest.skip("no short length with a result below %d" % full)
+    ids = np.random.RandomState(5).randint(0, 256, (3, L))
+    fused = eng.forward_indices(ids, out_len).cpu().numpy()
+    monkeypatch.setenv("WN_NO_FUSED_LAYER", "1")
+    two = eng.forward_indices(ids, out_len).cpu().numpy()
+    monkeypatch.delenv("WN_NO_FUSED_LAYER")
+    again = eng.forward_indices(ids, out_len).cpu().numpy()
+    assert np.isfinite(fused).all() and float(np.abs(fused).max()) > 0
+    assert np.array_equal(fused, two) and np.array_equal(again, fused)
+    eng.set_forward_precision(False)
+    y32 = eng.forward_indices(ids, out_len).cpu().numpy()
+    assert 0 < float(np.abs(fused - y32).max()) <= 3e-2 * float(np.abs(y32).max())
+
+
 def test_forward_bf16_refused_for_small_channel_counts():
     cfg = synth.CONFIGS["cfg1"]
     eng = engine.Engine(cfg, synth.init_weights(cfg, seed=1))

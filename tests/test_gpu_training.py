@@ -355,6 +355,27 @@ def test_bf16_step_at_the_headline_channel_widths():
         assert rel <= (5e-3 if k.startswith("end_conv_2") else 0.15) and cos >= 0.99, (k, rel, cos)
 
 
+def test_bf16_step_one_launch_per_forward_layer_equals_the_two_launch_form(monkeypatch):
+    """The bf16 step at the 128 / 128 widths runs each forward layer as ONE launch (wn_fwd_layer_bf16) on the bf16 shadow of x; with
+    WN_NO_FUSED_LAYER=1 the same build launches the two products.  Same roundings, same accumulation order: logits and loss are equal bit
+    for bit; the gradients agree to the rounding of their atomically accumulated weight-gradient tiles."""
+    monkeypatch.setenv("WN_TESTING", "1")
+    m = _model(True, layers=4, blocks=2, ch=128, skip=512, end=256, out_len=24, seed=4, gain=1.5)
+    m.matrix_precision = "bf16"
+    x, target = _batch(m, 2, 3)
+    out_f, loss_f, g_f = _step(m, x, target, torch_path=False)
+    monkeypatch.setenv("WN_NO_FUSED_LAYER", "1")
+    out_t, loss_t, g_t = _step(m, x, target, torch_path=False)
+    monkeypatch.delenv("WN_NO_FUSED_LAYER")
+    assert torch.equal(out_f, out_t) and loss_f == loss_t
+    for k in g_f:
+        if g_f[k] is None:
+            assert g_t[k] is None
+            continue
+        rel = float((g_f[k] - g_t[k]).norm() / (g_t[k].norm() + 1e-30))
+        assert rel <= 1e-5, (k, rel)
+
+
 def test_training_abi_error_codes():
     """wn_train_* through the C ABI: call-order and shape errors come back as codes with a message, nothing throws."""
     import ctypes
