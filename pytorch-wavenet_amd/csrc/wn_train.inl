@@ -129,6 +129,9 @@ static void wn_launch_transpose(hipStream_t st, const float* in, long long in_ba
                        in, in_batch_stride, out, rows, cols);
 }
 
+// (Round 4 tried the side stream at the LOWEST queue priority -- the chain's workgroups first, the side work in what is left: 63.7 -> 70.5 ms
+//  per bf16 config-5 step.  The side work is a third of the step's kernel time; starved, it is left over at the end.
+//  profiles/r04_fused_forward_layer.txt.)
 extern "C" int wn_train_forward(wn_handle* h, const float* params, const int32_t* indices, int64_t N, int64_t L, int64_t out_len,
                                 float* logits, void* hip_stream) {
     g_err[0] = 0;
