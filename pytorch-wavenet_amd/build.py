@@ -60,7 +60,7 @@ def check_hand_scheduled_registers(so, objdump=None):
     group's tap FIFO).  The kernels carry amdgpu_num_vgpr so that the compiler's own allocation ends below them; this check
     DISASSEMBLES the built library and raises unless (1) every instruction of those kernels that names a reserved register is one
     the blocks emit, in the operand position they emit it -- a tap-FIFO take directly behind one of the FIFO's hand-counted
-    `s_waitcnt vmcnt(n)` --, (2) nothing touches a register above v167, (3) the kernels use no scratch (a spill in a persistent hot loop is a performance bug, and spill code is where an allocator would reach for "free"
+    `s_waitcnt vmcnt(n)` --, (2) nothing touches a register above v167, (3) the kernels use no scratch, (4) no hand-scheduled load reads an SGPR base a VALU instruction wrote less than five wait states earlier (a spill in a persistent hot loop is a performance bug, and spill code is where an allocator would reach for "free"
     registers).  Called by build_hip(): a library that breaks the invariant is never left in place."""
     import re
     import tempfile
@@ -78,6 +78,7 @@ def check_hand_scheduled_registers(so, objdump=None):
     reserved = set(range(RESERVED_FIRST, RESERVED_LAST + 1))
     is_res = lambda tok: bool(_regs(tok) & reserved)  # noqa: E731
     seen, current, prev = 0, None, ""
+    history = []   # the last instructions of the kernel being read (hazard check below)
     fifo_waits = {"s_waitcnt vmcnt(%d)" % n for n in (5, 6, 10, 11)}  # WN_V3_TAP_AHEAD = 6: D - 1, D, 2 D - 2, 2 D - 1 younger operations
     for line in dis.splitlines():
         m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
@@ -91,6 +92,9 @@ def check_hand_scheduled_registers(so, objdump=None):
         if not text:
             continue
         before, prev = prev, text
+        history.append(text)
+        if len(history) > 8:
+            history.pop(0)
         op, _, rest = text.partition(" ")
         ops = [o.strip() for o in rest.split(",")]
         regs = _regs(text)
@@ -103,6 +107,25 @@ def check_hand_scheduled_registers(so, objdump=None):
         where = "%s: %s" % (current, text)
         if op == "global_load_dwordx2":      # a request set: destination pair inside the reserved range, address operands outside
             ok = re.fullmatch(r"v\[(\d+):(\d+)\]", ops[0]) and _regs(ops[0]) <= reserved and not any(is_res(o) for o in ops[1:])
+            # (4) its SGPR base must not have been written by a VALU instruction (v_readlane_b32 of a spilled pointer, ...) within the last
+            # five wait states: the hazard recognizer does not look into inline assembly (see WN_AP_SGPR_HAZARD in wn_kernel_v3.h)
+            m2 = re.search(r"\bs\[(\d+):(\d+)\]", ops[2] if len(ops) > 2 else "")
+            if ok and m2:
+                base = set(range(int(m2.group(1)), int(m2.group(2)) + 1))   # registers of the pair whose last writer has not been seen yet
+                waited = 0
+                for old in reversed(history[:-1]):
+                    if waited >= 5 or not base:
+                        break
+                    o_op, _, o_rest = old.partition(" ")
+                    dst = o_rest.split(",")[0].strip()
+                    if re.fullmatch(r"s\d+|s\[\d+:\d+\]", dst):
+                        d = [int(x) for x in re.findall(r"\d+", dst)]
+                        d = set(range(d[0], d[-1] + 1))
+                        if o_op.startswith("v_") and d & base:
+                            raise RuntimeError("%s: the SGPR base of a hand-scheduled load is written by `%s` %d wait state(s) before it (5 needed)" % (where, old, waited))
+                        if o_op.startswith("s_"):
+                            base -= d   # (written by the scalar unit: no hazard, and whatever wrote it before does not matter)
+                    waited += int(o_rest) + 1 if o_op == "s_nop" else 1
         elif op == "global_load_dword":      # the tap FIFO: destination v152-v157, address outside
             ok = ops[0] in ("v152", "v153", "v154", "v155", "v156", "v157") and not any(is_res(o) for o in ops[1:])
         elif op == "v_cmp_eq_u32_e32":       # vcc = (tag == v<reserved>): reserved register as the LAST source only
@@ -134,16 +157,28 @@ def build_hip(force=False, verbose=False, extra_flags=()):
     if not force and not _stale(OUT, DEPS):
         return OUT
     tmp_out = OUT + ".tmp"
-    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
-           "-Wno-unused-function", "-Wno-inline-asm", *extra_flags, "-o", tmp_out] + SOURCES
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
-    try:
-        check_hand_scheduled_registers(tmp_out)   # a library that breaks the reservation is never installed
-    except Exception:
-        os.remove(tmp_out)
-        raise
+    base = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
+            "-Wno-unused-function", "-Wno-inline-asm", *extra_flags]
+    # The hand-scheduled input poll needs five wait states in front of its first load ONLY where the compiler reloads a spilled base
+    # pointer right in front of the block (wn_kernel_v3.h, WN_AP_SGPR_HAZARD).  First the form without them; the disassembly decides:
+    # rule 4 of the check refuses a library that has the hazard, and the source's default (with the wait states) is built instead.
+    pinned = any(f.startswith("-DWN_AP_SGPR_HAZARD") for f in extra_flags)
+    attempts = [[]] if pinned else [['-DWN_AP_SGPR_HAZARD=""'], []]
+    for n, extra in enumerate(attempts):
+        cmd = base + extra + ["-o", tmp_out] + SOURCES
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+        try:
+            check_hand_scheduled_registers(tmp_out)   # a library that breaks the reservation is never installed
+            break
+        except Exception as e:
+            os.remove(tmp_out)
+            if n + 1 < len(attempts) and "SGPR base of a hand-scheduled load" in str(e):
+                if verbose:
+                    print("build.py: %s -- rebuilding with the wait states" % e)
+                continue
+            raise
     os.replace(tmp_out, OUT)
     return OUT
 

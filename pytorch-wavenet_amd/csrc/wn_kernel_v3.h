@@ -54,6 +54,10 @@
 #endif
 #define WN_V3_MIN_STREAMS 1
 #define WN_V3_TAP_AHEAD 6
+#ifndef WN_SAMPLER_PREFETCH
+#define WN_SAMPLER_PREFETCH 2  // the sampler asks for the item's uniform BEFORE it waits for the logits (2; 1: also temperature / given sample -- the
+                               // build whose scalar pressure spilled the input poll's base pointers, see WN_AP_SGPR_HAZARD; 0: everything behind the logits)
+#endif
 #ifndef WN_V3_WIDE_SAMPLER
 #define WN_V3_WIDE_SAMPLER 0  // experiment: head slices from which the samplers of variant 3 collect the logits with four waves (0 = never)
 #endif
@@ -149,10 +153,24 @@ static __device__ __forceinline__ wn_v4i wn_poll_pair(WnCtx& cx, __amdgpu_buffer
 // lands in registers nobody else uses and is overwritten (in order) by the next request.
 // (the clobbers make the kernel's register count cover v167; the compiler cannot allocate them anyway: amdgpu_num_vgpr)
 #define WN_AP_CLOBBERS "v152", "v153", "v154", "v155", "v156", "v157", "v158", "v159", "v160", "v161", "v162", "v163", "v164", "v165", "v166", "v167", "vcc", "scc", "memory"
+// The blocks take their base pointers in SGPR pairs ("s" operands).  Under register pressure the compiler keeps such a pointer in a lane of
+// its SGPR-spill VGPR and brings it back with v_readlane_b32 right in front of the block -- a VALU write of an SGPR that a VMEM instruction
+// reads as its address needs FIVE wait states in between on gfx9 (the backend's hazard recognizer inserts them for its own instructions,
+// not in front of inline assembly): without them the load goes out with whatever the SGPR pair held before -- round 4 met it as a memory
+// access fault on address nil / 0xffffa4db9000 in the two-slice form (tests/test_gpu_parity.py two_way_split, tools/stress_split.py),
+// the first build whose scalar pressure spilled those pointers.  Every block whose first VMEM instruction reads an "s" operand starts with
+// WN_AP_SGPR_HAZARD: five wait states by default.  They sit on the token's path (cfg3 single stream: 49.5 -> 51.3 us per timestep), and a
+// build in which no such pointer is reloaded in front of a block does not need them: build.py compiles with -DWN_AP_SGPR_HAZARD="" FIRST,
+// DISASSEMBLES the result and checks every hand-scheduled load for the hazard (check_hand_scheduled_registers, rule 4), and only falls back
+// to this default when the check finds one.  Any other way of compiling this file gets the safe form.
+#ifndef WN_AP_SGPR_HAZARD
+#define WN_AP_SGPR_HAZARD "s_nop 4\n\t"
+#endif
 // (addresses: a wave-uniform base per partial in an SGPR pair + ONE 32-bit byte offset per lane -- four 64-bit lane pointers were
 //  eight registers of the polling waves' budget)
 static __device__ __forceinline__ void wn_ap_issue_a4(unsigned off, const wn_u64* b0, const wn_u64* b1, const wn_u64* b2, const wn_u64* b3) {
     asm volatile(
+        WN_AP_SGPR_HAZARD
         "global_load_dwordx2 v[152:153], %0, %1 sc1\n\t"
         "global_load_dwordx2 v[154:155], %0, %2 sc1\n\t"
         "global_load_dwordx2 v[156:157], %0, %3 sc1\n\t"
@@ -161,12 +179,13 @@ static __device__ __forceinline__ void wn_ap_issue_a4(unsigned off, const wn_u64
 }
 static __device__ __forceinline__ void wn_ap_issue_a2(unsigned off, const wn_u64* b0, const wn_u64* b1) {
     asm volatile(
+        WN_AP_SGPR_HAZARD
         "global_load_dwordx2 v[152:153], %0, %1 sc1\n\t"
         "global_load_dwordx2 v[154:155], %0, %2 sc1"
         ::"v"(off), "s"(b0), "s"(b1) : WN_AP_CLOBBERS);
 }
 static __device__ __forceinline__ void wn_ap_issue_a1(unsigned off, const wn_u64* b0) {
-    asm volatile("global_load_dwordx2 v[152:153], %0, %1 sc1" ::"v"(off), "s"(b0) : WN_AP_CLOBBERS);
+    asm volatile(WN_AP_SGPR_HAZARD "global_load_dwordx2 v[152:153], %0, %1 sc1" ::"v"(off), "s"(b0) : WN_AP_CLOBBERS);
 }
 // one check of a set: lanes that are not ok yet and see fresh tags take their sum (fixed order ((0+x0)+x1)+x2)+x3, as wn_poll_fixed)
 #define WN_AP_MERGE                                      \
@@ -213,6 +232,7 @@ static __device__ __forceinline__ void wn_ap_issue_a1(unsigned off, const wn_u64
         "s_waitcnt vmcnt(0)\n\t"                                                  \
         WN_AP_CHECK4(152, 153, 154, 155, 156, 157, 158, 159)
 #define WN_AP_SPIN4_BODY                                                          \
+        WN_AP_SGPR_HAZARD                                                         \
         "s_mov_b32 %[cnt], %[rounds]\n\t"                                         \
         WN_AP_ISSUE4(160, 161, 162, 163, 164, 165, 166, 167)                      \
         "s_sleep 2\n\t"                                                           \
@@ -267,6 +287,7 @@ static __device__ __forceinline__ int wn_ap_spin4(unsigned off, const wn_u64* p0
         "s_waitcnt vmcnt(0)\n\t"                                                  \
         WN_AP_CHECK2(152, 153, 154, 155)
 #define WN_AP_SPIN2_BODY                                                          \
+        WN_AP_SGPR_HAZARD                                                         \
         "s_mov_b32 %[cnt], %[rounds]\n\t"                                         \
         WN_AP_ISSUE2(160, 161, 162, 163)                                          \
         "s_sleep 2\n\t"                                                           \
@@ -309,6 +330,7 @@ static __device__ __forceinline__ int wn_ap_spin2(unsigned off, const wn_u64* p0
         "s_waitcnt vmcnt(0)\n\t"                                                  \
         WN_AP_CHECK1(152, 153)
 #define WN_AP_SPIN1_BODY                                                          \
+        WN_AP_SGPR_HAZARD                                                         \
         "s_mov_b32 %[cnt], %[rounds]\n\t"                                         \
         "global_load_dwordx2 v[160:161], %[off], %[p0] sc1\n\t"                      \
         "s_sleep 2\n\t"                                                           \
@@ -1515,10 +1537,14 @@ static __device__ void wn_v3_sampler(const WnPlan& p, const WnRun& r, WnCtx& cx,
             // (+ lane0: 0 for every lane of this wave, unknown to the compiler -- vector loads into VGPRs; as scalar loads the values sit in
             //  SGPRs across the poll, and the kernel's scalar registers are already spilling into VGPR lanes)
             const long long g = e - r.n_given;
+#if WN_SAMPLER_PREFETCH == 1
             const float temp = r.stream_temps ? r.stream_temps[s + lane0] : r.temperature;
             const bool greedy = r.greedy != 0 || !(temp > 0.f);
             const double u = (g >= 0 && !greedy) ? r.uniforms[(size_t)s * r.num_samples + g + lane0] : 0.;
             const int given = g < 0 ? r.first[(size_t)s * r.n_given + e + lane0] : 0;
+#elif WN_SAMPLER_PREFETCH == 2   // only the uniform (the one that streams from HBM), taken whatever the temperature says: r.uniforms != NULL is all it needs
+            const double u = (g >= 0 && r.uniforms) ? r.uniforms[(size_t)s * r.num_samples + g + lane0] : 0.;
+#endif
             float logit[4] = {0.f, 0.f, 0.f, 0.f};
             if constexpr (WIDE) {   // class threadIdx.x: the PA partial logits summed in the order h = 0 .. PA-1, then four classes per lane of wave 0
                 float mine1 = 0.f;
@@ -1546,6 +1572,16 @@ static __device__ void wn_v3_sampler(const WnPlan& p, const WnRun& r, WnCtx& cx,
                 if (cx.fail) return;
             }
             wn_stamp(r, park, item, 1);
+#if WN_SAMPLER_PREFETCH == 0   // (A/B switch: the loads behind the logits' arrival, as before round 4)
+            const float temp = r.stream_temps ? r.stream_temps[s + lane0] : r.temperature;
+            const bool greedy = r.greedy != 0 || !(temp > 0.f);
+            const double u = (g >= 0 && !greedy) ? r.uniforms[(size_t)s * r.num_samples + g + lane0] : 0.;
+            const int given = g < 0 ? r.first[(size_t)s * r.n_given + e + lane0] : 0;
+#elif WN_SAMPLER_PREFETCH == 2
+            const float temp = r.stream_temps ? r.stream_temps[s + lane0] : r.temperature;
+            const bool greedy = r.greedy != 0 || !(temp > 0.f);
+            const int given = g < 0 ? r.first[(size_t)s * r.n_given + e + lane0] : 0;
+#endif
             int idx;
             if (g < 0) {
                 idx = given;

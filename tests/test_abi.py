@@ -182,6 +182,20 @@ def test_reserved_poll_registers_belong_to_the_hand_scheduled_blocks_only(tmp_pa
                 "scratch_load_dword v3, off, off"):               # a spill
         with pytest.raises(RuntimeError):
             run(good + [bad])
+    # rule 4: the SGPR base of a hand-scheduled load must not come out of a VALU instruction (v_readlane_b32 of a spilled pointer) less than
+    # five wait states earlier -- the hazard recognizer does not look into inline assembly (round 4: memory access faults in the two-slice form)
+    load = "global_load_dwordx2 v[152:153], v1, s[12:13] sc1"
+    for pre in (["v_readlane_b32 s12, v128, 20", "v_readlane_b32 s13, v128, 21"],                    # 0 and 1 wait states
+                ["v_readlane_b32 s13, v128, 21", "s_add_u32 s12, s12, s5", "s_addc_u32 s6, s6, 0"],     # 2 (only s12 re-written by the SALU)
+                ["v_readlane_b32 s12, v128, 20", "s_nop 2"],                                         # 3
+                ["v_cmp_eq_u32_e64 s[12:13], s5, v3", "s_nop 3"]):                                    # 4, any VALU write of the pair
+        with pytest.raises(RuntimeError, match="SGPR base of a hand-scheduled load"):
+            run(good + pre + [load])
+    for pre in (["v_readlane_b32 s12, v128, 20", "v_readlane_b32 s13, v128, 21", "s_nop 4"],         # five wait states
+                ["v_readlane_b32 s13, v128, 21", "s_nop 1", "s_mov_b32 s4, 1", "v_mov_b32_e32 v3, 0", "s_nop 0"],
+                ["v_readlane_b32 s10, v128, 20", "v_readlane_b32 s11, v128, 21"],                  # another pair
+                ["v_readlane_b32 s12, v128, 20", "v_readlane_b32 s13, v128, 21", "s_add_u32 s12, s12, s4", "s_addc_u32 s13, s13, 0"]):   # last written by the SALU: no hazard
+        assert run(good + pre + [load]) == 1
 
 
 def test_graft_entry_build_runs():
