@@ -112,8 +112,9 @@ static __device__ __forceinline__ uint2 wn_pack_bf16x4(float4 a) { return make_u
 static __device__ __forceinline__ uint4 wn_pack_bf16x8(float4 a, float4 b) {
     return make_uint4(wn_pack_bf16(a.x, a.y), wn_pack_bf16(a.z, a.w), wn_pack_bf16(b.x, b.y), wn_pack_bf16(b.z, b.w));
 }
-// NTILES: accumulator tiles of the strip that exist (WN_EPI_PLAIN; 32 columns each).  zl (WN_EPI_GATE with c_bf16): the strip's rows of an
-// LDS image of z, [row][zld bf16] -- the fused layer kernel's operand for the residual product; g.c.base may then be NULL (z not stored).
+// NTILES: accumulator tiles of the strip that exist (WN_EPI_PLAIN, WN_EPI_GATE_BWD; 32 columns each).  zl: the strip's rows of an LDS image
+// [row][zld bf16] of what the strip emits -- z (WN_EPI_GATE with c_bf16; g.c.base may then be NULL: z not stored) or the plain output
+// (WN_EPI_PLAIN) -- the A operand of the fused kernels' second product.
 template <int EPI, int NTILES = 4>
 static __device__ __forceinline__ void wn_gemm_epilogue(const WnGemmArgs& g, const wn_f16v (&acc)[NTILES], long long mw, int nw, int lane, float* stage,
                                                         unsigned short* zl = nullptr, int zld = 0) {
@@ -127,7 +128,7 @@ static __device__ __forceinline__ void wn_gemm_epilogue(const WnGemmArgs& g, con
     const int r8 = lane >> 2, c8 = 8 * (lane & 3);
     // (q, rem) of row m: M < 2^31 (checked on the host): 32-bit division, a 64-bit one is ~100 instructions
     auto split = [&](long long m, unsigned& q, unsigned& rem) { q = (unsigned)m / (unsigned)g.rows_per_batch; rem = (unsigned)m - q * (unsigned)g.rows_per_batch; };
-    static_assert(EPI == WN_EPI_PLAIN || NTILES == 4, "the gate epilogues take the whole 128-column strip");
+    static_assert(EPI != WN_EPI_GATE || NTILES == 4, "the gate epilogue takes the whole 128-column strip");
     if constexpr (EPI == WN_EPI_GATE && NTILES == 4) {
         const int NH = g.N >> 1;   // channels per row of z / the gate pair
 #pragma unroll
@@ -212,13 +213,13 @@ static __device__ __forceinline__ void wn_gemm_epilogue(const WnGemmArgs& g, con
                 }
             }
         }
-    } else if constexpr (EPI == WN_EPI_GATE_BWD && NTILES == 4) {
+    } else if constexpr (EPI == WN_EPI_GATE_BWD) {
         // The product is dz = dx' . Wres (N = D channels); the strip emits [dF | dG] = dz * {G (1 - T^2), T G (1 - G)} in the packed
         // [F(32) | G(32)] column order of Wfg^T (2N columns per row of c).  gate_t / gate_g are the forward's saved gates (INPUTS
         // here, row m, N columns; gate_packed as in the forward); c2 is the skip path's share of dz (READ here: rows >=
         // c2_first_row of a batch entry add c2's row (index - c2_first_row)).  dz itself never reaches HBM.
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < NTILES; ++j) {
             const int ch0 = nw + 32 * j;
             if (ch0 >= g.N) continue;   // (wave-uniform)
             float d[16];
@@ -332,6 +333,7 @@ static __device__ __forceinline__ void wn_gemm_epilogue(const WnGemmArgs& g, con
                 }
                 *reinterpret_cast<float4*>(crow + n) = v;
                 if (g.c_h) *reinterpret_cast<uint2*>(g.c_h + (crow - g.c.base) + n) = wn_pack_bf16x4(v);
+                if (zl) *reinterpret_cast<uint2*>(zl + row * zld + n) = wn_pack_bf16x4(v);   // (WN_EPI_PLAIN: the output tile as the next product's bf16 A operand, column n of an image that starts at column 0)
             }
         }
     }
@@ -729,6 +731,120 @@ __global__ __launch_bounds__(512, 4) void wn_fwd_layer_bf16(WnGemmArgsBf16 ga, W
     g2.relu_a = g2.relu_c = 0; g2.mask = nullptr; g2.gate_t = g2.gate_g = nullptr; g2.c2 = WnRowMap{nullptr, 0, 0, 0}; g2.c2_first_row = 0; g2.gate_packed = 0;
     g2.a_skip_lo[0] = g2.a_skip_lo[1] = g2.a_skip_hi[0] = g2.a_skip_hi[1] = 0; g2.cin_skip_lo = 0; g2.bt1 = nullptr; g2.a_bf16 = 0; g2.c_bf16 = 0; g2.c_h = la.c_h;
     wn_gemm_epilogue<WN_EPI_PLAIN, 2>(g2, acc2, m0 + 32 * wr, 64 * wc, lane, stage);   // (after the loop's last barrier: the B chunks are done with)
+}
+
+// ---- The backward's counterpart of wn_fwd_layer_bf16: the dx product of layer l and the gate-derivative product of layer l - 1 in ONE
+// kernel (bf16 step, R = D = 128).  dx_l = dx' + [dF|dG](t) . Wfg(tap 1) + [dF|dG](t + d) . Wfg(tap 0) is a 128-row x 128-column tile
+// (K = 4D over two row-windowed views, as wn_fwd_gemm_bf16<WN_EPI_PLAIN, 4, true>); layer l - 1's dz = dx_l . Wres is a product over the SAME
+// rows with dx_l as its A operand -- the tile goes to HBM (the residual weight gradient and the next dx product's addend read it) AND
+// stays in LDS as bf16, Wres(l - 1) streams through LDS, and the second product's epilogue is the gate derivative (WN_EPI_GATE_BWD:
+// [dF|dG] of layer l - 1).  Unfused, dx_l (0.25 GB at config 5) is read back by the next launch and each launch pays its own tail.  Same
+// operands, same chunk order, same accumulation: bit-identical to the two kernels.
+__global__ __launch_bounds__(512, 4) void wn_bwd_layer_bf16(WnGemmArgsBf16 ga, WnGemmArgsBf16 gb) {
+    const WnGemmArgs& g = ga.g;    // the dx product (A stored as bf16: [dF|dG] of layer l)
+    const WnGemmArgs& g2 = gb.g;   // the gate-derivative product of layer l - 1 (its A operand is this kernel's output tile)
+    constexpr int NT = 512, TM = 128, TN = 128, KC = WN_GEMM_BF16_KC, LD = KC + 8;
+    constexpr int TPR = NT / TM, HK = KC / TPR;
+    constexpr int K2 = 128, N2 = 128, LD2 = K2 + 8;
+    static_assert(KC == 32 && HK == 8, "one 16-byte piece per loader thread and operand");
+    constexpr int STAGE_SHORTS = 8 * WN_EPI_TILE_FLOATS * 2, OPER_SHORTS = 2 * TM * LD + 2 * TN * LD, ZOFF = STAGE_SHORTS;
+    static_assert(2 * N2 * LD <= STAGE_SHORTS && OPER_SHORTS <= ZOFF + TM * LD2, "LDS plan of the fused kernels");
+    __shared__ __attribute__((aligned(16))) unsigned short smem_h[ZOFF + TM * LD2];
+    unsigned short (*a_s)[TM * LD] = reinterpret_cast<unsigned short (*)[TM * LD]>(smem_h);
+    unsigned short (*b_s)[TN * LD] = reinterpret_cast<unsigned short (*)[TN * LD]>(smem_h + 2 * TM * LD);
+    unsigned short* x_s = smem_h + ZOFF;
+    unsigned short (*b2_s)[N2 * LD] = reinterpret_cast<unsigned short (*)[N2 * LD]>(smem_h);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wr = wv & 3, wc = wv >> 2;
+    const long long m0 = (long long)blockIdx.x * TM;
+    const int bcol = tid >> 2, bpart = tid & 3;   // B loaders of both products: 128 columns x 4 pieces of 8 bf16 per chunk
+    wn_f16v acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
+    {   // ---- first product (wave (wr, wc): rows 32 wr .., columns 64 wc ..)
+        const int lrow = tid / TPR, lpart = tid % TPR;
+        const long long am = m0 + lrow;
+        const bool arow_ok = am < g.M;
+        const unsigned aq = arow_ok ? (unsigned)am / (unsigned)g.rows_per_batch : 0u, arem = arow_ok ? (unsigned)am - aq * (unsigned)g.rows_per_batch : 0u;
+        const bool ok0 = arow_ok && (int)arem >= g.a_skip_lo[0] && (int)arem < g.rows_per_batch - g.a_skip_hi[0];
+        const bool ok1 = arow_ok && (int)arem >= g.a_skip_lo[1] && (int)arem < g.rows_per_batch - g.a_skip_hi[1];
+        const unsigned short* a0p = reinterpret_cast<const unsigned short*>(g.a0.base) + (long long)aq * g.a0.batch_stride + (g.a0.t0 + (long long)arem) * g.a0.row_stride + lpart * HK;
+        const unsigned short* a1p = reinterpret_cast<const unsigned short*>(g.a1.base) + (long long)aq * g.a1.batch_stride + (g.a1.t0 + (long long)arem) * g.a1.row_stride + lpart * HK;
+        const bool bcol_ok = bcol < g.N;
+        const int ldb = ga.ldb ? ga.ldb : g.K;
+        const unsigned short* bp0 = ga.bn + (size_t)bcol * ldb + bpart * 8;
+        const unsigned short* bp1 = ga.bn1 ? ga.bn1 + (size_t)bcol * ldb + bpart * 8 : bp0 + g.k_split;
+        float4 va;
+        uint4 vb;
+        auto fetch = [&](int kc) {
+            const int k0 = kc * KC;
+            const bool first = k0 < g.k_split, ok = first ? ok0 : ok1;
+            const unsigned short* src = (first ? a0p : a1p) + (first ? k0 : k0 - g.k_split);
+            va = ok ? *reinterpret_cast<const float4*>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const uint4* bsrc = reinterpret_cast<const uint4*>(first ? bp0 + k0 : bp1 + (k0 - g.k_split));
+            vb = bcol_ok ? *bsrc : make_uint4(0u, 0u, 0u, 0u);
+        };
+        auto stash = [&](int buf) {
+            *reinterpret_cast<float4*>(a_s[buf] + lrow * LD + lpart * HK) = va;
+            *reinterpret_cast<uint4*>(b_s[buf] + bcol * LD + bpart * 8) = vb;
+        };
+        const int nchunks = g.K / KC;
+        fetch(0);
+        stash(0);
+        __syncthreads();
+        for (int kc = 0; kc < nchunks; ++kc) {
+            const int buf = kc & 1;
+            if (kc + 1 < nchunks) fetch(kc + 1);
+            const unsigned short* ar = a_s[buf] + (32 * wr + (lane & 31)) * LD + 8 * (lane >> 5);
+            const unsigned short* br = b_s[buf] + (64 * wc + (lane & 31)) * LD + 8 * (lane >> 5);
+#pragma unroll
+            for (int ks = 0; ks < KC / 16; ++ks) {
+                const wn_bf16x8 a = *reinterpret_cast<const wn_bf16x8*>(ar + 16 * ks);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const wn_bf16x8 b = *reinterpret_cast<const wn_bf16x8*>(br + 32 * j * LD + 16 * ks);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[j], 0, 0, 0);
+                }
+            }
+            if (kc + 1 < nchunks) stash(buf ^ 1);
+            __syncthreads();
+        }
+    }
+    float* stage = reinterpret_cast<float*>(smem_h) + wv * WN_EPI_TILE_FLOATS;
+    // ---- dx_l: to HBM (fp32) and into the LDS image (bf16: what the second product's loader would round it to)
+    wn_gemm_epilogue<WN_EPI_PLAIN, 2>(g, acc, m0 + 32 * wr, 64 * wc, lane, stage, x_s + (32 * wr) * LD2, LD2);
+    __syncthreads();   // the image is complete, the staging tiles are free
+    wn_f16v acc2[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc2[j][i] = 0.f;
+    {   // ---- second product: dz tile = image . Wres(l - 1)  ([D][R] bf16, K = R contiguous)
+        const unsigned short* bp = gb.bn + (size_t)bcol * K2 + bpart * 8;
+        uint4 vb2 = *reinterpret_cast<const uint4*>(bp);
+        *reinterpret_cast<uint4*>(b2_s[0] + bcol * LD + bpart * 8) = vb2;
+        __syncthreads();
+        const unsigned short* xr = x_s + (32 * wr + (lane & 31)) * LD2 + 8 * (lane >> 5);
+#pragma unroll
+        for (int kc = 0; kc < K2 / KC; ++kc) {
+            const int buf = kc & 1;
+            if (kc + 1 < K2 / KC) vb2 = *reinterpret_cast<const uint4*>(bp + (kc + 1) * KC);
+            const unsigned short* br = b2_s[buf] + (64 * wc + (lane & 31)) * LD + 8 * (lane >> 5);
+#pragma unroll
+            for (int ks = 0; ks < KC / 16; ++ks) {
+                const wn_bf16x8 a = *reinterpret_cast<const wn_bf16x8*>(xr + KC * kc + 16 * ks);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const wn_bf16x8 b = *reinterpret_cast<const wn_bf16x8*>(br + 32 * j * LD + 16 * ks);
+                    acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc2[j], 0, 0, 0);
+                }
+            }
+            if (kc + 1 < K2 / KC) *reinterpret_cast<uint4*>(b2_s[buf ^ 1] + bcol * LD + bpart * 8) = vb2;
+            __syncthreads();
+        }
+    }
+    wn_gemm_epilogue<WN_EPI_GATE_BWD, 2>(g2, acc2, m0 + 32 * wr, 64 * wc, lane, stage);   // [dF|dG] of layer l - 1
 }
 
 // out[i] = bf16(in[i]) (round to nearest even): the backward products' weight operands, [N][K] row-major, are the forward

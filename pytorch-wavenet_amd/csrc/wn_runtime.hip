@@ -84,6 +84,23 @@ static bool wn_launch_layer(hipStream_t st, const WnGemmArgs& a, const unsigned 
     return true;
 }
 
+// The backward's fused pair (wn_bwd_layer_bf16): `a` = the dx product of layer l (bf16-stored A in two views, weight banks bn / bn1 with row
+// length ldb), `b` = the gate-derivative product of layer l - 1, whose A operand is `a`'s output.  Returns false when the shapes are not
+// the fused kernel's (the caller launches the two products).
+static bool wn_launch_bwd_layer(hipStream_t st, const WnGemmArgs& a, const unsigned short* bn, const unsigned short* bn1, int ldb,
+                                const WnGemmArgs& b, const unsigned short* bn_res) {
+    if (!bn || !bn_res || !a.a_bf16 || a.N != 128 || a.K % 32 != 0 || a.bias || a.relu_a || a.relu_c || a.mask || a.c_h ||
+        b.N != 128 || b.K != 128 || !b.c_bf16 || !b.gate_packed || b.M != a.M || b.rows_per_batch != a.rows_per_batch) return false;
+    if (b.a0.base != a.c.base || b.a0.t0 != a.c.t0 || b.a0.batch_stride != a.c.batch_stride || b.a0.row_stride != a.c.row_stride) return false;   // (the same rows)
+    if (!wn_fused_layer_enabled()) return false;
+    { const char* off = wn_dev_env("WN_NO_FUSED_BWD"); if (off && off[0] == '1') return false; }   // (A/B: the forward's fused layer alone)
+    WnGemmArgsBf16 x, y;
+    x.g = a; x.bn = bn; x.bn1 = bn1; x.ldb = ldb;
+    y.g = b; y.bn = bn_res; y.bn1 = nullptr; y.ldb = 0;
+    hipLaunchKernelGGL(wn_bwd_layer_bf16, dim3((unsigned)((a.M + 127) / 128)), dim3(512), 0, st, x, y);
+    return true;
+}
+
 // ------------------------------------------------------------------------------------------------ runtime shim
 static const char* g_hip_what = "";
 static int rt_hip(hipError_t e, const char* what) {

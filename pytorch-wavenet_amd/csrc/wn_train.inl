@@ -409,28 +409,43 @@ extern "C" int wn_train_backward(wn_handle* h, const float* params, const float*
     // ---- layers, last to first
     float* dxn = ws + t.dxa;  // dLoss/dx_{l+1}
     float* dxc = ws + t.dxb;  // dLoss/dx_l
+    // The arguments of layer k's gate-derivative product dz = dx' . Wres -> [dF | dG] (+ the layer's share of dzg on the skip rows): the
+    // gate derivative is the product's epilogue (WN_EPI_GATE_BWD), dz is never written (round 2: dz to HBM, then a streaming gate kernel).
+    auto gate_bwd_args = [&](int k, const float* dx_in, WnGemmArgs& o) {
+        const long long rows_k = t.need[k + 1], t0_k = L - rows_k;
+        const int gi_k = k % t.G, first_k = k - gi_k, cnt_k = NL - first_k < t.G ? NL - first_k : t.G;
+        float* dzg_k = ws + t.dzg + (size_t)(k / t.G) * ((size_t)Mo * t.G * D);
+        memset(&o, 0, sizeof(o));
+        o.a0 = o.a1 = WnRowMap{dx_in, L * (long long)R, R, t0_k};
+        o.k_split = R; o.K = R; o.bt = ws + t.res_o + (size_t)k * R * D; o.N = D;
+        o.c = WnRowMap{ws + ((k & 1) ? t.dfg2 : t.dfg), rows_k * 2 * D, 2 * D, 0}; o.c_bf16 = t.bf16 ? 1 : 0;   // bf16 step: [dF|dG] is STORED as bf16 (it only ever feeds bf16 matrix operands)
+        o.c2 = WnRowMap{dzg_k + (size_t)gi_k * D, out_len * (long long)cnt_k * D, (long long)cnt_k * D, 0};
+        o.c2_first_row = (int)(rows_k - out_len);
+        o.gate_t = ws + t.th[k]; o.gate_g = ws + t.sg[k]; o.gate_packed = t.bf16 ? 1 : 0;
+        o.M = N * rows_k; o.rows_per_batch = (int)rows_k;
+    };
+    // what the chain has to wait for before it may write layer k's [dF|dG]: the buffer's previous reader (dWfg of layer k + 2, side stream)
+    // and -- entering a block from above -- the block's dzg (side stream, enqueued before the loop)
+    auto gate_bwd_waits = [&](int k) {
+        if (k + 2 < NL) wait_for(st, fg_read[k + 2]);
+        const int gi_k = k % t.G, first_k = k - gi_k, cnt_k = NL - first_k < t.G ? NL - first_k : t.G;
+        if (gi_k == cnt_k - 1) wait_for(st, dzg_ready[k / t.G]);
+    };
+    bool have_dfg = false;   // [dF|dG] of the layer at hand came out of the previous iteration's fused launch (wn_bwd_layer_bf16)
     for (int l = NL - 1; l >= 0; --l) {
         const long long d = h->dil[l], rows = t.need[l + 1], t0 = L - rows, M = N * rows;
         const float* xin = ws + t.x[l];
         const float* z = ws + t.z[l];
         const bool has_res = l < NL - 1;
         float* dfg = ws + ((l & 1) ? t.dfg2 : t.dfg);
-        if (l + 2 < NL) wait_for(st, fg_read[l + 2]);   // (this layer's [dF|dG] overwrites the buffer of layer l + 2)
         const int gi = l % t.G, first = l - gi, cnt = NL - first < t.G ? NL - first : t.G;
         float* dzg = ws + t.dzg + (size_t)(l / t.G) * ((size_t)Mo * t.G * D);
-        if (gi == cnt - 1) wait_for(st, dzg_ready[l / t.G]);   // entering a block from above: its dzg (side stream, enqueued before the loop)
+        if (!have_dfg) gate_bwd_waits(l);
         if (has_res) {
-            // [dF | dG] straight from the product dz = dx' . Wres (+ this layer's share of dzg on the skip rows): the gate derivative is
-            // the product's epilogue (WN_EPI_GATE_BWD), dz is never written (round 2: dz to HBM, then a streaming gate kernel).
-            memset(&a, 0, sizeof(a));
-            a.a0 = a.a1 = WnRowMap{dxn, L * (long long)R, R, t0};
-            a.k_split = R; a.K = R; a.bt = ws + t.res_o + (size_t)l * R * D; a.N = D;
-            a.c = WnRowMap{dfg, rows * 2 * D, 2 * D, 0}; a.c_bf16 = t.bf16 ? 1 : 0;   // bf16 step: [dF|dG] is STORED as bf16 (it only ever feeds bf16 matrix operands)
-            a.c2 = WnRowMap{dzg + (size_t)gi * D, out_len * (long long)cnt * D, (long long)cnt * D, 0};
-            a.c2_first_row = (int)(rows - out_len);
-            a.gate_t = ws + t.th[l]; a.gate_g = ws + t.sg[l]; a.gate_packed = t.bf16 ? 1 : 0;
-            a.M = M; a.rows_per_batch = (int)rows;
-            wn_launch_nn(st, WN_EPI_GATE_BWD, a, bw ? bw + h->fw_off_res + (size_t)l * D * R : nullptr);
+            if (!have_dfg) {
+                gate_bwd_args(l, dxn, a);
+                wn_launch_nn(st, WN_EPI_GATE_BWD, a, bw ? bw + h->fw_off_res + (size_t)l * D * R : nullptr);
+            }
             memset(&g, 0, sizeof(g));   // dWres^T [D][R] = z^T . dx'
             g.a = WnRowMap{z, rows * D, D, 0}; g.b = WnRowMap{dxn, L * (long long)R, R, t0};
             g.Ka = D; g.Nb = R; g.c = grads + h->fw_off_res + (size_t)l * D * R; g.ldc = R; g.M = M; g.rows_per_batch = (int)rows;
@@ -493,9 +508,20 @@ extern "C" int wn_train_backward(wn_handle* h, const float* params, const float*
         a.M = N * rows_l; a.rows_per_batch = (int)rows_l;
         {
             const unsigned short* w = bw ? bw + h->fw_off_fg + (size_t)l * 2 * R * 2 * D : nullptr;  // native [2R][2D]: rows 0..R-1 tap 0, R.. tap 1
-            wn_launch_nn(st, WN_EPI_PLAIN, a, w ? w + (size_t)R * 2 * D : nullptr, w, 2 * D);
+            // bf16 step, the 128 / 128 shape: this product and layer l - 1's gate-derivative product (same rows, dx_l as its A operand) are
+            // ONE launch -- dx_l is handed over in LDS (wn_bwd_layer_bf16).  Layer l - 1's waits move in front of it.
+            have_dfg = false;
+            if (t.bf16 && l >= 1 && w) {
+                WnGemmArgs ag;
+                gate_bwd_args(l - 1, dxc, ag);
+                if (ag.M == a.M && ag.a0.t0 == a.c.t0 && R == 128 && D == 128 && wn_fused_layer_enabled()) {
+                    gate_bwd_waits(l - 1);
+                    have_dfg = wn_launch_bwd_layer(st, a, w + (size_t)R * 2 * D, w, 2 * D, ag, bw + h->fw_off_res + (size_t)(l - 1) * D * R);
+                }
+            }
+            if (!have_dfg) wn_launch_nn(st, WN_EPI_PLAIN, a, w ? w + (size_t)R * 2 * D : nullptr, w, 2 * D);
         }
-        wait_for(sd, signal(st));   // dx_l is complete: dWres of layer l - 1 may read it
+        wait_for(sd, signal(st));   // dx_l is complete: dWres of layer l - 1 may read it (fused: [dF|dG] of layer l - 1 as well)
         float* tmp = dxn; dxn = dxc; dxc = tmp;
     }
     wait_for(st, signal(sd));   // join: every weight gradient is complete before the caller's stream goes on
