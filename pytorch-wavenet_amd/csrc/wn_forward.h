@@ -594,8 +594,8 @@ struct WnLayerArgs {
     unsigned short* c_h;       // optional bf16 copy of the output (WnGemmArgs::c_h)
     int N;                     // R
 };
-template <bool A16>
 __global__ __launch_bounds__(512, 4) void wn_fwd_layer_bf16(WnGemmArgsBf16 ga, WnLayerArgs la) {
+    constexpr bool A16 = true;   // x comes from its bf16 shadow (the callers have one wherever this kernel applies)
     const WnGemmArgs& g = ga.g;
     constexpr int NT = 512, TM = 128, TN = 256, KC = WN_GEMM_BF16_KC, LD = KC + 8;
     constexpr int TPR = NT / TM, HK = KC / TPR, HB = KC / 2;

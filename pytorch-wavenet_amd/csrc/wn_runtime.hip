@@ -72,15 +72,15 @@ static void wn_launch_nn(hipStream_t st, int epi, const WnGemmArgs& a, const uns
 // kernel's (the caller launches the two products).  WN_NO_FUSED_LAYER=1 (with WN_TESTING=1) switches it off for A/B runs.
 static bool wn_fused_layer_enabled() { const char* off = wn_dev_env("WN_NO_FUSED_LAYER"); return !(off && off[0] == '1'); }
 static bool wn_launch_layer(hipStream_t st, const WnGemmArgs& a, const unsigned short* bn_fg, const WnGemmArgs& r, const unsigned short* bn_res) {
-    if (!bn_fg || !bn_res || a.N != 256 || r.N != 128 || r.K != 128 || a.K % 32 != 0 || !a.c_bf16 || a.relu_a || r.relu_a || r.relu_c || r.mask || r.cin_skip_lo) return false;
+    if (!bn_fg || !bn_res || !a.a_bf16 || a.N != 256 || r.N != 128 || r.K != 128 || a.K % 32 != 0 || a.k_split % 32 != 0 || !a.c_bf16 || a.relu_a || r.relu_a || r.relu_c ||
+        r.mask || r.cin_skip_lo || r.M != a.M || r.rows_per_batch != a.rows_per_batch) return false;   // (x from its bf16 shadow, z kept as bf16, the same rows in both products)
     if (!wn_fused_layer_enabled()) return false;
     WnGemmArgsBf16 b;
     b.g = a; b.bn = bn_fg; b.bn1 = nullptr; b.ldb = 0;
     WnLayerArgs la;
     la.bn = bn_res; la.bias = r.bias; la.cin = r.cin; la.c = r.c; la.c_h = r.c_h; la.N = r.N;
     const dim3 grid((unsigned)((a.M + 127) / 128));
-    if (a.a_bf16) hipLaunchKernelGGL((wn_fwd_layer_bf16<true>), grid, dim3(512), 0, st, b, la);
-    else hipLaunchKernelGGL((wn_fwd_layer_bf16<false>), grid, dim3(512), 0, st, b, la);
+    hipLaunchKernelGGL(wn_fwd_layer_bf16, grid, dim3(512), 0, st, b, la);
     return true;
 }
 
