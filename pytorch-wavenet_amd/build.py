@@ -74,17 +74,23 @@ def check_hand_scheduled_registers(so, objdump=None):
         co = [f for f in os.listdir(tmp) if "gfx950" in f]
         if len(co) != 1:
             raise RuntimeError("expected one gfx950 code object in %s, found %r" % (so, co))
-        dis = subprocess.check_output([objdump, "-d", os.path.join(tmp, co[0])]).decode()
+        dis = subprocess.check_output([objdump, "-d", "--symbolize-operands", os.path.join(tmp, co[0])]).decode()   # (branch targets as labels <Ln>: rule 4 follows them)
     reserved = set(range(RESERVED_FIRST, RESERVED_LAST + 1))
     is_res = lambda tok: bool(_regs(tok) & reserved)  # noqa: E731
     seen, current, prev = 0, None, ""
-    history = []   # the last instructions of the kernel being read (hazard check below)
+    items = {}     # kernel -> its instructions and branch-target labels in address order: ("ins", text) / ("label", name)  (rule 4)
     fifo_waits = {"s_waitcnt vmcnt(%d)" % n for n in (5, 6, 10, 11)}  # WN_V3_TAP_AHEAD = 6: D - 1, D, 2 D - 2, 2 D - 1 younger operations
     for line in dis.splitlines():
         m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
         if m:
+            if re.fullmatch(r"L\d+", m.group(1)):   # a branch target inside the current kernel (--symbolize-operands)
+                if current and "wn_generate_kernel_v3m" in current:
+                    items[current].append(("label", m.group(1)))
+                continue
             current = m.group(1)
-            seen += "wn_generate_kernel_v3m" in current
+            if "wn_generate_kernel_v3m" in current:
+                seen += 1
+                items[current] = []
             continue
         if not current or "wn_generate_kernel_v3m" not in current:
             continue
@@ -92,9 +98,7 @@ def check_hand_scheduled_registers(so, objdump=None):
         if not text:
             continue
         before, prev = prev, text
-        history.append(text)
-        if len(history) > 8:
-            history.pop(0)
+        items[current].append(("ins", text))
         op, _, rest = text.partition(" ")
         ops = [o.strip() for o in rest.split(",")]
         regs = _regs(text)
@@ -107,25 +111,6 @@ def check_hand_scheduled_registers(so, objdump=None):
         where = "%s: %s" % (current, text)
         if op == "global_load_dwordx2":      # a request set: destination pair inside the reserved range, address operands outside
             ok = re.fullmatch(r"v\[(\d+):(\d+)\]", ops[0]) and _regs(ops[0]) <= reserved and not any(is_res(o) for o in ops[1:])
-            # (4) its SGPR base must not have been written by a VALU instruction (v_readlane_b32 of a spilled pointer, ...) within the last
-            # five wait states: the hazard recognizer does not look into inline assembly (see WN_AP_SGPR_HAZARD in wn_kernel_v3.h)
-            m2 = re.search(r"\bs\[(\d+):(\d+)\]", ops[2] if len(ops) > 2 else "")
-            if ok and m2:
-                base = set(range(int(m2.group(1)), int(m2.group(2)) + 1))   # registers of the pair whose last writer has not been seen yet
-                waited = 0
-                for old in reversed(history[:-1]):
-                    if waited >= 5 or not base:
-                        break
-                    o_op, _, o_rest = old.partition(" ")
-                    dst = o_rest.split(",")[0].strip()
-                    if re.fullmatch(r"s\d+|s\[\d+:\d+\]", dst):
-                        d = [int(x) for x in re.findall(r"\d+", dst)]
-                        d = set(range(d[0], d[-1] + 1))
-                        if o_op.startswith("v_") and d & base:
-                            raise RuntimeError("%s: the SGPR base of a hand-scheduled load is written by `%s` %d wait state(s) before it (5 needed)" % (where, old, waited))
-                        if o_op.startswith("s_"):
-                            base -= d   # (written by the scalar unit: no hazard, and whatever wrote it before does not matter)
-                    waited += int(o_rest) + 1 if o_op == "s_nop" else 1
         elif op == "global_load_dword":      # the tap FIFO: destination v152-v157, address outside
             ok = ops[0] in ("v152", "v153", "v154", "v155", "v156", "v157") and not any(is_res(o) for o in ops[1:])
         elif op == "v_cmp_eq_u32_e32":       # vcc = (tag == v<reserved>): reserved register as the LAST source only
@@ -142,7 +127,65 @@ def check_hand_scheduled_registers(so, objdump=None):
             raise RuntimeError("use of a reserved poll register outside the hand-scheduled blocks in " + where)
     if not seen:
         raise RuntimeError("no wn_generate_kernel_v3m kernel found in %s" % so)
+    for kernel, seq in items.items():
+        _check_sgpr_base_hazard(kernel, seq, reserved)
     return seen
+
+
+def _check_sgpr_base_hazard(kernel, seq, reserved):
+    """Rule 4: the SGPR pair a hand-scheduled load (destination in the reserved range) takes its base address from must not have been
+    written by a VALU instruction (v_readlane_b32 of a spilled pointer, a compare, ...) within the last FIVE wait states on ANY path
+    that leads to the load -- a gfx9 hazard the backend resolves for its own instructions but not in front of inline assembly (see
+    WN_AP_SGPR_HAZARD in wn_kernel_v3.h).  `seq` is the kernel in address order, instructions and branch-target labels; the walk goes
+    backwards through fall-throughs and through every branch that targets a label it meets (each instruction one wait state, s_nop n
+    counts n + 1), until five wait states have passed or the scalar unit is found to have written the registers last."""
+    import re
+    targets = {}   # label -> indices of the branches that jump to it
+    for i, (kind, text) in enumerate(seq):
+        if kind == "ins" and text.startswith(("s_cbranch", "s_branch")):
+            m = re.search(r"\b(L\d+)\b", text)
+            if m:
+                targets.setdefault(m.group(1), []).append(i)
+
+    def walk(i, waited, pending, load, seen_states):
+        # i: index of the next item to look at (going backwards); pending: registers of the pair whose last writer has not been seen yet
+        while i >= 0 and waited < 5 and pending:
+            kind, text = seq[i]
+            if kind == "label":
+                for b in targets.get(text, ()):   # every branch to this label is a predecessor (the branch itself is looked at there)
+                    key = (b, waited, frozenset(pending))
+                    if key not in seen_states:
+                        seen_states.add(key)
+                        walk(b, waited, set(pending), load, seen_states)
+                # the fall-through predecessor -- unless the instruction in front is an unconditional transfer
+                k = i - 1
+                while k >= 0 and seq[k][0] == "label":
+                    k -= 1
+                if k >= 0 and seq[k][1].split(" ")[0] in ("s_branch", "s_endpgm", "s_setpc_b64", "s_swappc_b64"):
+                    return
+                i -= 1
+                continue
+            op, _, rest = text.partition(" ")
+            dst = rest.split(",")[0].strip()
+            if re.fullmatch(r"s\d+|s\[\d+:\d+\]", dst):
+                d = [int(x) for x in re.findall(r"\d+", dst)]
+                d = set(range(d[0], d[-1] + 1))
+                if op.startswith("v_") and d & pending:
+                    raise RuntimeError("%s: %s: the SGPR base of a hand-scheduled load is written by `%s` %d wait state(s) before it (5 needed)" % (kernel, load, text, waited))
+                if op.startswith("s_"):
+                    pending = pending - d   # (written by the scalar unit: no hazard, and whatever wrote it before does not matter)
+            waited += int(rest) + 1 if op == "s_nop" and rest.strip().isdigit() else 1
+            i -= 1
+
+    for i, (kind, text) in enumerate(seq):
+        if kind != "ins" or not text.startswith("global_load_dwordx2 "):
+            continue
+        ops = [o.strip() for o in text.partition(" ")[2].split(",")]
+        if not (_regs(ops[0]) and _regs(ops[0]) <= reserved) or len(ops) < 3:
+            continue
+        m = re.search(r"\bs\[(\d+):(\d+)\]", ops[2])
+        if m:
+            walk(i - 1, 0, set(range(int(m.group(1)), int(m.group(2)) + 1)), text, set())
 
 
 def _regs(text):

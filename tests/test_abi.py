@@ -158,7 +158,8 @@ def test_reserved_poll_registers_belong_to_the_hand_scheduled_blocks_only(tmp_pa
     fake = tmp_path / "objdump.py"   # a stand-in disassembler: feeds the checker hand-written listings
 
     def run(body):
-        listing = "0000000000001000 <_Z22wn_generate_kernel_v3mILi128EEv6WnPlan5WnRun>:\n" + "".join("\t%s   // 0: 0\n" % ln for ln in body)
+        listing = "0000000000001000 <_Z22wn_generate_kernel_v3mILi128EEv6WnPlan5WnRun>:\n" + "".join(
+            ("0000000000002000 %s:\n" % ln) if ln.startswith("<") else ("\t%s   // 0: 0\n" % ln) for ln in body)   # ("<L3>": a branch-target label)
         (tmp_path / "listing.txt").write_text(listing)
         fake.write_text("#!/usr/bin/env python3\nimport sys, os\n"
                         "if '--offloading' in sys.argv: open('x.gfx950', 'w').close()\n"
@@ -196,6 +197,16 @@ def test_reserved_poll_registers_belong_to_the_hand_scheduled_blocks_only(tmp_pa
                 ["v_readlane_b32 s10, v128, 20", "v_readlane_b32 s11, v128, 21"],                  # another pair
                 ["v_readlane_b32 s12, v128, 20", "v_readlane_b32 s13, v128, 21", "s_add_u32 s12, s12, s4", "s_addc_u32 s13, s13, 0"]):   # last written by the SALU: no hazard
         assert run(good + pre + [load]) == 1
+    # ... on EVERY path to the load: the walk follows the branches that target a label in front of it
+    rl = ["v_readlane_b32 s12, v128, 20", "v_readlane_b32 s13, v128, 21"]
+    with pytest.raises(RuntimeError, match="SGPR base of a hand-scheduled load"):   # the fall-through is long enough, the taken branch is not
+        run(good + rl + ["s_cbranch_vccnz L7", "s_nop 4", "v_mov_b32_e32 v3, 0", "<L7>", load])
+    with pytest.raises(RuntimeError, match="SGPR base of a hand-scheduled load"):   # two hops
+        run(good + rl + ["s_cbranch_scc1 L5", "s_nop 4", "<L5>", "s_cbranch_vccz L6", "s_nop 4", "<L6>", load])
+    assert run(good + rl + ["s_nop 4", "s_cbranch_vccnz L7", "v_mov_b32_e32 v3, 0", "<L7>", load]) == 1          # five wait states in front of the branch
+    assert run(good + rl + ["s_branch L9", "<L8>", load, "<L9>", "s_nop 0"]) == 1                                 # no fall-through behind s_branch, nobody jumps to L8
+    with pytest.raises(RuntimeError, match="SGPR base of a hand-scheduled load"):   # a loop's back edge
+        run(good + ["s_nop 4", "<L2>", load] + rl + ["s_cbranch_scc1 L2"])
 
 
 def test_graft_entry_build_runs():
