@@ -602,6 +602,33 @@ def test_wave_specialised_kernel_two_way_split(ns, mode, monkeypatch):
     eng.close()
 
 
+def test_two_slice_form_under_address_space_churn(monkeypatch):
+    """The scenario in which round 4's SGPR hazard showed (a stale base pointer in the hand-scheduled input poll: a memory access fault
+    only where nothing happened to be mapped at the stale address): the two-slice form again and again while tensors of odd sizes come
+    and go and the caching allocator hands its blocks back -- tools/stress_split.py in small; build.py's disassembly rule is the real
+    guard, this is the canary.  Outputs are checked for sanity only (the forms' parity is the test above)."""
+    import torch
+    rs = np.random.RandomState(0)
+    cfg = synth.CONFIGS["cfg2"]
+    W = synth.init_weights(cfg, seed=83)
+    junk = []
+    for it in range(3):
+        for ns, mode in ((1, 0), (6, 3)):
+            monkeypatch.setenv("WN_V3_MODE", str(mode))
+            for _ in range(4):
+                junk.append(torch.empty(int(rs.randint(1, 64)) << 20, dtype=torch.uint8, device="cuda"))
+            if len(junk) > 8:
+                for _ in range(5):
+                    junk.pop(int(rs.randint(0, len(junk))))
+                torch.cuda.empty_cache()
+            first = rs.randint(0, 256, (ns, 600)).astype(np.int32)
+            eng = engine.Engine(cfg, W, n_streams=ns, layer_split=2)
+            a = eng.generate(40, first, temperature=0.0, batched_prime=False, timeout_ms=8000)
+            b = eng.generate(40, first, temperature=0.9, regularize=0.002, uniforms=rs.random_sample((ns, 40)), batched_prime=False, timeout_ms=8000)
+            eng.close()
+            assert a.shape == b.shape == (ns, 40) and 0 <= int(a.min()) and int(a.max()) < 256 and 0 <= int(b.min()) and int(b.max()) < 256
+
+
 FORMS = [("cfg2_ns6", "cfg2", 6, 60, 600), ("cfg1_ns8_bias", dict(synth.CONFIGS["cfg1"], bias=True), 8, 120, 40), ("mini3_ns4", MINI3, 4, 160, 9), ("mini3_ns12", MINI3, 12, 120, 30), ("mini3_bias_ns10", dict(MINI3, bias=True), 10, 120, 4),
          ("mini3_ns7_odd", MINI3, 7, 100, 12), ("cfg3_ns6", "cfg3", 6, 60, 700), ("mini3_ns64", MINI3, 64, 100, 3)]
 
