@@ -1532,8 +1532,10 @@ static __device__ void wn_v3_sampler(const WnPlan& p, const WnRun& r, WnCtx& cx,
         for (int s = j; s < ns; s += p.n_smp) {
             const long long item = (e - 1) * ns + s;  // stamps (diagnostics): 0 start of the wait, 1 logits complete, 2 row published
             wn_stamp(r, park, item, 0);
-            // what the draw needs besides the logits is requested BEFORE the wait for them: a global load behind the logits' arrival
-            // would sit on the ring (a single stream's timestep is 8 - 20 us, an HBM miss is half a microsecond of it)
+            // The item's uniform (streamed from HBM, eight bytes per item) is requested BEFORE the wait for the logits: a global load behind
+            // their arrival sat on the ring (a single stream's timestep is 8 - 20 us, an HBM miss is half a microsecond of it).  The
+            // temperature and the given sample (kernel argument / L2 hits) stay behind the wait -- asking for them early as well raised
+            // the kernels' scalar pressure to where the input poll's base pointers were spilled (WN_AP_SGPR_HAZARD).
             // (+ lane0: 0 for every lane of this wave, unknown to the compiler -- vector loads into VGPRs; as scalar loads the values sit in
             //  SGPRs across the poll, and the kernel's scalar registers are already spilling into VGPR lanes)
             const long long g = e - r.n_given;
