@@ -209,6 +209,52 @@ def test_reserved_poll_registers_belong_to_the_hand_scheduled_blocks_only(tmp_pa
         run(good + ["s_nop 4", "<L2>", load] + rl + ["s_cbranch_scc1 L2"])
 
 
+def test_build_falls_back_to_the_wait_states_only_when_the_disassembly_demands_them(monkeypatch, tmp_path):
+    """build_hip compiles the form WITHOUT the five wait states in front of the hand-scheduled blocks first (-DWN_AP_SGPR_HAZARD="") and
+    keeps it only if check_hand_scheduled_registers accepts the result; a hazard finding makes it compile the source's default (with
+    them); any other finding, or a hazard in the default form, is an error and nothing is installed."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "pytorch-wavenet_amd"))
+    import build
+    out = tmp_path / "libwn_mi355.so"
+    monkeypatch.setattr(build, "OUT", str(out))
+    monkeypatch.setattr(build, "_stale", lambda *a: True)
+    calls, verdicts = [], []
+
+    def fake_compile(cmd, **kw):
+        calls.append([c for c in cmd if c.startswith("-DWN_AP_SGPR_HAZARD")])
+        open(cmd[cmd.index("-o") + 1], "wb").write(b"x")
+
+    def fake_check(path, objdump=None):
+        v = verdicts.pop(0)
+        if v:
+            raise RuntimeError(v)
+        return 11
+
+    monkeypatch.setattr(build.subprocess, "check_call", fake_compile)
+    monkeypatch.setattr(build, "check_hand_scheduled_registers", fake_check)
+    hazard = "k: load: the SGPR base of a hand-scheduled load is written by `v_readlane_b32 s9, v128, 21` 1 wait state(s) before it (5 needed)"
+    verdicts[:] = [None]                       # clean at the first attempt: the fast form is installed
+    assert build.build_hip(force=True) == str(out) and calls == [['-DWN_AP_SGPR_HAZARD=""']] and out.exists()
+    calls.clear(); out.unlink()
+    verdicts[:] = [hazard, None]               # hazard: second compile without the define (the source's default), installed
+    assert build.build_hip(force=True) == str(out) and calls == [['-DWN_AP_SGPR_HAZARD=""'], []] and out.exists()
+    calls.clear(); out.unlink()
+    verdicts[:] = [hazard, hazard]             # still there with the wait states: refused
+    with pytest.raises(RuntimeError):
+        build.build_hip(force=True)
+    assert not out.exists() and not os.path.exists(str(out) + ".tmp")
+    calls.clear()
+    verdicts[:] = ["k: use of a reserved poll register outside the hand-scheduled blocks in ..."]   # another rule: no second attempt
+    with pytest.raises(RuntimeError):
+        build.build_hip(force=True)
+    assert calls == [['-DWN_AP_SGPR_HAZARD=""']] and not out.exists()
+    calls.clear()
+    verdicts[:] = [None]                       # a caller that pins the macro gets exactly one attempt with its value
+    build.build_hip(force=True, extra_flags=('-DWN_AP_SGPR_HAZARD="s_nop 4\\n\\t"',))
+    assert len(calls) == 1 and calls[0][0].startswith('-DWN_AP_SGPR_HAZARD="s_nop')
+
+
 def test_graft_entry_build_runs():
     """The driver's "does it build" check (__graft_entry__.build()): builds the HIP library (checked: build.check_hand_scheduled_registers),
     the C oracle, loads the library through the binding and imports the facade -- on the CPU."""
