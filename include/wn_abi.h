@@ -16,19 +16,30 @@
  *     generate_fast from a daemon thread during training: model_logging.py:48-58).
  *   - wn_generate jobs are persistent kernels: every workgroup of a job must be resident before the job
  *     makes progress, and two jobs that do not fit the chip together would each get part of it and
- *     neither would ever run.  wn_generate therefore books the job's CUs (per XCD) in a per-device
- *     table shared by all processes on the host (a file in /dev/shm named after the device's PCI bus
- *     id, used under flock(); WN_GATE_DIR moves it) and WAITS -- bounded by WN_GATE_TIMEOUT_MS, default
- *     10 minutes, then WN_E_TIMEOUT -- until the jobs booked in front of it have finished whenever its
- *     booking does not fit next to theirs: two cfg3 jobs (220 of 256 CUs each) from two threads or two
- *     processes run one after the other, two cfg1 jobs (19 CUs) side by side.  Jobs one HIP stream
- *     already serialises (same process, same stream) share a booking: wn_generate stays asynchronous for
- *     them.  The booking is returned when the kernel finishes (a host function enqueued behind it), at
- *     the latest in wn_wait; bookings of processes that no longer exist are dropped.  Kernels that are not
- *     wn_generate jobs (a long torch kernel) are not booked: a job that finds CUs taken by one starts when
- *     they free up, and its hand-off timeout (timeout_ms) bounds every single hand-off wait.  A job is ONE
- *     persistent kernel (any stream count up to ~150 at cfg3's shape), or, beyond one chain's capacity,
- *     rounds of up to 128 streams, one kernel after the other on the caller's stream.
+ *     neither would ever run.  Two mechanisms make residency a requirement instead of a hope:
+ *     (1) ADMISSION.  wn_generate books the job's CUs (per XCD: the workgroups it keeps resident on its
+ *     fullest XCD) in a per-device table -- a file named after the device's PCI bus id, used under
+ *     flock(): /dev/shm/wn_mi355_gate_u<euid>_<busid>, mode 0600, shared by the processes of ONE user;
+ *     WN_GATE_DIR=<dir> names a directory an administrator prepared for all users of the device
+ *     (<dir>/wn_mi355_gate_<busid>).  The file is opened O_NOFOLLOW, created O_EXCL, and trusted only
+ *     after fstat() (regular, one link, the user's own, not world-writable); a table that fails the checks
+ *     is reported once on stderr and the device's gate is process-local from then on (wn_info.gate_shared
+ *     = 0).  A job whose booking does not fit WAITS -- first come first served, bounded by
+ *     WN_GATE_TIMEOUT_MS, default 10 minutes, then WN_E_TIMEOUT -- until the jobs in front of it have
+ *     finished: two cfg3 jobs (28 of 32 CUs per XCD each) from two threads or two processes run one after
+ *     the other, two cfg1 jobs side by side.  Jobs one HIP stream already serialises (same process, same
+ *     stream) share a booking: wn_generate stays asynchronous for them.  The booking is returned when the
+ *     kernel finishes (a host function enqueued behind it), at the latest in wn_wait; bookings of
+ *     processes that no longer exist are dropped.
+ *     (2) RESIDENCY BARRIER.  wn_create checks the plan against what the device can hold of the job's
+ *     kernel (hipOccupancyMaxActiveBlocksPerMultiprocessor), wn_generate against the stream's CU mask;
+ *     and every workgroup of a job checks in at start-up and enters the chain only when ALL have (kernels
+ *     that are not wn_generate jobs -- a long torch kernel -- are not booked: a job that finds CUs taken
+ *     by one starts when they free up).  That wait has its own bound (WN_RESIDENT_TIMEOUT_MS, default 60 s)
+ *     and its own error, WN_E_BUSY: nothing ran, queues unchanged, the call can be repeated.  The per-hand-off
+ *     bound (timeout_ms -> WN_E_TIMEOUT) only starts behind the barrier.
+ *     A job is ONE persistent kernel (any stream count up to ~150 at cfg3's shape), or, beyond one chain's
+ *     capacity, rounds of up to 128 streams, one kernel after the other on the caller's stream.
  */
 #ifndef WN_ABI_H
 #define WN_ABI_H
@@ -39,7 +50,8 @@
 extern "C" {
 #endif
 
-#define WN_ABI_VERSION 3  /* 3: per-device admission of persistent jobs (wn_info: gate_*), kernel variant 4 (layers_per_workgroup);
+#define WN_ABI_VERSION 4  /* 4: WN_E_BUSY (start-up residency barrier with its own bound, WN_RESIDENT_TIMEOUT_MS);
+                             3: per-device admission of persistent jobs (wn_info: gate_*), kernel variant 4 (layers_per_workgroup);
                              2: wn_train_loss; wn_info reports the form of the chain (streams_per_item, head_replicas, n_samplers) */
 
 enum {
@@ -49,7 +61,8 @@ enum {
     WN_E_HIP = -3,         /* a HIP runtime call failed (message carries hipGetErrorString) */
     WN_E_NOMEM = -4,
     WN_E_TIMEOUT = -5,     /* the persistent kernel gave up waiting on a hand-off (bounded spins) */
-    WN_E_STATE = -6        /* call order violated, e.g. generate before load_weights */
+    WN_E_STATE = -6,       /* call order violated, e.g. generate before load_weights */
+    WN_E_BUSY = -7         /* the job's workgroups did not all become resident (CUs held by other kernels): nothing ran, the call can be repeated */
 };
 
 /* Mirrors the constructor of WaveNetModel (wavenet_model.py:28-39) plus engine placement. */
@@ -139,10 +152,17 @@ typedef struct wn_info {
     int32_t n_samplers;       /* ... dedicated sampler workgroups (0: layer 0 samples itself, single-stream kernels of variant 1 / 2) */
     int32_t dev_overrides;    /* 1 iff WN_TESTING=1 let a development override (WN_KERNEL, WN_V3_MODE, ...) change what the planner chose */
     int32_t layers_per_workgroup; /* variant 4: consecutive layers one stack workgroup holds (hand-offs between them stay in LDS); 1 elsewhere */
-    int32_t gate_shared;      /* admission table of the LAST job: 1 = shared by all processes (file under /dev/shm), 0 = this process only
-                                 (no usable /dev/shm), -1 = no job yet */
+    int32_t gate_shared;      /* admission table of the LAST job: 1 = the shared table (see the header comment), 0 = this process only
+                                 (no usable table: said once on stderr), -1 = no job yet */
     int32_t gate_waited_ms;   /* how long the last job waited for jobs booked in front of it */
-    int32_t gate_need_per_xcd; /* CUs per XCD a job of this handle books (of n_compute_units / 8) */
+    int32_t gate_need_per_xcd; /* CUs per XCD a job of this handle books: the workgroups it keeps resident on its fullest XCD (of n_compute_units / 8) */
+    int32_t forward_native;   /* after wn_load_weights: 1 = wn_forward / wn_prime serve this handle's (padded) shape, 0 = they answer WN_E_UNSUPPORTED
+                                 for every call (kernel_size != 2, channel counts that are not multiples of 32 after padding); the facade keys its
+                                 "do not ask again" on THIS, not on the text of an error */
+    int32_t workgroups_per_cu; /* workgroups of the job's kernel ONE compute unit holds with the job's LDS (hipOccupancyMaxActiveBlocksPerMultiprocessor,
+                                  checked against the plan at wn_create) */
+    int32_t resident_timeout_ms; /* bound of the start-up residency barrier of the LAST job (WN_RESIDENT_TIMEOUT_MS, default 60 s); 0 = no job yet */
+    int32_t reserved_info;
 } wn_info;
 
 /* wn_config.reserved[0]: plan the model's OWN channel shape (no zero padding into a compiled kernel shape, see wn_create): what a

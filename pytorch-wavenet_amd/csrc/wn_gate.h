@@ -6,16 +6,27 @@
 // resident, both spin until their hand-off timeouts (WN_E_TIMEOUT).  The reference calls generate_fast from a daemon thread next to
 // the training loop (/root/reference/model_logging.py:48-58), so this is a use the drop-in has to survive.
 //
-// The gate: every job books the CUs it needs PER XCD (blocks are dispatched round-robin over the 8 XCDs, so a job of n blocks
-// needs ceil(n / 8) CUs on every XCD, and a full XCD stalls the dispatch however empty the others are) in a small table shared by
-// all processes that use the device -- a file in /dev/shm named after the device's PCI bus id, read and written under flock().
-// A job is admitted when its booking fits next to the bookings already there; otherwise wn_generate WAITS (bounded) until the
-// jobs in front of it have finished.  Bookings carry the owner's pid and start time; entries of processes that no longer exist (or whose
-// pid now belongs to another process) are dropped, so a crashed owner cannot close the device for everyone else.  Jobs that a HIP stream already serialises (same process, same
-// stream: the rounds of a large job, back-to-back calls of one caller) share ONE booking -- the launch stays asynchronous there.
-// The booking is released by a host function enqueued behind the kernel (hipLaunchHostFunc), at the latest by wn_wait.
+// The gate: every job books the CUs it needs PER XCD (blocks are dispatched round-robin over the 8 XCDs: a full XCD stalls the
+// dispatch however empty the others are) in a small table shared by the processes that use the device -- a file named after the
+// device's PCI bus id, read and written under flock().  Admission is FIRST COME FIRST SERVED: a job that does not fit at once takes
+// a WAITING entry with a sequence number; a job is admitted when its booking fits next to the running ones AND no job with a smaller
+// sequence number is still waiting (a stream of small jobs cannot starve a large one).  The wait is bounded (timeout_ms covers
+// everything: the file lock, the jobs in front).  Entries carry the owner's pid and start time; entries of processes that no longer
+// exist (or whose pid now belongs to another process) are dropped, so a crashed owner cannot close the device for everyone else.
+// Jobs that a HIP stream already serialises (same process, same stream: the rounds of a large job, back-to-back calls of one caller)
+// share ONE booking -- the launch stays asynchronous there.  The booking is released by a host function enqueued behind the kernel
+// (hipLaunchHostFunc), at the latest by wn_wait.
 //
-// No /dev/shm (or no permission): the gate still serialises the threads of this process, and says so in wn_get_info.
+// Where the table lives (round 5, after the advisor's review of the round-4 file -- world-writable, created through O_CREAT in /dev/shm):
+//   default          /dev/shm/wn_mi355_gate_u<euid>_<busid>, mode 0600: the processes of ONE user coordinate.  Jobs of different users
+//                    on one device are not serialised against each other (they never were before the gate existed; a table every local
+//                    user may write is a table every local user may fill or redirect).
+//   WN_GATE_DIR=dir  <dir>/wn_mi355_gate_<busid>, mode 0660 & ~umask: a directory an administrator prepared for the users that share the
+//                    device (e.g. group-writable, setgid) makes them share one table.
+// The file is opened O_NOFOLLOW, created only with O_CREAT | O_EXCL | O_NOFOLLOW, and trusted only after fstat(): a regular file with one
+// link, owned by this user (default location) and not writable by "other".  Anything else is an ERROR the first booking reports once on
+// stderr, and the device's gate is process-local from then on: a device keeps ONE mode (shared or local) for the life of the process, a
+// transient failure to open the table later is a retry, never a silent change of mode.
 #ifndef WN_GATE_H
 #define WN_GATE_H
 
@@ -38,9 +49,13 @@
 #include <string>
 
 #define WN_GATE_SLOTS 64
-struct WnGateSlot { int32_t pid; int32_t need; int64_t token; int64_t born; };   // need: CUs per XCD; pid 0 = free; born: the owner's start time
-struct WnGateFile { uint32_t magic, version; WnGateSlot slot[WN_GATE_SLOTS]; };
-#define WN_GATE_MAGIC 0x474e5732u  /* "2WNG" */
+// need: CUs per XCD; pid 0 = free; born: the owner's start time; seq: order of arrival; state: WN_GATE_RUNNING / WN_GATE_WAITING
+struct WnGateSlot { int32_t pid; int32_t need; int64_t token; int64_t born; int64_t seq; int32_t state; int32_t pad; };
+struct WnGateFile { uint32_t magic, version; int64_t next_seq; WnGateSlot slot[WN_GATE_SLOTS]; };
+#define WN_GATE_MAGIC 0x474e5733u  /* "3WNG" */
+#define WN_GATE_VERSION 3u
+#define WN_GATE_RUNNING 1
+#define WN_GATE_WAITING 2
 
 // Start time of a process in clock ticks since boot (/proc/<pid>/stat, field 22), 0 if it does not exist: a pid alone does not identify the
 // owner of a booking -- pids are re-used, and an entry left behind by a process that died mid-job must not be kept alive by a stranger.
@@ -78,36 +93,88 @@ struct WnGateRegistry {
     std::mutex mu;
     std::map<std::string, std::shared_ptr<WnGateBooking>> by_stream;   // live bookings of this process
     std::map<std::string, int> local_used;                              // device -> CUs per XCD booked by this process (no shared file)
+    std::map<std::string, int> mode;                                    // device -> 1 shared table, 0 process-local: decided ONCE per device
+    std::map<std::string, int64_t> local_next, local_serving;           // process-local first come first served
     int64_t next_token = 1;
 };
-static inline WnGateRegistry& wn_gate_registry() { static WnGateRegistry r; return r; }
+// heap-allocated and never destroyed: the runtime's callback thread (hipLaunchHostFunc -> wn_gate_release) may still run while the
+// process's static destructors do
+static inline WnGateRegistry& wn_gate_registry() { static WnGateRegistry* r = new WnGateRegistry(); return *r; }
 
 static inline std::string wn_gate_path(const char* busid) {
-    std::string name = "wn_mi355_gate_";
+    std::string name;
     for (const char* c = busid; *c; ++c) name += ((*c >= '0' && *c <= '9') || (*c >= 'a' && *c <= 'z') || (*c >= 'A' && *c <= 'Z')) ? *c : '_';
     const char* dir = getenv("WN_GATE_DIR");
-    return std::string(dir && dir[0] ? dir : "/dev/shm") + "/" + name;
+    if (dir && dir[0]) return std::string(dir) + "/wn_mi355_gate_" + name;
+    char uid[32];
+    snprintf(uid, sizeof(uid), "u%u_", (unsigned)geteuid());
+    return std::string("/dev/shm/wn_mi355_gate_") + uid + name;
 }
 
-// Opens (creating if needed) and locks the table; returns the descriptor or -1.
-static inline int wn_gate_open_locked(const std::string& path, WnGateFile* tab) {
-    const int fd = open(path.c_str(), O_RDWR | O_CREAT | O_CLOEXEC, 0666);
-    if (fd < 0) return -1;
-    (void)fchmod(fd, 0666);  // (other users of the same device must be able to book as well; the umask may have cut the mode)
-    if (flock(fd, LOCK_EX) != 0) { close(fd); return -1; }
-    const ssize_t n = pread(fd, tab, sizeof(*tab), 0);
-    if (n != (ssize_t)sizeof(*tab) || tab->magic != WN_GATE_MAGIC || tab->version != 2) {
-        memset(tab, 0, sizeof(*tab));
-        tab->magic = WN_GATE_MAGIC; tab->version = 2;
+static inline long long wn_gate_now_ms() {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (long long)ts.tv_sec * 1000 + ts.tv_nsec / 1000000;
+}
+
+// Opens the table without following links, creating it exclusively when it does not exist, and checks what was opened.
+// Returns the descriptor; -1 with *why set (a static text) otherwise.  Nothing is ever chmod'ed or written before the checks have passed.
+static inline int wn_gate_open_checked(const std::string& path, const char** why) {
+    const bool admin_dir = getenv("WN_GATE_DIR") && getenv("WN_GATE_DIR")[0];
+    const mode_t mode = admin_dir ? 0660 : 0600;
+    int fd = -1;
+    for (int attempt = 0; attempt < 4 && fd < 0; ++attempt) {
+        fd = open(path.c_str(), O_RDWR | O_NOFOLLOW | O_CLOEXEC);
+        if (fd >= 0 || errno != ENOENT) break;
+        fd = open(path.c_str(), O_RDWR | O_CREAT | O_EXCL | O_NOFOLLOW | O_CLOEXEC, mode);
+        if (fd < 0 && errno != EEXIST) break;   // (EEXIST: somebody else created it between the two calls -- open it)
     }
-    for (int i = 0; i < WN_GATE_SLOTS; ++i) {  // bookings of processes that are gone
+    if (fd < 0) {
+        *why = errno == ELOOP ? "the table's name is a symbolic link" : errno == EACCES ? "no permission to open the table (another user's file?)" : "cannot open or create the table";
+        return -1;
+    }
+    struct stat st;
+    if (fstat(fd, &st) != 0) { *why = "fstat failed"; close(fd); return -1; }
+    if (!S_ISREG(st.st_mode)) { *why = "the table is not a regular file"; close(fd); return -1; }
+    if (st.st_nlink != 1) { *why = "the table has more than one link"; close(fd); return -1; }
+    if (!admin_dir && st.st_uid != geteuid()) { *why = "the table belongs to another user"; close(fd); return -1; }
+    if (st.st_mode & S_IWOTH) { *why = "the table is writable by everybody"; close(fd); return -1; }
+    if (st.st_size != 0 && st.st_size != (off_t)sizeof(WnGateFile)) { *why = "the table has an unexpected size"; close(fd); return -1; }
+    return fd;
+}
+
+// Opens and locks the table (the lock is tried without blocking until deadline_ms: a stopped process that holds it cannot stall
+// the caller beyond its own timeout); returns the descriptor, -1 = could not (transient or not: *why says), -2 = deadline.
+static inline int wn_gate_open_locked(const std::string& path, WnGateFile* tab, long long deadline_ms = -1, const char** why = nullptr) {
+    const char* dummy = nullptr;
+    if (!why) why = &dummy;
+    const int fd = wn_gate_open_checked(path, why);
+    if (fd < 0) return -1;
+    long long backoff_us = 50;
+    while (flock(fd, LOCK_EX | LOCK_NB) != 0) {
+        if (errno != EWOULDBLOCK && errno != EINTR) { *why = "flock failed"; close(fd); return -1; }
+        if (deadline_ms >= 0 && wn_gate_now_ms() > deadline_ms) { *why = "the table's lock stayed taken"; close(fd); return -2; }
+        usleep((useconds_t)backoff_us);
+        if (backoff_us < 2000) backoff_us *= 2;
+    }
+    const ssize_t n = pread(fd, tab, sizeof(*tab), 0);
+    if (n != (ssize_t)sizeof(*tab) || tab->magic != WN_GATE_MAGIC || tab->version != WN_GATE_VERSION) {
+        memset(tab, 0, sizeof(*tab));
+        tab->magic = WN_GATE_MAGIC; tab->version = WN_GATE_VERSION; tab->next_seq = 1;
+    }
+    return fd;
+}
+// drops the entries of processes that are gone (called only when a booking does not fit: kill() + a /proc read per entry)
+static inline bool wn_gate_drop_stale(WnGateFile* tab) {
+    bool dropped = false;
+    for (int i = 0; i < WN_GATE_SLOTS; ++i) {
         WnGateSlot& s = tab->slot[i];
         if (s.pid <= 0) continue;
         const bool gone = kill((pid_t)s.pid, 0) != 0 && errno == ESRCH;
         const int64_t born = gone ? 0 : wn_gate_born(s.pid);   // (0: /proc not readable -- keep the entry, the pid answers)
-        if (gone || (born != 0 && s.born != 0 && born != s.born)) memset(&s, 0, sizeof(s));
+        if (gone || (born != 0 && s.born != 0 && born != s.born)) { memset(&s, 0, sizeof(s)); dropped = true; }
     }
-    return fd;
+    return dropped;
 }
 static inline void wn_gate_close(int fd, const WnGateFile* tab, bool dirty) {
     if (dirty) (void)!pwrite(fd, tab, sizeof(*tab), 0);
@@ -115,10 +182,47 @@ static inline void wn_gate_close(int fd, const WnGateFile* tab, bool dirty) {
     close(fd);
 }
 
-static inline long long wn_gate_now_ms() {
-    struct timespec ts;
-    clock_gettime(CLOCK_MONOTONIC, &ts);
-    return (long long)ts.tv_sec * 1000 + ts.tv_nsec / 1000000;
+// one admission attempt in the (locked) table for the entry (pid, token): 1 admitted, 0 waiting (a WAITING entry is kept), -1 table full
+static inline int wn_gate_try_table(WnGateFile* tab, int cap, int need, int64_t token, int64_t born, bool* dirty) {
+    const int32_t me = (int32_t)getpid();
+    for (int pass = 0; pass < 2; ++pass) {
+        int used = 0, free_slot = -1, mine = -1;
+        int64_t oldest_waiting = INT64_MAX;
+        for (int i = 0; i < WN_GATE_SLOTS; ++i) {
+            const WnGateSlot& s = tab->slot[i];
+            if (s.pid <= 0) { if (free_slot < 0) free_slot = i; continue; }
+            if (s.pid == me && s.token == token) { mine = i; continue; }
+            if (s.state == WN_GATE_RUNNING) used += s.need;
+            else if (s.seq < oldest_waiting) oldest_waiting = s.seq;
+        }
+        const int64_t my_seq = mine >= 0 ? tab->slot[mine].seq : tab->next_seq;
+        if (used + need <= cap && my_seq < oldest_waiting && (mine >= 0 || free_slot >= 0)) {
+            WnGateSlot& s = tab->slot[mine >= 0 ? mine : free_slot];
+            if (mine < 0) { s.pid = me; s.need = need; s.token = token; s.born = born; s.seq = tab->next_seq++; s.pad = 0; }
+            s.state = WN_GATE_RUNNING;
+            *dirty = true;
+            return 1;
+        }
+        if (pass == 0 && wn_gate_drop_stale(tab)) { *dirty = true; continue; }   // something in front of us may be dead: look again
+        if (mine < 0) {
+            if (free_slot < 0) return -1;
+            WnGateSlot& s = tab->slot[free_slot];
+            s.pid = me; s.need = need; s.token = token; s.born = born; s.seq = tab->next_seq++; s.state = WN_GATE_WAITING; s.pad = 0;
+            *dirty = true;
+        }
+        return 0;
+    }
+    return 0;
+}
+static inline void wn_gate_erase_entry(const std::string& path, int64_t token) {
+    WnGateFile tab;
+    const int fd = wn_gate_open_locked(path, &tab, wn_gate_now_ms() + 2000);
+    if (fd < 0) return;   // (a dead owner's entry is dropped by the next job that does not fit)
+    const int32_t me = (int32_t)getpid();
+    bool dirty = false;
+    for (int i = 0; i < WN_GATE_SLOTS; ++i)
+        if (tab.slot[i].pid == me && tab.slot[i].token == token) { memset(&tab.slot[i], 0, sizeof(tab.slot[i])); dirty = true; }
+    wn_gate_close(fd, &tab, dirty);
 }
 
 // Books `need` CUs per XCD (of `cap`) on the device `busid` for a job on `stream`.  Returns 0 and a ticket; 1 when the wait ran
@@ -131,13 +235,30 @@ static inline int wn_gate_acquire(const char* busid, int cap, int need, const vo
     snprintf(skey, sizeof(skey), "|%p", stream);
     const std::string dev(busid), key = dev + skey;
     const std::string path = wn_gate_path(busid);
-    const long long t0 = wn_gate_now_ms();
+    const long long t0 = wn_gate_now_ms(), deadline = t0 + timeout_ms;
     *waited_ms = 0;
+    int64_t token = 0, local_ticket = 0;   // this job's identity in the table / its place in the process-local queue (0: none yet)
+    const int64_t born = wn_gate_born((int)getpid());
+    long long nap_us = 200;
+    auto give_up = [&]() {
+        if (token) {
+            bool in_table;
+            { std::lock_guard<std::mutex> g(reg.mu); in_table = reg.mode[dev] == 1; }
+            if (in_table) wn_gate_erase_entry(path, token);
+        }
+        if (local_ticket) {   // leave the process-local queue: whoever is behind us must not wait for a job that will never run
+            std::lock_guard<std::mutex> g(reg.mu);
+            if (reg.local_serving[dev] == local_ticket) reg.local_serving[dev]++;
+            else reg.local_used[dev + "|left|" + std::to_string(local_ticket)] = 1;
+        }
+        *waited_ms = wn_gate_now_ms() - t0;
+        return 1;
+    };
     for (;;) {
         {
             std::lock_guard<std::mutex> g(reg.mu);
             auto it = reg.by_stream.find(key);
-            if (it != reg.by_stream.end() && it->second->jobs > 0 && it->second->need >= need) {
+            if (!token && !local_ticket && it != reg.by_stream.end() && it->second->jobs > 0 && it->second->need >= need) {
                 // a job of this process on this very stream is in flight: the stream serialises us behind it, one booking covers both
                 it->second->jobs++;
                 auto t = std::make_shared<WnGateTicket>();
@@ -146,31 +267,39 @@ static inline int wn_gate_acquire(const char* busid, int cap, int need, const vo
                 return 0;
             }
             // (a larger job behind a smaller one on the same stream books on its own: conservative, never wrong)
-            WnGateFile tab;
-            const int fd = wn_gate_open_locked(path, &tab);
+            if (!token) token = reg.next_token++;
+            auto mode_it = reg.mode.find(dev);
+            int mode = mode_it == reg.mode.end() ? -1 : mode_it->second;
             bool ok = false;
-            auto b = std::make_shared<WnGateBooking>();
-            b->key = key; b->need = need; b->jobs = 1; b->token = reg.next_token++;
-            if (fd >= 0) {
-                int used = 0, free_slot = -1;
-                for (int i = 0; i < WN_GATE_SLOTS; ++i) {
-                    if (tab.slot[i].pid > 0) used += tab.slot[i].need;
-                    else if (free_slot < 0) free_slot = i;
-                }
-                if (used + need <= cap && free_slot >= 0) {
-                    tab.slot[free_slot].pid = (int32_t)getpid(); tab.slot[free_slot].need = need; tab.slot[free_slot].token = b->token;
-                    tab.slot[free_slot].born = wn_gate_born((int)getpid());
-                    b->path = path;
-                    ok = true;
-                }
-                wn_gate_close(fd, &tab, ok);
-                *shared = 1;
-            } else {
+            if (mode != 0) {
+                WnGateFile tab;
+                const char* why = "";
+                const int fd = wn_gate_open_locked(path, &tab, deadline, &why);
+                if (fd >= 0) {
+                    if (mode < 0) reg.mode[dev] = mode = 1;
+                    bool dirty = false;
+                    const int r = wn_gate_try_table(&tab, cap, need, token, born, &dirty);
+                    wn_gate_close(fd, &tab, dirty);
+                    ok = r == 1;
+                } else if (mode < 0 && fd == -1) {
+                    // the FIRST booking on this device decides its mode for the life of the process -- and says why out loud
+                    fprintf(stderr, "wn_mi355: admission table %s unusable (%s): the jobs of THIS process are serialised on device %s, other "
+                            "processes are not (set WN_GATE_DIR to a directory the device's users share)\n", path.c_str(), why, busid);
+                    reg.mode[dev] = mode = 0;
+                }   // (mode == 1 and the table cannot be opened right now, or the lock is held: not admitted yet -- retry below)
+            }
+            if (mode == 0) {   // process-local, first come first served
+                if (!local_ticket) { int64_t& n = reg.local_next[dev]; if (n == 0) { n = 1; reg.local_serving[dev] = 1; } local_ticket = n++; }
+                int64_t& serving = reg.local_serving[dev];
+                while (serving < local_ticket && reg.local_used.erase(dev + "|left|" + std::to_string(serving))) ++serving;   // (tickets that gave up)
                 int& used = reg.local_used[dev];
-                if (used + need <= cap) { used += need; ok = true; }
-                *shared = 0;
+                if (serving == local_ticket && used + need <= cap) { used += need; ++serving; ok = true; }
             }
             if (ok) {
+                auto b = std::make_shared<WnGateBooking>();
+                b->key = key; b->need = need; b->jobs = 1; b->token = token;
+                if (mode == 1) b->path = path;
+                *shared = mode;
                 if (it == reg.by_stream.end() || it->second->jobs == 0) reg.by_stream[key] = b;  // (joinable by later jobs of this stream)
                 auto t = std::make_shared<WnGateTicket>();
                 t->booking = b;
@@ -178,35 +307,35 @@ static inline int wn_gate_acquire(const char* busid, int cap, int need, const vo
                 *waited_ms = wn_gate_now_ms() - t0;
                 return 0;
             }
+            *shared = mode;
         }
-        if (wn_gate_now_ms() - t0 > timeout_ms) { *waited_ms = wn_gate_now_ms() - t0; return 1; }
-        usleep(200);
+        if (wn_gate_now_ms() > deadline) return give_up();
+        usleep((useconds_t)nap_us);
+        if (nap_us < 2000) nap_us *= 2;   // 0.2 ms ... 2 ms between looks: a cfg3 job is tens of milliseconds at the least
     }
 }
 
 static inline void wn_gate_release(const std::shared_ptr<WnGateTicket>& t) {
     if (!t || t->released.exchange(1) != 0) return;
     WnGateRegistry& reg = wn_gate_registry();
-    std::lock_guard<std::mutex> g(reg.mu);
-    WnGateBooking& b = *t->booking;
-    if (--b.jobs > 0) return;
-    auto it = reg.by_stream.find(b.key);
-    if (it != reg.by_stream.end() && it->second.get() == &b) reg.by_stream.erase(it);
-    if (!b.path.empty()) {
-        WnGateFile tab;
-        const int fd = wn_gate_open_locked(b.path, &tab);
-        if (fd >= 0) {
-            const int32_t me = (int32_t)getpid();
-            for (int i = 0; i < WN_GATE_SLOTS; ++i)
-                if (tab.slot[i].pid == me && tab.slot[i].token == b.token) memset(&tab.slot[i], 0, sizeof(tab.slot[i]));
-            wn_gate_close(fd, &tab, true);
+    std::string path;
+    int64_t token = 0;
+    {
+        std::lock_guard<std::mutex> g(reg.mu);
+        WnGateBooking& b = *t->booking;
+        if (--b.jobs > 0) return;
+        auto it = reg.by_stream.find(b.key);
+        if (it != reg.by_stream.end() && it->second.get() == &b) reg.by_stream.erase(it);
+        if (!b.path.empty()) { path = b.path; token = b.token; }
+        else {
+            const std::string dev = b.key.substr(0, b.key.find('|'));
+            int& used = reg.local_used[dev];
+            used -= b.need;
+            if (used < 0) used = 0;
         }
-    } else {
-        const std::string dev = b.key.substr(0, b.key.find('|'));
-        int& used = reg.local_used[dev];
-        used -= b.need;
-        if (used < 0) used = 0;
     }
+    // (outside the registry mutex: this may run on the HIP runtime's callback thread, and the file lock is only ever tried, with a bound)
+    if (!path.empty()) wn_gate_erase_entry(path, token);
 }
 
 #endif  // WN_GATE_H

@@ -31,7 +31,7 @@ typedef float4 wn_f4;
 #define WN_UNROLL _Pragma("unroll")
 
 // where-codes reported in status[4] when a hand-off wait gives up
-enum { WN_W_LOGITS = 1, WN_W_X = 2, WN_W_SKIN = 3, WN_W_HEAD = 4 };
+enum { WN_W_LOGITS = 1, WN_W_X = 2, WN_W_SKIN = 3, WN_W_HEAD = 4, WN_W_RESIDENT = 5 };
 
 struct WnCtx {
     const WnPlan* p;
@@ -70,6 +70,43 @@ WN_DEV void wn_give_up(WnCtx& cx, int where, long long e, int s) {
         st[1] = (uint32_t)cx.w; st[2] = (uint32_t)e; st[3] = (uint32_t)s; st[4] = (uint32_t)where;
         __threadfence();
     }
+}
+
+// ---- Residency barrier.  A job is a chain of persistent workgroups that wait for each other: it only makes progress once ALL of them are
+// resident, and plain launches promise nothing of the kind -- CUs held by another kernel (a long torch kernel on another stream, a CU mask)
+// leave part of the job in the dispatcher's queue.  Every workgroup therefore checks in first (one atomic add on status[5]) and thread 0
+// waits until all n_wg of them have: only then does the workgroup enter the chain, and only from then on do the hand-off timeouts run.  The
+// wait has its own bound (r.resident_ticks) and its own report (WN_W_RESIDENT: status[2] = how many had checked in): nothing of the
+// job has run at that point -- queues, rings and hand-off words are untouched -- so the host can say exactly that (WN_E_BUSY) instead of a
+// hand-off timeout somewhere in the chain ten seconds later.
+WN_DEV void wn_resident_barrier(WnCtx& cx) {
+    if (threadIdx.x != 0) return;   // (the role's first workgroup barrier holds the other threads back)
+    uint32_t* st = cx.p->status;
+    const uint32_t want = (uint32_t)cx.p->n_wg;
+    uint32_t seen = __hip_atomic_fetch_add(st + 5, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+    const long long t0 = (long long)wall_clock64();
+    unsigned spins = 0;
+    while (seen < want) {
+        __builtin_amdgcn_s_sleep(16);
+        seen = __hip_atomic_load(st + 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((++spins & 15u) == 0u) {
+            if (__hip_atomic_load(st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { cx.fail = 1; return; }   // somebody else gave up
+            if ((long long)wall_clock64() - t0 > cx.r->resident_ticks) { wn_give_up(cx, WN_W_RESIDENT, (long long)seen, 0); return; }
+        }
+    }
+    cx.t_start = (long long)wall_clock64();
+}
+// ... and its verdict for the whole workgroup (through one word of the workgroup's LDS, before any role touches it): true = leave
+WN_DEV bool wn_not_resident(WnCtx& cx, float* lds) {
+    wn_resident_barrier(cx);
+    int* word = reinterpret_cast<int*>(lds);
+    if (threadIdx.x == 0) *word = cx.fail;
+    __syncthreads();
+    const int failed = *word;
+    __syncthreads();
+    cx.fail = 0;   // (known to the compiler again: a workgroup that goes on has not failed)
+    cx.t_start = (long long)wall_clock64();
+    return failed != 0;
 }
 
 // Spin until the granule carries `tag`.  Bounded: gives up after r->timeout_ticks of wall clock or as

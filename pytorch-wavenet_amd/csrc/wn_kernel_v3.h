@@ -64,7 +64,7 @@
 #define WN_V3_COMPILER_VGPRS 152  // v152-v167: request sets of the input poll / the queue group's tap FIFO (see wn_ap_*, wn_q_*)
 // ---- experiment switches.  A product build (build.py) leaves every one of them at its default; setting one requires -DWN_EXPERIMENT,
 // which build.py never passes (tools/ builds the A/B variants): a library with wrong-on-purpose timing ablations cannot ship by accident.
-#if !defined(WN_EXPERIMENT) && (defined(WN_V3_SKIP_SLEEP) || defined(WN_V3_ABL) || defined(WN_V3_PAIR_ROWS) || defined(WN_V3_PRIO) || defined(WN_V3_LAST_SKIP_PRIO) || defined(WN_V3_SKIP_CHAINS) || defined(WN_V3_FG_CHAINS) || defined(WN_V3_SKIP_SLOTS))
+#if !defined(WN_EXPERIMENT) && (defined(WN_V3_SKIP_SLEEP) || defined(WN_V3_ABL) || defined(WN_V3_PAIR_ROWS) || defined(WN_V3_PRIO) || defined(WN_V3_LAST_SKIP_PRIO) || defined(WN_V3_SKIP_CHAINS) || defined(WN_V3_FG_CHAINS) || defined(WN_V3_SKIP_SLOTS) || defined(WN_V3_TAP_AT_A))
 #error "WN_V3_* experiment switches need -DWN_EXPERIMENT"
 #endif
 #ifndef WN_V3_SKIP_SLEEP
@@ -93,6 +93,14 @@
 #endif
 #ifndef WN_V3_FG_CHAINS
 #define WN_V3_FG_CHAINS 4    // ... per stream of the critical group's filter/gate dot in the pair-rows form (2: rounds 2-3; 4: 64 streams 1000 -> 1010 k, profiles/r04_fma_chain_experiments.txt)
+#endif
+#ifndef WN_V3_TAP_AT_A
+#define WN_V3_TAP_AT_A 2     // when a late layer's queue waves request the tap of item i + 6: 0 behind their tap-0 dot after barrier B(i) (rounds 2-4), 1 right behind
+                             // barrier A(i), 2 behind A in the two-streams-per-item form only.  The rings of the layers with d >= 64 do not fit the L2 at 64
+                             // streams: such a tap load is a ~1 us miss, and whatever this CU requests behind it -- the critical group's input polls -- is
+                             // answered behind it.  Requested after the dot the miss was in flight when the next token arrived; behind barrier A it has the
+                             // item's whole service time and the wait for the next token to itself (round 5: hop into a layer with d >= 64 0.50 -> 0.35 us,
+                             // 64 streams 1.002 -> 1.069 M samples/s; one stream per item loses 1-3 %: profiles/r05_tap_request_behind_barrier_a.txt)
 #endif
 #ifndef WN_V3_PRIO
 #define WN_V3_PRIO 1  // 1: critical waves at a higher static wave priority (the queue and skip waves share their SIMDs: x64 911 -> 919 k, profiles/r02_v3_tap_fifo.txt)
@@ -1091,6 +1099,8 @@ static __device__ void wn_v3_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
     constexpr int D = WN_V3_TAP_AHEAD;
     const int xq = tg * L::XR + SH::xpad(tr);  // this lane's element in a [G][XR] staging area
     if (late && n_items > 0) xol[xq] = wn_q_take_slot<D - 1>(0);  // item 0's tap (D - 1 younger loads of the initial fill)
+    constexpr bool TAP_A = WN_V3_TAP_AT_A == 1 || (WN_V3_TAP_AT_A == 2 && G >= 2);   // the tap request behind barrier A (see WN_V3_TAP_AT_A)
+    const float* q_next = (TAP_A && late) ? next_tap_ptr() : nullptr;   // address of the tap of item D (requested behind barrier A of item 0)
     // ... and the push of a late layer is done by the waves that load no taps (lanes R..2R-1, when there are that many): the tap
     // waves then issue nothing but tap loads, and an entry always has exactly D - 1 younger operations
     constexpr bool PUSH_HI = 2 * G * R <= 256;
@@ -1106,6 +1116,7 @@ static __device__ void wn_v3_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
             if (wn_barrier_failed(cx, failflag)) return;  // ---- A(i): x of this item staged
             const bool stamp = r.prof && item < r.prof_items && tid == 512;
             const long long t0 = stamp ? (long long)wall_clock64() : 0;
+            if (TAP_A && late) wn_q_issue_slot(slot, q_next);  // the tap of item i + D goes into the entry item i gave up at the end of item i - 1
             // ---- queue push (wavenet_modules.py:55-57); stage the tap x[t+1-d] (d = 1: it is x[t] itself)
             if (!late_wg && qlane && !(WN_V3_ABL & 2)) {
                 const float xv = xs[buf * (G * L::XR) + xq];
@@ -1131,12 +1142,23 @@ static __device__ void wn_v3_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
             if (!(WN_V3_ABL & 2)) {
                 if (pusher) rings_l[((size_t)(s + pg) * ML + tmod) * R + prow] = xs[buf * (G * L::XR) + pg * L::XR + SH::xpad(prow)];  // the push, off the A -> B window
                 tap0_dot(xo_cur, s);
-                if (fifo) wn_q_issue_slot(slot, next_tap_ptr());  // the tap of item i + D goes into the entry item i has just given up
-                if (late && item + 1 < n_items) {
-                    // the NEXT item's tap into the other buffer: D - 1 younger loads; the stores of a wave that also pushes (R > 128:
-                    // program order push, load, take) only add to what may stay in flight from item D - 2 on
-                    const int ns1 = slot == D - 1 ? 0 : slot + 1;
-                    xo_nxt[xq] = (PUSH_SEP || item < D - 2) ? wn_q_take_slot<D - 1>(ns1) : wn_q_take_slot<2 * D - 2>(ns1);
+                if constexpr (TAP_A) {
+                    if (fifo && !late) wn_q_issue_slot(slot, next_tap_ptr());
+                    if (late) q_next = next_tap_ptr();   // (its address arithmetic here, the load behind the coming barrier A)
+                    if (late && item + 1 < n_items) {
+                        // program order of a tap wave per item: tap load (behind A), [push store], take (here).  The entry of item i + 1 was requested in
+                        // item i + 1 - D: D - 1 younger loads and, in a wave that also pushes, D younger stores (the initial fill: D + i operations in all)
+                        const int ns1 = slot == D - 1 ? 0 : slot + 1;
+                        xo_nxt[xq] = (PUSH_SEP || item < D - 1) ? wn_q_take_slot<D - 1>(ns1) : wn_q_take_slot<2 * D - 1>(ns1);
+                    }
+                } else {
+                    if (fifo) wn_q_issue_slot(slot, next_tap_ptr());  // the tap of item i + D goes into the entry item i has just given up
+                    if (late && item + 1 < n_items) {
+                        // the NEXT item's tap into the other buffer: D - 1 younger loads; the stores of a wave that also pushes (R > 128:
+                        // program order push, load, take) only add to what may stay in flight from item D - 2 on
+                        const int ns1 = slot == D - 1 ? 0 : slot + 1;
+                        xo_nxt[xq] = (PUSH_SEP || item < D - 2) ? wn_q_take_slot<D - 1>(ns1) : wn_q_take_slot<2 * D - 2>(ns1);
+                    }
                 }
             }
             slot = slot == D - 1 ? 0 : slot + 1;
@@ -1628,6 +1650,7 @@ void wn_generate_kernel_v3m(WnPlan p, WnRun r) {
     WnCtx cx;
     cx.p = &p; cx.r = &r; cx.lds = wn_lds3m; cx.w = w; cx.fail = 0;
     cx.t_start = (long long)wall_clock64();
+    if (wn_not_resident(cx, wn_lds3m)) return;   // (every workgroup of the job is resident from here on)
     const int n_layer_wg = p.NL * p.P;
     if (w < n_layer_wg) {
         wn_v3_layer<SH, P, G>(p, r, cx, wn_lds3m, w / P, w % P);

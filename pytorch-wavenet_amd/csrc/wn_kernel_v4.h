@@ -405,6 +405,7 @@ __global__ __launch_bounds__(WN_THREADS_V4) void wn_generate_kernel_v4(WnPlan p,
     WnCtx cx;
     cx.p = &p; cx.r = &r; cx.lds = wn_lds4; cx.w = w; cx.fail = 0;
     cx.t_start = (long long)wall_clock64();
+    if (wn_not_resident(cx, wn_lds4)) return;   // (every workgroup of the job is resident from here on)
     if (w < p.n_lw) {
         wn_v4_stack<V, LPW>(p, r, cx, wn_lds4, w);
         return;

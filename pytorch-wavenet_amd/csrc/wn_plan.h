@@ -99,6 +99,7 @@ struct WnRun {
     int32_t prof_items;
     int32_t pad;
     const float* stream_temps;  // optional [n_streams]: per-stream temperature (<= 0: that stream is greedy); NULL = `temperature` for all
+    int64_t resident_ticks;     // bound of the start-up residency barrier (wn_resident_barrier), wall_clock64 ticks
 };
 
 // ---- host-side planner / packer (plain C++; also parsed, unused, in the device pass) ----

@@ -127,9 +127,11 @@ __global__ __launch_bounds__(WN_THREADS) void wn_generate_kernel(WnPlan p, WnRun
     extern __shared__ __attribute__((aligned(16))) float wn_lds[];
     const int w = p.wg_map[blockIdx.x];
     if (w < 0) return;
-    wn_load_lds(p, w, wn_lds);
     WnCtx cx;
     cx.p = &p; cx.r = &r; cx.lds = wn_lds; cx.w = w; cx.fail = 0;
+    cx.t_start = (long long)wall_clock64();
+    if (wn_not_resident(cx, wn_lds)) return;   // (every workgroup of the job is resident from here on)
+    wn_load_lds(p, w, wn_lds);
     cx.t_start = (long long)wall_clock64();
     const int n_layer_wg = p.NL * p.P;
     if (w < n_layer_wg) {
@@ -514,13 +516,18 @@ struct wn_handle {
     char busid[32] = "";
     std::shared_ptr<WnGateTicket> gate;   // the booking of the job in flight (released by the host function behind the kernel, or in wn_wait)
     int gate_shared = -1, gate_waited_ms = 0;
+    int gate_need = 0;   // resident workgroups on the fullest XCD (wn_create)
+    int resident_ms = 0; // bound of the last job's residency barrier
+    int wg_per_cu = 0;   // workgroups of the job's kernel one CU holds (hipOccupancyMaxActiveBlocksPerMultiprocessor at wn_create)
+    long long last_n_eval = 0;   // evaluations the job in flight advances the queues by (rolled back when it never started: WN_E_BUSY)
 };
 
-// CUs per XCD a job of this handle needs (blocks are dispatched round-robin over the XCDs) and what an XCD has
+// CUs per XCD a job of this handle needs -- the workgroups that stay resident on the fullest XCD (blocks are dispatched round-robin over
+// the XCDs; the padding blocks of the layer-aligned placement exit at once and hold nothing) -- and what an XCD has
 static void wn_gate_numbers(const wn_handle* h, int* need, int* cap) {
     const int n_xcd = h->n_cu % 8 == 0 ? 8 : 1;
     *cap = h->n_cu / n_xcd;
-    *need = (h->plan.n_blocks + n_xcd - 1) / n_xcd;
+    *need = h->gate_need > 0 ? h->gate_need : (h->plan.n_blocks + n_xcd - 1) / n_xcd;
 }
 static void wn_gate_host_release(void* user) {   // runs on the runtime's callback thread once the job's kernel has finished
     std::shared_ptr<WnGateTicket>* t = static_cast<std::shared_ptr<WnGateTicket>*>(user);
@@ -771,6 +778,14 @@ static int wn_create_impl(const wn_config* cfg, wn_handle** out) {
     } else {
         wn_make_wg_map(pl.n_wg, 8, wg_map);
     }
+    {   // what a job of this handle keeps RESIDENT per XCD (block b lands on XCD b % 8; padding blocks exit at once and hold nothing)
+        int per_xcd[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        const int nx = n_cu % 8 == 0 ? 8 : 1;
+        for (int b = 0; b < pl.n_blocks; ++b)
+            if (wg_map[b] >= 0) per_xcd[b % nx]++;
+        h->gate_need = 0;
+        for (int x = 0; x < nx; ++x) h->gate_need = per_xcd[x] > h->gate_need ? per_xcd[x] : h->gate_need;
+    }
     const size_t n_lw = h->variant == 4 ? (size_t)pl.n_lw : (size_t)pl.NL * pl.P;
     const size_t gx_n = n_lw * pl.n_streams * pl.R, gs_n = n_lw * pl.n_streams * pl.S, gl_n = (size_t)pl.PA * pl.n_streams * pl.C;
     const size_t g0_n = h->variant >= 3 ? (size_t)pl.n_streams * pl.R : 0;
@@ -821,6 +836,22 @@ static int wn_create_impl(const wn_config* cfg, wn_handle** out) {
                                     hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes),
                 "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
     if (rc) { wn_destroy(h); return rc; }
+    {   // residency is a requirement, not a hope: what the hardware can keep resident of THIS kernel with THIS much LDS, against what the plan needs per XCD
+        const void* fn = h->variant == 4 ? wn_v4_table()[h->v2_index].fn : h->variant == 3 ? wn_v2_table()[h->v2_index].fn_v3[h->v3_mode & 1] : (const void*)wn_generate_kernel;
+        const int threads = h->variant == 4 ? WN_THREADS_V4 : h->variant == 3 ? WN_THREADS_V3 : WN_THREADS;
+        int per_cu = 0;
+        rc = rt_hip(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, threads, (size_t)h->lds_bytes), "hipOccupancyMaxActiveBlocksPerMultiprocessor");
+        if (rc) { wn_destroy(h); return rc; }
+        int need = 0, cap = 0;
+        wn_gate_numbers(h, &need, &cap);
+        h->wg_per_cu = per_cu;
+        if ((long long)per_cu * cap < need) {
+            const int n_wg = pl.n_wg;
+            wn_destroy(h);
+            return wn_fail(WN_E_UNSUPPORTED, "wn_create: the plan keeps %d workgroups resident on one XCD (%d in all), the device holds %d x %d of this kernel there",
+                           need, n_wg, cap, per_cu);
+        }
+    }
     h->dev_overrides = g_dev_env_used;
     *out = h;
     return WN_OK;
@@ -1094,6 +1125,25 @@ extern "C" int wn_generate(wn_handle* h, const wn_generate_args* a) {
     r.uniforms = a->uniforms; r.out_idx = a->out_idx; r.dbg_logits = a->dbg_logits; r.stream_temps = a->stream_temperatures;
     const long long ms = a->timeout_ms > 0 ? a->timeout_ms : 10000;
     r.timeout_ticks = ms * (long long)h->wall_khz;
+    {   // the start-up residency barrier has a bound of its own: a job that finds CUs taken by another kernel starts when they free up
+        const char* re = getenv("WN_RESIDENT_TIMEOUT_MS");
+        const long long rms = re && atoll(re) > 0 ? atoll(re) : 60000;
+        r.resident_ticks = rms * (long long)h->wall_khz;
+        h->resident_ms = (int)(rms > 0x7fffffff ? 0x7fffffff : rms);
+    }
+    {   // CUs this stream may use right now (a CU mask on the stream, or the process-wide one): fewer than the job keeps resident = it could never start
+        uint32_t mask[32];
+        memset(mask, 0, sizeof(mask));
+        if (hipExtStreamGetCUMask((hipStream_t)a->hip_stream, 32, mask) == hipSuccess) {
+            int cus = 0;
+            for (int i = 0; i < 32; ++i) cus += __builtin_popcount(mask[i]);
+            if (cus > 0 && cus < h->plan.n_wg)
+                return wn_fail(WN_E_UNSUPPORTED, "wn_generate: the stream's CU mask leaves %d compute units, the job keeps %d workgroups resident (one per CU); "
+                               "nothing was launched", cus, h->plan.n_wg);
+        } else {
+            (void)hipGetLastError();
+        }
+    }
     if (h->prof_items > 0) {
         rt_free(h->d_prof);
         const size_t nb = (size_t)h->plan.n_wg * h->prof_items * 8 * sizeof(long long);
@@ -1142,6 +1192,7 @@ extern "C" int wn_generate(wn_handle* h, const wn_generate_args* a) {
     h->pending = true;
     h->last_stream = a->hip_stream;
     h->t_base += n_eval;
+    h->last_n_eval = n_eval;
     return WN_OK;
 }
 
@@ -1166,6 +1217,14 @@ extern "C" int wn_wait(wn_handle* h) {
     uint32_t st[8];
     rc = rt_d2h(st, h->d_status, 32);
     if (rc) return rc;
+    if (st[0] != 0 && st[4] == 5) {   // WN_W_RESIDENT: the job never started -- no workgroup entered the chain, queues and rings are as they were
+        h->t_base -= h->last_n_eval;
+        h->last_n_eval = 0;
+        return wn_fail(WN_E_BUSY,
+                       "wn_generate: only %u of the job's %d workgroups had become resident after %d ms (WN_RESIDENT_TIMEOUT_MS): the device's compute units "
+                       "are held by other kernels (or masked); nothing was generated and the queues are unchanged -- the call can be repeated",
+                       st[2], h->plan.n_wg, h->resident_ms);
+    }
     if (st[0] != 0) {
         static const char* where[] = {"?", "partial logits (head -> L0)", "x partials (layer -> layer)", "skip lane (layer -> layer)",
                                       "skip lanes (last layer -> head)"};
@@ -1212,6 +1271,8 @@ extern "C" int wn_get_info(wn_handle* h, wn_info* out) {
     if (h->variant == 4) out->n_workgroups = pl.n_wg;
     out->gate_shared = h->gate_shared; out->gate_waited_ms = h->gate_waited_ms;
     { int need = 0, cap = 0; wn_gate_numbers(h, &need, &cap); out->gate_need_per_xcd = need; }
+    out->forward_native = (h->have_weights && h->fw_ok) ? 1 : 0;
+    out->workgroups_per_cu = h->wg_per_cu; out->resident_timeout_ms = h->resident_ms;
     return WN_OK;
 }
 

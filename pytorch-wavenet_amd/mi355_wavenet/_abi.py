@@ -10,9 +10,9 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 PRODUCT_LIB = os.path.join(_HERE, "libwn_mi355.so")
 
-WN_OK, WN_E_BADARG, WN_E_UNSUPPORTED, WN_E_HIP, WN_E_NOMEM, WN_E_TIMEOUT, WN_E_STATE = 0, -1, -2, -3, -4, -5, -6
+WN_OK, WN_E_BADARG, WN_E_UNSUPPORTED, WN_E_HIP, WN_E_NOMEM, WN_E_TIMEOUT, WN_E_STATE, WN_E_BUSY = 0, -1, -2, -3, -4, -5, -6, -7
 ERROR_NAMES = {0: "WN_OK", -1: "WN_E_BADARG", -2: "WN_E_UNSUPPORTED", -3: "WN_E_HIP", -4: "WN_E_NOMEM",
-               -5: "WN_E_TIMEOUT", -6: "WN_E_STATE"}
+               -5: "WN_E_TIMEOUT", -6: "WN_E_STATE", -7: "WN_E_BUSY"}
 
 
 class WnError(RuntimeError):
@@ -43,7 +43,7 @@ class wn_generate_args(ctypes.Structure):
                 ("stream_temperatures", ctypes.c_void_p)]
 
 
-ABI_VERSION = 3  # include/wn_abi.h: WN_ABI_VERSION
+ABI_VERSION = 4  # include/wn_abi.h: WN_ABI_VERSION
 
 
 class wn_info(ctypes.Structure):
@@ -51,7 +51,8 @@ class wn_info(ctypes.Structure):
                                                "lds_bytes", "n_compute_units", "receptive_field")] + \
                [(n, ctypes.c_int64) for n in ("weight_bytes", "queue_bytes", "handoff_bytes", "evals_done")] + \
                [(n, ctypes.c_int32) for n in ("kernel_variant", "n_chains", "streams_per_item", "head_replicas", "n_samplers", "dev_overrides",
-                                               "layers_per_workgroup", "gate_shared", "gate_waited_ms", "gate_need_per_xcd")]
+                                               "layers_per_workgroup", "gate_shared", "gate_waited_ms", "gate_need_per_xcd",
+                                               "forward_native", "workgroups_per_cu", "resident_timeout_ms", "reserved_info")]
 
 
 EXPORTS = ["wn_abi_version", "wn_create", "wn_destroy", "wn_load_weights", "wn_reset", "wn_generate", "wn_wait",

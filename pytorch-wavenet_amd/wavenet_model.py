@@ -138,42 +138,70 @@ class WaveNetModel(nn.Module):
         return self.kernel_size == 2 and not any(c % 32 for c in (self.residual_channels, self.dilation_channels, self.skip_channels,
                                                                   self.end_channels, self.classes))
 
+    def _fallback(self, reason, warn=True):
+        """forward() on a CUDA tensor is about to run the reference's algorithm in torch ops (MIOpen conv1d + autograd) instead of the
+        native kernels: counted per reason (wn_stats()) and said out loud ONCE per reason -- the dual path is never silent."""
+        stats = self.__dict__.setdefault("_wn_fallbacks", {})
+        stats[reason] = stats.get(reason, 0) + 1
+        if warn and stats[reason] == 1:
+            import warnings
+            warnings.warn("WaveNetModel.forward(): torch path instead of the MI355X matrix-core kernels: %s "
+                          "(said once per reason; model.wn_stats() counts every call)" % reason, RuntimeWarning, stacklevel=4)
+        return None
+
+    def wn_stats(self):
+        """Extension: which path forward() / model(x) calls of this module took so far: {'native_forward', 'native_train_forward',
+        'torch_fallbacks': {reason: calls}} -- CPU tensors are not fallbacks (the reference's own path), everything else on a CUDA
+        tensor that did not reach wn_forward / wn_train_* is."""
+        return {"native_forward": int(getattr(self, "_wn_forward_calls", 0)), "native_train_forward": int(getattr(self, "_wn_train_calls", 0)),
+                "torch_fallbacks": dict(self.__dict__.get("_wn_fallbacks", {}))}
+
     def _native_forward(self, input):
         """Matrix-core forward (C ABI wn_forward, or wn_train_forward + wn_train_backward behind a torch.autograd.Function
         when gradients are wanted) when it applies: CUDA input that is exactly one-hot, shapes the GEMM kernels support.  Returns
-        None otherwise -- the caller then runs the torch path.  Short clips (the reference's zero-padding regime) are served natively;
-        the engine answers WN_E_UNSUPPORTED only for lengths at which the reference has no defined result, and the torch path then
-        reproduces what the reference does there.  A library that is not built is NOT a reason to fall back: on a CUDA tensor that
-        raises (the product must not run silently without its kernels)."""
-        if not input.is_cuda or input.dim() != 3 or input.size(1) != self.classes or self.kernel_size != 2:
-            return None
+        None otherwise -- the caller then runs the torch path, and on a CUDA tensor that is counted and warned about (_fallback).
+        Short clips (the reference's zero-padding regime) are served natively; the engine answers WN_E_UNSUPPORTED only for lengths
+        at which the reference has no defined result, and the torch path then reproduces what the reference does there.  A library
+        that is not built is NOT a reason to fall back: on a CUDA tensor that raises (the product must not run silently without its
+        kernels)."""
+        if not input.is_cuda:
+            return None   # the reference's own path: nothing to report
+        if input.dim() != 3 or input.size(1) != self.classes:
+            return self._fallback("input is not (N, classes, L)")
+        if self.kernel_size != 2:
+            return self._fallback("kernel_size %d (the matrix-core kernels are written for 2)" % self.kernel_size)
         want_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
         # Without autograd the engine decides: a channel shape that is not a multiple of 32 may still run natively, zero-padded into a
         # compiled shape (include/wn_abi.h: wn_create); with autograd the handle keeps the model's own shape and needs the multiples.
         no_native = getattr(self, "_wn_forward_unsupported", None) == self._forward_shape_key(input.device)
         if (want_grad or no_native) and not self._native_supported():
-            return None
+            return self._fallback("channel counts that are not multiples of 32 %s" % ("under autograd" if want_grad else "and fit no compiled shape"))
         if torch.is_grad_enabled() and input.requires_grad:
-            return None  # a gradient w.r.t. the one-hot input itself: torch path
-        if want_grad and (input.dtype != torch.float32 or os.environ.get("WN_TORCH_BACKWARD") == "1"):
-            return None
+            return self._fallback("a gradient with respect to the one-hot input is wanted")
+        if want_grad and input.dtype != torch.float32:
+            return self._fallback("autograd on a %s input" % str(input.dtype).replace("torch.", ""))
+        if want_grad and os.environ.get("WN_TORCH_BACKWARD") == "1":
+            return self._fallback("WN_TORCH_BACKWARD=1")
         vals, idx = input.max(dim=1)
         if not bool(((vals == 1) & (input.sum(dim=1) == 1)).all()):
-            return None  # not a one-hot batch: start_conv is a real contraction
+            return self._fallback("the input is not a one-hot batch (start_conv is a real contraction)")
         from mi355_wavenet import _abi
         try:
             if want_grad:
                 return self._native_train_forward(idx)
             eng = self._forward_engine()
+            if not eng.info()["forward_native"]:
+                # THIS channel shape has no native forward on this device (not zero-padded into a compiled shape): do not ask again.
+                # Keyed on what the engine REPORTS (wn_info.forward_native), not on the wording of an error.
+                self._wn_forward_unsupported = self._forward_shape_key(input.device)
+                return self._fallback("channel counts that are not multiples of 32 and fit no compiled shape")
             self._apply_precision(eng)
             out = eng.forward_indices(idx, self.output_length)
         except _abi.WnError as e:
             if e.code == _abi.WN_E_UNSUPPORTED:
-                if not want_grad and "multiples of 32" in str(e):
-                    # THIS channel shape has no native forward on this device (not zero-padded into a compiled shape): do not ask again.
-                    # (Other refusals -- N*L >= 2^31 rows, a length the reference has no result for -- say nothing about the next call.)
-                    self._wn_forward_unsupported = self._forward_shape_key(input.device)
-                return None
+                # (refusals of ONE call -- N*L >= 2^31 rows, a clip length the reference has no result for -- say nothing about the next call;
+                #  the torch path reproduces what the reference does there: its error, or its shapes)
+                return self._fallback("the engine refused this call: %s" % e, warn=False)
             raise
         self._wn_forward_calls = getattr(self, "_wn_forward_calls", 0) + 1
         return out.to(input.dtype)

@@ -6,6 +6,9 @@ oracle/ref_shim.py -- the 3 documented import-time patches, nothing else) in the
     python tests/golden/make_golden.py --v3     # golden_v3.npz (forward() + parameter gradients of the reference: cfg2, the cfg3 stack)
     python tests/golden/make_golden.py --v4     # golden_v4.npz (the same for clips SHORTER than receptive_field + output_length - 1: the
                                                 #   reference left-pads the layers' activations with zeros there, wavenet_modules.py:24-27)
+    python tests/golden/make_golden.py --v5     # golden_v5.npz (the BF16 training step's oracle: oracle/bf16_step.py -- the reference's step with
+                                                #   operands rounded where the product rounds them -- after that restatement, roundings off, has been
+                                                #   checked against the imported reference on the same cases)
 
 The fixtures pin the oracle (oracle/restated.py, oracle/wn_oracle.c) and, through it, the HIP path.
 Weights are NOT stored: they are regenerated from mi355_wavenet.synth.init_weights(cfg, seed) which is
@@ -259,8 +262,66 @@ def main_v3():
     print("wrote", path, os.path.getsize(path), "bytes;", len(out), "arrays")
 
 
+# golden_v5.npz: the oracle of the bf16 training step.  case -> (config name or dict, weight seed, N, output_length)
+B64 = dict(layers=4, blocks=2, dilation_channels=64, residual_channels=64, skip_channels=128, end_channels=128, classes=256, kernel_size=2, bias=True)
+BF16_CASES = {"cfg3": ("cfg3", 22, 1, 4), "cfg2": ("cfg2", 21, 1, 6), "b64": (B64, 24, 2, 5)}
+
+
+def main_v5():
+    import torch.nn.functional as F
+    sys.path.insert(0, HERE)
+    import digest as dg
+    import bf16_step
+    mdl, wm, ad = ref_shim.load()
+    out = {}
+    for case, (cname, wseed, N, out_len) in BF16_CASES.items():
+        cfg = synth.CONFIGS[cname] if isinstance(cname, str) else cname
+        W = synth.init_weights(cfg, seed=wseed)
+        m = build_ref_model(mdl, cfg, wseed, output_length=out_len)
+        L = m.receptive_field + out_len - 1
+        rs = np.random.RandomState(wseed + 1)
+        ids = rs.randint(0, 256, (N, L))
+        target = rs.randint(0, 256, (N * out_len,))
+        # (1) the REAL reference, fp32
+        x = torch.zeros(N, 256, L)
+        x.scatter_(1, torch.from_numpy(ids).view(N, 1, L), 1.)
+        y = m(x)
+        loss = F.cross_entropy(y.squeeze(), torch.from_numpy(target))
+        loss.backward()
+        ref_g = {k: (p.grad.numpy() if p.grad is not None else np.zeros(tuple(p.shape), dtype=np.float32)) for k, p in m.named_parameters()}
+        ref_d = dg.digest(ref_g)
+        # (2) the restatement with its roundings OFF must be the reference
+        lo0, ls0, g0 = bf16_step.step(cfg, W, ids, target, out_len, round_operands=False)
+        dev_out = float(np.abs(lo0 - y.detach().numpy()).max())
+        assert dev_out <= 2e-5 and abs(ls0 - float(loss)) <= 1e-6 * max(1.0, abs(ls0)), (case, dev_out, ls0, float(loss))
+        worst = dg.compare(ref_d, dg.digest(g0), 2e-5)
+        print(case, "restatement (no rounding) vs the imported reference: logits", dev_out, "gradient digests", worst)
+        # (3) ... and with the product's rounding points ON it is the bf16 step's oracle
+        lo1, ls1, g1 = bf16_step.step(cfg, W, ids, target, out_len, round_operands=True)
+        d1 = dg.digest(g1)
+        cost = 0.0
+        for k, r in ref_d.items():
+            if r[0] > 0:
+                cost = max(cost, abs(d1[k][0] - r[0]) / r[0], abs(d1[k][1] - r[1]) / r[1], float(np.abs(d1[k][6:] - r[6:]).max()) / r[0])
+        print(case, "bf16 rounding moves the logits by", float(np.abs(lo1 - lo0).max()), "of", float(np.abs(lo0).max()), "the loss by", ls1 - ls0,
+              "and the gradient digests by up to", cost)
+        out["bf16_%s_ids" % case] = ids.astype(np.int16)
+        out["bf16_%s_target" % case] = target.astype(np.int16)
+        out["bf16_%s_out" % case] = lo1.astype(np.float32)
+        out["bf16_%s_loss" % case] = np.array([ls1, ls0], dtype=np.float64)            # [with the roundings, without]
+        out["bf16_%s_meta" % case] = np.array([wseed, N, out_len, L], dtype=np.int64)
+        out["bf16_%s_vs_fp32" % case] = np.array([float(np.abs(lo1 - lo0).max()), float(np.abs(lo0).max()), cost], dtype=np.float64)
+        for k, v in d1.items():
+            out["bf16_%s_d_%s" % (case, k)] = v
+    path = os.path.join(HERE, "golden_v5.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes;", len(out), "arrays")
+
+
 if __name__ == "__main__":
-    if "--v4" in sys.argv:
+    if "--v5" in sys.argv:
+        main_v5()
+    elif "--v4" in sys.argv:
         main_v4()
     elif "--v3" in sys.argv:
         main_v3()

@@ -42,14 +42,14 @@ def test_hip_library_builds_and_exports_every_symbol():
         targets = [t for t in bundle.stdout.split() if "amdgcn" in t]
         assert targets and all("gfx950" in t for t in targets), targets
     lib = _abi.Library(so)  # dlopen + prototype check; no device call
-    assert lib.dll.wn_abi_version() == _abi.ABI_VERSION == 3
+    assert lib.dll.wn_abi_version() == _abi.ABI_VERSION == 4
 
 
 def test_struct_sizes_match_header():
     assert ctypes.sizeof(_abi.wn_config) == 16 * 4
     assert ctypes.sizeof(_abi.wn_weight_ptrs) == 14 * 8
     assert ctypes.sizeof(_abi.wn_generate_args) == 8 + 8 + 8 + 4 + 4 + 8 * 5 + 4 + 4 + 8
-    assert ctypes.sizeof(_abi.wn_info) == 8 * 4 + 4 * 8 + 10 * 4
+    assert ctypes.sizeof(_abi.wn_info) == 8 * 4 + 4 * 8 + 14 * 4
     assert ctypes.sizeof(_abi.wn_train_layout) == 14 * 8
 
 

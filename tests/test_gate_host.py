@@ -19,14 +19,19 @@ HARNESS = r"""
 #include <vector>
 // gate <busid> <cap> <need> <hold_ms> <timeout_ms> [n_threads] [same_stream]
 //   every thread books `need`, holds it hold_ms, releases; prints per thread "rc waited_ms shared t_in t_out" (ms since start)
+//   n_threads < 0: -n_threads threads that start 30 ms apart, thread i books need_i = (i == 1 ? cap - 2 : need): a LARGE job behind a small one
 int main(int argc, char** argv) {
     const char* bus = argv[1];
     const int cap = atoi(argv[2]), need = atoi(argv[3]), hold = atoi(argv[4]), tmo = atoi(argv[5]);
-    const int nt = argc > 6 ? atoi(argv[6]) : 1, same = argc > 7 ? atoi(argv[7]) : 0;
+    int nt = argc > 6 ? atoi(argv[6]) : 1;
+    const int same = argc > 7 ? atoi(argv[7]) : 0;
+    const bool staggered = nt < 0;
+    if (staggered) nt = -nt;
     if (hold == -2) {  // forge an entry of a LIVE pid (our parent's) with another start time: a re-used pid must not keep a dead owner's booking alive
         WnGateFile tab;
         const int fd = wn_gate_open_locked(wn_gate_path(bus), &tab);
         tab.slot[0].pid = (int32_t)getppid(); tab.slot[0].need = need; tab.slot[0].token = 77; tab.slot[0].born = wn_gate_born((int)getppid()) + 12345;
+        tab.slot[0].state = WN_GATE_RUNNING; tab.slot[0].seq = tab.next_seq++;
         wn_gate_close(fd, &tab, true);
         printf("0 0 1\n");
         return 0;
@@ -45,7 +50,8 @@ int main(int argc, char** argv) {
         th.emplace_back([&, i] {
             std::shared_ptr<WnGateTicket> t; long long w = 0; int sh = -1;
             const void* stream = same ? (const void*)0x10 : (const void*)(uintptr_t)(0x100 + i);
-            const int rc = wn_gate_acquire(bus, cap, need, stream, tmo, &t, &w, &sh);
+            if (staggered) usleep(30000 * i);
+            const int rc = wn_gate_acquire(bus, cap, (staggered && i == 1) ? cap - 2 : need, stream, tmo, &t, &w, &sh);
             const long long tin = wn_gate_now_ms() - t0;
             if (rc == 0) { usleep(hold * 1000); wn_gate_release(t); wn_gate_release(t); }  // (a second release is a no-op)
             char buf[128];
@@ -135,3 +141,49 @@ def test_without_a_shared_directory_the_gate_is_process_local(gate):
     assert all(r[0] == 0 and r[2] == 0 for r in rows)         # shared == 0: this process only
     spans = sorted((r[3], r[4]) for r in rows)
     assert spans[1][0] >= spans[0][1] - 2
+
+
+def test_first_come_first_served_a_large_job_is_not_starved_by_small_ones(gate):
+    # thread 0 (small, 10 of 32) runs; thread 1 (LARGE, 30 of 32) arrives 30 ms later and has to wait for it; threads 2..5 (small) arrive behind the
+    # large one: each of them would fit next to thread 0, but the large job was there first -- they are admitted behind it, not in front
+    rows = gate("0000:b2:00.0", 32, 10, 150, 5000, -6)
+    assert all(r[0] == 0 for r in rows)
+    large_in, large_out = rows[1][3], rows[1][4]
+    assert large_in >= rows[0][4] - 2                          # the large job ran after the first small one ...
+    for r in rows[2:]:
+        assert r[3] >= large_in - 2, rows                      # ... and nobody that arrived behind it was admitted in front of it
+    assert large_in < 400                                       # (it did not wait for all the small ones to come and go)
+
+
+def test_the_table_is_private_to_the_user_and_never_opened_through_a_link(gate, tmp_path):
+    # default location: /dev/shm/wn_mi355_gate_u<euid>_<busid>, mode 0600
+    env = {k: v for k, v in os.environ.items() if k != "WN_GATE_DIR"}
+    bus = "0000:fe:%02x.0" % (os.getpid() % 200)
+    path = "/dev/shm/wn_mi355_gate_u%d_%s" % (os.geteuid(), bus.replace(":", "_").replace(".", "_"))
+    try:
+        rows = gate(bus, 32, 3, 10, 1000, env_extra={"WN_GATE_DIR": ""})
+        assert rows[0][0] == 0 and rows[0][2] == 1
+        st = os.stat(path)
+        assert (st.st_mode & 0o777) == 0o600 and st.st_uid == os.geteuid()
+    finally:
+        if os.path.exists(path):
+            os.remove(path)
+    # a symbolic link planted under the table's name is refused (nothing behind it is created, chmod'ed or written): process-local gate, said out loud
+    d = tmp_path / "linkdir"
+    d.mkdir()
+    victim = tmp_path / "victim"
+    victim.write_text("precious")
+    os.chmod(victim, 0o644)
+    os.symlink(victim, d / "wn_mi355_gate_0000_fd_00_0")
+    rows = gate("0000:fd:00.0", 32, 3, 10, 1000, env_extra={"WN_GATE_DIR": str(d)})
+    assert rows[0][0] == 0 and rows[0][2] == 0                 # admitted, but NOT through the shared table
+    assert victim.read_text() == "precious" and (os.stat(victim).st_mode & 0o777) == 0o644
+    # ... and so is a table that everybody may write
+    d2 = tmp_path / "worlddir"
+    d2.mkdir()
+    f = d2 / "wn_mi355_gate_0000_fc_00_0"
+    f.write_bytes(b"")
+    os.chmod(f, 0o666)
+    rows = gate("0000:fc:00.0", 32, 3, 10, 1000, env_extra={"WN_GATE_DIR": str(d2)})
+    assert rows[0][0] == 0 and rows[0][2] == 0
+    assert f.read_bytes() == b""

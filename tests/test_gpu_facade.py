@@ -117,3 +117,21 @@ def test_forward_on_gpu_matches_golden(golden):
     y = m(x).cpu().detach().numpy()
     ref = golden["fwd_cfg1_out"]
     assert np.abs(y - ref).max() <= 1e-4  # fp32 GPU convs vs the reference's CPU fp32
+
+
+def test_generate_fast_with_128_classes():
+    """The drop-in on a 128-class model (the reference's older checkpoints): default seed classes // 2 = 64, indices in [0, 128), the
+    de-quantisation o = idx / 128 * 2 - 1 and mu_law_expansion with mu = 128 (wavenet_model.py:246,296,314) -- audio equals the oracle's."""
+    cfg = dict(synth.CONFIGS["cfg1"], classes=128)
+    W = synth.init_weights(cfg, seed=73)
+    m = wavenet_model.WaveNetModel(**cfg)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in W.items()})
+    for first in (None, torch.from_numpy(np.random.RandomState(73).randint(0, 128, 90))):
+        np.random.seed(6)
+        with redirect_stdout(io.StringIO()):
+            a = m.generate_fast(300, first_samples=first, temperature=0.9)
+        np.random.seed(6)
+        f = np.array([64]) if first is None else first.numpy()
+        idx, _ = c_oracle.generate(cfg, W, 300, f, 0.9, 0.0, np.random.random_sample(300))
+        assert idx.max() < 128 and np.array_equal(a, c_oracle.expand(idx, 128))
+        assert np.abs(a).max() <= 1.0

@@ -254,3 +254,46 @@ def test_forward_of_a_zero_padded_channel_shape():
         a = tiny(xt)     # 8 channels pad into the 16-channel kernel, which has no GEMM banks: the torch graph answers, once and for all
         b = tiny(xt)
     assert torch.equal(a, b) and getattr(tiny, "_wn_forward_calls", 0) == 0 and tiny._wn_forward_unsupported
+
+
+def test_the_torch_path_is_never_silent():
+    """forward() keeps the reference's algorithm in torch ops for what has no native form.  On a CUDA tensor every such call is COUNTED per
+    reason (model.wn_stats()) and announced once per reason (RuntimeWarning): kernel_size 3, a soft (non-one-hot) input, WN_TORCH_BACKWARD=1.
+    The native path counts too, and a CPU tensor -- the reference's own path -- is not a fallback."""
+    import os
+    import warnings
+    k3 = wavenet_model.WaveNetModel(layers=3, blocks=2, dilation_channels=32, residual_channels=32, skip_channels=64, end_channels=64,
+                                    classes=256, output_length=4, kernel_size=3, bias=True)
+    x = _onehot(np.random.RandomState(97).randint(0, 256, (2, k3.receptive_field + 3)))
+    with torch.no_grad():
+        ref = k3(x)
+    assert k3.wn_stats() == {"native_forward": 0, "native_train_forward": 0, "torch_fallbacks": {}}   # CPU: nothing to report
+    k3 = k3.cuda()
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        with torch.no_grad():
+            a = k3(x.cuda())
+            b = k3(x.cuda())
+    assert torch.allclose(a.cpu(), ref, atol=1e-4) and torch.equal(a, b)
+    said = [str(i.message) for i in w if issubclass(i.category, RuntimeWarning)]
+    assert len(said) == 1 and "kernel_size 3" in said[0], said                   # once, with the reason
+    st = k3.wn_stats()
+    assert st["native_forward"] == 0 and list(st["torch_fallbacks"].values()) == [2], st
+    # a model the kernels DO serve: native calls are counted, a soft input and the A/B switch are fallbacks with their own reasons
+    m = wavenet_model.WaveNetModel(layers=3, blocks=2, dilation_channels=32, residual_channels=32, skip_channels=64, end_channels=64,
+                                   classes=256, output_length=4, kernel_size=2, bias=False).cuda()
+    xg = _onehot(np.random.RandomState(98).randint(0, 256, (2, m.receptive_field + 3))).cuda()
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        with torch.no_grad():
+            m(xg)
+            m(xg * 0.5 + 0.25 / 128)           # not one-hot
+        m(xg).sum().backward()                  # native training forward + backward
+        os.environ["WN_TORCH_BACKWARD"] = "1"
+        try:
+            m(xg).sum().backward()
+        finally:
+            os.environ.pop("WN_TORCH_BACKWARD", None)
+    st = m.wn_stats()
+    assert st["native_forward"] == 1 and st["native_train_forward"] == 1, st
+    assert sorted(st["torch_fallbacks"].values()) == [1, 1] and len([i for i in w if issubclass(i.category, RuntimeWarning)]) == 2, (st, [str(i.message) for i in w])

@@ -117,6 +117,31 @@ def test_baseline_configs(label, cfgname, ns, N, n_given):
     eng.close()
 
 
+OTHER_CLASSES = [("cfg1_128", dict(synth.CONFIGS["cfg1"], classes=128), 1, 200, 30),
+                 ("cfg1_128_ns3", dict(synth.CONFIGS["cfg1"], classes=128), 3, 120, 10),
+                 ("tiny_bias_100", dict(synth.CONFIGS["tiny_bias"], classes=100), 2, 200, 12),     # not a multiple of 4, not a power of two
+                 ("cfg2_stack_128", dict(synth.CONFIGS["cfg2"], layers=4, blocks=2, classes=128), 2, 100, 10)]
+
+
+@pytest.mark.parametrize("label,cfg,ns,N,n_given", OTHER_CLASSES, ids=[c[0] for c in OTHER_CLASSES])
+def test_other_class_counts(label, cfg, ns, N, n_given):
+    """classes != 256 (the reference's older checkpoints quantise to 128 classes, notebooks/WavenetGenerate.ipynb:52-54): served by the generic
+    kernel -- the register-resident kernels are written for 256 -- and held to the same bars against the C oracle: logits 1e-5, greedy
+    bit-exact, sampled indices identical (the samplers' softmax / CDF / searchsorted over C classes), seeds inside [0, C)."""
+    cfg, W, first, uniforms = make_case(cfg, 61, ns, n_given, N)
+    C = cfg["classes"]
+    assert first.max() < C
+    eng = engine.Engine(cfg, W, n_streams=ns)
+    assert eng.info()["kernel_variant"] == 1, eng.info()
+    g = check_engine(eng, cfg, W, N, first, 0.0, 0.0, None, label + " greedy")
+    s1 = check_engine(eng, cfg, W, N, first, 1.0, 0.0, uniforms, label + " sampled")
+    s2 = check_engine(eng, cfg, W, N, first, 0.8, 0.002, uniforms, label + " sampled + regulariser")
+    idx = eng.generate(N, first, temperature=1.0, uniforms=uniforms)
+    assert idx.min() >= 0 and idx.max() < C and len(np.unique(idx)) > C // 8      # every draw inside the class range, and spread over it
+    print(label, "greedy", g, "sampled", s1, s2, eng.info())
+    eng.close()
+
+
 def test_cfg1_long_free_running():
     """>= 1000 free-running steps, greedy bit-exact and sampled identical (SURVEY.md section 8c items 2,3)."""
     cfg, W, first, uniforms = make_case("cfg1", 53, 1, 63, 3000)
@@ -354,6 +379,101 @@ def test_two_processes_on_one_gpu_take_turns(tmp_path):
         for s in range(2):
             o_idx, _ = c_oracle.generate(cfg, W, N, first[s], 1.0, 0.0, uniforms[s])
             assert np.array_equal(got[s], o_idx)
+
+
+HOG_WORKER = r"""
+import os, sys, time
+import numpy as np, torch
+from parity_common import make_case
+from mi355_wavenet import engine
+cfg, W, first, uniforms = make_case("cfg3", 58, 2, 20, 8)
+hog = engine.Engine(cfg, W, n_streams=2)
+n = int(os.environ["WN_TEST_HOG_SAMPLES"])
+hfirst = hog.mem.upload(np.full((2, 1), 128, dtype=np.int32))
+hout = hog.mem.empty((2, n), np.int32)
+hog.reset()
+torch.cuda.synchronize()
+hog.launch(hfirst, 1, n, 0.0, None, None, hout, None, timeout_ms=60000)   # greedy, ~50 us per sample: 212 of the 256 CUs for n * 50 us
+open(os.environ["WN_TEST_READY"], "w").close()
+hog.wait()
+print("HOG DONE", hog.info()["n_workgroups"])
+"""
+
+
+def _start_hog(tmp_path, hog_samples):
+    """A cfg3 job (212 of 256 CUs) in ANOTHER PROCESS that is not booked at the gate (WN_NO_DEVICE_GATE=1) -- to the admission it is what any
+    foreign kernel is: invisible.  (Another process: two streams of one process may share a hardware queue, which would serialise the two
+    kernels and hide the situation.)  Returns the process once its kernel has been launched."""
+    import subprocess
+    import sys
+    import time
+    here = os.path.dirname(os.path.abspath(__file__))
+    root = os.path.dirname(here)
+    script = tmp_path / "hog_worker.py"
+    script.write_text(HOG_WORKER)
+    env = dict(os.environ, WN_TESTING="1", WN_NO_DEVICE_GATE="1", WN_TEST_HOG_SAMPLES=str(hog_samples), WN_TEST_READY=str(tmp_path / "hog_ready"))
+    env["PYTHONPATH"] = os.pathsep.join([os.path.join(root, "pytorch-wavenet_amd"), os.path.join(root, "oracle"), here, env.get("PYTHONPATH", "")])
+    p = subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    t0 = time.time()
+    while not os.path.exists(env["WN_TEST_READY"]):
+        assert p.poll() is None, p.communicate()
+        assert time.time() - t0 < 300
+        time.sleep(0.0005)
+    return p
+
+
+def _finish_hog(p):
+    so, se = p.communicate(timeout=300)
+    assert p.returncode == 0 and "HOG DONE" in so, so[-1500:] + se[-3000:]
+
+
+def test_a_job_that_finds_the_cus_taken_starts_when_they_free_up(monkeypatch, tmp_path):
+    """Residency barrier (csrc/wn_kernel.h: wn_resident_barrier): the workgroups of a job check in and enter the chain only when ALL of them
+    are resident; the hand-off timeout starts behind that.  With a hand-off bound of 300 ms and a foreign kernel that holds most of the chip
+    for ~2 s, the job used to die in a hand-off wait (its resident part spinning for the part still in the dispatcher's queue); now it
+    starts when the CUs free up and equals the oracle."""
+    import time
+    monkeypatch.setenv("WN_TESTING", "1")
+    monkeypatch.setenv("WN_NO_DEVICE_GATE", "1")
+    monkeypatch.setenv("WN_RESIDENT_TIMEOUT_MS", "60000")
+    N = 300
+    cfg, W, first, uniforms = make_case("cfg3", 58, 2, 20, N)
+    job = engine.Engine(cfg, W, n_streams=2)
+    job.generate(8, first, temperature=1.0, uniforms=uniforms[:, :8])     # (warm: code object loaded, buffers allocated)
+    hog = _start_hog(tmp_path, 40000)
+    t0 = time.time()
+    idx = job.generate(N, first, temperature=1.0, uniforms=uniforms, timeout_ms=300)
+    waited = time.time() - t0
+    _finish_hog(hog)
+    for s in range(2):
+        o_idx, _ = c_oracle.generate(cfg, W, N, first[s], 1.0, 0.0, uniforms[s])
+        assert np.array_equal(idx[s], o_idx)
+    assert waited > 0.5, waited          # (it did wait for the hog: 40 000 samples are ~2 s)
+    assert job.info()["resident_timeout_ms"] == 60000 and job.info()["workgroups_per_cu"] >= 1
+    job.close()
+
+
+def test_a_job_that_never_becomes_resident_reports_busy_and_can_be_repeated(monkeypatch, tmp_path):
+    """... and where the CUs do not free up within WN_RESIDENT_TIMEOUT_MS the job gives up AT THE BARRIER: WN_E_BUSY, not a hand-off timeout
+    somewhere in the chain -- nothing ran, the queues are untouched, and the same call succeeds once the device is free."""
+    monkeypatch.setenv("WN_TESTING", "1")
+    monkeypatch.setenv("WN_NO_DEVICE_GATE", "1")
+    monkeypatch.setenv("WN_RESIDENT_TIMEOUT_MS", "150")
+    N = 300
+    cfg, W, first, uniforms = make_case("cfg3", 58, 2, 20, N)
+    job = engine.Engine(cfg, W, n_streams=2)
+    job.generate(8, first, temperature=1.0, uniforms=uniforms[:, :8])
+    hog = _start_hog(tmp_path, 40000)
+    with pytest.raises(_abi.WnError) as ei:
+        job.generate(N, first, temperature=1.0, uniforms=uniforms, timeout_ms=300, reset=True, batched_prime=False)
+    assert ei.value.code == _abi.WN_E_BUSY and "resident" in str(ei.value), str(ei.value)
+    assert job.info()["evals_done"] == 0     # rolled back: the job never started
+    _finish_hog(hog)
+    idx = job.generate(N, first, temperature=1.0, uniforms=uniforms, timeout_ms=300, reset=False, batched_prime=False)   # no reset: the queues must still be the fresh ones
+    for s in range(2):
+        o_idx, _ = c_oracle.generate(cfg, W, N, first[s], 1.0, 0.0, uniforms[s])
+        assert np.array_equal(idx[s], o_idx)
+    job.close()
 
 
 @pytest.mark.parametrize("cfgname,ns,n_given", [("cfg1", 2, 200), ("cfg2", 1, 3100), ("cfg3", 2, 700), ("cfg3", 1, 5200)])

@@ -355,6 +355,56 @@ def test_bf16_step_at_the_headline_channel_widths():
         assert rel <= (5e-3 if k.startswith("end_conv_2") else 0.15) and cos >= 0.99, (k, rel, cos)
 
 
+B64 = dict(layers=4, blocks=2, dilation_channels=64, residual_channels=64, skip_channels=128, end_channels=128, classes=256, kernel_size=2, bias=True)
+BF16_CASES = {"cfg3": "cfg3", "cfg2": "cfg2", "b64": B64}
+# Bounds of the bf16 step against ITS oracle (oracle/bf16_step.py: the reference's step with operands rounded where the product rounds them,
+# exact accumulation; pinned to the imported reference with the roundings off).  What is left between the two is the order of the fp32
+# accumulation on the matrix cores (1e-7 of scale) and the bf16 roundings it flips: a value within 1e-7 of a rounding boundary lands on
+# the other side -- one bf16 ulp (0.4 %) of ONE element, a few elements in ten thousand.  Measured on MI355X (profiles/r05_bf16_step_oracle.txt);
+# the bounds are the measurements with a margin of about three.
+BF16_LOGIT_TOL = {"cfg3": 5e-2, "cfg2": 5e-2, "b64": 5e-2}     # of the largest |logit|
+BF16_GRAD_TOL = {"cfg3": 5e-2, "cfg2": 5e-2, "b64": 5e-2}      # of the tensor's largest |gradient element| / its norm (digest.compare)
+
+
+@pytest.mark.parametrize("case", sorted(BF16_CASES))
+def test_bf16_step_against_its_oracle_at_depth(case):
+    """golden_v5.npz: logits, loss and parameter-gradient digests of the reference's training step with bf16-rounded operands
+    (tests/golden/make_golden.py --v5) on the 50-layer cfg3 stack, cfg2 and a biased 64-channel model -- the bf16 step (the one bench.py's
+    train5 line leads with) reproduces them within the stated bounds.  Also printed: how far the bf16 step is from the REFERENCE's fp32
+    gradients (golden_v3.npz) -- the price of the opt-in precision on these synthetic weights, not a parity claim."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import digest as dg
+    import wavenet_model
+    from mi355_wavenet import synth
+    g5 = np.load(os.path.join(ROOT, "tests", "golden", "golden_v5.npz"))
+    wseed, N, out_len, L = [int(v) for v in g5["bf16_%s_meta" % case]]
+    cfg = synth.CONFIGS[BF16_CASES[case]] if isinstance(BF16_CASES[case], str) else BF16_CASES[case]
+    m = wavenet_model.WaveNetModel(output_length=out_len, **cfg)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.init_weights(cfg, seed=wseed).items()})
+    m = m.cuda()
+    m.matrix_precision = "bf16"
+    ids = torch.from_numpy(g5["bf16_%s_ids" % case].astype(np.int64))
+    x = torch.zeros(N, 256, ids.shape[1]).scatter_(1, ids.view(N, 1, -1), 1.0).cuda()
+    target = torch.from_numpy(g5["bf16_%s_target" % case].astype(np.int64)).cuda()
+    out_n, loss_n, g_n = _step(m, x, target, torch_path=False)
+    ref = g5["bf16_%s_out" % case]
+    scale = float(np.abs(ref).max())
+    dev = float(np.abs(out_n.cpu().numpy() - ref).max())
+    loss_o, loss_fp32 = [float(v) for v in g5["bf16_%s_loss" % case]]
+    got = dg.digest({k: (v.cpu().numpy() if v is not None else np.zeros(tuple(dict(m.named_parameters())[k].shape), np.float32)) for k, v in g_n.items()})
+    want = {k: g5["bf16_%s_d_%s" % (case, k)] for k in got}
+    worst = dg.compare(want, got, 1.0)   # (measure first: the assertion with the case's bound follows)
+    moved = [float(v) for v in g5["bf16_%s_vs_fp32" % case]]
+    print("bf16 step vs its oracle, %s: logits %.3g of %.3g (%.2e), loss %.6f vs %.6f, worst gradient digest %.3g at %s" % (
+        case, dev, scale, dev / scale, loss_n, loss_o, worst[0], worst[1]))
+    print("   (the oracle itself vs the reference's fp32 step: logits %.3g of %.3g, loss %.6f vs %.6f, gradient digests up to %.3g)" % (
+        moved[0], moved[1], loss_o, loss_fp32, moved[2]))
+    assert dev <= BF16_LOGIT_TOL[case] * scale, (dev, scale)
+    assert abs(loss_n - loss_o) <= BF16_LOGIT_TOL[case] * max(1.0, abs(loss_o))
+    assert worst[0] <= BF16_GRAD_TOL[case], worst
+    assert m._wn_train_calls >= 1 and not m.wn_stats()["torch_fallbacks"]
+
+
 def test_bf16_step_one_launch_per_forward_layer_equals_the_two_launch_form(monkeypatch):
     """The bf16 step at the 128 / 128 widths runs each forward layer as ONE launch (wn_fwd_layer_bf16) on the bf16 shadow of x; with
     WN_NO_FUSED_LAYER=1 the same build launches the two products.  Same roundings, same accumulation order: logits and loss are equal bit

@@ -157,3 +157,40 @@ def test_golden_file_is_reproducible(golden):
     np.random.seed(npseed)
     a = m.generate_fast(n, first_samples=torch.from_numpy(first), temperature=temp, regularize=regz)
     assert np.array_equal(a, golden["gen_tiny_audio"])
+
+
+# ---------------------------------------------------------------- the bf16 training step's oracle (oracle/bf16_step.py)
+@pytest.mark.parametrize("case", ["cfg2", "cfg3"])
+def test_bf16_step_restatement_is_the_reference_when_nothing_is_rounded(golden, case):
+    """oracle/bf16_step.py with round_operands=False against golden_v3.npz -- logits, loss and every parameter gradient the REAL reference
+    produced (forward -> F.cross_entropy -> backward) on BASELINE configs[1] and the 50-layer cfg3 stack: 1e-4 / 1e-5 / 2e-5, the bars the
+    product's fp32 step is held to.  With the roundings on, the same graph is the bf16 step's oracle (golden_v5.npz, next test)."""
+    import os
+    import sys
+    import bf16_step
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import digest as dg
+    wseed, N, out_len = [int(v) for v in golden["grad_%s_meta" % case]][:3]
+    cfg = synth.CONFIGS[case]
+    W = synth.init_weights(cfg, seed=wseed)
+    logits, loss, grads = bf16_step.step(cfg, W, golden["grad_%s_ids" % case].astype(np.int64), golden["grad_%s_target" % case].astype(np.int64),
+                                         out_len, round_operands=False)
+    assert float(np.abs(logits - golden["grad_%s_out" % case]).max()) <= 1e-4
+    assert abs(loss - float(golden["grad_%s_loss" % case][0])) <= 1e-5 * max(1.0, abs(loss))
+    want = {k: golden["grad_%s_d_%s" % (case, k)] for k in grads}
+    dg.compare(want, dg.digest(grads), 2e-5)
+
+
+def test_bf16_step_fixture_is_reproducible():
+    """golden_v5.npz is what oracle/bf16_step.py computes here and now (cfg2 case; numpy / torch CPU arithmetic in float64 accumulation:
+    deterministic), and the roundings really are in it: the logits differ from the unrounded evaluation by about a percent."""
+    import os
+    import bf16_step
+    g5 = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_v5.npz"))
+    wseed, N, out_len, L = [int(v) for v in g5["bf16_cfg2_meta"]]
+    cfg = synth.CONFIGS["cfg2"]
+    W = synth.init_weights(cfg, seed=wseed)
+    logits, loss, _ = bf16_step.step(cfg, W, g5["bf16_cfg2_ids"].astype(np.int64), g5["bf16_cfg2_target"].astype(np.int64), out_len, True)
+    assert float(np.abs(logits - g5["bf16_cfg2_out"]).max()) <= 1e-5 and abs(loss - float(g5["bf16_cfg2_loss"][0])) <= 1e-6
+    moved = [float(v) for v in g5["bf16_cfg2_vs_fp32"]]
+    assert 1e-4 * moved[1] < moved[0] < 0.05 * moved[1]
