@@ -196,32 +196,32 @@ def _regs(text):
     return regs
 
 
+# -mllvm -align-all-nofallthru-blocks=6: every basic block that is only ever entered through a branch starts on a 64-byte instruction-cache line
+# (the padding in front of it is never executed).  The persistent chains are latency bound and take ~10 branches per item: a target near the end of a
+# fetch window costs a second fetch.  Measured on cfg3 x 64: 1.102 -> 1.107 M samples/s, reproducible to 0.05 % (profiles/r05_instruction_trims_and_alignment.txt).
+ALIGN_FLAGS = ["-mllvm", "-align-all-nofallthru-blocks=6"]
+
+
 def build_hip(force=False, verbose=False, extra_flags=()):
+    """ONE compile, in the form whose hand-scheduled loads carry the five wait states (the source's default WN_AP_SGPR_HAZARD): correct whatever the
+    register allocator does with the polls' base pointers.  (Round 4 compiled a form without them first and let the disassembly decide; round 5
+    measured both forms of the same source on one box -- 64 streams of cfg3 1.094-1.101 M with the wait states against 1.068-1.113 M without,
+    single stream 19.7-21.1 k either way (the spread is the box's, not the form's) -- and dropped the second form: nothing to gain, one hazard less to
+    police.)  The disassembly check still runs on every build: reserved registers, no scratch in the generation kernels, and rule 4, which the wait
+    states now satisfy by construction."""
     if not force and not _stale(OUT, DEPS):
         return OUT
     tmp_out = OUT + ".tmp"
-    base = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
-            "-Wno-unused-function", "-Wno-inline-asm", *extra_flags]
-    # The hand-scheduled input poll needs five wait states in front of its first load ONLY where the compiler reloads a spilled base
-    # pointer right in front of the block (wn_kernel_v3.h, WN_AP_SGPR_HAZARD).  First the form without them; the disassembly decides:
-    # rule 4 of the check refuses a library that has the hazard, and the source's default (with the wait states) is built instead.
-    pinned = any(f.startswith("-DWN_AP_SGPR_HAZARD") for f in extra_flags)
-    attempts = [[]] if pinned else [['-DWN_AP_SGPR_HAZARD=""'], []]
-    for n, extra in enumerate(attempts):
-        cmd = base + extra + ["-o", tmp_out] + SOURCES
-        if verbose:
-            print(" ".join(cmd))
-        subprocess.check_call(cmd)
-        try:
-            check_hand_scheduled_registers(tmp_out)   # a library that breaks the reservation is never installed
-            break
-        except Exception as e:
-            os.remove(tmp_out)
-            if n + 1 < len(attempts) and "SGPR base of a hand-scheduled load" in str(e):
-                if verbose:
-                    print("build.py: %s -- rebuilding with the wait states" % e)
-                continue
-            raise
+    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
+           "-Wno-unused-function", "-Wno-inline-asm", *ALIGN_FLAGS, *extra_flags, "-o", tmp_out] + SOURCES
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    try:
+        check_hand_scheduled_registers(tmp_out)   # a library that breaks the reservation is never installed
+    except Exception:
+        os.remove(tmp_out)
+        raise
     os.replace(tmp_out, OUT)
     return OUT
 

@@ -64,7 +64,7 @@
 #define WN_V3_COMPILER_VGPRS 152  // v152-v167: request sets of the input poll / the queue group's tap FIFO (see wn_ap_*, wn_q_*)
 // ---- experiment switches.  A product build (build.py) leaves every one of them at its default; setting one requires -DWN_EXPERIMENT,
 // which build.py never passes (tools/ builds the A/B variants): a library with wrong-on-purpose timing ablations cannot ship by accident.
-#if !defined(WN_EXPERIMENT) && (defined(WN_V3_SKIP_SLEEP) || defined(WN_V3_ABL) || defined(WN_V3_PAIR_ROWS) || defined(WN_V3_PRIO) || defined(WN_V3_LAST_SKIP_PRIO) || defined(WN_V3_SKIP_CHAINS) || defined(WN_V3_FG_CHAINS) || defined(WN_V3_SKIP_SLOTS) || defined(WN_V3_TAP_AT_A))
+#if !defined(WN_EXPERIMENT) && (defined(WN_V3_SKIP_SLEEP) || defined(WN_V3_ABL) || defined(WN_V3_PAIR_ROWS) || defined(WN_V3_PRIO) || defined(WN_V3_LAST_SKIP_PRIO) || defined(WN_V3_SKIP_CHAINS) || defined(WN_V3_FG_CHAINS) || defined(WN_V3_SKIP_SLOTS) || defined(WN_V3_TAP_AT_A) || defined(WN_V3_FAST_GATE) || defined(WN_V3_KPACK))
 #error "WN_V3_* experiment switches need -DWN_EXPERIMENT"
 #endif
 #ifndef WN_V3_SKIP_SLEEP
@@ -101,6 +101,17 @@
                              // answered behind it.  Requested after the dot the miss was in flight when the next token arrived; behind barrier A it has the
                              // item's whole service time and the wait for the next token to itself (round 5: hop into a layer with d >= 64 0.50 -> 0.35 us,
                              // 64 streams 1.002 -> 1.069 M samples/s; one stream per item loses 1-3 %: profiles/r05_tap_request_behind_barrier_a.txt)
+#endif
+#ifndef WN_V3_FAST_GATE
+#define WN_V3_FAST_GATE 1    // e^-v of the gated unit as exp2(v * -log2 e) -- three instructions (select, multiply by a per-lane constant, v_exp_f32) instead of
+                             // the eleven of the library-accurate wn_exp; the single rounding of the product moves sigma by <= 1.4e-8 (the bound of variant 4's
+                             // gate, wn_kernel_v4.h).  The filter/gate window of a layer is ISSUE bound (round 5: ~125 instructions of one wave per SIMD in 0.39 us):
+                             // every instruction taken out of it is ~2.5 ns per layer, 0.12 us per timestep of the 64-stream ring.  0: wn_exp as in rounds 2-4
+#endif
+#ifndef WN_V3_KPACK
+#define WN_V3_KPACK 1        // pair-rows form: the packed FMAs pair CONSECUTIVE x elements {x[k], x[k+1]} against {w[k], w[k+1]} of the filter row and of the gate
+                             // row (no broadcast of one x element into both halves: the compiler spent a v_mov per fourth element on those), and the parked tap-0
+                             // sums enter through one FMA with a per-lane 0 / 1 factor behind the dot instead of two selects in front of it.  0: {filter, gate} pairs
 #endif
 #ifndef WN_V3_PRIO
 #define WN_V3_PRIO 1  // 1: critical waves at a higher static wave priority (the queue and skip waves share their SIMDs: x64 911 -> 919 k, profiles/r02_v3_tap_fifo.txt)
@@ -174,6 +185,9 @@ static __device__ __forceinline__ wn_v4i wn_poll_pair(WnCtx& cx, __amdgpu_buffer
 #ifndef WN_AP_SGPR_HAZARD
 #define WN_AP_SGPR_HAZARD "s_nop 4\n\t"
 #endif
+#ifndef WN_AP_LOOP_ALIGN
+#define WN_AP_LOOP_ALIGN ""   // e.g. ".p2align 6\n\t": the head of the polling loops on an instruction-cache line (filled with s_nop, executed once per entry)
+#endif
 // (addresses: a wave-uniform base per partial in an SGPR pair + ONE 32-bit byte offset per lane -- four 64-bit lane pointers were
 //  eight registers of the polling waves' budget)
 static __device__ __forceinline__ void wn_ap_issue_a4(unsigned off, const wn_u64* b0, const wn_u64* b1, const wn_u64* b2, const wn_u64* b3) {
@@ -245,6 +259,7 @@ static __device__ __forceinline__ void wn_ap_issue_a1(unsigned off, const wn_u64
         WN_AP_ISSUE4(160, 161, 162, 163, 164, 165, 166, 167)                      \
         "s_sleep 2\n\t"                                                           \
         WN_AP_ISSUE4(152, 153, 154, 155, 156, 157, 158, 159)                      \
+        WN_AP_LOOP_ALIGN                                                          \
         "1:\n\t"                                                                  \
         "s_waitcnt vmcnt(4)\n\t"                                                  \
         WN_AP_CHECK4(160, 161, 162, 163, 164, 165, 166, 167)                      \
@@ -300,6 +315,7 @@ static __device__ __forceinline__ int wn_ap_spin4(unsigned off, const wn_u64* p0
         WN_AP_ISSUE2(160, 161, 162, 163)                                          \
         "s_sleep 2\n\t"                                                           \
         WN_AP_ISSUE2(152, 153, 154, 155)                                          \
+        WN_AP_LOOP_ALIGN                                                          \
         "1:\n\t"                                                                  \
         "s_waitcnt vmcnt(2)\n\t"                                                  \
         WN_AP_CHECK2(160, 161, 162, 163)                                          \
@@ -343,6 +359,7 @@ static __device__ __forceinline__ int wn_ap_spin2(unsigned off, const wn_u64* p0
         "global_load_dwordx2 v[160:161], %[off], %[p0] sc1\n\t"                      \
         "s_sleep 2\n\t"                                                           \
         "global_load_dwordx2 v[152:153], %[off], %[p0] sc1\n\t"                      \
+        WN_AP_LOOP_ALIGN                                                          \
         "1:\n\t"                                                                  \
         "s_waitcnt vmcnt(1)\n\t"                                                  \
         WN_AP_CHECK1(160, 161)                                                    \
@@ -592,7 +609,15 @@ static __device__ void wn_v3_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
         const int t_f = (2 * ch8) * T1 + kq8 / 2;  // the image lane of the channel's filter row (gate row: + T1)
         float w1[PAIR ? 1 : K1], w2[K2];
         wn_f2 wfg[PAIR ? K8 : 1];
-        if constexpr (PAIR) {
+        constexpr bool KPACK = PAIR && WN_V3_KPACK != 0;
+        if constexpr (KPACK) {   // wfg[2 j] = {w_f[2 j], w_f[2 j + 1]}, wfg[2 j + 1] = {w_g[2 j], w_g[2 j + 1]} of this lane's half slice
+            const float* imw = p.blobs + (size_t)cx.w * (SH::NWL * 256);
+#pragma unroll
+            for (int j = 0; j < K8 / 2; ++j) {
+                wfg[2 * j] = wn_f2{imw[(size_t)(half8 * K8 + 2 * j) * 256 + t_f], imw[(size_t)(half8 * K8 + 2 * j + 1) * 256 + t_f]};
+                wfg[2 * j + 1] = wn_f2{imw[(size_t)(half8 * K8 + 2 * j) * 256 + t_f + T1], imw[(size_t)(half8 * K8 + 2 * j + 1) * 256 + t_f + T1]};
+            }
+        } else if constexpr (PAIR) {
             const float* imw = p.blobs + (size_t)cx.w * (SH::NWL * 256);
 #pragma unroll
             for (int k = 0; k < K8; ++k) wfg[k] = wn_f2{imw[(size_t)(half8 * K8 + k) * 256 + t_f], imw[(size_t)(half8 * K8 + k) * 256 + t_f + T1]};
@@ -603,6 +628,10 @@ static __device__ void wn_v3_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
 #pragma unroll
         for (int k = 0; k < K2; ++k) w2[k] = img[(size_t)(2 * K1 + k) * 256];
         const float bres = img[(size_t)(2 * K1 + K2 + RS * DC + 1) * 256];
+        // per-lane constants of the gate: the lane with the first half of a slice evaluates the filter factor 2 s(2 f) - 1, its neighbour the gate factor s(g)
+        const float gate_c = (PAIR ? half8 : is_gate) ? -1.44269504088896341f : -2.88539008177792681f;   // -log2 e, -2 log2 e
+        const float pre_m = half8 ? 0.f : 1.f;   // (the lane that takes the parked tap-0 sums of its slice)
+        const float res_m = (c == 0 && kq2 == 0) ? 1.f : 0.f;   // (the lane that adds x[t] to its row of the residual partial: wavenet_model.py:165)
         long long* park = reinterpret_cast<long long*>(lds + L::park);
         const __amdgpu_buffer_rsrc_t rs_gx = wn_rsrc(p.gx);
         if (poller) request(0);
@@ -627,13 +656,49 @@ static __device__ void wn_v3_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
                 // (the G streams' chains are kept in ONE basic block -- unconditional LDS reads, selects instead of lane-predicated
                 //  branches, the z stores after both chains -- so that the scheduler can interleave them: a predicated store between
                 //  them made the second stream's whole chain wait for the first one's)
-                float xres[G];
+                float xres[G];   // x[t] of this lane's row: the residual add (slice 0's lane kq2 == 0 adds it: res_m), one FMA behind the residual dot
 #pragma unroll
-                for (int g = 0; g < G; ++g) {
-                    const float xv = xb[g * L::XR + SH::xpad(row2)];
-                    xres[g] = (c == 0 && kq2 == 0) ? xv : 0.f;
-                }
-                if constexpr (PAIR) {
+                for (int g = 0; g < G; ++g) xres[g] = xb[g * L::XR + SH::xpad(row2)];
+                if constexpr (KPACK) {
+                    // lane (ch8, kq8): filter row AND gate row of channel ch8 on half a slice of x, K8 elements: per float4 of x two packed FMAs per row
+                    // ({x0, x1} and {x2, x3} against the rows' consecutive weights) -- four chains per stream, the streams interleaved
+                    wn_f2 f01[G], f23[G], g01[G], g23[G];
+                    float pf[G], pg[G];
+                    const float* prs = pre + s * 256 + t_f;
+#pragma unroll
+                    for (int g = 0; g < G; ++g) {
+                        pf[g] = prs[g * 256]; pg[g] = prs[g * 256 + T1];   // parked per image lane (row, kq1): taken by the lane with the first half of slice kq1
+                        f01[g] = f23[g] = g01[g] = g23[g] = wn_f2{0.f, 0.f};
+                    }
+                    float4 v[G][K8 / 4];
+                    const float* xsl = xb + (kq8 / 2) * (K1 + 4) + half8 * K8;
+#pragma unroll
+                    for (int g = 0; g < G; ++g)
+#pragma unroll
+                        for (int k = 0; k < K8 / 4; ++k) v[g][k] = reinterpret_cast<const float4*>(xsl + g * L::XR)[k];
+#pragma unroll
+                    for (int k = 0; k < K8 / 4; ++k)
+#pragma unroll
+                        for (int g = 0; g < G; ++g) {
+                            f01[g] = __builtin_elementwise_fma(wfg[4 * k], wn_f2{v[g][k].x, v[g][k].y}, f01[g]);
+                            g01[g] = __builtin_elementwise_fma(wfg[4 * k + 1], wn_f2{v[g][k].x, v[g][k].y}, g01[g]);
+                            f23[g] = __builtin_elementwise_fma(wfg[4 * k + 2], wn_f2{v[g][k].z, v[g][k].w}, f23[g]);
+                            g23[g] = __builtin_elementwise_fma(wfg[4 * k + 3], wn_f2{v[g][k].z, v[g][k].w}, g23[g]);
+                        }
+                    float z[G];
+#pragma unroll
+                    for (int g = 0; g < G; ++g) {
+                        const wn_f2 fs = f01[g] + f23[g], gs = g01[g] + g23[g];
+                        const float f = wn_reduce<T8>(fmaf(pf[g], pre_m, fs.x + fs.y)), gt = wn_reduce<T8>(fmaf(pg[g], pre_m, gs.x + gs.y));
+                        const float rc = __builtin_amdgcn_rcpf(1.0f + (WN_V3_FAST_GATE ? __builtin_amdgcn_exp2f((half8 ? gt : f) * gate_c) : wn_exp(half8 ? -gt : -2.0f * f)));
+                        const float fac = half8 ? rc : fmaf(2.0f, rc, -1.0f);
+                        z[g] = fac * wn_partner<1>(fac);  // (the DPP move outside any lane-dependent branch)
+                    }
+                    if (kq8 == 0) {
+#pragma unroll
+                        for (int g = 0; g < G; ++g) zs[g * L::DCP + ch8] = z[g];
+                    }
+                } else if constexpr (PAIR) {
                     // the parked tap-0 sums are per image lane (row, kq1): the lane with the first half of slice kq1 takes both rows' sums
                     wn_f2 a0[G], a1[G], a2[G], a3x[G];
 #pragma unroll
@@ -672,7 +737,7 @@ static __device__ void wn_v3_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
 #pragma unroll
                     for (int g = 0; g < G; ++g) {
                         const float f = wn_reduce<T8>(a0[g].x + a1[g].x), gt = wn_reduce<T8>(a0[g].y + a1[g].y);
-                        const float rc = __builtin_amdgcn_rcpf(1.0f + wn_exp(half8 ? -gt : -2.0f * f));
+                        const float rc = __builtin_amdgcn_rcpf(1.0f + (WN_V3_FAST_GATE ? __builtin_amdgcn_exp2f((half8 ? gt : f) * gate_c) : wn_exp(half8 ? -gt : -2.0f * f)));
                         const float fac = half8 ? rc : fmaf(2.0f, rc, -1.0f);
                         z[g] = fac * wn_partner<1>(fac);  // (the DPP move outside any lane-dependent branch)
                     }
@@ -692,7 +757,7 @@ static __device__ void wn_v3_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
                     // product is the same two numbers multiplied: bit-identical
 #pragma unroll
                     for (int g = 0; g < G; ++g) {
-                        const float rc = __builtin_amdgcn_rcpf(1.0f + wn_exp(is_gate ? -acc[g] : -2.0f * acc[g]));
+                        const float rc = __builtin_amdgcn_rcpf(1.0f + (WN_V3_FAST_GATE ? __builtin_amdgcn_exp2f(acc[g] * gate_c) : wn_exp(is_gate ? -acc[g] : -2.0f * acc[g])));
                         const float fac = is_gate ? rc : fmaf(2.0f, rc, -1.0f);
                         const float z = fac * wn_partner<T1>(fac);  // (the DPP move outside any lane-dependent branch)
                         if (!is_gate && kq1 == 0) zs[g * L::DCP + ch] = z;
@@ -708,7 +773,7 @@ static __device__ void wn_v3_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
                     for (int g = 0; g < G; ++g) zero[g] = 0.f;
                     wn_dot_lds_gp<K2, G>(w2, zs + kq2 * K2, L::DCP, zero, a2);
 #pragma unroll
-                    for (int g = 0; g < G; ++g) xn[g] = (wn_reduce<T2>(a2[g]) + bres) + xres[g];  // valid on the kq2 == 0 lane of every row
+                    for (int g = 0; g < G; ++g) xn[g] = fmaf(xres[g], res_m, wn_reduce<T2>(a2[g]) + bres);  // valid on the kq2 == 0 lane of every row
                     if constexpr (T2 == 2) {
                         // rows 2j and 2j+1 sit on lanes 4j and 4j+2: one 16-byte store {x'(2j), tag, x'(2j+1), tag} by lane 4j instead of
                         // two 8-byte stores (write-through stores are retired per lane; consumers keep reading their own 8-byte half)

@@ -296,23 +296,38 @@ def main_v5():
         assert dev_out <= 2e-5 and abs(ls0 - float(loss)) <= 1e-6 * max(1.0, abs(ls0)), (case, dev_out, ls0, float(loss))
         worst = dg.compare(ref_d, dg.digest(g0), 2e-5)
         print(case, "restatement (no rounding) vs the imported reference: logits", dev_out, "gradient digests", worst)
-        # (3) ... and with the product's rounding points ON it is the bf16 step's oracle
-        lo1, ls1, g1 = bf16_step.step(cfg, W, ids, target, out_len, round_operands=True)
-        d1 = dg.digest(g1)
-        cost = 0.0
-        for k, r in ref_d.items():
-            if r[0] > 0:
-                cost = max(cost, abs(d1[k][0] - r[0]) / r[0], abs(d1[k][1] - r[1]) / r[1], float(np.abs(d1[k][6:] - r[6:]).max()) / r[0])
-        print(case, "bf16 rounding moves the logits by", float(np.abs(lo1 - lo0).max()), "of", float(np.abs(lo0).max()), "the loss by", ls1 - ls0,
-              "and the gradient digests by up to", cost)
+        # (3) ... and with the product's rounding points ON it is the bf16 step's oracle -- up to its own noise: three evaluation orders of the SAME
+        # rounding model (exact / fp32 / fp32 over a permuted K axis accumulation) and how far each lands from the fp32 reference (bf16_step.py says why)
+        def digest_devs(d):   # per tensor: the digest.compare() measure against the reference's gradients
+            out_ = []
+            for k, r in ref_d.items():
+                if r[0] > 0:
+                    g = d[k]
+                    out_.append(max(abs(g[0] - r[0]) / r[0], abs(g[1] - r[1]) / r[1], float(np.abs(g[2:6] - r[2:6]).max()) / r[1], float(np.abs(g[6:] - r[6:]).max()) / r[0]))
+            return np.array(out_)
+        noise = []
+        lo1 = ls1 = d1 = None
+        for order in ("exact", "f32", "f32perm"):
+            bf16_step.ACCUMULATE = order
+            lo, ls, g = bf16_step.step(cfg, W, ids, target, out_len, round_operands=True)
+            dv = digest_devs(dg.digest(g))
+            noise.append([float(np.linalg.norm(lo - lo0)), float(np.abs(lo - lo0).max()), abs(ls - ls0), float(np.sqrt((dv ** 2).mean())), float(dv.max())])
+            if order == "exact":
+                lo1, ls1, d1 = lo, ls, dg.digest(g)
+            print(case, order, "vs the fp32 reference: logits norm %.4f max %.4f (scale %.3f), loss %.5f, gradient digests rms %.4f max %.4f" % (
+                tuple(noise[-1][:2]) + (float(np.abs(lo0).max()),) + tuple(noise[-1][2:])))
+        bf16_step.ACCUMULATE = "exact"
         out["bf16_%s_ids" % case] = ids.astype(np.int16)
         out["bf16_%s_target" % case] = target.astype(np.int16)
-        out["bf16_%s_out" % case] = lo1.astype(np.float32)
+        out["bf16_%s_out" % case] = lo1.astype(np.float32)                             # (exact accumulation)
+        out["bf16_%s_ref_out" % case] = lo0.astype(np.float32)                         # the unrounded evaluation = the reference's fp32 logits
         out["bf16_%s_loss" % case] = np.array([ls1, ls0], dtype=np.float64)            # [with the roundings, without]
         out["bf16_%s_meta" % case] = np.array([wseed, N, out_len, L], dtype=np.int64)
-        out["bf16_%s_vs_fp32" % case] = np.array([float(np.abs(lo1 - lo0).max()), float(np.abs(lo0).max()), cost], dtype=np.float64)
+        out["bf16_%s_noise" % case] = np.array(noise, dtype=np.float64)                # rows: exact, f32, f32perm; columns: logit norm, logit max, |dloss|, digest rms, digest max
         for k, v in d1.items():
             out["bf16_%s_d_%s" % (case, k)] = v
+        for k, v in ref_d.items():
+            out["bf16_%s_r_%s" % (case, k)] = v                                        # the REFERENCE's gradient digests (fp32), the measure's origin
     path = os.path.join(HERE, "golden_v5.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes;", len(out), "arrays")

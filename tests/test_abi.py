@@ -209,10 +209,10 @@ def test_reserved_poll_registers_belong_to_the_hand_scheduled_blocks_only(tmp_pa
         run(good + ["s_nop 4", "<L2>", load] + rl + ["s_cbranch_scc1 L2"])
 
 
-def test_build_falls_back_to_the_wait_states_only_when_the_disassembly_demands_them(monkeypatch, tmp_path):
-    """build_hip compiles the form WITHOUT the five wait states in front of the hand-scheduled blocks first (-DWN_AP_SGPR_HAZARD="") and
-    keeps it only if check_hand_scheduled_registers accepts the result; a hazard finding makes it compile the source's default (with
-    them); any other finding, or a hazard in the default form, is an error and nothing is installed."""
+def test_build_is_one_compile_in_the_safe_form_and_installs_nothing_the_check_refuses(monkeypatch, tmp_path):
+    """build_hip compiles ONCE, in the source's default form (five wait states in front of every hand-scheduled load: no -DWN_AP_SGPR_HAZARD on the
+    command line), with the branch-target alignment flag; the disassembly check runs on the result and a library it refuses is never installed
+    (nothing is left behind either)."""
     import sys
     sys.path.insert(0, os.path.join(ROOT, "pytorch-wavenet_amd"))
     import build
@@ -222,7 +222,7 @@ def test_build_falls_back_to_the_wait_states_only_when_the_disassembly_demands_t
     calls, verdicts = [], []
 
     def fake_compile(cmd, **kw):
-        calls.append([c for c in cmd if c.startswith("-DWN_AP_SGPR_HAZARD")])
+        calls.append(list(cmd))
         open(cmd[cmd.index("-o") + 1], "wb").write(b"x")
 
     def fake_check(path, objdump=None):
@@ -233,26 +233,17 @@ def test_build_falls_back_to_the_wait_states_only_when_the_disassembly_demands_t
 
     monkeypatch.setattr(build.subprocess, "check_call", fake_compile)
     monkeypatch.setattr(build, "check_hand_scheduled_registers", fake_check)
-    hazard = "k: load: the SGPR base of a hand-scheduled load is written by `v_readlane_b32 s9, v128, 21` 1 wait state(s) before it (5 needed)"
-    verdicts[:] = [None]                       # clean at the first attempt: the fast form is installed
-    assert build.build_hip(force=True) == str(out) and calls == [['-DWN_AP_SGPR_HAZARD=""']] and out.exists()
+    verdicts[:] = [None]
+    assert build.build_hip(force=True) == str(out) and len(calls) == 1 and out.exists()
+    assert not any(c.startswith("-DWN_AP_SGPR_HAZARD") for c in calls[0]) and "-align-all-nofallthru-blocks=6" in calls[0] and "--offload-arch=gfx950" in calls[0]
     calls.clear(); out.unlink()
-    verdicts[:] = [hazard, None]               # hazard: second compile without the define (the source's default), installed
-    assert build.build_hip(force=True) == str(out) and calls == [['-DWN_AP_SGPR_HAZARD=""'], []] and out.exists()
-    calls.clear(); out.unlink()
-    verdicts[:] = [hazard, hazard]             # still there with the wait states: refused
+    verdicts[:] = ["k: use of a reserved poll register outside the hand-scheduled blocks in ..."]
     with pytest.raises(RuntimeError):
         build.build_hip(force=True)
-    assert not out.exists() and not os.path.exists(str(out) + ".tmp")
-    calls.clear()
-    verdicts[:] = ["k: use of a reserved poll register outside the hand-scheduled blocks in ..."]   # another rule: no second attempt
-    with pytest.raises(RuntimeError):
-        build.build_hip(force=True)
-    assert calls == [['-DWN_AP_SGPR_HAZARD=""']] and not out.exists()
-    calls.clear()
-    verdicts[:] = [None]                       # a caller that pins the macro gets exactly one attempt with its value
-    build.build_hip(force=True, extra_flags=('-DWN_AP_SGPR_HAZARD="s_nop 4\\n\\t"',))
-    assert len(calls) == 1 and calls[0][0].startswith('-DWN_AP_SGPR_HAZARD="s_nop')
+    assert len(calls) == 1 and not out.exists() and not os.path.exists(str(out) + ".tmp")
+    with open(os.path.join(ROOT, "pytorch-wavenet_amd", "csrc", "wn_kernel_v3.h")) as f:
+        src = f.read()
+    assert '#define WN_AP_SGPR_HAZARD "s_nop 4\\n\\t"' in src    # the source's default IS the safe form
 
 
 def test_graft_entry_build_runs():

@@ -393,7 +393,7 @@ hfirst = hog.mem.upload(np.full((2, 1), 128, dtype=np.int32))
 hout = hog.mem.empty((2, n), np.int32)
 hog.reset()
 torch.cuda.synchronize()
-hog.launch(hfirst, 1, n, 0.0, None, None, hout, None, timeout_ms=60000)   # greedy, ~50 us per sample: 212 of the 256 CUs for n * 50 us
+hog.launch(hfirst, 1, n, 0.0, None, None, hout, None, timeout_ms=60000)   # greedy, generic kernel: ~290 us per sample
 open(os.environ["WN_TEST_READY"], "w").close()
 hog.wait()
 print("HOG DONE", hog.info()["n_workgroups"])
@@ -401,9 +401,12 @@ print("HOG DONE", hog.info()["n_workgroups"])
 
 
 def _start_hog(tmp_path, hog_samples):
-    """A cfg3 job (212 of 256 CUs) in ANOTHER PROCESS that is not booked at the gate (WN_NO_DEVICE_GATE=1) -- to the admission it is what any
-    foreign kernel is: invisible.  (Another process: two streams of one process may share a hardware queue, which would serialise the two
-    kernels and hide the situation.)  Returns the process once its kernel has been launched."""
+    """A cfg3 job on the GENERIC kernel (208 workgroups spread evenly over the XCDs: 26 of every XCD's 32 CUs) in ANOTHER PROCESS that is not booked
+    at the gate (WN_NO_DEVICE_GATE=1) -- to the admission it is what any foreign kernel is: invisible.  Evenly spread matters: the dispatcher hands
+    out workgroups in order, round-robin over the XCDs, and stalls at the first XCD without a free CU -- behind a layer-aligned job (XCD 0 full) NOTHING
+    of the next kernel starts and it simply runs afterwards; behind this one every XCD takes a handful of its workgroups and then stalls: the partial
+    residency the barrier is for (measured: 42 of 210).  (Another process: two streams of one process may share a hardware queue.)  Returns the
+    process once its kernel has been launched."""
     import subprocess
     import sys
     import time
@@ -411,7 +414,7 @@ def _start_hog(tmp_path, hog_samples):
     root = os.path.dirname(here)
     script = tmp_path / "hog_worker.py"
     script.write_text(HOG_WORKER)
-    env = dict(os.environ, WN_TESTING="1", WN_NO_DEVICE_GATE="1", WN_TEST_HOG_SAMPLES=str(hog_samples), WN_TEST_READY=str(tmp_path / "hog_ready"))
+    env = dict(os.environ, WN_TESTING="1", WN_NO_DEVICE_GATE="1", WN_KERNEL="generic", WN_TEST_HOG_SAMPLES=str(hog_samples), WN_TEST_READY=str(tmp_path / "hog_ready"))
     env["PYTHONPATH"] = os.pathsep.join([os.path.join(root, "pytorch-wavenet_amd"), os.path.join(root, "oracle"), here, env.get("PYTHONPATH", "")])
     p = subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     t0 = time.time()
@@ -430,7 +433,7 @@ def _finish_hog(p):
 def test_a_job_that_finds_the_cus_taken_starts_when_they_free_up(monkeypatch, tmp_path):
     """Residency barrier (csrc/wn_kernel.h: wn_resident_barrier): the workgroups of a job check in and enter the chain only when ALL of them
     are resident; the hand-off timeout starts behind that.  With a hand-off bound of 300 ms and a foreign kernel that holds most of the chip
-    for ~2 s, the job used to die in a hand-off wait (its resident part spinning for the part still in the dispatcher's queue); now it
+    for ~1.4 s, the job used to die in a hand-off wait (its resident part spinning for the part still in the dispatcher's queue); now it
     starts when the CUs free up and equals the oracle."""
     import time
     monkeypatch.setenv("WN_TESTING", "1")
@@ -440,7 +443,7 @@ def test_a_job_that_finds_the_cus_taken_starts_when_they_free_up(monkeypatch, tm
     cfg, W, first, uniforms = make_case("cfg3", 58, 2, 20, N)
     job = engine.Engine(cfg, W, n_streams=2)
     job.generate(8, first, temperature=1.0, uniforms=uniforms[:, :8])     # (warm: code object loaded, buffers allocated)
-    hog = _start_hog(tmp_path, 40000)
+    hog = _start_hog(tmp_path, 5000)
     t0 = time.time()
     idx = job.generate(N, first, temperature=1.0, uniforms=uniforms, timeout_ms=300)
     waited = time.time() - t0
@@ -448,7 +451,7 @@ def test_a_job_that_finds_the_cus_taken_starts_when_they_free_up(monkeypatch, tm
     for s in range(2):
         o_idx, _ = c_oracle.generate(cfg, W, N, first[s], 1.0, 0.0, uniforms[s])
         assert np.array_equal(idx[s], o_idx)
-    assert waited > 0.5, waited          # (it did wait for the hog: 40 000 samples are ~2 s)
+    assert waited > 0.5, waited          # (it did wait for the hog: 5000 samples of the generic kernel are ~1.4 s)
     assert job.info()["resident_timeout_ms"] == 60000 and job.info()["workgroups_per_cu"] >= 1
     job.close()
 
@@ -463,7 +466,7 @@ def test_a_job_that_never_becomes_resident_reports_busy_and_can_be_repeated(monk
     cfg, W, first, uniforms = make_case("cfg3", 58, 2, 20, N)
     job = engine.Engine(cfg, W, n_streams=2)
     job.generate(8, first, temperature=1.0, uniforms=uniforms[:, :8])
-    hog = _start_hog(tmp_path, 40000)
+    hog = _start_hog(tmp_path, 5000)
     with pytest.raises(_abi.WnError) as ei:
         job.generate(N, first, temperature=1.0, uniforms=uniforms, timeout_ms=300, reset=True, batched_prime=False)
     assert ei.value.code == _abi.WN_E_BUSY and "resident" in str(ei.value), str(ei.value)

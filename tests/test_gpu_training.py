@@ -357,21 +357,71 @@ def test_bf16_step_at_the_headline_channel_widths():
 
 B64 = dict(layers=4, blocks=2, dilation_channels=64, residual_channels=64, skip_channels=128, end_channels=128, classes=256, kernel_size=2, bias=True)
 BF16_CASES = {"cfg3": "cfg3", "cfg2": "cfg2", "b64": B64}
-# Bounds of the bf16 step against ITS oracle (oracle/bf16_step.py: the reference's step with operands rounded where the product rounds them,
-# exact accumulation; pinned to the imported reference with the roundings off).  What is left between the two is the order of the fp32
-# accumulation on the matrix cores (1e-7 of scale) and the bf16 roundings it flips: a value within 1e-7 of a rounding boundary lands on
-# the other side -- one bf16 ulp (0.4 %) of ONE element, a few elements in ten thousand.  Measured on MI355X (profiles/r05_bf16_step_oracle.txt);
-# the bounds are the measurements with a margin of about three.
-BF16_LOGIT_TOL = {"cfg3": 5e-2, "cfg2": 5e-2, "b64": 5e-2}     # of the largest |logit|
-BF16_GRAD_TOL = {"cfg3": 5e-2, "cfg2": 5e-2, "b64": 5e-2}      # of the tensor's largest |gradient element| / its norm (digest.compare)
+
+
+def _digest_devs(ref_d, got_d):
+    """per tensor: the digest.compare() measure of `got` against `ref` (largest relative deviation of maximum, norm, projections, strided elements)"""
+    out = []
+    for k, r in ref_d.items():
+        if r[0] > 0:
+            g = got_d[k]
+            out.append(max(abs(g[0] - r[0]) / r[0], abs(g[1] - r[1]) / r[1], float(np.abs(g[2:6] - r[2:6]).max()) / r[1], float(np.abs(g[6:] - r[6:]).max()) / r[0]))
+    return np.array(out)
+
+
+@pytest.mark.parametrize("width,layers", [(64, 1), (128, 1), (64, 2), (128, 2)])
+def test_bf16_step_reproduces_its_oracle_exactly_when_shallow(width, layers):
+    """oracle/bf16_step.py -- the reference's training step with operands rounded to bf16 WHERE THE PRODUCT ROUNDS THEM, pinned to the imported
+    reference with the roundings off -- against the product's bf16 step on one- and two-layer models at both kernel families' widths (64: the
+    two-launch products, 128: the one-launch layers, bf16 shadow of x): here the rounding model is decidable.  Every logit row agrees to 1e-5
+    of scale except where ONE rounding landed on the other neighbour (accumulation order: a few elements in 10^5 -- at most two rows are
+    allowed to carry such a flip, and they stay within one bf16 ulp of a head activation); gradients within 3e-3 of their tensor's scale.
+    A rounding point that is missing, added or misplaced shows here as a difference in EVERY row."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import bf16_step
+    import digest as dg
+    import wavenet_model
+    from mi355_wavenet import synth
+    cfg = dict(layers=layers, blocks=1, dilation_channels=width, residual_channels=width, skip_channels=2 * width, end_channels=2 * width, classes=256,
+               kernel_size=2, bias=True)
+    W = synth.init_weights(cfg, seed=41 + width + layers)
+    out_len, N = 8, 2
+    m = wavenet_model.WaveNetModel(output_length=out_len, **cfg)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in W.items()})
+    m = m.cuda()
+    m.matrix_precision = "bf16"
+    rs = np.random.RandomState(5)
+    ids = rs.randint(0, 256, (N, m.receptive_field + out_len - 1 + 16))
+    target = rs.randint(0, 256, (N * out_len,))
+    x = torch.zeros(N, 256, ids.shape[1]).scatter_(1, torch.from_numpy(ids).view(N, 1, -1), 1.0).cuda()
+    out_n, loss_n, g_n = _step(m, x, torch.from_numpy(target).cuda(), torch_path=False)
+    lo, ls, g = bf16_step.step(cfg, W, ids, target, out_len, round_operands=True)
+    lo32, _, _ = bf16_step.step(cfg, W, ids, target, out_len, round_operands=False)
+    scale = max(1.0, float(np.abs(lo).max()))
+    row_dev = np.abs(out_n.cpu().numpy() - lo).max(axis=1)
+    flipped = int((row_dev > 1e-5 * scale).sum())
+    moved = float(np.abs(lo - lo32).max())
+    print("bf16 step, %d layer(s) at width %d: %d of %d logit rows carry a flipped rounding (largest deviation %.2e; the roundings themselves move the logits by %.2e), "
+          "loss %.6f vs %.6f" % (layers, width, flipped, len(row_dev), float(row_dev.max()), moved, loss_n, ls))
+    assert moved > 20e-5 * scale                                   # (the roundings are really in it)
+    assert flipped <= 2 and float(row_dev.max()) <= 0.5 * moved, (flipped, row_dev)
+    assert abs(loss_n - ls) <= 2e-4 * max(1.0, abs(ls))
+    got = dg.digest({k: (v.cpu().numpy() if v is not None else np.zeros(tuple(dict(m.named_parameters())[k].shape), np.float32)) for k, v in g_n.items()})
+    devs = _digest_devs(dg.digest(g), got)
+    print("   gradient digests vs the oracle: rms %.2e, max %.2e" % (float(np.sqrt((devs ** 2).mean())), float(devs.max())))
+    assert float(devs.max()) <= 3e-3, devs
+    assert m._wn_train_calls >= 1 and not m.wn_stats()["torch_fallbacks"]
 
 
 @pytest.mark.parametrize("case", sorted(BF16_CASES))
 def test_bf16_step_against_its_oracle_at_depth(case):
-    """golden_v5.npz: logits, loss and parameter-gradient digests of the reference's training step with bf16-rounded operands
-    (tests/golden/make_golden.py --v5) on the 50-layer cfg3 stack, cfg2 and a biased 64-channel model -- the bf16 step (the one bench.py's
-    train5 line leads with) reproduces them within the stated bounds.  Also printed: how far the bf16 step is from the REFERENCE's fp32
-    gradients (golden_v3.npz) -- the price of the opt-in precision on these synthetic weights, not a parity claim."""
+    """golden_v5.npz (tests/golden/make_golden.py --v5): the 50-layer cfg3 stack, cfg2 and a biased 64-channel model through oracle/bf16_step.py.
+    At depth a bf16-rounded evaluation is only defined up to its own rounding noise -- three accumulation orders of the oracle itself land as far
+    from each other as from the fp32 reference (the fixture's `noise` rows; oracle/bf16_step.py explains the mechanism) -- so what is asserted is
+    the noise LEVEL: the product's bf16 logits, loss and parameter gradients deviate from the REFERENCE's fp32 step (the fixture's ref_out / r_*
+    digests, produced by the imported reference) by no more than the oracle's own evaluation orders do, with a factor for the spread between
+    draws (1.5 on the logits' norm, 2 on maxima and on the gradient digests); the shallow test above pins where the roundings sit."""
     sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
     import digest as dg
     import wavenet_model
@@ -387,21 +437,24 @@ def test_bf16_step_against_its_oracle_at_depth(case):
     x = torch.zeros(N, 256, ids.shape[1]).scatter_(1, ids.view(N, 1, -1), 1.0).cuda()
     target = torch.from_numpy(g5["bf16_%s_target" % case].astype(np.int64)).cuda()
     out_n, loss_n, g_n = _step(m, x, target, torch_path=False)
-    ref = g5["bf16_%s_out" % case]
-    scale = float(np.abs(ref).max())
-    dev = float(np.abs(out_n.cpu().numpy() - ref).max())
-    loss_o, loss_fp32 = [float(v) for v in g5["bf16_%s_loss" % case]]
+    out_n = out_n.cpu().numpy()
+    ref, oracle = g5["bf16_%s_ref_out" % case], g5["bf16_%s_out" % case]
+    loss_o, loss_ref = [float(v) for v in g5["bf16_%s_loss" % case]]
+    noise = g5["bf16_%s_noise" % case]            # rows: exact / f32 / f32perm accumulation; columns: logit norm, logit max, |dloss|, digest rms, digest max
     got = dg.digest({k: (v.cpu().numpy() if v is not None else np.zeros(tuple(dict(m.named_parameters())[k].shape), np.float32)) for k, v in g_n.items()})
-    want = {k: g5["bf16_%s_d_%s" % (case, k)] for k in got}
-    worst = dg.compare(want, got, 1.0)   # (measure first: the assertion with the case's bound follows)
-    moved = [float(v) for v in g5["bf16_%s_vs_fp32" % case]]
-    print("bf16 step vs its oracle, %s: logits %.3g of %.3g (%.2e), loss %.6f vs %.6f, worst gradient digest %.3g at %s" % (
-        case, dev, scale, dev / scale, loss_n, loss_o, worst[0], worst[1]))
-    print("   (the oracle itself vs the reference's fp32 step: logits %.3g of %.3g, loss %.6f vs %.6f, gradient digests up to %.3g)" % (
-        moved[0], moved[1], loss_o, loss_fp32, moved[2]))
-    assert dev <= BF16_LOGIT_TOL[case] * scale, (dev, scale)
-    assert abs(loss_n - loss_o) <= BF16_LOGIT_TOL[case] * max(1.0, abs(loss_o))
-    assert worst[0] <= BF16_GRAD_TOL[case], worst
+    devs = _digest_devs({k: g5["bf16_%s_r_%s" % (case, k)] for k in got}, got)
+    mine = [float(np.linalg.norm(out_n - ref)), float(np.abs(out_n - ref).max()), abs(loss_n - loss_ref), float(np.sqrt((devs ** 2).mean())), float(devs.max())]
+    print("bf16 step at depth, %s -- deviation from the reference's fp32 step (logit norm, logit max, loss, gradient digest rms, max):" % case)
+    print("   product            %s" % "  ".join("%.4f" % v for v in mine))
+    for name, row in zip(("oracle, exact acc.", "oracle, fp32 acc. ", "oracle, permuted K"), noise):
+        print("   %s %s" % (name, "  ".join("%.4f" % v for v in row)))
+    print("   product vs the exact-accumulation oracle: logits norm %.4f max %.4f" % (float(np.linalg.norm(out_n - oracle)), float(np.abs(out_n - oracle).max())))
+    worst = noise.max(axis=0)
+    assert mine[0] <= 1.5 * worst[0] and mine[1] <= 2.0 * worst[1], (mine, worst)
+    assert mine[2] <= 2.0 * worst[2] + 2e-3
+    assert mine[3] <= 2.0 * worst[3] and mine[4] <= 2.0 * worst[4], (mine, worst)
+    assert float(np.linalg.norm(out_n - oracle)) <= 1.5 * (mine[0] + worst[0])     # (and it is a draw around the same point, not somewhere else)
+    assert mine[0] > 0.2 * worst[0]                                                 # (really the bf16 arithmetic: the fp32 step would sit at 1e-5)
     assert m._wn_train_calls >= 1 and not m.wn_stats()["torch_fallbacks"]
 
 

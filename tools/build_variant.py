@@ -16,16 +16,21 @@ def main():
     args = sys.argv[1:]
     force_fast = "--force-fast" in args   # A/B runs only: keep the fast poll form whatever the hazard check says (report it)
     force_safe = "--safe" in args
+    hazard = None
+    if "--hazard" in args:   # e.g. --hazard 's_nop 4;s_nop 4' : the wait states in front of the hand-scheduled loads (A/B runs)
+        i = args.index("--hazard")
+        hazard = "".join(part.strip() + "\\n\\t" for part in args[i + 1].split(";") if part.strip())
+        del args[i:i + 2]
     args = [a for a in args if a not in ("--force-fast", "--safe")]
     name, flags = args[0], args[1:]
     out = os.path.join(ROOT, "tools", "variants", "libwn_%s.so" % name)
     base = [wn_build.hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-function", "-Wno-inline-asm",
             "-DWN_EXPERIMENT", *flags]
-    for extra in ([[]] if force_safe else (['-DWN_AP_SGPR_HAZARD=""'], [])):
+    for extra in ([['-DWN_AP_SGPR_HAZARD="%s"' % hazard]] if hazard is not None else [[]] if force_safe else (['-DWN_AP_SGPR_HAZARD=""'], [])):
         subprocess.check_call(base + extra + ["-o", out] + wn_build.SOURCES)
         try:
             wn_build.check_hand_scheduled_registers(out)
-            print("%s: built (%s poll form)" % (out, "fast" if extra else "safe"))
+            print("%s: built (%s)" % (out, " ".join(extra) if extra else "source default: safe poll form"))
             return 0
         except Exception as e:
             print("%s: %s" % (name, e))
