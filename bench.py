@@ -226,6 +226,7 @@ def train_step_cfg5(device, N=32, L=16000, reps=3, precision="fp32"):
     layers=10 blocks=5 128/128/512, N one-second 16 kHz clips given as class indices, through the facade's native
     matrix-core forward + backward.  Reports step time and executed TFLOP/s (forward GEMM work x 3)."""
     import wavenet_model
+    from mi355_wavenet.optim import FusedAdam
     torch.manual_seed(0)
     m = wavenet_model.WaveNetModel(layers=10, blocks=5, dilation_channels=128, residual_channels=128, skip_channels=512,
                                    end_channels=256, classes=256, output_length=1, kernel_size=2, bias=False).cuda(device)
@@ -234,7 +235,7 @@ def train_step_cfg5(device, N=32, L=16000, reps=3, precision="fp32"):
     g = torch.Generator().manual_seed(1)
     idx = torch.randint(0, 256, (N, L), generator=g).cuda(device)
     target = torch.randint(0, 256, (N * out_len,), generator=g).cuda(device)
-    opt = torch.optim.Adam(m.parameters(), lr=1e-4)
+    opt = FusedAdam(m.parameters(), lr=1e-4)   # torch.optim.Adam's step as the engine's optimiser kernels (mi355_wavenet/optim.py, pinned to torch's in tests/test_gpu_training.py)
     R = D = 128; S = 512; E = 256; C = 256
     need, fwd = out_len, 0
     for d in reversed([2 ** (i % 10) for i in range(50)]):
@@ -279,6 +280,7 @@ def train5_main(a, dist, rank, local, n_gpus, global_batch=32, L=16000):
     optimiser step; value = clips (= seconds of audio) per second over all GPUs; scaling is strong (fixed global batch)."""
     import wavenet_model
     import wavenet_training
+    from mi355_wavenet.optim import FusedAdam
     torch.manual_seed(0)
     m = wavenet_model.WaveNetModel(layers=10, blocks=5, dilation_channels=128, residual_channels=128, skip_channels=512,
                                    end_channels=256, classes=256, output_length=1, kernel_size=2, bias=False).cuda(local)
@@ -289,7 +291,7 @@ def train5_main(a, dist, rank, local, n_gpus, global_batch=32, L=16000):
     g = torch.Generator().manual_seed(1 + rank)
     idx = torch.randint(0, 256, (n_local, L), generator=g).cuda(local)
     target = torch.randint(0, 256, (n_local * out_len,), generator=g).cuda(local)
-    opt = torch.optim.Adam(m.parameters(), lr=1e-4)
+    opt = FusedAdam(m.parameters(), lr=1e-4)   # torch.optim.Adam's step as the engine's optimiser kernels (mi355_wavenet/optim.py, pinned to torch's in tests/test_gpu_training.py)
     group = dist.group.WORLD if dist else None
 
     from mi355_wavenet import training

@@ -50,7 +50,7 @@
 extern "C" {
 #endif
 
-#define WN_ABI_VERSION 4  /* 4: WN_E_BUSY (start-up residency barrier with its own bound, WN_RESIDENT_TIMEOUT_MS);
+#define WN_ABI_VERSION 4  /* 4: WN_E_BUSY (start-up residency barrier with its own bound, WN_RESIDENT_TIMEOUT_MS), wn_info.forward_native, wn_adam_step;
                              3: per-device admission of persistent jobs (wn_info: gate_*), kernel variant 4 (layers_per_workgroup);
                              2: wn_train_loss; wn_info reports the form of the chain (streams_per_item, head_replicas, n_samplers) */
 
@@ -279,6 +279,30 @@ int wn_train_backward(wn_handle* h, const float* params, const float* dlogits, f
  * row: log-sum-exp in fp32; the mean is accumulated in fp64 in a fixed order (bit-reproducible).  A target outside [0, classes)
  * makes the row's loss NaN (torch raises a device assert).  WN_E_UNSUPPORTED unless classes == 256. */
 int wn_train_loss(wn_handle* h, const float* logits, const int64_t* targets, int64_t M, float* loss, float* dlogits, void* hip_stream);
+
+/* The optimiser half of the training step (wavenet_training.py:72-77: optional torch.nn.utils.clip_grad_norm over all parameters, then
+ * optimizer.step() -- optim.Adam by default, :19-36) for a SET of tensors in a handful of launches (torch: ~130 multi-tensor launches on
+ * config 5's 205 parameters): one pass for the gradients' total 2-norm, one pass that scales the gradients by min(1, max_norm / (norm + 1e-6)),
+ * applies weight decay and takes the Adam step -- torch.optim.Adam's formulas operation for operation (csrc/wn_optim.h).  No handle:
+ * params / grads / exp_avg / exp_avg_sq are HOST arrays of n_tensors DEVICE pointers to fp32 tensors of sizes[i] elements each (the caller's
+ * nn.Parameters, their .grad and the optimiser's state; nothing is copied or kept); scratch: 8 bytes of DEVICE memory; total_norm: DEVICE
+ * float or NULL.  step: the 1-based count of this step (bias corrections).  Asynchronous on hip_stream. */
+typedef struct wn_adam_args {
+    int32_t n_tensors;
+    int32_t device_id;
+    const int64_t* sizes;
+    void* const* params;
+    void* const* grads;
+    void* const* exp_avg;
+    void* const* exp_avg_sq;
+    float lr, beta1, beta2, eps, weight_decay;
+    float max_grad_norm;   /* <= 0: no clipping (the reference's gradient_clipping=None) */
+    int64_t step;
+    float* total_norm;
+    void* scratch;
+    void* hip_stream;
+} wn_adam_args;
+int wn_adam_step(const wn_adam_args* args);
 
 /* Diagnostics: record wall-clock stamps (100 MHz ticks) for the first n_items (evaluation, stream) steps of every
  * workgroup during the NEXT wn_generate: 8 slots per step -- 0 start, 1 input staged, 2 x' published, 3 done,

@@ -1,0 +1,112 @@
+// wn_optim.h -- the optimiser half of the training step (gfx950, device + host launch code; included by wn_runtime.hip).
+//
+// Reference: WavenetTrainer.train, /root/reference/wavenet_training.py:72-77 --
+//     if self.clip is not None: torch.nn.utils.clip_grad_norm(self.model.parameters(), self.clip)
+//     self.optimizer.step()                       # optim.Adam by default (:19-36: lr, weight_decay from the ctor)
+// On 205 parameter tensors (config 5) torch runs this as ~130 multi-tensor launches per step.  Here it is a handful: the tensors'
+// pointers travel in the kernel arguments, up to WN_OPT_TENSORS per launch (no device-side tables to keep in step with gradients that
+// zero_grad(set_to_none=True) re-allocates every step): one pass for the sum of squares of all gradients, one pass that clips and steps.
+// The arithmetic is torch.optim.Adam's single-tensor formulas, operation for operation (torch/optim/adam.py, _single_tensor_adam):
+//     g      = grad * clip_coef                     clip_coef = min(1, max_norm / (total_norm + 1e-6))   (clip_grad_norm_)
+//     g     += weight_decay * p                      (weight_decay != 0)
+//     m      = m + (g - m) * (1 - beta1)             exp_avg.lerp_(grad, 1 - beta1)
+//     v      = v * beta2 + (1 - beta2) * g * g       exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
+//     denom  = sqrt(v) / sqrt(1 - beta2^t) + eps
+//     p      = p - (lr / (1 - beta1^t)) * (m / denom)                                              addcdiv_
+// The clipped gradient is written back (clip_grad_norm_ works in place; loggers read .grad after the step).
+#ifndef WN_OPTIM_H
+#define WN_OPTIM_H
+
+#define WN_OPT_TENSORS 48          // tensors per launch: 48 x (4 pointers + 1 size) = 1920 bytes of kernel arguments
+#define WN_OPT_CHUNK 4096          // elements per workgroup
+
+struct WnOptBatch {
+    float* p[WN_OPT_TENSORS];
+    float* g[WN_OPT_TENSORS];
+    float* m[WN_OPT_TENSORS];
+    float* v[WN_OPT_TENSORS];
+    int chunk0[WN_OPT_TENSORS + 1];    // first workgroup of every tensor (prefix sums of ceil(size / WN_OPT_CHUNK))
+    long long size[WN_OPT_TENSORS];
+    int n;
+};
+
+// which tensor a workgroup works on (wave-uniform binary search over <= 48 prefix sums)
+static __device__ __forceinline__ int wn_opt_find(const WnOptBatch& b, int wg) {
+    int lo = 0, hi = b.n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (b.chunk0[mid] <= wg) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+// sum of squares of every gradient element -> one double (atomics of one partial per workgroup)
+__global__ __launch_bounds__(256) void wn_opt_sumsq(WnOptBatch b, double* acc) {
+    const int t = wn_opt_find(b, (int)blockIdx.x);
+    const long long i0 = (long long)((int)blockIdx.x - b.chunk0[t]) * WN_OPT_CHUNK, n = b.size[t];
+    const float* g = b.g[t];
+    float s = 0.f;
+    if ((reinterpret_cast<uintptr_t>(g) & 15u) == 0 && i0 + WN_OPT_CHUNK <= n) {
+        const float4* g4 = reinterpret_cast<const float4*>(g + i0);
+#pragma unroll
+        for (int q = 0; q < WN_OPT_CHUNK / 4 / 256; ++q) {
+            const float4 x = g4[q * 256 + threadIdx.x];
+            s += (x.x * x.x + x.y * x.y) + (x.z * x.z + x.w * x.w);
+        }
+    } else {
+        for (long long i = i0 + threadIdx.x; i < n && i < i0 + WN_OPT_CHUNK; i += 256) s += g[i] * g[i];
+    }
+    __shared__ float part[4];
+    s = wn_wave_sum(s);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(acc, (double)((part[0] + part[1]) + (part[2] + part[3])));
+}
+
+struct WnAdamScalars {
+    float lr_over_bc1, inv_sqrt_bc2, one_minus_b1, b2, one_minus_b2, eps, weight_decay, max_norm;   // max_norm <= 0: no clipping
+};
+
+__global__ __launch_bounds__(256) void wn_opt_adam(WnOptBatch b, WnAdamScalars k, const double* sumsq, float* norm_out) {
+    const int t = wn_opt_find(b, (int)blockIdx.x);
+    const long long i0 = (long long)((int)blockIdx.x - b.chunk0[t]) * WN_OPT_CHUNK, n = b.size[t];
+    float coef = 1.f;
+    if (k.max_norm > 0.f) {
+        const float total = (float)sqrt(*sumsq);
+        const float c = k.max_norm / (total + 1e-6f);
+        coef = c < 1.f ? c : 1.f;
+        if (norm_out && blockIdx.x == 0 && threadIdx.x == 0) *norm_out = total;
+    }
+    float* p = b.p[t]; float* g = b.g[t]; float* m = b.m[t]; float* v = b.v[t];
+    auto one = [&](float pi, float gi, float& mi, float& vi, float& go) -> float {
+        gi = gi * coef;
+        go = gi;
+        if (k.weight_decay != 0.f) gi = gi + k.weight_decay * pi;
+        mi = mi + (gi - mi) * k.one_minus_b1;
+        vi = vi * k.b2 + k.one_minus_b2 * gi * gi;
+        const float denom = sqrtf(vi) * k.inv_sqrt_bc2 + k.eps;
+        return pi - k.lr_over_bc1 * (mi / denom);
+    };
+    const bool vec = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v)) & 15u) == 0 && i0 + WN_OPT_CHUNK <= n;
+    if (vec) {
+#pragma unroll
+        for (int q = 0; q < WN_OPT_CHUNK / 4 / 256; ++q) {
+            const long long i = i0 + 4 * (q * 256 + (int)threadIdx.x);
+            float4 pv = *reinterpret_cast<float4*>(p + i), gv = *reinterpret_cast<float4*>(g + i), mv = *reinterpret_cast<float4*>(m + i), vv = *reinterpret_cast<float4*>(v + i);
+            float4 go;
+            pv.x = one(pv.x, gv.x, mv.x, vv.x, go.x); pv.y = one(pv.y, gv.y, mv.y, vv.y, go.y);
+            pv.z = one(pv.z, gv.z, mv.z, vv.z, go.z); pv.w = one(pv.w, gv.w, mv.w, vv.w, go.w);
+            *reinterpret_cast<float4*>(p + i) = pv; *reinterpret_cast<float4*>(m + i) = mv; *reinterpret_cast<float4*>(v + i) = vv;
+            if (coef != 1.f) *reinterpret_cast<float4*>(g + i) = go;
+        }
+    } else {
+        for (long long i = i0 + threadIdx.x; i < n && i < i0 + WN_OPT_CHUNK; i += 256) {
+            float mi = m[i], vi = v[i], go;
+            p[i] = one(p[i], g[i], mi, vi, go);
+            m[i] = mi; v[i] = vi;
+            if (coef != 1.f) g[i] = go;
+        }
+    }
+}
+
+#endif  // WN_OPTIM_H

@@ -17,6 +17,7 @@
 #include "wn_kernel_v4.h"
 #include "wn_forward.h"
 #include "wn_gate.h"
+#include "wn_optim.h"
 
 static thread_local char g_err[512] = "";
 // Development overrides (WN_KERNEL, WN_V3_MODE, WN_CHAINS, WN_SAMPLERS, WN_NO_LOCAL_STORES) pick another kernel or form than the
@@ -1577,3 +1578,45 @@ extern "C" int wn_set_forward_precision(wn_handle* h, int32_t bf16) {
 }
 
 #include "wn_train.inl"
+
+extern "C" int wn_adam_step(const wn_adam_args* a) {
+    g_err[0] = 0;
+    if (!a || a->n_tensors < 0 || (a->n_tensors > 0 && (!a->sizes || !a->params || !a->grads || !a->exp_avg || !a->exp_avg_sq)) || !a->scratch)
+        return wn_fail(WN_E_BADARG, "wn_adam_step: NULL argument");
+    if (a->step < 1 || !(a->beta1 >= 0.f && a->beta1 < 1.f) || !(a->beta2 >= 0.f && a->beta2 < 1.f) || !(a->eps >= 0.f))
+        return wn_fail(WN_E_BADARG, "wn_adam_step: step must be >= 1, betas in [0, 1), eps >= 0");
+    { int rc = rt_hip(hipSetDevice(a->device_id), "hipSetDevice"); if (rc) return rc; }
+    hipStream_t st = (hipStream_t)a->hip_stream;
+    const bool clip = a->max_grad_norm > 0.f;
+    double* acc = static_cast<double*>(a->scratch);
+    WnAdamScalars k;
+    const double bc1 = 1.0 - pow((double)a->beta1, (double)a->step), bc2 = 1.0 - pow((double)a->beta2, (double)a->step);
+    k.lr_over_bc1 = (float)((double)a->lr / bc1); k.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+    k.one_minus_b1 = 1.f - a->beta1; k.b2 = a->beta2; k.one_minus_b2 = 1.f - a->beta2; k.eps = a->eps; k.weight_decay = a->weight_decay;
+    k.max_norm = clip ? a->max_grad_norm : 0.f;
+    // batches of up to WN_OPT_TENSORS tensors (skipping the ones without a gradient: torch's optimisers do)
+    std::vector<WnOptBatch> batches;
+    WnOptBatch b;
+    memset(&b, 0, sizeof(b));
+    auto flush = [&]() { if (b.n > 0) { batches.push_back(b); memset(&b, 0, sizeof(b)); } };
+    for (int i = 0; i < a->n_tensors; ++i) {
+        if (!a->grads[i] || a->sizes[i] <= 0) continue;
+        if (!a->params[i] || !a->exp_avg[i] || !a->exp_avg_sq[i]) return wn_fail(WN_E_BADARG, "wn_adam_step: tensor %d has a gradient but no parameter / state pointer", i);
+        const long long chunks = (a->sizes[i] + WN_OPT_CHUNK - 1) / WN_OPT_CHUNK;
+        if (b.n == WN_OPT_TENSORS || (long long)b.chunk0[b.n] + chunks > 0x3fffffffll) flush();
+        b.p[b.n] = static_cast<float*>(a->params[i]); b.g[b.n] = static_cast<float*>(a->grads[i]);
+        b.m[b.n] = static_cast<float*>(a->exp_avg[i]); b.v[b.n] = static_cast<float*>(a->exp_avg_sq[i]);
+        b.size[b.n] = a->sizes[i];
+        b.chunk0[b.n + 1] = b.chunk0[b.n] + (int)chunks;
+        b.n++;
+    }
+    flush();
+    if (clip) {
+        int rc = rt_hip(hipMemsetAsync(acc, 0, sizeof(double), st), "hipMemsetAsync(norm)");
+        if (rc) return rc;
+        for (const WnOptBatch& bb : batches) hipLaunchKernelGGL(wn_opt_sumsq, dim3((unsigned)bb.chunk0[bb.n]), dim3(256), 0, st, bb, acc);
+    }
+    for (const WnOptBatch& bb : batches)
+        hipLaunchKernelGGL(wn_opt_adam, dim3((unsigned)bb.chunk0[bb.n]), dim3(256), 0, st, bb, k, clip ? acc : nullptr, clip ? a->total_norm : nullptr);
+    return rt_hip(hipGetLastError(), "wn_adam_step launches");
+}

@@ -55,8 +55,16 @@ class wn_info(ctypes.Structure):
                                                "forward_native", "workgroups_per_cu", "resident_timeout_ms", "reserved_info")]
 
 
+class wn_adam_args(ctypes.Structure):
+    _fields_ = [("n_tensors", ctypes.c_int32), ("device_id", ctypes.c_int32), ("sizes", ctypes.c_void_p), ("params", ctypes.c_void_p),
+                ("grads", ctypes.c_void_p), ("exp_avg", ctypes.c_void_p), ("exp_avg_sq", ctypes.c_void_p),
+                ("lr", ctypes.c_float), ("beta1", ctypes.c_float), ("beta2", ctypes.c_float), ("eps", ctypes.c_float), ("weight_decay", ctypes.c_float),
+                ("max_grad_norm", ctypes.c_float), ("step", ctypes.c_int64), ("total_norm", ctypes.c_void_p), ("scratch", ctypes.c_void_p),
+                ("hip_stream", ctypes.c_void_p)]
+
+
 EXPORTS = ["wn_abi_version", "wn_create", "wn_destroy", "wn_load_weights", "wn_reset", "wn_generate", "wn_wait",
-           "wn_get_info", "wn_export_queue", "wn_forward", "wn_set_forward_precision", "wn_prime", "wn_train_get_layout", "wn_train_export_params", "wn_train_forward", "wn_train_backward", "wn_train_loss", "wn_profile_next", "wn_profile_read", "wn_last_error"]
+           "wn_get_info", "wn_export_queue", "wn_forward", "wn_set_forward_precision", "wn_prime", "wn_train_get_layout", "wn_train_export_params", "wn_train_forward", "wn_train_backward", "wn_train_loss", "wn_adam_step", "wn_profile_next", "wn_profile_read", "wn_last_error"]
 
 
 TRAIN_SECTIONS = ("fg", "bfg", "res", "bres", "skip", "bskip", "bskip_total", "w1", "b1", "w2", "b2", "start_t", "start_b")
@@ -101,6 +109,7 @@ class Library:
                                        ctypes.c_void_p, ctypes.c_void_p]
         d.wn_train_backward.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         d.wn_train_loss.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        d.wn_adam_step.argtypes = [ctypes.POINTER(wn_adam_args)]
         d.wn_profile_next.argtypes = [ctypes.c_void_p, ctypes.c_int32]
         d.wn_profile_read.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64]
         for name in EXPORTS:

@@ -6,6 +6,8 @@ snapshot -> logger.  On an MI355X ``model(x)`` and ``loss.backward()`` run throu
 (wavenet_model.WaveNetModel._native_forward, mi355_wavenet/training.py).  Extensions, all off by default:
   * ``device_batches=True``: batches are cut on the GPU from the resident class-index stream (audio_data.DeviceBatches)
     and enter the model as indices -- no host one-hot, no 256x inflated H2D copy;
+  * ``optimizer=mi355_wavenet.optim.FusedAdam``: Adam's step and the gradient clipping in front of it as the engine's native kernels
+    (the default stays ``optim.Adam``, like upstream: any torch optimiser class works);
   * ``process_group``: data-parallel training, one process per GPU: every rank steps on the average of all ranks'
     gradients (ONE flat all-reduce per step over RCCL; SURVEY.md section 8e "Training (cfg5): plain data parallel").
 """
@@ -139,10 +141,17 @@ class WavenetTrainer:
         self.optimizer.zero_grad()
         loss.backward()
         average_gradients(self.model.parameters(), self.process_group)
-        if self.clip is not None:
-            torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.clip)
-        self.optimizer.step()
+        if self._fused_optimizer():   # the engine's optimiser kernels: clip_grad_norm folded into the step (mi355_wavenet/optim.py)
+            self.optimizer.step(max_grad_norm=self.clip)
+        else:
+            if self.clip is not None:
+                torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.clip)
+            self.optimizer.step()
         return loss.item()
+
+    def _fused_optimizer(self):
+        from mi355_wavenet.optim import FusedAdam
+        return isinstance(self.optimizer, FusedAdam)
 
     def _loader(self, batch_size, train):
         """DataLoader over the split selected by ``dataset.train``; data parallel: a DistributedSampler over THAT split

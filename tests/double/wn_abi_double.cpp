@@ -191,5 +191,6 @@ extern "C" int wn_train_export_params(wn_handle*, float*, void*) { return fail(W
 extern "C" int wn_train_forward(wn_handle*, const float*, const int32_t*, int64_t, int64_t, int64_t, float*, void*) { return fail(WN_E_UNSUPPORTED, "test double: GPU only"); }
 extern "C" int wn_train_backward(wn_handle*, const float*, const float*, float*, void*) { return fail(WN_E_UNSUPPORTED, "test double: GPU only"); }
 extern "C" int wn_train_loss(wn_handle*, const float*, const int64_t*, int64_t, float*, float*, void*) { return fail(WN_E_UNSUPPORTED, "test double: GPU only"); }
+extern "C" int wn_adam_step(const wn_adam_args*) { return fail(WN_E_UNSUPPORTED, "test double: GPU only"); }
 extern "C" int wn_profile_next(wn_handle*, int32_t) { return fail(WN_E_UNSUPPORTED, "test double: GPU only"); }
 extern "C" int wn_profile_read(wn_handle*, int64_t*, int64_t) { return fail(WN_E_UNSUPPORTED, "test double: GPU only"); }

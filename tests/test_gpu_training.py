@@ -600,3 +600,66 @@ def test_trainer_step_uses_the_fused_loss_and_follows_torch(tmp_path):
     assert abs(res["0"][0] - res["1"][0]) <= 1e-6 * abs(res["1"][0])
     for k, g in res["1"][1].items():
         assert float((res["0"][1][k] - g).abs().max()) <= 2e-5 * max(float(g.abs().max()), 1e-12), k
+
+
+@pytest.mark.parametrize("clip,wd", [(None, 0.0), (0.05, 0.0), (1e9, 0.01)])
+def test_fused_adam_follows_torch_adam(clip, wd):
+    """mi355_wavenet.optim.FusedAdam -- clip_grad_norm + Adam's step as the engine's optimiser kernels (wn_adam_step: two launches per 48 tensors)
+    -- against torch.nn.utils.clip_grad_norm_ + torch.optim.Adam on the same gradients, six steps on a model with tensors of every kind (odd
+    sizes, biases, a tensor without a gradient): parameters, both moments and the clipped gradients agree to rounding; the reported total norm is
+    clip_grad_norm_'s; state_dicts interchange."""
+    import copy
+    from mi355_wavenet.optim import FusedAdam
+    torch.manual_seed(11)
+    ma = _model(True, layers=3, blocks=2, ch=32, skip=64, end=64, out_len=8, seed=9, gain=2.0)
+    mb = copy.deepcopy(ma)
+    oa = torch.optim.Adam(ma.parameters(), lr=3e-3, weight_decay=wd)
+    ob = FusedAdam(mb.parameters(), lr=3e-3, weight_decay=wd)
+    x, target = _batch(ma, 2, 0, seed=12)
+    for it in range(6):
+        for m, o in ((ma, oa), (mb, ob)):
+            o.zero_grad(set_to_none=True)
+            loss = torch.nn.functional.cross_entropy(m(x), target)
+            loss.backward()
+        for (ka, pa), (kb, pb) in zip(ma.named_parameters(), mb.named_parameters()):   # same starting point every step: the comparison is per step
+            if pa.grad is not None:
+                pb.grad.copy_(pa.grad)
+        if clip is not None:
+            total = torch.nn.utils.clip_grad_norm_(ma.parameters(), clip)
+        oa.step()
+        ob.step(max_grad_norm=clip)
+        if clip is not None:
+            assert abs(float(ob.last_total_norm) - float(total)) <= 1e-5 * float(total)
+        for (ka, pa), (kb, pb) in zip(ma.named_parameters(), mb.named_parameters()):
+            assert (pa.grad is None) == (pb.grad is None), ka
+            scale = float(pa.abs().max())
+            assert float((pa - pb).abs().max()) <= 2e-6 * max(scale, 1e-3), (it, ka, float((pa - pb).abs().max()), scale)
+            if pa.grad is not None:
+                assert torch.allclose(pa.grad, pb.grad, rtol=1e-5, atol=1e-12), ka          # the clipped gradients are written back
+                sa, sb = oa.state[pa], ob.state[pb]
+                assert torch.allclose(sa["exp_avg"], sb["exp_avg"], rtol=1e-5, atol=1e-12) and torch.allclose(sa["exp_avg_sq"], sb["exp_avg_sq"], rtol=1e-5, atol=1e-20), ka
+                assert int(sa["step"]) == int(sb["step"]) == it + 1
+    oc = torch.optim.Adam(mb.parameters(), lr=3e-3, weight_decay=wd)
+    oc.load_state_dict(ob.state_dict())          # FusedAdam's state IS Adam's
+    assert int(next(iter(oc.state.values()))["step"]) == 6
+
+
+def test_trainer_with_the_fused_optimiser_follows_the_default_one():
+    """WavenetTrainer(optimizer=FusedAdam, gradient_clipping=...): clipping and step are ONE native call (wavenet_training.train_step) -- same losses
+    as the default optim.Adam + clip_grad_norm_ path over a few steps on resident device batches."""
+    import copy
+    import wavenet_training
+    from mi355_wavenet.optim import FusedAdam
+
+    class Data:   # the slice of WavenetDataset's interface DeviceBatches uses
+        classes, train = 256, True
+    m0 = _model(False, layers=3, blocks=2, ch=32, skip=64, end=64, out_len=8, seed=21, gain=2.0)
+    x, target = _batch(m0, 2, 0, seed=22)
+    losses = {}
+    for name, opt in (("adam", torch.optim.Adam), ("fused", FusedAdam)):
+        m = copy.deepcopy(m0)
+        tr = wavenet_training.WavenetTrainer(m, dataset=None, optimizer=opt, lr=2e-3, gradient_clipping=0.5)
+        losses[name] = [tr.train_step("onehot", x, target) for _ in range(5)]
+    assert losses["adam"][0] == losses["fused"][0]
+    assert np.allclose(losses["adam"], losses["fused"], rtol=2e-5), losses
+    assert losses["adam"][-1] < losses["adam"][0]

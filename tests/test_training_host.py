@@ -324,3 +324,19 @@ def test_data_parallel_validate_scores_the_test_split_once(dataset_file):
     assert got[0][0] == got[1][0]                                       # all-reduced: identical on both ranks
     # the per-batch mean of batch-mean losses depends on how the items fall into batches; bound it by the spread
     assert abs(got[0][0][0] - loss1) < 0.05 * max(1.0, abs(loss1))
+
+
+def test_fused_adam_refuses_what_it_cannot_step_natively():
+    """mi355_wavenet.optim.FusedAdam is the engine's optimiser kernel or nothing: CPU parameters raise (no silent torch fallback); its constructor
+    and state layout are torch.optim.Adam's."""
+    import torch
+    from mi355_wavenet.optim import FusedAdam
+    p = torch.nn.Parameter(torch.randn(7, 3))
+    opt = FusedAdam([p], lr=1e-3, betas=(0.8, 0.9), weight_decay=0.1)
+    assert opt.param_groups[0]["betas"] == (0.8, 0.9) and opt.param_groups[0]["weight_decay"] == 0.1
+    opt.step()                                   # no gradient: nothing to do, like torch's optimisers
+    p.grad = torch.ones_like(p)
+    with pytest.raises(TypeError, match="MI355X"):
+        opt.step()
+    with pytest.raises(ValueError):
+        FusedAdam([p], betas=(1.0, 0.9))
