@@ -295,8 +295,8 @@ typedef struct wn_adam_args {
     void* const* grads;
     void* const* exp_avg;
     void* const* exp_avg_sq;
-    float lr, beta1, beta2, eps, weight_decay;
-    float max_grad_norm;   /* <= 0: no clipping (the reference's gradient_clipping=None) */
+    double lr, beta1, beta2, eps, weight_decay;   /* doubles, like the Python floats torch derives its fp32 scalars from (1 - beta2 is formed in double) */
+    double max_grad_norm;  /* <= 0: no clipping (the reference's gradient_clipping=None) */
     int64_t step;
     float* total_norm;
     void* scratch;

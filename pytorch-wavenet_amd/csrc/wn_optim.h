@@ -9,10 +9,11 @@
 // The arithmetic is torch.optim.Adam's single-tensor formulas, operation for operation (torch/optim/adam.py, _single_tensor_adam):
 //     g      = grad * clip_coef                     clip_coef = min(1, max_norm / (total_norm + 1e-6))   (clip_grad_norm_)
 //     g     += weight_decay * p                      (weight_decay != 0)
-//     m      = m + (g - m) * (1 - beta1)             exp_avg.lerp_(grad, 1 - beta1)
-//     v      = v * beta2 + (1 - beta2) * g * g       exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
+//     m      = m + (1 - beta1) * (g - m)             _foreach_lerp_(exp_avgs, grads, 1 - beta1)
+//     v      = v * beta2;  v = v + ((1 - beta2) * g) * g                     _foreach_mul_, _foreach_addcmul_
 //     denom  = sqrt(v) / sqrt(1 - beta2^t) + eps
-//     p      = p - (lr / (1 - beta1^t)) * (m / denom)                                              addcdiv_
+//     p      = p + (-(lr / (1 - beta1^t))) * (m / denom)                                           _foreach_addcdiv_
+// with every scalar formed in double (as Python does) and rounded to fp32 once, and the fp32 roundings pinned per torch kernel.
 // The clipped gradient is written back (clip_grad_norm_ works in place; loggers read .grad after the step).
 #ifndef WN_OPTIM_H
 #define WN_OPTIM_H
@@ -64,7 +65,7 @@ __global__ __launch_bounds__(256) void wn_opt_sumsq(WnOptBatch b, double* acc) {
 }
 
 struct WnAdamScalars {
-    float lr_over_bc1, inv_sqrt_bc2, one_minus_b1, b2, one_minus_b2, eps, weight_decay, max_norm;   // max_norm <= 0: no clipping
+    float neg_step, sqrt_bc2, one_minus_b1, b2, one_minus_b2, eps, weight_decay, max_norm;   // neg_step = -(lr / (1 - beta1^t)); max_norm <= 0: no clipping
 };
 
 __global__ __launch_bounds__(256) void wn_opt_adam(WnOptBatch b, WnAdamScalars k, const double* sumsq, float* norm_out) {
@@ -78,14 +79,17 @@ __global__ __launch_bounds__(256) void wn_opt_adam(WnOptBatch b, WnAdamScalars k
         if (norm_out && blockIdx.x == 0 && threadIdx.x == 0) *norm_out = total;
     }
     float* p = b.p[t]; float* g = b.g[t]; float* m = b.m[t]; float* v = b.v[t];
+    // (each line is one of torch's foreach kernels; the intrinsics pin the roundings: every kernel's result is a rounded fp32, a multiply-add INSIDE one
+    //  kernel contracts to an FMA in torch's build as it does here)
     auto one = [&](float pi, float gi, float& mi, float& vi, float& go) -> float {
-        gi = gi * coef;
+        gi = __fmul_rn(gi, coef);                                        // _foreach_mul_(grads, clip_coef)
         go = gi;
-        if (k.weight_decay != 0.f) gi = gi + k.weight_decay * pi;
-        mi = mi + (gi - mi) * k.one_minus_b1;
-        vi = vi * k.b2 + k.one_minus_b2 * gi * gi;
-        const float denom = sqrtf(vi) * k.inv_sqrt_bc2 + k.eps;
-        return pi - k.lr_over_bc1 * (mi / denom);
+        if (k.weight_decay != 0.f) gi = __fmaf_rn(k.weight_decay, pi, gi);  // _foreach_add(grads, params, alpha=weight_decay)
+        mi = __fmaf_rn(k.one_minus_b1, __fsub_rn(gi, mi), mi);          // _foreach_lerp_(exp_avgs, grads, 1 - beta1)
+        vi = __fmul_rn(vi, k.b2);                                        // _foreach_mul_(exp_avg_sqs, beta2)
+        vi = __fmaf_rn(__fmul_rn(k.one_minus_b2, gi), gi, vi);           // _foreach_addcmul_(exp_avg_sqs, grads, grads, 1 - beta2)
+        const float denom = __fadd_rn(__fdiv_rn(__fsqrt_rn(vi), k.sqrt_bc2), k.eps);   // sqrt, div by sqrt(1 - beta2^t), add eps
+        return __fmaf_rn(k.neg_step, __fdiv_rn(mi, denom), pi);          // _foreach_addcdiv_(params, exp_avgs, denom, -step_size)
     };
     const bool vec = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v)) & 15u) == 0 && i0 + WN_OPT_CHUNK <= n;
     if (vec) {

@@ -1583,17 +1583,17 @@ extern "C" int wn_adam_step(const wn_adam_args* a) {
     g_err[0] = 0;
     if (!a || a->n_tensors < 0 || (a->n_tensors > 0 && (!a->sizes || !a->params || !a->grads || !a->exp_avg || !a->exp_avg_sq)) || !a->scratch)
         return wn_fail(WN_E_BADARG, "wn_adam_step: NULL argument");
-    if (a->step < 1 || !(a->beta1 >= 0.f && a->beta1 < 1.f) || !(a->beta2 >= 0.f && a->beta2 < 1.f) || !(a->eps >= 0.f))
+    if (a->step < 1 || !(a->beta1 >= 0. && a->beta1 < 1.) || !(a->beta2 >= 0. && a->beta2 < 1.) || !(a->eps >= 0.))
         return wn_fail(WN_E_BADARG, "wn_adam_step: step must be >= 1, betas in [0, 1), eps >= 0");
     { int rc = rt_hip(hipSetDevice(a->device_id), "hipSetDevice"); if (rc) return rc; }
     hipStream_t st = (hipStream_t)a->hip_stream;
-    const bool clip = a->max_grad_norm > 0.f;
+    const bool clip = a->max_grad_norm > 0.;
     double* acc = static_cast<double*>(a->scratch);
-    WnAdamScalars k;
-    const double bc1 = 1.0 - pow((double)a->beta1, (double)a->step), bc2 = 1.0 - pow((double)a->beta2, (double)a->step);
-    k.lr_over_bc1 = (float)((double)a->lr / bc1); k.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
-    k.one_minus_b1 = 1.f - a->beta1; k.b2 = a->beta2; k.one_minus_b2 = 1.f - a->beta2; k.eps = a->eps; k.weight_decay = a->weight_decay;
-    k.max_norm = clip ? a->max_grad_norm : 0.f;
+    WnAdamScalars k;   // every fp32 scalar is the double torch forms in Python, rounded once (torch/optim/adam.py: _multi_tensor_adam)
+    const double bc1 = 1.0 - pow(a->beta1, (double)a->step), bc2 = 1.0 - pow(a->beta2, (double)a->step);
+    k.neg_step = (float)(-(a->lr / bc1)); k.sqrt_bc2 = (float)sqrt(bc2);
+    k.one_minus_b1 = (float)(1.0 - a->beta1); k.b2 = (float)a->beta2; k.one_minus_b2 = (float)(1.0 - a->beta2); k.eps = (float)a->eps;
+    k.weight_decay = (float)a->weight_decay; k.max_norm = clip ? (float)a->max_grad_norm : 0.f;
     // batches of up to WN_OPT_TENSORS tensors (skipping the ones without a gradient: torch's optimisers do)
     std::vector<WnOptBatch> batches;
     WnOptBatch b;

@@ -58,8 +58,8 @@ class wn_info(ctypes.Structure):
 class wn_adam_args(ctypes.Structure):
     _fields_ = [("n_tensors", ctypes.c_int32), ("device_id", ctypes.c_int32), ("sizes", ctypes.c_void_p), ("params", ctypes.c_void_p),
                 ("grads", ctypes.c_void_p), ("exp_avg", ctypes.c_void_p), ("exp_avg_sq", ctypes.c_void_p),
-                ("lr", ctypes.c_float), ("beta1", ctypes.c_float), ("beta2", ctypes.c_float), ("eps", ctypes.c_float), ("weight_decay", ctypes.c_float),
-                ("max_grad_norm", ctypes.c_float), ("step", ctypes.c_int64), ("total_norm", ctypes.c_void_p), ("scratch", ctypes.c_void_p),
+                ("lr", ctypes.c_double), ("beta1", ctypes.c_double), ("beta2", ctypes.c_double), ("eps", ctypes.c_double), ("weight_decay", ctypes.c_double),
+                ("max_grad_norm", ctypes.c_double), ("step", ctypes.c_int64), ("total_norm", ctypes.c_void_p), ("scratch", ctypes.c_void_p),
                 ("hip_stream", ctypes.c_void_p)]
 
 
