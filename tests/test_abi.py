@@ -246,6 +246,27 @@ def test_build_is_one_compile_in_the_safe_form_and_installs_nothing_the_check_re
     assert '#define WN_AP_SGPR_HAZARD "s_nop 4\\n\\t"' in src    # the source's default IS the safe form
 
 
+def test_scratch_rule_covers_the_whole_library():
+    """build.py rule 3, round 5: a spill in ANY kernel fails the build, except the recorded matrix-core instantiations -- and those only up to their
+    recorded count (a regression there is a finding too)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "pytorch-wavenet_amd"))
+    import build
+
+    def dis(kernel, n):
+        return "0000000000001000 <%s>:\n" % kernel + "\ts_nop 0\n" + "\tscratch_store_dword off, v1, off // 000: 0\n" * n + "0000000000002000 <L12>:\n\ts_endpgm\n"
+
+    build._check_scratch_everywhere(dis("_Z11wn_fwd_gemmILi0EEv10WnGemmArgs", 0))
+    with pytest.raises(RuntimeError, match="spills to scratch"):
+        build._check_scratch_everywhere(dis("_Z11wn_fwd_gemmILi0EEv10WnGemmArgs", 1))
+    with pytest.raises(RuntimeError, match="spills to scratch"):
+        build._check_scratch_everywhere(dis("_Z17wn_bwd_layer_bf1614WnGemmArgsBf16S_", 2))
+    known = "_Z19wn_bwd_gemm_tn_bf16ILi8ELb0ELb1EEv12WnGemmTnArgs"
+    build._check_scratch_everywhere(dis(known, build.KNOWN_SPILLS["wn_bwd_gemm_tn_bf16ILi8ELb0ELb1E"]))
+    with pytest.raises(RuntimeError, match="tolerated"):
+        build._check_scratch_everywhere(dis(known, build.KNOWN_SPILLS["wn_bwd_gemm_tn_bf16ILi8ELb0ELb1E"] + 1))
+
+
 def test_graft_entry_build_runs():
     """The driver's "does it build" check (__graft_entry__.build()): builds the HIP library (checked: build.check_hand_scheduled_registers),
     the C oracle, loads the library through the binding and imports the facade -- on the CPU."""
