@@ -162,7 +162,8 @@ typedef struct wn_info {
     int32_t workgroups_per_cu; /* workgroups of the job's kernel ONE compute unit holds with the job's LDS (hipOccupancyMaxActiveBlocksPerMultiprocessor,
                                   checked against the plan at wn_create) */
     int32_t resident_timeout_ms; /* bound of the start-up residency barrier of the LAST job (WN_RESIDENT_TIMEOUT_MS, default 60 s); 0 = no job yet */
-    int32_t reserved_info;
+    int32_t skip_lane_slots;   /* variant 3: hand-off slots of the skip lanes re-used per in-flight item (the throughput-bound form of cfg3's kernel, 96 streams
+                                  and more); 0 = one slot per stream */
 } wn_info;
 
 /* wn_config.reserved[0]: plan the model's OWN channel shape (no zero padding into a compiled kernel shape, see wn_create): what a

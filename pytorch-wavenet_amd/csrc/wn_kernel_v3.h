@@ -85,8 +85,11 @@
 #endif
 #ifndef WN_V3_SKIP_SLOTS
 #define WN_V3_SKIP_SLOTS 0   // > 0: hand-off slots of a skip lane that stays inside one XCD are re-used per in-flight ITEM instead of one per stream (0: per
-                             // stream).  Correct, cuts the job's L2 <-> fabric traffic, and LOSES 3-13 %: the back-pressure look sits in front of the skip
-                             // chain's store, and that chain is as long as the x' chain (profiles/r04_skip_lane_slot_reuse_experiment.txt).
+                             // stream), in EVERY kernel (experiment switch).  Correct, cuts the job's L2 <-> fabric traffic, and LOSES 2-6 % where the ring is
+                             // latency bound (cfg3 up to 80 streams; round 4: profiles/r04_skip_lane_slot_reuse_experiment.txt) -- and GAINS 1-6 % where it is
+                             // throughput bound (cfg3 from 96 streams: 128 streams 1.50 -> 1.58 M): the product has it as a FORM of the cfg3 kernel (template
+                             // parameter SK = 4 of wn_generate_kernel_v3m, chosen by the host from 96 streams up: wn_v3_slots_for).  Other shapes lose with it
+                             // at every stream count (cfg2 x 128 -21 %, the train_script shape x 64 -25 %) and have no such form.
 #endif
 #ifndef WN_V3_SKIP_CHAINS
 #define WN_V3_SKIP_CHAINS 1  // independent FMA chains per row pair of the skip group's dot (1: one chain of DC packed FMAs, the arithmetic of rounds 2-3)
@@ -494,7 +497,7 @@ static __device__ __forceinline__ void wn_dot_lds_gp(const float (&w)[K], const 
     }
 }
 
-template <class SH, int P, int G>
+template <class SH, int P, int G, int SK = 0>
 static __device__ void wn_v3_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, float* lds, int l, int c) {
     constexpr int R = SH::R, DC = SH::DC, S = SH::S, T1 = SH::T1, K1 = SH::K1, T2 = SH::T2, K2 = SH::K2, RS = SH::RS;
     using L = WnV3Lds<SH, G>;
@@ -854,7 +857,7 @@ static __device__ void wn_v3_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
 #ifndef WN_V3_SLOT_DEBUG
 #define WN_V3_SLOT_DEBUG 0   // timing experiments (-DWN_EXPERIMENT): 1 = re-used slots WITHOUT the back-pressure look (unsafe), 2 = the look without re-use
 #endif
-        constexpr int NSLOT_C = WN_V3_SKIP_SLOTS;
+        constexpr int NSLOT_C = SK > 0 ? SK : WN_V3_SKIP_SLOTS;   // (SK: the form the host picks for cfg3 from 96 streams up, wn_v3_slots_for)
         const int NSLOT = NSLOT_C > 0 && NSLOT_C * G <= ns ? NSLOT_C : 0;
         const bool slot_look = NSLOT > 0 && l < NL - 1 && local_s && WN_V3_SLOT_DEBUG != 1;
         const bool slot_out = NSLOT > 0 && l < NL - 1 && local_s && WN_V3_SLOT_DEBUG != 2;                 // my lane: re-used slots
@@ -1705,7 +1708,7 @@ static __device__ void wn_v3_sampler(const WnPlan& p, const WnRun& r, WnCtx& cx,
 // by construction, not by the luck of the allocator; the launch bound still gives every lane the 168 the blocks address).  On gfx90a and
 // later the backend DOUBLES the attribute's value (unified VGPR + AGPR file) before it compares it with the occupancy limit -- a value above
 // 84 is silently dropped at 3 waves per SIMD -- hence WN_V3_COMPILER_VGPRS / 2; build.py disassembles the library and checks the result.
-template <int R, int DC, int S, int EC, int P, int G = 1>
+template <int R, int DC, int S, int EC, int P, int G = 1, int SK = 0>
 __global__ __launch_bounds__(WN_THREADS_V3) __attribute__((amdgpu_num_vgpr(WN_V3_COMPILER_VGPRS / 2)))
 void wn_generate_kernel_v3m(WnPlan p, WnRun r) {
     using SH = WnV2Shape<R, DC, S, EC>;
@@ -1718,7 +1721,7 @@ void wn_generate_kernel_v3m(WnPlan p, WnRun r) {
     if (wn_not_resident(cx, wn_lds3m)) return;   // (every workgroup of the job is resident from here on)
     const int n_layer_wg = p.NL * p.P;
     if (w < n_layer_wg) {
-        wn_v3_layer<SH, P, G>(p, r, cx, wn_lds3m, w / P, w % P);
+        wn_v3_layer<SH, P, G, SK>(p, r, cx, wn_lds3m, w / P, w % P);
         return;
     }
     if (threadIdx.x >= WN_THREADS) return;  // the head role is a 256-thread role, the sampler role a one-wave role

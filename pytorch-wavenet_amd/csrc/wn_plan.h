@@ -312,6 +312,16 @@ static inline int wn_v3_mode_for(int n_streams, const char* pin, int n_layers = 
     if (n_streams < 2) mode = 0;
     return mode;
 }
+// Skip-lane slot re-use (wn_kernel_v3.h, WN_V3_SKIP_SLOTS): a form of the two-streams-per-item kernel of shapes that have it (`has_form`: cfg3's), taken
+// where the chain is throughput bound -- measured crossover on cfg3 (50 layers): 80 streams -2 %, 96 +1 %, 112 +4 %, 128 +6 %, 150 +2.5 %
+// (profiles/r05_skip_lane_slots_by_stream_count.txt).  `pin`: the WN_V3_SLOTS environment override ("0" / "4"), or NULL.  Returns the slot count (0 = off).
+static inline int wn_v3_slots_for(int n_streams, int mode, bool has_form, const char* pin, int n_layers = 50) {
+    if (!has_form || !(mode & 1)) return 0;
+    int slots = n_streams >= 2 * n_layers - 4 ? 4 : 0;
+    if (pin && (pin[0] == '0' || pin[0] == '4') && !pin[1]) slots = pin[0] - '0';
+    if (slots * 2 > n_streams) slots = 0;
+    return slots;
+}
 // sizes of the rounds a job of n_streams > round_max streams runs in: as few rounds as possible, equal within one or two streams,
 // even (two streams per pipeline item) wherever streams are left for it, none above round_max
 static inline std::vector<int> wn_v3_round_sizes(int n_streams, int round_max) {

@@ -164,11 +164,12 @@ struct WnV2Entry {
     int R, DC, S, EC, nwl, nwh;
     int Pm;  // layer split the kernel is compiled for (its input poll is unrolled over it)
     void (*pack)(const WnPlan& pl, const WnHostWeights& w, std::vector<float>& out);
-    // [g2]: 0 = one stream per pipeline item of a layer workgroup, 1 = two (wn_v3_mode; NULL where the shape has no such form)
-    const void* fn_v3[2];
+    // [form]: 0 = one stream per pipeline item of a layer workgroup, 1 = two (wn_v3_mode), 2 = two + skip-lane slot re-use (wn_v3_slots_for); NULL where
+    // the shape has no such form
+    const void* fn_v3[3];
     int (*lds_floats_v3)(int ns, int g2);
     int lds_pre_v3;  // float offset of the per-stream area = what head / sampler workgroups use in front of their own tables
-    void (*launch_v3)(int g2, int grid, size_t lds, hipStream_t st, const WnPlan& p, const WnRun& r);
+    void (*launch_v3)(int form, int grid, size_t lds, hipStream_t st, const WnPlan& p, const WnRun& r);
 };
 
 template <class SH>
@@ -219,17 +220,18 @@ static void wn_pack_v2(const WnPlan& pl, const WnHostWeights& w, std::vector<flo
     (void)C;
 }
 
-template <int R, int DC, int S, int EC, int PM>
+template <int R, int DC, int S, int EC, int PM, int SK = 0>
 static WnV2Entry wn_v2_entry() {
     using SH = WnV2Shape<R, DC, S, EC>;
     WnV2Entry e;
     e.R = R; e.DC = DC; e.S = S; e.EC = EC; e.nwl = SH::NWL; e.nwh = SH::NWH; e.Pm = PM;
     e.pack = wn_pack_v2<SH>;
-    e.fn_v3[0] = e.fn_v3[1] = nullptr; e.lds_floats_v3 = nullptr; e.launch_v3 = nullptr; e.lds_pre_v3 = 0;
+    e.fn_v3[0] = e.fn_v3[1] = e.fn_v3[2] = nullptr; e.lds_floats_v3 = nullptr; e.launch_v3 = nullptr; e.lds_pre_v3 = 0;
     static_assert(wn_v3_fits<SH, PM>(), "every table entry runs the wave-specialised kernel");
     {
         e.fn_v3[0] = (const void*)wn_generate_kernel_v3m<R, DC, S, EC, PM, 1>;
         if constexpr (wn_v3_g2_fits<SH>()) e.fn_v3[1] = (const void*)wn_generate_kernel_v3m<R, DC, S, EC, PM, 2>;
+        if constexpr (wn_v3_g2_fits<SH>() && SK > 0) e.fn_v3[2] = (const void*)wn_generate_kernel_v3m<R, DC, S, EC, PM, 2, SK>;
         e.lds_pre_v3 = WnV3Lds<SH, 1>::pre;
         e.lds_floats_v3 = [](int ns, int g2) {
             int lay = WnV3Lds<SH, 1>::floats(ns);
@@ -240,9 +242,12 @@ static WnV2Entry wn_v2_entry() {
             if (smp * 4 <= WN_LDS_MAX_BYTES && smp > need) need = smp;
             return need;
         };
-        e.launch_v3 = [](int g2, int grid, size_t lds, hipStream_t st, const WnPlan& p, const WnRun& r) {
+        e.launch_v3 = [](int form, int grid, size_t lds, hipStream_t st, const WnPlan& p, const WnRun& r) {
+            if constexpr (wn_v3_g2_fits<SH>() && SK > 0) {
+                if (form == 2) { hipLaunchKernelGGL((wn_generate_kernel_v3m<R, DC, S, EC, PM, 2, SK>), dim3(grid), dim3(WN_THREADS_V3), lds, st, p, r); return; }
+            }
             if constexpr (wn_v3_g2_fits<SH>()) {
-                if (g2) { hipLaunchKernelGGL((wn_generate_kernel_v3m<R, DC, S, EC, PM, 2>), dim3(grid), dim3(WN_THREADS_V3), lds, st, p, r); return; }
+                if (form >= 1) { hipLaunchKernelGGL((wn_generate_kernel_v3m<R, DC, S, EC, PM, 2>), dim3(grid), dim3(WN_THREADS_V3), lds, st, p, r); return; }
             }
             hipLaunchKernelGGL((wn_generate_kernel_v3m<R, DC, S, EC, PM, 1>), dim3(grid), dim3(WN_THREADS_V3), lds, st, p, r);
         };
@@ -252,7 +257,7 @@ static WnV2Entry wn_v2_entry() {
 
 static const std::vector<WnV2Entry>& wn_v2_table() {
     static const std::vector<WnV2Entry> t = {
-        wn_v2_entry<128, 32, 512, 32, 4>(),   // cfg3: P=4, PA=8 (a 64-row head slice is the slowest pipeline stage)
+        wn_v2_entry<128, 32, 512, 32, 4, 4>(),   // cfg3: P=4, PA=8 (a 64-row head slice is the slowest pipeline stage); + the slot re-use form (96 streams and more)
         wn_v2_entry<64, 64, 256, 64, 1>(),    // cfg2: P=1, PA=4
         wn_v2_entry<32, 32, 256, 64, 1>(),    // cfg1: P=1, PA=4
         wn_v2_entry<32, 16, 1024, 32, 2>(),   // train_script.py chaconne shape, split two ways (64 skip weights per lane), PA=16 (end_conv_1 slice in LDS)
@@ -474,6 +479,7 @@ struct wn_handle {
     int v2_index;  // row of wn_v2_table()
     int lds_bytes;
     int v3_mode;   // variant 3: streams per pipeline item (wn_v3_mode)
+    int v3_slots = 0;   // variant 3: skip-lane slots re-used per in-flight item (wn_v3_slots_for; 0 = one slot per stream)
     int dev_overrides = 0;  // a development override was in effect when this handle was planned (wn_dev_env)
     // Zero padding: a channel shape the wave-specialised kernel is not compiled for runs as the next instantiated shape that holds it,
     // its weights padded with zeros (wn_pad_config).  cfg / plan then carry the PADDED channel counts; these are the caller's.
@@ -678,7 +684,7 @@ static int wn_create_impl(const wn_config* cfg, wn_handle** out) {
                 f->plan.n_streams = cfg->n_streams;
                 f->have_weights = false; f->pending = false; f->last_stream = nullptr; f->t_base = 0;
                 f->n_cu = n_cu; f->wall_khz = wall_khz; f->variant = c0->variant; f->v2_index = c0->v2_index; f->lds_bytes = c0->lds_bytes;
-                f->v3_mode = c0->v3_mode;
+                f->v3_mode = c0->v3_mode; f->v3_slots = c0->v3_slots;
                 f->d_blobs = f->d_start_t = f->d_start_b = f->d_rings = nullptr;
                 f->d_dil = f->d_wg_map = nullptr; f->d_ring_off = nullptr; f->d_gran = nullptr; f->d_status = nullptr;
                 f->d_prof = nullptr; f->prof_items = 0; f->prof_recorded = 0;
@@ -745,6 +751,7 @@ static int wn_create_impl(const wn_config* cfg, wn_handle** out) {
             } else {
                 h->v3_mode &= 1;
             }
+            h->v3_slots = wn_v3_slots_for(pl.n_streams, h->v3_mode, wn_v2_table()[vi3].fn_v3[2] != nullptr, wn_dev_env("WN_V3_SLOTS"), pl.NL);
             h->lds_bytes = wn_v2_table()[vi3].lds_floats_v3(pl.n_streams, h->v3_mode & 1) * 4;
             if (pl.n_streams <= 4 && !(h->v3_mode & 1)) h->lds_bytes = WN_LDS_MAX_BYTES;  // 1-4 streams (8: measured level, profiles/r03_few_stream_lds_queues.txt): the layers' dilation queues live in LDS where they fit (wn_v3_layer)
             pl.lds_floats = h->lds_bytes / 4;
@@ -833,12 +840,12 @@ static int wn_create_impl(const wn_config* cfg, wn_handle** out) {
     pl.g0 = pl.gi + pl.n_streams;
     pl.status = h->d_status;
     pl.xcc_tab = h->d_status + 8;
-    rc = rt_hip(hipFuncSetAttribute(h->variant == 4 ? wn_v4_table()[h->v2_index].fn : h->variant == 3 ? wn_v2_table()[h->v2_index].fn_v3[h->v3_mode & 1] : (const void*)wn_generate_kernel,
+    rc = rt_hip(hipFuncSetAttribute(h->variant == 4 ? wn_v4_table()[h->v2_index].fn : h->variant == 3 ? wn_v2_table()[h->v2_index].fn_v3[h->v3_slots ? 2 : (h->v3_mode & 1)] : (const void*)wn_generate_kernel,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes),
                 "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
     if (rc) { wn_destroy(h); return rc; }
     {   // residency is a requirement, not a hope: what the hardware can keep resident of THIS kernel with THIS much LDS, against what the plan needs per XCD
-        const void* fn = h->variant == 4 ? wn_v4_table()[h->v2_index].fn : h->variant == 3 ? wn_v2_table()[h->v2_index].fn_v3[h->v3_mode & 1] : (const void*)wn_generate_kernel;
+        const void* fn = h->variant == 4 ? wn_v4_table()[h->v2_index].fn : h->variant == 3 ? wn_v2_table()[h->v2_index].fn_v3[h->v3_slots ? 2 : (h->v3_mode & 1)] : (const void*)wn_generate_kernel;
         const int threads = h->variant == 4 ? WN_THREADS_V4 : h->variant == 3 ? WN_THREADS_V3 : WN_THREADS;
         int per_cu = 0;
         rc = rt_hip(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, threads, (size_t)h->lds_bytes), "hipOccupancyMaxActiveBlocksPerMultiprocessor");
@@ -1180,7 +1187,7 @@ extern "C" int wn_generate(wn_handle* h, const wn_generate_args* a) {
     if (h->variant == 4)
         wn_v4_table()[h->v2_index].launch(h->plan.n_blocks, (size_t)h->lds_bytes, (hipStream_t)a->hip_stream, h->plan, r);
     else if (h->variant == 3)
-        wn_v2_table()[h->v2_index].launch_v3(h->v3_mode & 1, h->plan.n_blocks, (size_t)h->lds_bytes, (hipStream_t)a->hip_stream, h->plan, r);
+        wn_v2_table()[h->v2_index].launch_v3(h->v3_slots ? 2 : (h->v3_mode & 1), h->plan.n_blocks, (size_t)h->lds_bytes, (hipStream_t)a->hip_stream, h->plan, r);
     else
         hipLaunchKernelGGL(wn_generate_kernel, dim3(h->plan.n_blocks), dim3(WN_THREADS), (size_t)h->lds_bytes,
                            (hipStream_t)a->hip_stream, h->plan, r);
@@ -1273,7 +1280,7 @@ extern "C" int wn_get_info(wn_handle* h, wn_info* out) {
     out->gate_shared = h->gate_shared; out->gate_waited_ms = h->gate_waited_ms;
     { int need = 0, cap = 0; wn_gate_numbers(h, &need, &cap); out->gate_need_per_xcd = need; }
     out->forward_native = (h->have_weights && h->fw_ok) ? 1 : 0;
-    out->workgroups_per_cu = h->wg_per_cu; out->resident_timeout_ms = h->resident_ms;
+    out->workgroups_per_cu = h->wg_per_cu; out->resident_timeout_ms = h->resident_ms; out->skip_lane_slots = h->variant == 3 ? h->v3_slots : 0;
     return WN_OK;
 }
 

@@ -52,7 +52,7 @@ class wn_info(ctypes.Structure):
                [(n, ctypes.c_int64) for n in ("weight_bytes", "queue_bytes", "handoff_bytes", "evals_done")] + \
                [(n, ctypes.c_int32) for n in ("kernel_variant", "n_chains", "streams_per_item", "head_replicas", "n_samplers", "dev_overrides",
                                                "layers_per_workgroup", "gate_shared", "gate_waited_ms", "gate_need_per_xcd",
-                                               "forward_native", "workgroups_per_cu", "resident_timeout_ms", "reserved_info")]
+                                               "forward_native", "workgroups_per_cu", "resident_timeout_ms", "skip_lane_slots")]
 
 
 class wn_adam_args(ctypes.Structure):

@@ -170,7 +170,7 @@ extern "C" int wn_get_info(wn_handle* h, wn_info* out) {
     out->n_chains = 1;
     out->streams_per_item = 1; out->head_replicas = 1; out->n_samplers = 0; out->dev_overrides = 0;
     out->layers_per_workgroup = 1; out->gate_shared = -1; out->gate_waited_ms = 0; out->gate_need_per_xcd = 0;
-    out->forward_native = 0; out->workgroups_per_cu = 0; out->resident_timeout_ms = 0;
+    out->forward_native = 0; out->workgroups_per_cu = 0; out->resident_timeout_ms = 0; out->skip_lane_slots = 0;
     return WN_OK;
 }
 

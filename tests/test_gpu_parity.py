@@ -786,6 +786,41 @@ def test_wave_specialised_kernel_throughput_forms(label, cfg, ns, N, n_given, mo
             assert row[-1] - row[-2] <= 10 * tol, (label, mode, s, t)
 
 
+SLOT_CASES = [("mini3_ns16", MINI3, 16, 120, 5), ("mini3_bias_ns30", dict(MINI3, bias=True), 30, 80, 40), ("cfg3_ns96", "cfg3", 96, 24, 3)]
+
+
+@pytest.mark.parametrize("slots", [0, 4])
+@pytest.mark.parametrize("label,cfg,ns,N,n_given", SLOT_CASES, ids=[c[0] for c in SLOT_CASES])
+def test_skip_lane_slot_form(label, cfg, ns, N, n_given, slots, monkeypatch):
+    """The slot re-use form of cfg3's two-streams-per-item kernel (wn_generate_kernel_v3m<..., 2, 4>: the skip lanes of a pipeline ITEM go into slot
+    item mod 4 instead of one slot per stream wherever producer and consumer share an XCD, with back-pressure through the reader's own lane --
+    the planner's choice from 2 n_layers - 4 streams up, wn_v3_slots_for) and the per-stream form pinned next to it (WN_V3_SLOTS): identical
+    sampled indices, logits within the bar, on streams of both parities and at both ends; priming (no skip work) in front of generation; the
+    full-depth chain at 96 streams."""
+    monkeypatch.setenv("WN_V3_SLOTS", str(slots))
+    cfg, W, first, uniforms = make_case(cfg, 88, ns, n_given, N)
+    eng = engine.Engine(cfg, W, n_streams=ns)
+    info = eng.info()
+    assert info["kernel_variant"] == 3 and info["streams_per_item"] == 2 and info["skip_lane_slots"] == slots, info
+    out, logits = eng.generate(N, first, temperature=0.9, regularize=0.002, uniforms=uniforms, want_logits=True, batched_prime=False, timeout_ms=8000)
+    again = eng.generate(N, first, temperature=0.9, regularize=0.002, uniforms=uniforms, batched_prime=False, timeout_ms=8000)   # (tags restart at 1 every job)
+    eng.close()
+    assert np.array_equal(out, again)
+    for s in sorted(set((0, 1, ns // 2, ns - 1))):
+        o_idx, o_log = c_oracle.generate(cfg, W, N, first[s], 0.9, 0.002, uniforms[s])
+        assert np.array_equal(out[s], o_idx), (label, slots, s, int(np.argmax(out[s] != o_idx)))
+        assert float(np.abs(logits[s] - o_log).max()) <= 1e-5 * max(1.0, float(np.abs(o_log).max())), (label, slots, s)
+
+
+def test_skip_lane_slot_form_is_the_planners_choice_where_it_pays():
+    """Without a pin: cfg3 takes the slot form from 96 streams (measured: +1 % at 96, +6 % at 128, -2 % at 80) and no other shape ever does."""
+    for cname, ns, want in (("cfg3", 64, 0), ("cfg3", 96, 4), ("cfg3", 128, 4), ("cfg2", 128, 0), ("chaconne", 64, 0)):
+        cfg = synth.CONFIGS[cname]
+        eng = engine.Engine(cfg, synth.init_weights(cfg, seed=1), n_streams=ns)
+        assert eng.info()["skip_lane_slots"] == want, (cname, ns, eng.info())
+        eng.close()
+
+
 @pytest.mark.parametrize("ns", [170, 256])
 def test_wave_specialised_kernel_rounds(ns):
     """More streams than one wave-specialised chain holds (its LDS parks one tap-0 sum per stream and lane: 151 streams at this

@@ -19,6 +19,10 @@ int main(int argc, char** argv) {
         printf("%d\n", wn_v3_mode_for(atoi(argv[2]), (argc > 3 && argv[3][0] != '-') ? argv[3] : nullptr, argc > 4 ? atoi(argv[4]) : 50));
         return 0;
     }
+    if (argc >= 2 && argv[1][0] == 's') {  // s <n_streams> <mode> <has_form> [pin] [n_layers]: skip-lane slots of the form that runs
+        printf("%d\n", wn_v3_slots_for(atoi(argv[2]), atoi(argv[3]), atoi(argv[4]) != 0, (argc > 5 && argv[5][0] != '-') ? argv[5] : nullptr, argc > 6 ? atoi(argv[6]) : 50));
+        return 0;
+    }
     if (argc >= 2 && argv[1][0] == 'r') {  // r <n_streams>: round sizes
         for (int n : wn_v3_round_sizes(atoi(argv[2]), WN_V3_ROUND_STREAMS)) printf("%d\n", n);
         return 0;
@@ -269,3 +273,15 @@ def test_stream_limit_of_the_stacked_kernel(harness):
     """wn_v4_stream_limit: up to how many streams variant 4's short pipeline beats variant 3's (measured on MI355X, profiles/r04_v4_vs_v3_streams.txt)."""
     lim = lambda n: int(subprocess.check_output([harness, "v", str(n)]).decode())
     assert lim(10) == 6 and lim(2) == 2 and lim(15) == 8 and lim(1) == 1 and lim(0) == 1
+
+
+def test_skip_lane_slot_form_by_stream_count(harness):
+    """wn_v3_slots_for: the slot re-use form of cfg3's two-streams-per-item kernel from 96 streams up (2 n_layers - 4: where the measured gain
+    starts), never without the two-streams form, never for shapes that have no such kernel, pinnable for tests."""
+    run = lambda *a: int(subprocess.check_output([harness, "s"] + [str(x) for x in a]).decode().split()[0])   # noqa: E731
+    assert [run(n, 3, 1) for n in (64, 80, 94, 96, 112, 128, 150)] == [0, 0, 0, 4, 4, 4, 4]
+    assert run(128, 0, 1) == 0 and run(128, 2, 1) == 0        # one stream per item: no such form
+    assert run(128, 3, 0) == 0                                 # a shape without the kernel (everything but cfg3's)
+    assert run(64, 3, 1, "4") == 4 and run(128, 3, 1, "0") == 0   # WN_V3_SLOTS pins (tests)
+    assert run(6, 3, 1, "4") == 0                              # fewer items than slots: off
+    assert run(20, 3, 1, "-", 12) == 4 and run(18, 3, 1, "-", 12) == 0   # the rule follows the depth
