@@ -16,6 +16,9 @@
 // Jobs that a HIP stream already serialises (same process, same stream: the rounds of a large job, back-to-back calls of one caller)
 // share ONE booking -- the launch stays asynchronous there.  The booking is released by a host function enqueued behind the kernel
 // (hipLaunchHostFunc), at the latest by wn_wait.
+// Locks: the registry mutex (threads of this process) is never held while the FILE lock is awaited; the file lock is only ever tried, with a
+// bound (a job's own timeout when it books, 2 s when it releases -- an erasure that gives up leaves an orphan this process sweeps on its next
+// visit to the table: an entry of a live process is never dropped by anybody else).
 //
 // Where the table lives (round 5, after the advisor's review of the round-4 file -- world-writable, created through O_CREAT in /dev/shm):
 //   default          /dev/shm/wn_mi355_gate_u<euid>_<busid>, mode 0600: the processes of ONE user coordinate.  Jobs of different users
@@ -47,6 +50,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <vector>
 
 #define WN_GATE_SLOTS 64
 // need: CUs per XCD; pid 0 = free; born: the owner's start time; seq: order of arrival; state: WN_GATE_RUNNING / WN_GATE_WAITING
@@ -95,6 +99,7 @@ struct WnGateRegistry {
     std::map<std::string, int> local_used;                              // device -> CUs per XCD booked by this process (no shared file)
     std::map<std::string, int> mode;                                    // device -> 1 shared table, 0 process-local: decided ONCE per device
     std::map<std::string, int64_t> local_next, local_serving;           // process-local first come first served
+    std::multimap<std::string, int64_t> orphans;                        // table path -> tokens of OUR entries whose erasure did not get the file lock in time
     int64_t next_token = 1;
 };
 // heap-allocated and never destroyed: the runtime's callback thread (hipLaunchHostFunc -> wn_gate_release) may still run while the
@@ -214,16 +219,27 @@ static inline int wn_gate_try_table(WnGateFile* tab, int cap, int need, int64_t 
     }
     return 0;
 }
-static inline void wn_gate_erase_entry(const std::string& path, int64_t token) {
+// Erases this process's entry `token` (and the entries in `also`: earlier erasures that did not get the lock) from the table.  false: the lock
+// stayed taken for 2 s or the table could not be opened -- the caller keeps the token as an orphan and the next visit to the table retries
+// (an entry of a LIVE process is never dropped by anybody else: left behind, it would book CUs for the life of this process).
+static inline bool wn_gate_erase_entry(const std::string& path, int64_t token, const int64_t* also = nullptr, int n_also = 0) {
     WnGateFile tab;
     const int fd = wn_gate_open_locked(path, &tab, wn_gate_now_ms() + 2000);
-    if (fd < 0) return;   // (a dead owner's entry is dropped by the next job that does not fit)
+    if (fd < 0) return false;
     const int32_t me = (int32_t)getpid();
     bool dirty = false;
-    for (int i = 0; i < WN_GATE_SLOTS; ++i)
-        if (tab.slot[i].pid == me && tab.slot[i].token == token) { memset(&tab.slot[i], 0, sizeof(tab.slot[i])); dirty = true; }
+    for (int i = 0; i < WN_GATE_SLOTS; ++i) {
+        WnGateSlot& sl = tab.slot[i];
+        if (sl.pid != me) continue;
+        bool hit = sl.token == token;
+        for (int k = 0; k < n_also && !hit; ++k) hit = sl.token == also[k];
+        if (hit) { memset(&sl, 0, sizeof(sl)); dirty = true; }
+    }
     wn_gate_close(fd, &tab, dirty);
+    return true;
 }
+// (both below: under no lock of ours while the FILE lock is awaited -- see wn_gate_acquire)
+static inline void wn_gate_erase_or_remember(const std::string& path, int64_t token);
 
 // Books `need` CUs per XCD (of `cap`) on the device `busid` for a job on `stream`.  Returns 0 and a ticket; 1 when the wait ran
 // into timeout_ms (nothing booked).  *waited_ms: how long the job was held back; *shared: 1 = inter-process table, 0 = this process only.
@@ -243,8 +259,8 @@ static inline int wn_gate_acquire(const char* busid, int cap, int need, const vo
     auto give_up = [&]() {
         if (token) {
             bool in_table;
-            { std::lock_guard<std::mutex> g(reg.mu); in_table = reg.mode[dev] == 1; }
-            if (in_table) wn_gate_erase_entry(path, token);
+            { std::lock_guard<std::mutex> g(reg.mu); auto m = reg.mode.find(dev); in_table = m == reg.mode.end() || m->second == 1; }   // (undecided: a WAITING entry may exist)
+            if (in_table) wn_gate_erase_or_remember(path, token);
         }
         if (local_ticket) {   // leave the process-local queue: whoever is behind us must not wait for a job that will never run
             std::lock_guard<std::mutex> g(reg.mu);
@@ -254,7 +270,11 @@ static inline int wn_gate_acquire(const char* busid, int cap, int need, const vo
         *waited_ms = wn_gate_now_ms() - t0;
         return 1;
     };
+    // The registry mutex is never held while the FILE lock is awaited (a stopped process that holds the file lock would otherwise stall every
+    // thread of this process that books or releases -- the HIP runtime's callback thread among them -- for this job's whole timeout).
     for (;;) {
+        int mode;
+        std::vector<int64_t> sweep;   // our orphaned entries in this table: erased on this visit
         {
             std::lock_guard<std::mutex> g(reg.mu);
             auto it = reg.by_stream.find(key);
@@ -269,25 +289,48 @@ static inline int wn_gate_acquire(const char* busid, int cap, int need, const vo
             // (a larger job behind a smaller one on the same stream books on its own: conservative, never wrong)
             if (!token) token = reg.next_token++;
             auto mode_it = reg.mode.find(dev);
-            int mode = mode_it == reg.mode.end() ? -1 : mode_it->second;
-            bool ok = false;
+            mode = mode_it == reg.mode.end() ? -1 : mode_it->second;
             if (mode != 0) {
-                WnGateFile tab;
-                const char* why = "";
-                const int fd = wn_gate_open_locked(path, &tab, deadline, &why);
-                if (fd >= 0) {
-                    if (mode < 0) reg.mode[dev] = mode = 1;
-                    bool dirty = false;
-                    const int r = wn_gate_try_table(&tab, cap, need, token, born, &dirty);
-                    wn_gate_close(fd, &tab, dirty);
-                    ok = r == 1;
-                } else if (mode < 0 && fd == -1) {
-                    // the FIRST booking on this device decides its mode for the life of the process -- and says why out loud
+                auto range = reg.orphans.equal_range(path);
+                for (auto o = range.first; o != range.second; ++o) sweep.push_back(o->second);
+            }
+        }
+        bool ok = false;
+        if (mode != 0) {
+            WnGateFile tab;
+            const char* why = "";
+            const int fd = wn_gate_open_locked(path, &tab, deadline, &why);
+            if (fd >= 0) {
+                bool dirty = false;
+                const int32_t me = (int32_t)getpid();
+                for (int i = 0; i < WN_GATE_SLOTS && !sweep.empty(); ++i)
+                    for (int64_t tk : sweep)
+                        if (tab.slot[i].pid == me && tab.slot[i].token == tk) { memset(&tab.slot[i], 0, sizeof(tab.slot[i])); dirty = true; }
+                const int r = wn_gate_try_table(&tab, cap, need, token, born, &dirty);
+                wn_gate_close(fd, &tab, dirty);
+                ok = r == 1;
+                std::lock_guard<std::mutex> g(reg.mu);
+                if (mode < 0) { auto ins = reg.mode.emplace(dev, 1); mode = ins.first->second; }   // (another thread may have decided meanwhile: its word stands)
+                for (int64_t tk : sweep) {
+                    auto range = reg.orphans.equal_range(path);
+                    for (auto o = range.first; o != range.second; ++o) if (o->second == tk) { reg.orphans.erase(o); break; }
+                }
+                if (mode == 0 && ok) {   // (lost the race against a thread that found the table unusable: hand the entry back, queue locally)
+                    ok = false;
+                }
+            } else if (mode < 0 && fd == -1) {
+                // the FIRST booking on this device decides its mode for the life of the process -- and says why out loud
+                std::lock_guard<std::mutex> g(reg.mu);
+                auto ins = reg.mode.emplace(dev, 0);
+                mode = ins.first->second;
+                if (ins.second)
                     fprintf(stderr, "wn_mi355: admission table %s unusable (%s): the jobs of THIS process are serialised on device %s, other "
                             "processes are not (set WN_GATE_DIR to a directory the device's users share)\n", path.c_str(), why, busid);
-                    reg.mode[dev] = mode = 0;
-                }   // (mode == 1 and the table cannot be opened right now, or the lock is held: not admitted yet -- retry below)
-            }
+            }   // (mode == 1 and the table cannot be opened right now, or the lock is held: not admitted yet -- retry below)
+            if (mode == 0 && fd >= 0) wn_gate_erase_or_remember(path, token);
+        }
+        {
+            std::lock_guard<std::mutex> g(reg.mu);
             if (mode == 0) {   // process-local, first come first served
                 if (!local_ticket) { int64_t& n = reg.local_next[dev]; if (n == 0) { n = 1; reg.local_serving[dev] = 1; } local_ticket = n++; }
                 int64_t& serving = reg.local_serving[dev];
@@ -300,6 +343,7 @@ static inline int wn_gate_acquire(const char* busid, int cap, int need, const vo
                 b->key = key; b->need = need; b->jobs = 1; b->token = token;
                 if (mode == 1) b->path = path;
                 *shared = mode;
+                auto it = reg.by_stream.find(key);
                 if (it == reg.by_stream.end() || it->second->jobs == 0) reg.by_stream[key] = b;  // (joinable by later jobs of this stream)
                 auto t = std::make_shared<WnGateTicket>();
                 t->booking = b;
@@ -307,11 +351,31 @@ static inline int wn_gate_acquire(const char* busid, int cap, int need, const vo
                 *waited_ms = wn_gate_now_ms() - t0;
                 return 0;
             }
-            *shared = mode;
+            *shared = mode < 0 ? 0 : mode;
         }
         if (wn_gate_now_ms() > deadline) return give_up();
         usleep((useconds_t)nap_us);
         if (nap_us < 2000) nap_us *= 2;   // 0.2 ms ... 2 ms between looks: a cfg3 job is tens of milliseconds at the least
+    }
+}
+
+static inline void wn_gate_erase_or_remember(const std::string& path, int64_t token) {
+    WnGateRegistry& reg = wn_gate_registry();
+    std::vector<int64_t> also;
+    {
+        std::lock_guard<std::mutex> g(reg.mu);
+        auto range = reg.orphans.equal_range(path);
+        for (auto o = range.first; o != range.second; ++o) also.push_back(o->second);
+    }
+    const bool done = wn_gate_erase_entry(path, token, also.data(), (int)also.size());
+    std::lock_guard<std::mutex> g(reg.mu);
+    if (done) {
+        for (int64_t tk : also) {
+            auto range = reg.orphans.equal_range(path);
+            for (auto o = range.first; o != range.second; ++o) if (o->second == tk) { reg.orphans.erase(o); break; }
+        }
+    } else {
+        reg.orphans.emplace(path, token);
     }
 }
 
@@ -335,7 +399,7 @@ static inline void wn_gate_release(const std::shared_ptr<WnGateTicket>& t) {
         }
     }
     // (outside the registry mutex: this may run on the HIP runtime's callback thread, and the file lock is only ever tried, with a bound)
-    if (!path.empty()) wn_gate_erase_entry(path, token);
+    if (!path.empty()) wn_gate_erase_or_remember(path, token);
 }
 
 #endif  // WN_GATE_H

@@ -36,6 +36,21 @@ int main(int argc, char** argv) {
         printf("0 0 1\n");
         return 0;
     }
+    if (hold == -3) {  // book, release while somebody else holds the FILE lock (the erasure gives up after 2 s), then book the whole device
+        std::shared_ptr<WnGateTicket> t; long long w; int sh;
+        const int rc1 = wn_gate_acquire(bus, cap, need, nullptr, tmo, &t, &w, &sh);
+        printf("booked\n"); fflush(stdout);
+        usleep(400 * 1000);
+        const long long r0 = wn_gate_now_ms();
+        wn_gate_release(t);
+        const long long release_ms = wn_gate_now_ms() - r0;
+        usleep(1500 * 1000);
+        std::shared_ptr<WnGateTicket> t2;
+        const int rc2 = wn_gate_acquire(bus, cap, cap, nullptr, tmo, &t2, &w, &sh);
+        printf("%d %d %lld %lld\n", rc1, rc2, release_ms, w);
+        if (rc2 == 0) wn_gate_release(t2);
+        return 0;
+    }
     if (hold < 0) {  // "crash": book and exit without releasing
         std::shared_ptr<WnGateTicket> t; long long w; int sh;
         const int rc = wn_gate_acquire(bus, cap, need, nullptr, tmo, &t, &w, &sh);
@@ -187,3 +202,21 @@ def test_the_table_is_private_to_the_user_and_never_opened_through_a_link(gate, 
     rows = gate("0000:fc:00.0", 32, 3, 10, 1000, env_extra={"WN_GATE_DIR": str(d2)})
     assert rows[0][0] == 0 and rows[0][2] == 0
     assert f.read_bytes() == b""
+
+
+def test_a_release_that_cannot_get_the_file_lock_is_retried_by_the_next_booking(gate, tmp_path):
+    # Somebody holds the table's lock (a stopped process, say) while a job's booking is released: the erasure gives up after 2 s instead of hanging
+    # the HIP callback thread -- and the entry of this LIVE process (which nobody else may drop) is swept by the process's next visit to the table.
+    import fcntl
+    d = tmp_path / "orphans"
+    d.mkdir()
+    env = {"WN_GATE_DIR": str(d)}
+    p = gate("0000:fb:00.0", 32, 20, -3, 6000, wait=False, env_extra=env)
+    assert p.stdout.readline().strip() == "booked"
+    with open(d / "wn_mi355_gate_0000_fb_00_0", "r+b") as f:
+        fcntl.flock(f, fcntl.LOCK_EX)
+        time.sleep(2.8)                                        # the release (0.4 s after the booking) tries for 2 s and gives up
+        fcntl.flock(f, fcntl.LOCK_UN)
+    rc1, rc2, release_ms, waited = [int(v) for v in p.communicate(timeout=30)[0].split()]
+    assert rc1 == 0 and 1900 <= release_ms <= 2600
+    assert rc2 == 0 and waited < 1000                          # the whole device could be booked: the orphaned 20 were swept first
