@@ -274,18 +274,34 @@ static inline int wn_gate_acquire(const char* busid, int cap, int need, const vo
     // thread of this process that books or releases -- the HIP runtime's callback thread among them -- for this job's whole timeout).
     for (;;) {
         int mode;
+        bool joined = false, maybe_in_table = false;
         std::vector<int64_t> sweep;   // our orphaned entries in this table: erased on this visit
         {
             std::lock_guard<std::mutex> g(reg.mu);
             auto it = reg.by_stream.find(key);
-            if (!token && !local_ticket && it != reg.by_stream.end() && it->second->jobs > 0 && it->second->need >= need) {
+            if (it != reg.by_stream.end() && it->second->jobs > 0 && it->second->need >= need) {
                 // a job of this process on this very stream is in flight: the stream serialises us behind it, one booking covers both
+                // (also when we already queued -- a sibling that started booking at the same moment got there first: leave the queue)
                 it->second->jobs++;
                 auto t = std::make_shared<WnGateTicket>();
                 t->booking = it->second;
                 *out = t; *shared = it->second->path.empty() ? 0 : 1;
-                return 0;
+                if (local_ticket) {
+                    if (reg.local_serving[dev] == local_ticket) reg.local_serving[dev]++;
+                    else reg.local_used[dev + "|left|" + std::to_string(local_ticket)] = 1;
+                }
+                auto m = reg.mode.find(dev);
+                maybe_in_table = token != 0 && (m == reg.mode.end() || m->second == 1);
+                joined = true;
             }
+        }
+        if (joined) {
+            if (maybe_in_table) wn_gate_erase_or_remember(path, token);   // (a WAITING entry we may have left in the table; no entry: a no-op visit)
+            *waited_ms = wn_gate_now_ms() - t0;
+            return 0;
+        }
+        {
+            std::lock_guard<std::mutex> g(reg.mu);
             // (a larger job behind a smaller one on the same stream books on its own: conservative, never wrong)
             if (!token) token = reg.next_token++;
             auto mode_it = reg.mode.find(dev);
