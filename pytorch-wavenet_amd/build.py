@@ -61,7 +61,7 @@ def check_hand_scheduled_registers(so, objdump=None):
     DISASSEMBLES the built library and raises unless (1) every instruction of those kernels that names a reserved register is one
     the blocks emit, in the operand position they emit it -- a tap-FIFO take directly behind one of the FIFO's hand-counted
     `s_waitcnt vmcnt(n)` --, (2) nothing touches a register above v167, (3) the kernels use no scratch -- and, round 5, no OTHER kernel of the library does either beyond the
-    recorded matrix-core instantiations (KNOWN_SPILLS) --, (4) no hand-scheduled load reads an SGPR base a VALU instruction wrote less than five wait states earlier (a spill in a persistent hot loop is a performance bug, and spill code is where an allocator would reach for "free"
+    recorded matrix-core instantiations (KNOWN_SPILLS) --, (4) no memory instruction of ANY kernel reads an SGPR a VALU instruction wrote less than five wait states earlier (a spill in a persistent hot loop is a performance bug, and spill code is where an allocator would reach for "free"
     registers).  Called by build_hip(): a library that breaks the invariant is never left in place."""
     import re
     import tempfile
@@ -85,21 +85,23 @@ def check_hand_scheduled_registers(so, objdump=None):
         m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
         if m:
             if re.fullmatch(r"L\d+", m.group(1)):   # a branch target inside the current kernel (--symbolize-operands)
-                if current and "wn_generate_kernel_v3m" in current:
+                if current:
                     items[current].append(("label", m.group(1)))
                 continue
             current = m.group(1)
+            items[current] = []
             if "wn_generate_kernel_v3m" in current:
                 seen += 1
-                items[current] = []
             continue
-        if not current or "wn_generate_kernel_v3m" not in current:
+        if not current:
             continue
         text = line.split("//")[0].strip()
         if not text:
             continue
+        items[current].append(("ins", text))   # (every kernel of the library: rule 4)
+        if "wn_generate_kernel_v3m" not in current:
+            continue
         before, prev = prev, text
-        items[current].append(("ins", text))
         op, _, rest = text.partition(" ")
         ops = [o.strip() for o in rest.split(",")]
         regs = _regs(text)
@@ -163,12 +165,15 @@ def _check_scratch_everywhere(dis):
 
 
 def _check_sgpr_base_hazard(kernel, seq, reserved):
-    """Rule 4: the SGPR pair a hand-scheduled load (destination in the reserved range) takes its base address from must not have been
-    written by a VALU instruction (v_readlane_b32 of a spilled pointer, a compare, ...) within the last FIVE wait states on ANY path
-    that leads to the load -- a gfx9 hazard the backend resolves for its own instructions but not in front of inline assembly (see
-    WN_AP_SGPR_HAZARD in wn_kernel_v3.h).  `seq` is the kernel in address order, instructions and branch-target labels; the walk goes
-    backwards through fall-throughs and through every branch that targets a label it meets (each instruction one wait state, s_nop n
-    counts n + 1), until five wait states have passed or the scalar unit is found to have written the registers last."""
+    """Rule 4: an SGPR that a vector MEMORY instruction reads (the base pair of a global_* access, the descriptor / offset of a buffer_* one)
+    must not have been written by a VALU instruction (v_readlane_b32 of a spilled pointer, v_readfirstlane_b32, a compare, ...) within the
+    last FIVE wait states on ANY path that leads to it -- a gfx9 hazard the backend resolves for its own instructions but not in front of
+    inline assembly (see WN_AP_SGPR_HAZARD in wn_kernel_v3.h).  Round 4 found it on the hand-scheduled input polls of one kernel form; since
+    round 5 the rule is generic: EVERY memory instruction of EVERY kernel in the library is checked (the compiler's own pass it by
+    construction; whatever an inline-assembly block emits is held to the same standard without the rule having to know the block).  `seq` is
+    the kernel in address order, instructions and branch-target labels; the walk goes backwards through fall-throughs and through every
+    branch that targets a label it meets (each instruction one wait state, s_nop n counts n + 1), until five wait states have passed or the
+    scalar unit is found to have written the registers last."""
     import re
     targets = {}   # label -> indices of the branches that jump to it
     for i, (kind, text) in enumerate(seq):
@@ -201,21 +206,21 @@ def _check_sgpr_base_hazard(kernel, seq, reserved):
                 d = [int(x) for x in re.findall(r"\d+", dst)]
                 d = set(range(d[0], d[-1] + 1))
                 if op.startswith("v_") and d & pending:
-                    raise RuntimeError("%s: %s: the SGPR base of a hand-scheduled load is written by `%s` %d wait state(s) before it (5 needed)" % (kernel, load, text, waited))
+                    raise RuntimeError("%s: %s: an SGPR operand of this memory instruction is written by `%s` %d wait state(s) before it (5 needed)" % (kernel, load, text, waited))
                 if op.startswith("s_"):
                     pending = pending - d   # (written by the scalar unit: no hazard, and whatever wrote it before does not matter)
             waited += int(rest) + 1 if op == "s_nop" and rest.strip().isdigit() else 1
             i -= 1
 
     for i, (kind, text) in enumerate(seq):
-        if kind != "ins" or not text.startswith("global_load_dwordx2 "):
+        if kind != "ins" or not text.startswith(("global_", "buffer_", "flat_", "scratch_")):
             continue
-        ops = [o.strip() for o in text.partition(" ")[2].split(",")]
-        if not (_regs(ops[0]) and _regs(ops[0]) <= reserved) or len(ops) < 3:
-            continue
-        m = re.search(r"\bs\[(\d+):(\d+)\]", ops[2])
-        if m:
-            walk(i - 1, 0, set(range(int(m.group(1)), int(m.group(2)) + 1)), text, set())
+        rest = text.partition(" ")[2]
+        sregs = set(int(x) for x in re.findall(r"\bs(\d+)\b", rest))
+        for a, b in re.findall(r"\bs\[(\d+):(\d+)\]", rest):
+            sregs.update(range(int(a), int(b) + 1))
+        if sregs:
+            walk(i - 1, 0, sregs, text, set())
 
 
 def _regs(text):

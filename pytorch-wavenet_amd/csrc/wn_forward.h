@@ -1180,33 +1180,41 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? WN_TN_BF16_MINB : 4) void 
 // dzg != NULL: the skip path's share of dz -- column block of the per-block product dskip . Wskip^T, [N*out_len][ldg] -- is
 // added on the last out_len rows of every batch entry (the rows the skip conv saw).
 // PACKED: th holds one dword per element, {bf16 tanh (low half), bf16 sigmoid (high half)} (the bf16 step's saved gates); sg unused.
+// Four consecutive channels per thread (D is a multiple of 32: a group of four never straddles the [F(32) | G(32)] packing): 16-byte loads, 8- / 16-byte
+// stores.  dz == NULL: no residual share (the LAST layer: its dz is the skip path's alone -- no zero-filled buffer is written and read back for it).
 template <bool PACKED>
-__global__ void wn_bwd_gate(const float* dz, const float* th, const float* sg, float* dfg, long long M, int D,
-                            const float* dzg, int ldg, int rows, int out_len) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void wn_bwd_gate(const float* dz, const float* th, const float* sg, float* dfg, long long M, int D,
+                                                   const float* dzg, int ldg, int rows, int out_len) {
+    const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (i >= M * D) return;
     const long long m = i / D;
-    const int ch = (int)(i % D);
-    float d = dz[i];
+    const int ch = (int)(i - m * D);
+    float4 d = dz ? *reinterpret_cast<const float4*>(dz + i) : make_float4(0.f, 0.f, 0.f, 0.f);
     if (dzg) {
         const unsigned n = (unsigned)m / (unsigned)rows, tt = (unsigned)m - n * (unsigned)rows;
-        if ((int)tt >= rows - out_len) d += dzg[((long long)n * out_len + ((int)tt - (rows - out_len))) * ldg + ch];
+        if ((int)tt >= rows - out_len) {
+            const float4 e = *reinterpret_cast<const float4*>(dzg + ((long long)n * out_len + ((int)tt - (rows - out_len))) * ldg + ch);
+            d.x += e.x; d.y += e.y; d.z += e.z; d.w += e.w;
+        }
     }
-    float t, s;
+    float4 t, s;
     if (PACKED) {
-        const unsigned ts = reinterpret_cast<const unsigned*>(th)[i];
-        t = __uint_as_float(ts << 16); s = __uint_as_float(ts & 0xffff0000u);
+        const uint4 ts = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned*>(th) + i);
+        t = make_float4(__uint_as_float(ts.x << 16), __uint_as_float(ts.y << 16), __uint_as_float(ts.z << 16), __uint_as_float(ts.w << 16));
+        s = make_float4(__uint_as_float(ts.x & 0xffff0000u), __uint_as_float(ts.y & 0xffff0000u), __uint_as_float(ts.z & 0xffff0000u), __uint_as_float(ts.w & 0xffff0000u));
     } else {
-        t = th[i]; s = sg[i];
+        t = *reinterpret_cast<const float4*>(th + i); s = *reinterpret_cast<const float4*>(sg + i);
     }
+    const float4 df = make_float4(d.x * s.x * (1.f - t.x * t.x), d.y * s.y * (1.f - t.y * t.y), d.z * s.z * (1.f - t.z * t.z), d.w * s.w * (1.f - t.w * t.w));
+    const float4 dg = make_float4(d.x * t.x * s.x * (1.f - s.x), d.y * t.y * s.y * (1.f - s.y), d.z * t.z * s.z * (1.f - s.z), d.w * t.w * s.w * (1.f - s.w));
     const int nf = 64 * (ch >> 5) + (ch & 31);
     if (PACKED) {   // the bf16 step stores [dF|dG] as bf16
         unsigned short* o = reinterpret_cast<unsigned short*>(dfg) + m * 2 * D + nf;
-        o[0] = (unsigned short)wn_pack_bf16(d * s * (1.f - t * t), 0.f);
-        o[32] = (unsigned short)wn_pack_bf16(d * t * s * (1.f - s), 0.f);
+        *reinterpret_cast<uint2*>(o) = wn_pack_bf16x4(df);
+        *reinterpret_cast<uint2*>(o + 32) = wn_pack_bf16x4(dg);
     } else {
-        dfg[m * 2 * D + nf] = d * s * (1.f - t * t);
-        dfg[m * 2 * D + nf + 32] = d * t * s * (1.f - s);
+        *reinterpret_cast<float4*>(dfg + m * 2 * D + nf) = df;
+        *reinterpret_cast<float4*>(dfg + m * 2 * D + nf + 32) = dg;
     }
 }
 

@@ -454,14 +454,13 @@ extern "C" int wn_train_backward(wn_handle* h, const float* params, const float*
             if (pl.has_bias) wn_launch_colsum(sd, WnRowMap{dxn, L * (long long)R, R, t0}, M, (int)rows, R, grads + h->fw_off_bres + (size_t)l * R);
             if (two) res_read[l] = signal(sd);
         } else {   // the last layer has no residual output: dz is its share of dzg alone
-            rc = rt_hip(hipMemsetAsync(dz, 0, (size_t)M * D * 4, st), "hipMemsetAsync(dz)");
-            if (rc) return rc;
-            const long long work = M * D;
+            const long long work = M * D / 4;   // (four channels per thread; no residual share: dz = NULL, nothing zero-filled)
+            const float* no_dz = nullptr;
             if (t.bf16)
-                hipLaunchKernelGGL(wn_bwd_gate<true>, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, dz, ws + t.th[l], ws + t.sg[l], dfg, M, D,
+                hipLaunchKernelGGL(wn_bwd_gate<true>, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, no_dz, ws + t.th[l], ws + t.sg[l], dfg, M, D,
                                    dzg + (size_t)gi * D, cnt * D, (int)rows, (int)out_len);
             else
-                hipLaunchKernelGGL(wn_bwd_gate<false>, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, dz, ws + t.th[l], ws + t.sg[l], dfg, M, D,
+                hipLaunchKernelGGL(wn_bwd_gate<false>, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, no_dz, ws + t.th[l], ws + t.sg[l], dfg, M, D,
                                    dzg + (size_t)gi * D, cnt * D, (int)rows, (int)out_len);
         }
         wait_for(sd, signal(st));   // [dF|dG] of this layer is complete

@@ -190,7 +190,7 @@ def test_reserved_poll_registers_belong_to_the_hand_scheduled_blocks_only(tmp_pa
                 ["v_readlane_b32 s13, v128, 21", "s_add_u32 s12, s12, s5", "s_addc_u32 s6, s6, 0"],     # 2 (only s12 re-written by the SALU)
                 ["v_readlane_b32 s12, v128, 20", "s_nop 2"],                                         # 3
                 ["v_cmp_eq_u32_e64 s[12:13], s5, v3", "s_nop 3"]):                                    # 4, any VALU write of the pair
-        with pytest.raises(RuntimeError, match="SGPR base of a hand-scheduled load"):
+        with pytest.raises(RuntimeError, match="SGPR operand of this memory instruction"):
             run(good + pre + [load])
     for pre in (["v_readlane_b32 s12, v128, 20", "v_readlane_b32 s13, v128, 21", "s_nop 4"],         # five wait states
                 ["v_readlane_b32 s13, v128, 21", "s_nop 1", "s_mov_b32 s4, 1", "v_mov_b32_e32 v3, 0", "s_nop 0"],
@@ -199,14 +199,26 @@ def test_reserved_poll_registers_belong_to_the_hand_scheduled_blocks_only(tmp_pa
         assert run(good + pre + [load]) == 1
     # ... on EVERY path to the load: the walk follows the branches that target a label in front of it
     rl = ["v_readlane_b32 s12, v128, 20", "v_readlane_b32 s13, v128, 21"]
-    with pytest.raises(RuntimeError, match="SGPR base of a hand-scheduled load"):   # the fall-through is long enough, the taken branch is not
+    with pytest.raises(RuntimeError, match="SGPR operand of this memory instruction"):   # the fall-through is long enough, the taken branch is not
         run(good + rl + ["s_cbranch_vccnz L7", "s_nop 4", "v_mov_b32_e32 v3, 0", "<L7>", load])
-    with pytest.raises(RuntimeError, match="SGPR base of a hand-scheduled load"):   # two hops
+    with pytest.raises(RuntimeError, match="SGPR operand of this memory instruction"):   # two hops
         run(good + rl + ["s_cbranch_scc1 L5", "s_nop 4", "<L5>", "s_cbranch_vccz L6", "s_nop 4", "<L6>", load])
     assert run(good + rl + ["s_nop 4", "s_cbranch_vccnz L7", "v_mov_b32_e32 v3, 0", "<L7>", load]) == 1          # five wait states in front of the branch
     assert run(good + rl + ["s_branch L9", "<L8>", load, "<L9>", "s_nop 0"]) == 1                                 # no fall-through behind s_branch, nobody jumps to L8
-    with pytest.raises(RuntimeError, match="SGPR base of a hand-scheduled load"):   # a loop's back edge
+    with pytest.raises(RuntimeError, match="SGPR operand of this memory instruction"):   # a loop's back edge
         run(good + ["s_nop 4", "<L2>", load] + rl + ["s_cbranch_scc1 L2"])
+    # ... and, round 5, for EVERY memory instruction of EVERY kernel (not only the poll sets of the wave-specialised ones): whatever an inline-assembly
+    # block emits anywhere in the library is held to the rule, the compiler's own instructions pass it by construction
+    other = "<_Z21wn_generate_kernel_v4ILi64EEv6WnPlan5WnRun>"
+    with pytest.raises(RuntimeError, match="wn_generate_kernel_v4.*SGPR operand of this memory instruction"):
+        run(good + [other, "v_readfirstlane_b32 s8, v1", "s_nop 1", "buffer_load_dwordx4 v[0:3], v4, s[8:11], 0 offen sc1"])
+    with pytest.raises(RuntimeError, match="SGPR operand of this memory instruction"):          # the offset register of a buffer store
+        run(good + [other, "v_readfirstlane_b32 s20, v1", "buffer_store_dwordx2 v[0:1], v4, s[8:11], s20 offen"])
+    with pytest.raises(RuntimeError, match="SGPR operand of this memory instruction"):          # a plain store's base pair
+        run(good + [other, "v_readlane_b32 s3, v9, 1", "s_nop 3", "global_store_dword v1, v2, s[2:3]"])
+    assert run(good + [other, "v_readfirstlane_b32 s8, v1", "s_nop 4", "buffer_load_dwordx4 v[0:3], v4, s[8:11], 0 offen sc1",
+                       "v_readlane_b32 s3, v9, 1", "v_mov_b32_e32 v1, 0", "v_mov_b32_e32 v2, 0", "s_nop 2", "global_store_dword v1, v2, s[2:3]",
+                       "v_cmp_eq_u32_e64 s[30:31], s5, v3", "global_load_dword v5, v[6:7], off"]) == 1   # (no SGPR operand: nothing to wait for)
 
 
 def test_build_is_one_compile_in_the_safe_form_and_installs_nothing_the_check_refuses(monkeypatch, tmp_path):

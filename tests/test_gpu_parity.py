@@ -725,17 +725,23 @@ def test_wave_specialised_kernel_two_way_split(ns, mode, monkeypatch):
     eng.close()
 
 
-def test_two_slice_form_under_address_space_churn(monkeypatch):
+CHURN_SHAPES = [("cfg2_two_slices", "cfg2", 2, 600), ("cfg3", "cfg3", 0, 700), ("cfg1", "cfg1", 0, 40), ("mini3", MINI3, 0, 9)]
+
+
+@pytest.mark.parametrize("label,cfg,split,n_given", CHURN_SHAPES, ids=[c[0] for c in CHURN_SHAPES])
+def test_wave_specialised_forms_under_address_space_churn(label, cfg, split, n_given, monkeypatch):
     """The scenario in which round 4's SGPR hazard showed (a stale base pointer in the hand-scheduled input poll: a memory access fault
-    only where nothing happened to be mapped at the stale address): the two-slice form again and again while tensors of odd sizes come
-    and go and the caching allocator hands its blocks back -- tools/stress_split.py in small; build.py's disassembly rule is the real
-    guard, this is the canary.  Outputs are checked for sanity only (the forms' parity is the test above)."""
+    only where nothing happened to be mapped at the stale address): every instantiated shape of the wave-specialised kernel, one and two
+    streams per item, again and again while tensors of odd sizes come and go and the caching allocator hands its blocks back --
+    tools/stress_split.py in small; build.py's disassembly rule (every memory instruction of every kernel) is the real guard, this is the
+    canary.  Outputs are checked for sanity only (the forms' parity is the tests around this one)."""
     import torch
     rs = np.random.RandomState(0)
-    cfg = synth.CONFIGS["cfg2"]
+    cfg = synth.CONFIGS[cfg] if isinstance(cfg, str) else cfg
     W = synth.init_weights(cfg, seed=83)
+    monkeypatch.setenv("WN_KERNEL", "v3")
     junk = []
-    for it in range(3):
+    for it in range(2):
         for ns, mode in ((1, 0), (6, 3)):
             monkeypatch.setenv("WN_V3_MODE", str(mode))
             for _ in range(4):
@@ -744,8 +750,10 @@ def test_two_slice_form_under_address_space_churn(monkeypatch):
                 for _ in range(5):
                     junk.pop(int(rs.randint(0, len(junk))))
                 torch.cuda.empty_cache()
-            first = rs.randint(0, 256, (ns, 600)).astype(np.int32)
-            eng = engine.Engine(cfg, W, n_streams=ns, layer_split=2)
+            first = rs.randint(0, 256, (ns, n_given)).astype(np.int32)
+            eng = engine.Engine(cfg, W, n_streams=ns, **({"layer_split": split} if split else {}))
+            info = eng.info()
+            assert info["kernel_variant"] == 3 and info["streams_per_item"] == (2 if mode & 1 else 1), (label, info)
             a = eng.generate(40, first, temperature=0.0, batched_prime=False, timeout_ms=8000)
             b = eng.generate(40, first, temperature=0.9, regularize=0.002, uniforms=rs.random_sample((ns, 40)), batched_prime=False, timeout_ms=8000)
             eng.close()

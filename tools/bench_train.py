@@ -32,7 +32,8 @@ def main():
     idx = torch.randint(0, 256, (N, L), generator=g).cuda()
     x = torch.zeros(N, 256, L, device="cuda").scatter_(1, idx.unsqueeze(1), 1.0)
     target = torch.randint(0, 256, (N * out_len,), generator=g).cuda()
-    opt = torch.optim.Adam(m.parameters(), lr=1e-4)
+    from mi355_wavenet.optim import FusedAdam   # (what WavenetTrainer uses on the GPU and bench.py's training legs time; --torch-adam: torch's foreach kernels)
+    opt = torch.optim.Adam(m.parameters(), lr=1e-4) if "--torch-adam" in sys.argv else FusedAdam(m.parameters(), lr=1e-4)
     R = D = 128; S = 512; E = 256; C = 256
     need, fwd = out_len, 0
     for d in reversed([2 ** (i % 10) for i in range(50)]):
@@ -42,7 +43,12 @@ def main():
 
     def step():
         opt.zero_grad(set_to_none=True)
-        loss = torch.nn.functional.cross_entropy(m(x), target)
+        if "--facade-loss" in sys.argv:   # model(x) on a one-hot input and torch's cross_entropy (the reference's own lines; the one-hot scatter and torch's loss kernels are in the profile then)
+            loss = torch.nn.functional.cross_entropy(m(x), target)
+        else:                             # what WavenetTrainer.train_step and bench.py's training legs run: class indices in, the engine's fused loss
+            from mi355_wavenet import training
+            logits = m.train_forward_indices(idx)
+            loss = training.cross_entropy(m._wn_train_runner, logits, target)
         loss.backward()
         opt.step()
         return loss

@@ -22,5 +22,5 @@ cd "$ROOT"
   grep -h 'ms / step' /tmp/tkt.log | head -2
   python tools/rocprof_summary.py $(find /tmp/prof_tkt -name "*.db" | sort) 2>&1 | head -40
 } > "$OUT/rocprofv3_train_${PREC}_$TAG.txt" 2>&1
-python tools/make_pmc_train_json.py $(find /tmp/prof_tf -name "*.db" | head -1) $(find /tmp/prof_tw -name "*.db" | head -1) "$PREC" "profiles/${TAG}_rocprofv3_train_step_cfg5_${PREC}.txt" "$OUT/pmc_traffic_train.json" >> "$OUT/rocprofv3_train_${PREC}_$TAG.txt" 2>&1
+python tools/make_pmc_train_json.py $(find /tmp/prof_tf -name "*.db" | head -1) $(find /tmp/prof_tw -name "*.db" | head -1) "$PREC" "profiles/${TAG}_rocprofv3_train_step_cfg5_${PREC}.txt" "$OUT/pmc_traffic_train.json" $(find /tmp/prof_tkt -name "*.db" | head -1) >> "$OUT/rocprofv3_train_${PREC}_$TAG.txt" 2>&1
 head -c 2500 "$OUT/rocprofv3_train_${PREC}_$TAG.txt"; tail -5 "$OUT/rocprofv3_train_${PREC}_$TAG.txt"

@@ -1,7 +1,9 @@
 """Runs on the GPU box after tools/collect_train_profiles.sh: sums FETCH_SIZE / WRITE_SIZE (rocprofv3 PMC passes, KiB per dispatch) over EVERY kernel of the
 profiled training run and divides by the number of steps (= dispatches of wn_fwd_start, one per forward): HBM bytes per training step, into the
 pmc_traffic_train.json that bench.py replays next to the algorithmic figure.
-    python tools/make_pmc_train_json.py <fetch.db> <write.db> <bf16|fp32> <summary file> <out.json>"""
+    python tools/make_pmc_train_json.py <fetch.db> <write.db> <bf16|fp32> <summary file> <out.json> [<stats.db>]
+With the --kernel-trace --stats database of the same command as a sixth argument: per kernel, counted bytes (2 x FETCH + WRITE) over its own time in the
+UNPERTURBED pass = the rate it moves data at, next to the chip's measured streaming ceilings (profiles/r04_pmc_calibration.txt: 4.45 TB/s load, 5.56 TB/s store)."""
 import datetime
 import json
 import os
@@ -37,6 +39,21 @@ def main():
         print("# largest by %s (GB per step):" % label)
         for k, v, c in top:
             print("#   %-90s %8.2f GB  (%d dispatches)" % (k[:90], v / steps * 1024 / 1e9, c))
+    if len(sys.argv) > 6:
+        per = {}
+        for db, name, mult in ((fdb, "FETCH_SIZE", 2.0), (wdb, "WRITE_SIZE", 1.0)):
+            for k, v in sqlite3.connect(db).execute("select kernel_name, sum(value) from counters_collection where counter_name = ? group by kernel_name", (name,)):
+                per[k] = per.get(k, 0.0) + mult * float(v) * 1024
+        rows = sqlite3.connect(sys.argv[6]).execute("select name, total_calls, total_duration from top_kernels").fetchall()
+        print("# counted bytes (2 x FETCH_SIZE + WRITE_SIZE) over the kernel's own time in the --stats pass; ceilings of this chip: 4.45 TB/s streaming load, 5.56 TB/s streaming")
+        print("# store (profiles/r04_pmc_calibration.txt); kernels overlap on two streams, so the rates of concurrent kernels ADD UP to what the memory system delivers:")
+        for name, calls, total_us in rows[:10]:   # (top_kernels.total_duration is in microseconds: tools/rocprof_summary.py prints the same column)
+            b = per.get(name)
+            if b is None:
+                cands = [k for k in per if k.startswith(name[:40])]
+                b = per[cands[0]] if len(cands) == 1 else None
+            if b is not None and total_us > 0:
+                print("#   %-78s %7.2f GB/step in %6.2f ms/step = %5.2f TB/s" % (name[:78], b / sf / 1e9, total_us / sf / 1e3, b / (total_us * 1e-6) / 1e12))
 
 
 if __name__ == "__main__":
