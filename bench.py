@@ -199,10 +199,13 @@ def train_algorithmic_bytes(N, L, out_len, bf16, layers=10, blocks=5, R=128, D=1
       forward   read x_l (4R), write x_{l+1} (4R), write z (zb D), write the gate pair tanh | sigmoid (gb D)
       backward  read dx' (4R), read the gate pair (gb D), write and read [dF|dG] (2 fb 2D), read z (zb D: dWres), read x_l (4R: dWfg), write dx_l (4R)
     with zb / gb / fb bytes per element: 2 / 4 / 2 in the bf16 step (z, the packed pair and [dF|dG] stored as bf16), 4 / 8 / 4 in the fp32 step.
-    Skip path on the Mo = N * output_length skip rows: z on the skip rows written once and read twice (zb D per layer), dskip read twice per
-    block (4S), dzg written and read (4D per layer), skip read-modify-write per block (8S); head: logits and dlogits (4C each), e and de (2 x 4E
-    each), skip and dskip once more (4S each).  Weights and their gradients (30 MB each) are noise next to the activations."""
+    Skip path on the Mo = N * output_length skip rows: z on the skip rows read twice where the layers left it (zb D per layer: the grouped skip product
+    and its weight gradient; until round 5 a second copy was written for them), dskip read twice per block (sb S: the bf16 step reads its bf16 shadow,
+    written once: 2S), dzg written and read (db D per layer: stored as bf16 in the bf16 step since round 5), skip read-modify-write per block (8S);
+    head: logits and dlogits (4C each), e and de (2 x 4E each), skip and dskip once more (4S each).  Weights and their gradients (30 MB each) are
+    noise next to the activations."""
     zb, gb, fb = (2, 4, 2) if bf16 else (4, 8, 4)
+    sb, db = (2, 2) if bf16 else (4, 4)
     NL = layers * blocks
     dil = [2 ** (i % layers) for i in range(NL)]
     need = [0] * (NL + 1)
@@ -216,7 +219,7 @@ def train_algorithmic_bytes(N, L, out_len, bf16, layers=10, blocks=5, R=128, D=1
         total += M * (4 * R + 4 * R * res + zb * D + gb * D)                                     # forward
         total += M * (4 * R * res + gb * D + 2 * fb * 2 * D + zb * D * res + 4 * R + 4 * R)     # backward
     Mo = N * out_len
-    total += Mo * NL * (3 * zb * D + 2 * 4 * D) + Mo * blocks * (2 * 4 * S + 8 * S)
+    total += Mo * NL * (2 * zb * D + 2 * db * D) + Mo * blocks * (2 * sb * S + 8 * S) + (Mo * 2 * S if bf16 else 0)
     total += Mo * (2 * 4 * C + 4 * 4 * E + 2 * 4 * S)
     return int(total)
 
@@ -268,7 +271,7 @@ def train_step_cfg5(device, N=32, L=16000, reps=3, precision="fp32"):
     return {"ms_per_step": round(ms, 2), "clips": N, "clip_samples": L, "output_length": out_len,
             "hbm_algorithmic_bytes_per_step": hbm, "hbm_gbs": round(hbm / (ms * 1e-3) / 1e9, 1), "hbm_frac": round(hbm / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
             "hbm_measured": _train_pmc(precision, N, L),
-            "dtype": "f32 (matrix cores)" if precision == "fp32" else "bf16 matrix operands (forward, activation- and weight-gradient products), f32 accumulation, f32 residual stream; z, gates and [dF|dG] stored as bf16",
+            "dtype": "f32 (matrix cores)" if precision == "fp32" else "bf16 matrix operands (forward, activation- and weight-gradient products), f32 accumulation, f32 residual stream; z, gates, [dF|dG] and the skip convs' share of dz stored as bf16",
             "tflop_per_step": round(3 * fwd / 1e12, 2), "tflops": round(3 * fwd / ms / 1e9, 1),
             "mfma_peak_tflops": peak, "mfma_peak_frac": round(3 * fwd / ms / 1e9 / peak, 4), "loss": round(float(loss.detach()), 4)}
 

@@ -15,6 +15,8 @@ rounding points and nothing else:
   * z = tanh(F) * sigmoid(G) is STORED as bf16 (consumers see the rounded value; the gradient passes straight through);
   * tanh(F) and sigmoid(G) are saved for the backward as bf16: the gate derivative dF = dz * G * (1 - T^2), dG = dz * T * G * (1 - G) is
     evaluated on the rounded pair, and [dF | dG] is stored as bf16 (the bias gradient of the filter / gate convs sums the stored values);
+  * the skip convs' share of dz -- dzg = rb(dskip) . rb(Wskip), one product per block of layers in the kernels -- is STORED as bf16 (round 5,
+    WN_DZG_BF16 in csrc/wn_forward.h); the gate derivative adds it to the residual conv's share (fp32, never stored) in fp32;
   * the residual stream x, the skip sum, the pre-activations, biases, the loss and every bias gradient stay fp32; start_conv's gradient
     is an exact gather-sum (one-hot rows);
   * full-length clips only (L >= receptive_field + output_length - 1: no returned position sees the reference's pad zeros).
@@ -58,20 +60,23 @@ def _dot(a, b):   # a (M, K) . b (K, N)
 
 
 class _MM(torch.autograd.Function):
-    """Y = A . W^T with both operands rounded to bf16 when `rnd`; float32 result; accumulation as ACCUMULATE says (default: exact)."""
+    """Y = A . W^T with both operands rounded to bf16 when `rnd`; float32 result; accumulation as ACCUMULATE says (default: exact).
+    store_da: the activation gradient dA this product hands back is STORED as bf16 (the skip convs: their share of dz, `dzg`)."""
 
     @staticmethod
-    def forward(ctx, A, W, rnd):
+    def forward(ctx, A, W, rnd, store_da=False):
         a, w = (rb(A), rb(W)) if rnd else (A, W)
         ctx.save_for_backward(a, w)
         ctx.rnd = rnd
+        ctx.store_da = bool(store_da) and rnd
         return _dot(a, w.t())
 
     @staticmethod
     def backward(ctx, dY):
         a, w = ctx.saved_tensors
         dy = rb(dY) if ctx.rnd else dY
-        return _dot(dy, w), _dot(dy.t(), a), None
+        dA = _dot(dy, w)
+        return (rb(dA) if ctx.store_da else dA), _dot(dy.t(), a), None, None
 
 
 class _Gate(torch.autograd.Function):
@@ -130,7 +135,7 @@ def step(cfg, weights, ids, target, output_length, round_operands=True):
             Fp, Gp = Fp + P["filter_convs.%d.bias" % l], Gp + P["gate_convs.%d.bias" % l]
         z = _Gate.apply(Fp, Gp, rnd)                                                     # (N * rows, D)
         zs = z.reshape(N, rows, -1)[:, -output_length:, :].reshape(N * output_length, -1)
-        s = _MM.apply(zs, P["skip_convs.%d.weight" % l][:, :, 0], rnd)                   # :154-162 (only the returned positions matter)
+        s = _MM.apply(zs, P["skip_convs.%d.weight" % l][:, :, 0], rnd, True)             # :154-162 (only the returned positions matter; dzg stored as bf16)
         if bias:
             s = s + P["skip_convs.%d.bias" % l]
         skip = s if skip is None else skip + s

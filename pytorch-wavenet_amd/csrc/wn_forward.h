@@ -74,7 +74,8 @@ struct WnGemmArgs {
     // bf16 STORAGE (the bf16 training step's [dF|dG]; bf16 kernels only).  The row maps of a bf16 matrix point at unsigned short and
     // count their strides in bf16 elements.
     int a_bf16;           // A (both views) is stored as bf16: staged into LDS as it is          (wn_fwd_gemm_bf16<*, *, true>)
-    int c_bf16;           // WN_EPI_GATE_BWD: c receives bf16 (round to nearest even); WN_EPI_GATE: c and c2 do
+    int c_bf16;           // WN_EPI_GATE_BWD: c receives bf16 (round to nearest even); WN_EPI_GATE: c and c2 do; WN_EPI_PLAIN (the stand-alone bf16
+                          // products only): c receives bf16 INSTEAD of fp32 (its row map counts bf16 elements) -- the skip path's share of dz (dzg)
     unsigned short* c_h;  // WN_EPI_PLAIN: optional bf16 COPY of the output (round to nearest even), laid out like c (same strides, in elements):
                           // the bf16 training step's shadow of the residual stream -- every matrix operand read of x takes half the bytes,
                           // with the bits the fp32-stored operand would be rounded to on its way to LDS
@@ -115,7 +116,14 @@ static __device__ __forceinline__ uint4 wn_pack_bf16x8(float4 a, float4 b) {
 // NTILES: accumulator tiles of the strip that exist (WN_EPI_PLAIN, WN_EPI_GATE_BWD; 32 columns each).  zl: the strip's rows of an LDS image
 // [row][zld bf16] of what the strip emits -- z (WN_EPI_GATE with c_bf16; g.c.base may then be NULL: z not stored) or the plain output
 // (WN_EPI_PLAIN) -- the A operand of the fused kernels' second product.
-template <int EPI, int NTILES = 4>
+// CB16: WN_EPI_PLAIN honours g.c_bf16 (the stand-alone bf16 products; the fused kernels' plain epilogues always write fp32 and compile without the branch).
+#ifndef WN_DZG_BF16
+#define WN_DZG_BF16 1   // bf16 step: the skip path's share of dz -- dzg = dskip . Wskip of a block of layers, written by one product, read once by every layer's
+                        // gate derivative -- is STORED as bf16 like every other product output that only feeds the next stage ([dF|dG], z, the gate pair): 8.9 GB
+                        // of fp32 written and 8.9 GB read per config-5 step become 4.45 + 4.45.  One more rounding point of the bf16 step (oracle/bf16_step.py
+                        // carries it); 0 keeps fp32 (A/B builds: host and kernels read the same switch).
+#endif
+template <int EPI, int NTILES = 4, bool CB16 = false>
 static __device__ __forceinline__ void wn_gemm_epilogue(const WnGemmArgs& g, const wn_f16v (&acc)[NTILES], long long mw, int nw, int lane, float* stage,
                                                         unsigned short* zl = nullptr, int zld = 0) {
     const int col = lane & 31;
@@ -239,9 +247,17 @@ static __device__ __forceinline__ void wn_gemm_epilogue(const WnGemmArgs& g, con
                     { const float4 a = *reinterpret_cast<const float4*>(sp), b = *reinterpret_cast<const float4*>(sp + 4);
                       dz[0] = a.x; dz[1] = a.y; dz[2] = a.z; dz[3] = a.w; dz[4] = b.x; dz[5] = b.y; dz[6] = b.z; dz[7] = b.w; }
                     if (g.c2.base && (int)rem >= g.c2_first_row) {
+#if WN_DZG_BF16   // (dzg is stored as bf16: c2's row map counts bf16 elements; one 16-byte load)
+                        const unsigned short* zrow = reinterpret_cast<const unsigned short*>(g.c2.base) + (long long)q * g.c2.batch_stride +
+                                                     (g.c2.t0 + (long long)rem - g.c2_first_row) * g.c2.row_stride + ch0 + c8;
+                        const uint4 a = *reinterpret_cast<const uint4*>(zrow);
+                        dz[0] += __uint_as_float(a.x << 16); dz[1] += __uint_as_float(a.x & 0xffff0000u); dz[2] += __uint_as_float(a.y << 16); dz[3] += __uint_as_float(a.y & 0xffff0000u);
+                        dz[4] += __uint_as_float(a.z << 16); dz[5] += __uint_as_float(a.z & 0xffff0000u); dz[6] += __uint_as_float(a.w << 16); dz[7] += __uint_as_float(a.w & 0xffff0000u);
+#else
                         const float* zrow = g.c2.base + (long long)q * g.c2.batch_stride + (g.c2.t0 + (long long)rem - g.c2_first_row) * g.c2.row_stride + ch0 + c8;
                         const float4 a = *reinterpret_cast<const float4*>(zrow), b = *reinterpret_cast<const float4*>(zrow + 4);
                         dz[0] += a.x; dz[1] += a.y; dz[2] += a.z; dz[3] += a.w; dz[4] += b.x; dz[5] += b.y; dz[6] += b.z; dz[7] += b.w;
+#endif
                     }
                     if (g.gate_packed) {
                         const unsigned* gp = reinterpret_cast<const unsigned*>(g.gate_t) + m * g.N + ch0 + c8;
@@ -316,7 +332,7 @@ static __device__ __forceinline__ void wn_gemm_epilogue(const WnGemmArgs& g, con
                 if (m >= g.M) continue;
                 unsigned q, rem;
                 split(m, q, rem);
-                float* crow = const_cast<float*>(wn_row_at(g.c, q, rem));
+                const long long coff = (long long)q * g.c.batch_stride + (g.c.t0 + (long long)rem) * g.c.row_stride;   // the row's offset in ELEMENTS of c (fp32 or bf16)
                 float4 v = *reinterpret_cast<const float4*>(stage + row * WN_EPI_PITCH + c4);
                 v.x += bias.x; v.y += bias.y; v.z += bias.z; v.w += bias.w;
                 if (g.cin.base && (int)rem >= g.cin_skip_lo) {
@@ -325,14 +341,15 @@ static __device__ __forceinline__ void wn_gemm_epilogue(const WnGemmArgs& g, con
                 }
                 if (g.relu_c) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
                 if (g.mask) {  // the mask shares the output's row layout
-                    const float4 mk = *reinterpret_cast<const float4*>(g.mask + (crow - g.c.base) + n);
+                    const float4 mk = *reinterpret_cast<const float4*>(g.mask + coff + n);
                     if (!(mk.x > 0.f)) v.x = 0.f;
                     if (!(mk.y > 0.f)) v.y = 0.f;
                     if (!(mk.z > 0.f)) v.z = 0.f;
                     if (!(mk.w > 0.f)) v.w = 0.f;
                 }
-                *reinterpret_cast<float4*>(crow + n) = v;
-                if (g.c_h) *reinterpret_cast<uint2*>(g.c_h + (crow - g.c.base) + n) = wn_pack_bf16x4(v);
+                if (CB16 && g.c_bf16) *reinterpret_cast<uint2*>(const_cast<unsigned short*>(reinterpret_cast<const unsigned short*>(g.c.base)) + coff + n) = wn_pack_bf16x4(v);
+                else *reinterpret_cast<float4*>(const_cast<float*>(g.c.base) + coff + n) = v;
+                if (g.c_h) *reinterpret_cast<uint2*>(g.c_h + coff + n) = wn_pack_bf16x4(v);
                 if (zl) *reinterpret_cast<uint2*>(zl + row * zld + n) = wn_pack_bf16x4(v);   // (WN_EPI_PLAIN: the output tile as the next product's bf16 A operand, column n of an image that starts at column 0)
             }
         }
@@ -576,7 +593,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? WN_GEMM_BF16_MINB : 4) voi
             __syncthreads();
         }
     }
-    wn_gemm_epilogue<EPI>(g, acc, m0 + 32 * wr, n0 + 128 * wc, lane, reinterpret_cast<float*>(smem_h) + wv * WN_EPI_TILE_FLOATS);   // (after the loop's last barrier)
+    wn_gemm_epilogue<EPI, 4, true>(g, acc, m0 + 32 * wr, n0 + 128 * wc, lane, reinterpret_cast<float*>(smem_h) + wv * WN_EPI_TILE_FLOATS);   // (after the loop's last barrier)
 }
 
 // ---- One layer of the forward in ONE kernel (bf16 operands; the shape whose filter/gate product is ONE 256-column tile: D = 128, and
@@ -1193,8 +1210,14 @@ __global__ __launch_bounds__(256) void wn_bwd_gate(const float* dz, const float*
     if (dzg) {
         const unsigned n = (unsigned)m / (unsigned)rows, tt = (unsigned)m - n * (unsigned)rows;
         if ((int)tt >= rows - out_len) {
-            const float4 e = *reinterpret_cast<const float4*>(dzg + ((long long)n * out_len + ((int)tt - (rows - out_len))) * ldg + ch);
-            d.x += e.x; d.y += e.y; d.z += e.z; d.w += e.w;
+            const long long off = ((long long)n * out_len + ((int)tt - (rows - out_len))) * ldg + ch;
+            if (PACKED && WN_DZG_BF16) {   // (the bf16 step stores dzg as bf16: `dzg` points at unsigned short, ldg counts bf16 elements)
+                const uint2 e = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(dzg) + off);
+                d.x += __uint_as_float(e.x << 16); d.y += __uint_as_float(e.x & 0xffff0000u); d.z += __uint_as_float(e.y << 16); d.w += __uint_as_float(e.y & 0xffff0000u);
+            } else {
+                const float4 e = *reinterpret_cast<const float4*>(dzg + off);
+                d.x += e.x; d.y += e.y; d.z += e.z; d.w += e.w;
+            }
         }
     }
     float4 t, s;

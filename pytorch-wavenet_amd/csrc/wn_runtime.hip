@@ -90,7 +90,7 @@ static bool wn_launch_layer(hipStream_t st, const WnGemmArgs& a, const unsigned 
 // the fused kernel's (the caller launches the two products).
 static bool wn_launch_bwd_layer(hipStream_t st, const WnGemmArgs& a, const unsigned short* bn, const unsigned short* bn1, int ldb,
                                 const WnGemmArgs& b, const unsigned short* bn_res) {
-    if (!bn || !bn_res || !a.a_bf16 || a.N != 128 || a.K % 32 != 0 || a.bias || a.relu_a || a.relu_c || a.mask || a.c_h ||
+    if (!bn || !bn_res || !a.a_bf16 || a.N != 128 || a.K % 32 != 0 || a.bias || a.relu_a || a.relu_c || a.mask || a.c_h || a.c_bf16 ||
         b.N != 128 || b.K != 128 || !b.c_bf16 || !b.gate_packed || b.M != a.M || b.rows_per_batch != a.rows_per_batch) return false;
     if (b.a0.base != a.c.base || b.a0.t0 != a.c.t0 || b.a0.batch_stride != a.c.batch_stride || b.a0.row_stride != a.c.row_stride) return false;   // (the same rows)
     if (!wn_fused_layer_enabled()) return false;
@@ -459,9 +459,12 @@ struct WnTrainLay {
     long long N, L, out_len;
     std::vector<long long> need;          // need[l] = trailing time steps of layer l's input the loss depends on (and that exist: wn_forward_geometry)
     std::vector<long long> zlo;           // zlo[l] = leading output rows of layer l whose tap x(t - d) is one of the reference's pad zeros
-    std::vector<size_t> x, z, th, sg;     // per layer offsets (floats) into the training workspace
+    std::vector<size_t> x, th, sg;        // per layer offsets (floats) into the training workspace
+    std::vector<size_t> zb;               // per skip block: Z_b, the block's z matrices side by side -- row (n, t) holds [z_first(n, t) | ... | z_{first+cnt-1}(n, t)] (see wn_train_layout_ws)
+    std::vector<long long> zb_rows;       //   rows per batch entry of Z_b (the block's first layer has the most)
     std::vector<size_t> xh;               // bf16 step: the bf16 shadow of x[l] (same shape; offsets in floats, N * L * R / 2 floats each); empty otherwise
-    size_t skip, ev, zg, dzg, bskip_total, res_o, skip_o, w1_o, w2_o, fgb0, fgb1, dskip, de, dz, dfg, dfg2, dxa, dxb, colsum_tmp, idx, total;
+    size_t skip, ev, dzg, bskip_total, res_o, skip_o, w1_o, w2_o, fgb0, fgb1, dskip, de, dz, dfg, dfg2, dxa, dxb, colsum_tmp, idx, total;
+    size_t dskip_h;                       // bf16 step: the bf16 shadow of dskip (a matrix operand twice per skip block: the dzg product and the skip weight gradient); offset in floats
     size_t bw, bt_fg, bt_res, bt_skip, bt_w1, bt_w2;  // bf16 operand banks (offsets in floats)
     int G, nblk;  // layers per skip block, blocks
     bool bf16;  // the saved forward ran with bf16 operands: so does its backward

@@ -32,13 +32,26 @@ static int wn_train_layout_ws(const wn_handle* h, long long N, long long L, long
     t.G = pl.layers < NL ? pl.layers : NL;
     size_t o = 0;
     auto take = [&](size_t n) { size_t r = o; o += (n + 63) & ~(size_t)63; return r; };
-    t.x.resize(NL); t.z.resize(NL); t.th.resize(NL); t.sg.resize(NL);
+    t.x.resize(NL); t.th.resize(NL); t.sg.resize(NL);
     size_t zmax = 0;
     for (int l = 0; l < NL; ++l) {
         const size_t zl = (size_t)N * t.need[l + 1] * D;
         zmax = zl > zmax ? zl : zmax;
         t.x[l] = take((size_t)N * L * R);
-        t.z[l] = take(zl); t.th[l] = take(zl); t.sg[l] = take(zl);
+        t.th[l] = take(zl); t.sg[l] = take(zl);
+    }
+    // z of a skip block's layers lives SIDE BY SIDE in one matrix Z_b: row (n, t) = [z_first(n, t) | z_first+1(n, t) | ...] (cnt * D elements; rows
+    // aligned at the clips' ends, as many per clip as the block's first layer has).  z_l is a strided VIEW of it (row stride cnt * D, column block
+    // l - first, the layer's own trailing rows) -- every consumer takes row maps --, and the last output_length rows of every clip, all columns, ARE the
+    // A operand of the block's grouped skip product and of its weight gradient: rounds 2-4 wrote that operand as a second copy of z on the skip rows
+    // (`zg`: 4.45 GB per bf16 config-5 step written by the gate epilogues, and as much workspace).  The rows a deeper layer of the block does not have
+    // (at most the block's dilations: ~5 %) are never touched.
+    t.nblk = (NL + t.G - 1) / t.G;
+    t.zb.resize(t.nblk); t.zb_rows.resize(t.nblk);
+    for (int b = 0; b < t.nblk; ++b) {
+        const int first = b * t.G, cnt = NL - first < t.G ? NL - first : t.G;
+        t.zb_rows[b] = t.need[first + 1];
+        t.zb[b] = take((size_t)N * t.zb_rows[b] * cnt * D);
     }
     // The bf16 step keeps a bf16 SHADOW of the residual stream next to the fp32 one.  x_l is a matrix operand four times per step (the
     // two tap views of the filter/gate product and of its weight gradient) and an addend once (the residual); the operand reads convert
@@ -51,10 +64,11 @@ static int wn_train_layout_ws(const wn_handle* h, long long N, long long L, long
         for (int l = 0; l < NL; ++l) t.xh[l] = take(((size_t)N * L * R + 1) / 2);
     }
     const size_t Mo = (size_t)N * out_len;
-    t.skip = take(Mo * S); t.ev = take(Mo * E); t.nblk = (NL + t.G - 1) / t.G; t.zg = take((size_t)t.nblk * Mo * t.G * D); t.dzg = take((size_t)t.nblk * Mo * t.G * D); t.bskip_total = take(S);
+    t.skip = take(Mo * S); t.ev = take(Mo * E); t.dzg = take((size_t)t.nblk * Mo * t.G * D); t.bskip_total = take(S);
     t.res_o = take((size_t)NL * R * D); t.skip_o = take((size_t)NL * S * D); t.w1_o = take((size_t)E * S); t.w2_o = take((size_t)C * E);
     t.fgb0 = take((size_t)NL * 2 * D * R); t.fgb1 = take((size_t)NL * 2 * D * R);
     t.dskip = take(Mo * S); t.de = take(Mo * E); t.dz = take(zmax); t.dfg = take(2 * zmax); t.dfg2 = take(2 * zmax);
+    t.dskip_h = (h->fw_bf16 && h->fwb_ok) ? take((Mo * S + 1) / 2) : 0;   // (written by the dskip product next to the fp32 matrix: WnGemmArgs::c_h)
     t.dxa = take((size_t)N * L * R); t.dxb = take((size_t)N * L * R);
     t.colsum_tmp = take(S);
     t.idx = take((size_t)N * L);
@@ -65,6 +79,19 @@ static int wn_train_layout_ws(const wn_handle* h, long long N, long long L, long
     t.bt_w1 = take((size_t)E * S / 2); t.bt_w2 = take((size_t)C * E / 2);
     t.total = o;
     return WN_OK;
+}
+
+// Row maps into Z_b (wn_train_layout_ws).  h16: z is stored as bf16 (the maps count bf16 elements then; the base is a bf16 address behind a float pointer).
+static WnRowMap wn_z_map(const WnTrainLay& t, float* ws, int NL, int D, int l, bool h16) {       // z_l on its own rows (index 0 = the first of its need[l + 1])
+    const int b = l / t.G, first = b * t.G, cnt = NL - first < t.G ? NL - first : t.G, gi = l - first;
+    const long long ld = (long long)cnt * D, rows_b = t.zb_rows[b];
+    float* base = h16 ? reinterpret_cast<float*>(reinterpret_cast<unsigned short*>(ws + t.zb[b]) + (size_t)gi * D) : ws + t.zb[b] + (size_t)gi * D;
+    return WnRowMap{base, rows_b * ld, ld, rows_b - t.need[l + 1]};
+}
+static WnRowMap wn_zg_map(const WnTrainLay& t, float* ws, int NL, int D, int b) {                 // the block's z on the last output_length rows of every clip, all columns
+    const int first = b * t.G, cnt = NL - first < t.G ? NL - first : t.G;
+    const long long ld = (long long)cnt * D, rows_b = t.zb_rows[b];
+    return WnRowMap{ws + t.zb[b], rows_b * ld, ld, rows_b - t.out_len};
 }
 
 extern "C" int wn_train_get_layout(wn_handle* h, wn_train_layout* out) {
@@ -103,7 +130,7 @@ static void wn_launch_cvt_t(hipStream_t st, const float* in, long long in_batch_
 #endif
 static void wn_launch_tn(hipStream_t st, WnGemmTnArgs a, bool bf16 = false) {
     // bf16 products with Nb % 256 == 0 take the 128 x 256 tile (A streamed once per 256 columns of B); rows split by wn_tn_grid (wn_plan.h)
-    const bool wide16 = bf16 && !a.a_idx && a.a_bf16 && a.b_bf16 && a.ka_split > 0 && a.Nb % 256 == 0;   // (both operands stored as bf16: the filter/gate weight gradient on the shadow of x)
+    const bool wide16 = bf16 && !a.a_idx && a.a_bf16 && a.b_bf16 && a.Nb % 256 == 0;   // (both operands stored as bf16: the filter/gate weight gradient on the shadow of x -- two tap views, ka_split > 0 --, the skip weight gradient on the shadow of dskip)
     const bool wide = wide16 || (bf16 && !a.a_idx && !a.a_bf16 && a.Nb % 256 == 0);
     const WnTnGrid tg = wn_tn_grid(a.M, a.Ka, a.Nb, wide ? 256 : 128, wide ? 512 : 1024);
     a.rows_per_split = tg.rows_per_split;
@@ -225,9 +252,8 @@ extern "C" int wn_train_forward(wn_handle* h, const float* params, const int32_t
     for (int l = 0; l < NL; ++l) {
         const long long d = h->dil[l], rows = t.need[l + 1], t0 = L - rows;
         const int gi = l % G;
-        float* zg = ws + t.zg + (size_t)(l / G) * ((size_t)N * out_len * G * D);  // this block's z on the skip rows (kept for the backward)
         float* xin = ws + t.x[l];
-        float* z = ws + t.z[l];
+        const WnRowMap zmap = wn_z_map(t, ws, NL, D, l, bf16);   // z_l: a strided view of the block's Z_b (wn_train_layout_ws)
         WnGemmArgs a;
         memset(&a, 0, sizeof(a));
         const bool shadow = bf16 && !t.xh.empty();   // matrix operand reads of x take its bf16 shadow (wn_train_layout_ws)
@@ -238,10 +264,7 @@ extern "C" int wn_train_forward(wn_handle* h, const float* params, const int32_t
         a.a_bf16 = shadow ? 1 : 0;
         a.k_split = R; a.K = 2 * R; a.bt = fw + h->fw_off_fg + (size_t)l * 2 * R * 2 * D; a.N = 2 * D;
         a.bias = pl.has_bias ? fw + h->fw_off_bfg + (size_t)l * 2 * D : nullptr;
-        a.c = WnRowMap{z, rows * D, D, 0};
-        // (column block gi of zg; in the bf16 step zg holds bf16 and the offset counts bf16 elements)
-        a.c2 = WnRowMap{bf16 ? reinterpret_cast<float*>(reinterpret_cast<unsigned short*>(zg) + (size_t)gi * D) : zg + (size_t)gi * D, out_len * (long long)G * D, (long long)G * D, 0};
-        a.c2_first_row = (int)(rows - out_len);
+        a.c = zmap;   // (no second copy on the skip rows: the grouped skip product reads those rows of Z_b where they lie)
         a.gate_t = ws + t.th[l]; a.gate_g = ws + t.sg[l];
         a.gate_packed = bf16 ? 1 : 0;  // bf16 step: tanh and sigmoid saved as one {bf16, bf16} dword per element (half the bytes, written once)
         a.c_bf16 = bf16 ? 1 : 0;       //            z (and its copy on the skip rows, zg) stored as bf16
@@ -249,7 +272,7 @@ extern "C" int wn_train_forward(wn_handle* h, const float* params, const int32_t
         WnGemmArgs ar;   // the residual product x_{l+1} = z . Wres^T + bias + x_l
         memset(&ar, 0, sizeof(ar));
         if (l < NL - 1) {
-            ar.a0 = ar.a1 = WnRowMap{z, rows * D, D, 0};
+            ar.a0 = ar.a1 = zmap;
             ar.k_split = D; ar.K = D; ar.bt = fw + h->fw_off_res + (size_t)l * D * R; ar.N = R;
             ar.bias = pl.has_bias ? fw + h->fw_off_bres + (size_t)l * R : nullptr;
             ar.cin = WnRowMap{xin, (long long)L * R, R, t0};
@@ -266,13 +289,13 @@ extern "C" int wn_train_forward(wn_handle* h, const float* params, const int32_t
         if (gi == G - 1 || l == NL - 1) {
             const int first = l - gi, cnt = gi + 1;
             memset(&a, 0, sizeof(a));
-            a.a0 = a.a1 = WnRowMap{zg, out_len * (long long)G * D, (long long)G * D, 0};
+            a.a0 = a.a1 = wn_zg_map(t, ws, NL, D, first / G);
             a.k_split = cnt * D; a.K = cnt * D; a.bt = fw + h->fw_off_skip + (size_t)first * D * S; a.N = S;
             a.bias = (pl.has_bias && first == 0) ? ws + t.bskip_total : nullptr;
             if (first > 0) a.cin = WnRowMap{skip, out_len * S, S, 0};
             a.c = WnRowMap{skip, out_len * S, S, 0};
             a.M = N * out_len; a.rows_per_batch = (int)out_len; a.a_bf16 = bf16 ? 1 : 0;
-            wait_for(sd, signal(st));   // the block's zg is complete (every gate product of the block ran on the caller's stream)
+            wait_for(sd, signal(st));   // the block's Z_b is complete (every gate product of the block ran on the caller's stream)
             wn_launch_nn(sd, WN_EPI_PLAIN, a, bf16 ? bt_skip + (size_t)(first / G) * S * G * D : nullptr);
         }
     }
@@ -313,7 +336,7 @@ extern "C" int wn_train_backward(wn_handle* h, const float* params, const float*
     (void)params;  // the operand layouts of this step's parameters were rebuilt by wn_train_forward
     int rc = rt_hip(hipMemsetAsync(grads, 0, h->fw_floats * 4, st), "hipMemsetAsync(grads)");
     if (rc) return rc;
-    float* dskip = ws + t.dskip; float* de = ws + t.de; float* dz = ws + t.dz;
+    float* dskip = ws + t.dskip; float* de = ws + t.de;
     // Two streams.  The activation-gradient chain (dz -> [dF|dG] -> dx, layer after layer) is strictly sequential; the weight-gradient
     // products only hang off it (dWres needs dx', dWfg needs [dF|dG], the grouped dWskip needs dskip) and nobody waits for them before
     // the optimizer.  They run on a side stream, ordered by events: every product of the chain then has a second, independent kernel
@@ -369,6 +392,11 @@ extern "C" int wn_train_backward(wn_handle* h, const float* params, const float*
     a.a0 = a.a1 = WnRowMap{de, out_len * E, E, 0};
     a.k_split = E; a.K = E; a.bt = ws + t.w1_o; a.N = S;
     a.c = WnRowMap{dskip, out_len * S, S, 0}; a.mask = skip;
+    // bf16 step: dskip is a matrix operand twice per skip block (the dzg product's A, the skip weight gradient's) and an fp32 column sum once (the
+    // skip biases): the product also writes the bits those operand reads would round it to (as x has its shadow), they take half the bytes
+    unsigned short* dskip_h = t.bf16 ? reinterpret_cast<unsigned short*>(ws + t.dskip_h) : nullptr;
+    { const char* off = wn_dev_env("WN_NO_DSKIP_SHADOW"); if (off && off[0] == '1') dskip_h = nullptr; }   // (A/B runs, with WN_TESTING=1)
+    a.c_h = dskip_h;
     a.M = Mo; a.rows_per_batch = (int)out_len;
     wn_launch_nn(st, WN_EPI_PLAIN, a, bw ? bw + h->fw_off_w1 : nullptr);
     if (pl.has_bias) {          // every layer's skip bias sees the same gradient
@@ -387,22 +415,29 @@ extern "C" int wn_train_backward(wn_handle* h, const float* params, const float*
     // dzg_b to dz on the skip rows.  Both products only need dskip: all blocks are enqueued NOW on the side stream, last block first --
     // the chain waits 1.2 ms for the last block's dzg (as it always did) and finds the others ready (one dzg buffer per block).
     std::vector<hipEvent_t> dzg_ready(t.nblk, nullptr);
+    // bf16 step: dzg is STORED as bf16 (WN_DZG_BF16, wn_forward.h) -- element (block b, row, column) of the buffer, as a float pointer the row maps carry
+    const bool dzg16 = t.bf16 && WN_DZG_BF16;
+    auto dzg_at = [&](int b, size_t col) -> float* {
+        const size_t e = (size_t)b * ((size_t)Mo * t.G * D) + col;
+        return dzg16 ? reinterpret_cast<float*>(reinterpret_cast<unsigned short*>(ws + t.dzg) + e) : ws + t.dzg + e;
+    };
     for (int b = t.nblk - 1; b >= 0; --b) {
         const int first = b * t.G, cnt = NL - first < t.G ? NL - first : t.G;
-        float* dzg_b = ws + t.dzg + (size_t)b * ((size_t)Mo * t.G * D);
-        const float* zg = ws + t.zg + (size_t)b * ((size_t)Mo * t.G * D);
+        float* dzg_b = dzg_at(b, 0);
         memset(&a, 0, sizeof(a));
-        a.a0 = a.a1 = WnRowMap{dskip, out_len * S, S, 0};
+        if (dskip_h) { a.a0 = a.a1 = WnRowMap{reinterpret_cast<const float*>(dskip_h), out_len * S, S, 0}; a.a_bf16 = 1; }   // (the same bits, half the bytes)
+        else a.a0 = a.a1 = WnRowMap{dskip, out_len * S, S, 0};
         a.k_split = S; a.K = S; a.bt = ws + t.skip_o + (size_t)first * S * D; a.N = cnt * D;
-        a.c = WnRowMap{dzg_b, out_len * (long long)cnt * D, (long long)cnt * D, 0};
+        a.c = WnRowMap{dzg_b, out_len * (long long)cnt * D, (long long)cnt * D, 0}; a.c_bf16 = dzg16 ? 1 : 0;
         a.M = Mo; a.rows_per_batch = (int)out_len;
         wn_launch_nn(sd, WN_EPI_PLAIN, a, bw ? bw + h->fw_off_skip + (size_t)first * D * S : nullptr);
         if (two) dzg_ready[b] = signal(sd);
         memset(&g, 0, sizeof(g));
-        g.a = WnRowMap{zg, out_len * (long long)t.G * D, (long long)t.G * D, 0}; g.b = WnRowMap{dskip, out_len * S, S, 0};
+        g.a = wn_zg_map(t, ws, NL, D, b); g.b = WnRowMap{dskip, out_len * S, S, 0};   // (the block's z on the skip rows, where the forward left it)
         g.Ka = cnt * D; g.Nb = S; g.c = grads + h->fw_off_skip + (size_t)first * D * S; g.ldc = S; g.M = Mo; g.rows_per_batch = (int)out_len;
         if (t.bf16) {   // zg is stored as bf16: it goes in as B (operands swapped, C written transposed -- same [cnt*D][S] gradient)
             WnRowMap zmap = g.a; g.a = g.b; g.b = zmap; g.Ka = S; g.Nb = cnt * D; g.b_bf16 = 1; g.c_trans = 1;
+            if (dskip_h && (cnt * D) % 256 == 0) { g.a = WnRowMap{reinterpret_cast<const float*>(dskip_h), out_len * S, S, 0}; g.a_bf16 = 1; }   // (the 256-column tile has the form with both operands stored as bf16)
         }
         wn_launch_tn(sd, g, t.bf16);
     }
@@ -414,12 +449,11 @@ extern "C" int wn_train_backward(wn_handle* h, const float* params, const float*
     auto gate_bwd_args = [&](int k, const float* dx_in, WnGemmArgs& o) {
         const long long rows_k = t.need[k + 1], t0_k = L - rows_k;
         const int gi_k = k % t.G, first_k = k - gi_k, cnt_k = NL - first_k < t.G ? NL - first_k : t.G;
-        float* dzg_k = ws + t.dzg + (size_t)(k / t.G) * ((size_t)Mo * t.G * D);
         memset(&o, 0, sizeof(o));
         o.a0 = o.a1 = WnRowMap{dx_in, L * (long long)R, R, t0_k};
         o.k_split = R; o.K = R; o.bt = ws + t.res_o + (size_t)k * R * D; o.N = D;
         o.c = WnRowMap{ws + ((k & 1) ? t.dfg2 : t.dfg), rows_k * 2 * D, 2 * D, 0}; o.c_bf16 = t.bf16 ? 1 : 0;   // bf16 step: [dF|dG] is STORED as bf16 (it only ever feeds bf16 matrix operands)
-        o.c2 = WnRowMap{dzg_k + (size_t)gi_k * D, out_len * (long long)cnt_k * D, (long long)cnt_k * D, 0};
+        o.c2 = WnRowMap{dzg_at(k / t.G, (size_t)gi_k * D), out_len * (long long)cnt_k * D, (long long)cnt_k * D, 0};   // (bf16 step: bf16 elements, WN_DZG_BF16)
         o.c2_first_row = (int)(rows_k - out_len);
         o.gate_t = ws + t.th[k]; o.gate_g = ws + t.sg[k]; o.gate_packed = t.bf16 ? 1 : 0;
         o.M = N * rows_k; o.rows_per_batch = (int)rows_k;
@@ -435,11 +469,9 @@ extern "C" int wn_train_backward(wn_handle* h, const float* params, const float*
     for (int l = NL - 1; l >= 0; --l) {
         const long long d = h->dil[l], rows = t.need[l + 1], t0 = L - rows, M = N * rows;
         const float* xin = ws + t.x[l];
-        const float* z = ws + t.z[l];
         const bool has_res = l < NL - 1;
         float* dfg = ws + ((l & 1) ? t.dfg2 : t.dfg);
         const int gi = l % t.G, first = l - gi, cnt = NL - first < t.G ? NL - first : t.G;
-        float* dzg = ws + t.dzg + (size_t)(l / t.G) * ((size_t)Mo * t.G * D);
         if (!have_dfg) gate_bwd_waits(l);
         if (has_res) {
             if (!have_dfg) {
@@ -447,7 +479,7 @@ extern "C" int wn_train_backward(wn_handle* h, const float* params, const float*
                 wn_launch_nn(st, WN_EPI_GATE_BWD, a, bw ? bw + h->fw_off_res + (size_t)l * D * R : nullptr);
             }
             memset(&g, 0, sizeof(g));   // dWres^T [D][R] = z^T . dx'
-            g.a = WnRowMap{z, rows * D, D, 0}; g.b = WnRowMap{dxn, L * (long long)R, R, t0};
+            g.a = wn_z_map(t, ws, NL, D, l, t.bf16); g.b = WnRowMap{dxn, L * (long long)R, R, t0};
             g.Ka = D; g.Nb = R; g.c = grads + h->fw_off_res + (size_t)l * D * R; g.ldc = R; g.M = M; g.rows_per_batch = (int)rows;
             g.a_bf16 = t.bf16 ? 1 : 0;   // z is stored as bf16 in the bf16 step (here as A: ~1000 row splits, see wn_bwd_gemm_tn_bf16)
             wn_launch_tn(sd, g, t.bf16);   // (dx' is complete: the side stream waited for the dx product of layer l + 1, below)
@@ -458,10 +490,10 @@ extern "C" int wn_train_backward(wn_handle* h, const float* params, const float*
             const float* no_dz = nullptr;
             if (t.bf16)
                 hipLaunchKernelGGL(wn_bwd_gate<true>, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, no_dz, ws + t.th[l], ws + t.sg[l], dfg, M, D,
-                                   dzg + (size_t)gi * D, cnt * D, (int)rows, (int)out_len);
+                                   dzg_at(l / t.G, (size_t)gi * D), cnt * D, (int)rows, (int)out_len);
             else
                 hipLaunchKernelGGL(wn_bwd_gate<false>, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, no_dz, ws + t.th[l], ws + t.sg[l], dfg, M, D,
-                                   dzg + (size_t)gi * D, cnt * D, (int)rows, (int)out_len);
+                                   dzg_at(l / t.G, (size_t)gi * D), cnt * D, (int)rows, (int)out_len);
         }
         wait_for(sd, signal(st));   // [dF|dG] of this layer is complete
         // dWfg^T [2R][2D]: rows 0..R-1 = x_l(t - d)^T . dfg (tap 0), rows R.. = x_l(t)^T . dfg (tap 1) -- one launch, the taps are two

@@ -2,7 +2,7 @@
 dil/res=128 skip=512, N one-second 16 kHz mu-law clips, through the facade -- native matrix-core forward + backward
 (wn_train_forward / wn_train_backward) next to the facade's torch path (MIOpen conv1d + autograd) on the same GPU.
 
-    python tools/bench_train.py [N] [L] [--no-torch]
+    python tools/bench_train.py [N] [L] [--no-torch] [--reps=K]
 """
 import os
 import sys
@@ -72,10 +72,11 @@ def main():
             label, ms, float(loss.detach()), fwd / 1e12, 3 * fwd / ms / 1e9, N * L / 16000 / (ms * 1e-3)))
         return ms
 
-    a = timed("native fp32 matrix-core step", 3) if "--only-bf16" not in sys.argv else 0.0
+    reps = ([int(v.split("=")[1]) for v in sys.argv if v.startswith("--reps=")] or [3])[0]
+    a = timed("native fp32 matrix-core step", reps) if "--only-bf16" not in sys.argv else 0.0
     if "--only-fp32" not in sys.argv:
         m.matrix_precision = "bf16"
-        timed("native step, bf16 operands for forward + activation gradients", 3)
+        timed("native step, bf16 operands for forward + activation gradients", reps)
         m.matrix_precision = "fp32"
     peak = torch.cuda.max_memory_allocated() / 2**30
     print("torch-allocated peak %.1f GiB (the native workspace is allocated by the library, not by torch)" % peak)
