@@ -132,7 +132,13 @@ static void wn_launch_tn(hipStream_t st, WnGemmTnArgs a, bool bf16 = false) {
     // bf16 products with Nb % 256 == 0 take the 128 x 256 tile (A streamed once per 256 columns of B); rows split by wn_tn_grid (wn_plan.h)
     const bool wide16 = bf16 && !a.a_idx && a.a_bf16 && a.b_bf16 && a.Nb % 256 == 0;   // (both operands stored as bf16: the filter/gate weight gradient on the shadow of x -- two tap views, ka_split > 0 --, the skip weight gradient on the shadow of dskip)
     const bool wide = wide16 || (bf16 && !a.a_idx && !a.a_bf16 && a.Nb % 256 == 0);
-    const WnTnGrid tg = wn_tn_grid(a.M, a.Ka, a.Nb, wide ? 256 : 128, wide ? 512 : 1024);
+    // How many workgroups share the rows (each adds its 128 x 128 / 128 x 256 partial tile with fp32 atomics).  The bf16 forms: 512 -- one full round of
+    // the resident slots (two 512-thread or three 256-thread workgroups per CU), half the atomic traffic of round 4's 1024 for the 128-column form:
+    // 57.6 -> 55.5 ms per config-5 step (384-640: level; 256: 55.6; the 256-column form at 256 / 384 / 768 / 1024: 60.5 / 55.1 / 56.6 / 60.0 against
+    // 54.9 at 512; profiles/r05_training_step_byte_cuts.txt).  The fp32 kernel is matrix-pipe bound and wants the rows spread wider: 1024 (512: 179 -> 194 ms).
+    int want = (wide || (bf16 && !a.a_idx)) ? 512 : 1024;
+    { const char* wv = wn_dev_env(wide ? "WN_TN_WANT_WIDE" : "WN_TN_WANT"); if (wv && atoi(wv) > 0) want = atoi(wv); }   // (A/B runs, with WN_TESTING=1)
+    const WnTnGrid tg = wn_tn_grid(a.M, a.Ka, a.Nb, wide ? 256 : 128, want);
     a.rows_per_split = tg.rows_per_split;
     a.tiles_ka = tg.tiles_ka; a.n_splits = tg.splits;
     const dim3 grid(tg.blocks);   // wn_tile_of: the tiles of a row split share an XCD
