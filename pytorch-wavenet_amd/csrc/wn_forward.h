@@ -117,6 +117,9 @@ static __device__ __forceinline__ uint4 wn_pack_bf16x8(float4 a, float4 b) {
 // [row][zld bf16] of what the strip emits -- z (WN_EPI_GATE with c_bf16; g.c.base may then be NULL: z not stored) or the plain output
 // (WN_EPI_PLAIN) -- the A operand of the fused kernels' second product.
 // CB16: WN_EPI_PLAIN honours g.c_bf16 (the stand-alone bf16 products; the fused kernels' plain epilogues always write fp32 and compile without the branch).
+#ifndef WN_ABL_TN_PLAIN_STORE
+#define WN_ABL_TN_PLAIN_STORE 0   // timing ablation of wn_bwd_gemm_tn_bf16 (tools/build_variant.py; results wrong): plain stores instead of the fp32 atomics
+#endif
 #ifndef WN_DZG_BF16
 #define WN_DZG_BF16 1   // bf16 step: the skip path's share of dz -- dzg = dskip . Wskip of a block of layers, written by one product, read once by every layer's
                         // gate derivative -- is STORED as bf16 like every other product output that only feeds the next stage ([dF|dG], z, the gate pair): 8.9 GB
@@ -1188,7 +1191,11 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? WN_TN_BF16_MINB : 4) void 
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int nb = nb0 + 128 * wc + 32 * j + col;
+#if WN_ABL_TN_PLAIN_STORE   // timing ablation (results wrong): what the fp32 atomics of the row splits cost
+            if (nb < g.Nb) g.c[g.c_trans ? (size_t)nb * g.ldc + ka : (size_t)ka * g.ldc + nb] = acc[j][i];
+#else
             if (nb < g.Nb) unsafeAtomicAdd(g.c + (g.c_trans ? (size_t)nb * g.ldc + ka : (size_t)ka * g.ldc + nb), acc[j][i]);
+#endif
         }
     }
 }
