@@ -377,23 +377,38 @@ extern "C" int wn_train_backward(wn_handle* h, const float* params, const float*
     const float* skip = ws + t.skip; const float* ev = ws + t.ev;
     WnGemmArgs a;
     WnGemmTnArgs g;
-    // ---- head
-    memset(&g, 0, sizeof(g));   // dW2^T [E][C] = e^T . dlogits
-    g.a = WnRowMap{ev, out_len * E, E, 0}; g.b = WnRowMap{dlogits, out_len * C, C, 0};
-    g.Ka = E; g.Nb = C; g.c = grads + h->fw_off_w2; g.ldc = C; g.M = Mo; g.rows_per_batch = (int)out_len;
-    wn_launch_tn(st, g, t.bf16);
-    wn_launch_colsum(st, WnRowMap{dlogits, out_len * C, C, 0}, Mo, (int)out_len, C, grads + h->fw_off_b2);
+    // ---- head.  Only de and dskip are on the way to the layers; the head's own weight and bias gradients (two products over the rows, three column sums:
+    // 0.7 ms at config 5) hang off them like every other weight gradient and run on the side stream, behind the first dzg product the chain waits for
+    // (round 4 ran them on the caller's stream in front of dskip).
+    auto head_weight_grads = [&](hipStream_t s2) -> int {
+        WnGemmTnArgs gh;
+        memset(&gh, 0, sizeof(gh));   // dW2^T [E][C] = e^T . dlogits
+        gh.a = WnRowMap{ev, out_len * E, E, 0}; gh.b = WnRowMap{dlogits, out_len * C, C, 0};
+        gh.Ka = E; gh.Nb = C; gh.c = grads + h->fw_off_w2; gh.ldc = C; gh.M = Mo; gh.rows_per_batch = (int)out_len;
+        wn_launch_tn(s2, gh, t.bf16);
+        wn_launch_colsum(s2, WnRowMap{dlogits, out_len * C, C, 0}, Mo, (int)out_len, C, grads + h->fw_off_b2);
+        memset(&gh, 0, sizeof(gh));   // dW1^T [S][E] = relu(skip)^T . de
+        gh.a = WnRowMap{skip, out_len * S, S, 0}; gh.b = WnRowMap{de, out_len * E, E, 0}; gh.relu_a = 1;
+        gh.Ka = S; gh.Nb = E; gh.c = grads + h->fw_off_w1; gh.ldc = E; gh.M = Mo; gh.rows_per_batch = (int)out_len;
+        wn_launch_tn(s2, gh, t.bf16);
+        wn_launch_colsum(s2, WnRowMap{de, out_len * E, E, 0}, Mo, (int)out_len, E, grads + h->fw_off_b1);
+        if (pl.has_bias) {          // every layer's skip bias sees the same gradient
+            int rc2 = rt_hip(hipMemsetAsync(ws + t.colsum_tmp, 0, (size_t)S * 4, s2), "hipMemsetAsync");
+            if (rc2) return rc2;
+            wn_launch_colsum(s2, WnRowMap{dskip, out_len * S, S, 0}, Mo, (int)out_len, S, ws + t.colsum_tmp);
+            for (int l = 0; l < NL; ++l) {
+                rc2 = rt_hip(hipMemcpyAsync(grads + h->fw_off_bskip + (size_t)l * S, ws + t.colsum_tmp, (size_t)S * 4, hipMemcpyDeviceToDevice, s2), "hipMemcpyAsync(dbskip)");
+                if (rc2) return rc2;
+            }
+        }
+        return 0;
+    };
     memset(&a, 0, sizeof(a));   // de = (dlogits . W2) * [e > 0]
     a.a0 = a.a1 = WnRowMap{dlogits, out_len * C, C, 0};
     a.k_split = C; a.K = C; a.bt = ws + t.w2_o; a.N = E;
     a.c = WnRowMap{de, out_len * E, E, 0}; a.mask = ev;
     a.M = Mo; a.rows_per_batch = (int)out_len;
     wn_launch_nn(st, WN_EPI_PLAIN, a, bw ? bw + h->fw_off_w2 : nullptr);
-    memset(&g, 0, sizeof(g));   // dW1^T [S][E] = relu(skip)^T . de
-    g.a = WnRowMap{skip, out_len * S, S, 0}; g.b = WnRowMap{de, out_len * E, E, 0}; g.relu_a = 1;
-    g.Ka = S; g.Nb = E; g.c = grads + h->fw_off_w1; g.ldc = E; g.M = Mo; g.rows_per_batch = (int)out_len;
-    wn_launch_tn(st, g, t.bf16);
-    wn_launch_colsum(st, WnRowMap{de, out_len * E, E, 0}, Mo, (int)out_len, E, grads + h->fw_off_b1);
     memset(&a, 0, sizeof(a));   // dskip = (de . W1) * [skip > 0]
     a.a0 = a.a1 = WnRowMap{de, out_len * E, E, 0};
     a.k_split = E; a.K = E; a.bt = ws + t.w1_o; a.N = S;
@@ -405,16 +420,7 @@ extern "C" int wn_train_backward(wn_handle* h, const float* params, const float*
     a.c_h = dskip_h;
     a.M = Mo; a.rows_per_batch = (int)out_len;
     wn_launch_nn(st, WN_EPI_PLAIN, a, bw ? bw + h->fw_off_w1 : nullptr);
-    if (pl.has_bias) {          // every layer's skip bias sees the same gradient
-        rc = rt_hip(hipMemsetAsync(ws + t.colsum_tmp, 0, (size_t)S * 4, st), "hipMemsetAsync");
-        if (rc) return rc;
-        wn_launch_colsum(st, WnRowMap{dskip, out_len * S, S, 0}, Mo, (int)out_len, S, ws + t.colsum_tmp);
-        for (int l = 0; l < NL; ++l) {
-            rc = rt_hip(hipMemcpyAsync(grads + h->fw_off_bskip + (size_t)l * S, ws + t.colsum_tmp, (size_t)S * 4, hipMemcpyDeviceToDevice, st), "hipMemcpyAsync(dbskip)");
-            if (rc) return rc;
-        }
-    }
-    wait_for(sd, signal(st));   // grads cleared, dskip complete: the side stream may start
+    wait_for(sd, signal(st));   // grads cleared, de and dskip complete: the side stream may start
     // The skip path's gradients, one block of G layers at a time (as in the forward):
     //   dzg_b [Mo][cnt*D] = dskip . [Wskip of the block's layers]      dWskip^T of the block [cnt*D][S] = zg^T . dskip
     // so dskip (0.7 GB at config 5) is read twice per block instead of twice per layer; the gate step of a layer adds its column block of
@@ -438,6 +444,7 @@ extern "C" int wn_train_backward(wn_handle* h, const float* params, const float*
         a.M = Mo; a.rows_per_batch = (int)out_len;
         wn_launch_nn(sd, WN_EPI_PLAIN, a, bw ? bw + h->fw_off_skip + (size_t)first * D * S : nullptr);
         if (two) dzg_ready[b] = signal(sd);
+        if (b == t.nblk - 1) { rc = head_weight_grads(sd); if (rc) return rc; }   // (behind the one product the chain is waiting for)
         memset(&g, 0, sizeof(g));
         g.a = wn_zg_map(t, ws, NL, D, b); g.b = WnRowMap{dskip, out_len * S, S, 0};   // (the block's z on the skip rows, where the forward left it)
         g.Ka = cnt * D; g.Nb = S; g.c = grads + h->fw_off_skip + (size_t)first * D * S; g.ldc = S; g.M = Mo; g.rows_per_batch = (int)out_len;
@@ -561,8 +568,8 @@ extern "C" int wn_train_backward(wn_handle* h, const float* params, const float*
         wait_for(sd, signal(st));   // dx_l is complete: dWres of layer l - 1 may read it (fused: [dF|dG] of layer l - 1 as well)
         float* tmp = dxn; dxn = dxc; dxc = tmp;
     }
-    wait_for(st, signal(sd));   // join: every weight gradient is complete before the caller's stream goes on
-    // ---- start_conv: dstart^T [C][R] = onehot(indices)^T . dx_0 over the rows dx_0 exists on (the last need[0] time steps)
+    // ---- start_conv: dstart^T [C][R] = onehot(indices)^T . dx_0 over the rows dx_0 exists on (the last need[0] time steps) -- in FRONT of the join: it
+    // only needs dx_0, and runs next to what the side stream still has to do (the first layer's weight gradients)
     {
         const long long r0 = t.need[0], f0 = L - r0;
         memset(&g, 0, sizeof(g));
@@ -572,6 +579,7 @@ extern "C" int wn_train_backward(wn_handle* h, const float* params, const float*
         wn_launch_tn(st, g, t.bf16);
         if (pl.has_bias) wn_launch_colsum(st, WnRowMap{dxn, L * (long long)R, R, f0}, N * r0, (int)r0, R, grads + h->fw_off_start_b);
     }
+    wait_for(st, signal(sd));   // join: every weight gradient is complete before the caller's stream goes on
     return rt_hip(hipGetLastError(), "wn_train_backward launches");
 }
 
