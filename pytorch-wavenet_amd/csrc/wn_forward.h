@@ -607,6 +607,32 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? WN_GEMM_BF16_MINB : 4) voi
 // (0.13 GB per layer at config 5) and each launch pays its own tail (3250 workgroups = 3.2 rounds of the chip); the second product adds
 // ~20 % to the tile's MFMA work and nothing to its global reads but the addend.  Same operands, same chunk order, same accumulation as
 // the two kernels: the results are theirs bit for bit.  g.c.base == NULL: z itself is not stored (forward only: nothing reads it again).
+// Row tile of a workgroup of the one-launch layer kernels.  Workgroups are handed to the eight XCDs round robin, so with tile = blockIdx neighbouring row tiles
+// run on DIFFERENT XCDs -- and the layer kernels read every row twice: the tap view x(t - d) / [dF|dG](t + d) of a tile is the other view of the tile d / 128 further
+// (or of itself and its neighbour for d < 128).  With one contiguous range of tiles per XCD, in dispatch order, both reads meet in one L2 a few microseconds apart
+// instead of going out to the fabric twice.  grid = 8 * ceil(tiles / 8) workgroups; the ones past the end return.  (The mapping of workgroups to XCDs is not a
+// contract: a different one costs the locality, nothing else.)
+#ifndef WN_LAYER_XCD_RANGES
+#define WN_LAYER_XCD_RANGES 1
+#endif
+static __device__ __forceinline__ long long wn_layer_tile(long long M) {
+#if WN_LAYER_XCD_RANGES
+    const unsigned tiles = (unsigned)((M + 127) / 128), per = (tiles + 7) / 8;
+    const unsigned t = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+    return (blockIdx.x >> 3) < per && t < tiles ? (long long)t : -1;
+#else
+    return (long long)blockIdx.x < (M + 127) / 128 ? (long long)blockIdx.x : -1;
+#endif
+}
+static inline unsigned wn_layer_grid(long long M) {
+    const unsigned tiles = (unsigned)((M + 127) / 128);
+#if WN_LAYER_XCD_RANGES
+    return 8u * ((tiles + 7) / 8);
+#else
+    return tiles;
+#endif
+}
+
 struct WnLayerArgs {
     const unsigned short* bn;  // Wres as bf16 [R][D] row-major (K = D contiguous)
     const float* bias;         // [R] or NULL
@@ -632,7 +658,9 @@ __global__ __launch_bounds__(512, 4) void wn_fwd_layer_bf16(WnGemmArgsBf16 ga, W
     unsigned short* z_s = smem_h + ZOFF;
     unsigned short (*b2_s)[N2 * LD] = reinterpret_cast<unsigned short (*)[N2 * LD]>(smem_h);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wr = wv & 3, wc = wv >> 2;
-    const long long m0 = (long long)blockIdx.x * TM;
+    const long long tile = wn_layer_tile(g.M);
+    if (tile < 0) return;   // (block-uniform)
+    const long long m0 = tile * TM;
     wn_f16v acc[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -775,7 +803,9 @@ __global__ __launch_bounds__(512, 4) void wn_bwd_layer_bf16(WnGemmArgsBf16 ga, W
     unsigned short* x_s = smem_h + ZOFF;
     unsigned short (*b2_s)[N2 * LD] = reinterpret_cast<unsigned short (*)[N2 * LD]>(smem_h);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wr = wv & 3, wc = wv >> 2;
-    const long long m0 = (long long)blockIdx.x * TM;
+    const long long tile = wn_layer_tile(g.M);
+    if (tile < 0) return;   // (block-uniform)
+    const long long m0 = tile * TM;
     const int bcol = tid >> 2, bpart = tid & 3;   // B loaders of both products: 128 columns x 4 pieces of 8 bf16 per chunk
     wn_f16v acc[2];
 #pragma unroll

@@ -80,7 +80,7 @@ static bool wn_launch_layer(hipStream_t st, const WnGemmArgs& a, const unsigned 
     b.g = a; b.bn = bn_fg; b.bn1 = nullptr; b.ldb = 0;
     WnLayerArgs la;
     la.bn = bn_res; la.bias = r.bias; la.cin = r.cin; la.c = r.c; la.c_h = r.c_h; la.N = r.N;
-    const dim3 grid((unsigned)((a.M + 127) / 128));
+    const dim3 grid(wn_layer_grid(a.M));
     hipLaunchKernelGGL(wn_fwd_layer_bf16, grid, dim3(512), 0, st, b, la);
     return true;
 }
@@ -98,7 +98,7 @@ static bool wn_launch_bwd_layer(hipStream_t st, const WnGemmArgs& a, const unsig
     WnGemmArgsBf16 x, y;
     x.g = a; x.bn = bn; x.bn1 = bn1; x.ldb = ldb;
     y.g = b; y.bn = bn_res; y.bn1 = nullptr; y.ldb = 0;
-    hipLaunchKernelGGL(wn_bwd_layer_bf16, dim3((unsigned)((a.M + 127) / 128)), dim3(512), 0, st, x, y);
+    hipLaunchKernelGGL(wn_bwd_layer_bf16, dim3(wn_layer_grid(a.M)), dim3(512), 0, st, x, y);
     return true;
 }
 
