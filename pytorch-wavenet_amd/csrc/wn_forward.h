@@ -596,7 +596,12 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? WN_GEMM_BF16_MINB : 4) voi
             __syncthreads();
         }
     }
-    wn_gemm_epilogue<EPI, 4, true>(g, acc, m0 + 32 * wr, n0 + 128 * wc, lane, reinterpret_cast<float*>(smem_h) + wv * WN_EPI_TILE_FLOATS);   // (after the loop's last barrier)
+    // (the epilogue's lane roles from an OPAQUE copy of the thread index: otherwise the compiler forms its row and column offsets in front of the K loop and
+    //  carries them through it -- at the 128 registers of the four-workgroups-per-CU form that was 2-5 spilled registers in the loop)
+    int te = threadIdx.x;
+    asm volatile("" : "+v"(te));
+    const int lane_e = te & 63, wv_e = te >> 6, wr_e = wv_e & 3, wc_e = wv_e >> 2;
+    wn_gemm_epilogue<EPI, 4, true>(g, acc, m0 + 32 * wr_e, n0 + 128 * wc_e, lane_e, reinterpret_cast<float*>(smem_h) + wv_e * WN_EPI_TILE_FLOATS);   // (after the loop's last barrier)
 }
 
 // ---- One layer of the forward in ONE kernel (bf16 operands; the shape whose filter/gate product is ONE 256-column tile: D = 128, and
