@@ -227,7 +227,9 @@ int wn_forward(wn_handle* h, const int32_t* indices, int64_t N, int64_t L, int64
  * gradients; the one-hot product of start_conv stays fp32):
  * 0 = fp32 matrix-core GEMMs (default: equals the reference's fp32 graph to rounding), 1 = bf16 operands with fp32
  * accumulation (residual stream, skip sum and all accumulators stay fp32; the training step keeps the activations that only
- * ever feed bf16 operands -- z, tanh, sigmoid, [dF|dG] -- in bf16, which is the same rounding taken once at the store;
+ * ever feed bf16 operands -- z, tanh, sigmoid, [dF|dG] -- in bf16, which is the same rounding taken once at the store, and
+ * since round 5 the skip convs' share of dz (one product per block of layers, added to the residual conv's share by the gate
+ * derivative) as well: one more rounding point, carried by the step's oracle, oracle/bf16_step.py;
  * logits differ from the fp32 path at the 1e-2 level of their scale, gradients by a few per cent in norm -- mostly sign
  * flips of ReLU masks).  WN_E_UNSUPPORTED unless R, D, S and E are multiples of 64. */
 int wn_set_forward_precision(wn_handle* h, int32_t bf16);
