@@ -50,7 +50,9 @@
 extern "C" {
 #endif
 
-#define WN_ABI_VERSION 4  /* 4: WN_E_BUSY (start-up residency barrier with its own bound, WN_RESIDENT_TIMEOUT_MS), wn_info.forward_native, wn_adam_step;
+#define WN_ABI_VERSION 5  /* 5: wn_train_pack / wn_train_unpack_grads (wn_train_tensors), wn_train_set_deterministic, wn_adam_args.flags (several parameter groups
+                                clipped together); a job of several rounds reports WN_E_BUSY only when NO round started (mixed outcomes: WN_E_STATE until wn_reset);
+                             4: WN_E_BUSY (start-up residency barrier with its own bound, WN_RESIDENT_TIMEOUT_MS), wn_info.forward_native, wn_adam_step;
                              3: per-device admission of persistent jobs (wn_info: gate_*), kernel variant 4 (layers_per_workgroup);
                              2: wn_train_loss; wn_info reports the form of the chain (streams_per_item, head_replicas, n_samplers) */
 
@@ -266,6 +268,42 @@ int wn_train_get_layout(wn_handle* h, wn_train_layout* out);
 /* Copies the parameters last given to wn_load_weights into `params` (DEVICE, layout.total floats). */
 int wn_train_export_params(wn_handle* h, float* params, void* hip_stream);
 
+/* The parameters' own tensors -- the reference's Conv1d layouts (out, in, k), one allocation per nn.Parameter (wavenet_model.py:59-119) -- as the
+ * native training step takes and returns them (ABI 5).  filter_w .. skip_b: HOST arrays of n_layers DEVICE pointers (layer order); the others single
+ * DEVICE pointers; the bias members are NULL for a model without stack biases. */
+typedef struct wn_train_tensors {
+    int32_t n_layers;          /* layers * blocks */
+    int32_t reserved;          /* 0 */
+    void* const* filter_w;     /* [n_layers] (D, R, 2) */
+    void* const* gate_w;       /* [n_layers] (D, R, 2) */
+    void* const* res_w;        /* [n_layers] (R, D, 1) */
+    void* const* skip_w;       /* [n_layers] (S, D, 1) */
+    void* const* filter_b;     /* [n_layers] (D) or NULL */
+    void* const* gate_b;
+    void* const* res_b;        /* (R) */
+    void* const* skip_b;       /* (S) */
+    void* start_w;             /* (R, classes, 1) */
+    void* start_b;             /* (R) or NULL */
+    void* end1_w;              /* (E, S, 1) */
+    void* end1_b;
+    void* end2_w;              /* (classes, E, 1) */
+    void* end2_b;
+} wn_train_tensors;
+
+/* params (DEVICE, layout.total floats, overwritten) = the flat GEMM layout of the tensors: what a training step does with its nn.Parameters before
+ * wn_train_forward, in a handful of launches (the tensors' addresses travel in the kernel arguments) instead of ~150 torch view / stack / copy
+ * launches.  Every pointer the model's shape calls for must be set. */
+int wn_train_pack(wn_handle* h, const wn_train_tensors* tensors, float* params, void* hip_stream);
+
+/* The inverse, for gradients: grads (DEVICE, layout.total floats: what wn_train_backward wrote) -> one gradient tensor per parameter, in the
+ * parameter's own layout.  A NULL pointer skips that tensor (the last layer's residual conv never reaches the loss: its .grad stays None upstream). */
+int wn_train_unpack_grads(wn_handle* h, const float* grads, const wn_train_tensors* tensors, void* hip_stream);
+
+/* on != 0: weight and bias gradients are bit-reproducible from run to run -- the row splits of every weight-gradient product store their partial
+ * tiles in a workspace and a second kernel adds them in order, instead of fp32 atomics (default: off, or WN_DETERMINISTIC=1 in the environment at
+ * wn_create; costs a write and a read of at most 67 MB of partial tiles per product).  The forward and the loss are deterministic either way. */
+int wn_train_set_deterministic(wn_handle* h, int32_t on);
+
 /* model(x) for training: like wn_forward (fp32) but reads the parameters from `params` and keeps every layer's input, gate
  * activations and the head's intermediates in a workspace owned by the handle for the following wn_train_backward. */
 int wn_train_forward(wn_handle* h, const float* params, const int32_t* indices, int64_t N, int64_t L, int64_t output_length,
@@ -273,7 +311,7 @@ int wn_train_forward(wn_handle* h, const float* params, const int32_t* indices, 
 
 /* loss.backward(): `dlogits` [N*output_length][classes] (DEVICE) is dLoss/dlogits for the logits of the last
  * wn_train_forward on this handle; writes dLoss/dparams into `grads` (DEVICE, layout.total floats, overwritten).
- * Sums over rows are accumulated with fp32 atomics: results are reproducible to rounding, not bit for bit. */
+ * Sums over rows are accumulated with fp32 atomics: results are reproducible to rounding, not bit for bit -- unless wn_train_set_deterministic. */
 int wn_train_backward(wn_handle* h, const float* params, const float* dlogits, float* grads, void* hip_stream);
 
 /* loss = F.cross_entropy(logits, targets) (mean over the M rows) and dLoss/dlogits in ONE pass over the logits -- the loss of the
@@ -304,7 +342,14 @@ typedef struct wn_adam_args {
     float* total_norm;
     void* scratch;
     void* hip_stream;
+    int64_t flags;         /* 0, or WN_ADAM_* below (ABI 5) */
 } wn_adam_args;
+/* Several parameter groups clipped TOGETHER (clip_grad_norm_ over model.parameters() in front of an optimiser with more than one group): add every
+ * group's sum of squares into `scratch` first -- NORM_ONLY: no update is made; NORM_KEEP: `scratch` is not zeroed first (second group on) --, then step
+ * every group with NORM_GIVEN: `scratch` already holds the sum of squares of all gradients, no norm pass.  One group: flags = 0 does both passes. */
+#define WN_ADAM_NORM_ONLY  1
+#define WN_ADAM_NORM_KEEP  2
+#define WN_ADAM_NORM_GIVEN 4
 int wn_adam_step(const wn_adam_args* args);
 
 /* Diagnostics: record wall-clock stamps (100 MHz ticks) for the first n_items (evaluation, stream) steps of every

@@ -961,7 +961,9 @@ struct WnGemmTnArgs {
     int c_trans, a_bf16;   // c_trans: C is stored transposed, element (ka, nb) at c[nb * ldc + ka] (operands swapped by the caller so that the
                            // bf16-stored one is B);  a_bf16: A is stored as bf16 (excludes relu_a, a_idx)
     int a_skip_lo;         // row window of view `a` (not a1): it reads as ZERO on the first a_skip_lo rows of every batch entry (their addresses are
-};                         // never formed into loads) -- the tap x(t - d) where the reference's left zero padding stands in for it
+                           // never formed into loads) -- the tap x(t - d) where the reference's left zero padding stands in for it
+    float* part;           // deterministic mode (wn_train_set_deterministic): != NULL -- every row split STORES its partial tile at part[split][ka][nb]
+};                         // (Nb columns per row) instead of adding it to C with atomics; wn_tn_reduce then adds the splits in their order
 
 __global__ __launch_bounds__(256, WN_GEMM_MINB) void wn_bwd_gemm_tn(WnGemmTnArgs g) {
     constexpr int T = 128, KC = WN_GEMM_KC, NQ = KC / 8, LT = 256 / KC;  // NQ float4 per thread per operand, LT threads per row
@@ -1047,9 +1049,26 @@ __global__ __launch_bounds__(256, WN_GEMM_MINB) void wn_bwd_gemm_tn(WnGemmTnArgs
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int nb = nb0 + 32 * j + col;
-            if (nb < g.Nb) unsafeAtomicAdd(g.c + (size_t)ka * g.ldc + nb, acc[j][i]);
+            if (nb >= g.Nb) continue;
+            if (g.part) g.part[((size_t)split * g.Ka + ka) * g.Nb + nb] = acc[j][i];
+            else unsafeAtomicAdd(g.c + (size_t)ka * g.ldc + nb, acc[j][i]);
         }
     }
+}
+
+// Deterministic mode: C[ka][nb] (or its transpose) = the row splits' partial tiles added in the order of the splits -- one thread per four columns.
+// Also the second half of the bias gradients' column sums (Ka = 1, one "split" per 512-row block).
+__global__ __launch_bounds__(256) void wn_tn_reduce(const float* part, int n_splits, int Ka, int Nb, float* c, int ldc, int c_trans) {
+    const long long e4 = (long long)blockIdx.x * 256 + threadIdx.x, per = (long long)Ka * Nb;
+    if (e4 * 4 >= per) return;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int sp = 0; sp < n_splits; ++sp) {
+        const float4 v = *reinterpret_cast<const float4*>(part + (size_t)sp * per + e4 * 4);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    const int ka = (int)(e4 * 4 / Nb), nb = (int)(e4 * 4 % Nb);   // (Nb is a multiple of 4: the four columns share a row)
+    if (c_trans) { c[(size_t)nb * ldc + ka] = s.x; c[(size_t)(nb + 1) * ldc + ka] = s.y; c[(size_t)(nb + 2) * ldc + ka] = s.z; c[(size_t)(nb + 3) * ldc + ka] = s.w; }
+    else *reinterpret_cast<float4*>(c + (size_t)ka * ldc + nb) = s;
 }
 
 // The same weight-gradient product with bf16 MATRIX OPERANDS (fp32 accumulation, fp32 atomics into the gradient): the rows of
@@ -1229,7 +1248,9 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? WN_TN_BF16_MINB : 4) void 
 #if WN_ABL_TN_PLAIN_STORE   // timing ablation (results wrong): what the fp32 atomics of the row splits cost
             if (nb < g.Nb) g.c[g.c_trans ? (size_t)nb * g.ldc + ka : (size_t)ka * g.ldc + nb] = acc[j][i];
 #else
-            if (nb < g.Nb) unsafeAtomicAdd(g.c + (g.c_trans ? (size_t)nb * g.ldc + ka : (size_t)ka * g.ldc + nb), acc[j][i]);
+            if (nb >= g.Nb) continue;
+            if (g.part) g.part[((size_t)split * g.Ka + ka) * g.Nb + nb] = acc[j][i];
+            else unsafeAtomicAdd(g.c + (g.c_trans ? (size_t)nb * g.ldc + ka : (size_t)ka * g.ldc + nb), acc[j][i]);
 #endif
         }
     }
@@ -1329,8 +1350,9 @@ __global__ __launch_bounds__(1024) void wn_xent_reduce(const float* row_loss, lo
 
 // out[n] += sum over rows of x[row][n]   (bias gradients); x rows addressed through a row map
 // X16: x is stored as bf16 (base points at unsigned short, strides in bf16 elements)
+// part != NULL (deterministic mode): block bx stores its sums at part[bx][n]; wn_tn_reduce adds the blocks in order.
 template <bool X16>
-__global__ void wn_bwd_colsum(WnRowMap x, long long M, int rows_per_batch, int N, float* out) {
+__global__ void wn_bwd_colsum(WnRowMap x, long long M, int rows_per_batch, int N, float* out, float* part = nullptr) {
     const int n = blockIdx.y * blockDim.x + threadIdx.x;
     const long long m0 = (long long)blockIdx.x * 512;
     if (n >= N) return;
@@ -1343,7 +1365,8 @@ __global__ void wn_bwd_colsum(WnRowMap x, long long M, int rows_per_batch, int N
             s += wn_row(x, m, rows_per_batch)[n];
         }
     }
-    unsafeAtomicAdd(out + n, s);
+    if (part) part[(size_t)blockIdx.x * N + n] = s;
+    else unsafeAtomicAdd(out + n, s);
 }
 
 
@@ -1359,6 +1382,41 @@ __global__ void wn_transpose_batched(const float* in, long long in_batch_stride,
     __syncthreads();
     for (int i = ty; i < 32; i += 8)
         if (c0 + i < cols && r0 + tx < rows) ob[(long long)(c0 + i) * rows + r0 + tx] = tile[tx][i];
+}
+
+// ---- wn_train_pack / wn_train_unpack_grads: the parameters' own tensors (the reference's Conv1d layouts, one allocation each) <-> the flat GEMM layout
+// of wn_train_layout, and back for the gradients.  Every piece is a strided transpose
+//     flat[off + j * ld + cmap(i)] <-> ref[i * rs + j * cs]      i < rows, j < cols,   cmap(i) = (i / 32) * cm_blk + (i % 32) + cm_off
+// (a filter conv's tap: rows = D output channels, cols = R inputs, rs = 2R, cs = 2, ld = 2D, cmap = the [F(32) | G(32)] column packing; a 1x1 conv: a
+// plain transpose; a bias: one column).  Up to WN_RELAYOUT_PIECES pieces travel in the kernel arguments of one launch (the tensors' addresses are the
+// caller's: nothing to keep in step on the device), 32 x 32 tiles through LDS so that both sides are accessed along their contiguous index.
+#define WN_RELAYOUT_PIECES 72
+struct WnRelayoutPiece { float* ref; long long off; int rows, cols, rs, cs, ld, cm_blk, cm_off, tile0; };   // tile0: first workgroup of the piece
+struct WnRelayoutBatch { WnRelayoutPiece p[WN_RELAYOUT_PIECES]; int n, tiles; };
+template <bool UNPACK>
+__global__ __launch_bounds__(256) void wn_relayout(WnRelayoutBatch b, float* flat) {
+    __shared__ float tile[32][33];
+    int lo = 0, hi = b.n - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (b.p[mid].tile0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1; }
+    const WnRelayoutPiece& q = b.p[lo];
+    const int t = (int)blockIdx.x - q.tile0, tj = (q.cols + 31) / 32;
+    const int i0 = (t / tj) * 32, j0 = (t % tj) * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    float* fl = flat + q.off;
+    if (!UNPACK) {
+        for (int k = ty; k < 32; k += 8)        // ref side: j along the lanes
+            if (i0 + k < q.rows && j0 + tx < q.cols) tile[k][tx] = q.ref[(long long)(i0 + k) * q.rs + (long long)(j0 + tx) * q.cs];
+        __syncthreads();
+        const int i = i0 + tx;
+        for (int k = ty; k < 32; k += 8)        // flat side: i along the lanes
+            if (i < q.rows && j0 + k < q.cols) fl[(long long)(j0 + k) * q.ld + (i / 32) * q.cm_blk + (i % 32) + q.cm_off] = tile[tx][k];
+    } else {
+        const int i = i0 + tx;
+        for (int k = ty; k < 32; k += 8)
+            if (i < q.rows && j0 + k < q.cols) tile[tx][k] = fl[(long long)(j0 + k) * q.ld + (i / 32) * q.cm_blk + (i % 32) + q.cm_off];
+        __syncthreads();
+        for (int k = ty; k < 32; k += 8)
+            if (i0 + k < q.rows && j0 + tx < q.cols) q.ref[(long long)(i0 + k) * q.rs + (long long)(j0 + tx) * q.cs] = tile[k][tx];
+    }
 }
 
 // Batched priming: copies the newest `count` time steps of a layer's input x (time-major rows of R floats; `x` points at

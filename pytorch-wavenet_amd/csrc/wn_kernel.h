@@ -83,15 +83,29 @@ WN_DEV void wn_resident_barrier(WnCtx& cx) {
     if (threadIdx.x != 0) return;   // (the role's first workgroup barrier holds the other threads back)
     uint32_t* st = cx.p->status;
     const uint32_t want = (uint32_t)cx.p->n_wg;
+    // Arrival and give-up exclude each other: a workgroup that runs out of patience POISONS the counter (top bit) with a compare-and-swap on the count
+    // it last saw -- if somebody arrived in between the swap fails and it looks again --, and whoever arrives (or looks) after that finds the bit and
+    // leaves without touching a queue.  So "the job never started" (WN_E_BUSY: queues unchanged, the call can be repeated) holds for EVERY workgroup,
+    // also for the ones the dispatcher only placed after the verdict (round 5 let those pass with seen >= want).
     uint32_t seen = __hip_atomic_fetch_add(st + 5, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+    if (seen & 0x80000000u) { cx.fail = 1; return; }
     const long long t0 = (long long)wall_clock64();
     unsigned spins = 0;
     while (seen < want) {
         __builtin_amdgcn_s_sleep(16);
         seen = __hip_atomic_load(st + 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (seen & 0x80000000u) { cx.fail = 1; return; }
         if ((++spins & 15u) == 0u) {
             if (__hip_atomic_load(st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { cx.fail = 1; return; }   // somebody else gave up
-            if ((long long)wall_clock64() - t0 > cx.r->resident_ticks) { wn_give_up(cx, WN_W_RESIDENT, (long long)seen, 0); return; }
+            if ((long long)wall_clock64() - t0 > cx.r->resident_ticks) {
+                uint32_t expect = seen;
+                if (__hip_atomic_compare_exchange_strong(st + 5, &expect, seen | 0x80000000u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                    wn_give_up(cx, WN_W_RESIDENT, (long long)seen, 0);
+                    return;
+                }
+                seen = expect;   // somebody arrived (go on waiting, or everybody is here) or somebody else closed the door
+                if (seen & 0x80000000u) { cx.fail = 1; return; }
+            }
         }
     }
     cx.t_start = (long long)wall_clock64();

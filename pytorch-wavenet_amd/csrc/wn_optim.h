@@ -9,7 +9,7 @@
 // The arithmetic is torch.optim.Adam's single-tensor formulas, operation for operation (torch/optim/adam.py, _single_tensor_adam):
 //     g      = grad * clip_coef                     clip_coef = min(1, max_norm / (total_norm + 1e-6))   (clip_grad_norm_)
 //     g     += weight_decay * p                      (weight_decay != 0)
-//     m      = m + (1 - beta1) * (g - m)             _foreach_lerp_(exp_avgs, grads, 1 - beta1)
+//     m      = m + (1 - beta1) * (g - m)             _foreach_lerp_(exp_avgs, grads, 1 - beta1)   [beta1 <= 0.5: g - (g - m) * beta1, ATen's other lerp branch]
 //     v      = v * beta2;  v = v + ((1 - beta2) * g) * g                     _foreach_mul_, _foreach_addcmul_
 //     denom  = sqrt(v) / sqrt(1 - beta2^t) + eps
 //     p      = p + (-(lr / (1 - beta1^t))) * (m / denom)                                           _foreach_addcdiv_
@@ -66,6 +66,7 @@ __global__ __launch_bounds__(256) void wn_opt_sumsq(WnOptBatch b, double* acc) {
 
 struct WnAdamScalars {
     float neg_step, sqrt_bc2, one_minus_b1, b2, one_minus_b2, eps, weight_decay, max_norm;   // neg_step = -(lr / (1 - beta1^t)); max_norm <= 0: no clipping
+    int lerp_hi;   // the lerp weight 1 - beta1 is >= 0.5 (beta1 <= 0.5): torch's lerp then evaluates b - (b - a) * (1 - w)
 };
 
 __global__ __launch_bounds__(256) void wn_opt_adam(WnOptBatch b, WnAdamScalars k, const double* sumsq, float* norm_out) {
@@ -75,7 +76,7 @@ __global__ __launch_bounds__(256) void wn_opt_adam(WnOptBatch b, WnAdamScalars k
     if (k.max_norm > 0.f) {
         const float total = (float)sqrt(*sumsq);
         const float c = k.max_norm / (total + 1e-6f);
-        coef = c < 1.f ? c : 1.f;
+        coef = !(c >= 1.f) ? c : 1.f;   // torch.clamp(c, max=1.0): a NaN norm stays NaN and poisons every gradient, as clip_grad_norm_ does
         if (norm_out && blockIdx.x == 0 && threadIdx.x == 0) *norm_out = total;
     }
     float* p = b.p[t]; float* g = b.g[t]; float* m = b.m[t]; float* v = b.v[t];
@@ -85,7 +86,8 @@ __global__ __launch_bounds__(256) void wn_opt_adam(WnOptBatch b, WnAdamScalars k
         gi = __fmul_rn(gi, coef);                                        // _foreach_mul_(grads, clip_coef)
         go = gi;
         if (k.weight_decay != 0.f) gi = __fmaf_rn(k.weight_decay, pi, gi);  // _foreach_add(grads, params, alpha=weight_decay)
-        mi = __fmaf_rn(k.one_minus_b1, __fsub_rn(gi, mi), mi);          // _foreach_lerp_(exp_avgs, grads, 1 - beta1)
+        // _foreach_lerp_(exp_avgs, grads, w = 1 - beta1): ATen's lerp is a + w * (b - a) for w < 0.5 and b - (b - a) * (1 - w) from 0.5 up
+        mi = k.lerp_hi ? __fmaf_rn(-__fsub_rn(gi, mi), __fsub_rn(1.f, k.one_minus_b1), gi) : __fmaf_rn(k.one_minus_b1, __fsub_rn(gi, mi), mi);
         vi = __fmul_rn(vi, k.b2);                                        // _foreach_mul_(exp_avg_sqs, beta2)
         vi = __fmaf_rn(__fmul_rn(k.one_minus_b2, gi), gi, vi);           // _foreach_addcmul_(exp_avg_sqs, grads, grads, 1 - beta2)
         const float denom = __fadd_rn(__fdiv_rn(__fsqrt_rn(vi), k.sqrt_bc2), k.eps);   // sqrt, div by sqrt(1 - beta2^t), add eps

@@ -469,6 +469,7 @@ struct WnTrainLay {
     int G, nblk;  // layers per skip block, blocks
     bool bf16;  // the saved forward ran with bf16 operands: so does its backward
 };
+struct WnDetWs { float* buf = nullptr; size_t floats = 0; };
 struct wn_handle {
     wn_config cfg;
     WnPlan plan;
@@ -523,6 +524,10 @@ struct wn_handle {
     // wn_train_backward: the weight-gradient products run on a second stream next to the activation-gradient chain (wn_train.inl)
     hipStream_t side_stream = nullptr;
     std::vector<hipEvent_t> events;
+    // deterministic weight / bias gradients (wn_train_set_deterministic; default from WN_DETERMINISTIC=1 at wn_create): partial tiles of the row splits
+    // in a workspace per stream + an ordered reduction instead of fp32 atomics (wn_train.inl)
+    bool deterministic = false;
+    WnDetWs det_ws[2];
     char busid[32] = "";
     std::shared_ptr<WnGateTicket> gate;   // the booking of the job in flight (released by the host function behind the kernel, or in wn_wait)
     int gate_shared = -1, gate_waited_ms = 0;
@@ -566,6 +571,7 @@ extern "C" void wn_destroy(wn_handle* h) {
     rt_free(h->d_wg_map); rt_free(h->d_ring_off); rt_free(h->d_gran); rt_free(h->d_status); rt_free(h->d_prof); rt_free(h->d_ws);
     rt_free(h->d_tws);
     rt_free(h->d_xent);
+    rt_free(h->det_ws[0].buf); rt_free(h->det_ws[1].buf);
     delete h;
 }
 
@@ -711,6 +717,7 @@ static int wn_create_impl(const wn_config* cfg, wn_handle** out) {
     memset(&h->plan, 0, sizeof(h->plan));
     h->cfg = *cfg;
     h->v3_mode = 0; h->rounds = false;
+    { const char* de = getenv("WN_DETERMINISTIC"); h->deterministic = de && de[0] == '1'; }
     h->have_weights = false; h->pending = false; h->last_stream = nullptr; h->t_base = 0;
     h->n_cu = n_cu; h->wall_khz = wall_khz;
     memcpy(h->busid, busid, sizeof(busid));
@@ -1148,9 +1155,10 @@ extern "C" int wn_generate(wn_handle* h, const wn_generate_args* a) {
         if (hipExtStreamGetCUMask((hipStream_t)a->hip_stream, 32, mask) == hipSuccess) {
             int cus = 0;
             for (int i = 0; i < 32; ++i) cus += __builtin_popcount(mask[i]);
-            if (cus > 0 && cus < h->plan.n_wg)
-                return wn_fail(WN_E_UNSUPPORTED, "wn_generate: the stream's CU mask leaves %d compute units, the job keeps %d workgroups resident (one per CU); "
-                               "nothing was launched", cus, h->plan.n_wg);
+            const int per_cu = h->wg_per_cu > 0 ? h->wg_per_cu : 1;
+            if (cus > 0 && (long long)cus * per_cu < h->plan.n_wg)
+                return wn_fail(WN_E_UNSUPPORTED, "wn_generate: the stream's CU mask leaves %d compute units (%d workgroup%s of this kernel each), the job keeps %d "
+                               "workgroups resident; nothing was launched", cus, per_cu, per_cu == 1 ? "" : "s", h->plan.n_wg);
         } else {
             (void)hipGetLastError();
         }
@@ -1212,13 +1220,28 @@ extern "C" int wn_wait(wn_handle* h) {
     if (!h->pending) return WN_OK;
     h->pending = false;
     if (!h->chains.empty()) {
-        int first_rc = WN_OK;
+        // Every round is a kernel of its own with its own residency barrier: "nothing ran, repeat the call" (WN_E_BUSY) is only true of the JOB when
+        // it is true of EVERY round.  A round that gave up while another ran to completion leaves the rounds' queue times apart -- a repeated call
+        // would advance the completed rounds twice -- so a mixed outcome closes the handle until wn_reset, like a launch that failed half way.
+        int first_rc = WN_OK, n_busy = 0, n_ok = 0;
         char msg[sizeof(g_err)] = "";
         for (wn_handle* c : h->chains) {
             const int rc = wn_wait(c);
-            if (rc && !first_rc) { first_rc = rc; memcpy(msg, g_err, sizeof(msg)); }
+            if (rc == WN_E_BUSY) ++n_busy;
+            else if (rc == WN_OK) ++n_ok;
+            if (rc && (!first_rc || (first_rc == WN_E_BUSY && rc != WN_E_BUSY))) { first_rc = rc; memcpy(msg, g_err, sizeof(msg)); }   // (a hard error outranks BUSY)
         }
-        if (first_rc) memcpy(g_err, msg, sizeof(msg));
+        if (!first_rc) return WN_OK;
+        if (n_busy == (int)h->chains.size()) {   // no round started: every member rolled its own queue time back, the parent follows
+            h->t_base = h->chains[0]->t_base;
+            memcpy(g_err, msg, sizeof(msg));
+            return WN_E_BUSY;
+        }
+        h->broken = true;
+        if (first_rc == WN_E_BUSY)
+            return wn_fail(WN_E_STATE, "wn_generate: %d of the job's %d rounds never became resident (WN_RESIDENT_TIMEOUT_MS) while %d ran: the rounds' queues are "
+                           "out of step -- call wn_reset", n_busy, (int)h->chains.size(), n_ok);
+        memcpy(g_err, msg, sizeof(msg));
         return first_rc;
     }
     int rc = rt_sync(h->last_stream);
@@ -1595,15 +1618,25 @@ extern "C" int wn_adam_step(const wn_adam_args* a) {
         return wn_fail(WN_E_BADARG, "wn_adam_step: NULL argument");
     if (a->step < 1 || !(a->beta1 >= 0. && a->beta1 < 1.) || !(a->beta2 >= 0. && a->beta2 < 1.) || !(a->eps >= 0.))
         return wn_fail(WN_E_BADARG, "wn_adam_step: step must be >= 1, betas in [0, 1), eps >= 0");
+    if (a->flags & ~(int64_t)(WN_ADAM_NORM_ONLY | WN_ADAM_NORM_KEEP | WN_ADAM_NORM_GIVEN)) return wn_fail(WN_E_BADARG, "wn_adam_step: unknown flags");
+    if ((a->flags & WN_ADAM_NORM_ONLY) && (a->flags & WN_ADAM_NORM_GIVEN)) return wn_fail(WN_E_BADARG, "wn_adam_step: NORM_ONLY and NORM_GIVEN exclude each other");
+    // (no handle: the caller's current device is left as it was -- torch's current device is process state the parameters' device must not change)
+    struct DeviceGuard {
+        int prev = -1;
+        ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+    } guard;
+    { int cur = -1; if (hipGetDevice(&cur) == hipSuccess && cur != a->device_id) guard.prev = cur; else (void)hipGetLastError(); }
     { int rc = rt_hip(hipSetDevice(a->device_id), "hipSetDevice"); if (rc) return rc; }
     hipStream_t st = (hipStream_t)a->hip_stream;
-    const bool clip = a->max_grad_norm > 0.;
+    const bool norm_only = (a->flags & WN_ADAM_NORM_ONLY) != 0;
+    const bool clip = a->max_grad_norm > 0. || norm_only;
     double* acc = static_cast<double*>(a->scratch);
     WnAdamScalars k;   // every fp32 scalar is the double torch forms in Python, rounded once (torch/optim/adam.py: _multi_tensor_adam)
     const double bc1 = 1.0 - pow(a->beta1, (double)a->step), bc2 = 1.0 - pow(a->beta2, (double)a->step);
     k.neg_step = (float)(-(a->lr / bc1)); k.sqrt_bc2 = (float)sqrt(bc2);
     k.one_minus_b1 = (float)(1.0 - a->beta1); k.b2 = (float)a->beta2; k.one_minus_b2 = (float)(1.0 - a->beta2); k.eps = (float)a->eps;
-    k.weight_decay = (float)a->weight_decay; k.max_norm = clip ? (float)a->max_grad_norm : 0.f;
+    k.weight_decay = (float)a->weight_decay; k.max_norm = (clip && !norm_only) ? (float)a->max_grad_norm : 0.f;
+    k.lerp_hi = k.one_minus_b1 >= 0.5f ? 1 : 0;
     // batches of up to WN_OPT_TENSORS tensors (skipping the ones without a gradient: torch's optimisers do)
     std::vector<WnOptBatch> batches;
     WnOptBatch b;
@@ -1621,11 +1654,17 @@ extern "C" int wn_adam_step(const wn_adam_args* a) {
         b.n++;
     }
     flush();
-    if (clip) {
-        int rc = rt_hip(hipMemsetAsync(acc, 0, sizeof(double), st), "hipMemsetAsync(norm)");
-        if (rc) return rc;
+    // The norm of a clipped step is the norm of ALL gradients that are clipped together (clip_grad_norm_(model.parameters())): a caller with several
+    // parameter groups first adds every group's sum of squares into `scratch` (NORM_ONLY; NORM_KEEP from the second group on), then steps each group on
+    // the total (NORM_GIVEN).  One group: one call, no flags.
+    if (clip && !(a->flags & WN_ADAM_NORM_GIVEN)) {
+        if (!(a->flags & WN_ADAM_NORM_KEEP)) {
+            int rc = rt_hip(hipMemsetAsync(acc, 0, sizeof(double), st), "hipMemsetAsync(norm)");
+            if (rc) return rc;
+        }
         for (const WnOptBatch& bb : batches) hipLaunchKernelGGL(wn_opt_sumsq, dim3((unsigned)bb.chunk0[bb.n]), dim3(256), 0, st, bb, acc);
     }
+    if (norm_only) return rt_hip(hipGetLastError(), "wn_adam_step launches");
     for (const WnOptBatch& bb : batches)
         hipLaunchKernelGGL(wn_opt_adam, dim3((unsigned)bb.chunk0[bb.n]), dim3(256), 0, st, bb, k, clip ? acc : nullptr, clip ? a->total_norm : nullptr);
     return rt_hip(hipGetLastError(), "wn_adam_step launches");

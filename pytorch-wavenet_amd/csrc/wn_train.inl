@@ -109,6 +109,14 @@ extern "C" int wn_train_get_layout(wn_handle* h, wn_train_layout* out) {
     return WN_OK;
 }
 
+extern "C" int wn_train_set_deterministic(wn_handle* h, int32_t on) {
+    g_err[0] = 0;
+    if (!h) return wn_fail(WN_E_BADARG, "wn_train_set_deterministic: NULL handle");
+    if (!h->chains.empty()) return wn_train_set_deterministic(h->chains[0], on);
+    h->deterministic = on != 0;
+    return WN_OK;
+}
+
 extern "C" int wn_train_export_params(wn_handle* h, float* params, void* hip_stream) {
     g_err[0] = 0;
     if (!h || !params) return wn_fail(WN_E_BADARG, "wn_train_export_params: NULL argument");
@@ -120,6 +128,82 @@ extern "C" int wn_train_export_params(wn_handle* h, float* params, void* hip_str
     return rt_hip(hipMemcpyAsync(params, h->d_fw, h->fw_floats * 4, hipMemcpyDeviceToDevice, (hipStream_t)hip_stream), "hipMemcpyAsync(params)");
 }
 
+// wn_train_pack / wn_train_unpack_grads: see wn_relayout (wn_forward.h) for the piece algebra.  A NULL tensor pointer is skipped (unpack: a gradient the
+// caller does not want, e.g. the last layer's residual conv, which never reaches the loss).
+static int wn_relayout_run(wn_handle* h, const wn_train_tensors* t, float* flat, bool unpack, hipStream_t st, const char* who) {
+    const WnPlan& pl = h->plan;
+    const int R = pl.R, D = pl.D, S = pl.S, E = pl.E, C = pl.C, NL = pl.NL;
+    if (t->n_layers != NL) return wn_fail(WN_E_BADARG, "%s: n_layers = %d, the model has %d", who, t->n_layers, NL);
+    if (!t->filter_w || !t->gate_w || !t->res_w || !t->skip_w) return wn_fail(WN_E_BADARG, "%s: a per-layer pointer array is NULL", who);
+    if (pl.has_bias && (!t->filter_b || !t->gate_b || !t->res_b || !t->skip_b)) return wn_fail(WN_E_BADARG, "%s: cfg.bias = 1 but a per-layer bias array is NULL", who);
+    std::vector<WnRelayoutBatch> batches;
+    WnRelayoutBatch b;
+    memset(&b, 0, sizeof(b));
+    auto flush = [&]() { if (b.n > 0) { batches.push_back(b); memset(&b, 0, sizeof(b)); } };
+    bool missing = false;
+    auto piece = [&](void* ref, size_t off, int rows, int cols, int rs, int cs, int ld, int cm_blk, int cm_off) {
+        if (!ref) { missing = true; return; }
+        if (b.n == WN_RELAYOUT_PIECES) flush();
+        WnRelayoutPiece& q = b.p[b.n++];
+        q.ref = static_cast<float*>(ref); q.off = (long long)off; q.rows = rows; q.cols = cols; q.rs = rs; q.cs = cs; q.ld = ld; q.cm_blk = cm_blk; q.cm_off = cm_off;
+        q.tile0 = b.tiles;
+        b.tiles += ((rows + 31) / 32) * ((cols + 31) / 32);
+    };
+    for (int l = 0; l < NL; ++l) {
+        for (int tap = 0; tap < 2; ++tap) {   // (D, R, 2) -> rows tap * R .. of [2R][2D], columns [F(32) | G(32)] per 32 channels
+            const size_t off = h->fw_off_fg + ((size_t)l * 2 * R + (size_t)tap * R) * 2 * D;
+            piece(t->filter_w[l] ? static_cast<float*>(t->filter_w[l]) + tap : nullptr, off, D, R, 2 * R, 2, 2 * D, 64, 0);
+            piece(t->gate_w[l] ? static_cast<float*>(t->gate_w[l]) + tap : nullptr, off, D, R, 2 * R, 2, 2 * D, 64, 32);
+        }
+        piece(t->res_w[l], h->fw_off_res + (size_t)l * D * R, R, D, D, 1, R, 32, 0);       // (R, D, 1) -> [D][R]
+        piece(t->skip_w[l], h->fw_off_skip + (size_t)l * D * S, S, D, D, 1, S, 32, 0);     // (S, D, 1) -> [D][S]
+        if (pl.has_bias) {
+            piece(t->filter_b[l], h->fw_off_bfg + (size_t)l * 2 * D, D, 1, 1, 0, 0, 64, 0);
+            piece(t->gate_b[l], h->fw_off_bfg + (size_t)l * 2 * D, D, 1, 1, 0, 0, 64, 32);
+            piece(t->res_b[l], h->fw_off_bres + (size_t)l * R, R, 1, 1, 0, 0, 32, 0);
+            piece(t->skip_b[l], h->fw_off_bskip + (size_t)l * S, S, 1, 1, 0, 0, 32, 0);
+        }
+    }
+    piece(t->end1_w, h->fw_off_w1, E, S, S, 1, E, 32, 0);        // (E, S, 1) -> [S][E]
+    piece(t->end1_b, h->fw_off_b1, E, 1, 1, 0, 0, 32, 0);
+    piece(t->end2_w, h->fw_off_w2, C, E, E, 1, C, 32, 0);        // (C, E, 1) -> [E][C]
+    piece(t->end2_b, h->fw_off_b2, C, 1, 1, 0, 0, 32, 0);
+    piece(t->start_w, h->fw_off_start_t, R, C, C, 1, R, 32, 0);  // (R, C, 1) -> [C][R]
+    if (pl.has_bias) piece(t->start_b, h->fw_off_start_b, R, 1, 1, 0, 0, 32, 0);
+    flush();
+    if (missing && !unpack) return wn_fail(WN_E_BADARG, "%s: a parameter tensor pointer is NULL", who);
+    for (const WnRelayoutBatch& bb : batches) {
+        if (unpack) hipLaunchKernelGGL(wn_relayout<true>, dim3((unsigned)bb.tiles), dim3(256), 0, st, bb, flat);
+        else hipLaunchKernelGGL(wn_relayout<false>, dim3((unsigned)bb.tiles), dim3(256), 0, st, bb, flat);
+    }
+    return rt_hip(hipGetLastError(), who);
+}
+
+static int wn_train_tensors_check(wn_handle* h, const char* who) {
+    if (!h->have_weights) return wn_fail(WN_E_STATE, "%s: wn_load_weights has not been called", who);
+    if (!h->fw_ok) return wn_fail(WN_E_UNSUPPORTED, "wn_train: needs kernel_size 2 and channel counts that are multiples of 32");
+    if (h->padded) return wn_fail(WN_E_UNSUPPORTED, "wn_train: this handle runs a zero-padded channel shape (its parameter layout is not the caller's)");
+    return rt_hip(hipSetDevice(h->cfg.device_id), "hipSetDevice");
+}
+
+extern "C" int wn_train_pack(wn_handle* h, const wn_train_tensors* tensors, float* params, void* hip_stream) {
+    g_err[0] = 0;
+    if (!h || !tensors || !params) return wn_fail(WN_E_BADARG, "wn_train_pack: NULL argument");
+    if (!h->chains.empty()) return wn_train_pack(h->chains[0], tensors, params, hip_stream);
+    { int rc = wn_train_tensors_check(h, "wn_train_pack"); if (rc) return rc; }
+    // (sections no tensor maps to -- the bias sections of a model without biases, bskip_total -- read as zero, like the Python pack's torch.zeros)
+    int rc = rt_hip(hipMemsetAsync(params, 0, h->fw_floats * 4, (hipStream_t)hip_stream), "hipMemsetAsync(params)");
+    return rc ? rc : wn_relayout_run(h, tensors, params, false, (hipStream_t)hip_stream, "wn_train_pack");
+}
+
+extern "C" int wn_train_unpack_grads(wn_handle* h, const float* grads, const wn_train_tensors* tensors, void* hip_stream) {
+    g_err[0] = 0;
+    if (!h || !tensors || !grads) return wn_fail(WN_E_BADARG, "wn_train_unpack_grads: NULL argument");
+    if (!h->chains.empty()) return wn_train_unpack_grads(h->chains[0], grads, tensors, hip_stream);
+    { int rc = wn_train_tensors_check(h, "wn_train_unpack_grads"); if (rc) return rc; }
+    return wn_relayout_run(h, tensors, const_cast<float*>(grads), true, (hipStream_t)hip_stream, "wn_train_unpack_grads");
+}
+
 static void wn_launch_cvt_t(hipStream_t st, const float* in, long long in_batch_stride, unsigned short* out, int rows, int cols, int batches) {
     hipLaunchKernelGGL(wn_cvt_bf16_transposed, dim3((unsigned)((cols + 31) / 32), (unsigned)((rows + 31) / 32), (unsigned)batches), dim3(256), 0, st,
                        in, in_batch_stride, out, rows, cols);
@@ -128,6 +212,27 @@ static void wn_launch_cvt_t(hipStream_t st, const float* in, long long in_batch_
 #ifndef WN_TN_MERGE_TAPS
 #define WN_TN_MERGE_TAPS 1
 #endif
+// Deterministic mode (wn_train_set_deterministic / WN_DETERMINISTIC=1): the row splits of a weight-gradient product and the row blocks of a bias
+// gradient store their partial results in a workspace -- one per stream the backward uses: the two run side by side -- and a second kernel adds them
+// in order.  Bit-equal gradients from run to run for the price of one write and one read of the partial tiles (at most 67 MB per product).
+static thread_local WnDetWs* t_tn_det[2] = {nullptr, nullptr};   // [0]: the caller's stream, [1]: the side stream
+static thread_local hipStream_t t_tn_side = nullptr;
+struct WnDetScope {   // the launches of one wn_train_forward / wn_train_backward call find the handle's partial-tile workspaces through the thread-locals
+    explicit WnDetScope(wn_handle* h) { if (h->deterministic) { t_tn_det[0] = &h->det_ws[0]; t_tn_det[1] = &h->det_ws[1]; } t_tn_side = nullptr; }
+    ~WnDetScope() { t_tn_det[0] = t_tn_det[1] = nullptr; t_tn_side = nullptr; }
+};
+static float* wn_det_part(hipStream_t st, size_t floats) {
+    WnDetWs* w = t_tn_det[(t_tn_side && st == t_tn_side) ? 1 : 0];
+    if (!w) return nullptr;
+    if (w->floats < floats) {
+        (void)hipDeviceSynchronize();
+        rt_free(w->buf);
+        w->buf = (float*)rt_malloc(floats * 4);
+        w->floats = w->buf ? floats : 0;
+    }
+    return w->buf;
+}
+
 static void wn_launch_tn(hipStream_t st, WnGemmTnArgs a, bool bf16 = false) {
     // bf16 products with Nb % 256 == 0 take the 128 x 256 tile (A streamed once per 256 columns of B); rows split by wn_tn_grid (wn_plan.h)
     const bool wide16 = bf16 && !a.a_idx && a.a_bf16 && a.b_bf16 && a.Nb % 256 == 0;   // (both operands stored as bf16: the filter/gate weight gradient on the shadow of x -- two tap views, ka_split > 0 --, the skip weight gradient on the shadow of dskip)
@@ -142,6 +247,7 @@ static void wn_launch_tn(hipStream_t st, WnGemmTnArgs a, bool bf16 = false) {
     a.rows_per_split = tg.rows_per_split;
     a.tiles_ka = tg.tiles_ka; a.n_splits = tg.splits;
     const dim3 grid(tg.blocks);   // wn_tile_of: the tiles of a row split share an XCD
+    a.part = wn_det_part(st, (size_t)tg.splits * a.Ka * a.Nb);   // (NULL outside the deterministic mode: atomics)
     // (b_bf16 / a_bf16: that operand is stored as bf16 -- [dF|dG] in the filter/gate weight gradient, z in the residual and skip ones)
     if (wide16) hipLaunchKernelGGL((wn_bwd_gemm_tn_bf16<8, true, true>), grid, dim3(512), 0, st, a);
     else if (wide && a.b_bf16) hipLaunchKernelGGL((wn_bwd_gemm_tn_bf16<8, false, true>), grid, dim3(512), 0, st, a);
@@ -150,11 +256,16 @@ static void wn_launch_tn(hipStream_t st, WnGemmTnArgs a, bool bf16 = false) {
     else if (bf16 && !a.a_idx && a.a_bf16) hipLaunchKernelGGL((wn_bwd_gemm_tn_bf16<4, true, false>), grid, dim3(256), 0, st, a);
     else if (bf16 && !a.a_idx) hipLaunchKernelGGL((wn_bwd_gemm_tn_bf16<4, false, false>), grid, dim3(256), 0, st, a);  // bf16 matrix operands, fp32 accumulation
     else hipLaunchKernelGGL(wn_bwd_gemm_tn, grid, dim3(256), 0, st, a);
+    if (a.part)
+        hipLaunchKernelGGL(wn_tn_reduce, dim3((unsigned)(((long long)a.Ka * a.Nb / 4 + 255) / 256)), dim3(256), 0, st, a.part, tg.splits, a.Ka, a.Nb, a.c, a.ldc, a.c_trans);
 }
 
 static void wn_launch_colsum(hipStream_t st, const WnRowMap& x, long long M, int rows_per_batch, int N, float* out, bool x16 = false) {
-    if (x16) { hipLaunchKernelGGL(wn_bwd_colsum<true>, dim3((unsigned)((M + 511) / 512), (unsigned)((N + 63) / 64)), dim3(64), 0, st, x, M, rows_per_batch, N, out); return; }
-    hipLaunchKernelGGL(wn_bwd_colsum<false>, dim3((unsigned)((M + 511) / 512), (unsigned)((N + 63) / 64)), dim3(64), 0, st, x, M, rows_per_batch, N, out);
+    const unsigned blocks = (unsigned)((M + 511) / 512);
+    float* part = (N % 4 == 0) ? wn_det_part(st, (size_t)blocks * N) : nullptr;
+    if (x16) hipLaunchKernelGGL(wn_bwd_colsum<true>, dim3(blocks, (unsigned)((N + 63) / 64)), dim3(64), 0, st, x, M, rows_per_batch, N, out, part);
+    else hipLaunchKernelGGL(wn_bwd_colsum<false>, dim3(blocks, (unsigned)((N + 63) / 64)), dim3(64), 0, st, x, M, rows_per_batch, N, out, part);
+    if (part) hipLaunchKernelGGL(wn_tn_reduce, dim3((unsigned)((N / 4 + 255) / 256)), dim3(256), 0, st, part, (int)blocks, 1, N, out, N, 0);
 }
 
 static void wn_launch_transpose(hipStream_t st, const float* in, long long in_batch_stride, float* out, int rows, int cols, int batches) {
@@ -180,6 +291,7 @@ extern "C" int wn_train_forward(wn_handle* h, const float* params, const int32_t
     { int rc = rt_hip(hipSetDevice(h->cfg.device_id), "hipSetDevice"); if (rc) return rc; }
     WnTrainLay& t = h->train;
     h->train_valid = false;
+    WnDetScope det_scope(h);
     { int rc = wn_train_layout_ws(h, N, L, out_len, t); if (rc) return rc; }
     if (h->tws_floats < t.total) {
         (void)hipDeviceSynchronize();
@@ -243,6 +355,7 @@ extern "C" int wn_train_forward(wn_handle* h, const float* params, const int32_t
         if (rc) return rc;
     }
     hipStream_t sd = two ? h->side_stream : st;
+    t_tn_side = two ? h->side_stream : nullptr;
     size_t ev_next = 0;
     auto signal = [&](hipStream_t from) -> hipEvent_t {
         if (ev_next == h->events.size()) {
@@ -336,6 +449,7 @@ extern "C" int wn_train_backward(wn_handle* h, const float* params, const float*
     const WnPlan& pl = h->plan;
     const int R = pl.R, D = pl.D, S = pl.S, E = pl.E, C = pl.C, NL = pl.NL;
     const WnTrainLay& t = h->train;
+    WnDetScope det_scope(h);
     const long long N = t.N, L = t.L, out_len = t.out_len, Mo = N * out_len;
     float* ws = h->d_tws;
     hipStream_t st = (hipStream_t)hip_stream;
@@ -359,6 +473,7 @@ extern "C" int wn_train_backward(wn_handle* h, const float* params, const float*
         if (rc) return rc;
     }
     hipStream_t sd = two ? h->side_stream : st;
+    t_tn_side = two ? h->side_stream : nullptr;
     size_t ev_next = 0;
     auto signal = [&](hipStream_t from) -> hipEvent_t {   // an event recorded on `from` now
         if (ev_next == h->events.size()) {

@@ -43,7 +43,7 @@ class wn_generate_args(ctypes.Structure):
                 ("stream_temperatures", ctypes.c_void_p)]
 
 
-ABI_VERSION = 4  # include/wn_abi.h: WN_ABI_VERSION
+ABI_VERSION = 5  # include/wn_abi.h: WN_ABI_VERSION
 
 
 class wn_info(ctypes.Structure):
@@ -60,11 +60,21 @@ class wn_adam_args(ctypes.Structure):
                 ("grads", ctypes.c_void_p), ("exp_avg", ctypes.c_void_p), ("exp_avg_sq", ctypes.c_void_p),
                 ("lr", ctypes.c_double), ("beta1", ctypes.c_double), ("beta2", ctypes.c_double), ("eps", ctypes.c_double), ("weight_decay", ctypes.c_double),
                 ("max_grad_norm", ctypes.c_double), ("step", ctypes.c_int64), ("total_norm", ctypes.c_void_p), ("scratch", ctypes.c_void_p),
-                ("hip_stream", ctypes.c_void_p)]
+                ("hip_stream", ctypes.c_void_p), ("flags", ctypes.c_int64)]
+
+
+WN_ADAM_NORM_ONLY, WN_ADAM_NORM_KEEP, WN_ADAM_NORM_GIVEN = 1, 2, 4
+
+TRAIN_TENSOR_ARRAYS = ("filter_w", "gate_w", "res_w", "skip_w", "filter_b", "gate_b", "res_b", "skip_b")
+TRAIN_TENSOR_SINGLES = ("start_w", "start_b", "end1_w", "end1_b", "end2_w", "end2_b")
+
+
+class wn_train_tensors(ctypes.Structure):
+    _fields_ = [("n_layers", ctypes.c_int32), ("reserved", ctypes.c_int32)] + [(n, ctypes.c_void_p) for n in TRAIN_TENSOR_ARRAYS + TRAIN_TENSOR_SINGLES]
 
 
 EXPORTS = ["wn_abi_version", "wn_create", "wn_destroy", "wn_load_weights", "wn_reset", "wn_generate", "wn_wait",
-           "wn_get_info", "wn_export_queue", "wn_forward", "wn_set_forward_precision", "wn_prime", "wn_train_get_layout", "wn_train_export_params", "wn_train_forward", "wn_train_backward", "wn_train_loss", "wn_adam_step", "wn_profile_next", "wn_profile_read", "wn_last_error"]
+           "wn_get_info", "wn_export_queue", "wn_forward", "wn_set_forward_precision", "wn_prime", "wn_train_get_layout", "wn_train_export_params", "wn_train_forward", "wn_train_backward", "wn_train_loss", "wn_train_pack", "wn_train_unpack_grads", "wn_train_set_deterministic", "wn_adam_step", "wn_profile_next", "wn_profile_read", "wn_last_error"]
 
 
 TRAIN_SECTIONS = ("fg", "bfg", "res", "bres", "skip", "bskip", "bskip_total", "w1", "b1", "w2", "b2", "start_t", "start_b")
@@ -109,6 +119,9 @@ class Library:
                                        ctypes.c_void_p, ctypes.c_void_p]
         d.wn_train_backward.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         d.wn_train_loss.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        d.wn_train_pack.argtypes = [ctypes.c_void_p, ctypes.POINTER(wn_train_tensors), ctypes.c_void_p, ctypes.c_void_p]
+        d.wn_train_unpack_grads.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(wn_train_tensors), ctypes.c_void_p]
+        d.wn_train_set_deterministic.argtypes = [ctypes.c_void_p, ctypes.c_int32]
         d.wn_adam_step.argtypes = [ctypes.POINTER(wn_adam_args)]
         d.wn_profile_next.argtypes = [ctypes.c_void_p, ctypes.c_int32]
         d.wn_profile_read.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64]

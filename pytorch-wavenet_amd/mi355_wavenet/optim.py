@@ -34,6 +34,7 @@ class FusedAdam(torch.optim.Optimizer):
                 loss = closure()
         if self._lib is None:
             self._lib = _abi.load_product_library()
+        jobs = []   # one per group that has gradients: (group, args builder inputs)
         for group in self.param_groups:
             ps = [p for p in group["params"] if p.grad is not None]
             if not ps:
@@ -53,27 +54,52 @@ class FusedAdam(torch.optim.Optimizer):
                 steps.add(int(st["step"]))
             if len(steps) != 1:
                 raise RuntimeError("FusedAdam: the parameters of a group must have taken the same number of steps (got %r)" % sorted(steps))
-            n = len(ps)
             grads = [p.grad if p.grad.is_contiguous() else p.grad.contiguous() for p in ps]
+            clip = max_grad_norm if max_grad_norm is not None else group.get("max_grad_norm")
+            jobs.append((group, ps, grads, dev, steps.pop(), float(clip) if clip else 0.0))
+        if not jobs:
+            return loss
+        if len({j[3] for j in jobs}) != 1:
+            raise TypeError("FusedAdam steps the parameters of ONE MI355X (the groups live on %s)" % sorted(str(j[3]) for j in jobs))
+        clips = {j[5] for j in jobs}
+        if len(jobs) > 1 and len(clips) != 1:
+            raise ValueError("FusedAdam: the groups are clipped TOGETHER (clip_grad_norm_ over all parameters): one max_grad_norm for all of them, got %r" % sorted(clips))
+        dev = jobs[0][3]
+        key = (dev.index or 0)
+        if key not in self._scratch:
+            self._scratch[key] = (torch.zeros(1, dtype=torch.float64, device=dev), torch.zeros((), dtype=torch.float32, device=dev))
+        acc, norm = self._scratch[key]
+        stream = torch.cuda.current_stream(dev).cuda_stream
+
+        def call(job, flags):
+            group, ps, grads, _, step, clip = job
+            n = len(ps)
             arr = lambda vals: (ctypes.c_void_p * n)(*vals)   # noqa: E731
             sizes = (ctypes.c_int64 * n)(*[p.numel() for p in ps])
             tabs = [arr([p.data_ptr() for p in ps]), arr([g.data_ptr() for g in grads]),
                     arr([self.state[p]["exp_avg"].data_ptr() for p in ps]), arr([self.state[p]["exp_avg_sq"].data_ptr() for p in ps])]
-            key = (dev.index or 0)
-            if key not in self._scratch:
-                self._scratch[key] = (torch.zeros(1, dtype=torch.float64, device=dev), torch.zeros((), dtype=torch.float32, device=dev))
-            acc, norm = self._scratch[key]
-            clip = max_grad_norm if max_grad_norm is not None else group.get("max_grad_norm")
             b1, b2 = group["betas"]
             a = _abi.wn_adam_args(n, dev.index or 0, ctypes.cast(sizes, ctypes.c_void_p), ctypes.cast(tabs[0], ctypes.c_void_p),
                                   ctypes.cast(tabs[1], ctypes.c_void_p), ctypes.cast(tabs[2], ctypes.c_void_p), ctypes.cast(tabs[3], ctypes.c_void_p),
                                   float(group["lr"]), float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]),
-                                  float(clip) if clip else 0.0, steps.pop(), norm.data_ptr(), acc.data_ptr(),
-                                  torch.cuda.current_stream(dev).cuda_stream)
+                                  clip, step, norm.data_ptr(), acc.data_ptr(), stream, flags)
             self._lib.check(self._lib.dll.wn_adam_step(ctypes.byref(a)))
+
+        clip = jobs[0][5]
+        if len(jobs) > 1 and clip:
+            # the total norm is the norm over ALL groups' gradients: one norm pass per group into the same accumulator first, then every group
+            # steps on that total (round 5 took a norm per group: wrong with a second group, e.g. biases without weight decay -- ADVICE r05)
+            for k, job in enumerate(jobs):
+                call(job, _abi.WN_ADAM_NORM_ONLY | (_abi.WN_ADAM_NORM_KEEP if k else 0))
+            for job in jobs:
+                call(job, _abi.WN_ADAM_NORM_GIVEN)
+        else:
+            for job in jobs:
+                call(job, 0)
+        for _, ps, grads, _, _, c in jobs:
             for p, g in zip(ps, grads):
-                if g is not p.grad and clip:
+                if g is not p.grad and c:
                     p.grad.copy_(g)   # (a non-contiguous .grad was stepped through a copy: the clipped values go back)
-            if clip:
-                self.last_total_norm = norm
+        if clip:
+            self.last_total_norm = norm
         return loss

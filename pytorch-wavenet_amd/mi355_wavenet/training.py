@@ -4,8 +4,10 @@ Replaces, for one-hot inputs on an MI355X, the autograd graph the reference buil
 (wavenet_model.py:125-196) when WavenetTrainer.train (wavenet_training.py:58-107) calls ``output = self.model(x)`` and
 ``loss.backward()``.  The parameters stay ordinary ``nn.Parameter``s in the reference's Conv1d layouts (so optimisers,
 ``clip_grad_norm`` and ``torch.save(model)`` keep working): every step they are packed into the flat GEMM layout of
-``wn_train_layout`` (include/wn_abi.h) with a handful of torch view ops, and the flat gradient that wn_train_backward
-returns is unpacked the same way.  The loss (F.cross_entropy on the returned logits, wavenet_training.py:69-70) is one fused pass
+``wn_train_layout`` (include/wn_abi.h) by the engine itself (wn_train_pack: the tensors' addresses in, a handful of launches -- round 5
+did it with ~150 torch stack / view / copy launches per step), and the flat gradient that wn_train_backward returns goes back into ONE
+buffer in the parameters' own layouts (wn_train_unpack_grads), of which every parameter's gradient is a view.  ``pack`` / ``unpack``
+below are the same maps in torch ops: the tests' second opinion on the native ones, not on the step's path.  The loss (F.cross_entropy on the returned logits, wavenet_training.py:69-70) is one fused pass
 over the logits as well (wn_train_loss: value and gradient together), behind ``cross_entropy`` below.
 """
 import ctypes
@@ -31,6 +33,10 @@ class StackRunner:
         self.bias = bool(c.get("bias", False))
         self.ticket = 0
         self.device = engine.mem.device
+        self._flat = None        # the packed parameters of the step in flight (one buffer per model: stable addresses)
+        self._gflat = None       # the flat gradient wn_train_backward writes
+        self._ptr_key = None     # the parameter tensors the cached pointer tables below were built for
+        self._ptr_tabs = None
 
     # ---- layout conversion (reference Conv1d layouts <-> wn_train_layout) ------------------------------------------
     def sizes(self):
@@ -87,6 +93,71 @@ class StackRunner:
                         "skip_b": get("bskip").reshape(NL, S).clone(), "start_b": get("start_b").clone()})
         return out
 
+    # ---- native layout conversion: the tensors themselves in, a view per gradient out ---------------------------------------
+    @staticmethod
+    def _tensor_table(by_key, NL):
+        """wn_train_tensors over {key: [tensors or None]} (PARAM_ORDER keys); returns (struct, keep-alive list)."""
+        t = _abi.wn_train_tensors()
+        t.n_layers, t.reserved = NL, 0
+        keep = []
+        names = {"filter_w": "filter_w", "gate_w": "gate_w", "res_w": "res_w", "skip_w": "skip_w", "filter_b": "filter_b", "gate_b": "gate_b",
+                 "res_b": "res_b", "skip_b": "skip_b"}
+        for key, field in names.items():
+            ts = by_key.get(key)
+            if ts is None:
+                setattr(t, field, None)
+                continue
+            arr = (ctypes.c_void_p * NL)(*[(x.data_ptr() if x is not None else None) for x in ts])
+            keep.append(arr)
+            setattr(t, field, ctypes.cast(arr, ctypes.c_void_p))
+        for key in ("start_w", "start_b", "end1_w", "end1_b", "end2_w", "end2_b"):
+            ts = by_key.get(key)
+            setattr(t, key, ts[0].data_ptr() if ts is not None and ts[0] is not None else None)
+        return t, keep
+
+    def pack_native(self, by_key):
+        """by_key: {key: list of the parameter tensors} -> the flat GEMM layout (one launch per 72 pieces: 5 at config 5)."""
+        tensors = [x for k in PARAM_ORDER for x in (by_key.get(k) or [])]
+        for x in tensors:
+            if not (x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()):
+                raise TypeError("the native training step takes contiguous fp32 parameters on the MI355X (got %s %s on %s)" % (x.dtype, tuple(x.shape), x.device))
+        key = tuple(x.data_ptr() for x in tensors)
+        if key != self._ptr_key:
+            self._ptr_tabs = self._tensor_table(by_key, self.NL)
+            self._ptr_key = key
+        if self._flat is None:
+            self._flat = torch.empty(self.total, dtype=torch.float32, device=self.device)
+        e = self.eng
+        e.lib.check(e.lib.dll.wn_train_pack(e._h, ctypes.byref(self._ptr_tabs[0]), self._flat.data_ptr(), e.mem.stream()))
+        return self._flat
+
+    def unpack_native(self, gflat, by_key):
+        """The flat gradient -> {key: [gradient tensors]}: views of ONE new buffer in the parameters' own layouts (the last layer's residual conv gets
+        None: it never reaches the loss, and upstream its .grad stays None)."""
+        shapes = {k: [tuple(x.shape) for x in ts] for k, ts in by_key.items()}
+        total = sum(int(torch.Size(sh).numel()) for shs in shapes.values() for sh in shs)
+        buf = torch.empty(total, dtype=torch.float32, device=self.device)
+        out, pos = {}, 0
+        for k in PARAM_ORDER:
+            if k not in shapes:
+                continue
+            views = []
+            for i, sh in enumerate(shapes[k]):
+                n = int(torch.Size(sh).numel())
+                views.append(None if (k in ("res_w", "res_b") and i == self.NL - 1) else buf[pos:pos + n].view(sh))
+                pos += n
+            out[k] = views
+        t, keep = self._tensor_table(out, self.NL)
+        e = self.eng
+        e.lib.check(e.lib.dll.wn_train_unpack_grads(e._h, gflat.data_ptr(), ctypes.byref(t), e.mem.stream()))
+        del keep
+        return out
+
+    def set_deterministic(self, on):
+        """Bit-reproducible weight / bias gradients (wn_train_set_deterministic: partial tiles + an ordered reduction instead of fp32 atomics)."""
+        e = self.eng
+        e.lib.check(e.lib.dll.wn_train_set_deterministic(e._h, 1 if on else 0))
+
     # ---- the two launches ----------------------------------------------------------------------------------------------
     def forward(self, flat, idx, output_length):
         idx = idx.to(self.device, torch.int32).contiguous()
@@ -100,7 +171,9 @@ class StackRunner:
 
     def backward(self, flat, dlogits):
         dlogits = dlogits.to(torch.float32).contiguous()
-        grads = torch.empty(self.total, dtype=torch.float32, device=self.device)
+        if self._gflat is None:
+            self._gflat = torch.empty(self.total, dtype=torch.float32, device=self.device)
+        grads = self._gflat
         e = self.eng
         e.lib.check(e.lib.dll.wn_train_backward(e._h, flat.data_ptr(), dlogits.data_ptr(), grads.data_ptr(), e.mem.stream()))
         return grads
@@ -116,20 +189,23 @@ PARAM_ORDER = ("start_w", "filter_w", "gate_w", "res_w", "skip_w", "end1_w", "en
                "start_b", "filter_b", "gate_b", "res_b", "skip_b")
 
 
+SINGLE_KEYS = ("start_w", "start_b", "end1_w", "end1_b", "end2_w", "end2_b")
+
+
 class StackFunction(torch.autograd.Function):
     """logits = stack(indices; parameters).  Inputs after ``output_length``: the model's parameters as flat lists, per layer,
     in the order given by ``names`` (a tuple of (key, count) pairs); gradients come back in the same order."""
 
     @staticmethod
     def forward(ctx, runner, idx, output_length, names, *tensors):
-        stacked, pos = {}, 0
+        by_key, pos = {}, 0
         for key, count in names:
-            ts = tensors[pos:pos + count]
+            by_key[key] = list(tensors[pos:pos + count])
             pos += count
-            stacked[key] = ts[0] if count == 1 and key in ("start_w", "start_b", "end1_w", "end1_b", "end2_w", "end2_b") else torch.stack(ts)
-        flat = runner.pack(stacked)
+        flat = runner.pack_native({k: [x.detach() for x in v] for k, v in by_key.items()})
         logits = runner.forward(flat, idx, output_length)
         ctx.runner, ctx.flat, ctx.names, ctx.ticket = runner, flat, names, runner.ticket
+        ctx.shapes = {k: [x.detach() for x in v] for k, v in by_key.items()}   # (shapes only: detached aliases, no copies)
         return logits
 
     @staticmethod
@@ -138,16 +214,10 @@ class StackFunction(torch.autograd.Function):
         if ctx.ticket != r.ticket:
             raise RuntimeError("native WaveNet backward: another forward ran on this model since the one being differentiated "
                                "(the saved activations live in one workspace per model)")
-        g = r.unpack(r.backward(ctx.flat, dlogits))
+        g = r.unpack_native(r.backward(ctx.flat, dlogits), ctx.shapes)
         out = []
         for key, count in ctx.names:
-            if count == 1 and key in ("start_w", "start_b", "end1_w", "end1_b", "end2_w", "end2_b"):
-                out.append(g[key])
-            else:
-                rows = list(g[key].unbind(0))
-                if key in ("res_w", "res_b"):
-                    rows[-1] = None  # the last layer's residual conv never reaches the loss (also upstream: its .grad stays None)
-                out.extend(rows)
+            out.extend(g[key])
         return (None, None, None, None, *out)
 
 

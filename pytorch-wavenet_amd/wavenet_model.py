@@ -103,6 +103,9 @@ class WaveNetModel(nn.Module):
         # reference's fp32 graph to rounding) or "bf16" (bf16 operands, fp32 accumulation and fp32 residual stream;
         # needs channel counts that are multiples of 64, otherwise fp32 is used)
         self.matrix_precision = "fp32"
+        # Extension: True = the native backward's weight / bias gradients are bit-reproducible from run to run (ordered reduction of the row splits'
+        # partial tiles instead of fp32 atomics: C ABI wn_train_set_deterministic); None = the library's default (off, or WN_DETERMINISTIC=1)
+        self.deterministic_gradients = None
 
     # ------------------------------------------------------------------ training path (torch ops)
     def wavenet(self, input, dilation_func):
@@ -257,6 +260,9 @@ class WaveNetModel(nn.Module):
             add("skip_b", [m.bias for m in self.skip_convs])
         self._wn_train_calls = getattr(self, "_wn_train_calls", 0) + 1
         self._apply_precision(runner.eng)
+        det = getattr(self, "deterministic_gradients", None)
+        if det is not None:
+            runner.set_deterministic(bool(det))
         return training.StackFunction.apply(runner, idx, self.output_length, tuple(names), *tensors)
 
     def _checked_indices(self, indices, check):
@@ -523,6 +529,7 @@ class WaveNetModel(nn.Module):
         d.setdefault("_wn_train_runner", None)
         d.setdefault("_wn_train_calls", 0)
         d.setdefault("matrix_precision", "fp32")
+        d.setdefault("deterministic_gradients", None)
         if "end_channels" not in d:
             d["end_channels"] = self.end_conv_1.out_channels
         if "bias" not in d:

@@ -191,6 +191,9 @@ extern "C" int wn_train_export_params(wn_handle*, float*, void*) { return fail(W
 extern "C" int wn_train_forward(wn_handle*, const float*, const int32_t*, int64_t, int64_t, int64_t, float*, void*) { return fail(WN_E_UNSUPPORTED, "test double: GPU only"); }
 extern "C" int wn_train_backward(wn_handle*, const float*, const float*, float*, void*) { return fail(WN_E_UNSUPPORTED, "test double: GPU only"); }
 extern "C" int wn_train_loss(wn_handle*, const float*, const int64_t*, int64_t, float*, float*, void*) { return fail(WN_E_UNSUPPORTED, "test double: GPU only"); }
+extern "C" int wn_train_pack(wn_handle*, const wn_train_tensors*, float*, void*) { return fail(WN_E_UNSUPPORTED, "test double: GPU only"); }
+extern "C" int wn_train_unpack_grads(wn_handle*, const float*, const wn_train_tensors*, void*) { return fail(WN_E_UNSUPPORTED, "test double: GPU only"); }
+extern "C" int wn_train_set_deterministic(wn_handle*, int32_t) { return fail(WN_E_UNSUPPORTED, "test double: GPU only"); }
 extern "C" int wn_adam_step(const wn_adam_args*) { return fail(WN_E_UNSUPPORTED, "test double: GPU only"); }
 extern "C" int wn_profile_next(wn_handle*, int32_t) { return fail(WN_E_UNSUPPORTED, "test double: GPU only"); }
 extern "C" int wn_profile_read(wn_handle*, int64_t*, int64_t) { return fail(WN_E_UNSUPPORTED, "test double: GPU only"); }

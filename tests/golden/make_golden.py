@@ -6,6 +6,9 @@ oracle/ref_shim.py -- the 3 documented import-time patches, nothing else) in the
     python tests/golden/make_golden.py --v3     # golden_v3.npz (forward() + parameter gradients of the reference: cfg2, the cfg3 stack)
     python tests/golden/make_golden.py --v4     # golden_v4.npz (the same for clips SHORTER than receptive_field + output_length - 1: the
                                                 #   reference left-pads the layers' activations with zeros there, wavenet_modules.py:24-27)
+    python tests/golden/make_golden.py --v6     # golden_v6.npz (BASELINE configs[4] AT ITS OWN SIZE: 32 one-second clips of 16 000 samples, output_length 10 885,
+                                                #   the 10 x 5 / 128 / 128 / 512 / 256 stack -- the real reference's loss, logit samples and gradient digests, run
+                                                #   four clips at a time (~5 min of CPU), plus the bf16 step's oracle and its noise rows at that size (~40 min))
     python tests/golden/make_golden.py --v5     # golden_v5.npz (the BF16 training step's oracle: oracle/bf16_step.py -- the reference's step with
                                                 #   operands rounded where the product rounds them -- after that restatement, roundings off, has been
                                                 #   checked against the imported reference on the same cases)
@@ -333,8 +336,133 @@ def main_v5():
     print("wrote", path, os.path.getsize(path), "bytes;", len(out), "arrays")
 
 
+# golden_v6.npz: BASELINE configs[4] at its own geometry.  N = 32 clips of L = 16 000 samples, output_length = L - rf + 1 = 10 885,
+# cfg3's stack.  Nothing of that size was pinned before round 6 (largest case: N <= 2, output_length <= 64).  The inputs are NOT stored: they are
+# regenerated from numpy RandomState seeds (bit-stable) and guarded by CRCs.  The reference runs FOUR clips per forward()/backward() call (its whole
+# batch at once would need ~130 GB of autograd state) with the chunk losses averaged -- F.cross_entropy's mean over N * output_length rows of equal-sized
+# chunks -- and gradients accumulated in .grad by loss_c / n_chunks: the reference's own code on every clip, fp32 summation order across chunks aside.
+CFG5 = dict(cname="cfg3", wseed=41, dseed=42, N=32, L=16000, chunk=4)
+
+
+def cfg5_inputs(N=CFG5["N"], L=CFG5["L"], dseed=CFG5["dseed"]):
+    """(ids (N, L), target (N * out_len,)) of the config-5 fixture: shared by the generator, the GPU tests and bench.py's `verified` leg."""
+    cfg = synth.CONFIGS[CFG5["cname"]]
+    out_len = L - synth.receptive_field(cfg) + 1
+    rs = np.random.RandomState(dseed)
+    ids = rs.randint(0, 256, (CFG5["N"], L))
+    target = rs.randint(0, 256, (CFG5["N"], out_len))
+    return ids[:N], target[:N].reshape(-1), out_len
+
+
+def _ref_cfg5(mdl, clips, chunk):
+    """The real reference on clips [0, clips): returns (loss, chunk losses, sampled logits, per-clip logit norms, gradients)."""
+    import torch.nn.functional as F
+    import digest as dg
+    cfg = synth.CONFIGS[CFG5["cname"]]
+    ids, target, out_len = cfg5_inputs(clips)
+    m = build_ref_model(mdl, cfg, CFG5["wseed"], output_length=out_len)
+    L = ids.shape[1]
+    n_chunks = (clips + chunk - 1) // chunk
+    assert clips % chunk == 0
+    losses, samples, norms = [], [], []
+    for c in range(n_chunks):
+        sl = slice(c * chunk, (c + 1) * chunk)
+        x = torch.zeros(chunk, 256, L)
+        x.scatter_(1, torch.from_numpy(ids[sl]).view(chunk, 1, L), 1.)
+        y = m(x)                                                                                       # wavenet_model.py:186-196
+        loss = F.cross_entropy(y.squeeze(), torch.from_numpy(target.reshape(clips, out_len)[sl].reshape(-1)))   # wavenet_training.py:69
+        (loss / n_chunks).backward()
+        yy = y.detach().numpy().reshape(chunk, out_len, 256)
+        samples.append(yy[:, dg.logit_rows(out_len), :].astype(np.float32))
+        norms.append(np.sqrt((yy.astype(np.float64) ** 2).sum(axis=(1, 2))))
+        losses.append(float(loss))
+        print("  reference chunk %d/%d loss %.6f" % (c + 1, n_chunks, losses[-1]), flush=True)
+    g = {k: (p.grad.numpy().copy() if p.grad is not None else np.zeros(tuple(p.shape), dtype=np.float32)) for k, p in m.named_parameters()}
+    return float(np.mean(losses)), np.array(losses), np.concatenate(samples), np.concatenate(norms), g
+
+
+def _bf16_cfg5(clips, order, chunk=2):
+    """oracle/bf16_step.py on clips [0, clips), two at a time: gradients averaged over the chunks.  Exactly the full-batch evaluation under the
+    rounding model -- the chunks' dlogits differ from the batch's by the factor n_chunks, a power of two, which no rounding to bf16 sees."""
+    import bf16_step
+    import digest as dg
+    cfg = synth.CONFIGS[CFG5["cname"]]
+    W = synth.init_weights(cfg, seed=CFG5["wseed"])
+    ids, target, out_len = cfg5_inputs(clips)
+    n_chunks = clips // chunk
+    assert n_chunks & (n_chunks - 1) == 0, "power-of-two chunk counts only (see the docstring)"
+    bf16_step.ACCUMULATE = order
+    G, losses, samples, norms = None, [], [], []
+    for c in range(n_chunks):
+        sl = slice(c * chunk, (c + 1) * chunk)
+        lo, ls, g = bf16_step.step(cfg, W, ids[sl], target.reshape(clips, out_len)[sl].reshape(-1), out_len, round_operands=True)
+        yy = lo.reshape(chunk, out_len, 256)
+        samples.append(yy[:, dg.logit_rows(out_len), :].astype(np.float32))
+        norms.append(np.sqrt((yy.astype(np.float64) ** 2).sum(axis=(1, 2))))
+        losses.append(ls)
+        G = {k: v.astype(np.float64) / n_chunks for k, v in g.items()} if G is None else {k: G[k] + v.astype(np.float64) / n_chunks for k, v in g.items()}
+        print("  bf16 oracle (%s) chunk %d/%d loss %.6f" % (order, c + 1, n_chunks, ls), flush=True)
+    bf16_step.ACCUMULATE = "exact"
+    return float(np.mean(losses)), np.concatenate(samples), np.concatenate(norms), {k: v.astype(np.float32) for k, v in G.items()}
+
+
+def main_v6():
+    import zlib
+    sys.path.insert(0, HERE)
+    import digest as dg
+    mdl, wm, ad = ref_shim.load()
+    path = os.path.join(HERE, "golden_v6.npz")
+    out = dict(np.load(path)) if ("--resume" in sys.argv and os.path.exists(path)) else {}
+    ids, target, out_len = cfg5_inputs()
+    out["cfg5_meta"] = np.array([CFG5["wseed"], CFG5["dseed"], CFG5["N"], CFG5["L"], out_len, zlib.crc32(ids.astype(np.int16).tobytes()), zlib.crc32(target.astype(np.int16).tobytes())], dtype=np.int64)
+    out["cfg5_logit_rows"] = dg.logit_rows(out_len).astype(np.int64)
+
+    def devs(ref_d, d):
+        o = []
+        for k, r in ref_d.items():
+            if r[0] > 0:
+                g = d[k]
+                o.append(max(abs(g[0] - r[0]) / r[0], abs(g[1] - r[1]) / r[1], float(np.abs(g[2:6] - r[2:6]).max()) / r[1], float(np.abs(g[6:] - r[6:]).max()) / r[0]))
+        return np.array(o)
+
+    for tag, clips, chunk, orders in (("n2", 2, 2, ("exact", "f32", "f32perm")), ("n32", CFG5["N"], CFG5["chunk"], ("exact", "f32"))):
+        if "cfg5_%s_loss" % tag not in out:
+            print("cfg5 %s: the real reference, %d clips" % (tag, clips), flush=True)
+            loss, losses, samp, norms, g = _ref_cfg5(mdl, clips, chunk)
+            out["cfg5_%s_loss" % tag] = np.array([loss], dtype=np.float64)
+            out["cfg5_%s_chunk_losses" % tag] = losses
+            out["cfg5_%s_logits" % tag] = samp                       # (clips, 8, 256): rows dg.logit_rows(out_len) of every clip
+            out["cfg5_%s_logit_norms" % tag] = norms                 # (clips,) float64
+            for k, v in dg.digest(g).items():
+                out["cfg5_%s_d_%s" % (tag, k)] = v
+            np.savez_compressed(path, **out)
+            print("cfg5 %s: loss %.6f (ln 256 = %.4f)" % (tag, loss, np.log(256.0)), flush=True)
+        if "--no-bf16" in sys.argv or "cfg5_%s_bf16_noise" % tag in out:
+            continue
+        ref_d = {k[len("cfg5_%s_d_" % tag):]: out[k] for k in out if k.startswith("cfg5_%s_d_" % tag)}
+        noise = []
+        for order in orders:
+            ls, samp, norms, g = _bf16_cfg5(clips, order)
+            d = dg.digest(g)
+            dv = devs(ref_d, d)
+            dl = samp.astype(np.float64) - out["cfg5_%s_logits" % tag]
+            noise.append([float(np.sqrt((dl ** 2).mean())), float(np.abs(dl).max()), abs(ls - float(out["cfg5_%s_loss" % tag][0])), float(np.sqrt((dv ** 2).mean())), float(dv.max())])
+            print("cfg5 %s bf16 oracle (%s) vs the fp32 reference: sampled logits rms %.4f max %.4f, |dloss| %.5f, gradient digests rms %.4f max %.4f" % ((tag, order) + tuple(noise[-1])), flush=True)
+            if order == "exact":
+                out["cfg5_%s_bf16_loss" % tag] = np.array([ls], dtype=np.float64)
+                out["cfg5_%s_bf16_logits" % tag] = samp
+                for k, v in d.items():
+                    out["cfg5_%s_bf16_d_%s" % (tag, k)] = v
+        out["cfg5_%s_bf16_noise" % tag] = np.array(noise, dtype=np.float64)   # rows: the orders; columns: sampled-logit rms, max, |dloss|, digest rms, digest max (all vs the fp32 reference)
+        np.savez_compressed(path, **out)
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes;", len(out), "arrays")
+
+
 if __name__ == "__main__":
-    if "--v5" in sys.argv:
+    if "--v6" in sys.argv:
+        main_v6()
+    elif "--v5" in sys.argv:
         main_v5()
     elif "--v4" in sys.argv:
         main_v4()

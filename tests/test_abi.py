@@ -42,7 +42,7 @@ def test_hip_library_builds_and_exports_every_symbol():
         targets = [t for t in bundle.stdout.split() if "amdgcn" in t]
         assert targets and all("gfx950" in t for t in targets), targets
     lib = _abi.Library(so)  # dlopen + prototype check; no device call
-    assert lib.dll.wn_abi_version() == _abi.ABI_VERSION == 4
+    assert lib.dll.wn_abi_version() == _abi.ABI_VERSION == 5
 
 
 def test_struct_sizes_match_header():

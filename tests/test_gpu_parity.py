@@ -479,6 +479,55 @@ def test_a_job_that_never_becomes_resident_reports_busy_and_can_be_repeated(monk
     job.close()
 
 
+def _check_streams(cfg, W, first, uniforms, idx, N, streams):
+    for s in streams:
+        o_idx, _ = c_oracle.generate(cfg, W, N, first[s], 1.0, 0.0, uniforms[s])
+        assert np.array_equal(idx[s], o_idx), s
+
+
+@pytest.mark.parametrize("resident_ms,hog_samples", [(150, 5000), (1000, 6000)])
+def test_busy_of_a_job_in_rounds_is_all_or_nothing(monkeypatch, tmp_path, resident_ms, hog_samples):
+    """More streams than one chain holds run as ROUNDS, one kernel each, each with its own residency barrier (round 0 can give up while
+    round 1 -- the CUs free by then -- runs to completion).  "Nothing ran, repeat the call" (WN_E_BUSY) must then be true of the JOB: it is reported only
+    when NO round started (150 ms bound behind a 1.4 s hog: both rounds give up; evals_done rolled back; the repeated call equals the oracle without a
+    reset).  A mixed outcome (1 s bound behind a 1.7 s hog: round 0 gives up at 1.0 s, round 1 starts at 1.7 s) leaves the rounds' queues out of step:
+    WN_E_STATE, the handle refuses further jobs until wn_reset, and behind the reset everything equals the oracle again.  The second case depends on
+    timing: whichever outcome the box produces is checked against ITS contract, and printed."""
+    monkeypatch.setenv("WN_TESTING", "1")
+    monkeypatch.setenv("WN_NO_DEVICE_GATE", "1")
+    monkeypatch.setenv("WN_RESIDENT_TIMEOUT_MS", str(resident_ms))
+    N, ns = 40, 160
+    cfg, W, first, uniforms = make_case("cfg3", 61, ns, 4, N)
+    job = engine.Engine(cfg, W, n_streams=ns)
+    assert job.info()["n_chains"] >= 2
+    job.generate(4, first, temperature=1.0, uniforms=uniforms[:, :4])     # (warm)
+    probe = (0, 79, 80, 127, 128, ns - 1)
+    hog = _start_hog(tmp_path, hog_samples)
+    outcome = "ran"
+    idx = None
+    try:
+        idx = job.generate(N, first, temperature=1.0, uniforms=uniforms, timeout_ms=300, reset=True, batched_prime=False)
+    except _abi.WnError as e:
+        outcome = {_abi.WN_E_BUSY: "busy", _abi.WN_E_STATE: "mixed"}.get(e.code)
+        assert outcome is not None, str(e)
+        if outcome == "mixed":
+            assert "out of step" in str(e) and "wn_reset" in str(e), str(e)
+    _finish_hog(hog)
+    print("rounds behind a hog, residency bound %d ms: %s" % (resident_ms, outcome))
+    if resident_ms == 150:
+        assert outcome == "busy"
+    if outcome == "busy":
+        assert job.info()["evals_done"] == 0
+        idx = job.generate(N, first, temperature=1.0, uniforms=uniforms, timeout_ms=300, reset=False, batched_prime=False)   # no reset: fresh queues in EVERY round
+    elif outcome == "mixed":
+        with pytest.raises(_abi.WnError) as ei:
+            job.generate(N, first, temperature=1.0, uniforms=uniforms, timeout_ms=300, reset=False, batched_prime=False)
+        assert ei.value.code == _abi.WN_E_STATE and "wn_reset" in str(ei.value)
+        idx = job.generate(N, first, temperature=1.0, uniforms=uniforms, timeout_ms=300, reset=True, batched_prime=False)
+    _check_streams(cfg, W, first, uniforms, idx, N, probe)
+    job.close()
+
+
 @pytest.mark.parametrize("cfgname,ns,n_given", [("cfg1", 2, 200), ("cfg2", 1, 3100), ("cfg3", 2, 700), ("cfg3", 1, 5200)])
 def test_batched_priming_equals_chain_priming(cfgname, ns, n_given):
     """wn_prime (GEMM priming) leaves the queues exactly where n_given-1 single evaluations

@@ -1,0 +1,229 @@
+"""BASELINE configs[4] AT ITS OWN SIZE: the 10 x 5 / 128 / 128 / 512 / 256 stack on one-second 16 kHz clips --
+L = 16 000, output_length = L - receptive_field + 1 = 10 885, batch 32 -- the geometry bench.py times: 3360-tile launches, 512-way row splits of the
+weight-gradient products, the XCD tile remap of the one-launch layers, side-stream double buffering, 512 000-row maps.  Before round 6 the largest parity
+case anywhere was N <= 2, output_length <= 64.
+
+Checker: tests/golden/golden_v6.npz -- loss, eight logit rows per clip, per-clip logit norms and the gradient digests of tests/golden/digest.py, produced
+by the REAL reference (tests/golden/make_golden.py --v6: /root/reference's forward() -> F.cross_entropy -> backward(), four clips per call) on seeded
+inputs that are regenerated here (numpy RandomState; guarded by CRCs) and informative weights (synth gain-1 init: loss 6.05, not ln 256 = 5.545) -- and,
+for two clips, the facade's torch path on the same GPU, element for element.  The bf16 step is held to the spread of its own oracle's evaluation orders at
+THIS size (oracle/bf16_step.py, rows cfg5_*_bf16_noise of the fixture), the way tests/test_gpu_training.py does at depth.
+
+Tolerances: logits 1e-4 absolute (fp32 matrix cores vs the reference's CPU GEMMs, scale 3.6), loss 1e-5 relative, gradients 2e-5 of the tensor's
+largest element.
+"""
+import os
+import sys
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "pytorch-wavenet_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+
+pytestmark = pytest.mark.gpu
+
+WSEED, DSEED, N_FULL, L = 41, 42, 32, 16000
+
+
+@pytest.fixture(scope="module")
+def v6():
+    z = np.load(os.path.join(ROOT, "tests", "golden", "golden_v6.npz"))
+    return {k: z[k] for k in z.files}
+
+
+def _inputs(v6, n):
+    """The fixture's clips [0, n): regenerated, and proven to be the ones the reference saw."""
+    from mi355_wavenet import synth
+    out_len = L - synth.receptive_field(synth.CONFIGS["cfg3"]) + 1
+    rs = np.random.RandomState(DSEED)
+    ids = rs.randint(0, 256, (N_FULL, L))
+    target = rs.randint(0, 256, (N_FULL, out_len))
+    meta = [int(v) for v in v6["cfg5_meta"]]
+    assert meta[:5] == [WSEED, DSEED, N_FULL, L, out_len]
+    assert zlib.crc32(ids.astype(np.int16).tobytes()) == meta[5] and zlib.crc32(target.astype(np.int16).tobytes()) == meta[6]
+    return torch.from_numpy(ids[:n]), torch.from_numpy(target[:n].reshape(-1)), out_len
+
+
+def _model(out_len, precision="fp32"):
+    import wavenet_model
+    from mi355_wavenet import synth
+    cfg = synth.CONFIGS["cfg3"]
+    m = wavenet_model.WaveNetModel(output_length=out_len, **cfg)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.init_weights(cfg, seed=WSEED).items()})
+    m.matrix_precision = precision
+    return m.cuda()
+
+
+def _native_step(m, ids, target):
+    """What bench.py's training legs and WavenetTrainer.train_step run: class indices in, the engine's fused loss, backward."""
+    from mi355_wavenet import training
+    m.zero_grad(set_to_none=True)
+    logits = m.train_forward_indices(ids.cuda())
+    loss = training.cross_entropy(m._wn_train_runner, logits, target.cuda())
+    loss.backward()
+    torch.cuda.synchronize()
+    assert not m.wn_stats()["torch_fallbacks"]
+    grads = {k: (p.grad.detach().cpu().numpy() if p.grad is not None else np.zeros(tuple(p.shape), np.float32)) for k, p in m.named_parameters()}
+    return logits.detach(), float(loss.detach()), grads
+
+
+def _sampled(logits, n, out_len, rows):
+    return logits.view(n, out_len, 256)[:, torch.as_tensor(rows, device=logits.device), :].cpu().numpy()
+
+
+def _digest_devs(ref_d, got_d):
+    out = []
+    for k, r in ref_d.items():
+        if r[0] > 0:
+            g = got_d[k]
+            out.append(max(abs(g[0] - r[0]) / r[0], abs(g[1] - r[1]) / r[1], float(np.abs(g[2:6] - r[2:6]).max()) / r[1], float(np.abs(g[6:] - r[6:]).max()) / r[0]))
+    return np.array(out)
+
+
+def _ref_digests(v6, tag, prefix="d_"):
+    head = "cfg5_%s_%s" % (tag, prefix)
+    return {k[len(head):]: v for k, v in v6.items() if k.startswith(head)}
+
+
+def test_forward_alone_at_config5_size(v6):
+    """wn_forward (model.forward_indices, no autograd) on all 32 clips: the eight stored rows of every clip to 1e-4, every clip's logit norm to 1e-5."""
+    ids, _, out_len = _inputs(v6, N_FULL)
+    m = _model(out_len)
+    with torch.no_grad():
+        y = m.forward_indices(ids.cuda())
+    assert tuple(y.shape) == (N_FULL * out_len, 256)
+    got = _sampled(y, N_FULL, out_len, v6["cfg5_logit_rows"])
+    dev = float(np.abs(got - v6["cfg5_n32_logits"]).max())
+    norms = torch.sqrt((y.view(N_FULL, -1).double() ** 2).sum(dim=1)).cpu().numpy()
+    ndev = float(np.abs(norms / v6["cfg5_n32_logit_norms"] - 1).max())
+    print("cfg5 forward alone, fp32: sampled logits max |d| %.2e (scale %.2f), per-clip norms %.2e relative" % (dev, float(np.abs(v6["cfg5_n32_logits"]).max()), ndev))
+    assert dev <= 1e-4 and ndev <= 1e-5
+    m.matrix_precision = "bf16"
+    with torch.no_grad():
+        yb = m.forward_indices(ids.cuda())
+    noise = v6["cfg5_n32_bf16_noise"]
+    d = _sampled(yb, N_FULL, out_len, v6["cfg5_logit_rows"]).astype(np.float64) - v6["cfg5_n32_logits"]
+    rms, mx = float(np.sqrt((d ** 2).mean())), float(np.abs(d).max())
+    print("cfg5 forward alone, bf16 operands: sampled logits rms %.4f max %.4f vs the fp32 reference (the oracle's orders: rms %s max %s)" % (
+        rms, mx, np.round(noise[:, 0], 4).tolist(), np.round(noise[:, 1], 4).tolist()))
+    assert rms <= 1.5 * noise[:, 0].max() and mx <= 2.0 * noise[:, 1].max()
+    assert m.wn_stats()["native_forward"] == 2 and not m.wn_stats()["torch_fallbacks"]
+
+
+def test_two_clips_native_fp32_vs_the_torch_path_and_the_reference(v6):
+    """N = 2 at the full clip length: native fp32 forward + backward against (a) the facade's torch path -- the reference's conv1d / dilate graph under
+    torch autograd, WN_TORCH_BACKWARD=1, same GPU -- element for element, and (b) the real reference's digests."""
+    import digest as dg
+    ids, target, out_len = _inputs(v6, 2)
+    m = _model(out_len)
+    logits_n, loss_n, g_n = _native_step(m, ids, target)
+    # (a) torch path on the GPU, through the facade's forward() on the one-hot batch like the reference's trainer (wavenet_training.py:64-72)
+    x = torch.zeros(2, 256, L).scatter_(1, ids.view(2, 1, L), 1.0).cuda()
+    os.environ["WN_TORCH_BACKWARD"] = "1"
+    try:
+        m.zero_grad(set_to_none=True)
+        with pytest.warns(RuntimeWarning, match="WN_TORCH_BACKWARD"):
+            out_t = m(x)
+        loss_t = torch.nn.functional.cross_entropy(out_t, target.cuda())
+        loss_t.backward()
+        torch.cuda.synchronize()
+    finally:
+        os.environ.pop("WN_TORCH_BACKWARD", None)
+    dl = float((logits_n - out_t.detach()).abs().max())
+    assert dl <= 1e-4, dl
+    assert abs(loss_n - float(loss_t)) <= 1e-5 * abs(float(loss_t))
+    worst = 0.0
+    for k, p in m.named_parameters():
+        if p.grad is None:
+            assert not g_n[k].any(), k
+            continue
+        gt = p.grad.detach().cpu().numpy()
+        scale = float(np.abs(gt).max())
+        err = float(np.abs(g_n[k] - gt).max())
+        worst = max(worst, err / scale)
+        assert err <= 2e-5 * scale + 1e-12, (k, err, scale)
+    # (b) the real reference
+    ref_l = float(v6["cfg5_n2_loss"][0])
+    assert abs(loss_n - ref_l) <= 1e-5 * ref_l and abs(ref_l - np.log(256.0)) > 0.3   # (an informative loss: not the ln 256 of near-zero logits)
+    dref = float(np.abs(_sampled(logits_n, 2, out_len, v6["cfg5_logit_rows"]) - v6["cfg5_n2_logits"]).max())
+    assert dref <= 1e-4, dref
+    w = dg.compare(_ref_digests(v6, "n2"), dg.digest(g_n), 2e-5)
+    print("cfg5 x 2 clips, fp32: logits vs torch path %.2e, vs the reference's rows %.2e; worst gradient element vs torch path %.2e of its tensor's max; "
+          "digests vs the reference %.2e (%s); loss %.6f" % (dl, dref, worst, w[0], w[1], loss_n))
+
+
+@pytest.mark.parametrize("deterministic", [False, True])
+def test_full_step_fp32_against_the_reference(v6, deterministic):
+    """The whole config-5 step -- 32 clips -- in fp32 against the real reference: loss, 8 x 32 logit rows, per-clip norms, every gradient's digest.
+    Both forms of the row-split reduction (fp32 atomics / ordered partial tiles)."""
+    import digest as dg
+    ids, target, out_len = _inputs(v6, N_FULL)
+    m = _model(out_len)
+    m.deterministic_gradients = deterministic
+    logits, loss, g = _native_step(m, ids, target)
+    ref_l = float(v6["cfg5_n32_loss"][0])
+    dev = float(np.abs(_sampled(logits, N_FULL, out_len, v6["cfg5_logit_rows"]) - v6["cfg5_n32_logits"]).max())
+    norms = torch.sqrt((logits.view(N_FULL, -1).double() ** 2).sum(dim=1)).cpu().numpy()
+    ndev = float(np.abs(norms / v6["cfg5_n32_logit_norms"] - 1).max())
+    assert abs(loss - ref_l) <= 1e-5 * ref_l, (loss, ref_l)
+    assert dev <= 1e-4 and ndev <= 1e-5, (dev, ndev)
+    w = dg.compare(_ref_digests(v6, "n32"), dg.digest(g), 2e-5)
+    print("cfg5 full step, fp32%s: loss %.6f (reference %.6f), logit rows %.2e, norms %.2e, gradient digests %.2e (%s)" % (
+        " deterministic" if deterministic else "", loss, ref_l, dev, ndev, w[0], w[1]))
+
+
+def test_full_step_bf16_within_its_oracles_noise(v6):
+    """The bf16 step at config 5's size.  A rounding to bf16 is a discontinuity (oracle/bf16_step.py says what that does at depth): what can be pinned
+    at 50 layers is the noise LEVEL -- the product's deviation from the reference's fp32 step must not exceed what the oracle's own evaluation orders
+    (exact / fp32 accumulation, regenerated at THIS size: cfg5_n32_bf16_noise) show, factor 1.5 on rms figures and 2 on maxima.  The measured
+    deviations are printed next to the oracle's."""
+    import digest as dg
+    ids, target, out_len = _inputs(v6, N_FULL)
+    m = _model(out_len, "bf16")
+    logits, loss, g = _native_step(m, ids, target)
+    noise = v6["cfg5_n32_bf16_noise"]   # rows: orders; columns: sampled-logit rms, max, |dloss|, digest rms, digest max -- all vs the fp32 reference
+    d = _sampled(logits, N_FULL, out_len, v6["cfg5_logit_rows"]).astype(np.float64) - v6["cfg5_n32_logits"]
+    rms, mx = float(np.sqrt((d ** 2).mean())), float(np.abs(d).max())
+    dloss = abs(loss - float(v6["cfg5_n32_loss"][0]))
+    dv = _digest_devs(_ref_digests(v6, "n32"), dg.digest(g))
+    drms, dmax = float(np.sqrt((dv ** 2).mean())), float(dv.max())
+    print("cfg5 full step, bf16: vs the fp32 reference -- logit rows rms %.4f max %.4f, |dloss| %.5f, gradient digests rms %.4f max %.4f; "
+          "the oracle's orders: %s" % (rms, mx, dloss, drms, dmax, np.round(noise, 4).tolist()))
+    do = _sampled(logits, N_FULL, out_len, v6["cfg5_logit_rows"]).astype(np.float64) - v6["cfg5_n32_bf16_logits"]
+    print("                      vs the bf16 oracle (exact accumulation) -- logit rows rms %.4f max %.4f, loss %.6f vs %.6f" % (
+        float(np.sqrt((do ** 2).mean())), float(np.abs(do).max()), loss, float(v6["cfg5_n32_bf16_loss"][0])))
+    assert rms <= 1.5 * noise[:, 0].max() and mx <= 2.0 * noise[:, 1].max()
+    assert dloss <= max(2.0 * noise[:, 2].max(), 2e-4)
+    assert drms <= 1.5 * noise[:, 3].max() and dmax <= 2.0 * noise[:, 4].max()
+    assert abs(loss - np.log(256.0)) > 0.3
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_deterministic_gradients_are_bit_equal_from_run_to_run(v6, precision):
+    """WN_DETERMINISTIC / model.deterministic_gradients: the row splits' partial tiles added in order (wn_tn_reduce) instead of fp32 atomics -- two runs
+    of the same step give the same bits in every gradient (4 clips at the full length: the same split counts as the full batch's residual / filter-gate
+    products have); the atomics form differs from it only by rounding."""
+    ids, target, out_len = _inputs(v6, 4)
+    m = _model(out_len, precision)
+    m.deterministic_gradients = True
+    _, loss_a, g_a = _native_step(m, ids, target)
+    _, loss_b, g_b = _native_step(m, ids, target)
+    assert loss_a == loss_b
+    for k in g_a:
+        assert np.array_equal(g_a[k], g_b[k]), k
+    m.deterministic_gradients = False
+    _, loss_c, g_c = _native_step(m, ids, target)
+    assert loss_c == loss_a   # (forward and loss are deterministic either way)
+    worst, differ = 0.0, 0
+    for k in g_a:
+        scale = float(np.abs(g_a[k]).max())
+        if scale > 0:
+            worst = max(worst, float(np.abs(g_c[k] - g_a[k]).max()) / scale)
+            differ += int(not np.array_equal(g_c[k], g_a[k]))
+    print("deterministic %s gradients: bit-equal across two runs; the atomics form differs in %d of %d tensors, by at most %.1e of a tensor's max" % (
+        precision, differ, len(g_a), worst))
+    assert worst <= 2e-5

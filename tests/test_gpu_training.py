@@ -162,6 +162,20 @@ def test_packed_layout_matches_the_c_side():
         back = r.unpack(flat)
         for k, v in p.items():
             assert torch.equal(back[k].reshape(v.shape), v), k
+        # the step's own path: the tensors themselves in (wn_train_pack: addresses in the kernel arguments), one view per gradient out (wn_train_unpack_grads)
+        by_key = {k: ([v] if k in training.SINGLE_KEYS else list(v.unbind(0))) for k, v in p.items()}
+        by_key = {k: [t.contiguous() for t in v] for k, v in by_key.items()}
+        nflat = r.pack_native(by_key)
+        torch.cuda.synchronize()
+        assert torch.equal(nflat, flat)
+        gback = r.unpack_native(flat, by_key)
+        torch.cuda.synchronize()
+        for k, ts in by_key.items():
+            for i, t in enumerate(ts):
+                if k in ("res_w", "res_b") and i == NL - 1:
+                    assert gback[k][i] is None   # (the last layer's residual conv never reaches the loss)
+                else:
+                    assert torch.equal(gback[k][i], t), (k, i)
         eng.close()
 
 
@@ -645,6 +659,70 @@ def test_fused_adam_follows_torch_adam(clip, wd):
     oc = torch.optim.Adam(mb.parameters(), lr=3e-3, weight_decay=wd)
     oc.load_state_dict(ob.state_dict())          # FusedAdam's state IS Adam's
     assert int(next(iter(oc.state.values()))["step"]) == 6
+
+
+@pytest.mark.parametrize("beta1", [0.9, 0.4])
+def test_fused_adam_clips_all_parameter_groups_together(beta1):
+    """Two parameter groups (weights with weight decay, biases without: the usual split) and gradient clipping: clip_grad_norm_ over
+    model.parameters() takes ONE norm over all gradients.  FusedAdam runs a norm pass per group into one accumulator (WN_ADAM_NORM_ONLY / _KEEP), then
+    steps every group on the total (WN_ADAM_NORM_GIVEN) -- round 5 took a norm per group.  Against clip_grad_norm_ + torch.optim.Adam with
+    the same groups, four steps; beta1 = 0.4 also takes ATen's other lerp branch (weight 1 - beta1 >= 0.5: g - (g - m) * beta1).  Groups with
+    different max_grad_norm are refused."""
+    import copy
+    from mi355_wavenet.optim import FusedAdam
+    ma = _model(True, layers=3, blocks=2, ch=32, skip=64, end=64, out_len=8, seed=31, gain=2.0)
+    mb = copy.deepcopy(ma)
+
+    def groups(m):
+        w = [p for k, p in m.named_parameters() if k.endswith("weight")]
+        b = [p for k, p in m.named_parameters() if k.endswith("bias")]
+        return [{"params": w, "weight_decay": 0.01}, {"params": b, "weight_decay": 0.0, "lr": 1e-3}]
+    oa = torch.optim.Adam(groups(ma), lr=3e-3, betas=(beta1, 0.999))
+    ob = FusedAdam(groups(mb), lr=3e-3, betas=(beta1, 0.999))
+    x, target = _batch(ma, 2, 0, seed=32)
+    clip = 0.05
+    for it in range(4):
+        for m, o in ((ma, oa), (mb, ob)):
+            o.zero_grad(set_to_none=True)
+            torch.nn.functional.cross_entropy(m(x), target).backward()
+        for pa, pb in zip(ma.parameters(), mb.parameters()):
+            if pa.grad is not None:
+                pb.grad.copy_(pa.grad)
+        total = torch.nn.utils.clip_grad_norm_(ma.parameters(), clip)
+        assert float(total) > clip     # (the clipping is active: a per-group norm would scale the two groups differently)
+        oa.step()
+        ob.step(max_grad_norm=clip)
+        assert abs(float(ob.last_total_norm) - float(total)) <= 1e-5 * float(total)
+        for (ka, pa), (kb, pb) in zip(ma.named_parameters(), mb.named_parameters()):
+            assert float((pa - pb).abs().max()) <= 2e-6 * max(float(pa.abs().max()), 1e-3), (it, ka)
+            if pa.grad is not None:
+                assert float((pa.grad - pb.grad).abs().max()) <= 2e-6 * float(pa.grad.abs().max()) + 1e-30, ka
+                for sk in ("exp_avg", "exp_avg_sq"):
+                    a, b = oa.state[pa][sk], ob.state[pb][sk]
+                    assert float((a - b).abs().max()) <= 2e-6 * float(a.abs().max()) + 1e-30, (ka, sk)
+    oc = FusedAdam([{"params": [p for p in mb.parameters()][:3], "max_grad_norm": 1.0}, {"params": [p for p in mb.parameters()][3:], "max_grad_norm": 2.0}])
+    with pytest.raises(ValueError, match="TOGETHER"):
+        oc.step()
+
+
+def test_fused_adam_leaves_the_current_device_and_propagates_a_nan_norm():
+    """wn_adam_step restores the caller's current HIP device (torch's is process state), and a non-finite total norm poisons the clipped gradients the
+    way torch.clamp(max_norm / (norm + 1e-6), max=1.0) does (a NaN coefficient stays NaN)."""
+    from mi355_wavenet.optim import FusedAdam
+    p = torch.nn.Parameter(torch.ones(5000, device="cuda"))
+    p.grad = torch.full_like(p, 0.5)
+    p.grad[17] = float("nan")
+    o = FusedAdam([p], lr=1e-2)
+    before = torch.cuda.current_device()
+    o.step(max_grad_norm=1.0)
+    torch.cuda.synchronize()
+    assert torch.cuda.current_device() == before
+    assert bool(torch.isnan(p.grad).all()) and bool(torch.isnan(p).all())
+    q = torch.nn.Parameter(torch.ones(5000, device="cuda"))
+    q.grad = torch.full_like(q, 0.5)
+    q.grad[17] = float("nan")
+    torch.nn.utils.clip_grad_norm_([q], 1.0)
+    assert bool(torch.isnan(q.grad).all())   # (torch's own behaviour, the thing mirrored)
 
 
 def test_trainer_with_the_fused_optimiser_follows_the_default_one():

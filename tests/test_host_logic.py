@@ -3,6 +3,9 @@ argument shaping, default first sample, continuation without reset, zero-sample 
 export -- against the C oracle, with the host-memory test double of include/wn_abi.h (tests/double) standing in for the
 device.  The double IS the oracle behind the ABI, so nothing here says anything about the HIP kernels: those are checked on
 the GPU (tests/test_gpu_parity.py)."""
+import os
+import sys
+
 import numpy as np
 
 import c_oracle
@@ -10,6 +13,8 @@ import restated
 from double_lib import double_backend, double_library
 from mi355_wavenet import engine
 from parity_common import check_engine, make_case
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_engine_wrapper_round_trip_multi_stream():
@@ -114,3 +119,33 @@ def test_engine_passes_the_no_padding_flag_and_the_abi_rejects_other_reserved_bi
                            cfg["end_channels"], 256, 2, 0, 1, 0, 0, 0)
         c.reserved[0], c.reserved[1], c.reserved[2] = bad
         assert dll.wn_create(ctypes.byref(c), ctypes.byref(h)) == _abi.WN_E_BADARG
+
+
+def test_bench_reducer_on_fake_eight_rank_stats():
+    """bench.py's reduction of an N-rank run (the first multi-GPU line must explain itself).  Fed fake 8-rank records: weak scaling =
+    64 streams on every rank, strong = BASELINE configs[3]'s 512 streams sharded; `value` is the whole job against the SLOWEST rank's wall clock,
+    `value_per_gpu` the metric's per-GPU figure, and every rank reports its own rate (a straggler is visible)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    import json
+    assert bench.BASELINE_METRIC == json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
+    samples, steps = 16000, 5
+    ms = [930.0, 931.0, 929.5, 930.2, 990.0, 930.1, 930.3, 929.9]   # rank 4 is a straggler
+    per_rank = [{"rank": r, "kernel_ms": ms[r] - 6.0, "gather_ms": 1.0, "facade_ms": ms[r]} for r in (3, 0, 7, 1, 2, 6, 5, 4)]   # (any order)
+    fac_wall = max(ms) * steps * 1e-3
+    eng_wall = (max(ms) - 5.0) * steps * 1e-3
+    weak = bench.reduce_ranks(per_rank, bench.streams_by_rank("weak", 64, 8), samples, steps, fac_wall, eng_wall)
+    assert weak["total_streams"] == 512
+    assert abs(weak["value"] - 512 * samples / 0.990) < 1e-6 * weak["value"]
+    assert abs(weak["value_per_gpu"] * 8 - weak["value"]) < 1e-9 * weak["value"]
+    assert [r["rank"] for r in weak["per_rank"]] == list(range(8)) and all(r["streams"] == 64 for r in weak["per_rank"])
+    assert abs(weak["per_rank"][0]["samples_per_s"] - 64 * samples / 0.930) < 1.0
+    assert weak["per_rank"][4]["samples_per_s"] < 0.95 * weak["per_rank"][0]["samples_per_s"]      # the straggler shows
+    assert sum(r["samples_per_s"] for r in weak["per_rank"]) > weak["value"]                       # ... and is what bounds the job
+    strong = bench.reduce_ranks(per_rank, bench.streams_by_rank("strong", 64, 8), samples, steps, fac_wall, eng_wall)
+    assert strong["total_streams"] == 512 and [r["streams"] for r in strong["per_rank"]] == [64] * 8
+    assert bench.streams_by_rank("strong", 64, 3) == [171, 171, 170] or sum(bench.streams_by_rank("strong", 64, 3)) == 512
+    one = bench.reduce_ranks([{"rank": 0, "kernel_ms": 922.0, "gather_ms": 0.0, "facade_ms": 928.0}], [64], samples, 20, 0.928 * 20, 0.922 * 20)
+    assert abs(one["value"] - one["value_per_gpu"]) < 1e-9 and abs(one["value"] - 64 * samples / 0.928) < 1e-3

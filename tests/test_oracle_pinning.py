@@ -5,6 +5,9 @@
 Tolerances are stated where used.  fp32 noise floor of the reference itself (fp32 vs fp64 evaluation of
 the same weights) is ~2e-7..7e-7 at these logit scales.
 """
+import os
+import sys
+
 import numpy as np
 import pytest
 import torch
@@ -13,6 +16,8 @@ import c_oracle
 import ref_shim
 import restated
 from mi355_wavenet import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 GEN_CASES = {"tiny": "tiny", "tiny_bias": "tiny_bias", "cfg1": "cfg1", "cfg1_seed128": "cfg1",
              "cfg2": "cfg2", "cfg3": "cfg3"}  # cfg2 / cfg3: golden_v2.npz, 640 / 700 given samples (the d=512 queues wrap)
@@ -203,3 +208,39 @@ def test_bf16_step_fixture_is_reproducible():
         bf16_step.ACCUMULATE = "exact"
     between = float(np.linalg.norm(logits32 - logits))
     assert 0.4 * float(g5["bf16_cfg2_noise"][0][0]) < between < 2.0 * float(g5["bf16_cfg2_noise"][0][0])
+
+
+
+def test_config5_fixture_inputs_are_regenerated_bit_for_bit():
+    """golden_v6.npz (BASELINE configs[4] at its own size) stores no inputs: the GPU tests and bench.py regenerate them from RandomState seeds.  The CRCs
+    the generator recorded next to the reference's results prove they are the arrays the reference saw."""
+    import zlib
+    sys.path.insert(0, os.path.join(ROOT, "pytorch-wavenet_amd"))
+    from mi355_wavenet import synth
+    z = np.load(os.path.join(ROOT, "tests", "golden", "golden_v6.npz"))
+    wseed, dseed, N, L, out_len, crc_ids, crc_tgt = [int(v) for v in z["cfg5_meta"]]
+    assert (N, L) == (32, 16000) and out_len == L - synth.receptive_field(synth.CONFIGS["cfg3"]) + 1 == 10885
+    rs = np.random.RandomState(dseed)
+    ids = rs.randint(0, 256, (N, L))
+    target = rs.randint(0, 256, (N, out_len))
+    assert zlib.crc32(ids.astype(np.int16).tobytes()) == crc_ids and zlib.crc32(target.astype(np.int16).tobytes()) == crc_tgt
+    assert abs(float(z["cfg5_n32_loss"][0]) - np.log(256.0)) > 0.3    # informative weights: not the ln 256 of near-zero logits
+    assert z["cfg5_n32_logits"].shape == (32, len(z["cfg5_logit_rows"]), 256) and z["cfg5_n32_bf16_noise"].shape[1] == 5
+
+
+@needs_ref
+@pytest.mark.reference
+def test_config5_fixture_is_reproducible_from_the_live_reference():
+    """Two clips of golden_v6.npz at the full clip length (16 000 samples, output_length 10 885) re-run through the LIVE reference (~10 s): loss, the
+    stored logit rows and every gradient digest come back (same machine, same torch: to fp32 reduction-order noise of the CPU GEMMs)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import digest as dg
+    import make_golden as mg
+    mdl, _, _ = ref_shim.load()
+    z = np.load(os.path.join(ROOT, "tests", "golden", "golden_v6.npz"))
+    loss, _, samp, norms, g = mg._ref_cfg5(mdl, 2, 2)
+    assert abs(loss - float(z["cfg5_n2_loss"][0])) <= 1e-6 * loss
+    assert float(np.abs(samp - z["cfg5_n2_logits"]).max()) <= 2e-5
+    assert float(np.abs(norms / z["cfg5_n2_logit_norms"] - 1).max()) <= 1e-6
+    head = "cfg5_n2_d_"
+    dg.compare({k[len(head):]: z[k] for k in z.files if k.startswith(head)}, dg.digest(g), 2e-5)
