@@ -329,9 +329,14 @@ def cfg5_verify(m, v6, idx, target, out_len, clip0, n_total, precision):
 
 
 def cfg5_verify_grads(v6, g, precision):
+    """Gradient digests of the full-batch step against the fixture.  bf16 step: against the reference's fp32 digests, inside the spread of the bf16 oracle's
+    evaluation orders.  fp32 step: against the reference's FLOAT64 evaluation, no further from it than the reference's own fp32 step is -- at this size
+    a few hundred of the head's 267 M ReLU inputs lie within fp32 noise of zero, two correct fp32 evaluations disagree on those masks, and each flip moves
+    the weight gradients by ~1e-3 of a tensor's largest element (tests/test_gpu_train_cfg5.py pins the gradients at 2e-5 on the rows whose masks are decided)."""
     sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
     import digest as dg
-    head = "cfg5_n32_d_"
+    bf16 = precision != "fp32"
+    head = "cfg5_n32_d_" if bf16 else "cfg5_n32_f64_d_"
     ref_d = {k[len(head):]: v for k, v in v6.items() if k.startswith(head)}
     got_d = dg.digest(g)
     devs = []
@@ -341,11 +346,16 @@ def cfg5_verify_grads(v6, g, precision):
             devs.append(max(abs(q[0] - r[0]) / r[0], abs(q[1] - r[1]) / r[1], float(np.abs(q[2:6] - r[2:6]).max()) / r[1], float(np.abs(q[6:] - r[6:]).max()) / r[0]))
     devs = np.array(devs)
     drms, dmax = float(np.sqrt((devs ** 2).mean())), float(devs.max())
-    noise = v6["cfg5_n32_bf16_noise"]
-    ok = (drms <= 1.5 * noise[:, 3].max() and dmax <= 2.0 * noise[:, 4].max()) if precision != "fp32" else dmax <= 2e-5
-    return ok, {"gradient_digest_dev_rms": float("%.3g" % drms), "gradient_digest_dev_max": float("%.3g" % dmax),
-                "bar": ("inside the spread of the bf16 oracle's evaluation orders at this size (rms x1.5, max x2: golden_v6 cfg5_n32_bf16_noise)" if precision != "fp32"
-                        else "logit rows 1e-4, loss 1e-5, gradient digests 2e-5 against the real reference (golden_v6)")}
+    if bf16:
+        noise = v6["cfg5_n32_bf16_noise"]
+        ok = drms <= 1.5 * noise[:, 3].max() and dmax <= 2.0 * noise[:, 4].max()
+        bar = "gradient digests vs the real reference's fp32 step: inside the spread of the bf16 oracle's evaluation orders at this size (rms x1.5, max x2: golden_v6 cfg5_n32_bf16_noise)"
+    else:
+        noise = v6["cfg5_n32_fp32_noise"]
+        ok = drms <= 2.5 * noise[0] and dmax <= 2.5 * noise[1]
+        bar = ("logit rows 1e-4, loss 1e-5 against the real reference; gradient digests vs the reference's float64 evaluation: no further than the reference's own fp32 "
+               "step is (rms %.1e max %.1e), times 2.5 -- undecidable ReLU masks, see tests/test_gpu_train_cfg5.py" % (noise[0], noise[1]))
+    return ok, {"gradient_digest_dev_rms": float("%.3g" % drms), "gradient_digest_dev_max": float("%.3g" % dmax), "bar": bar}
 
 
 def train_step_cfg5(device, N=32, L=16000, reps=3, precision="fp32"):
@@ -362,6 +372,10 @@ def train_step_cfg5(device, N=32, L=16000, reps=3, precision="fp32"):
     opt = FusedAdam(m.parameters(), lr=1e-4)   # torch.optim.Adam's step as the engine's optimiser kernels (mi355_wavenet/optim.py, pinned to torch's in tests/test_gpu_training.py)
     R = D = 128; S = 512; E = 256; C = 256
     need, fwd = out_len, 0
+    for d in reversed([2 ** (i % 10) for i in range(50)]):
+        fwd += 2 * N * need * (2 * R * 2 * D + D * R) + 2 * N * out_len * D * S
+        need += d
+    fwd += 2 * N * out_len * (S * E + E * C)
     from mi355_wavenet import training
 
     def step():  # WavenetTrainer.train_step: forward, the engine's fused loss (WavenetTrainer._loss), backward, optimizer

@@ -15,7 +15,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "mi355_wavenet", "libwn_mi355.so")
-SOURCES = [os.path.join(CSRC, "wn_runtime.hip")]
+SOURCES = [os.path.join(CSRC, "wn_runtime.hip"), os.path.join(CSRC, "wn_stacked.hip")]
+# translation units built WITHOUT ALIGN_FLAGS (below): the stacked-layer kernels lose 1.2-1.3 % with them (csrc/wn_stacked_table.h)
+UNALIGNED_SOURCES = {os.path.join(CSRC, "wn_stacked.hip")}
 DEPS = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h", ".inl"))) + [os.path.join(ROOT, "include", "wn_abi.h")]
 
 
@@ -73,9 +75,10 @@ def check_hand_scheduled_registers(so, objdump=None):
         local = shutil.copy(so, os.path.join(tmp, "lib.so"))
         subprocess.check_call([objdump, "--offloading", local], cwd=tmp, stdout=subprocess.DEVNULL)
         co = [f for f in os.listdir(tmp) if "gfx950" in f]
-        if len(co) != 1:
-            raise RuntimeError("expected one gfx950 code object in %s, found %r" % (so, co))
-        dis = subprocess.check_output([objdump, "-d", "--symbolize-operands", os.path.join(tmp, co[0])]).decode()   # (branch targets as labels <Ln>: rule 4 follows them)
+        if len(co) != len(SOURCES) and len(co) != 1:   # one code object per translation unit (a variant built in one hipcc call with several sources has as many)
+            raise RuntimeError("expected %d gfx950 code object(s) in %s, found %r" % (len(SOURCES), so, co))
+        # (branch targets as labels <Ln>: rule 4 follows them; the units' disassemblies one behind the other -- every rule is per kernel)
+        dis = "\n".join(subprocess.check_output([objdump, "-d", "--symbolize-operands", os.path.join(tmp, c)]).decode() for c in sorted(co))
     reserved = set(range(RESERVED_FIRST, RESERVED_LAST + 1))
     is_res = lambda tok: bool(_regs(tok) & reserved)  # noqa: E731
     seen, current, prev = 0, None, ""
@@ -237,8 +240,17 @@ def _regs(text):
 ALIGN_FLAGS = ["-mllvm", "-align-all-nofallthru-blocks=6"]
 
 
+def _compile_all(cmds):
+    """The translation units' compiles, side by side; raises if one fails."""
+    procs = [subprocess.Popen(c) for c in cmds]
+    rcs = [p.wait() for p in procs]
+    for c, rc in zip(cmds, rcs):
+        if rc:
+            raise subprocess.CalledProcessError(rc, c)
+
+
 def build_hip(force=False, verbose=False, extra_flags=()):
-    """ONE compile, in the form whose hand-scheduled loads carry the five wait states (the source's default WN_AP_SGPR_HAZARD): correct whatever the
+    """One compile per translation unit, in the form whose hand-scheduled loads carry the five wait states (the source's default WN_AP_SGPR_HAZARD): correct whatever the
     register allocator does with the polls' base pointers.  (Round 4 compiled a form without them first and let the disassembly decide; round 5
     measured both forms of the same source on one box -- 64 streams of cfg3 1.094-1.101 M with the wait states against 1.068-1.113 M without,
     single stream 19.7-21.1 k either way (the spread is the box's, not the form's) -- and dropped the second form: nothing to gain, one hazard less to
@@ -247,11 +259,24 @@ def build_hip(force=False, verbose=False, extra_flags=()):
     if not force and not _stale(OUT, DEPS):
         return OUT
     tmp_out = OUT + ".tmp"
-    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
-           "-Wno-unused-function", "-Wno-inline-asm", *ALIGN_FLAGS, *extra_flags, "-o", tmp_out] + SOURCES
+    common = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-inline-asm", *extra_flags]
+    objs, cmds = [], []
+    for src in SOURCES:   # one object per translation unit (their flags differ: ALIGN_FLAGS), compiled side by side, then one link
+        obj = os.path.join(os.path.dirname(OUT), "." + os.path.basename(src) + ".o")
+        cmds.append(common + ([] if src in UNALIGNED_SOURCES else ALIGN_FLAGS) + ["-c", src, "-o", obj])
+        objs.append(obj)
+        if verbose:
+            print(" ".join(cmds[-1]))
+    _compile_all(cmds)
+    link = [hipcc_path(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp_out] + objs
     if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+        print(" ".join(link))
+    try:
+        subprocess.check_call(link)
+    finally:
+        for obj in objs:
+            if os.path.exists(obj):
+                os.remove(obj)
     try:
         check_hand_scheduled_registers(tmp_out)   # a library that breaks the reservation is never installed
     except Exception:

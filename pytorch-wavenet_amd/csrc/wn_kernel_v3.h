@@ -64,8 +64,16 @@
 #define WN_V3_COMPILER_VGPRS 152  // v152-v167: request sets of the input poll / the queue group's tap FIFO (see wn_ap_*, wn_q_*)
 // ---- experiment switches.  A product build (build.py) leaves every one of them at its default; setting one requires -DWN_EXPERIMENT,
 // which build.py never passes (tools/ builds the A/B variants): a library with wrong-on-purpose timing ablations cannot ship by accident.
-#if !defined(WN_EXPERIMENT) && (defined(WN_V3_SKIP_SLEEP) || defined(WN_V3_ABL) || defined(WN_V3_PAIR_ROWS) || defined(WN_V3_PRIO) || defined(WN_V3_LAST_SKIP_PRIO) || defined(WN_V3_SKIP_CHAINS) || defined(WN_V3_FG_CHAINS) || defined(WN_V3_SKIP_SLOTS) || defined(WN_V3_TAP_AT_A) || defined(WN_V3_FAST_GATE) || defined(WN_V3_KPACK))
+#if !defined(WN_EXPERIMENT) && (defined(WN_V3_SKIP_DEFER) || defined(WN_V3_QUEUE_DEFER) || defined(WN_V3_SKIP_SLEEP) || defined(WN_V3_ABL) || defined(WN_V3_PAIR_ROWS) || defined(WN_V3_PRIO) || defined(WN_V3_LAST_SKIP_PRIO) || defined(WN_V3_SKIP_CHAINS) || defined(WN_V3_FG_CHAINS) || defined(WN_V3_SKIP_SLOTS) || defined(WN_V3_TAP_AT_A) || defined(WN_V3_FAST_GATE) || defined(WN_V3_KPACK))
 #error "WN_V3_* experiment switches need -DWN_EXPERIMENT"
+#endif
+#ifndef WN_V3_SKIP_DEFER
+#define WN_V3_SKIP_DEFER 0   // two-streams-per-item form: s_sleep count (64 clocks each) at the head of the skip group's chunk behind barrier B (not the last
+                             // layer's: its lanes are the head's input) -- the chunk then runs while the critical waves wait for the next token instead of next
+                             // to their residual dot, the piece of the window that is on the token's path
+#endif
+#ifndef WN_V3_QUEUE_DEFER
+#define WN_V3_QUEUE_DEFER 0  // ... and the same in front of the queue group's chunk behind barrier B (push, tap-0 dot of the next timestep)
 #endif
 #ifndef WN_V3_SKIP_SLEEP
 #define WN_V3_SKIP_SLEEP 0  // s_sleep between the skip group's poll retries (the skip lane is not latency critical; fewer polls on the fabric)
@@ -897,6 +905,7 @@ static __device__ void wn_v3_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
             const uint32_t tag = (uint32_t)(e + 1);
             for (int s = 0; s < ns; s += G, ++item) {
                 if (wn_barrier_failed(cx, failflag)) return;  // ---- B(i): z of this item staged
+                if (WN_V3_SKIP_DEFER > 0 && G >= 2 && l < NL - 1) __builtin_amdgcn_s_sleep(WN_V3_SKIP_DEFER);
                 const bool stamp = r.prof && item < r.prof_items && tid == 256;
                 const long long t0 = stamp ? (long long)wall_clock64() : 0;
                 const int s2 = s + G < ns ? s + G : 0;  // the coming item's first stream
@@ -1205,6 +1214,7 @@ static __device__ void wn_v3_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
                 hx[0] = xv;
             }
             if (wn_barrier_failed(cx, failflag)) return;  // ---- B(i): the tap is staged
+            if (WN_V3_QUEUE_DEFER > 0 && G >= 2) __builtin_amdgcn_s_sleep(WN_V3_QUEUE_DEFER);
             const long long t1 = stamp ? (long long)wall_clock64() : 0;
             // ---- tap-0 half of the dilated conv for the NEXT timestep of this stream, parked for the critical group
             if (!(WN_V3_ABL & 2)) {

@@ -32,7 +32,9 @@
 
 #include "wn_kernel_v3.h"
 
-#define WN_THREADS_V4 512
+#ifndef WN_THREADS_V4
+#define WN_THREADS_V4 512   // (also wn_stacked_table.h: the host side plans with it)
+#endif
 
 template <int R_, int D_, int S_>
 struct WnV4Shape {

@@ -354,31 +354,57 @@ def cfg5_inputs(N=CFG5["N"], L=CFG5["L"], dseed=CFG5["dseed"]):
     return ids[:N], target[:N].reshape(-1), out_len
 
 
-def _ref_cfg5(mdl, clips, chunk):
-    """The real reference on clips [0, clips): returns (loss, chunk losses, sampled logits, per-clip logit norms, gradients)."""
+def _ref_cfg5(mdl, clips, chunk, double=False, ignore=None, record_tau=None):
+    """The real reference on clips [0, clips): returns (loss, chunk losses, sampled logits, per-clip logit norms, gradients[, ambiguous rows]).
+    double: the reference's own code in float64 (model.double()): the truth its fp32 arithmetic approximates.  ignore: bool (clips, out_len) -- those rows
+    get F.cross_entropy's ignore_index (-100) as their target.  record_tau: also return the rows (clip, position) at which a ReLU input of the head
+    (wavenet_model.py:167-168: the skip sum, end_conv_1's output) lies within record_tau of zero -- the rows whose ReLU mask two fp32 evaluations can
+    disagree on."""
     import torch.nn.functional as F
     import digest as dg
     cfg = synth.CONFIGS[CFG5["cname"]]
     ids, target, out_len = cfg5_inputs(clips)
     m = build_ref_model(mdl, cfg, CFG5["wseed"], output_length=out_len)
+    if double:
+        m = m.double()
     L = ids.shape[1]
     n_chunks = (clips + chunk - 1) // chunk
     assert clips % chunk == 0
-    losses, samples, norms = [], [], []
+    tgt = target.reshape(clips, out_len).copy()
+    if ignore is not None:
+        tgt[ignore] = -100
+    n_valid = int((tgt >= 0).sum())
+    losses, samples, norms, amb = [], [], [], []
+    real_relu = F.relu
     for c in range(n_chunks):
         sl = slice(c * chunk, (c + 1) * chunk)
-        x = torch.zeros(chunk, 256, L)
+        x = torch.zeros(chunk, 256, L, dtype=torch.float64 if double else torch.float32)
         x.scatter_(1, torch.from_numpy(ids[sl]).view(chunk, 1, L), 1.)
-        y = m(x)                                                                                       # wavenet_model.py:186-196
-        loss = F.cross_entropy(y.squeeze(), torch.from_numpy(target.reshape(clips, out_len)[sl].reshape(-1)))   # wavenet_training.py:69
-        (loss / n_chunks).backward()
+        seen = []
+        if record_tau is not None:
+            def spy(v, *a, **k):
+                seen.append((v.detach()[:, :, -out_len:].abs() < record_tau).any(dim=1))   # (n, out_len): any channel of this ReLU input near zero
+                return real_relu(v, *a, **k)
+            F.relu = spy
+        try:
+            y = m(x)                                                                                   # wavenet_model.py:186-196
+        finally:
+            F.relu = real_relu
+        if record_tau is not None:
+            assert len(seen) == 2, len(seen)   # F.relu(skip), F.relu(end_conv_1(x))
+            amb.append((seen[0] | seen[1]).numpy())
+        t_c = torch.from_numpy(tgt[sl].reshape(-1))
+        # F.cross_entropy's mean runs over the rows that are not ignored: chunk sums / the batch's valid rows == the batch's mean
+        loss = F.cross_entropy(y.squeeze(), t_c, reduction="sum") / n_valid                          # wavenet_training.py:69 (mean over the batch)
+        loss.backward()
         yy = y.detach().numpy().reshape(chunk, out_len, 256)
         samples.append(yy[:, dg.logit_rows(out_len), :].astype(np.float32))
         norms.append(np.sqrt((yy.astype(np.float64) ** 2).sum(axis=(1, 2))))
-        losses.append(float(loss))
-        print("  reference chunk %d/%d loss %.6f" % (c + 1, n_chunks, losses[-1]), flush=True)
+        losses.append(float(loss.detach()))
+        print("  reference%s chunk %d/%d loss share %.6f" % (" (float64)" if double else "", c + 1, n_chunks, losses[-1]), flush=True)
     g = {k: (p.grad.numpy().copy() if p.grad is not None else np.zeros(tuple(p.shape), dtype=np.float32)) for k, p in m.named_parameters()}
-    return float(np.mean(losses)), np.array(losses), np.concatenate(samples), np.concatenate(norms), g
+    out = (float(np.sum(losses)), np.array(losses), np.concatenate(samples), np.concatenate(norms), g)
+    return out + (np.concatenate(amb),) if record_tau is not None else out
 
 
 def _bf16_cfg5(clips, order, chunk=2):
@@ -454,6 +480,38 @@ def main_v6():
                 for k, v in d.items():
                     out["cfg5_%s_bf16_d_%s" % (tag, k)] = v
         out["cfg5_%s_bf16_noise" % tag] = np.array(noise, dtype=np.float64)   # rows: the orders; columns: sampled-logit rms, max, |dloss|, digest rms, digest max (all vs the fp32 reference)
+        np.savez_compressed(path, **out)
+    # ---- what fp32 can and cannot pin at this size.  The head has two ReLUs (wavenet_model.py:167-168) on 32 x 10 885 rows x (512 + 256) channels = 267 M
+    # pre-activations; where one lies within fp32 noise of zero, two correct fp32 evaluations disagree on its mask, and the weight gradients change by that
+    # row's whole contribution -- ~1e-3 of a tensor's largest element per flip.  Measured: the reference's OWN fp32 gradients differ from its float64
+    # evaluation by 7e-3 from output_length ~3000 up (5e-6 below ~600), and so does any other fp32 implementation (tools/debug_grad_scaling.py).
+    # (a) "n32r": the rows with a ReLU input within TAU of zero (either ReLU, any channel: a few per cent) get ignore_index as their target -- no gradient
+    #     flows through an ambiguous mask, and every gradient is pinned at 2e-5 again;  (b) "n32 f64": the reference's code in float64 on the plain targets --
+    #     the truth -- and how far its fp32 evaluation lands from it: the bar for the plain step.
+    TAU = 2e-4
+    if "cfg5_n32r_loss" not in out and "--no-robust" not in sys.argv:
+        print("cfg5 n32: ambiguous ReLU rows of the real reference (tau %g)" % TAU, flush=True)
+        amb = _ref_cfg5(mdl, CFG5["N"], CFG5["chunk"], record_tau=TAU)[5]
+        print("cfg5 n32r: %d of %d rows ignored" % (int(amb.sum()), amb.size), flush=True)
+        loss, losses, samp, norms, g = _ref_cfg5(mdl, CFG5["N"], CFG5["chunk"], ignore=amb)
+        out["cfg5_n32r_ignore"] = np.packbits(amb.reshape(-1))
+        out["cfg5_n32r_tau"] = np.array([TAU])
+        out["cfg5_n32r_loss"] = np.array([loss], dtype=np.float64)
+        for k, v in dg.digest(g).items():
+            out["cfg5_n32r_d_%s" % k] = v
+        np.savez_compressed(path, **out)
+        print("cfg5 n32r: loss %.6f" % loss, flush=True)
+    if "cfg5_n32_fp32_noise" not in out and "--no-f64" not in sys.argv:
+        print("cfg5 n32: the reference in float64", flush=True)
+        loss, losses, samp, norms, g = _ref_cfg5(mdl, CFG5["N"], 2, double=True)
+        d64 = dg.digest(g)
+        for k, v in d64.items():
+            out["cfg5_n32_f64_d_%s" % k] = v
+        out["cfg5_n32_f64_loss"] = np.array([loss], dtype=np.float64)
+        ref_d = {k[len("cfg5_n32_d_"):]: out[k] for k in out if k.startswith("cfg5_n32_d_")}
+        dv = devs(d64, ref_d)   # the fp32 reference measured against the float64 truth
+        out["cfg5_n32_fp32_noise"] = np.array([float(np.sqrt((dv ** 2).mean())), float(dv.max()), abs(loss - float(out["cfg5_n32_loss"][0]))])
+        print("cfg5 n32: the reference's fp32 step vs its float64 evaluation: gradient digests rms %.2e max %.2e, |dloss| %.1e" % tuple(out["cfg5_n32_fp32_noise"]), flush=True)
         np.savez_compressed(path, **out)
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes;", len(out), "arrays")

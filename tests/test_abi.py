@@ -221,9 +221,10 @@ def test_reserved_poll_registers_belong_to_the_hand_scheduled_blocks_only(tmp_pa
                        "v_cmp_eq_u32_e64 s[30:31], s5, v3", "global_load_dword v5, v[6:7], off"]) == 1   # (no SGPR operand: nothing to wait for)
 
 
-def test_build_is_one_compile_in_the_safe_form_and_installs_nothing_the_check_refuses(monkeypatch, tmp_path):
-    """build_hip compiles ONCE, in the source's default form (five wait states in front of every hand-scheduled load: no -DWN_AP_SGPR_HAZARD on the
-    command line), with the branch-target alignment flag; the disassembly check runs on the result and a library it refuses is never installed
+def test_build_compiles_each_unit_once_in_the_safe_form_and_installs_nothing_the_check_refuses(monkeypatch, tmp_path):
+    """build_hip compiles every translation unit ONCE, in the source's default form (five wait states in front of every hand-scheduled load: no
+    -DWN_AP_SGPR_HAZARD on the command line) -- the runtime unit with the branch-target alignment flag, the stacked-layer kernels' unit without it
+    (round 6: csrc/wn_stacked_table.h) --, links them once; the disassembly check runs on the result and a library it refuses is never installed
     (nothing is left behind either)."""
     import sys
     sys.path.insert(0, os.path.join(ROOT, "pytorch-wavenet_amd"))
@@ -231,10 +232,15 @@ def test_build_is_one_compile_in_the_safe_form_and_installs_nothing_the_check_re
     out = tmp_path / "libwn_mi355.so"
     monkeypatch.setattr(build, "OUT", str(out))
     monkeypatch.setattr(build, "_stale", lambda *a: True)
-    calls, verdicts = [], []
+    compiles, links, verdicts = [], [], []
 
-    def fake_compile(cmd, **kw):
-        calls.append(list(cmd))
+    def fake_compile_all(cmds):
+        for cmd in cmds:
+            compiles.append(list(cmd))
+            open(cmd[cmd.index("-o") + 1], "wb").write(b"x")
+
+    def fake_link(cmd, **kw):
+        links.append(list(cmd))
         open(cmd[cmd.index("-o") + 1], "wb").write(b"x")
 
     def fake_check(path, objdump=None):
@@ -243,16 +249,23 @@ def test_build_is_one_compile_in_the_safe_form_and_installs_nothing_the_check_re
             raise RuntimeError(v)
         return 11
 
-    monkeypatch.setattr(build.subprocess, "check_call", fake_compile)
+    monkeypatch.setattr(build, "_compile_all", fake_compile_all)
+    monkeypatch.setattr(build.subprocess, "check_call", fake_link)
     monkeypatch.setattr(build, "check_hand_scheduled_registers", fake_check)
     verdicts[:] = [None]
-    assert build.build_hip(force=True) == str(out) and len(calls) == 1 and out.exists()
-    assert not any(c.startswith("-DWN_AP_SGPR_HAZARD") for c in calls[0]) and "-align-all-nofallthru-blocks=6" in calls[0] and "--offload-arch=gfx950" in calls[0]
-    calls.clear(); out.unlink()
+    assert build.build_hip(force=True) == str(out) and len(compiles) == len(build.SOURCES) == 2 and len(links) == 1 and out.exists()
+    by_src = {c[c.index("-c") + 1]: c for c in compiles}
+    assert sorted(by_src) == sorted(build.SOURCES)
+    for src, c in by_src.items():
+        assert not any(x.startswith("-DWN_AP_SGPR_HAZARD") for x in c) and "--offload-arch=gfx950" in c
+        assert ("-align-all-nofallthru-blocks=6" in c) == (not src.endswith("wn_stacked.hip"))
+    assert all(o in links[0] for o in (c[c.index("-o") + 1] for c in compiles)) and "-shared" in links[0]
+    assert not any(os.path.exists(c[c.index("-o") + 1]) for c in compiles)   # (the objects are removed behind the link)
+    compiles.clear(); links.clear(); out.unlink()
     verdicts[:] = ["k: use of a reserved poll register outside the hand-scheduled blocks in ..."]
     with pytest.raises(RuntimeError):
         build.build_hip(force=True)
-    assert len(calls) == 1 and not out.exists() and not os.path.exists(str(out) + ".tmp")
+    assert len(compiles) == 2 and len(links) == 1 and not out.exists() and not os.path.exists(str(out) + ".tmp")
     with open(os.path.join(ROOT, "pytorch-wavenet_amd", "csrc", "wn_kernel_v3.h")) as f:
         src = f.read()
     assert '#define WN_AP_SGPR_HAZARD "s_nop 4\\n\\t"' in src    # the source's default IS the safe form

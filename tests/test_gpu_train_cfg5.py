@@ -9,8 +9,18 @@ inputs that are regenerated here (numpy RandomState; guarded by CRCs) and inform
 for two clips, the facade's torch path on the same GPU, element for element.  The bf16 step is held to the spread of its own oracle's evaluation orders at
 THIS size (oracle/bf16_step.py, rows cfg5_*_bf16_noise of the fixture), the way tests/test_gpu_training.py does at depth.
 
-Tolerances: logits 1e-4 absolute (fp32 matrix cores vs the reference's CPU GEMMs, scale 3.6), loss 1e-5 relative, gradients 2e-5 of the tensor's
-largest element.
+Tolerances: logits 1e-4 absolute (fp32 matrix cores vs the reference's CPU GEMMs, scale 4.8), loss 1e-5 relative, gradients 2e-5 of the tensor's
+largest element -- ON ROWS WHOSE RELU MASKS ARE DECIDED.  What round 6 found when it first ran this size (profiles/r06_relu_masks_at_config5_size.txt): the
+head's two ReLUs (wavenet_model.py:167-168) see 32 x 10 885 x (512 + 256) = 267 M pre-activations per step; a few hundred of them lie within fp32 noise of
+zero, two correct fp32 evaluations disagree on those masks, and every flip moves the weight gradients by that row's whole contribution (~1e-3 of a tensor's
+largest element).  The reference's OWN fp32 gradients are 7e-3 away from its float64 evaluation from output_length ~3000 up (5e-6 below ~600), MIOpen's by as
+much, and so are the native ones.  So the gradients are pinned twice:
+  * strictly (2e-5) with the ambiguous rows taken out of the loss: rows where a ReLU input lies within 2e-4 of zero (~6 % of the rows, recorded from the
+    reference's forward in the fixture) get F.cross_entropy's ignore_index -- no gradient passes an undecided mask, and native == reference again, at
+    full size, through every large-geometry code path;
+  * on the plain targets (what bench.py times) against the reference's float64 evaluation: the native fp32 step may be no further from that truth than
+    the reference's own fp32 step is, times 2.5 (rms and max over the gradient digests; measured: 1.6 x its rms -- the matrix cores' fp32
+    accumulation order leaves a little more noise on the head's pre-activations than the reference's CPU GEMMs, hence a few more flipped masks).
 """
 import os
 import sys
@@ -67,8 +77,7 @@ def _native_step(m, ids, target):
     loss.backward()
     torch.cuda.synchronize()
     assert not m.wn_stats()["torch_fallbacks"]
-    grads = {k: (p.grad.detach().cpu().numpy() if p.grad is not None else np.zeros(tuple(p.shape), np.float32)) for k, p in m.named_parameters()}
-    return logits.detach(), float(loss.detach()), grads
+    return logits.detach(), float(loss.detach()), _grads(m)
 
 
 def _sampled(logits, n, out_len, rows):
@@ -114,56 +123,111 @@ def test_forward_alone_at_config5_size(v6):
     assert m.wn_stats()["native_forward"] == 2 and not m.wn_stats()["torch_fallbacks"]
 
 
+def _grads(m):
+    return {k: (p.grad.detach().cpu().numpy() if p.grad is not None else np.zeros(tuple(p.shape), np.float32)) for k, p in m.named_parameters()}
+
+
+def _native_step_torch_loss(m, ids, target):
+    """Native forward + backward around torch's own F.cross_entropy (the reference trainer's line, wavenet_training.py:69): rows whose target is the
+    ignore_index (-100) contribute nothing."""
+    m.zero_grad(set_to_none=True)
+    before = dict(m.wn_stats()["torch_fallbacks"])
+    logits = m.train_forward_indices(ids.cuda())
+    loss = torch.nn.functional.cross_entropy(logits, target.cuda())
+    loss.backward()
+    torch.cuda.synchronize()
+    assert dict(m.wn_stats()["torch_fallbacks"]) == before   # (this step stayed on the native kernels)
+    return logits.detach(), float(loss.detach()), _grads(m)
+
+
 def test_two_clips_native_fp32_vs_the_torch_path_and_the_reference(v6):
-    """N = 2 at the full clip length: native fp32 forward + backward against (a) the facade's torch path -- the reference's conv1d / dilate graph under
-    torch autograd, WN_TORCH_BACKWARD=1, same GPU -- element for element, and (b) the real reference's digests."""
-    import digest as dg
+    """N = 2 at the full clip length.  Logits and loss: native fp32 against the real reference's record and against the facade's torch path -- the
+    reference's conv1d / dilate graph under torch autograd, WN_TORCH_BACKWARD=1, same GPU.  Gradients, element for element against the torch path, on
+    targets that ignore the rows whose ReLU masks fp32 cannot decide (a ReLU input within 2e-4 of zero in the torch path's own forward; module docstring):
+    2e-5 of every tensor's largest element."""
+    import torch.nn.functional as F
     ids, target, out_len = _inputs(v6, 2)
     m = _model(out_len)
-    logits_n, loss_n, g_n = _native_step(m, ids, target)
-    # (a) torch path on the GPU, through the facade's forward() on the one-hot batch like the reference's trainer (wavenet_training.py:64-72)
-    x = torch.zeros(2, 256, L).scatter_(1, ids.view(2, 1, L), 1.0).cuda()
-    os.environ["WN_TORCH_BACKWARD"] = "1"
-    try:
-        m.zero_grad(set_to_none=True)
-        with pytest.warns(RuntimeWarning, match="WN_TORCH_BACKWARD"):
-            out_t = m(x)
-        loss_t = torch.nn.functional.cross_entropy(out_t, target.cuda())
-        loss_t.backward()
-        torch.cuda.synchronize()
-    finally:
-        os.environ.pop("WN_TORCH_BACKWARD", None)
-    dl = float((logits_n - out_t.detach()).abs().max())
-    assert dl <= 1e-4, dl
-    assert abs(loss_n - float(loss_t)) <= 1e-5 * abs(float(loss_t))
-    worst = 0.0
-    for k, p in m.named_parameters():
-        if p.grad is None:
-            assert not g_n[k].any(), k
-            continue
-        gt = p.grad.detach().cpu().numpy()
-        scale = float(np.abs(gt).max())
-        err = float(np.abs(g_n[k] - gt).max())
-        worst = max(worst, err / scale)
-        assert err <= 2e-5 * scale + 1e-12, (k, err, scale)
-    # (b) the real reference
+    logits_n, loss_n, _ = _native_step(m, ids, target)
     ref_l = float(v6["cfg5_n2_loss"][0])
     assert abs(loss_n - ref_l) <= 1e-5 * ref_l and abs(ref_l - np.log(256.0)) > 0.3   # (an informative loss: not the ln 256 of near-zero logits)
     dref = float(np.abs(_sampled(logits_n, 2, out_len, v6["cfg5_logit_rows"]) - v6["cfg5_n2_logits"]).max())
     assert dref <= 1e-4, dref
-    w = dg.compare(_ref_digests(v6, "n2"), dg.digest(g_n), 2e-5)
-    print("cfg5 x 2 clips, fp32: logits vs torch path %.2e, vs the reference's rows %.2e; worst gradient element vs torch path %.2e of its tensor's max; "
-          "digests vs the reference %.2e (%s); loss %.6f" % (dl, dref, worst, w[0], w[1], loss_n))
+    # the torch path on the GPU, through the facade's forward() on the one-hot batch like the reference's trainer (wavenet_training.py:64-72); its two
+    # F.relu calls are watched for inputs near zero
+    x = torch.zeros(2, 256, L).scatter_(1, ids.view(2, 1, L), 1.0).cuda()
+    real_relu, seen = F.relu, []
+
+    def spy(v, *a, **k):
+        seen.append((v.detach()[:, :, -out_len:].abs() < 2e-4).any(dim=1))
+        return real_relu(v, *a, **k)
+    os.environ["WN_TORCH_BACKWARD"] = "1"
+    try:
+        m.zero_grad(set_to_none=True)
+        F.relu = spy
+        try:
+            with pytest.warns(RuntimeWarning, match="WN_TORCH_BACKWARD"):
+                out_t = m(x)
+        finally:
+            F.relu = real_relu
+        assert len(seen) == 2
+        amb = (seen[0] | seen[1]).reshape(-1).cpu()
+        tgt = target.clone()
+        tgt[amb] = -100
+        loss_t = F.cross_entropy(out_t, tgt.cuda())
+        loss_t.backward()
+        torch.cuda.synchronize()
+    finally:
+        os.environ.pop("WN_TORCH_BACKWARD", None)
+    g_t = _grads(m)
+    dl = float((logits_n - out_t.detach()).abs().max())
+    assert dl <= 1e-4, dl
+    logits_r, loss_r, g_n = _native_step_torch_loss(m, ids, tgt)
+    assert torch.equal(logits_r, logits_n)
+    assert abs(loss_r - float(loss_t.detach())) <= 1e-5 * abs(loss_r)
+    worst, worst_k = 0.0, None
+    for k, gt in g_t.items():
+        scale = float(np.abs(gt).max())
+        if scale == 0.0:
+            assert not g_n[k].any(), k
+            continue
+        err = float(np.abs(g_n[k] - gt).max()) / scale
+        if err > worst:
+            worst, worst_k = err, k
+    print("cfg5 x 2 clips, fp32: logits vs torch path %.2e, vs the reference's rows %.2e; loss %.6f; %d of %d rows ignored (ReLU input within 2e-4 of zero); "
+          "worst gradient element native vs torch path %.2e of its tensor's max (%s)" % (dl, dref, loss_n, int(amb.sum()), amb.numel(), worst, worst_k))
+    assert worst <= 2e-5, (worst, worst_k)
 
 
 @pytest.mark.parametrize("deterministic", [False, True])
-def test_full_step_fp32_against_the_reference(v6, deterministic):
-    """The whole config-5 step -- 32 clips -- in fp32 against the real reference: loss, 8 x 32 logit rows, per-clip norms, every gradient's digest.
-    Both forms of the row-split reduction (fp32 atomics / ordered partial tiles)."""
+def test_full_step_fp32_gradients_against_the_reference_on_decided_rows(v6, deterministic):
+    """The whole config-5 batch -- 32 clips -- in fp32, strictly: the fixture's robust targets (cfg5_n32r: ignore_index on the rows the REFERENCE's forward
+    found a ReLU input within 2e-4 of zero on) through native forward, F.cross_entropy, native backward -- loss 1e-5, every gradient's digest 2e-5 against
+    the real reference.  Both forms of the row-split reduction (fp32 atomics / ordered partial tiles)."""
+    import digest as dg
+    ids, target, out_len = _inputs(v6, N_FULL)
+    ignore = np.unpackbits(v6["cfg5_n32r_ignore"])[:N_FULL * out_len].astype(bool)
+    tgt = target.clone()
+    tgt[torch.from_numpy(ignore)] = -100
+    m = _model(out_len)
+    m.deterministic_gradients = deterministic
+    logits, loss, g = _native_step_torch_loss(m, ids, tgt)
+    ref_l = float(v6["cfg5_n32r_loss"][0])
+    assert abs(loss - ref_l) <= 1e-5 * ref_l, (loss, ref_l)
+    dev = float(np.abs(_sampled(logits, N_FULL, out_len, v6["cfg5_logit_rows"]) - v6["cfg5_n32_logits"]).max())
+    assert dev <= 1e-4, dev
+    w = dg.compare(_ref_digests(v6, "n32r"), dg.digest(g), 2e-5)
+    print("cfg5 full batch, fp32%s, %d of %d rows ignored: loss %.6f (reference %.6f), logit rows %.2e, gradient digests vs the reference %.2e (%s)" % (
+        " deterministic" if deterministic else "", int(ignore.sum()), ignore.size, loss, ref_l, dev, w[0], w[1]))
+
+
+def test_full_step_fp32_plain_targets_no_further_from_float64_than_the_reference(v6):
+    """The step bench.py times: plain targets, the engine's fused loss.  Loss, logit rows and per-clip norms against the real reference (1e-5 / 1e-4 / 1e-5);
+    the gradients against the reference's FLOAT64 evaluation (cfg5_n32_f64_d_*): no further from it than the reference's own fp32 step lands
+    (cfg5_n32_fp32_noise; rms and max x2.5: measured x1.6 on the rms) -- with a few hundred undecidable ReLU masks per step that is what fp32 can promise (module docstring)."""
     import digest as dg
     ids, target, out_len = _inputs(v6, N_FULL)
     m = _model(out_len)
-    m.deterministic_gradients = deterministic
     logits, loss, g = _native_step(m, ids, target)
     ref_l = float(v6["cfg5_n32_loss"][0])
     dev = float(np.abs(_sampled(logits, N_FULL, out_len, v6["cfg5_logit_rows"]) - v6["cfg5_n32_logits"]).max())
@@ -171,9 +235,14 @@ def test_full_step_fp32_against_the_reference(v6, deterministic):
     ndev = float(np.abs(norms / v6["cfg5_n32_logit_norms"] - 1).max())
     assert abs(loss - ref_l) <= 1e-5 * ref_l, (loss, ref_l)
     assert dev <= 1e-4 and ndev <= 1e-5, (dev, ndev)
-    w = dg.compare(_ref_digests(v6, "n32"), dg.digest(g), 2e-5)
-    print("cfg5 full step, fp32%s: loss %.6f (reference %.6f), logit rows %.2e, norms %.2e, gradient digests %.2e (%s)" % (
-        " deterministic" if deterministic else "", loss, ref_l, dev, ndev, w[0], w[1]))
+    dv = _digest_devs(_ref_digests(v6, "n32", "f64_d_"), dg.digest(g))
+    rms, mx = float(np.sqrt((dv ** 2).mean())), float(dv.max())
+    noise = v6["cfg5_n32_fp32_noise"]
+    dv32 = _digest_devs(_ref_digests(v6, "n32"), dg.digest(g))
+    print("cfg5 full step, fp32, plain targets: loss %.6f (reference %.6f), logit rows %.2e, norms %.2e; gradient digests vs the reference's float64 evaluation: "
+          "rms %.2e max %.2e (the reference's own fp32 step: rms %.2e max %.2e); vs the reference's fp32 step: rms %.2e max %.2e" % (
+              loss, ref_l, dev, ndev, rms, mx, noise[0], noise[1], float(np.sqrt((dv32 ** 2).mean())), float(dv32.max())))
+    assert rms <= 2.5 * noise[0] and mx <= 2.5 * noise[1], (rms, mx, noise.tolist())
 
 
 def test_full_step_bf16_within_its_oracles_noise(v6):
