@@ -146,6 +146,9 @@ typedef struct wn_info {
                                     stationary in registers, one chain for up to ~150 streams; from n_layers + 6 streams two streams per
                                     layer item and two replicas of the head workgroups): every instantiated shape -- BASELINE configs 1-4
                                     and the train_script.py shape
+                                4 = stacked-layer kernel (2-5 consecutive layers per 512-thread workgroup, the layer-to-layer hand-off in LDS;
+                                    layers_per_workgroup says how many): the small shapes -- cfg1, cfg2, the train_script.py shape -- at few
+                                    streams (up to (stack workgroups + 2) / 2)
                                 (2 = the 256-thread register-resident kernels of ABI version 1: removed) */
     int32_t n_chains;        /* 1, or the rounds of up to 128 streams a job beyond one chain's capacity runs one after the other;
                                 n_workgroups and the byte counts are totals over them */

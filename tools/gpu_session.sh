@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-6 GPU session script (one parametrised script instead of a file per run).   tools/r06_run.sh <tag> <what...>
+# GPU session script (one parametrised script instead of a file per run).   tools/gpu_session.sh <tag> <what...>
 #   what: new   -- the tests round 6 added / touched        full  -- the whole GPU suite + smoke + the default bench line
 #         train -- tools/bench_train.py (bf16 + fp32 step)  bench -- the default bench line only     k=<expr> -- pytest -k <expr>
 TAG=$1; shift
@@ -14,7 +14,6 @@ for what in "$@"; do
     full) bash tools/gpu_validate.sh $TAG ;;
     train) ( timeout 600 python tools/bench_train.py 32 16000 --no-torch --reps=5 2>&1 | tail -6 ) | tee gpurun_out/train_$TAG.txt ;;
     traindet) ( WN_DETERMINISTIC=1 timeout 600 python tools/bench_train.py 32 16000 --no-torch --reps=5 2>&1 | tail -6 ) | tee gpurun_out/traindet_$TAG.txt ;;
-    ab_small) bash tools/r06_ab_small.sh ;;
     cfg5) ( time timeout 1500 python -m pytest tests/test_gpu_train_cfg5.py -m gpu -q -s 2>&1 | grep -v "^$" | tail -150 ) 2>&1 | tee gpurun_out/pytest_cfg5_$TAG.txt ;;
     bench) ( time timeout 900 python bench.py 2> gpurun_out/bench_$TAG.err | tail -1 > gpurun_out/bench_$TAG.json ) 2>&1 | tail -3; tail -3 gpurun_out/bench_$TAG.err ;;
     k=*) ( time timeout 1500 python -m pytest tests -m gpu -q -x -s -k "${what#k=}" 2>&1 | tail -30 ) 2>&1 | tee gpurun_out/pytest_k_$TAG.txt ;;

@@ -27,6 +27,8 @@ DB=$(find /tmp/prof_tr -name "*.db" | head -1)
   python tools/rocprof_summary.py $DB | head -24
   echo "# the same dispatches by (kernel, grid): which product costs what"
   python tools/rocprof_dispatches.py $DB 100000 40 --group
+  echo "# timeline of the last three steps: queue occupancy and the main queue's gaps (tools/rocprof_timeline.py)"
+  python tools/rocprof_timeline.py $DB ${WINDOW_MS:-170} 14
   if [ "${PMC:-0}" = "1" ]; then
     echo "# PMC passes (FETCH_SIZE / WRITE_SIZE in KiB per dispatch; raw counter values)"
     python tools/rocprof_summary.py $(find /tmp/prof_trf /tmp/prof_trw -name "*.db" | sort) | grep -v "^kernel stats\|^name \|^void at::\|^__amd\|^## " | grep "n=" | grep "wn_"
