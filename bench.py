@@ -554,7 +554,7 @@ def cpu_baseline(cfgname, budget_s=3.0):
 def _pmc_traffic(a, info, per_gpu):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json: FETCH_SIZE + WRITE_SIZE of one launch,
     separate passes), scaled to this launch's timesteps -- hand-off traffic is linear in them.  The file names the kernel, its form and
-    the date it was measured; the figure is REFUSED (traffic null, the reason in traffic_replayed_from) when the library that just ran is not
+    the date it was measured; the figure is REFUSED (traffic null, the reason in traffic_source) when the library that just ran is not
     that kernel in that form: a stale constant must not pass for a measurement of this build."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if a.scaling != "weak" or not os.path.exists(path):
@@ -570,6 +570,56 @@ def _pmc_traffic(a, info, per_gpu):
     return traffic, {"file": "profiles/pmc_traffic.json", "kernel": pmc.get("kernel"), "measured": pmc.get("date"), "summary": pmc.get("summary"),
                      "counters": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, %d timesteps per launch, scaled to %d; traffic = %.1f x FETCH_SIZE + WRITE_SIZE (%s)"
                                  % (pmc["samples_per_launch"], a.samples, pmc.get("fetch_correction", 1.0), pmc.get("calibration", "uncalibrated"))}
+
+
+PMC_LIVE_TIMESTEPS = 2000   # timesteps of the job the live PMC passes count (hand-off traffic is linear in them; the figure is scaled to --samples)
+
+
+def _pmc_live(a, info, per_gpu, cfgname):
+    """HBM bytes per launch MEASURED IN THIS RUN: two rocprofv3 passes -- `--pmc FETCH_SIZE`, then `--pmc WRITE_SIZE`: the counters in their own passes,
+    with --kernel-trace only, as MI355X_MICROARCH.md prescribes -- around `tools/rate.py <cfg> <streams> 2000 1` in child processes (rocprofv3 cannot
+    wrap the process that is already running; the children build the same library's engine on this GPU and run the same one-kernel job, two launches each,
+    behind the timed region).  traffic = 2 x FETCH_SIZE + WRITE_SIZE (profiles/r04_pmc_calibration.txt: on the hand-offs' access patterns WRITE_SIZE is exact
+    and FETCH_SIZE reports half of the sc1 misses), KiB -> bytes, scaled to this launch's timesteps.  Returns (traffic, source) or (None, reason): the
+    caller falls back to the committed passes, labelled as replayed."""
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    if os.environ.get("WN_BENCH_NO_LIVE_PMC") == "1" or a.scaling != "weak":
+        return None, "live PMC passes switched off"
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    got = {}
+    t0 = time.perf_counter()
+    try:
+        with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
+            env = dict(os.environ, TMPDIR="/tmp", WN_TESTING="1")
+            for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+                out = os.path.join(tmp, counter)
+                cmd = [exe, "--kernel-trace", "--pmc", counter, "-d", out, "-o", "p", "--", sys.executable, os.path.join(ROOT, "tools", "rate.py"),
+                       cfgname, str(per_gpu), str(PMC_LIVE_TIMESTEPS), "1"]
+                r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+                dbs = [os.path.join(d, f) for d, _, fs in os.walk(out) for f in fs if f.endswith(".db")]
+                if r.returncode != 0 or not dbs:
+                    return None, "rocprofv3 --pmc %s failed (rc %d): %s" % (counter, r.returncode, r.stdout.decode(errors="replace")[-300:])
+                rows = sqlite3.connect(dbs[0]).execute(
+                    "select kernel_name, avg(value), count(*) from counters_collection where counter_name = ? and kernel_name like '%wn_generate_kernel%' group by kernel_name",
+                    (counter,)).fetchall()
+                if len(rows) != 1 or not rows[0][1]:
+                    return None, "rocprofv3 --pmc %s: unexpected rows %r" % (counter, rows)
+                got[counter] = rows[0]
+    except Exception as e:   # (a profiler problem must not cost the bench line: the caller replays the committed passes instead)
+        return None, "live PMC passes failed: %r" % (e,)
+    fetch, write = got["FETCH_SIZE"][1], got["WRITE_SIZE"][1]
+    traffic = int((2.0 * fetch + write) * 1024 * a.samples / PMC_LIVE_TIMESTEPS)
+    return traffic, {"kernel": got["FETCH_SIZE"][0], "fetch_kib_per_launch": round(fetch, 1), "write_kib_per_launch": round(write, 1),
+                     "dispatches_averaged": [got["FETCH_SIZE"][2], got["WRITE_SIZE"][2]], "timesteps_per_counted_launch": PMC_LIVE_TIMESTEPS,
+                     "seconds": round(time.perf_counter() - t0, 1),
+                     "counters": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes in child processes behind the timed region, %d timesteps per "
+                                 "launch, scaled to %d; traffic = 2.0 x FETCH_SIZE + WRITE_SIZE (profiles/r04_pmc_calibration.txt: WRITE_SIZE exact, FETCH_SIZE reports half "
+                                 "of the missed bytes for 8- and 16-byte sc1 loads)" % (PMC_LIVE_TIMESTEPS, a.samples)}
 
 
 def _train_pmc(precision, N, L):
@@ -622,6 +672,7 @@ def main():
                          "with ONE rank: the multi-GPU path exercised on a 1-GPU box")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
+    ap.add_argument("--no-live-pmc", action="store_true", help="roofline.traffic from the committed PMC passes (replayed) instead of two rocprofv3 passes behind the timed region")
     a = ap.parse_args()
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -685,7 +736,15 @@ def main():
     bytes_per_tstep = synth.algorithmic_bytes_per_step(cfg, per_gpu)   # W_touched + streams*(Q+8)
     bytes_per_launch = bytes_per_tstep * a.samples
     achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
-    traffic, traffic_source = _pmc_traffic(a, info, per_gpu)
+    traffic, traffic_source, traffic_kind = None, None, None
+    if n_gpus == 1 and not dist and not a.no_live_pmc:
+        traffic, traffic_source = _pmc_live(a, info, per_gpu, WORKLOADS[a.workload][0])
+        traffic_kind = "measured in this run: rocprofv3 PMC passes of the same job (same library, same GPU) in child processes, scaled to this launch's timesteps"
+    if traffic is None:
+        live_reason = traffic_source
+        traffic, traffic_source = _pmc_traffic(a, info, per_gpu)
+        traffic_kind = None if traffic is None else ("replayed: PMC passes of an EARLIER run of this kernel in this form, scaled to this launch's timesteps -- not a "
+                                                     "measurement of this run (live passes: %s)" % (live_reason or "not attempted"))
     kname = {1: "wn_generate_kernel", 3: "wn_generate_kernel_v3m", 4: "wn_generate_kernel_v4"}.get(info["kernel_variant"], "?")
     line = {
         "metric": BASELINE_METRIC,
@@ -714,9 +773,8 @@ def main():
         "rccl_ranks": dist.get_world_size() if dist else 0, "dist_backend": dist.get_backend() if dist else None,
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                     "traffic_kind": None if traffic is None else "replayed: PMC passes of an EARLIER run of this kernel in this form (rocprofv3 cannot "
-                                     "wrap the driver's own bench run), scaled to this launch's timesteps -- not a measurement of this run",
-                     "traffic_replayed_from": traffic_source,
+                     "traffic_kind": traffic_kind,
+                     "traffic_source": traffic_source,
                      "traffic_over_algorithmic": None if traffic is None else round(traffic / bytes_per_launch, 3),
                      "kernel": kname, "kernel_ms_per_launch": round(kernel_ms, 3), "kernel_ms_per_launch_median": round(eng_leg["kernel_ms_median"], 3),
                      "algorithmic_bytes_per_launch": int(bytes_per_launch),

@@ -139,13 +139,11 @@ def check_hand_scheduled_registers(so, objdump=None):
     return seen
 
 
-# Matrix-core kernels that are KNOWN to spill a few VGPRs at their 128-register cap (8 % of the training step's time; the judge's
-# round-4 finding).  Everything else in the library must be free of scratch: a new spill anywhere -- or one of these growing past its recorded count --
-# fails the build instead of going unnoticed.  kernel-name fragment -> most scratch instructions tolerated.
-KNOWN_SPILLS = {
-    "wn_fwd_gemm_bf16ILi0ELi4ELb0E": 4, "wn_fwd_gemm_bf16ILi1ELi4ELb0E": 2, "wn_fwd_gemm_bf16ILi2ELi4ELb0E": 2,   # (round 5: the epilogue's lane roles from an opaque thread index -- 6 / 2 / 4 / 4 before)
-    "wn_bwd_gemm_tn_bf16ILi8ELb0ELb0E": 25, "wn_bwd_gemm_tn_bf16ILi8ELb0ELb1E": 8,
-}
+# Kernels that are allowed to touch scratch: kernel-name fragment -> most scratch instructions tolerated.  EMPTY since round 6: the five matrix-core
+# instantiations that spilled 2-10 VGPRs at their 128-register cap (rounds 4-5: wn_fwd_gemm_bf16<*, 4, false>, wn_bwd_gemm_tn_bf16<8, false, *> -- the forms
+# that convert an fp32-stored operand on its way to LDS) now run at three waves per SIMD (150 / 146-154 VGPRs, csrc/wn_forward.h launch bounds).  The
+# mechanism stays: a new spill anywhere fails the build instead of going unnoticed.
+KNOWN_SPILLS = {}
 
 
 def _check_scratch_everywhere(dis):

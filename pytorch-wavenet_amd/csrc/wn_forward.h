@@ -475,6 +475,7 @@ struct WnGemmArgsBf16 {
 #endif
 #ifndef WN_GEMM_BF16_MINB
 #define WN_GEMM_BF16_MINB 4   // 4-wave form: 4 workgroups per CU (exactly the CU's 160 KB of LDS, 128 VGPRs): 3 -> 4 took the residual / dx products from 346 to 314 us
+                              // (the forms that convert an fp32-stored A on its way to LDS keep 3: at 128 VGPRs they spilled 2-3 registers -- round 6)
 #endif
 
 // WAVES = 4: 128 x 128 tile (wave w: rows 32w.., all 128 columns).  WAVES = 8: 128 x 256 tile (wave w: rows 32 (w & 3).., column half
@@ -483,7 +484,7 @@ struct WnGemmArgsBf16 {
 // once for all 256 columns.
 // A16: A is stored as bf16 (g.a_bf16): its pieces go to LDS as they are.
 template <int EPI, int WAVES, bool A16 = false>
-__global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? WN_GEMM_BF16_MINB : 4) void wn_fwd_gemm_bf16(WnGemmArgsBf16 ga) {
+__global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? (A16 ? WN_GEMM_BF16_MINB : 3) : 4) void wn_fwd_gemm_bf16(WnGemmArgsBf16 ga) {
     const WnGemmArgs& g = ga.g;
     constexpr int NT = 64 * WAVES, TM = 128, TN = 32 * WAVES, KC = WN_GEMM_BF16_KC, LD = KC + 8;  // LD: padded row length (bf16): 80-byte rows, conflict-free b128 reads
     constexpr int TPR = NT / TM;   // loader threads per A row (2 / 4)
@@ -1095,8 +1096,11 @@ typedef short wn_s8 __attribute__((ext_vector_type(8)));
 // residual weight gradient) where B16 is a clear gain (211 -> 160 us in the filter/gate one), so where the choice exists the bf16-stored
 // operand goes in as B (operands swapped, c_trans) -- but only for few row splits: a transposed tile of atomics touches 32x the cache
 // lines (residual weight gradient, ~1000 splits: 598 us).
+#ifndef WN_TN_DEEP
+#define WN_TN_DEEP 0   // 1: two chunks in flight per workgroup where both operands are stored as bf16 (see the K loop) -- built in round 6, at the 128-register cap of the 256-column form it spills, at 256 registers (one workgroup per CU) it is level: off -- profiles/r06_tn_loads.txt
+#endif
 template <int WAVES, bool A16, bool B16>
-__global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? WN_TN_BF16_MINB : 4) void wn_bwd_gemm_tn_bf16(WnGemmTnArgs g) {
+__global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? WN_TN_BF16_MINB : ((A16 && !(B16 && WN_TN_DEEP)) ? 4 : 2)) void wn_bwd_gemm_tn_bf16(WnGemmTnArgs g) {
     constexpr int T = 128, TB = 32 * WAVES, KC = 32, LD = KC + 8;  // fp32-stored operand: LDS rows [column][KC rows of the chunk] bf16, padded to 80 bytes
     constexpr int RSA = T * 2 + 64, RSB = TB * 2 + 64;             // bf16-stored operand: bytes per row of its row-major image
     constexpr int ASZ = A16 ? KC * RSA / 2 : T * LD, BSZ = B16 ? KC * RSB / 2 : TB * LD;   // shorts per buffer
@@ -1132,58 +1136,74 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? WN_TN_BF16_MINB : 4) void 
     float4 v[8];
     // bf16-stored operand `map` (g.a or g.b named directly: its fields stay scalar), tile origin `org`, PPR pieces per row, loader thread lt
     // win_lo: rows whose index inside the batch entry is below it read as ZERO (never loaded)
-    auto fetch16 = [&](const WnRowMap& map, int org, int ncols16, auto pprc, int lt, long long mc, int win_lo = 0) {
+    // (Loads are UNCONDITIONAL buffer loads: a piece that lies outside the operand gets an offset beyond the descriptor's range and reads as zero.  Written
+    //  as `ok ? *ptr : zero` every load sat in a predicated block of its own with an s_waitcnt vmcnt(0) at its end -- a loader thread's four (eight) loads of
+    //  a chunk were four (eight) round trips one after the other, and the weight-gradient products ran at half the rate of a stream: round 6,
+    //  profiles/r06_tn_loads.txt.  The descriptor starts at the row split's first row -- wave-uniform --, so a lane carries ONE 32-bit byte offset per load
+    //  instead of a 64-bit pointer: these kernels sit at their register cap.)
+    constexpr unsigned WN_OOB = 0x80000000u;   // beyond the 2 GB window of wn_rsrc: the load returns zeros
+    // element offset of row m of a map (64-bit), and the wave-uniform origin of this workgroup's rows
+    auto row_elem = [&](const WnRowMap& map, unsigned q, unsigned rem) -> long long { return (long long)q * map.batch_stride + (map.t0 + (long long)rem) * map.row_stride; };
+    const unsigned q_wg = (unsigned)((unsigned long long)m_begin / (unsigned)g.rows_per_batch), rem_wg = (unsigned)m_begin - q_wg * (unsigned)g.rows_per_batch;
+    auto fetch16 = [&](const WnRowMap& map, int org, int ncols16, auto pprc, int lt, long long mc, int win_lo = 0, int vo = 0) {   // vo: first register of the set (DEEP)
         constexpr int PPR = decltype(pprc)::value;
         const int row16 = lt / PPR, piece16 = lt % PPR;
         const bool ok16 = org + 8 * piece16 < ncols16;
-        const unsigned short* base16 = reinterpret_cast<const unsigned short*>(map.base);
+        const long long e_wg = row_elem(map, q_wg, rem_wg);
+        const __amdgpu_buffer_rsrc_t rs = wn_rsrc(reinterpret_cast<const unsigned short*>(map.base) + e_wg);
         const long long m = mc + row16;
         unsigned q = (unsigned)m / (unsigned)g.rows_per_batch, rem = (unsigned)m - q * (unsigned)g.rows_per_batch;
-        const unsigned short* ptr = base16 + (long long)q * map.batch_stride + (map.t0 + (long long)rem) * map.row_stride + org + 8 * piece16;
+        unsigned off = (unsigned)((row_elem(map, q, rem) - e_wg + org + 8 * piece16) * 2);   // bytes from the descriptor's base
 #pragma unroll
         for (int qq = 0; qq < 4; ++qq) {
-            v[qq] = (ok16 && m + 8 * qq < m_end && (int)rem >= win_lo) ? *reinterpret_cast<const float4*>(ptr) : make_float4(0.f, 0.f, 0.f, 0.f);   // 8 bf16, moved as bits
+            const bool okq = ok16 && m + 8 * qq < m_end && (int)rem >= win_lo;
+            const wn_v4i got = __builtin_amdgcn_raw_buffer_load_b128(rs, okq ? off : WN_OOB, 0, 0);   // 8 bf16, moved as bits
+            v[vo + qq] = make_float4(__int_as_float(got.x), __int_as_float(got.y), __int_as_float(got.z), __int_as_float(got.w));
             rem += 8;
             if (rem >= (unsigned)g.rows_per_batch) {   // the row 8 further down is in a later batch entry
                 do { rem -= (unsigned)g.rows_per_batch; ++q; } while (rem >= (unsigned)g.rows_per_batch);
-                ptr = base16 + (long long)q * map.batch_stride + (map.t0 + (long long)rem) * map.row_stride + org + 8 * piece16;
+                off = (unsigned)((row_elem(map, q, rem) - e_wg + org + 8 * piece16) * 2);
             } else {
-                ptr += 8 * map.row_stride;
+                off += (unsigned)(8 * map.row_stride * 2);
             }
         }
     };
-    auto stash16 = [&](unsigned short* imgs, int rs, auto pprc, int lt) {
+    auto stash16 = [&](unsigned short* imgs, int rs, auto pprc, int lt, int vo = 0) {
         constexpr int PPR = decltype(pprc)::value;
         char* img = reinterpret_cast<char*>(imgs);
 #pragma unroll
-        for (int qq = 0; qq < 4; ++qq) *reinterpret_cast<float4*>(img + (lt / PPR + 8 * qq) * rs + 16 * (lt % PPR)) = v[qq];
+        for (int qq = 0; qq < 4; ++qq) *reinterpret_cast<float4*>(img + (lt / PPR + 8 * qq) * rs + 16 * (lt % PPR)) = v[vo + qq];
     };
-    auto fetch = [&](long long mc) {
-        if (B16 && is_b) { if (loads) fetch16(g.b, nb0, g.Nb, std::integral_constant<int, TB / 8>{}, tid - 128, mc); return; }
+    auto fetch = [&](long long mc, int vo = 0) {
+        if (B16 && is_b) { if (loads) fetch16(g.b, nb0, g.Nb, std::integral_constant<int, TB / 8>{}, tid - 128, mc, 0, vo); return; }
         if (A16 && !is_b) {   // (the two tap views of the filter/gate weight gradient: block-uniform choice, the maps' fields stay scalar)
-            if (second) fetch16(g.a1, ka0 - g.ka_split, g.Ka - g.ka_split, std::integral_constant<int, T / 8>{}, tid, mc);
-            else fetch16(g.a, ka0, g.ka_split > 0 ? g.ka_split : g.Ka, std::integral_constant<int, T / 8>{}, tid, mc, g.a_skip_lo);
+            if (second) fetch16(g.a1, ka0 - g.ka_split, g.Ka - g.ka_split, std::integral_constant<int, T / 8>{}, tid, mc, 0, vo);
+            else fetch16(g.a, ka0, g.ka_split > 0 ? g.ka_split : g.Ka, std::integral_constant<int, T / 8>{}, tid, mc, g.a_skip_lo, vo);
             return;
         }
         long long m = mc + mg * 8;
         unsigned q = (unsigned)m / (unsigned)g.rows_per_batch, rem = (unsigned)m - q * (unsigned)g.rows_per_batch;
-        const float* ptr = rm.base + (long long)q * rm.batch_stride + (rm.t0 + (long long)rem) * rm.row_stride + pcol0;
+        const long long e_wg = row_elem(rm, q_wg, rem_wg);
+        const __amdgpu_buffer_rsrc_t rs = wn_rsrc(rm.base + e_wg);
+        unsigned off = (unsigned)((row_elem(rm, q, rem) - e_wg + pcol0) * 4);
         const int win_lo = (is_b || second) ? 0 : g.a_skip_lo;   // (view `a` only)
 #pragma unroll
         for (int rr = 0; rr < 8; ++rr) {
-            v[rr] = (col_ok && m + rr < m_end && (int)rem >= win_lo) ? *reinterpret_cast<const float4*>(ptr) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const bool okr = col_ok && m + rr < m_end && (int)rem >= win_lo;
+            const wn_v4i got = __builtin_amdgcn_raw_buffer_load_b128(rs, okr ? off : WN_OOB, 0, 0);
+            v[rr] = make_float4(__int_as_float(got.x), __int_as_float(got.y), __int_as_float(got.z), __int_as_float(got.w));
             if (++rem == (unsigned)g.rows_per_batch) {  // next row is in the next batch entry
                 rem = 0; ++q;
-                ptr = rm.base + (long long)q * rm.batch_stride + rm.t0 * rm.row_stride + pcol0;
+                off = (unsigned)((row_elem(rm, q, 0) - e_wg + pcol0) * 4);
             } else {
-                ptr += rm.row_stride;
+                off += (unsigned)(rm.row_stride * 4);
             }
         }
     };
-    auto stash = [&](int buf) {
+    auto stash = [&](int buf, int vo = 0) {
         if (!loads) return;
-        if (B16 && is_b) { stash16(b_s[buf], RSB, std::integral_constant<int, TB / 8>{}, tid - 128); return; }
-        if (A16 && !is_b) { stash16(a_s[buf], RSA, std::integral_constant<int, T / 8>{}, tid); return; }
+        if (B16 && is_b) { stash16(b_s[buf], RSB, std::integral_constant<int, TB / 8>{}, tid - 128, vo); return; }
+        if (A16 && !is_b) { stash16(a_s[buf], RSA, std::integral_constant<int, T / 8>{}, tid, vo); return; }
         unsigned short* dst = (is_b ? b_s[buf] : a_s[buf]) + lcol * LD + mg * 8;
         if (relu) {
 #pragma unroll
@@ -1199,12 +1219,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? WN_TN_BF16_MINB : 4) void 
     const int tp = lane & 15, tg = (lane >> 4) & 1, th = lane >> 5;
     const int tra_off = (8 * th + (tp >> 2)) * RSA + (32 * wr + 16 * tg + 4 * (tp & 3)) * 2;
     const int trb_off = (8 * th + (tp >> 2)) * RSB + (128 * wc + 16 * tg + 4 * (tp & 3)) * 2;
-    fetch(m_begin);
-    stash(0);
-    __syncthreads();
-    int buf = 0;
-    for (long long mc = m_begin; mc < m_end; mc += KC, buf ^= 1) {
-        if (mc + KC < m_end) fetch(mc + KC);
+    auto products = [&](int buf) {   // the chunk in LDS buffer `buf` against the accumulators
         const unsigned short* ar = a_s[buf] + (A16 ? 0 : (32 * wr + (lane & 31)) * LD + 8 * (lane >> 5));
         const unsigned short* br = b_s[buf] + (B16 ? 0 : (128 * wc + (lane & 31)) * LD + 8 * (lane >> 5));
         const char* at_img = reinterpret_cast<const char*>(a_s[buf]) + tra_off;
@@ -1234,8 +1249,44 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? WN_TN_BF16_MINB : 4) void 
                 acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[j], 0, 0, 0);
             }
         }
-        if (mc + KC < m_end) stash(buf ^ 1);
+    };
+    // DEEP (both operands stored as bf16: a loader thread moves four 16-byte pieces per chunk, half of v[]): TWO chunks in flight per workgroup.  Alone on the
+    // chip the one-chunk loop ran the filter/gate weight gradient at 2.5 TB/s -- 3.7 us per 24 KB chunk and workgroup, a load round trip per chunk, where the
+    // layer kernels stream 5 TB/s (profiles/r06_train_step_sq_counters.txt) -- and the step is the sum of its kernels' stand-alone times.  Chunk k + 2 is
+    // requested before the products of chunk k, chunk k + 1 goes from its registers to LDS behind them; the barrier is the LDS-only one (a __syncthreads
+    // would drain the loads in flight).  Loads past the split's last row are predicated off (zeros), so every path issues the same sequence and the
+    // compiler's wait counts stay exact.
+    constexpr bool DEEP = A16 && B16 && WN_TN_DEEP;
+    if constexpr (DEEP) {
+        fetch(m_begin, 0);
+        stash(0, 0);
+        fetch(m_begin + KC, 4);
+        wn_lds_barrier();
+        for (long long mc = m_begin;;) {
+            fetch(mc + 2 * KC, 0);
+            products(0);
+            stash(1, 4);
+            wn_lds_barrier();
+            mc += KC;
+            if (mc >= m_end) break;
+            fetch(mc + 2 * KC, 4);
+            products(1);
+            stash(0, 0);
+            wn_lds_barrier();
+            mc += KC;
+            if (mc >= m_end) break;
+        }
+    } else {
+        fetch(m_begin);
+        stash(0);
         __syncthreads();
+        int buf = 0;
+        for (long long mc = m_begin; mc < m_end; mc += KC, buf ^= 1) {
+            if (mc + KC < m_end) fetch(mc + KC);
+            products(buf);
+            if (mc + KC < m_end) stash(buf ^ 1);
+            __syncthreads();
+        }
     }
     const int col = lane & 31;
 #pragma unroll

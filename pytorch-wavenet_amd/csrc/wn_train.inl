@@ -30,6 +30,7 @@ static int wn_train_layout_ws(const wn_handle* h, long long N, long long L, long
         t.need = geo.rows; t.zlo = geo.zlo;
     }
     t.G = pl.layers < NL ? pl.layers : NL;
+    { const char* gb = wn_dev_env("WN_TRAIN_SKIP_BLOCK"); if (gb && atoi(gb) > 0) t.G = atoi(gb) < NL ? atoi(gb) : NL; }   // (A/B runs, with WN_TESTING=1: layers per grouped skip product)
     size_t o = 0;
     auto take = [&](size_t n) { size_t r = o; o += (n + 63) & ~(size_t)63; return r; };
     t.x.resize(NL); t.th.resize(NL); t.sg.resize(NL);

@@ -11,7 +11,7 @@ python - <<PY
 import json
 d = json.load(open("gpurun_out/bench_$TAG.json"))
 e = d.get("extra", {})
-print("value", d["value"], "median ms", d.get("median_ms_per_step"), "engine", d["engine_level"]["value"], "roofline", d["roofline"]["frac"], "traffic", d["roofline"]["traffic"], d["roofline"]["traffic_replayed_from"] if d["roofline"]["traffic"] is None else "", "verified", d["verified"])
+print("value", d["value"], "median ms", d.get("median_ms_per_step"), "engine", d["engine_level"]["value"], "roofline", d["roofline"]["frac"], "traffic", d["roofline"]["traffic"], d["roofline"].get("traffic_kind", "")[:40], d["roofline"].get("traffic_over_algorithmic"), "verified", d["verified"])
 for k, v in e.items():
     print(" ", k, {kk: v[kk] for kk in v if kk in ("samples_per_s", "hbm_frac", "kernel_variant", "verified", "ms_per_step", "mfma_peak_frac", "batched_ms", "error")})
 print("cpu", d.get("cpu_baseline", {}).get("matrix"))

@@ -35,7 +35,7 @@ DB=$(find /tmp/prof_tr -name "*.db" | head -1)
   fi
   if [ "${SQ:-0}" = "1" ]; then
     echo "# SQ pass (per dispatch averages)"
-    python tools/rocprof_summary.py $(find /tmp/prof_trs -name "*.db" | sort) | grep "n=" | grep "wn_.*gemm"
+    python tools/rocprof_summary.py $(find /tmp/prof_trs -name "*.db" | sort) | grep "n=" | grep "wn_"
     tail -3 /tmp/trs.log
   fi
 } > "$OUT/rocprofv3_train_$TAG.txt" 2>&1
