@@ -1307,6 +1307,152 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? WN_TN_BF16_MINB : ((A16 &&
     }
 }
 
+// ---- Weight gradients with both operands stored as bf16 in 256 x 256 tiles, one workgroup per CU (round 6): the filter/gate gradient of a 128 / 128
+// layer (ONE tile: both tap views side by side) and the grouped skip gradient (Ka = 512 x Nb = 1280: ten tiles per row split instead of twenty).
+//     dWfg^T [2R = 256][2D = 256]  =  [x(t - d) | x(t)]^T . [dF | dG]        over the layer's rows, both operands stored as bf16
+// wn_bwd_gemm_tn_bf16<8, true, true> runs this product as two 128 x 256 tiles per row split -- both read all of [dF|dG] (737 MB requested for 491 MB of
+// operands per layer at config 5), two workgroups per CU with ONE 24 KB chunk in flight each -- and alone on the chip reaches 2.5 TB/s where the layer
+// kernels stream 5 (profiles/r06_tn_loads.txt): it is bound by its bytes in flight.  Here a 512-thread workgroup has a CU to itself and 256 registers a
+// lane: the whole 256 x 256 accumulator (wave w: ka strips 32 (w & 3) of BOTH tap views x nb half w >> 2 = 8 MFMA tiles, 128 registers), every operand
+// byte requested once, and THREE 32 KB chunks in flight (three register sets of four 16-byte pieces; two LDS stages; LDS-only barriers).
+// Loader thread lt: role lt >> 7 -- 0: view a (tap 0, with its zero-pad row window), 1: view a1 (tap 1), 2-3: B -- four pieces per chunk, rows +0 / 8 / 16 / 24.
+// LDS images, transposing reads and the epilogue are wn_bwd_gemm_tn_bf16's (both operands row-major [32 rows][256 columns + 32], ds_read_b64_tr_b16).
+__global__ __launch_bounds__(512, 2) void wn_bwd_wfg_bf16(WnGemmTnArgs g) {
+    constexpr int KC = 32, RS = 256 * 2 + 64, BUF = KC * RS / 2;   // bytes per image row; shorts per stage and operand
+    __shared__ __attribute__((aligned(16))) unsigned short a_s[2][BUF];
+    __shared__ __attribute__((aligned(16))) unsigned short b_s[2][BUF];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wr = wv & 3, wc = wv >> 2;
+    // tiles_ka counts 256-column tiles of A here; the tiles of a row split share an XCD (wn_tile_of)
+    unsigned split, tile;
+    if (!wn_tile_of(blockIdx.x, (unsigned)(g.tiles_ka * (g.Nb / 256)), (unsigned)g.n_splits, split, tile)) return;
+    const int ka0 = (int)(tile % (unsigned)g.tiles_ka) * 256, nb0 = (int)(tile / (unsigned)g.tiles_ka) * 256;
+    const long long m_begin = (long long)split * g.rows_per_split;
+    long long m_end = m_begin + g.rows_per_split;
+    if (m_end > g.M) m_end = g.M;
+    if (m_begin >= m_end) return;
+    wn_f16v acc[2][4];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[h][j][i] = 0.f;
+    // ---- loader
+    const int role = __builtin_amdgcn_readfirstlane(tid >> 7);   // (two waves per role: told to the compiler, so that the role's row map and its buffer
+    const bool is_b = role >= 2;                                  //  descriptor live in scalar registers -- a lane-dependent map is re-read from the kernel
+    WnRowMap map = g.a;                                           //  arguments with vector loads in every chunk, and every wait for those drains the prefetch)
+    const bool taps = g.ka_split > 0;                             // two row views of A side by side (Ka = 256: view a, view a1) / one view, 256 of its columns
+    if (role == 1 && taps) map = g.a1;
+    if (is_b) map = g.b;
+    const int win_lo = role == 0 || !taps ? (is_b ? 0 : g.a_skip_lo) : 0;
+    const int org = is_b ? nb0 : (taps ? 0 : ka0 + 128 * (role == 1));   // first column of this role's 128 / 256 columns inside its row view
+    const int lt = is_b ? tid - 256 : (tid & 127);
+    const int ppr = is_b ? 32 : 16;                       // 16-byte pieces per operand row this role covers
+    const int row0 = lt / ppr, piece = lt % ppr;
+    const int col0 = org + 8 * piece;                     // first column inside the row view
+    unsigned short* const img0 = (is_b ? b_s[0] : a_s[0]);
+    const int img_off = row0 * RS + (is_b ? 0 : 256 * (role == 1)) + 16 * piece;   // byte offset of this lane's first piece inside a stage (view a1: columns 128..)
+    constexpr unsigned OOB = 0x80000000u;
+    const unsigned q_wg = (unsigned)((unsigned long long)m_begin / (unsigned)g.rows_per_batch), rem_wg = (unsigned)m_begin - q_wg * (unsigned)g.rows_per_batch;
+    const long long e_wg = (long long)q_wg * map.batch_stride + (map.t0 + (long long)rem_wg) * map.row_stride;
+    const __amdgpu_buffer_rsrc_t rs = wn_rsrc(reinterpret_cast<const unsigned short*>(map.base) + e_wg);
+    float4 v[12];   // three sets of four pieces
+    auto fetch = [&](long long mc, int vo) {
+        const long long m = mc + row0;
+        unsigned q = (unsigned)m / (unsigned)g.rows_per_batch, rem = (unsigned)m - q * (unsigned)g.rows_per_batch;
+        unsigned off = (unsigned)(((long long)q * map.batch_stride + (map.t0 + (long long)rem) * map.row_stride - e_wg + col0) * 2);
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {
+            const bool ok = m + 8 * qq < m_end && (int)rem >= win_lo;
+            const wn_v4i got = __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? off : OOB, 0, 0);   // 8 bf16, moved as bits; outside the operand: zeros
+            v[vo + qq] = make_float4(__int_as_float(got.x), __int_as_float(got.y), __int_as_float(got.z), __int_as_float(got.w));
+            rem += 8;
+            if (rem >= (unsigned)g.rows_per_batch) {   // the row 8 further down is in a later batch entry
+                do { rem -= (unsigned)g.rows_per_batch; ++q; } while (rem >= (unsigned)g.rows_per_batch);
+                off = (unsigned)(((long long)q * map.batch_stride + (map.t0 + (long long)rem) * map.row_stride - e_wg + col0) * 2);
+            } else {
+                off += (unsigned)(8 * map.row_stride * 2);
+            }
+        }
+    };
+    auto stash = [&](int buf, int vo) {
+        char* img = reinterpret_cast<char*>(img0 + buf * BUF) + img_off;
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) *reinterpret_cast<float4*>(img + 8 * qq * RS) = v[vo + qq];
+    };
+    // ---- products of the chunk in stage `buf`
+    typedef __attribute__((address_space(3))) wn_s4 lds_s4;
+    const int tp = lane & 15, tg = (lane >> 4) & 1, th = lane >> 5;
+    const int tra_off = (8 * th + (tp >> 2)) * RS + (32 * wr + 16 * tg + 4 * (tp & 3)) * 2;
+    const int trb_off = (8 * th + (tp >> 2)) * RS + (128 * wc + 16 * tg + 4 * (tp & 3)) * 2;
+    auto products = [&](int buf) {
+        const char* at_img = reinterpret_cast<const char*>(a_s[buf]) + tra_off;
+        const char* bt_img = reinterpret_cast<const char*>(b_s[buf]) + trb_off;
+#pragma unroll
+        for (int ks = 0; ks < KC / 16; ++ks) {
+            wn_bf16x8 a[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const char* at = at_img + ks * 16 * RS + h * 256;   // tap view h: columns 128 h ..
+                const wn_s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(at));
+                const wn_s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(at + 4 * RS));
+                a[h] = __builtin_bit_cast(wn_bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const char* bt = bt_img + ks * 16 * RS + j * 64;
+                const wn_s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(bt));
+                const wn_s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(bt + 4 * RS));
+                const wn_bf16x8 b = __builtin_bit_cast(wn_bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b, acc[0][j], 0, 0, 0);
+                acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b, acc[1][j], 0, 0, 0);
+            }
+        }
+    };
+    // ---- three chunks in flight.  Loads past the split's last row are zeros (never out of the descriptor's window), so every path issues the same
+    // sequence of memory operations and the compiler's wait counts are exact: chunk k + 1 is waited for with the loads of k + 2 and k + 3 outstanding.
+    fetch(m_begin, 0);
+    fetch(m_begin + KC, 4);
+    fetch(m_begin + 2 * KC, 8);
+    stash(0, 0);
+    wn_lds_barrier();
+    int buf = 0;
+    for (long long mc = m_begin;;) {
+        fetch(mc + 3 * KC, 0);
+        products(buf);
+        stash(buf ^ 1, 4);
+        wn_lds_barrier();
+        buf ^= 1; mc += KC;
+        if (mc >= m_end) break;
+        fetch(mc + 3 * KC, 4);
+        products(buf);
+        stash(buf ^ 1, 8);
+        wn_lds_barrier();
+        buf ^= 1; mc += KC;
+        if (mc >= m_end) break;
+        fetch(mc + 3 * KC, 8);
+        products(buf);
+        stash(buf ^ 1, 0);
+        wn_lds_barrier();
+        buf ^= 1; mc += KC;
+        if (mc >= m_end) break;
+    }
+    // ---- the partial tile: fp32 atomics into the gradient, or (deterministic mode) this split's tile into the workspace
+    const int col = lane & 31;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int ka = ka0 + 128 * h + 32 * wr + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int nb = nb0 + 128 * wc + 32 * j + col;
+                if (g.part) g.part[((size_t)split * g.Ka + ka) * g.Nb + nb] = acc[h][j][i];
+                else unsafeAtomicAdd(g.c + (g.c_trans ? (size_t)nb * g.ldc + ka : (size_t)ka * g.ldc + nb), acc[h][j][i]);
+            }
+        }
+}
+
 // dF = dz * G * (1 - T^2), dG = dz * T * G * (1 - G), written in the packed [F(32) | G(32)] column order of Wfg^T.
 // dzg != NULL: the skip path's share of dz -- column block of the per-block product dskip . Wskip^T, [N*out_len][ldg] -- is
 // added on the last out_len rows of every batch entry (the rows the skip conv saw).

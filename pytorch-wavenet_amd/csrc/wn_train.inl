@@ -238,6 +238,31 @@ static void wn_launch_tn(hipStream_t st, WnGemmTnArgs a, bool bf16 = false) {
     // bf16 products with Nb % 256 == 0 take the 128 x 256 tile (A streamed once per 256 columns of B); rows split by wn_tn_grid (wn_plan.h)
     const bool wide16 = bf16 && !a.a_idx && a.a_bf16 && a.b_bf16 && a.Nb % 256 == 0;   // (both operands stored as bf16: the filter/gate weight gradient on the shadow of x -- two tap views, ka_split > 0 --, the skip weight gradient on the shadow of dskip)
     const bool wide = wide16 || (bf16 && !a.a_idx && !a.a_bf16 && a.Nb % 256 == 0);
+    // both operands stored as bf16 and 256-column multiples on both sides: 256 x 256 tiles, one workgroup per CU, three chunks in flight (wn_bwd_wfg_bf16,
+    // round 6) -- the filter/gate weight gradient of a 128 / 128 layer on the shadow of x (one tile: both tap views) and the grouped skip weight gradient
+    // on the shadow of dskip.  WN_NO_TALL_WFG=1 with WN_TESTING=1: the 128 x 256 tiles of rounds 3-5.
+    // (Measured, one stream, stand-alone: the filter/gate gradient 145 -> 134 us per layer; the grouped skip gradient 855 -> 892 us in ten 256 x 256 tiles per
+    //  row split -- it stays on the 128 x 256 tiles unless WN_TALL_SKIP=1 asks for it.  Step: 54.6 -> 54.2 ms.  profiles/r06_tn_loads.txt.)
+    const char* tall_skip = wn_dev_env("WN_TALL_SKIP");
+    if (wide16 && !a.relu_a && a.Nb % 256 == 0 && ((a.ka_split == 128 && a.Ka == 256) || (a.ka_split == 0 && a.Ka % 256 == 0 && tall_skip && tall_skip[0] == '1'))) {
+        const char* off = wn_dev_env("WN_NO_TALL_WFG");
+        if (!(off && off[0] == '1')) {
+            const int tiles = (a.Ka / 256) * (a.Nb / 256);
+            int want_t = 256;   // workgroups in flight: one per CU
+            { const char* wv = wn_dev_env("WN_TALL_WANT"); if (wv && atoi(wv) > 0) want_t = atoi(wv); }
+            long long splits = want_t / tiles > 1 ? want_t / tiles : 1;
+            if (splits >= 8) splits -= splits % 8;
+            long long rps = (a.M + splits - 1) / splits;
+            rps = (rps + 31) / 32 * 32;
+            splits = (a.M + rps - 1) / rps;
+            a.rows_per_split = rps; a.tiles_ka = a.Ka / 256; a.n_splits = (int)splits;
+            a.part = wn_det_part(st, (size_t)splits * a.Ka * a.Nb);
+            hipLaunchKernelGGL(wn_bwd_wfg_bf16, dim3(8u * (unsigned)tiles * (unsigned)((splits + 7) / 8)), dim3(512), 0, st, a);
+            if (a.part)
+                hipLaunchKernelGGL(wn_tn_reduce, dim3((unsigned)(((long long)a.Ka * a.Nb / 4 + 255) / 256)), dim3(256), 0, st, a.part, (int)splits, a.Ka, a.Nb, a.c, a.ldc, a.c_trans);
+            return;
+        }
+    }
     // How many workgroups share the rows (each adds its 128 x 128 / 128 x 256 partial tile with fp32 atomics).  The bf16 forms: 512 -- one full round of
     // the resident slots (two 512-thread or three 256-thread workgroups per CU), half the atomic traffic of round 4's 1024 for the 128-column form:
     // 57.6 -> 55.5 ms per config-5 step (384-640: level; 256: 55.6; the 256-column form at 256 / 384 / 768 / 1024: 60.5 / 55.1 / 56.6 / 60.0 against
