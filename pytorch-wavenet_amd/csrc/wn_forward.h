@@ -408,9 +408,11 @@ __global__ __launch_bounds__(256, WN_GEMM_MINB) void wn_fwd_gemm(WnGemmArgs g) {
 #pragma unroll
         for (int q = 0; q < NQ; ++q) va[q] = ok ? *reinterpret_cast<const float4*>(src + ahalf * (KC / 2) + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
         const float* bsrc = ((first || !g.bt1) ? g.bt + (size_t)(k0 + brow) * g.N : g.bt1 + (size_t)(k0 - g.k_split + brow) * g.N) + n0 + bcol;
+        // (ONE predicate for the thread's NQ loads -- N % 32 == 0 and bcol is a multiple of KC / 2 = 4 NQ floats, so they are in range together: with a
+        //  predicate per load each one sat in a block of its own with a full wait behind it.  Round 6, profiles/r06_tn_loads.txt.)
+        const bool okb = n0 + bcol < g.N;
 #pragma unroll
-        for (int q = 0; q < NQ; ++q)
-            vb[q] = (n0 + bcol + q * 4 < g.N) ? *reinterpret_cast<const float4*>(bsrc + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int q = 0; q < NQ; ++q) vb[q] = okb ? *reinterpret_cast<const float4*>(bsrc + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
     };
     auto stash = [&](int buf) {  // registers -> LDS (A transposed to [k][row])
         float* at = a_t[buf];
@@ -988,9 +990,15 @@ __global__ __launch_bounds__(256, WN_GEMM_MINB) void wn_bwd_gemm_tn(WnGemmTnArgs
     const WnRowMap& amap = second ? g.a1 : g.a;
     const int kap0 = second ? ka0 - g.ka_split : ka0;          // first column of this tile inside its view
     float4 va[NQ], vb[NQ];
+    constexpr unsigned WN_OOB = 0x80000000u;   // beyond the 2 GB window of wn_rsrc: the load returns zeros
+    auto row_elem = [&](const WnRowMap& map, unsigned q, unsigned rem) -> long long { return (long long)q * map.batch_stride + (map.t0 + (long long)rem) * map.row_stride; };
+    const unsigned q_wg = (unsigned)((unsigned long long)m_begin / (unsigned)g.rows_per_batch), rem_wg = (unsigned)m_begin - q_wg * (unsigned)g.rows_per_batch;
+    const long long ea_wg = g.a_idx ? 0 : row_elem(amap, q_wg, rem_wg), eb_wg = row_elem(g.b, q_wg, rem_wg);   // descriptors start at the row split's first row
+    const __amdgpu_buffer_rsrc_t rs_a = wn_rsrc(g.a_idx ? g.b.base : amap.base + ea_wg), rs_b = wn_rsrc(g.b.base + eb_wg);
     auto fetch = [&](long long mc) {
         const long long m = mc + lrow;
         const bool ok = m < m_end;
+        const unsigned q_m = (unsigned)m / (unsigned)g.rows_per_batch, rem_m = (unsigned)m - q_m * (unsigned)g.rows_per_batch;
         if (g.a_idx) {
             int cls = -1;
             if (ok) {  // the row map of `a` addresses the index array: base holds no data, strides are in elements
@@ -1003,15 +1011,23 @@ __global__ __launch_bounds__(256, WN_GEMM_MINB) void wn_bwd_gemm_tn(WnGemmTnArgs
                 va[q] = make_float4(cls == k ? 1.f : 0.f, cls == k + 1 ? 1.f : 0.f, cls == k + 2 ? 1.f : 0.f, cls == k + 3 ? 1.f : 0.f);
             }
         } else {
-            bool oka = ok;
-            if (ok && !second && g.a_skip_lo > 0) oka = (int)((unsigned)m % (unsigned)g.rows_per_batch) >= g.a_skip_lo;
-            const float* ap = oka ? wn_row(amap, m, g.rows_per_batch) + kap0 + lcol : nullptr;
+            // (unconditional, range-checked buffer loads -- an offset beyond the descriptor's window reads as zero -- instead of `ok ? *ptr : zero`: every
+            //  predicated load sat in a block of its own with a full wait behind it, four round trips per 16-row chunk and thread.  Round 6, as in
+            //  wn_bwd_gemm_tn_bf16: profiles/r06_tn_loads.txt.)
+            const bool oka = ok && (second || (int)rem_m >= g.a_skip_lo);
+            const unsigned offa = (unsigned)((row_elem(amap, q_m, rem_m) - ea_wg + kap0 + lcol) * 4);
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) va[q] = (oka && ka0 + lcol + q * 4 < g.Ka) ? *reinterpret_cast<const float4*>(ap + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int q = 0; q < NQ; ++q) {
+                const wn_v4i got = __builtin_amdgcn_raw_buffer_load_b128(rs_a, (oka && ka0 + lcol + q * 4 < g.Ka) ? offa + 16u * q : WN_OOB, 0, 0);
+                va[q] = make_float4(__int_as_float(got.x), __int_as_float(got.y), __int_as_float(got.z), __int_as_float(got.w));
+            }
         }
-        const float* bp = ok ? wn_row(g.b, m, g.rows_per_batch) + nb0 + lcol : nullptr;
+        const unsigned offb = (unsigned)((row_elem(g.b, q_m, rem_m) - eb_wg + nb0 + lcol) * 4);
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) vb[q] = (ok && nb0 + lcol + q * 4 < g.Nb) ? *reinterpret_cast<const float4*>(bp + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int q = 0; q < NQ; ++q) {
+            const wn_v4i got = __builtin_amdgcn_raw_buffer_load_b128(rs_b, (ok && nb0 + lcol + q * 4 < g.Nb) ? offb + 16u * q : WN_OOB, 0, 0);
+            vb[q] = make_float4(__int_as_float(got.x), __int_as_float(got.y), __int_as_float(got.z), __int_as_float(got.w));
+        }
     };
     auto stash = [&](int buf) {
         float* ad = a_s[buf] + lrow * T + lcol;
