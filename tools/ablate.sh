@@ -4,7 +4,7 @@
 cfg=${1:-cfg3}; streams=${2:-"64"}; list=${3:-"1 2 3"}
 mkdir -p tools/variants
 for n in $list; do
-  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DWN_EXPERIMENT -DWN_V3_ABL=$n -o tools/variants/libwn_abl$n.so pytorch-wavenet_amd/csrc/wn_runtime.hip 2>/dev/null || exit 1
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DWN_EXPERIMENT -DWN_V3_ABL=$n -o tools/variants/libwn_abl$n.so pytorch-wavenet_amd/csrc/wn_runtime.hip pytorch-wavenet_amd/csrc/wn_stacked.hip 2>/dev/null || exit 1
   echo "=== WN_V3_ABL=$n"
   for s in $streams; do WN_DEV_LIB=tools/variants/libwn_abl$n.so python tools/rate.py $cfg $s 3000 2 2>&1 | grep "samples/s"; done
 done
