@@ -20,7 +20,10 @@ from . import _abi
 class StackRunner:
     """Owns one engine handle (for the plan / layout / workspace) and runs the packed forward / backward."""
 
-    def __init__(self, engine):
+    def __init__(self, engine, model_shape=None):
+        """model_shape: (R, D, S, E) of the MODEL when the engine was created for a zero-padded channel shape (wavenet_model.py:
+        _native_train_forward pads channel counts that are not multiples of 32 up to multiples of 64): the parameters then travel through
+        zero-filled tensors of the engine's shape (pad_tensors) and only their own block of the gradients comes back (crop_grads)."""
         self.eng = engine
         lay = _abi.wn_train_layout()
         engine.lib.check(engine.lib.dll.wn_train_get_layout(engine._h, ctypes.byref(lay)))
@@ -37,6 +40,41 @@ class StackRunner:
         self._gflat = None       # the flat gradient wn_train_backward writes
         self._ptr_key = None     # the parameter tensors the cached pointer tables below were built for
         self._ptr_tabs = None
+        self.padded = model_shape is not None and tuple(model_shape) != (self.R, self.D, self.S, self.E)
+        self._pad_bufs = {}      # (key, index) -> the zero-filled tensor of the engine's shape a parameter is copied into every step
+
+    # ---- zero padding of the channel shape (training on channel counts that are not multiples of 32) -----------------------------
+    # Padded channels carry zeros through the whole step: zero start_conv rows and zero residual rows keep the extra residual channels at 0,
+    # zero filter / gate rows give tanh(0) * sigmoid(0) = 0, extra skip / end channels are relu(0) = 0 against zero weights -- and no gradient
+    # reaches a real weight through them, nor a padded weight at all (its activation or its incoming gradient is zero).  The logits and the real
+    # parameters' gradients are those of the model's own shape; the tests compare them with torch autograd.
+    def padded_shape(self, key):
+        R, D, S, E, C = self.R, self.D, self.S, self.E, self.C
+        return {"start_w": (R, C, 1), "start_b": (R,), "filter_w": (D, R, 2), "gate_w": (D, R, 2), "filter_b": (D,), "gate_b": (D,),
+                "res_w": (R, D, 1), "res_b": (R,), "skip_w": (S, D, 1), "skip_b": (S,), "end1_w": (E, S, 1), "end1_b": (E,),
+                "end2_w": (C, E, 1), "end2_b": (C,)}[key]
+
+    def pad_tensors(self, by_key):
+        """{key: [parameter tensors]} -> the same parameters inside zero-filled tensors of the engine's channel shape (kept from step to step:
+        only a parameter's own block is ever written)."""
+        out = {}
+        for key, ts in by_key.items():
+            shape = self.padded_shape(key)
+            row = []
+            for i, t in enumerate(ts):
+                buf = self._pad_bufs.get((key, i))
+                if buf is None or buf.device != t.device:
+                    buf = torch.zeros(shape, dtype=torch.float32, device=t.device)
+                    self._pad_bufs[(key, i)] = buf
+                buf[tuple(slice(0, n) for n in t.shape)].copy_(t)
+                row.append(buf)
+            out[key] = row
+        return out
+
+    @staticmethod
+    def crop_grads(grads, real):
+        """Gradients of the padded tensors -> the parameters' own blocks (contiguous copies; None stays None)."""
+        return {key: [None if g is None else g[tuple(slice(0, n) for n in t.shape)].contiguous() for g, t in zip(gs, real[key])] for key, gs in grads.items()}
 
     # ---- layout conversion (reference Conv1d layouts <-> wn_train_layout) ------------------------------------------
     def sizes(self):
@@ -202,10 +240,13 @@ class StackFunction(torch.autograd.Function):
         for key, count in names:
             by_key[key] = list(tensors[pos:pos + count])
             pos += count
-        flat = runner.pack_native({k: [x.detach() for x in v] for k, v in by_key.items()})
+        real = {k: [x.detach() for x in v] for k, v in by_key.items()}
+        packed = runner.pad_tensors(real) if runner.padded else real   # (a zero-padded channel shape: see StackRunner.pad_tensors)
+        flat = runner.pack_native(packed)
         logits = runner.forward(flat, idx, output_length)
         ctx.runner, ctx.flat, ctx.names, ctx.ticket = runner, flat, names, runner.ticket
-        ctx.shapes = {k: [x.detach() for x in v] for k, v in by_key.items()}   # (shapes only: detached aliases, no copies)
+        ctx.shapes = packed                                  # (shapes only: detached aliases / the runner's own padded tensors, no copies)
+        ctx.real = real if runner.padded else None
         return logits
 
     @staticmethod
@@ -215,6 +256,8 @@ class StackFunction(torch.autograd.Function):
             raise RuntimeError("native WaveNet backward: another forward ran on this model since the one being differentiated "
                                "(the saved activations live in one workspace per model)")
         g = r.unpack_native(r.backward(ctx.flat, dlogits), ctx.shapes)
+        if ctx.real is not None:
+            g = r.crop_grads(g, ctx.real)
         out = []
         for key, count in ctx.names:
             out.extend(g[key])

@@ -17,8 +17,8 @@ What is different underneath:
     behind a torch.autograd.Function when gradients are wanted) -- including clips shorter than receptive_field +
     output_length - 1, where the reference left-pads the layers' activations with zeros (wavenet_modules.py:24-27: per-layer row
     windows in the kernels).  The reference's algorithm with torch ops remains for: CPU tensors, inputs that are not one-hot,
-    gradients w.r.t. the input, autograd on channel counts that are not multiples of 32 (without autograd those run natively,
-    zero-padded), and the input lengths for which the reference itself has no defined result (its error, or its shapes, are reproduced).
+    gradients w.r.t. the input, kernel_size != 2, a class count that is not a multiple of 32 under autograd (channel counts that are not
+    multiples of 32 run natively, zero-padded: with and, since round 6, under autograd), and the input lengths for which the reference itself has no defined result (its error, or its shapes, are reproduced).
 """
 import os
 import os.path
@@ -141,6 +141,22 @@ class WaveNetModel(nn.Module):
         return self.kernel_size == 2 and not any(c % 32 for c in (self.residual_channels, self.dilation_channels, self.skip_channels,
                                                                   self.end_channels, self.classes))
 
+    def _native_trainable(self):
+        """Shapes the native training step covers: kernel_size 2 and a class count that is a multiple of 32 -- channel counts that are not multiples
+        of 32 are zero-padded up to multiples of 64 for it (round 6: mi355_wavenet/training.py StackRunner.pad_tensors; same logits, same gradients)."""
+        return self.kernel_size == 2 and self.classes % 32 == 0
+
+    def _padded_train_config(self):
+        """(config, model shape) of the training engine: the model's own when its channel counts are multiples of 32, else padded to multiples of 64
+        (so that the bf16 step's kernels apply as well)."""
+        cfg = self._config()
+        if self._native_supported():
+            return cfg, None
+        shape = (self.residual_channels, self.dilation_channels, self.skip_channels, self.end_channels)
+        up = lambda c: (c + 63) // 64 * 64  # noqa: E731
+        cfg.update(residual_channels=up(shape[0]), dilation_channels=up(shape[1]), skip_channels=up(shape[2]), end_channels=up(shape[3]))
+        return cfg, shape
+
     def _fallback(self, reason, warn=True):
         """forward() on a CUDA tensor is about to run the reference's algorithm in torch ops (MIOpen conv1d + autograd) instead of the
         native kernels: counted per reason (wn_stats()) and said out loud ONCE per reason -- the dual path is never silent."""
@@ -177,8 +193,10 @@ class WaveNetModel(nn.Module):
         # Without autograd the engine decides: a channel shape that is not a multiple of 32 may still run natively, zero-padded into a
         # compiled shape (include/wn_abi.h: wn_create); with autograd the handle keeps the model's own shape and needs the multiples.
         no_native = getattr(self, "_wn_forward_unsupported", None) == self._forward_shape_key(input.device)
-        if (want_grad or no_native) and not self._native_supported():
-            return self._fallback("channel counts that are not multiples of 32 %s" % ("under autograd" if want_grad else "and fit no compiled shape"))
+        if want_grad and not self._native_trainable():
+            return self._fallback("a class count that is not a multiple of 32 under autograd")
+        if not want_grad and no_native and not self._native_supported():
+            return self._fallback("channel counts that are not multiples of 32 and fit no compiled shape")
         if torch.is_grad_enabled() and input.requires_grad:
             return self._fallback("a gradient with respect to the one-hot input is wanted")
         if want_grad and input.dtype != torch.float32:
@@ -226,7 +244,8 @@ class WaveNetModel(nn.Module):
 
     def _apply_precision(self, eng):
         want = getattr(self, "matrix_precision", "fp32") == "bf16"
-        if want and any(c % 64 for c in (self.residual_channels, self.dilation_channels, self.skip_channels, self.end_channels)):
+        c = eng.cfg   # (the ENGINE's channel shape: the training engine of a model with odd channel counts is zero-padded to multiples of 64)
+        if want and any(c[k] % 64 for k in ("residual_channels", "dilation_channels", "skip_channels", "end_channels")):
             want = False
         eng.set_forward_precision(want)
 
@@ -236,8 +255,24 @@ class WaveNetModel(nn.Module):
         runner = getattr(self, "_wn_train_runner", None)
         dev = next(self.parameters()).device
         if runner is None or runner.device != dev:
-            eng = engine.Engine(self._config(), dict(self.state_dict()), n_streams=1, device_index=dev.index or 0, pad_channels=False)
-            runner = training.StackRunner(eng)  # the handle only provides plan, layout and workspace: parameters are passed per call
+            cfg, shape = self._padded_train_config()
+            weights = dict(self.state_dict())
+            if shape is not None:   # (the handle is created on zero-padded weights of ITS shape; the step's parameters are passed per call)
+                probe = training.StackRunner.__new__(training.StackRunner)
+                probe.R, probe.D, probe.S, probe.E, probe.C = (cfg["residual_channels"], cfg["dilation_channels"], cfg["skip_channels"],
+                                                               cfg["end_channels"], cfg["classes"])
+                kinds = {"start_conv": "start", "end_conv_1": "end1", "end_conv_2": "end2", "filter_convs": "filter", "gate_convs": "gate",
+                         "residual_convs": "res", "skip_convs": "skip"}
+                padded = {}
+                for name, t in weights.items():
+                    parts = name.split(".")
+                    key = kinds[parts[0]] + ("_w" if parts[-1] == "weight" else "_b")
+                    buf = torch.zeros(probe.padded_shape(key), dtype=t.dtype, device=t.device)
+                    buf[tuple(slice(0, n) for n in t.shape)].copy_(t)
+                    padded[name] = buf
+                weights = padded
+            eng = engine.Engine(cfg, weights, n_streams=1, device_index=dev.index or 0, pad_channels=False)
+            runner = training.StackRunner(eng, model_shape=shape)  # the handle only provides plan, layout and workspace: parameters are passed per call
             self._wn_train_runner = runner
         names, tensors = [], []
 
@@ -265,11 +300,13 @@ class WaveNetModel(nn.Module):
             runner.set_deterministic(bool(det))
         return training.StackFunction.apply(runner, idx, self.output_length, tuple(names), *tensors)
 
-    def _checked_indices(self, indices, check):
+    def _checked_indices(self, indices, check, training=False):
         idx = torch.as_tensor(indices)
         if idx.dim() != 2:
             raise ValueError("indices must be (N, L) class indices")
-        if not self._native_supported():
+        if training and self._native_trainable():
+            pass   # (the training engine pads odd channel counts itself)
+        elif not self._native_supported():
             raise ValueError("the index-based forward needs kernel_size 2 and channel counts that are multiples of 32 "
                              "(residual %d, dilation %d, skip %d, end %d, classes %d)" % (
                                  self.residual_channels, self.dilation_channels, self.skip_channels, self.end_channels, self.classes))
@@ -305,7 +342,7 @@ class WaveNetModel(nn.Module):
     def train_forward_indices(self, indices, check=True):
         """Extension: the differentiable forward() on class indices (N, L) -- the training-time sibling of forward_indices:
         logits (N*output_length, classes) whose backward runs natively (see _native_train_forward).  MI355X only."""
-        idx = self._checked_indices(indices, check)
+        idx = self._checked_indices(indices, check, training=True)
         return self._index_call(lambda: self._native_train_forward(idx))
 
     def forward(self, input):
