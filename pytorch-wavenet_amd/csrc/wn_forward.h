@@ -530,7 +530,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? (A16 ? WN_GEMM_BF16_MINB :
     const unsigned short* bp1 = ga.bn1 ? ga.bn1 + (size_t)(n0 + bcol) * ldb + bhalf * HB : bp0 + g.k_split;
 
     // Staging registers of the chunk in flight.  (Two A chunks in flight per workgroup -- a second register set, chunk kc + 2 fetched
-    // while kc + 1 waits to be staged -- measured level in both forms: profiles/r03_train_step_experiments.txt.)
+    // while kc + 1 waits to be staged -- measured level in both forms: profiles/archive/r03_train_step_experiments.txt.)
     float4 va0[HK / 4];   // A16: only the first HK / 8 hold data (HK bf16)
     uint4 vb[HB / 8];
     auto fetch_a = [&](int kc, float4 (&va)[HK / 4]) {

@@ -2,7 +2,7 @@
 //
 // The chain, its hand-off granules, the HBM buffers and the per-lane weight images are those of DESIGN.md sections 2 and 7 (shapes and
 // images: wn_chain_regs.h, WnV2Shape); this file decides WHO inside a layer workgroup does what.  The form it replaced (rounds 1-2: one
-// 256-thread workgroup per layer slice with a single instruction stream, profiles/HISTORY.md) measured on cfg3 (profiles/r02_sweep_one_chain.txt):
+// 256-thread workgroup per layer slice with a single instruction stream, profiles/HISTORY.md) measured on cfg3 (profiles/archive/r02_sweep_one_chain.txt):
 // a pipeline item keeps such a workgroup busy ~1.15 us, of which only ~0.47 us (stage x, filter/gate, gate, residual,
 // publish x') is on the token's critical path; the other ~0.7 us (skip 1x1 + the running skip lane, queue push, queue tap, the
 // next step's tap-0 half of the dilated conv) is work nobody downstream is waiting for -- but it sits in the same instruction
@@ -87,7 +87,7 @@
 #ifndef WN_V3_PAIR_ROWS
 #define WN_V3_PAIR_ROWS 2  // a critical lane computes the filter AND the gate row of one channel on a half-width slice of x (see wn_v3_layer):
                            // 0 never, 1 always, 2 in the two-streams-per-item form only (64 streams: 961 -> 974 k samples/s, 128: 1.464 -> 1.478 M;
-                           // one stream: 18.87 -> 18.74 k -- the longer lane reduction is on the single token's path; profiles/r02_v3_forms_final.txt)
+                           // one stream: 18.87 -> 18.74 k -- the longer lane reduction is on the single token's path; profiles/archive/r02_v3_forms_final.txt)
 #endif
 #ifndef WN_V3_LAST_SKIP_PRIO
 #define WN_V3_LAST_SKIP_PRIO 3  // wave priority of the LAST layer's skip group in the two-streams-per-item form (64 streams: 998.6 -> 1004.5 k)
@@ -126,13 +126,13 @@
                              // sums enter through one FMA with a per-lane 0 / 1 factor behind the dot instead of two selects in front of it.  0: {filter, gate} pairs
 #endif
 #ifndef WN_V3_PRIO
-#define WN_V3_PRIO 1  // 1: critical waves at a higher static wave priority (the queue and skip waves share their SIMDs: x64 911 -> 919 k, profiles/r02_v3_tap_fifo.txt)
+#define WN_V3_PRIO 1  // 1: critical waves at a higher static wave priority (the queue and skip waves share their SIMDs: x64 911 -> 919 k, profiles/archive/r02_v3_tap_fifo.txt)
 #endif
 
 // ---- 16-byte skip-lane hand-offs.  A lane of the skip group owns rows t and t + 256 of the running skip sum.  Written as two
 // 8-byte granules that is two write-through stores per lane and item -- and the fabric retires write-through stores per LANE, not
 // per byte (MI355X guide: dwordx2 stores cost 2.7x the dwordx4 time per byte): at 64 streams the chain sat on a ceiling of ~130 G
-// lane-stores/s, 1.0-1.06 TB/s of granules whatever the stream count (profiles/r02_v3_lazy_clock.txt).  The two granules of a lane
+// lane-stores/s, 1.0-1.06 TB/s of granules whatever the stream count (profiles/archive/r02_v3_lazy_clock.txt).  The two granules of a lane
 // are therefore adjacent in memory, {value(t), tag, value(t+256), tag}, written by ONE 16-byte store and read by ONE 16-byte
 // load; each 8-byte half still carries its own tag, so nothing depends on the 16 bytes arriving together.
 typedef int wn_v4i __attribute__((ext_vector_type(4)));
@@ -167,7 +167,7 @@ static __device__ __forceinline__ wn_v4i wn_poll_pair(WnCtx& cx, __amdgpu_buffer
 }
 
 // ---- Input polling of the critical group with TWO request sets in flight, hand-scheduled.
-// What the stamps of a 64-stream run show (profiles/r02_v3_first_check.txt, r02_load_flavour_probe.txt): a load takes ~0.1 us
+// What the stamps of a 64-stream run show (profiles/archive/r02_v3_first_check.txt, r02_load_flavour_probe.txt): a load takes ~0.1 us
 // on an idle chip and 0.25-0.3 us in the running chain, a store becomes visible ~0.25 us after its issue idle and ~0.45 us in the
 // running chain.  The request issued at the end of an item therefore comes back STALE in every item, and the token is caught by
 // the next poll a whole round trip later: the stage's cycle is quantised, service + 2 round trips (1.19 us).  With two sets in
@@ -176,7 +176,7 @@ static __device__ __forceinline__ wn_v4i wn_poll_pair(WnCtx& cx, __amdgpu_buffer
 // sees and falls back to waiting for (nearly) everything wherever paths with different sequences meet (loop entry vs back edge,
 // early exits, a store under a lane predicate) -- every variant written in C++ ended up waiting for the YOUNGEST set at every
 // check, and registers of a set that is still in flight when the wave moves on are handed to the next temporary behind a
-// full wait (profiles/r02_v3_request_experiments.txt).  So the sets live in the sixteen HIGHEST registers of the
+// full wait (profiles/archive/r02_v3_request_experiments.txt).  So the sets live in the sixteen HIGHEST registers of the
 // 168 a 768-thread workgroup leaves each lane (A = v[152:159], B = v[160:167]; the compiler's own allocation stays below them --
 // tests/test_abi.py disassembles the library and checks that no instruction outside these blocks touches them; accumulation
 // registers would make the allocator split the register file in halves), and the loop is written out: issue, s_waitcnt vmcnt(4) = "the older set
@@ -408,7 +408,7 @@ static __device__ __forceinline__ int wn_ap_spin1(unsigned off, const wn_u64* p0
 // (rows of large-d layers miss the L2).  Held in a C++ array the FIFO is loop carried, and the compiler's wait in front of the
 // OLDEST entry is a wait for the YOUNGEST one, requested one item ago: layers with d >= 128 ran 0.06-0.12 us per item slower than
 // the others and set the pace of the 64-stream chain (tools/dilation_probe.py: all dilations <= 64: 930 k samples/s, cfg3: 837 k;
-// three entries hand-scheduled: cfg3 881 k, d <= 128 as fast as d = 1; profiles/r02_v3_tap_fifo.txt).  The loads carry sc1 (served by the
+// three entries hand-scheduled: cfg3 881 k, d <= 128 as fast as d = 1; profiles/archive/r02_v3_tap_fifo.txt).  The loads carry sc1 (served by the
 // L2, never by this CU's L1): the row was pushed by ANOTHER wave of the workgroup with a plain store as little as one item (two LDS-only
 // barriers) earlier, and the L2 is where that store is ordered with this load.  The entries live in
 // v152-v157 of the queue waves (the critical waves' request sets are other waves' registers of the same numbers).
@@ -554,7 +554,7 @@ static __device__ void wn_v3_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
     // ---- fetching the layer's input (lanes t < G*R of the critical group): request (set A), first look, spin with two sets in flight, stage.
     // (Round 3 also tried the SKIP group as the fetcher -- request after barrier B, look after its chunk, the critical group pure compute --
     //  and the skip group's chunk deferred into the next item's filter/gate window so that its polling waves are free between B and the
-    //  next A: profiles/r03_skip_group_polls.txt.  Slower wherever tokens queue: the request just misses the token, the next look comes a
+    //  next A: profiles/archive/r03_skip_group_polls.txt.  Slower wherever tokens queue: the request just misses the token, the next look comes a
     //  chunk later; and ANY work next to the critical group's filter/gate window doubles that window -- the LDS pipe is what both wait for.)
     // (Round 6 tried barrier A as an LDS counter only its consumers wait for -- the skip and queue groups free to run their chunk anywhere between
     //  B(i) and B(i + 1): one stream per item 64 streams 0.910 -> 0.904 M, 32 streams 0.657 -> 0.573 M; two streams per item 1.092 -> 0.872 M: the
@@ -581,7 +581,7 @@ static __device__ void wn_v3_layer(const WnPlan& p, const WnRun& r, WnCtx& cx, f
     };
     // (Round 3 tried a pre-poll sleep here -- a polling wave sleeping through a fraction of its predicted wait before it requests again, to
     //  take the chain's own polls off the L2s: 3/8 of the wait changed nothing (64 streams 994 k against 991 k), 4/8 and more collapse --
-    //  a token that waits for a sleeping stage lengthens every later wait, which lengthens the sleep: profiles/r03_presleep.txt.)
+    //  a token that waits for a sleeping stage lengthens every later wait, which lengthens the sleep: profiles/archive/r03_presleep.txt.)
     // spins until every lane of this wave has its input (bounded like wn_poll_fixed), then stages it
     auto finish_input = [&](long long e2, int s2, float* xb2, float sum, int ok, long long item2) {
         const uint32_t tag2 = (uint32_t)(e2 + 1);
@@ -1330,7 +1330,7 @@ static __device__ void wn_v3_head(const WnPlan& p, const WnRun& r, WnCtx& cx, fl
     const __amdgpu_buffer_rsrc_t rs_gs = wn_rsrc(p.gs);
     // The P lanes of the running skip sum (published by the last layer's skip groups; layout: see the skip group) of the NEXT item are
     // requested early (after this item's long dot): with tokens queued in front of it the head's cycle would otherwise be compute PLUS a
-    // request round trip -- the slowest stage of the 64-stream chain, whatever the layer stages did (profiles/r02_v3_head_request.txt).
+    // request round trip -- the slowest stage of the 64-stream chain, whatever the layer stages did (profiles/archive/r02_v3_head_request.txt).
     // Nothing queued (latency-bound runs): the early request comes back stale and the lanes are polled when due.
     constexpr int NPL = QS / 2, ODD = QS % 2, NPR = NPL + ODD;
     constexpr unsigned ODD_BASE = 2048u * (unsigned)(QS - 1);
@@ -1356,7 +1356,7 @@ static __device__ void wn_v3_head(const WnPlan& p, const WnRun& r, WnCtx& cx, fl
             wn_stamp(r, park, item, 0);
             // (this item's stream: requested for it one item ago.)  Stale lanes are re-requested TOGETHER until all carry the tag: polled
             // one by one, every late lane cost a round trip of its own -- with nothing queued in front of the head (latency-bound runs)
-            // that was 4 x ~0.5 us between the last layer's publication and the head's first instruction (profiles/r03_ring_tail.txt)
+            // that was 4 x ~0.5 us between the last layer's publication and the head's first instruction (profiles/archive/r03_ring_tail.txt)
             {
                 unsigned spins = 0;
                 while (!cx.fail) {
@@ -1459,7 +1459,7 @@ static __device__ void wn_v3_head(const WnPlan& p, const WnRun& r, WnCtx& cx, fl
 
 // ---- one-wave sampling: C = 256 classes, lane i holds the four CONSECUTIVE classes 4i .. 4i+3 (wavenet_model.py:280-294).
 // The four-wave sampler (wn_sample_v2: one class per lane) spends 1.65 us per token, most of it in six workgroup barriers and LDS
-// round trips between its waves (profiles/r03_ablations_two_streams_form_and_ring_tail.txt); a first one-wave version that kept its
+// round trips between its waves (profiles/archive/r03_ablations_two_streams_form_and_ring_tail.txt); a first one-wave version that kept its
 // arithmetic register by register (lane i: classes i, i+64, ...) was issue bound -- four of every wave-level reduction and scan in one
 // instruction stream: 2.0 us.  Here a lane reduces its own four classes first, so there is ONE wave-level max, sum and float64 scan
 // (DPP inside the 16-lane rows, row_bcast across them) and no LDS at all.  The probabilities are the same floats up to the order of

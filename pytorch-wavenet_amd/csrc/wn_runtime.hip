@@ -659,7 +659,7 @@ static int wn_create_impl(const wn_config* cfg, wn_handle** out) {
             }
             h->v3_slots = wn_v3_slots_for(pl.n_streams, h->v3_mode, wn_v2_table()[vi3].fn_v3[2] != nullptr, wn_dev_env("WN_V3_SLOTS"), pl.NL);
             h->lds_bytes = wn_v2_table()[vi3].lds_floats_v3(pl.n_streams, h->v3_mode & 1) * 4;
-            if (pl.n_streams <= 4 && !(h->v3_mode & 1)) h->lds_bytes = WN_LDS_MAX_BYTES;  // 1-4 streams (8: measured level, profiles/r03_few_stream_lds_queues.txt): the layers' dilation queues live in LDS where they fit (wn_v3_layer)
+            if (pl.n_streams <= 4 && !(h->v3_mode & 1)) h->lds_bytes = WN_LDS_MAX_BYTES;  // 1-4 streams (8: measured level, profiles/archive/r03_few_stream_lds_queues.txt): the layers' dilation queues live in LDS where they fit (wn_v3_layer)
             pl.lds_floats = h->lds_bytes / 4;
         }
     }

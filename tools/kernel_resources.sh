@@ -1,6 +1,6 @@
 #!/bin/bash
 # Compile-time resource usage of every kernel in libwn_mi355.so (no GPU needed): VGPRs, AGPRs, scratch, occupancy, LDS.
-#   tools/kernel_resources.sh > profiles/r01_kernel_resources.txt
+#   tools/kernel_resources.sh > profiles/archive/r01_kernel_resources.txt
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 echo "# hipcc --offload-arch=gfx950 -O3 -Rpass-analysis=kernel-resource-usage on pytorch-wavenet_amd/csrc/wn_runtime.hip + wn_stacked.hip"
 echo "# name | VGPRs | AGPRs | scratch bytes/lane | occupancy waves/SIMD | static LDS bytes/block (dynamic LDS is set at launch)"
