@@ -494,7 +494,7 @@ def train5_main(a, dist, rank, local, n_gpus, global_batch=32, L=16000):
                          "hbm": {"algorithmic_bytes_per_step": hbm, "achieved_gbs": round(hbm / (ms * 1e-3) / 1e9, 1), "peak_gbs": HBM_PEAK_GBS * n_gpus,
                                  "frac": round(hbm / (ms * 1e-3) / 1e9 / (HBM_PEAK_GBS * n_gpus), 4),
                                  "note": "the step is a stream over saved activations: this is the roofline that binds (formula: bench.py train_algorithmic_bytes)"},
-                         "kernel": "wn_fwd_gemm_bf16 / wn_bwd_gemm_tn_bf16 (bf16 MFMA; the products are HBM streams at K = 128-512: DESIGN.md 2c)" if bf16
+                         "kernel": "wn_fwd_layer_bf16 / wn_bwd_layer_bf16 / wn_bwd_wfg_bf16 / wn_bwd_gemm_tn_bf16 / wn_fwd_gemm_bf16 (bf16 MFMA; the products are HBM streams at K = 128-512: DESIGN.md section 6)" if bf16
                                    else "wn_fwd_gemm / wn_bwd_gemm_tn (fp32 MFMA)", "flop_per_step": int(3 * fwd)}}))
     if dist:
         dist.destroy_process_group()
