@@ -575,6 +575,24 @@ def _pmc_traffic(a, info, per_gpu):
 PMC_LIVE_TIMESTEPS = 2000   # timesteps of the job the live PMC passes count (hand-off traffic is linear in them; the figure is scaled to --samples)
 
 
+def pmc_counter_from_db(db_path, counter):
+    """(kernel name, mean counter value per dispatch in KiB, dispatches) of the ONE generation kernel in a rocprofv3 results database, or None
+    (pure: tests/test_host_logic.py feeds it a hand-made table)."""
+    import sqlite3
+    rows = sqlite3.connect(db_path).execute(
+        "select kernel_name, avg(value), count(*) from counters_collection where counter_name = ? and kernel_name like '%wn_generate_kernel%' group by kernel_name",
+        (counter,)).fetchall()
+    if len(rows) != 1 or not rows[0][1]:
+        return None
+    return rows[0]
+
+
+def pmc_traffic_bytes(fetch_kib, write_kib, samples, counted_timesteps, fetch_correction=2.0):
+    """HBM bytes of a launch of `samples` timesteps from the counters of a launch of `counted_timesteps`: fetch_correction x FETCH_SIZE + WRITE_SIZE (KiB),
+    linear in the timesteps (profiles/r04_pmc_calibration.txt: on the hand-offs' access patterns FETCH_SIZE reports half of the sc1 misses)."""
+    return int((fetch_correction * fetch_kib + write_kib) * 1024 * samples / counted_timesteps)
+
+
 def _pmc_live(a, info, per_gpu, cfgname):
     """HBM bytes per launch MEASURED IN THIS RUN: two rocprofv3 passes -- `--pmc FETCH_SIZE`, then `--pmc WRITE_SIZE`: the counters in their own passes,
     with --kernel-trace only, as MI355X_MICROARCH.md prescribes -- around `tools/rate.py <cfg> <streams> 2000 1` in child processes (rocprofv3 cannot
@@ -583,7 +601,6 @@ def _pmc_live(a, info, per_gpu, cfgname):
     and FETCH_SIZE reports half of the sc1 misses), KiB -> bytes, scaled to this launch's timesteps.  Returns (traffic, source) or (None, reason): the
     caller falls back to the committed passes, labelled as replayed."""
     import shutil
-    import sqlite3
     import subprocess
     import tempfile
     if os.environ.get("WN_BENCH_NO_LIVE_PMC") == "1" or a.scaling != "weak":
@@ -604,16 +621,14 @@ def _pmc_live(a, info, per_gpu, cfgname):
                 dbs = [os.path.join(d, f) for d, _, fs in os.walk(out) for f in fs if f.endswith(".db")]
                 if r.returncode != 0 or not dbs:
                     return None, "rocprofv3 --pmc %s failed (rc %d): %s" % (counter, r.returncode, r.stdout.decode(errors="replace")[-300:])
-                rows = sqlite3.connect(dbs[0]).execute(
-                    "select kernel_name, avg(value), count(*) from counters_collection where counter_name = ? and kernel_name like '%wn_generate_kernel%' group by kernel_name",
-                    (counter,)).fetchall()
-                if len(rows) != 1 or not rows[0][1]:
-                    return None, "rocprofv3 --pmc %s: unexpected rows %r" % (counter, rows)
-                got[counter] = rows[0]
+                row = pmc_counter_from_db(dbs[0], counter)
+                if row is None:
+                    return None, "rocprofv3 --pmc %s: no single generation kernel in the counter table" % counter
+                got[counter] = row
     except Exception as e:   # (a profiler problem must not cost the bench line: the caller replays the committed passes instead)
         return None, "live PMC passes failed: %r" % (e,)
     fetch, write = got["FETCH_SIZE"][1], got["WRITE_SIZE"][1]
-    traffic = int((2.0 * fetch + write) * 1024 * a.samples / PMC_LIVE_TIMESTEPS)
+    traffic = pmc_traffic_bytes(fetch, write, a.samples, PMC_LIVE_TIMESTEPS)
     return traffic, {"kernel": got["FETCH_SIZE"][0], "fetch_kib_per_launch": round(fetch, 1), "write_kib_per_launch": round(write, 1),
                      "dispatches_averaged": [got["FETCH_SIZE"][2], got["WRITE_SIZE"][2]], "timesteps_per_counted_launch": PMC_LIVE_TIMESTEPS,
                      "seconds": round(time.perf_counter() - t0, 1),

@@ -149,3 +149,25 @@ def test_bench_reducer_on_fake_eight_rank_stats():
     assert bench.streams_by_rank("strong", 64, 3) == [171, 171, 170] or sum(bench.streams_by_rank("strong", 64, 3)) == 512
     one = bench.reduce_ranks([{"rank": 0, "kernel_ms": 922.0, "gather_ms": 0.0, "facade_ms": 928.0}], [64], samples, 20, 0.928 * 20, 0.922 * 20)
     assert abs(one["value"] - one["value_per_gpu"]) < 1e-9 and abs(one["value"] - 64 * samples / 0.928) < 1e-3
+
+
+def test_bench_reads_the_pmc_counters_of_the_one_generation_kernel(tmp_path):
+    """bench.py's live roofline.traffic (round 6): the mean counter value of the ONE generation kernel in a rocprofv3 results database, scaled to the
+    launch's timesteps with the calibrated FETCH_SIZE correction -- on a hand-made table; two generation kernels (a rounds job) or none are refused."""
+    import sqlite3
+    import bench
+    db = str(tmp_path / "r.db")
+    con = sqlite3.connect(db)
+    con.execute("create table counters_collection (kernel_name text, counter_name text, value real)")
+    k = "void wn_generate_kernel_v3m<128, 32, 512, 32, 4, 2, 0>(WnPlan, WnRun)"
+    con.executemany("insert into counters_collection values (?, ?, ?)",
+                    [(k, "FETCH_SIZE", 72.0e6), (k, "FETCH_SIZE", 72.4e6), ("__amd_rocclr_fillBufferAligned", "FETCH_SIZE", 11.7), (k, "WRITE_SIZE", 142.5e6)])
+    con.commit()
+    name, fetch, n = bench.pmc_counter_from_db(db, "FETCH_SIZE")
+    assert name == k and n == 2 and abs(fetch - 72.2e6) < 1.0
+    _, write, _ = bench.pmc_counter_from_db(db, "WRITE_SIZE")
+    assert bench.pmc_traffic_bytes(fetch, write, 16000, 2000) == int((2.0 * 72.2e6 + 142.5e6) * 1024 * 8)
+    assert bench.pmc_counter_from_db(db, "TCC_HIT_sum") is None
+    con.execute("insert into counters_collection values (?, ?, ?)", ("void wn_generate_kernel_v4<64, 64, 256, 64, 3>(WnPlan, WnRun)", "WRITE_SIZE", 5.0))
+    con.commit()
+    assert bench.pmc_counter_from_db(db, "WRITE_SIZE") is None
